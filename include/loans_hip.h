@@ -1,0 +1,202 @@
+/*
+ * loans_hip.h -- C ABI of the MI355X (gfx950) kernels behind the LoANs
+ * localizer -> STN crop -> assessor training hot path.
+ *
+ * The reference (Bartzi/loans) has NO FFI of its own: every FLOP of this path
+ * is executed inside Chainer 4.1 / CuPy / cuDNN, reached through Chainer's
+ * Link / Function interface.  Each entry point below therefore replaces the
+ * third-party kernel behind a reference *call site* (cited per function,
+ * paths relative to /root/reference).  The Python host in loans_amd/ binds
+ * this header with ctypes (loans_amd/_lib.py); INTEGRATION.md shows the stub a
+ * maintainer of the reference would add.
+ *
+ * Contract for every function:
+ *   - plain device pointers + explicit sizes; no torch / framework types;
+ *   - returns 0 on success, a negative LOANS_E* code for rejected arguments,
+ *     or a positive hipError_t from the launch;
+ *   - never allocates, frees or synchronises; work is enqueued on `stream`
+ *     (a hipStream_t passed as void*; NULL = the default stream);
+ *   - caller owns every buffer (workspaces included) until the stream passes;
+ *   - device = current HIP device of the calling thread; re-entrant.
+ *
+ * Layouts: activations NHWC float32 with C a multiple of 4 (3-channel images
+ * are carried as 4 channels, the 4th zero); conv weights "OHWI"
+ * [Cout][kh][kw][Cin]; Linear W [out][in].
+ */
+#ifndef LOANS_HIP_H
+#define LOANS_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LOANS_OK 0
+#define LOANS_EINVAL (-1)   /* bad shape / null pointer / misaligned size */
+#define LOANS_ERANGE (-2)   /* size beyond what the kernel's 32-bit indexing supports */
+
+#define LOANS_MAX_TAPS 64
+
+/* epilogue / loader flags of the implicit-GEMM kernels */
+#define LOANS_F_RELU_IN   1   /* gather relu(in) instead of in (pre-activation blocks, common/net.py:22,43,44,64,65) */
+#define LOANS_F_BIAS      2   /* out += bias[n]                         (sheep/resnet.py:43 conv1) */
+#define LOANS_F_STATS     4   /* stats[0][n] += sum_m out, stats[1][n] += sum_m out^2 (double)  */
+#define LOANS_F_MASK      8   /* out = (ref[m][n] > 0) ? out : 0        (ReLU backward folded into dgrad) */
+#define LOANS_F_ADDEND   16   /* out += addend[m][n]                    (residual sums; may alias out) */
+#define LOANS_F_ADDEND_MASK 32 /* with ADDEND: out += (ref[m][n] > 0) ? addend[m][n] : 0  (identity shortcut through a ReLU) */
+
+/*
+ * One implicit-GEMM problem:  out[m][n] = sum_{t<ntaps} sum_{c<Cin} in[pix(m,t)][c] * w[n][t][c]
+ * m enumerates (b, y, x) over B x gridH x gridW;
+ *   output pixel  = (y*osy + oy0, x*osx + ox0)   in an outH x outW x Cout tensor,
+ *   gathered pixel = (y*isy + dy[t], x*isx + dx[t]) in an inH x inW x Cin tensor (zero outside).
+ * fprop:  isy = stride, dy[t] = r - pad, os = 1.          (F.convolution_2d forward)
+ * dgrad:  `in` is the output gradient, one launch per stride-parity class.
+ */
+typedef struct loans_igemm_desc {
+    int32_t B, inH, inW, Cin;
+    int32_t outH, outW, Cout;
+    int32_t gridH, gridW;
+    int32_t osy, osx, oy0, ox0;
+    int32_t isy, isx;
+    int32_t ntaps;
+    int32_t flags;
+    int32_t tile;               /* 0 = auto, else LOANS_TILE_* */
+    int8_t dy[LOANS_MAX_TAPS];
+    int8_t dx[LOANS_MAX_TAPS];
+} loans_igemm_desc;
+
+#define LOANS_TILE_128x128 1
+#define LOANS_TILE_128x64  2
+#define LOANS_TILE_64x64   3
+#define LOANS_TILE_256x64  4
+
+/* ---- convolution (replaces cuDNN ConvolutionForward / BackwardData / BackwardFilter behind
+ *      L.Convolution2D: sheep/resnet.py:43,128-133,151-153 ; common/net.py:15-17,37-39,59-60) ---- */
+
+/* fprop and dgrad. `w` is [Cout][ntaps][Cin] in the launch's tap order. Optional pointers may be NULL
+ * when their flag is clear. */
+int loans_igemm_f32(const float* in, const float* w, float* out,
+                    const float* bias, double* stats, const float* ref, const float* addend,
+                    const loans_igemm_desc* d, void* stream);
+
+/* wgrad: dw[n][t][c] += sum_m gy[opix(m)][n] * x[pix(m,t)][c]   (atomic accumulation into dw).
+ * The descriptor is the FORWARD conv's (Cin = x channels, Cout = gy channels; LOANS_F_RELU_IN gathers
+ * relu(x)). `splits` = number of m-slices (0 = auto). */
+int loans_wgrad_f32(const float* x, const float* gy, float* dw,
+                    const loans_igemm_desc* d, int32_t splits, void* stream);
+
+/* weight repack for dgrad: dst[ci][t][co] = src[co][tapsel[t]][ci]  (src is OHWI with `src_taps` taps) */
+int loans_repack_dgrad_f32(const float* src, float* dst, int32_t Cout, int32_t Cin, int32_t src_taps,
+                           const int32_t* tapsel_host, int32_t ntaps, void* stream);
+
+/* ---- preprocessing (replaces the per-image PIL round trip of resnet.prepare,
+ *      sheep/sheep_localizer.py:45,72-82): NCHW RGB [0,1] -> trunc_u8(x*255) -> BGR - mean -> NHWC4 ---- */
+int loans_prep_images_f32(const float* images_nchw, float* out_nhwc4, int32_t B, int32_t H, int32_t W, void* stream);
+/* NCHW (C=3) -> NHWC4 without arithmetic (the assessor's `real` batch, sheep_updater.py:32-35) */
+int loans_nchw3_to_nhwc4_f32(const float* in, float* out, int32_t B, int32_t H, int32_t W, void* stream);
+
+/* ---- batch normalisation (replaces cuDNN BatchNormalizationForwardTraining/Backward behind
+ *      L.BatchNormalization, sheep/resnet.py:44,129-134,152-154; eps 2e-5, decay 0.9) ---- */
+
+/* stats (double [2][C]: sum, sum of squares over `count` rows) -> mean, rstd, scale=gamma*rstd,
+ * shift=beta-mean*scale; updates running stats in place (unbiased var, + eps if eps_in_running_var). */
+int loans_bn_finalize_f32(const double* stats, int32_t C, int64_t count, float eps, float decay,
+                          const float* gamma, const float* beta, float* running_mean, float* running_var,
+                          int32_t eps_in_running_var,
+                          float* mean, float* rstd, float* scale, float* shift, void* stream);
+/* test-mode coefficients from the running statistics */
+int loans_bn_eval_coeffs_f32(int32_t C, float eps, const float* gamma, const float* beta,
+                             const float* running_mean, const float* running_var,
+                             float* mean, float* rstd, float* scale, float* shift, void* stream);
+
+/* y = act(x*scale+shift [+ r | + x2*scale2+shift2]);  mode 0: no second term, 1: + r, 2: + bn(x2). relu!=0 -> ReLU */
+int loans_bn_apply_f32(const float* x, const float* scale, const float* shift,
+                       const float* x2, const float* scale2, const float* shift2,
+                       float* y, int64_t rows, int32_t C, int32_t mode, int32_t relu, void* stream);
+
+/* stem: y = max_pool_3x3_s2_cover_all(relu(x*scale+shift)); idx = argmax position 0..8 (first maximum)
+ * (sheep/resnet.py:72-73). */
+int loans_bn_relu_maxpool_f32(const float* x, const float* scale, const float* shift, float* y, uint8_t* idx,
+                              int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream);
+/* gx = (sum over windows whose argmax is this pixel of gy) * (x*scale+shift > 0) */
+int loans_maxpool_relu_bwd_f32(const float* gy, const uint8_t* idx, const float* x, const float* scale,
+                               const float* shift, float* gx,
+                               int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream);
+
+/* backward reductions: sums[0][c] += sum g, sums[1][c] += sum g*xhat  with g = gy*(mask>0) (mask may be
+ * NULL), xhat = (x-mean)*rstd. If x2 != NULL also sums[2], sums[3] for (x2, mean2, rstd2). */
+int loans_bn_bwd_reduce_f32(const float* gy, const float* mask, const float* x, const float* mean,
+                            const float* rstd, const float* x2, const float* mean2, const float* rstd2,
+                            double* sums, int64_t rows, int32_t C, void* stream);
+/* from the sums: ggamma += , gbeta += , and the coefficients of gx = k1*g + k2*x + k3 */
+int loans_bn_bwd_coeffs_f32(const double* sums, int32_t C, int64_t count, const float* gamma,
+                            const float* mean, const float* rstd, float* ggamma, float* gbeta,
+                            float* k1, float* k2, float* k3, void* stream);
+/* gx = k1*g + k2*x + k3, g = gy*(mask>0); optional second output for (x2, k1b, k2b, k3b) */
+int loans_bn_bwd_apply_f32(const float* gy, const float* mask, const float* x,
+                           const float* k1, const float* k2, const float* k3, float* gx,
+                           const float* x2, const float* k1b, const float* k2b, const float* k3b, float* gx2,
+                           int64_t rows, int32_t C, void* stream);
+
+/* ---- small dense ops ---- */
+/* out[c] += sum_rows x[row][c]   (conv bias gradient) */
+int loans_colsum_f32(const float* x, float* out, int64_t rows, int32_t C, void* stream);
+/* _global_average_pooling_2d (sheep_localizer.py:58): x [B][HW][C] -> y [B][C] ; backward broadcast */
+int loans_gap_fwd_f32(const float* x, float* y, int32_t B, int32_t HW, int32_t C, void* stream);
+int loans_gap_bwd_f32(const float* gy, float* gx, int32_t B, int32_t HW, int32_t C, void* stream);
+/* L.Linear (sheep_localizer.py:60 ; common/net.py:81,90). act_in: 1 = relu(x) on load; act_out: 1 = sigmoid */
+int loans_linear_fwd_f32(const float* x, const float* W, const float* b, float* y,
+                         int32_t B, int32_t K, int32_t N, int32_t act_in, int32_t act_out, void* stream);
+/* gz = gy (act_out 0) or gy*y*(1-y) (act_out 1). gx[b][k] = sum_n gz W (times x>0 if act_in);
+ * gW[n][k] += sum_b gz relu?(x); gb[n] += sum_b gz. gx / gW / gb may be NULL. */
+int loans_linear_bwd_f32(const float* x, const float* W, const float* y, const float* gy,
+                         float* gx, float* gW, float* gb,
+                         int32_t B, int32_t K, int32_t N, int32_t act_in, int32_t act_out, void* stream);
+/* y = x * mask (elementwise, n floats) -- RotationDropout forward/backward (functions/rotation_droput.py:26-48) */
+int loans_mul_f32(const float* x, const float* mask, float* y, int64_t n, void* stream);
+/* y = a*x + b*y */
+int loans_axpby_f32(float a, const float* x, float b, float* y, int64_t n, void* stream);
+
+/* ---- spatial transformer (replaces cuDNN SpatialTf*; sheep_localizer.py:62-63) ---- */
+/* grid [B][2][th][tw] (channel 0 = x) from theta [B][2][3] */
+int loans_st_grid_fwd_f32(const float* theta, float* grid, int32_t B, int32_t th, int32_t tw, void* stream);
+int loans_st_grid_bwd_f32(const float* ggrid, float* gtheta, int32_t B, int32_t th, int32_t tw, void* stream);
+/* bilinear, align-corners, one-pixel zero border. images NCHW (C=3) ; rois NHWC4 [B][th][tw][4] */
+int loans_st_sampler_fwd_f32(const float* images_nchw, const float* grid, float* rois_nhwc4,
+                             int32_t B, int32_t H, int32_t W, int32_t th, int32_t tw, void* stream);
+/* ggrid [B][2][th][tw] (+= if accumulate) from grois NHWC4 */
+int loans_st_sampler_bwd_grid_f32(const float* images_nchw, const float* grid, const float* grois_nhwc4,
+                                  float* ggrid, int32_t accumulate,
+                                  int32_t B, int32_t H, int32_t W, int32_t th, int32_t tw, void* stream);
+
+/* ---- losses (sheep_updater.py:42-46,60 ; common/utils.py:142-178,301-316) ---- */
+/* loss[0] = mean((y-t)^2); t = target[i] or the constant `tconst` when target == NULL */
+int loans_mse_fwd_f32(const float* y, const float* target, float tconst, float* loss, int32_t n, void* stream);
+/* gy[i] = gloss[0] * 2/n * (y-t) */
+int loans_mse_bwd_f32(const float* y, const float* target, float tconst, const float* gloss, float* gy,
+                      int32_t n, void* stream);
+/* kind 0 = DirectionLoss (needs imgH,imgW), 1 = OutOfImageLoss * oob_scale. grid [B][2][th][tw]. */
+int loans_grid_loss_fwd_f32(const float* grid, float* loss, int32_t kind, float imgH, float imgW, float oob_scale,
+                            int32_t B, int32_t th, int32_t tw, void* stream);
+/* ggrid += gloss[0] * dloss/dgrid (touches only the three corner points) */
+int loans_grid_loss_bwd_f32(const float* grid, const float* gloss, float* ggrid, int32_t kind,
+                            float imgH, float imgW, float oob_scale,
+                            int32_t B, int32_t th, int32_t tw, void* stream);
+
+/* ---- optimiser: chainer.optimizers.Adam(alpha, amsgrad=True) over one flat buffer
+ *      (train_sheep_localizer.py:130-134; sheep_updater.py:52,66). lr_t = alpha*sqrt(1-b2^t)/(1-b1^t)
+ *      is computed by the caller; eps sits outside the bias correction. grad_scale multiplies g first
+ *      (1/world_size after a sum all-reduce). ---- */
+int loans_adam_amsgrad_f32(float* p, const float* g, float* m, float* v, float* vhat, int64_t n,
+                           double lr_t, double beta1, double beta2, double eps, double eta, double weight_decay_rate,
+                           double grad_scale, void* stream);
+
+/* library / build identification */
+const char* loans_hip_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LOANS_HIP_H */

@@ -1,0 +1,94 @@
+"""ctypes binding of ``include/loans_hip.h`` (the C-ABI drop-in boundary).
+
+The shared library is built in-tree by ``__graft_entry__.build()`` /
+``make -C loans_amd/csrc``.  There is NO fallback: if the library is missing
+or a symbol is absent, importing the compute path raises, and every kernel
+wrapper raises ``HipKernelError`` on a non-zero return code.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libloans_hip.so')
+
+MAX_TAPS = 64
+F_RELU_IN, F_BIAS, F_STATS, F_MASK, F_ADDEND, F_ADDEND_MASK = 1, 2, 4, 8, 16, 32
+TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_256x64 = 0, 1, 2, 3, 4
+
+
+class HipKernelError(RuntimeError):
+    pass
+
+
+class IgemmDesc(C.Structure):
+    """Mirror of ``loans_igemm_desc``."""
+    _fields_ = [(n, C.c_int32) for n in (
+        'B', 'inH', 'inW', 'Cin', 'outH', 'outW', 'Cout', 'gridH', 'gridW',
+        'osy', 'osx', 'oy0', 'ox0', 'isy', 'isx', 'ntaps', 'flags', 'tile')] + [
+        ('dy', C.c_int8 * MAX_TAPS), ('dx', C.c_int8 * MAX_TAPS)]
+
+
+_p = C.c_void_p
+_i32, _i64, _f32, _f64 = C.c_int32, C.c_int64, C.c_float, C.c_double
+
+# name -> argtypes, exactly the prototypes of include/loans_hip.h
+SIGNATURES = {
+    'loans_igemm_f32': [_p, _p, _p, _p, _p, _p, _p, C.POINTER(IgemmDesc), _p],
+    'loans_wgrad_f32': [_p, _p, _p, C.POINTER(IgemmDesc), _i32, _p],
+    'loans_repack_dgrad_f32': [_p, _p, _i32, _i32, _i32, C.POINTER(_i32), _i32, _p],
+    'loans_prep_images_f32': [_p, _p, _i32, _i32, _i32, _p],
+    'loans_nchw3_to_nhwc4_f32': [_p, _p, _i32, _i32, _i32, _p],
+    'loans_bn_finalize_f32': [_p, _i32, _i64, _f32, _f32, _p, _p, _p, _p, _i32, _p, _p, _p, _p, _p],
+    'loans_bn_eval_coeffs_f32': [_i32, _f32, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    'loans_bn_apply_f32': [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p],
+    'loans_bn_relu_maxpool_f32': [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p],
+    'loans_maxpool_relu_bwd_f32': [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p],
+    'loans_bn_bwd_reduce_f32': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p],
+    'loans_bn_bwd_coeffs_f32': [_p, _i32, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    'loans_bn_bwd_apply_f32': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p],
+    'loans_colsum_f32': [_p, _p, _i64, _i32, _p],
+    'loans_gap_fwd_f32': [_p, _p, _i32, _i32, _i32, _p],
+    'loans_gap_bwd_f32': [_p, _p, _i32, _i32, _i32, _p],
+    'loans_linear_fwd_f32': [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p],
+    'loans_linear_bwd_f32': [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p],
+    'loans_mul_f32': [_p, _p, _p, _i64, _p],
+    'loans_axpby_f32': [_f32, _p, _f32, _p, _i64, _p],
+    'loans_st_grid_fwd_f32': [_p, _p, _i32, _i32, _i32, _p],
+    'loans_st_grid_bwd_f32': [_p, _p, _i32, _i32, _i32, _p],
+    'loans_st_sampler_fwd_f32': [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p],
+    'loans_st_sampler_bwd_grid_f32': [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p],
+    'loans_mse_fwd_f32': [_p, _p, _f32, _p, _i32, _p],
+    'loans_mse_bwd_f32': [_p, _p, _f32, _p, _p, _i32, _p],
+    'loans_grid_loss_fwd_f32': [_p, _p, _i32, _f32, _f32, _f32, _i32, _i32, _i32, _p],
+    'loans_grid_loss_bwd_f32': [_p, _p, _p, _i32, _f32, _f32, _f32, _i32, _i32, _i32, _p],
+    'loans_adam_amsgrad_f32': [_p, _p, _p, _p, _p, _i64, _f64, _f64, _f64, _f64, _f64, _f64, _f64, _p],
+}
+
+_lib = None
+
+
+def load():
+    """Load (once) and return the ctypes library; raises if it is not built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise HipKernelError(
+            "HIP kernel library not built: %s is missing. Run `python -c 'import __graft_entry__ as g; "
+            "g.build()'` or `make -C loans_amd/csrc`. There is no CPU fallback." % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)          # AttributeError if the symbol is missing
+        fn.argtypes = argtypes
+        fn.restype = C.c_int
+    lib.loans_hip_version.restype = C.c_char_p
+    lib.loans_hip_version.argtypes = []
+    _lib = lib
+    return lib
+
+
+def check(rc, name):
+    if rc != 0:
+        kind = {-1: 'LOANS_EINVAL (rejected arguments)', -2: 'LOANS_ERANGE (size beyond 32-bit indexing)'}.get(
+            rc, 'hipError_t %d' % rc)
+        raise HipKernelError('%s failed: %s' % (name, kind))

@@ -1,0 +1,358 @@
+// Batch-normalisation, ReLU, residual-add and max-pool kernels (NHWC, C % 4 == 0, fp32).
+// All of them are HBM-bound streaming passes: 16-byte accesses, grid-stride over float4
+// elements, per-channel coefficients re-read from L1/L2.  Reductions go per-thread (fp32)
+// -> LDS across the block -> one fp64 atomic per channel per block.
+#include "common.h"
+
+namespace {
+
+__device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ f32x4 relu4(f32x4 v) {
+    v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
+    return v;
+}
+__device__ __forceinline__ f32x4 maskpos4(f32x4 g, f32x4 m) {
+    g.x = m.x > 0.f ? g.x : 0.f; g.y = m.y > 0.f ? g.y : 0.f;
+    g.z = m.z > 0.f ? g.z : 0.f; g.w = m.w > 0.f ? g.w : 0.f;
+    return g;
+}
+
+__global__ void bn_finalize_kernel(const double* stats, int C, double inv_count, double adjust, float eps,
+                                   float decay, const float* gamma, const float* beta, float* rmean, float* rvar,
+                                   int eps_in_rv, float* mean, float* rstd, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double mu = stats[c] * inv_count;
+    double var = stats[C + c] * inv_count - mu * mu;
+    if (var < 0.0) var = 0.0;
+    const double vpe = var + (double)eps;
+    const float rs = (float)(1.0 / sqrt(vpe));
+    const float muf = (float)mu;
+    mean[c] = muf;
+    rstd[c] = rs;
+    const float sc = gamma[c] * rs;
+    scale[c] = sc;
+    shift[c] = beta[c] - muf * sc;
+    rmean[c] = decay * rmean[c] + (1.f - decay) * muf;
+    rvar[c] = decay * rvar[c] + (1.f - decay) * (float)(adjust * (eps_in_rv ? vpe : var));
+}
+
+__global__ void bn_eval_coeffs_kernel(int C, float eps, const float* gamma, const float* beta, const float* rmean,
+                                      const float* rvar, float* mean, float* rstd, float* scale, float* shift) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const float rs = 1.f / sqrtf(rvar[c] + eps);
+    mean[c] = rmean[c];
+    rstd[c] = rs;
+    const float sc = gamma[c] * rs;
+    scale[c] = sc;
+    shift[c] = beta[c] - rmean[c] * sc;
+}
+
+template <int MODE>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const float* x, const float* scale, const float* shift,
+                                                       const float* x2, const float* scale2, const float* shift2,
+                                                       float* y, int64_t n4, int C4, int relu) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        f32x4 v = ld4(x + i * 4);
+        const f32x4 s = ld4(scale + c), t = ld4(shift + c);
+        v = v * s + t;
+        if (MODE == 1) v += ld4(x2 + i * 4);
+        if (MODE == 2) v += ld4(x2 + i * 4) * ld4(scale2 + c) + ld4(shift2 + c);
+        if (relu) v = relu4(v);
+        st4(y + i * 4, v);
+    }
+}
+
+__global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const float* x, const float* scale, const float* shift,
+                                                              float* y, uint8_t* idx, int B, int H, int W, int C4,
+                                                              int OH, int OW) {
+    const int64_t total = (int64_t)B * OH * OW * C4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        int64_t p = i / C4;
+        const int ow = (int)(p % OW); p /= OW;
+        const int oh = (int)(p % OH);
+        const int b = (int)(p / OH);
+        const f32x4 s = ld4(scale + c4 * 4), t = ld4(shift + c4 * 4);
+        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+        int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+#pragma unroll
+        for (int r = 0; r < 3; ++r) {
+            const int ih = oh * 2 + r;
+            if (ih >= H) continue;
+#pragma unroll
+            for (int q = 0; q < 3; ++q) {
+                const int iw = ow * 2 + q;
+                if (iw >= W) continue;
+                f32x4 v = relu4(ld4(x + (((int64_t)b * H + ih) * W + iw) * C4 * 4 + c4 * 4) * s + t);
+                const int k = r * 3 + q;
+                if (v.x > best.x) { best.x = v.x; a0 = k; }
+                if (v.y > best.y) { best.y = v.y; a1 = k; }
+                if (v.z > best.z) { best.z = v.z; a2 = k; }
+                if (v.w > best.w) { best.w = v.w; a3 = k; }
+            }
+        }
+        st4(y + i * 4, best);
+        *reinterpret_cast<uchar4*>(idx + i * 4) = make_uchar4(a0, a1, a2, a3);
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool_relu_bwd_kernel(const float* gy, const uint8_t* idx, const float* x,
+                                                               const float* scale, const float* shift, float* gx,
+                                                               int B, int H, int W, int C4, int OH, int OW) {
+    const int64_t total = (int64_t)B * H * W * C4;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c4 = (int)(i % C4);
+        int64_t p = i / C4;
+        const int iw = (int)(p % W); p /= W;
+        const int ih = (int)(p % H);
+        const int b = (int)(p / H);
+        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+        const int oh_lo = ih >= 2 ? (ih - 1) >> 1 : 0, oh_hi = min(ih >> 1, OH - 1);
+        const int ow_lo = iw >= 2 ? (iw - 1) >> 1 : 0, ow_hi = min(iw >> 1, OW - 1);
+        for (int oh = oh_lo; oh <= oh_hi; ++oh)
+            for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+                const int k = (ih - 2 * oh) * 3 + (iw - 2 * ow);
+                const int64_t o = (((int64_t)b * OH + oh) * OW + ow) * C4 + c4;
+                const uchar4 a = *reinterpret_cast<const uchar4*>(idx + o * 4);
+                const f32x4 gv = ld4(gy + o * 4);
+                if (a.x == k) g.x += gv.x;
+                if (a.y == k) g.y += gv.y;
+                if (a.z == k) g.z += gv.z;
+                if (a.w == k) g.w += gv.w;
+            }
+        const f32x4 pre = ld4(x + i * 4) * ld4(scale + c4 * 4) + ld4(shift + c4 * 4);
+        st4(gx + i * 4, maskpos4(g, pre));
+    }
+}
+
+// Per-channel reductions over rows.  Thread (cg = tid % C4, rl = tid / C4) walks rows rl, rl+RL, ...
+// of the block's slab; NS = number of sums per channel.
+template <bool DUAL, bool MASK>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* gy, const float* mask, const float* x,
+                                                            const float* mean, const float* rstd, const float* x2,
+                                                            const float* mean2, const float* rstd2, double* sums,
+                                                            int64_t rows, int C4, int rows_per_block) {
+    constexpr int NS = DUAL ? 3 : 2;
+    __shared__ f32x4 red[NS][256];
+    const int tid = threadIdx.x;
+    const int cg = tid % C4, rl = tid / C4, RL = 256 / C4;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    const f32x4 mu = ld4(mean + cg * 4), rs = ld4(rstd + cg * 4);
+    f32x4 mu2 = mu, rs2 = rs;
+    if (DUAL) { mu2 = ld4(mean2 + cg * 4); rs2 = ld4(rstd2 + cg * 4); }
+    f32x4 sg = {0.f, 0.f, 0.f, 0.f}, sgx = sg, sgx2 = sg;
+    if (rl < RL) {
+        for (int64_t r = r0 + rl; r < r1; r += RL) {
+            const int64_t o = (r * C4 + cg) * 4;
+            f32x4 g = ld4(gy + o);
+            if (MASK) g = maskpos4(g, ld4(mask + o));
+            sg += g;
+            sgx += g * ((ld4(x + o) - mu) * rs);
+            if (DUAL) sgx2 += g * ((ld4(x2 + o) - mu2) * rs2);
+        }
+    }
+    red[0][tid] = sg;
+    red[1][tid] = sgx;
+    if (DUAL) red[2][tid] = sgx2;
+    __syncthreads();
+    if (tid < C4) {
+        for (int k = 1; k < RL; ++k) {
+            sg += red[0][tid + k * C4];
+            sgx += red[1][tid + k * C4];
+            if (DUAL) sgx2 += red[2][tid + k * C4];
+        }
+        const int C = C4 * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            atomic_add_f64(sums + cg * 4 + e, (double)sg[e]);
+            atomic_add_f64(sums + C + cg * 4 + e, (double)sgx[e]);
+            if (DUAL) {
+                atomic_add_f64(sums + 2 * C + cg * 4 + e, (double)sg[e]);
+                atomic_add_f64(sums + 3 * C + cg * 4 + e, (double)sgx2[e]);
+            }
+        }
+    }
+}
+
+__global__ void bn_bwd_coeffs_kernel(const double* sums, int C, double inv_count, const float* gamma, const float* mean,
+                                     const float* rstd, float* ggamma, float* gbeta, float* k1, float* k2, float* k3) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    const double db = sums[c], dg = sums[C + c];
+    ggamma[c] += (float)dg;
+    gbeta[c] += (float)db;
+    const double a = (double)gamma[c] * (double)rstd[c];
+    k1[c] = (float)a;
+    k2[c] = (float)(-a * (double)rstd[c] * dg * inv_count);
+    k3[c] = (float)(a * ((double)mean[c] * (double)rstd[c] * dg - db) * inv_count);
+}
+
+template <bool DUAL, bool MASK>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* gy, const float* mask, const float* x,
+                                                           const float* k1, const float* k2, const float* k3, float* gx,
+                                                           const float* x2, const float* k1b, const float* k2b,
+                                                           const float* k3b, float* gx2, int64_t n4, int C4) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C4) * 4;
+        f32x4 g = ld4(gy + i * 4);
+        if (MASK) g = maskpos4(g, ld4(mask + i * 4));
+        st4(gx + i * 4, ld4(k1 + c) * g + ld4(k2 + c) * ld4(x + i * 4) + ld4(k3 + c));
+        if (DUAL) st4(gx2 + i * 4, ld4(k1b + c) * g + ld4(k2b + c) * ld4(x2 + i * 4) + ld4(k3b + c));
+    }
+}
+
+__global__ __launch_bounds__(256) void colsum_kernel(const float* x, float* out, int64_t rows, int C4, int rows_per_block) {
+    __shared__ f32x4 red[256];
+    const int tid = threadIdx.x;
+    const int cg = tid % C4, rl = tid / C4, RL = 256 / C4;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    f32x4 s = {0.f, 0.f, 0.f, 0.f};
+    if (rl < RL)
+        for (int64_t r = r0 + rl; r < r1; r += RL) s += ld4(x + (r * C4 + cg) * 4);
+    red[tid] = s;
+    __syncthreads();
+    if (tid < C4) {
+        for (int k = 1; k < RL; ++k) s += red[tid + k * C4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) atomic_add_f32(out + cg * 4 + e, s[e]);
+    }
+}
+
+int reduce_geometry(int64_t rows, int C, int* rows_per_block) {
+    // C4 must divide into a 256-thread block
+    const int C4 = C / 4;
+    const int RL = 256 / C4;
+    int64_t rpb = ((rows + 1023) / 1024 + RL - 1) / RL * RL;   // <= 1024 blocks
+    if (rpb < 8 * RL) rpb = 8 * RL;
+    *rows_per_block = (int)rpb;
+    return (int)((rows + rpb - 1) / rpb);
+}
+
+bool chan_ok(int C) { return C >= 4 && (C & 3) == 0 && C <= 1024 && (256 % (C / 4) == 0 || (C / 4) <= 256); }
+
+}  // namespace
+
+extern "C" int loans_bn_finalize_f32(const double* stats, int32_t C, int64_t count, float eps, float decay,
+                                     const float* gamma, const float* beta, float* running_mean, float* running_var,
+                                     int32_t eps_in_running_var, float* mean, float* rstd, float* scale, float* shift,
+                                     void* stream) {
+    if (!stats || !gamma || !beta || !running_mean || !running_var || !mean || !rstd || !scale || !shift) return LOANS_EINVAL;
+    if (C <= 0 || count <= 0) return LOANS_EINVAL;
+    const double adjust = (double)count / (count > 1 ? (double)(count - 1) : 1.0);
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), stats, C,
+                       1.0 / (double)count, adjust, eps, decay, gamma, beta, running_mean, running_var,
+                       eps_in_running_var, mean, rstd, scale, shift);
+    LOANS_LAUNCH_CHECK();
+    return LOANS_OK;
+}
+
+extern "C" int loans_bn_eval_coeffs_f32(int32_t C, float eps, const float* gamma, const float* beta,
+                                        const float* running_mean, const float* running_var, float* mean, float* rstd,
+                                        float* scale, float* shift, void* stream) {
+    if (!gamma || !beta || !running_mean || !running_var || !mean || !rstd || !scale || !shift || C <= 0) return LOANS_EINVAL;
+    hipLaunchKernelGGL(bn_eval_coeffs_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), C, eps, gamma,
+                       beta, running_mean, running_var, mean, rstd, scale, shift);
+    LOANS_LAUNCH_CHECK();
+    return LOANS_OK;
+}
+
+extern "C" int loans_bn_apply_f32(const float* x, const float* scale, const float* shift, const float* x2,
+                                  const float* scale2, const float* shift2, float* y, int64_t rows, int32_t C,
+                                  int32_t mode, int32_t relu, void* stream) {
+    if (!x || !scale || !shift || !y || rows <= 0 || C <= 0 || (C & 3)) return LOANS_EINVAL;
+    if (mode < 0 || mode > 2 || (mode >= 1 && !x2) || (mode == 2 && (!scale2 || !shift2))) return LOANS_EINVAL;
+    const int64_t n4 = rows * (C / 4);
+    const int grid = grid_for(n4, 256);
+    hipStream_t st = as_stream(stream);
+    if (mode == 0) hipLaunchKernelGGL(bn_apply_kernel<0>, dim3(grid), dim3(256), 0, st, x, scale, shift, x2, scale2, shift2, y, n4, C / 4, relu);
+    if (mode == 1) hipLaunchKernelGGL(bn_apply_kernel<1>, dim3(grid), dim3(256), 0, st, x, scale, shift, x2, scale2, shift2, y, n4, C / 4, relu);
+    if (mode == 2) hipLaunchKernelGGL(bn_apply_kernel<2>, dim3(grid), dim3(256), 0, st, x, scale, shift, x2, scale2, shift2, y, n4, C / 4, relu);
+    LOANS_LAUNCH_CHECK();
+    return LOANS_OK;
+}
+
+extern "C" int loans_bn_relu_maxpool_f32(const float* x, const float* scale, const float* shift, float* y, uint8_t* idx,
+                                         int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream) {
+    if (!x || !scale || !shift || !y || !idx || B <= 0 || H < 3 || W < 3 || C <= 0 || (C & 3)) return LOANS_EINVAL;
+    if (OH != (H - 2) / 2 + 1 || OW != (W - 2) / 2 + 1) return LOANS_EINVAL;   // cover_all out size, k=3 s=2 p=0
+    const int64_t total = (int64_t)B * OH * OW * (C / 4);
+    hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), x, scale,
+                       shift, y, idx, B, H, W, C / 4, OH, OW);
+    LOANS_LAUNCH_CHECK();
+    return LOANS_OK;
+}
+
+extern "C" int loans_maxpool_relu_bwd_f32(const float* gy, const uint8_t* idx, const float* x, const float* scale,
+                                          const float* shift, float* gx, int32_t B, int32_t H, int32_t W, int32_t C,
+                                          int32_t OH, int32_t OW, void* stream) {
+    if (!gy || !idx || !x || !scale || !shift || !gx || B <= 0 || H < 3 || W < 3 || C <= 0 || (C & 3)) return LOANS_EINVAL;
+    if (OH != (H - 2) / 2 + 1 || OW != (W - 2) / 2 + 1) return LOANS_EINVAL;
+    const int64_t total = (int64_t)B * H * W * (C / 4);
+    hipLaunchKernelGGL(maxpool_relu_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), gy, idx, x,
+                       scale, shift, gx, B, H, W, C / 4, OH, OW);
+    LOANS_LAUNCH_CHECK();
+    return LOANS_OK;
+}
+
+extern "C" int loans_bn_bwd_reduce_f32(const float* gy, const float* mask, const float* x, const float* mean,
+                                       const float* rstd, const float* x2, const float* mean2, const float* rstd2,
+                                       double* sums, int64_t rows, int32_t C, void* stream) {
+    if (!gy || !x || !mean || !rstd || !sums || rows <= 0) return LOANS_EINVAL;
+    if (C < 4 || (C & 3) || C > 1024 || 256 % (C / 4)) return LOANS_EINVAL;
+    if (x2 && (!mean2 || !rstd2)) return LOANS_EINVAL;
+    int rpb;
+    const int grid = reduce_geometry(rows, C, &rpb);
+    hipStream_t st = as_stream(stream);
+#define LAUNCH_RED(D, M) \
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<D, M>), dim3(grid), dim3(256), 0, st, gy, mask, x, mean, rstd, x2, mean2, rstd2, sums, rows, C / 4, rpb)
+    if (x2) { if (mask) LAUNCH_RED(true, true); else LAUNCH_RED(true, false); }
+    else { if (mask) LAUNCH_RED(false, true); else LAUNCH_RED(false, false); }
+#undef LAUNCH_RED
+    LOANS_LAUNCH_CHECK();
+    return LOANS_OK;
+}
+
+extern "C" int loans_bn_bwd_coeffs_f32(const double* sums, int32_t C, int64_t count, const float* gamma,
+                                       const float* mean, const float* rstd, float* ggamma, float* gbeta, float* k1,
+                                       float* k2, float* k3, void* stream) {
+    if (!sums || !gamma || !mean || !rstd || !ggamma || !gbeta || !k1 || !k2 || !k3 || C <= 0 || count <= 0) return LOANS_EINVAL;
+    hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), sums, C,
+                       1.0 / (double)count, gamma, mean, rstd, ggamma, gbeta, k1, k2, k3);
+    LOANS_LAUNCH_CHECK();
+    return LOANS_OK;
+}
+
+extern "C" int loans_bn_bwd_apply_f32(const float* gy, const float* mask, const float* x, const float* k1,
+                                      const float* k2, const float* k3, float* gx, const float* x2, const float* k1b,
+                                      const float* k2b, const float* k3b, float* gx2, int64_t rows, int32_t C,
+                                      void* stream) {
+    if (!gy || !x || !k1 || !k2 || !k3 || !gx || rows <= 0 || C <= 0 || (C & 3)) return LOANS_EINVAL;
+    if (x2 && (!k1b || !k2b || !k3b || !gx2)) return LOANS_EINVAL;
+    const int64_t n4 = rows * (C / 4);
+    const int grid = grid_for(n4, 256);
+    hipStream_t st = as_stream(stream);
+#define LAUNCH_APP(D, M) \
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<D, M>), dim3(grid), dim3(256), 0, st, gy, mask, x, k1, k2, k3, gx, x2, k1b, k2b, k3b, gx2, n4, C / 4)
+    if (x2) { if (mask) LAUNCH_APP(true, true); else LAUNCH_APP(true, false); }
+    else { if (mask) LAUNCH_APP(false, true); else LAUNCH_APP(false, false); }
+#undef LAUNCH_APP
+    LOANS_LAUNCH_CHECK();
+    return LOANS_OK;
+}
+
+extern "C" int loans_colsum_f32(const float* x, float* out, int64_t rows, int32_t C, void* stream) {
+    if (!x || !out || rows <= 0 || C < 4 || (C & 3) || C > 1024 || 256 % (C / 4)) return LOANS_EINVAL;
+    int rpb;
+    const int grid = reduce_geometry(rows, C, &rpb);
+    hipLaunchKernelGGL(colsum_kernel, dim3(grid), dim3(256), 0, as_stream(stream), x, out, rows, C / 4, rpb);
+    LOANS_LAUNCH_CHECK();
+    return LOANS_OK;
+}

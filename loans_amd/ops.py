@@ -1,0 +1,396 @@
+"""Typed Python wrappers over the C ABI (include/loans_hip.h).
+
+Device memory, streams and allocation come from PyTorch-ROCm (plumbing); all
+arithmetic is in the HIP kernels.  Tensors handed to these wrappers are NHWC
+float32 and contiguous unless a wrapper says otherwise.  Nothing here has a CPU
+fallback: without the built library ``_lib.load()`` raises.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib
+from ._lib import (F_ADDEND, F_ADDEND_MASK, F_BIAS, F_MASK, F_RELU_IN, F_STATS, IgemmDesc, check)
+
+BN_EPS = 2e-5          # chainer.links.BatchNormalization default (sheep/resnet.py:44)
+BN_DECAY = 0.9
+# Chainer 4.1.0's CPU path folds eps into the running variance (see oracle/chainer_ops.py)
+RUNNING_VAR_INCLUDES_EPS = 1
+
+
+def _stream():
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _ptr(t):
+    return 0 if t is None else t.data_ptr()
+
+
+def _chk(t, name='tensor'):
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise ValueError('%s must be a contiguous float32 device tensor' % name)
+
+
+# --------------------------------------------------------------------------- #
+# convolution geometry -> descriptors
+# --------------------------------------------------------------------------- #
+def conv_outsize(size, k, s, p, cover_all=False):
+    if cover_all:
+        return (size + p * 2 - k + s - 1) // s + 1
+    return (size + p * 2 - k) // s + 1
+
+
+class ConvGeometry:
+    """Descriptors for one Convolution2D at a fixed input shape (cached by the
+    caller): forward, weight-gradient and the per-stride-parity-class data
+    gradient launches.  Channels are the PHYSICAL (multiple-of-4) counts."""
+
+    def __init__(self, B, H, W, Cin, Cout, k, stride, pad):
+        self.B, self.H, self.W, self.Cin, self.Cout = B, H, W, Cin, Cout
+        self.k, self.stride, self.pad = k, stride, pad
+        self.Ho, self.Wo = conv_outsize(H, k, stride, pad), conv_outsize(W, k, stride, pad)
+        d = IgemmDesc()
+        d.B, d.inH, d.inW, d.Cin = B, H, W, Cin
+        d.outH, d.outW, d.Cout = self.Ho, self.Wo, Cout
+        d.gridH, d.gridW = self.Ho, self.Wo
+        d.osy = d.osx = 1
+        d.oy0 = d.ox0 = 0
+        d.isy = d.isx = stride
+        d.ntaps = k * k
+        t = 0
+        for r in range(k):
+            for s in range(k):
+                d.dy[t], d.dx[t] = r - pad, s - pad
+                t += 1
+        self.fwd = d
+        # data gradient: gathered tensor = gy (Ho x Wo x Cout), output = gx (H x W x Cin)
+        self.dgrad = []          # list of (desc, tapsel, weight_offset_in_floats)
+        off = 0
+        for cy in range(stride):
+            for cx in range(stride):
+                gh = (H - cy + stride - 1) // stride
+                gw = (W - cx + stride - 1) // stride
+                if gh <= 0 or gw <= 0:
+                    continue
+                taps = [(r, s) for r in range(k) for s in range(k)
+                        if (cy + pad - r) % stride == 0 and (cx + pad - s) % stride == 0]
+                if not taps:
+                    raise NotImplementedError('stride-parity class without taps (k < stride)')
+                g = IgemmDesc()
+                g.B, g.inH, g.inW, g.Cin = B, self.Ho, self.Wo, Cout
+                g.outH, g.outW, g.Cout = H, W, Cin
+                g.gridH, g.gridW = gh, gw
+                g.osy = g.osx = stride
+                g.oy0, g.ox0 = cy, cx
+                g.isy = g.isx = 1
+                g.ntaps = len(taps)
+                for t, (r, s) in enumerate(taps):
+                    g.dy[t] = (cy + pad - r) // stride
+                    g.dx[t] = (cx + pad - s) // stride
+                tapsel = (C.c_int32 * len(taps))(*[r * k + s for r, s in taps])
+                self.dgrad.append((g, tapsel, off))
+                off += Cin * len(taps) * Cout
+        self.dgrad_weight_floats = off
+        self.flops_fwd = 2 * B * self.Ho * self.Wo * Cout * k * k * Cin
+
+
+def _with_flags(desc, flags, tile=0):
+    desc.flags = flags
+    desc.tile = tile
+    return desc
+
+
+def conv_fprop(x, w, geo, out=None, bias=None, stats=None, relu_in=False, addend=None, tile=0):
+    """out[B,Ho,Wo,Cout] = conv(x[B,H,W,Cin], w[Cout,k,k,Cin]) (+bias) (+addend); optional BN statistics."""
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty((geo.B, geo.Ho, geo.Wo, geo.Cout), device=x.device, dtype=torch.float32)
+    flags = (F_RELU_IN if relu_in else 0) | (F_BIAS if bias is not None else 0) | \
+            (F_STATS if stats is not None else 0) | (F_ADDEND if addend is not None else 0)
+    d = _with_flags(geo.fwd, flags, tile)
+    assert x.numel() == geo.B * geo.H * geo.W * geo.Cin and w.numel() == geo.Cout * geo.k * geo.k * geo.Cin
+    check(lib.loans_igemm_f32(_ptr(x), _ptr(w), _ptr(out), _ptr(bias), _ptr(stats), 0, _ptr(addend),
+                              C.byref(d), _stream()), 'loans_igemm_f32[fprop]')
+    return out
+
+
+def conv_dgrad(gy, w, geo, out=None, mask_ref=None, addend=None, addend_mask_ref=None, tile=0):
+    """gx[B,H,W,Cin] = conv_transpose(gy, w); epilogue: (* (mask_ref>0)), (+ addend [masked by addend_mask_ref>0]).
+    Re-packs w per stride-parity class first (weights change every step)."""
+    lib = _lib.load()
+    if out is None:
+        out = torch.empty((geo.B, geo.H, geo.W, geo.Cin), device=gy.device, dtype=torch.float32)
+    assert gy.numel() == geo.B * geo.Ho * geo.Wo * geo.Cout
+    wp = torch.empty(geo.dgrad_weight_floats, device=gy.device, dtype=torch.float32)
+    flags = (F_MASK if mask_ref is not None else 0) | (F_ADDEND if addend is not None else 0) | \
+            (F_ADDEND_MASK if addend_mask_ref is not None else 0)
+    ref = mask_ref if mask_ref is not None else addend_mask_ref
+    assert not (mask_ref is not None and addend_mask_ref is not None)
+    st = _stream()
+    for d, tapsel, off in geo.dgrad:
+        wcls = wp[off:]
+        check(lib.loans_repack_dgrad_f32(_ptr(w), _ptr(wcls), geo.Cout, geo.Cin, geo.k * geo.k, tapsel,
+                                         d.ntaps, st), 'loans_repack_dgrad_f32')
+        _with_flags(d, flags, tile)
+        check(lib.loans_igemm_f32(_ptr(gy), _ptr(wcls), _ptr(out), 0, 0, _ptr(ref), _ptr(addend),
+                                  C.byref(d), st), 'loans_igemm_f32[dgrad]')
+    return out
+
+
+def conv_wgrad(x, gy, dw, geo, relu_in=False, splits=0):
+    """dw[Cout,k,k,Cin] += sum over pixels (atomic accumulate into the gradient arena)."""
+    lib = _lib.load()
+    d = _with_flags(geo.fwd, F_RELU_IN if relu_in else 0, 0)
+    assert dw.numel() == geo.Cout * geo.k * geo.k * geo.Cin
+    check(lib.loans_wgrad_f32(_ptr(x), _ptr(gy), _ptr(dw), C.byref(d), splits, _stream()), 'loans_wgrad_f32')
+
+
+# --------------------------------------------------------------------------- #
+# preprocessing / layout
+# --------------------------------------------------------------------------- #
+def prep_images(images_nchw):
+    B, c, H, W = images_nchw.shape
+    assert c == 3
+    _chk(images_nchw, 'images')
+    out = torch.empty((B, H, W, 4), device=images_nchw.device, dtype=torch.float32)
+    check(_lib.load().loans_prep_images_f32(_ptr(images_nchw), _ptr(out), B, H, W, _stream()), 'loans_prep_images_f32')
+    return out
+
+
+def nchw3_to_nhwc4(x):
+    B, c, H, W = x.shape
+    assert c == 3
+    _chk(x, 'images')
+    out = torch.empty((B, H, W, 4), device=x.device, dtype=torch.float32)
+    check(_lib.load().loans_nchw3_to_nhwc4_f32(_ptr(x), _ptr(out), B, H, W, _stream()), 'loans_nchw3_to_nhwc4_f32')
+    return out
+
+
+# --------------------------------------------------------------------------- #
+# batch normalisation
+# --------------------------------------------------------------------------- #
+class BNState:
+    """Per-call batch statistics + affine coefficients (device vectors of C floats)."""
+    __slots__ = ('mean', 'rstd', 'scale', 'shift', 'count')
+
+    def __init__(self, C_, device):
+        buf = torch.empty((4, C_), device=device, dtype=torch.float32)
+        self.mean, self.rstd, self.scale, self.shift = buf[0], buf[1], buf[2], buf[3]
+        self.count = 0
+
+
+def bn_finalize(stats, count, gamma, beta, running_mean, running_var):
+    C_ = gamma.numel()
+    st = BNState(C_, gamma.device)
+    st.count = count
+    check(_lib.load().loans_bn_finalize_f32(_ptr(stats), C_, count, BN_EPS, BN_DECAY, _ptr(gamma), _ptr(beta),
+                                            _ptr(running_mean), _ptr(running_var), RUNNING_VAR_INCLUDES_EPS,
+                                            _ptr(st.mean), _ptr(st.rstd), _ptr(st.scale), _ptr(st.shift), _stream()),
+          'loans_bn_finalize_f32')
+    return st
+
+
+def bn_eval_coeffs(gamma, beta, running_mean, running_var):
+    C_ = gamma.numel()
+    st = BNState(C_, gamma.device)
+    check(_lib.load().loans_bn_eval_coeffs_f32(C_, BN_EPS, _ptr(gamma), _ptr(beta), _ptr(running_mean),
+                                               _ptr(running_var), _ptr(st.mean), _ptr(st.rstd), _ptr(st.scale),
+                                               _ptr(st.shift), _stream()), 'loans_bn_eval_coeffs_f32')
+    return st
+
+
+def bn_apply(x, st, relu=True, residual=None, x2=None, st2=None):
+    C_ = x.shape[-1]
+    rows = x.numel() // C_
+    y = torch.empty_like(x)
+    mode = 0
+    second = None
+    if residual is not None:
+        mode, second = 1, residual
+    elif x2 is not None:
+        mode, second = 2, x2
+    check(_lib.load().loans_bn_apply_f32(_ptr(x), _ptr(st.scale), _ptr(st.shift), _ptr(second),
+                                         _ptr(st2.scale if st2 else None), _ptr(st2.shift if st2 else None),
+                                         _ptr(y), rows, C_, mode, 1 if relu else 0, _stream()), 'loans_bn_apply_f32')
+    return y
+
+
+def bn_relu_maxpool(x, st):
+    B, H, W, C_ = x.shape
+    OH, OW = conv_outsize(H, 3, 2, 0, True), conv_outsize(W, 3, 2, 0, True)
+    y = torch.empty((B, OH, OW, C_), device=x.device, dtype=torch.float32)
+    idx = torch.empty((B, OH, OW, C_), device=x.device, dtype=torch.uint8)
+    check(_lib.load().loans_bn_relu_maxpool_f32(_ptr(x), _ptr(st.scale), _ptr(st.shift), _ptr(y), _ptr(idx),
+                                                B, H, W, C_, OH, OW, _stream()), 'loans_bn_relu_maxpool_f32')
+    return y, idx
+
+
+def maxpool_relu_bwd(gy, idx, x, st):
+    B, H, W, C_ = x.shape
+    OH, OW = gy.shape[1], gy.shape[2]
+    gx = torch.empty_like(x)
+    check(_lib.load().loans_maxpool_relu_bwd_f32(_ptr(gy), _ptr(idx), _ptr(x), _ptr(st.scale), _ptr(st.shift),
+                                                 _ptr(gx), B, H, W, C_, OH, OW, _stream()), 'loans_maxpool_relu_bwd_f32')
+    return gx
+
+
+def bn_backward(gy, mask, x, st, gamma, ggamma, gbeta, x2=None, st2=None, gamma2=None, ggamma2=None, gbeta2=None):
+    """Training-mode BN backward for one or two BNs fed by the same upstream gradient
+    g = gy * (mask > 0).  Accumulates ggamma/gbeta in place, returns gx (and gx2)."""
+    lib = _lib.load()
+    C_ = x.shape[-1]
+    rows = x.numel() // C_
+    dual = x2 is not None
+    sums = torch.zeros((4 if dual else 2, C_), device=x.device, dtype=torch.float64)
+    s = _stream()
+    check(lib.loans_bn_bwd_reduce_f32(_ptr(gy), _ptr(mask), _ptr(x), _ptr(st.mean), _ptr(st.rstd), _ptr(x2),
+                                      _ptr(st2.mean if dual else None), _ptr(st2.rstd if dual else None),
+                                      _ptr(sums), rows, C_, s), 'loans_bn_bwd_reduce_f32')
+    k = torch.empty((6 if dual else 3, C_), device=x.device, dtype=torch.float32)
+    check(lib.loans_bn_bwd_coeffs_f32(_ptr(sums), C_, rows, _ptr(gamma), _ptr(st.mean), _ptr(st.rstd), _ptr(ggamma),
+                                      _ptr(gbeta), _ptr(k[0]), _ptr(k[1]), _ptr(k[2]), s), 'loans_bn_bwd_coeffs_f32')
+    gx = torch.empty_like(x)
+    gx2 = None
+    if dual:
+        check(lib.loans_bn_bwd_coeffs_f32(_ptr(sums[2]), C_, rows, _ptr(gamma2), _ptr(st2.mean), _ptr(st2.rstd),
+                                          _ptr(ggamma2), _ptr(gbeta2), _ptr(k[3]), _ptr(k[4]), _ptr(k[5]), s),
+              'loans_bn_bwd_coeffs_f32')
+        gx2 = torch.empty_like(x2)
+    check(lib.loans_bn_bwd_apply_f32(_ptr(gy), _ptr(mask), _ptr(x), _ptr(k[0]), _ptr(k[1]), _ptr(k[2]), _ptr(gx),
+                                     _ptr(x2), _ptr(k[3]) if dual else 0, _ptr(k[4]) if dual else 0,
+                                     _ptr(k[5]) if dual else 0, _ptr(gx2), rows, C_, s), 'loans_bn_bwd_apply_f32')
+    return (gx, gx2) if dual else gx
+
+
+def bn_backward_fixed(gy, mask, st_eval_scale):
+    """Test-mode (fixed statistics) backward: gx = scale * gy * (mask > 0)."""
+    raise NotImplementedError('backward through test-mode BatchNormalization is not on the training path')
+
+
+def colsum_acc(x, out):
+    C_ = x.shape[-1]
+    check(_lib.load().loans_colsum_f32(_ptr(x), _ptr(out), x.numel() // C_, C_, _stream()), 'loans_colsum_f32')
+
+
+# --------------------------------------------------------------------------- #
+# small dense ops
+# --------------------------------------------------------------------------- #
+def gap_fwd(x):
+    B, H, W, C_ = x.shape
+    y = torch.empty((B, C_), device=x.device, dtype=torch.float32)
+    check(_lib.load().loans_gap_fwd_f32(_ptr(x), _ptr(y), B, H * W, C_, _stream()), 'loans_gap_fwd_f32')
+    return y
+
+
+def gap_bwd(gy, shape):
+    B, H, W, C_ = shape
+    gx = torch.empty(shape, device=gy.device, dtype=torch.float32)
+    check(_lib.load().loans_gap_bwd_f32(_ptr(gy), _ptr(gx), B, H * W, C_, _stream()), 'loans_gap_bwd_f32')
+    return gx
+
+
+def linear_fwd(x, W, b, act_in=False, act_out=False):
+    B = x.shape[0]
+    K = x.numel() // B
+    N = W.numel() // K
+    y = torch.empty((B, N), device=x.device, dtype=torch.float32)
+    check(_lib.load().loans_linear_fwd_f32(_ptr(x), _ptr(W), _ptr(b), _ptr(y), B, K, N, int(act_in), int(act_out),
+                                           _stream()), 'loans_linear_fwd_f32')
+    return y
+
+
+def linear_bwd(x, W, y, gy, gW=None, gb=None, need_gx=True, act_in=False, act_out=False):
+    B = x.shape[0]
+    K = x.numel() // B
+    N = W.numel() // K
+    gx = torch.empty_like(x) if need_gx else None
+    check(_lib.load().loans_linear_bwd_f32(_ptr(x), _ptr(W), _ptr(y), _ptr(gy), _ptr(gx), _ptr(gW), _ptr(gb),
+                                           B, K, N, int(act_in), int(act_out), _stream()), 'loans_linear_bwd_f32')
+    return gx
+
+
+def mul(x, m):
+    y = torch.empty_like(x)
+    check(_lib.load().loans_mul_f32(_ptr(x), _ptr(m), _ptr(y), x.numel(), _stream()), 'loans_mul_f32')
+    return y
+
+
+def axpby(a, x, b, y):
+    """y = a*x + b*y in place."""
+    assert x.numel() == y.numel()
+    check(_lib.load().loans_axpby_f32(a, _ptr(x), b, _ptr(y), x.numel(), _stream()), 'loans_axpby_f32')
+    return y
+
+
+# --------------------------------------------------------------------------- #
+# spatial transformer
+# --------------------------------------------------------------------------- #
+def st_grid_fwd(theta, out_size):
+    B = theta.shape[0]
+    th, tw = out_size
+    grid = torch.empty((B, 2, th, tw), device=theta.device, dtype=torch.float32)
+    check(_lib.load().loans_st_grid_fwd_f32(_ptr(theta), _ptr(grid), B, th, tw, _stream()), 'loans_st_grid_fwd_f32')
+    return grid
+
+
+def st_grid_bwd(ggrid):
+    B, _, th, tw = ggrid.shape
+    gtheta = torch.empty((B, 2, 3), device=ggrid.device, dtype=torch.float32)
+    check(_lib.load().loans_st_grid_bwd_f32(_ptr(ggrid), _ptr(gtheta), B, th, tw, _stream()), 'loans_st_grid_bwd_f32')
+    return gtheta
+
+
+def st_sampler_fwd(images_nchw, grid):
+    B, _, H, W = images_nchw.shape
+    th, tw = grid.shape[2:]
+    rois = torch.empty((B, th, tw, 4), device=grid.device, dtype=torch.float32)
+    check(_lib.load().loans_st_sampler_fwd_f32(_ptr(images_nchw), _ptr(grid), _ptr(rois), B, H, W, th, tw, _stream()),
+          'loans_st_sampler_fwd_f32')
+    return rois
+
+
+def st_sampler_bwd_grid(images_nchw, grid, grois):
+    B, _, H, W = images_nchw.shape
+    th, tw = grid.shape[2:]
+    ggrid = torch.empty_like(grid)
+    check(_lib.load().loans_st_sampler_bwd_grid_f32(_ptr(images_nchw), _ptr(grid), _ptr(grois), _ptr(ggrid), 0,
+                                                    B, H, W, th, tw, _stream()), 'loans_st_sampler_bwd_grid_f32')
+    return ggrid
+
+
+# --------------------------------------------------------------------------- #
+# losses / optimiser
+# --------------------------------------------------------------------------- #
+def mse_fwd(y, target=None, tconst=0.0):
+    loss = torch.empty((), device=y.device, dtype=torch.float32)
+    check(_lib.load().loans_mse_fwd_f32(_ptr(y), _ptr(target), tconst, _ptr(loss), y.numel(), _stream()), 'loans_mse_fwd_f32')
+    return loss
+
+
+def mse_bwd(y, gloss, target=None, tconst=0.0):
+    gy = torch.empty_like(y)
+    check(_lib.load().loans_mse_bwd_f32(_ptr(y), _ptr(target), tconst, _ptr(gloss), _ptr(gy), y.numel(), _stream()),
+          'loans_mse_bwd_f32')
+    return gy
+
+
+def grid_loss_fwd(grid, kind, img_h=0.0, img_w=0.0, oob_scale=1.0):
+    B, _, th, tw = grid.shape
+    loss = torch.empty((), device=grid.device, dtype=torch.float32)
+    check(_lib.load().loans_grid_loss_fwd_f32(_ptr(grid), _ptr(loss), kind, img_h, img_w, oob_scale, B, th, tw,
+                                              _stream()), 'loans_grid_loss_fwd_f32')
+    return loss
+
+
+def grid_loss_bwd(grid, gloss, kind, img_h=0.0, img_w=0.0, oob_scale=1.0):
+    B, _, th, tw = grid.shape
+    ggrid = torch.zeros_like(grid)
+    check(_lib.load().loans_grid_loss_bwd_f32(_ptr(grid), _ptr(gloss), _ptr(ggrid), kind, img_h, img_w, oob_scale,
+                                              B, th, tw, _stream()), 'loans_grid_loss_bwd_f32')
+    return ggrid
+
+
+def adam_amsgrad(p, g, m, v, vhat, lr_t, beta1, beta2, eps, eta, weight_decay_rate, grad_scale=1.0):
+    check(_lib.load().loans_adam_amsgrad_f32(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(vhat), p.numel(), lr_t, beta1,
+                                             beta2, eps, eta, weight_decay_rate, grad_scale, _stream()),
+          'loans_adam_amsgrad_f32')

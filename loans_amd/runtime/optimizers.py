@@ -1,0 +1,72 @@
+"""``chainer.optimizers.Adam(alpha, amsgrad=True)`` (train_sheep_localizer.py:130-134)
+as ONE fused kernel launch over the model's flat parameter arena.
+
+Chainer 4.1.0 semantics (oracle/chainer_ops.py:adam_amsgrad_update): eps sits outside
+the bias correction, ``lr_t = alpha * sqrt(1 - beta2^t) / (1 - beta1^t)``, parameters
+without a gradient are updated with zeros.  With a communicator attached
+(``parallel.create_multi_node_optimizer``) gradients are all-reduced over RCCL first."""
+import math
+from types import SimpleNamespace
+
+import torch
+
+from .. import ops
+
+
+class Adam:
+
+    def __init__(self, alpha=0.001, beta1=0.9, beta2=0.999, eps=1e-8, eta=1.0, weight_decay_rate=0, amsgrad=False):
+        if not amsgrad:
+            raise NotImplementedError("the LoANs trainer only uses amsgrad=True")
+        self.hyperparam = SimpleNamespace(alpha=alpha, beta1=beta1, beta2=beta2, eps=eps, eta=eta,
+                                          weight_decay_rate=weight_decay_rate, amsgrad=amsgrad)
+        self.t = 0
+        self.target = None
+        self.comm = None
+        self._state = None
+
+    def setup(self, link):
+        self.target = link
+        return self
+
+    @property
+    def alpha(self):
+        return self.hyperparam.alpha
+
+    @alpha.setter
+    def alpha(self, v):
+        self.hyperparam.alpha = v
+
+    @property
+    def lr(self):
+        hp = self.hyperparam
+        if self.t == 0:
+            raise RuntimeError("Can't determine the learning rate of Adam optimizer because the update steps have not been started.")
+        fix1 = 1. - math.pow(hp.beta1, self.t)
+        fix2 = 1. - math.pow(hp.beta2, self.t)
+        return hp.alpha * math.sqrt(fix2) / fix1
+
+    def _ensure_state(self):
+        arena = self.target.arena
+        if arena is None:
+            arena = self.target.finalize()
+        if self._state is None or self._state[0].numel() != arena.numel:
+            z = lambda: torch.zeros(arena.numel, device=arena.device, dtype=torch.float32)   # noqa: E731
+            self._state = (z(), z(), z())
+        return arena
+
+    def update(self, lossfun=None, *args, **kwds):
+        if lossfun is not None:
+            raise NotImplementedError("update(lossfun) is not used by the LoANs updater")
+        if not any(p.update_rule.enabled for p in self.target.params()):
+            return
+        arena = self._ensure_state()
+        grad_scale = 1.0
+        if self.comm is not None and self.comm.size > 1:
+            self.comm.allreduce_grad(arena)
+            grad_scale = 1.0 / self.comm.size
+        self.t += 1
+        hp = self.hyperparam
+        m, v, vhat = self._state
+        ops.adam_amsgrad(arena.data, arena.grad, m, v, vhat, self.lr, hp.beta1, hp.beta2, hp.eps, hp.eta,
+                         hp.weight_decay_rate, grad_scale)

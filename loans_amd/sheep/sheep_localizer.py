@@ -1,0 +1,115 @@
+"""``SheepLocalizer`` (reference sheep/sheep_localizer.py:18-117), MI355X-native.
+
+Same constructor, call signature, attributes and ``predict`` contract:
+``localizer(images (B,3,H,W) f32 RGB in [0,1]) -> (rois (B,3,th,tw), points (B,2,th,tw))``.
+
+What changed underneath: ``prepare_images`` is one HIP kernel instead of a
+device->host->PIL->device round trip per image (:72-82); the backbone runs NHWC
+on the fp32 MFMA implicit-GEMM kernels; ``rois`` is an NCHW view of the NHWC4
+buffer the assessor consumes directly.
+"""
+import numpy as np
+import torch
+
+from .. import links as L
+from .. import ops
+from ..common.utils import Size
+from ..functions import (global_average_pooling_2d, linear, reshape, rotation_dropout,
+                         spatial_transformer_grid, spatial_transformer_sampler)
+from ..functions.ops_small import ExposeNCHW
+from ..runtime.core import Chain, Variable, as_variable, config, using_config
+from .resnet import BasicBlock, ResNet
+
+
+def _as_device_batch(images, device):
+    if isinstance(images, Variable):
+        images = images.data
+    if isinstance(images, np.ndarray):
+        images = torch.from_numpy(np.ascontiguousarray(images, dtype=np.float32))
+    return images.to(device=device, dtype=torch.float32).contiguous()
+
+
+class SheepLocalizer(Chain):
+
+    def __init__(self, out_size, transform_rois_to_grayscale=False, train_imagenet=False):
+        super().__init__()
+        if train_imagenet:
+            raise NotImplementedError("ImageNet pre-training head is outside the LoANs training path")
+        with self.init_scope():
+            self.feature_extractor = ResNet(18, class_labels=None)
+            self.res6 = BasicBlock(2, 512, in_ch=512)
+            self.res7 = BasicBlock(2, 512, in_ch=512)
+            self.param_predictor = L.Linear(512, 6)
+
+            transform_bias = self.param_predictor.b.host
+            transform_bias[[0, 4]] = 0.8
+            transform_bias[[2, 5]] = 0
+            self.param_predictor.W.host[...] = 0
+
+        self.visual_backprop_anchors = []
+        self.out_size = tuple(out_size)
+        self.transform_rois_to_grayscale = transform_rois_to_grayscale
+        self.train_imagenet = train_imagenet
+
+    def __call__(self, images):
+        self.visual_backprop_anchors.clear()
+        device = images.data.device if isinstance(images, Variable) else (
+            images.device if torch.is_tensor(images) and images.is_cuda else torch.device('cuda', torch.cuda.current_device()))
+        self.finalize(device)
+        images = _as_device_batch(images, device)
+
+        input_images = self.prepare_images(images)
+        h = self.feature_extractor(input_images)
+
+        if images.shape[-2] > 224:
+            h = self.res6(h)
+
+            if images.shape[-2] > 300:
+                h = self.res7(h)
+
+        self.visual_backprop_anchors.append(h)
+        h = global_average_pooling_2d(h)
+
+        transform_params = linear(h, self.param_predictor.W, self.param_predictor.b)
+        transform_params = rotation_dropout(reshape(transform_params, (-1, 2, 3)), ratio=0.0)
+        points = spatial_transformer_grid(transform_params, self.out_size)
+        rois = ExposeNCHW()(spatial_transformer_sampler(as_variable(images), points))
+        self.last_transform_params = transform_params
+
+        if self.transform_rois_to_grayscale:
+            raise NotImplementedError("grayscale rois are off on the training path (train_sheep_localizer.py:118-119)")
+
+        return rois, points
+
+    def prepare_images(self, images):
+        """``images * 255`` -> uint8 truncation -> BGR -> minus mean, cutting the graph
+        (sheep_localizer.py:45,72-82); returns NHWC4."""
+        return Variable(ops.prep_images(images), requires_grad=False)
+
+    def extract_corners(self, bboxes):
+        data = bboxes.data if isinstance(bboxes, Variable) else bboxes
+        top = data[:, 1, 0, 0]
+        left = data[:, 0, 0, 0]
+        bottom = data[:, 1, -1, -1]
+        right = data[:, 0, -1, -1]
+        return torch.stack([top, left, bottom, right], dim=1)
+
+    def scale_bboxes(self, bboxes, image_size):
+        bboxes = (bboxes + 1) / 2
+        bboxes[:, ::2] *= image_size.height
+        bboxes[:, 1::2] *= image_size.width
+        return bboxes
+
+    def predict(self, images, return_visual_backprop=False):
+        images = np.stack([np.asarray(image, dtype=np.float32) for image in images], axis=0)
+        with using_config('train', False), using_config('enable_backprop', False):
+            rois, bboxes = self(images)
+            if return_visual_backprop:
+                raise NotImplementedError("VisualBackprop is a visualisation tool outside the hot path (SURVEY §2.1 #13)")
+            visual_backprop = None
+            bboxes = self.extract_corners(bboxes)
+            bboxes = self.scale_bboxes(bboxes, Size._make(images.shape[-2:]))
+
+        bboxes = [bbox.cpu().numpy().reshape(1, -1) for bbox in bboxes]
+
+        return bboxes, rois, np.ones((len(bboxes), 1)), visual_backprop

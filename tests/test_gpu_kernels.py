@@ -1,0 +1,251 @@
+"""-m gpu: every HIP kernel family against the CPU oracle, through the C ABI
+(loans_amd.ops is a 1:1 ctypes wrapper of include/loans_hip.h).  fp32 tolerances are
+written next to each check; integer/index results (argmax, uint8 truncation) are exact."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import chainer_ops as C
+from tests.gpu_util import dev, rel_err
+
+pytestmark = pytest.mark.gpu
+
+
+def _nhwc(x, cpad=None):
+    x = np.transpose(x, (0, 2, 3, 1))
+    if cpad and x.shape[-1] < cpad:
+        x = np.concatenate([x, np.zeros(x.shape[:-1] + (cpad - x.shape[-1],), x.dtype)], axis=-1)
+    return np.ascontiguousarray(x)
+
+
+def _nchw(t, c=None):
+    a = t.detach().cpu().numpy().transpose(0, 3, 1, 2)
+    return a if c is None else a[:, :c]
+
+
+def _ohwi(w, cpad=None):
+    return _nhwc(w, cpad)
+
+
+CONV_CASES = [
+    # B, Cin, H, W, Cout, k, stride, pad
+    (2, 3, 32, 32, 64, 7, 2, 3),      # stem
+    (3, 64, 14, 14, 64, 3, 1, 1),     # res2-like
+    (2, 64, 15, 13, 128, 3, 2, 1),    # strided, odd sizes
+    (2, 128, 9, 9, 128, 4, 2, 1),     # assessor 4x4/2
+    (2, 3, 19, 19, 128, 4, 2, 1),     # assessor cs on rgb
+    (1, 256, 7, 7, 512, 3, 2, 1),     # res5 entry
+    (5, 128, 6, 6, 200, 3, 1, 1),     # Cout not a multiple of the tile
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
+def test_conv_fprop_dgrad_wgrad(case, tile):
+    from loans_amd import ops
+    B, Cin, H, W, Cout, k, s, p = case
+    rng = np.random.RandomState(hash(case) % 1000)
+    x = rng.standard_normal((B, Cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    cp = (Cin + 3) // 4 * 4
+    geo = ops.ConvGeometry(B, H, W, cp, Cout, k, s, p)
+    xd, wd, bd = dev(_nhwc(x, cp)), dev(_ohwi(w, cp)), dev(b)
+
+    y_ref, col = C.conv2d_fwd(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64), s, p)
+    stats = torch.zeros((2, Cout), device='cuda', dtype=torch.float64)
+    y = ops.conv_fprop(xd, wd, geo, bias=bd, stats=stats, tile=tile)
+    assert rel_err(_nchw(y), y_ref) < 2e-6          # exact-f32 MFMA chain vs f64
+    np.testing.assert_allclose(stats[0].cpu().numpy(), y_ref.sum(axis=(0, 2, 3)), rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(stats[1].cpu().numpy(), (y_ref ** 2).sum(axis=(0, 2, 3)), rtol=1e-5)
+
+    # relu_in + addend epilogue
+    add = rng.standard_normal(y_ref.shape).astype(np.float32)
+    y2_ref, _ = C.conv2d_fwd(np.maximum(x, 0).astype(np.float64), w.astype(np.float64), None, s, p)
+    y2 = ops.conv_fprop(xd, wd, geo, relu_in=True, addend=dev(_nhwc(add)), tile=tile)
+    assert rel_err(_nchw(y2), y2_ref + add) < 2e-6
+
+    gy = rng.standard_normal(y_ref.shape).astype(np.float32)
+    gx_ref, gw_ref, _ = C.conv2d_bwd(x.shape, col, w.astype(np.float64), gy.astype(np.float64), s, p, False)
+    gyd = dev(_nhwc(gy))
+    if tile in (0, 1, 2, 3, 4):
+        gx = ops.conv_dgrad(gyd, wd, geo, tile=tile)
+        assert rel_err(_nchw(gx, Cin), gx_ref) < 2e-6
+        # mask + addend epilogues
+        ref_t = rng.standard_normal(x.shape).astype(np.float32)
+        addx = rng.standard_normal(x.shape).astype(np.float32)
+        gx2 = ops.conv_dgrad(gyd, wd, geo, mask_ref=dev(_nhwc(ref_t, cp)), addend=dev(_nhwc(addx, cp)), tile=tile)
+        assert rel_err(_nchw(gx2, Cin), gx_ref * (ref_t > 0) + addx) < 2e-6
+        gx3 = ops.conv_dgrad(gyd, wd, geo, addend=dev(_nhwc(addx, cp)), addend_mask_ref=dev(_nhwc(ref_t, cp)), tile=tile)
+        assert rel_err(_nchw(gx3, Cin), gx_ref + addx * (ref_t > 0)) < 2e-6
+    if tile in (0, 1, 3):
+        dw = torch.zeros_like(wd)
+        geo.fwd.tile = tile
+        ops.conv_wgrad(xd, gyd, dw, geo)
+        got = dw.cpu().numpy().transpose(0, 3, 1, 2)[:, :Cin]
+        assert rel_err(got, gw_ref) < 5e-6
+        ops.conv_wgrad(xd, gyd, dw, geo, splits=3)       # accumulates
+        got = dw.cpu().numpy().transpose(0, 3, 1, 2)[:, :Cin]
+        assert rel_err(got, 2 * gw_ref) < 5e-6
+        geo.fwd.tile = 0
+
+
+def test_prep_images_exact():
+    from loans_amd import ops
+    rng = np.random.RandomState(0)
+    k = rng.randint(0, 256, size=(3, 3, 20, 24)).astype(np.float32)
+    x = (k / np.float32(255)).astype(np.float32)
+    x[0, 0, 0, :8] = np.clip((k[0, 0, 0, :8] + 0.5) / 255, 0, 1)        # truncation, not rounding
+    ref = C.prepare_images(x)
+    out = ops.prep_images(dev(x)).cpu().numpy()
+    np.testing.assert_array_equal(out[..., :3].transpose(0, 3, 1, 2), ref)
+    assert not out[..., 3].any()
+
+
+@pytest.mark.parametrize("C_", [64, 128, 512])
+def test_bn_forward_backward(C_):
+    from loans_amd import ops
+    rng = np.random.RandomState(1)
+    B, H, W = 3, 9, 7
+    x = (rng.standard_normal((B, C_, H, W)) * 2 + 0.5).astype(np.float32)
+    gamma = (1 + 0.1 * rng.standard_normal(C_)).astype(np.float32)
+    beta = (0.1 * rng.standard_normal(C_)).astype(np.float32)
+    rm, rv = np.zeros(C_), np.ones(C_)
+    y_ref, ctx = C.bn_fwd_train(x.astype(np.float64), gamma.astype(np.float64), beta.astype(np.float64), rm, rv)
+    xd = dev(_nhwc(x))
+    stats = torch.stack([xd.double().sum(dim=(0, 1, 2)), (xd.double() ** 2).sum(dim=(0, 1, 2))])
+    rmd, rvd = torch.zeros(C_, device='cuda'), torch.ones(C_, device='cuda')
+    st = ops.bn_finalize(stats, B * H * W, dev(gamma), dev(beta), rmd, rvd)
+    np.testing.assert_allclose(rmd.cpu().numpy(), rm, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(rvd.cpu().numpy(), rv, rtol=1e-5)
+    y = ops.bn_apply(xd, st, relu=False)
+    assert rel_err(_nchw(y), y_ref) < 1e-5
+    res = rng.standard_normal(x.shape).astype(np.float32)
+    y = ops.bn_apply(xd, st, relu=True, residual=dev(_nhwc(res)))
+    assert rel_err(_nchw(y), np.maximum(y_ref + res, 0)) < 1e-5
+    y = ops.bn_apply(xd, st, relu=True, x2=xd, st2=st)
+    assert rel_err(_nchw(y), np.maximum(2 * y_ref, 0)) < 1e-5
+
+    gy = rng.standard_normal(x.shape).astype(np.float32)
+    mask = rng.standard_normal(x.shape).astype(np.float32)
+    g_eff = gy * (mask > 0)
+    gx_ref, gg_ref, gb_ref = C.bn_bwd(ctx, gamma.astype(np.float64), g_eff.astype(np.float64))
+    gg, gb = torch.zeros(C_, device='cuda'), torch.zeros(C_, device='cuda')
+    gx = ops.bn_backward(dev(_nhwc(gy)), dev(_nhwc(mask)), xd, st, dev(gamma), gg, gb)
+    assert rel_err(_nchw(gx), gx_ref) < 2e-5
+    assert rel_err(gg.cpu().numpy(), gg_ref) < 1e-5 and rel_err(gb.cpu().numpy(), gb_ref) < 1e-5
+    # dual form (BasicA's output feeds bn2 and bn3)
+    gg2, gb2 = torch.zeros(C_, device='cuda'), torch.zeros(C_, device='cuda')
+    gg.zero_(); gb.zero_()
+    gxa, gxb = ops.bn_backward(dev(_nhwc(gy)), dev(_nhwc(mask)), xd, st, dev(gamma), gg, gb,
+                               x2=xd, st2=st, gamma2=dev(gamma), ggamma2=gg2, gbeta2=gb2)
+    assert rel_err(_nchw(gxa), gx_ref) < 2e-5 and rel_err(_nchw(gxb), gx_ref) < 2e-5
+    assert rel_err(gg2.cpu().numpy(), gg_ref) < 1e-5
+
+
+def test_stem_pool_forward_backward():
+    from loans_amd import ops
+    rng = np.random.RandomState(2)
+    for (B, H, W) in [(2, 16, 16), (1, 9, 12), (2, 8, 7)]:
+        C_ = 64
+        x = rng.standard_normal((B, C_, H, W)).astype(np.float32)
+        scale = (1 + 0.1 * rng.standard_normal(C_)).astype(np.float32)
+        shift = (0.1 * rng.standard_normal(C_)).astype(np.float32)
+        pre = np.maximum(x * scale[None, :, None, None] + shift[None, :, None, None], 0)
+        y_ref, idx_ref = C.max_pool_fwd(pre)
+        st = ops.BNState(C_, 'cuda')
+        st.scale.copy_(dev(scale)); st.shift.copy_(dev(shift))
+        xd = dev(_nhwc(x))
+        y, idx = ops.bn_relu_maxpool(xd, st)
+        np.testing.assert_allclose(_nchw(y), y_ref, rtol=1e-6, atol=1e-6)
+        np.testing.assert_array_equal(idx.cpu().numpy().transpose(0, 3, 1, 2), idx_ref)
+        gy = rng.standard_normal(y_ref.shape).astype(np.float32)
+        g_ref = C.max_pool_bwd(pre.shape, idx_ref, gy) * (pre > 0)
+        g = ops.maxpool_relu_bwd(dev(_nhwc(gy)), idx, xd, st)
+        np.testing.assert_allclose(_nchw(g), g_ref, rtol=1e-6, atol=1e-6)
+
+
+def test_spatial_transformer_forward_backward():
+    from loans_amd import ops
+    rng = np.random.RandomState(3)
+    B, H, W, th, tw = 4, 20, 28, 9, 11
+    img = rng.rand(B, 3, H, W).astype(np.float32)
+    theta = np.tile(np.array([[.8, 0, 0], [0, .8, 0]], np.float32), (B, 1, 1))
+    theta += (0.3 * rng.standard_normal(theta.shape)).astype(np.float32)
+    theta[1] = [[1.6, 0, 0.2], [0, 1.7, -0.1]]       # samples well outside the frame
+    grid_ref, coords = C.st_grid_fwd(theta, (th, tw))
+    grid = ops.st_grid_fwd(dev(theta), (th, tw))
+    np.testing.assert_allclose(grid.cpu().numpy(), grid_ref, atol=2e-7)
+    rois_ref = C.st_sampler_fwd(img, grid_ref)
+    rois = ops.st_sampler_fwd(dev(img), dev(grid_ref))
+    np.testing.assert_allclose(rois.cpu().numpy()[..., :3].transpose(0, 3, 1, 2), rois_ref, atol=1e-6)
+    gy = rng.standard_normal(rois_ref.shape).astype(np.float32)
+    gg_ref = C.st_sampler_bwd_grid(img, grid_ref, gy)
+    gg = ops.st_sampler_bwd_grid(dev(img), dev(grid_ref), dev(_nhwc(gy, 4)))
+    np.testing.assert_allclose(gg.cpu().numpy(), gg_ref, rtol=1e-4, atol=1e-5)
+    gt_ref = C.st_grid_bwd(coords, gg_ref)
+    gt = ops.st_grid_bwd(dev(gg_ref))
+    np.testing.assert_allclose(gt.cpu().numpy(), gt_ref, rtol=1e-4, atol=1e-5)
+
+
+def test_losses_and_heads():
+    from loans_amd import ops
+    rng = np.random.RandomState(4)
+    B, th, tw = 5, 6, 7
+    theta = (rng.standard_normal((B, 2, 3)) * 0.9).astype(np.float32)
+    grid, _ = C.st_grid_fwd(theta, (th, tw))
+    gd = dev(grid)
+    one = torch.ones((), device='cuda')
+    l_ref, g_ref = C.direction_loss(grid, (48, 64))
+    np.testing.assert_allclose(float(ops.grid_loss_fwd(gd, 0, 48, 64)), l_ref, rtol=1e-5)
+    np.testing.assert_allclose(ops.grid_loss_bwd(gd, one, 0, 48, 64).cpu().numpy(), g_ref, rtol=1e-5, atol=1e-7)
+    l_ref, g_ref = C.out_of_image_loss(grid)
+    np.testing.assert_allclose(float(ops.grid_loss_fwd(gd, 1)), l_ref, rtol=1e-5)
+    np.testing.assert_allclose(ops.grid_loss_bwd(gd, one, 1).cpu().numpy(), g_ref, rtol=1e-5, atol=1e-7)
+    # mse
+    y = rng.rand(B, 1).astype(np.float32); t = rng.rand(B, 1).astype(np.float32)
+    np.testing.assert_allclose(float(ops.mse_fwd(dev(y), dev(t))), C.mse_fwd(y, t), rtol=1e-6)
+    np.testing.assert_allclose(ops.mse_bwd(dev(y), one, dev(t)).cpu().numpy(), C.mse_bwd(y, t), rtol=1e-6)
+    np.testing.assert_allclose(float(ops.mse_fwd(dev(y), None, 1.0)), C.mse_fwd(y, np.ones_like(y)), rtol=1e-6)
+    # gap + linear (+ relu-in / sigmoid-out head)
+    x = rng.standard_normal((B, 512, 3, 3)).astype(np.float32)
+    np.testing.assert_allclose(ops.gap_fwd(dev(_nhwc(x))).cpu().numpy(), C.gap_fwd(x), rtol=1e-5, atol=1e-6)
+    gp = rng.standard_normal((B, 512)).astype(np.float32)
+    np.testing.assert_allclose(_nchw(ops.gap_bwd(dev(gp), (B, 3, 3, 512))), C.gap_bwd(x.shape, gp), rtol=1e-6)
+    Wl = rng.standard_normal((6, 512)).astype(np.float32); bl = rng.standard_normal(6).astype(np.float32)
+    h = rng.standard_normal((B, 512)).astype(np.float32)
+    np.testing.assert_allclose(ops.linear_fwd(dev(h), dev(Wl), dev(bl)).cpu().numpy(), C.linear_fwd(h, Wl, bl), rtol=1e-4, atol=1e-5)
+    gy = rng.standard_normal((B, 6)).astype(np.float32)
+    gx_ref, gW_ref, gb_ref = C.linear_bwd(h, Wl, gy, True)
+    gW, gb = torch.zeros(6, 512, device='cuda'), torch.zeros(6, device='cuda')
+    gx = ops.linear_bwd(dev(h), dev(Wl), None, dev(gy), gW=gW, gb=gb)
+    np.testing.assert_allclose(gx.cpu().numpy(), gx_ref, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(gW.cpu().numpy(), gW_ref, rtol=1e-4, atol=1e-5)
+    np.testing.assert_allclose(gb.cpu().numpy(), gb_ref, rtol=1e-4, atol=1e-5)
+    K = 128 * 5 * 5
+    hh = rng.standard_normal((B, K)).astype(np.float32); W4 = (0.02 * rng.standard_normal((1, K))).astype(np.float32)
+    y_ref = C.sigmoid(C.linear_fwd(np.maximum(hh, 0), W4, None))
+    yd = ops.linear_fwd(dev(hh), dev(W4), None, act_in=True, act_out=True)
+    np.testing.assert_allclose(yd.cpu().numpy(), y_ref, rtol=1e-5)
+    gy = rng.standard_normal((B, 1)).astype(np.float32)
+    gz = C.sigmoid_bwd(y_ref, gy)
+    gx_ref, gW_ref, _ = C.linear_bwd(np.maximum(hh, 0), W4, gz, False)
+    gW = torch.zeros(1, K, device='cuda')
+    gx = ops.linear_bwd(dev(hh), dev(W4), yd, dev(gy), gW=gW, act_in=True, act_out=True)
+    np.testing.assert_allclose(gx.cpu().numpy(), gx_ref * (hh > 0), rtol=1e-4, atol=1e-6)
+    np.testing.assert_allclose(gW.cpu().numpy(), gW_ref, rtol=1e-4, atol=1e-6)
+
+
+def test_adam_amsgrad_matches_chainer_placement():
+    from loans_amd import ops
+    rng = np.random.RandomState(5)
+    n = 1003
+    p = rng.standard_normal(n).astype(np.float32)
+    pr, m, v, vh = p.copy(), np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    pd, md, vd, vhd = dev(p), torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda')
+    for t in range(1, 5):
+        g = (rng.standard_normal(n) * 10.0 ** rng.uniform(-9, 0, n)).astype(np.float32)
+        C.adam_amsgrad_update(pr, g, m, v, vh, t, alpha=1e-3)
+        ops.adam_amsgrad(pd, dev(g), md, vd, vhd, C.adam_lr(1e-3, .9, .999, t), .9, .999, 1e-8, 1.0, 0.0)
+        np.testing.assert_allclose(pd.cpu().numpy(), pr, rtol=0, atol=2e-7)
+        np.testing.assert_allclose(vhd.cpu().numpy(), vh, rtol=1e-5, atol=1e-30)

@@ -1,0 +1,106 @@
+"""CPU-side checks (no GPU): the C-ABI library exports every symbol include/loans_hip.h
+declares, argument validation rejects bad shapes before any launch, and the host-side
+link tree / parameter layouts / geometry are right."""
+import ctypes
+import os
+import re
+
+import numpy as np
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+@pytest.fixture(scope='module')
+def lib():
+    import __graft_entry__
+    __graft_entry__.build()
+    from loans_amd import _lib
+    return _lib.load()
+
+
+def test_library_exports_every_declared_symbol(lib):
+    header = open(os.path.join(ROOT, 'include', 'loans_hip.h')).read()
+    declared = set(re.findall(r'\b(loans_[a-z0-9_]+)\s*\(', header))
+    assert len(declared) >= 30
+    from loans_amd import _lib
+    for name in sorted(declared):
+        assert hasattr(lib, name), name
+    assert declared - {'loans_hip_version'} == set(_lib.SIGNATURES), 'ctypes table out of sync with the header'
+    assert b'gfx950' in lib.loans_hip_version()
+
+
+def test_argument_validation_without_gpu(lib):
+    from loans_amd._lib import IgemmDesc
+    d = IgemmDesc()
+    # null pointers / zero sizes are rejected with LOANS_EINVAL (-1) before any HIP call
+    assert lib.loans_igemm_f32(0, 0, 0, 0, 0, 0, 0, ctypes.byref(d), 0) == -1
+    assert lib.loans_prep_images_f32(0, 0, 1, 8, 8, 0) == -1
+    assert lib.loans_bn_apply_f32(0, 0, 0, 0, 0, 0, 0, 4, 64, 0, 1, 0) == -1
+    assert lib.loans_adam_amsgrad_f32(0, 0, 0, 0, 0, 16, 1e-3, .9, .999, 1e-8, 1., 0., 1., 0) == -1
+    d.B, d.inH, d.inW, d.Cin, d.outH, d.outW, d.Cout = 1, 8, 8, 6, 8, 8, 64      # Cin not a multiple of 4
+    d.gridH = d.gridW = 8; d.osy = d.osx = d.isy = d.isx = 1; d.ntaps = 9
+    assert lib.loans_igemm_f32(8, 8, 8, 0, 0, 0, 0, ctypes.byref(d), 0) == -1
+    d.Cin = 8; d.B = 1 << 20; d.inH = d.inW = 1 << 10                            # beyond 32-bit indexing
+    assert lib.loans_igemm_f32(8, 8, 8, 0, 0, 0, 0, ctypes.byref(d), 0) == -2
+
+
+def test_conv_geometry_classes():
+    from loans_amd import ops
+    g = ops.ConvGeometry(2, 56, 56, 64, 128, 3, 2, 1)
+    assert (g.Ho, g.Wo) == (28, 28) and g.fwd.ntaps == 9
+    assert sorted(d.ntaps for d, _, _ in g.dgrad) == [1, 2, 2, 4]                # 3x3 / stride 2 parity classes
+    assert g.dgrad_weight_floats == 64 * 9 * 128
+    g = ops.ConvGeometry(2, 75, 75, 128, 128, 4, 2, 1)
+    assert (g.Ho, g.Wo) == (37, 37) and [d.ntaps for d, _, _ in g.dgrad] == [4, 4, 4, 4]
+    g = ops.ConvGeometry(2, 224, 224, 4, 64, 7, 2, 3)
+    assert (g.Ho, g.Wo) == (112, 112) and g.fwd.ntaps == 49
+    # every (input pixel, tap) pair of the forward conv appears exactly once over the dgrad classes
+    g = ops.ConvGeometry(1, 9, 8, 4, 4, 3, 2, 1)
+    pairs = set()
+    for d, tapsel, _ in g.dgrad:
+        for y in range(d.gridH):
+            for t in range(d.ntaps):
+                h = y * d.osy + d.oy0
+                o = y + d.dy[t]
+                r = tapsel[t] // 3
+                if 0 <= o < g.Ho:
+                    assert o * 2 - 1 + r == h
+                    pairs.add((h, o, r))
+    fw = {(o * 2 - 1 + r, o, r) for o in range(g.Ho) for r in range(3) if 0 <= o * 2 - 1 + r < 9}
+    assert {(h, o, r) for (h, o, r) in pairs} == fw
+
+
+def test_link_tree_matches_reference_paths_and_counts():
+    import loans_amd
+    np.random.seed(0)
+    loc = loans_amd.SheepLocalizer((75, 75))
+    keys = [k for k, _ in loc.namedparams()]
+    assert '/feature_extractor/res3/0/conv3/W' in keys and '/res7/1/bn2/beta' in keys
+    logical = {k: p.logical_shape for k, p in loc.namedparams()}
+    n224 = sum(int(np.prod(s)) for k, s in logical.items() if not k.startswith(('/res6', '/res7')))
+    assert n224 == 12592902
+    assert logical['/feature_extractor/conv1/W'] == (64, 3, 7, 7)
+    w = loc.feature_extractor.conv1.W
+    assert w.physical_shape == (64, 7, 7, 4) and not w.host[..., 3].any()
+    np.testing.assert_array_equal(loc.param_predictor.b.host, np.array([0.8, 0, 0, 0, 0.8, 0], np.float32))
+    assert not loc.param_predictor.W.host.any()
+    st = loc.state_dict_chainer()
+    assert st['feature_extractor/bn1/avg_var'].shape == (64,) and st['feature_extractor/conv1/W'].shape == (64, 3, 7, 7)
+    # OIHW <-> OHWI(+pad) round trip
+    a = np.random.standard_normal((64, 3, 7, 7)).astype(np.float32)
+    w.set_logical(a)
+    np.testing.assert_array_equal(w.get_logical(), a)
+    dis = loans_amd.ResnetAssessor()
+    assert [k for k, _ in dis.namedparams()][:3] == ['/r0/c0/W', '/r0/c1/W', '/r0/cs/W']
+
+
+def test_product_never_imports_oracle():
+    bad = []
+    for dirpath, _, files in os.walk(os.path.join(ROOT, 'loans_amd')):
+        for f in files:
+            if f.endswith('.py'):
+                src = open(os.path.join(dirpath, f)).read()
+                if re.search(r'^\s*(from|import)\s+oracle\b', src, re.M) or 'from oracle' in src:
+                    bad.append(os.path.join(dirpath, f))
+    assert not bad, bad
