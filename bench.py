@@ -1,0 +1,172 @@
+#!/usr/bin/env python
+"""bench.py -- LoANs localizer + assessor joint training step on N MI355X of one node.
+
+One "step" = one ``SheepAssessor.update_core`` (reference sheep/sheep_updater.py:26-68):
+assessor forward on the labelled batch, localizer forward, STN crop, assessor forward on the
+crops, localizer-chain backward + Adam-AMSGrad, assessor-chain backward + Adam-AMSGrad.
+
+Workload (BASELINE.json): N=1 -> configs[1] shape, batch 256 x 3 x 224 x 224 fp32 on one GPU
+(the full joint step, a superset of "localizer forward+backward only"); N>1 -> configs[3],
+128 frames per GPU (global 1024 at N=8), gradients all-reduced over RCCL.  Synthetic
+paste-and-crop frames, random-init weights; inputs are resident in HBM before timing.
+
+Prints ONE JSON line (rank 0) with the contract keys plus
+  roofline     : the ResNet-18 conv-forward MFMA roofline, measured live with HIP events
+                 around the 21 forward implicit-GEMM launches of every timed step
+  cpu_baseline : the CPU oracle ("port": NumPy restatement of the Chainer graph) timed on
+                 the host cores on a bounded sample (B=8) of the same workload (N=1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONV_FWD_FLOP_PER_IMAGE_224 = 4166615040        # 21 conv contractions, 2 FLOP per MAC
+FP32_MFMA_PEAK_TFLOPS = 157.3                   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=10)
+    ap.add_argument('--warmup', type=int, default=3)
+    ap.add_argument('--batch', type=int, default=0, help='per-GPU batch (default 256 at N=1, 128 at N>1)')
+    ap.add_argument('--image-size', type=int, default=224)
+    ap.add_argument('--target-size', type=int, default=75)
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--cpu-batch', type=int, default=8)
+    ap.add_argument('--cpu-iters', type=int, default=2)
+    return ap.parse_args()
+
+
+def cpu_baseline(args, hw, crop):
+    """Oracle step timed on the host cores (kind "port")."""
+    from oracle import model as M
+    from loans_amd.datasets import synthetic
+    B = args.cpu_batch
+    rng = np.random.RandomState(0)
+    lp = M.init_localizer_params(rng, predictor_w_std=1e-3)
+    dp = M.init_assessor_params(rng, (crop, crop))
+    frames = synthetic.make_frames(100, B, hw, hw)
+    real, labels = synthetic.make_assessor_batch(101, B, crop, crop)
+    og, od = M.AdamAMSGrad(lp), M.AdamAMSGrad(dp)
+    times = []
+    for i in range(1 + args.cpu_iters):
+        t0 = time.perf_counter()
+        M.update_core(lp, dp, og, od, frames, real, labels, (crop, crop), rng=np.random.RandomState(0))
+        times.append(time.perf_counter() - t0)
+    t = float(np.median(times[1:]))
+    return {"value": round(B / t, 3), "unit": "images/s", "cores": os.cpu_count(), "kind": "port",
+            "sample": "%d joint steps of batch %d x 3 x %d x %d (+%d x 3 x %d x %d crops), NumPy fp32 oracle, "
+                      "median after 1 warm-up" % (args.cpu_iters, B, hw, hw, B, crop, crop),
+            "s_per_step": round(t, 3)}
+
+
+def main():
+    args = parse()
+    import loans_amd
+    from loans_amd import ops, parallel
+    from loans_amd.datasets import synthetic
+    from loans_amd.runtime import training
+
+    comm = parallel.init_from_env()
+    world, rank = comm.size, comm.rank
+    if world != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run' % (args.gpus, world))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+
+    B = args.batch or (256 if world == 1 else 128)
+    hw, crop = args.image_size, args.target_size
+
+    # ---- synthetic inputs, resident in HBM ----
+    pool = 32
+    frames = synthetic.make_frames(1000 + rank, pool, hw, hw)
+    real, labels = synthetic.make_assessor_batch(2000 + rank, pool, crop, crop)
+    reps = (B + pool - 1) // pool
+    frames_d = torch.from_numpy(np.tile(frames, (reps, 1, 1, 1))[:B]).to(dev)
+    real_d = torch.from_numpy(np.tile(real, (reps, 1, 1, 1))[:B]).to(dev)
+    labels_d = torch.from_numpy(np.tile(labels, (reps, 1))[:B]).to(dev)
+
+    # ---- models (random init; param_predictor.W seeded non-zero so the backbone gets gradients) ----
+    np.random.seed(1234)
+    localizer = loans_amd.SheepLocalizer((crop, crop))
+    localizer.param_predictor.W.set_logical((1e-3 * np.random.standard_normal((6, 512))).astype(np.float32))
+    discriminator = loans_amd.ResnetAssessor()
+    with loans_amd.using_config('enable_backprop', False):
+        discriminator(real_d[:2])                     # materialise the lazy l4, build the arenas
+    localizer.finalize(dev)
+    comm.bcast_data(localizer)
+    comm.bcast_data(discriminator)
+
+    opt_gen = parallel.create_multi_node_optimizer(loans_amd.Adam(alpha=1e-3, amsgrad=True).setup(localizer), comm)
+    opt_dis = parallel.create_multi_node_optimizer(loans_amd.Adam(alpha=1e-3, amsgrad=True).setup(discriminator), comm)
+    updater = loans_amd.SheepAssessor(
+        models=[localizer, discriminator],
+        iterator={'main': training.DeviceBatchIterator([frames_d]),
+                  'real': training.DeviceBatchIterator([(real_d, labels_d)])},
+        optimizer={'opt_gen': opt_gen, 'opt_dis': opt_dis},
+        converter=training.identity_converter, device=local_rank, comm=comm)
+
+    for _ in range(args.warmup):
+        updater.update()
+
+    # ---- timed region: exactly K steps between barrier + synchronize ----
+    ops.EVENT_LOG = [] if rank == 0 else None          # HIP events around the conv-forward launches
+    comm.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        updater.update()
+    torch.cuda.synchronize()
+    comm.barrier()
+    elapsed = comm.allreduce_max(time.perf_counter() - t0)
+    log, ops.EVENT_LOG = ops.EVENT_LOG, None
+
+    if rank != 0:
+        return
+    ms_per_step = elapsed / args.steps * 1e3
+    value = B * world * args.steps / elapsed
+
+    # ---- conv-forward roofline from the events of the timed steps ----
+    roofline = None
+    if log:
+        loc = [(tag, flops, s.elapsed_time(e)) for tag, flops, s, e in log if tag == 'fprop_bn']
+        tot_ms = sum(x[2] for x in loc)
+        tot_flop = sum(x[1] for x in loc)
+        n_launch = len(loc)
+        achieved = tot_flop / (tot_ms * 1e-3) / 1e12
+        roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
+                    "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                    "kernel": "igemm_kernel (ResNet-18 conv forward, %d launches/step)" % (n_launch // args.steps),
+                    "avg_launch_ms": round(tot_ms / max(n_launch, 1), 4),
+                    "conv_fwd_ms_per_step": round(tot_ms / args.steps, 3),
+                    "algorithmic_flop_per_step": tot_flop // args.steps}
+        if hw == 224:
+            assert tot_flop // args.steps == B * CONV_FWD_FLOP_PER_IMAGE_224, (tot_flop // args.steps, B)
+
+    out = {
+        "metric": "localizer+assessor train images/sec", "value": round(value, 2), "unit": "images/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "config": {"workload": "LoANs joint step: ResNet-18 localizer + STN crop + assessor, fwd+bwd+2xAdam-AMSGrad",
+                   "per_gpu_batch": B, "global_batch": B * world, "frame": "3x%dx%d" % (hw, hw),
+                   "crop": "3x%dx%d" % (crop, crop), "parallelism": "dp%d" % world,
+                   "baseline_config": "configs[1]" if world == 1 else "configs[3]"},
+        "roofline": roofline,
+    }
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(args, hw, crop)
+    print(json.dumps(out))
+
+
+if __name__ == '__main__':
+    main()

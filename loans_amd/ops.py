@@ -12,6 +12,10 @@ import torch
 from . import _lib
 from ._lib import (F_ADDEND, F_ADDEND_MASK, F_BIAS, F_MASK, F_RELU_IN, F_STATS, IgemmDesc, check)
 
+# When bench.py sets this to a list, conv_fprop brackets each launch with HIP events recorded on the
+# launch stream and appends (tag, algorithmic_flops, start_event, end_event).
+EVENT_LOG = None
+
 BN_EPS = 2e-5          # chainer.links.BatchNormalization default (sheep/resnet.py:44)
 BN_DECAY = 0.9
 # Chainer 4.1.0's CPU path folds eps into the running variance (see oracle/chainer_ops.py)
@@ -109,8 +113,18 @@ def conv_fprop(x, w, geo, out=None, bias=None, stats=None, relu_in=False, addend
             (F_STATS if stats is not None else 0) | (F_ADDEND if addend is not None else 0)
     d = _with_flags(geo.fwd, flags, tile)
     assert x.numel() == geo.B * geo.H * geo.W * geo.Cin and w.numel() == geo.Cout * geo.k * geo.k * geo.Cin
+    log = EVENT_LOG
+    if log is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
     check(lib.loans_igemm_f32(_ptr(x), _ptr(w), _ptr(out), _ptr(bias), _ptr(stats), 0, _ptr(addend),
                               C.byref(d), _stream()), 'loans_igemm_f32[fprop]')
+    if log is not None:
+        ev1.record()
+        # algorithmic FLOPs: logical input channels (3 for the RGB stem), no padding, no im2col redundancy
+        cin = 3 if geo.Cin == 4 else geo.Cin
+        log.append(('fprop_bn' if stats is not None else 'fprop', 2 * geo.B * geo.Ho * geo.Wo * geo.Cout * geo.k * geo.k * cin,
+                    ev0, ev1))
     return out
 
 

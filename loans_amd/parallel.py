@@ -1,0 +1,78 @@
+"""Data-parallel training over the GPUs of one node: one process per GPU,
+``torch.distributed`` with the ``nccl`` backend (= RCCL over xGMI on ROCm).
+
+The reference's LoANs trainer is single-GPU (train_sheep_localizer.py:59); its only
+data-parallel call site is Chainer's ``MultiprocessParallelUpdater`` in the SSD
+sub-project (schaaaafrichter/train.py:159-191: reduce-to-root + update + broadcast, local
+BN statistics).  MI355X-first design instead: every rank holds the same parameters, all
+gradients of a model live in ONE flat arena, and each optimiser step is
+  all-reduce(sum) of that arena in a few large buckets  ->  identical fused Adam on every rank
+(no parameter broadcast after the initial one).  xGMI is a point-to-point mesh, so few large
+collectives beat many small ones; the 1/world_size factor is folded into the Adam kernel.
+BN statistics stay local to each shard, like the reference's DP.
+"""
+import os
+
+import torch
+import torch.distributed as dist
+
+BUCKET_FLOATS = 16 * 1024 * 1024      # 64 MiB buckets: the localizer's active gradients are one bucket
+
+
+class Communicator:
+    def __init__(self, group=None):
+        self.group = group
+        self.size = dist.get_world_size(group) if dist.is_initialized() else 1
+        self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+
+    def bcast_data(self, link):
+        """Rank 0's parameters and persistents to everyone (once, after construction)."""
+        if self.size == 1:
+            return
+        arena = link.arena or link.finalize()
+        dist.broadcast(arena.data, src=0, group=self.group)
+        for _, l, n in link.namedpersistents():
+            v = getattr(l, n)
+            if torch.is_tensor(v):
+                dist.broadcast(v, src=0, group=self.group)
+
+    def allreduce_grad(self, arena):
+        """Sum the gradient arena over all ranks, in place, in large buckets."""
+        if self.size == 1:
+            return
+        g = arena.grad[:getattr(arena, 'active_numel', arena.numel)]
+        n = g.numel()
+        for lo in range(0, n, BUCKET_FLOATS):
+            dist.all_reduce(g[lo:min(lo + BUCKET_FLOATS, n)], op=dist.ReduceOp.SUM, group=self.group)
+
+    def allreduce_max(self, value):
+        t = torch.tensor([value], dtype=torch.float64, device='cuda' if torch.cuda.is_available() else 'cpu')
+        if self.size > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
+        return float(t.item())
+
+    def barrier(self):
+        if self.size > 1:
+            dist.barrier(group=self.group)
+
+
+def init_from_env(backend=None):
+    """Join the process group torchrun described (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)."""
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world == 1:
+        return Communicator() if not dist.is_initialized() else Communicator()
+    local_rank = int(os.environ.get('LOCAL_RANK', os.environ.get('RANK', '0')))
+    if backend is None:
+        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
+    if backend == 'nccl':
+        torch.cuda.set_device(local_rank)
+    os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+    if not dist.is_initialized():
+        dist.init_process_group(backend=backend)
+    return Communicator()
+
+
+def create_multi_node_optimizer(optimizer, comm):
+    """Attach a communicator to an optimiser (ChainerMN's name for the same thing)."""
+    optimizer.comm = comm
+    return optimizer

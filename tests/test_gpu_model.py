@@ -32,12 +32,13 @@ def test_localizer_assessor_forward_parity(shape):
     B, H, W, crop = shape
     loc, dis = build_pair(0, crop)
     frames, real, labels = inputs(1, B, H, W, crop)
+    with loans_amd.using_config('enable_backprop', False):
+        y_real = dis(dev(real))                       # also materialises the lazy l4
+    lp, dp = oracle_params(loc, np.float32), oracle_params(dis, np.float32)   # before BN running stats move
     rois, points = loc(dev(frames))
     y_fake = dis(rois)
-    y_real = dis(dev(real))
     assert tuple(rois.shape) == (B, 3) + crop and tuple(points.shape) == (B, 2) + crop
 
-    lp, dp = oracle_params(loc, np.float32), oracle_params(dis, np.float32)
     oloc = M.Localizer(lp, crop, train=True, rng=np.random.RandomState(0))
     o_rois, o_points = oloc.forward(frames)
     o_yfake = M.Assessor(dp).forward(o_rois)
