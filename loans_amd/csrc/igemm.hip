@@ -17,11 +17,29 @@
 //   register-staged double buffering: global loads of chunk c+1 are issued before the 64
 //   MFMAs of chunk c and written to the other LDS buffer after them (one barrier per chunk).
 #include "common.h"
+#include <stdlib.h>
+
+#ifdef LOANS_STAMPS
+// Diagnostic build only (tools/stamp_build.sh): per-wave cycle sums of the K-loop phases of the
+// first 64 blocks, written to a buffer of their own.  Never part of libloans_hip.so.
+__device__ unsigned long long g_stamps[64 * 4 * 8];
+#define STAMP(t)                                                                         \
+    do {                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");       \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+    } while (0)
+#else
+#define STAMP(t) do { } while (0)
+#endif
 
 namespace {
 
 constexpr int BK = 32;
 constexpr int LDK = BK + 4;
+#ifndef PRIO_AUX
+#define PRIO_AUX 3
+#endif
 
 struct IgemmArgs {
     const float* in;
@@ -33,6 +51,8 @@ struct IgemmArgs {
     const float* addend;
     loans_igemm_desc d;
     int M, Ktot, nchunks, tiles_m, tiles_n;
+    unsigned in_bytes, w_bytes, out_bytes;
+    int sep_nx;     // > 0: taps are an (ntaps / sep_nx) x sep_nx grid, dy constant per row, dx per column
 };
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -43,15 +63,23 @@ __device__ __forceinline__ int xcd_remap(int id, int nblk) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
 }
 
-template <int BM, int BN, int WM, int WN>
+// sched_group_barrier masks (LLVM SchedGroupMask)
+#define SG_VALU 0x2
+#define SG_MFMA 0x8
+#define SG_VMEM_READ 0x20
+#define SG_DS_READ 0x100
+#define SG_DS_WRITE 0x200
+
+template <int BM, int BN, int WM, int WN, bool RELU>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int RA = BM / 32, RB = BN / 32;
+    constexpr int NMMA = TM * TN * 4;          // MFMAs per 8-deep k group
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* As = reinterpret_cast<float*>(smem);        // [2][BM][LDK]
     float* Bs = As + 2 * BM * LDK;                     // [2][BN][LDK]
     int* taps = reinterpret_cast<int*>(Bs + 2 * BN * LDK);
-    int* opix = taps + LOANS_MAX_TAPS;                 // [BM] output pixel index, -1 = invalid row
+    unsigned* opix = reinterpret_cast<unsigned*>(taps + LOANS_MAX_TAPS);   // [BM] output row byte offset, ~0u = no row
 
     const loans_igemm_desc& d = a.d;
     const int tid = threadIdx.x;
@@ -59,83 +87,134 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     const int tn = logical % a.tiles_n;
     const int tm = logical / a.tiles_n;
     const int lu = tid & 7, lrow = tid >> 3;
-    const bool relu_in = d.flags & LOANS_F_RELU_IN;
-
+    // tap table in LDS: byte offset of tap t relative to the row's base pixel
     if (tid < LOANS_MAX_TAPS) {
         const int t = tid < d.ntaps ? tid : 0;
-        taps[tid] = (int(d.dy[t]) << 16) | (int(d.dx[t]) & 0xffff);
+        taps[tid] = (int(d.dy[t]) * d.inW + int(d.dx[t])) * d.Cin * 4;
     }
 
-    int rowbase[RA], iy0[RA], ix0[RA];
+    // per row (fixed for the whole K loop): byte offset of its base pixel and a bitmask with bit t SET
+    // when tap t must read zero (outside the image, beyond ntaps, or the row does not exist)
+    unsigned rowoff[RA];
+    unsigned long long badmask[RA];
     {
         const int gHW = d.gridH * d.gridW;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             const int m = tm * BM + lrow + 32 * i;
-            int pix = -1;
+            unsigned pixoff = 0xFFFFFFFFu;
+            unsigned long long mask = 0;
+            rowoff[i] = 0;
             if (m < a.M) {
                 const int b = m / gHW;
                 const int rem = m - b * gHW;
                 const int y = rem / d.gridW;
                 const int x = rem - y * d.gridW;
-                iy0[i] = y * d.isy;
-                ix0[i] = x * d.isx;
-                rowbase[i] = ((b * d.inH + iy0[i]) * d.inW + ix0[i]) * d.Cin;
-                pix = (b * d.outH + y * d.osy + d.oy0) * d.outW + x * d.osx + d.ox0;
-            } else {
-                iy0[i] = -(1 << 20);
-                ix0[i] = -(1 << 20);
-                rowbase[i] = 0;
+                const int iy0 = y * d.isy, ix0 = x * d.isx;
+                rowoff[i] = (unsigned)(((b * d.inH + iy0) * d.inW + ix0) * d.Cin) * 4u;
+                pixoff = (unsigned)((b * d.outH + y * d.osy + d.oy0) * d.outW + x * d.osx + d.ox0) * (unsigned)d.Cout * 4u;
+                if (a.sep_nx > 0) {      // taps form an ny x nx grid (every conv here): O(ny + nx)
+                    unsigned colbits = 0;
+                    for (int s = 0; s < a.sep_nx; ++s)
+                        if ((unsigned)(ix0 + d.dx[s]) < (unsigned)d.inW) colbits |= 1u << s;
+                    for (int t = 0; t < d.ntaps; t += a.sep_nx)
+                        if ((unsigned)(iy0 + d.dy[t]) < (unsigned)d.inH) mask |= (unsigned long long)colbits << t;
+                } else {
+                    for (int t = 0; t < d.ntaps; ++t) {
+                        const int iy = iy0 + d.dy[t], ix = ix0 + d.dx[t];
+                        if ((unsigned)iy < (unsigned)d.inH && (unsigned)ix < (unsigned)d.inW) mask |= 1ull << t;
+                    }
+                }
             }
-            if (lu == 0) opix[lrow + 32 * i] = pix;
+            badmask[i] = ~mask;
+            if (lu == 0) opix[lrow + 32 * i] = pixoff;
         }
     }
     __syncthreads();
 
+    // bounds-checked buffer descriptors: an offset beyond num_records loads zeros / drops the store, so
+    // padding, ragged tiles and K tails need no branches: invalid accesses get offset 0xFFFFFFFF
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.in), 0, (int)a.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.w), 0, (int)a.w_bytes, 0x00020000);
+
     const int cpt = d.Cin >> 2;   // float4 units per tap
+    int u = lu;                   // this thread's K unit in the chunk being loaded
     int tap = lu / cpt, c4 = lu - tap * cpt;
-    const int nbase = tn * BN + lrow;
+    unsigned woff[RB], wbad[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const int n = tn * BN + lrow + 32 * i;
+        wbad[i] = n < d.Cout ? 0u : 0xFFFFFFFFu;
+        woff[i] = n < d.Cout ? (unsigned)n * (unsigned)a.Ktot * 4u : 0u;
+    }
+    unsigned toff = (unsigned)taps[min(tap, LOANS_MAX_TAPS - 1)] + (unsigned)c4 * 16u;   // prefetched one chunk ahead
 
     f32x4 ra[RA], rb[RB];
-    auto load_chunk = [&](int c) {
-        const bool tv = tap < d.ntaps;
-        const int tp = taps[tv ? tap : 0];
-        const int dy = tp >> 16, dx = (int)(short)(tp & 0xffff);
-        const int toff = (dy * d.inW + dx) * d.Cin + c4 * 4;
-#pragma unroll
-        for (int i = 0; i < RA; ++i) {
-            const int iy = iy0[i] + dy, ix = ix0[i] + dx;
-            const bool ok = tv && (unsigned)iy < (unsigned)d.inH && (unsigned)ix < (unsigned)d.inW;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (ok) v = ld4(a.in + (int64_t)(rowbase[i] + toff));
-            if (relu_in) {
-                v.x = fmaxf(v.x, 0.f); v.y = fmaxf(v.y, 0.f); v.z = fmaxf(v.z, 0.f); v.w = fmaxf(v.w, 0.f);
-            }
-            ra[i] = v;
+    // The loader is cut into RA + RB + 1 independent pieces (one buffer load each, then the advance) so
+    // that the K loop can drop one piece behind each MFMA of group 0: no waits, no branches.
+    auto load_a = [&](int i) {
+        const int tc = min(tap, LOANS_MAX_TAPS - 1);
+        const unsigned kbad = (unsigned)(u * 4 < a.Ktot) - 1u;
+        const unsigned bad = 0u - ((unsigned)(badmask[i] >> tc) & 1u);
+        const unsigned off = (rowoff[i] + toff) | bad | kbad;
+        ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)off, 0, 0));
+    };
+    auto load_b = [&](int i) {
+        const unsigned kbad = (unsigned)(u * 4 < a.Ktot) - 1u;
+        const unsigned off = (woff[i] + (unsigned)u * 16u) | wbad[i] | kbad;
+        rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)off, 0, 0));
+    };
+    auto advance = [&]() {      // to the following chunk (8 units further along K); prefetch its tap offset
+        u += 8;
+        if (cpt >= 8) {
+            c4 += 8;
+            const int wrap = c4 >= cpt;
+            c4 -= wrap ? cpt : 0;
+            tap += wrap;
+        } else {
+            tap = u / cpt;
+            c4 = u - tap * cpt;
         }
-        const int kidx = (c * 8 + lu) * 4;
+        toff = (unsigned)taps[min(tap, LOANS_MAX_TAPS - 1)] + (unsigned)c4 * 16u;
+    };
+    auto load_chunk = [&]() {
 #pragma unroll
-        for (int i = 0; i < RB; ++i) {
-            const int n = nbase + 32 * i;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (n < d.Cout && kidx < a.Ktot) v = ld4(a.w + (int64_t)n * a.Ktot + kidx);
-            rb[i] = v;
+        for (int i = 0; i < RA; ++i) load_a(i);
+#pragma unroll
+        for (int i = 0; i < RB; ++i) load_b(i);
+        advance();
+    };
+    auto store_a = [&](int buf, int i) {
+        if (RELU) {
+            ra[i].x = fmaxf(ra[i].x, 0.f); ra[i].y = fmaxf(ra[i].y, 0.f);
+            ra[i].z = fmaxf(ra[i].z, 0.f); ra[i].w = fmaxf(ra[i].w, 0.f);
         }
-        // advance (tap, c4) by one chunk = 8 units
-        c4 += 8;
-        while (c4 >= cpt) { c4 -= cpt; ++tap; }
+        *reinterpret_cast<f32x4*>(As + buf * BM * LDK + (lrow + 32 * i) * LDK + lu * 4) = ra[i];
+    };
+    auto store_b = [&](int buf, int i) {
+        *reinterpret_cast<f32x4*>(Bs + buf * BN * LDK + (lrow + 32 * i) * LDK + lu * 4) = rb[i];
     };
     auto store_chunk = [&](int buf) {
-        float* Ab = As + buf * BM * LDK;
-        float* Bb = Bs + buf * BN * LDK;
 #pragma unroll
-        for (int i = 0; i < RA; ++i) *reinterpret_cast<f32x4*>(Ab + (lrow + 32 * i) * LDK + lu * 4) = ra[i];
+        for (int i = 0; i < RA; ++i) store_a(buf, i);
 #pragma unroll
-        for (int i = 0; i < RB; ++i) *reinterpret_cast<f32x4*>(Bb + (lrow + 32 * i) * LDK + lu * 4) = rb[i];
+        for (int i = 0; i < RB; ++i) store_b(buf, i);
     };
 
     const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
+    const int fragA = (wm * TM * 32 + r) * LDK + h * 4;
+    const int fragB = (wn * TN * 32 + r) * LDK + h * 4;
+    auto read_frag = [&](int buf, int g, f32x4 (&af)[TM], f32x4 (&bf)[TN]) {
+        const float* Ab = As + buf * BM * LDK + fragA + g * 8;
+        const float* Bb = Bs + buf * BN * LDK + fragB + g * 8;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK);
+    };
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -144,75 +223,174 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    // MFMA number s (0 .. NMMA-1) of a k group
+    auto mma_one = [&](int s, const f32x4 (&af)[TM], const f32x4 (&bf)[TN]) {
+        const int kk = s / (TM * TN), i = (s / TN) % TM, j = s % TN;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
+    };
+    auto mma = [&](const f32x4 (&af)[TM], const f32x4 (&bf)[TN]) {
+#pragma unroll
+        for (int s = 0; s < NMMA; ++s) mma_one(s, af, bf);
+    };
 
-    load_chunk(0);
+    // ---- software-pipelined K loop ---------------------------------------------------------------
+    // A chunk (32 of K) = 4 groups of 8; fragments of group g+1 are read from LDS while the MFMAs of
+    // group g run; the loader pieces of chunk c+1 ride one behind each MFMA of group 0, their LDS
+    // writes one behind each MFMA of group 2 (order pinned with sched_barrier: a wave issues in order,
+    // and anything queued between two of its own MFMAs is free), and group 3's MFMAs (operands already
+    // in registers) run after the barrier so that they cover its skew and the next chunk's first reads.
+    constexpr int NPIECE = RA + RB + 1;                       // loader pieces (last = advance)
+    constexpr int PPG = (NPIECE + NMMA - 1) / NMMA;           // pieces per MFMA gap
+    auto load_piece = [&](int p) {
+        if (p < RA) load_a(p);
+        else if (p < RA + RB) load_b(p - RA);
+        else if (p == RA + RB) advance();
+    };
+    auto store_piece = [&](int buf, int p) {
+        if (p < RA) store_a(buf, p);
+        else if (p < RA + RB) store_b(buf, p - RA);
+    };
+    f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+    load_chunk();
     store_chunk(0);
     __syncthreads();
+    read_frag(0, 0, fa0, fb0);
 
-    for (int c = 0; c < a.nchunks; ++c) {
+#ifdef LOANS_STAMPS
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, s_load = 0, s_mfma = 0, s_store = 0, s_bar = 0, t_begin = 0;
+    STAMP(t_begin);
+#endif
+    int c = 0;
+    for (; c + 1 < a.nchunks; ++c) {
         const int buf = c & 1;
-        const bool more = (c + 1) < a.nchunks;
-        if (more) load_chunk(c + 1);
-        const float* Ab = As + buf * BM * LDK + (wm * TM * 32 + r) * LDK + h * 4;
-        const float* Bb = Bs + buf * BN * LDK + (wn * TN * 32 + r) * LDK + h * 4;
+        STAMP(t0);
+        // group 0 (+ loader)
+        read_frag(buf, 1, fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-        for (int g = 0; g < 4; ++g) {
-            f32x4 af[TM], bf[TN];
+        for (int s = 0; s < NMMA; ++s) {
+            mma_one(s, fa0, fb0);
 #pragma unroll
-            for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK + g * 8);
-#pragma unroll
-            for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK + g * 8);
-#pragma unroll
-            for (int kk = 0; kk < 4; ++kk)
-#pragma unroll
-                for (int i = 0; i < TM; ++i)
-#pragma unroll
-                    for (int j = 0; j < TN; ++j)
-                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
+            for (int p = s * PPG; p < (s + 1) * PPG; ++p) load_piece(p);
+            __builtin_amdgcn_sched_barrier(0);
         }
-        if (more) store_chunk(buf ^ 1);
+        STAMP(t1);
+        // group 1
+        read_frag(buf, 2, fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        // group 2 (+ LDS writes of the staged chunk into the other buffer)
+        read_frag(buf, 3, fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < NMMA; ++s) {
+            mma_one(s, fa0, fb0);
+#pragma unroll
+            for (int p = s * PPG; p < (s + 1) * PPG; ++p) store_piece(buf ^ 1, p);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        STAMP(t2);
+        // group 3 runs behind the barrier with operands that are already in registers
         __syncthreads();
+        STAMP(t3);
+        read_frag(buf ^ 1, 0, fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        STAMP(t4);
+#ifdef LOANS_STAMPS
+        s_load += t1 - t0; s_mfma += t2 - t1; s_store += t3 - t2; s_bar += t4 - t3;
+#endif
     }
+    {   // last chunk: nothing left to stage
+        const int buf = c & 1;
+        read_frag(buf, 1, fa1, fb1);
+        mma(fa0, fb0);
+        read_frag(buf, 2, fa0, fb0);
+        mma(fa1, fb1);
+        read_frag(buf, 3, fa1, fb1);
+        mma(fa0, fb0);
+        mma(fa1, fb1);
+    }
+#ifdef LOANS_STAMPS
+    unsigned long long t_loop_end = 0;
+    STAMP(t_loop_end);
+#endif
 
-    // ---- epilogue ----
+    // ---- epilogue: bounds-checked buffer stores, row offsets read once from LDS ----------------------
     const bool f_bias = d.flags & LOANS_F_BIAS, f_stats = d.flags & LOANS_F_STATS;
     const bool f_mask = d.flags & LOANS_F_MASK, f_add = d.flags & LOANS_F_ADDEND;
     const bool f_addmask = d.flags & LOANS_F_ADDEND_MASK;
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)a.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_ref = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.ref ? a.ref : a.out), 0, (int)a.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_add = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<float*>(a.addend ? a.addend : a.out), 0, (int)a.out_bytes, 0x00020000);
+    typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+    u32x4 prow[TM][4];            // byte offsets of this lane's 16 rows per MFMA tile (~0u = no such row)
+    int nvalid = 0;
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            prow[i][q] = *reinterpret_cast<const u32x4*>(opix + wm * TM * 32 + i * 32 + 8 * q + 4 * h);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) nvalid += prow[i][q][e] != 0xFFFFFFFFu;
+        }
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
         const int col = tn * BN + wn * TN * 32 + j * 32 + r;
         const bool cok = col < d.Cout;
+        const unsigned cbad = cok ? 0u : 0xFFFFFFFFu;
+        const unsigned coff = cok ? (unsigned)col * 4u : 0u;
         const float bv = (f_bias && cok) ? a.bias[col] : 0.f;
-        float s = 0.f, q = 0.f;
+        float s = 0.f, q2 = 0.f;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int rl = wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                const int pix = opix[rl];
-                if (pix >= 0 && cok) {
-                    float v = acc[i][j][e] + bv;
-                    s += v;
-                    q += v * v;
-                    const int64_t off = (int64_t)pix * d.Cout + col;
-                    if (f_mask) v = a.ref[off] > 0.f ? v : 0.f;
+                const unsigned po = prow[i][e >> 2][e & 3];
+                const unsigned off = (po + coff) | (po == 0xFFFFFFFFu ? 0xFFFFFFFFu : 0u) | cbad;
+                const float raw = acc[i][j][e];       // rows that do not exist gathered zeros: raw == 0
+                s += raw;
+                q2 += raw * raw;
+                float v = raw + bv;
+                if (f_mask || f_addmask) {
+                    const float rf = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_ref, (int)off, 0, 0));
+                    if (f_mask) v = rf > 0.f ? v : 0.f;
                     if (f_add) {
-                        const float ad = a.addend[off];
-                        v += (!f_addmask || a.ref[off] > 0.f) ? ad : 0.f;
+                        const float ad = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_add, (int)off, 0, 0));
+                        v += (!f_addmask || rf > 0.f) ? ad : 0.f;
                     }
-                    a.out[off] = v;
+                } else if (f_add) {
+                    v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_add, (int)off, 0, 0));
                 }
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_out, (int)off, 0, 0);
             }
         }
         if (f_stats) {
+            // statistics of (raw + bias) over the rows that exist, from the raw sums
+            const float cnt = (float)nvalid;
+            q2 = q2 + 2.f * bv * s + cnt * bv * bv;
+            s = s + cnt * bv;
             s += __shfl_xor(s, 32, 64);
-            q += __shfl_xor(q, 32, 64);
+            q2 += __shfl_xor(q2, 32, 64);
             if (h == 0 && cok) {
                 atomic_add_f64(a.stats + col, (double)s);
-                atomic_add_f64(a.stats + d.Cout + col, (double)q);
+                atomic_add_f64(a.stats + d.Cout + col, (double)q2);
             }
         }
     }
+#ifdef LOANS_STAMPS
+    unsigned long long t_end = 0;
+    STAMP(t_end);
+    if (logical < 64 && lane == 0) {
+        unsigned long long* o = g_stamps + (logical * 4 + wave) * 8;
+        o[0] = s_load; o[1] = s_mfma; o[2] = s_store; o[3] = s_bar;
+        o[4] = t_loop_end - t_begin; o[5] = t_end - t_loop_end; o[6] = a.nchunks; o[7] = t_begin;
+    }
+#endif
 }
 
 template <int BM, int BN>
@@ -220,11 +398,17 @@ constexpr size_t igemm_lds_bytes() {
     return (size_t)(2 * BM * LDK + 2 * BN * LDK) * 4 + LOANS_MAX_TAPS * 4 + BM * 4;
 }
 
-template <int BM, int BN, int WM, int WN>
-int launch_igemm(IgemmArgs& a, hipStream_t st) {
+template <int BM, int BN, int WM, int WN, bool RELU>
+int launch_igemm_r(IgemmArgs& a, hipStream_t st) {
     static bool attr_set = false;
+#ifdef LOANS_STAMPS
+    // diagnostic: LOANS_DBG_LDS=<bytes> pads the LDS request to force fewer blocks per CU
+    const char* dbg_lds = getenv("LOANS_DBG_LDS");
+    const size_t lds = dbg_lds ? (size_t)atol(dbg_lds) : igemm_lds_bytes<BM, BN>();
+#else
     constexpr size_t lds = igemm_lds_bytes<BM, BN>();
-    auto kern = igemm_kernel<BM, BN, WM, WN>;
+#endif
+    auto kern = igemm_kernel<BM, BN, WM, WN, RELU>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -237,6 +421,22 @@ int launch_igemm(IgemmArgs& a, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, st, a);
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;
+}
+
+// number of columns if the tap list is a row-major (dy) x (dx) grid, else 0
+int separable_nx(const loans_igemm_desc* d) {
+    int nx = 1;
+    while (nx < d->ntaps && d->dy[nx] == d->dy[0]) ++nx;
+    if (d->ntaps % nx) return 0;
+    for (int t = 0; t < d->ntaps; ++t)
+        if (d->dy[t] != d->dy[(t / nx) * nx] || d->dx[t] != d->dx[t % nx]) return 0;
+    return nx;
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_igemm(IgemmArgs& a, hipStream_t st) {
+    return (a.d.flags & LOANS_F_RELU_IN) ? launch_igemm_r<BM, BN, WM, WN, true>(a, st)
+                                         : launch_igemm_r<BM, BN, WM, WN, false>(a, st);
 }
 
 int check_desc(const loans_igemm_desc* d) {
@@ -274,6 +474,15 @@ extern "C" int loans_igemm_f32(const float* in, const float* w, float* out, cons
     a.M = d->B * d->gridH * d->gridW;
     a.Ktot = d->ntaps * d->Cin;
     a.nchunks = (a.Ktot + BK - 1) / BK;
+    {
+        const int64_t ib = (int64_t)d->B * d->inH * d->inW * d->Cin * 4, wb = (int64_t)d->Cout * a.Ktot * 4;
+        const int64_t ob = (int64_t)d->B * d->outH * d->outW * d->Cout * 4;
+        if (ib >= 0xFFFFFFF0ll || wb >= 0xFFFFFFF0ll || ob >= 0xFFFFFFF0ll) return LOANS_ERANGE;   // 32-bit buffer offsets
+        a.in_bytes = (unsigned)ib;
+        a.w_bytes = (unsigned)wb;
+        a.out_bytes = (unsigned)ob;
+    }
+    a.sep_nx = separable_nx(d);
     hipStream_t st = as_stream(stream);
     int tile = d->tile;
     if (tile == 0) {
@@ -309,6 +518,7 @@ struct WgradArgs {
     float* dw;
     loans_igemm_desc d;
     int M, Ktot, tiles_co, tiles_j, splits, chunks_per_split;
+    unsigned x_bytes, gy_bytes;
 };
 
 template <int BT>   // square BT x BT block tile, 4 waves as 2 x 2
@@ -339,41 +549,62 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     const bool xtv = xtap < d.ntaps;
     const int dy = xtv ? (int)d.dy[xtap] : 0;
     const int dx = xtv ? (int)d.dx[xtap] : 0;
-    const int toff = (dy * d.inW + dx) * d.Cin + xc4 * 4;
     const int yco = tco * BT + unit * 4;
     const bool yv = yco < d.Cout;        // Cout is a multiple of 4 for every layer on this path
-
-    const int gHW = d.gridH * d.gridW;
     const bool relu_in = d.flags & LOANS_F_RELU_IN;
+
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gy), 0, (int)a.gy_bytes, 0x00020000);
+
     const int c_begin = split * a.chunks_per_split;
     int c_end = c_begin + a.chunks_per_split;
     const int total_chunks = (a.M + 31) / 32;
     if (c_end > total_chunks) c_end = total_chunks;
 
-    f32x4 ry[NP], rx[NP];
-    auto load_chunk = [&](int c) {
+    // (b, y, x) of this thread's NP rows, advanced by 32 pixels per chunk without divisions
+    int pb[NP], py[NP], px[NP];
+    {
+        const int gHW = d.gridH * d.gridW;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-            const int m = c * 32 + prow + RPP * p;
-            f32x4 vy = {0.f, 0.f, 0.f, 0.f}, vx = {0.f, 0.f, 0.f, 0.f};
-            if (m < a.M) {
-                const int b = m / gHW;
-                const int rem = m - b * gHW;
-                const int y = rem / d.gridW;
-                const int x = rem - y * d.gridW;
-                if (yv) {
-                    const int pix = (b * d.outH + y * d.osy + d.oy0) * d.outW + x * d.osx + d.ox0;
-                    vy = ld4(a.gy + (int64_t)pix * d.Cout + yco);
-                }
-                const int iy = y * d.isy + dy, ix = x * d.isx + dx;
-                if (xtv && (unsigned)iy < (unsigned)d.inH && (unsigned)ix < (unsigned)d.inW)
-                    vx = ld4(a.x + (int64_t)(((b * d.inH + y * d.isy) * d.inW + x * d.isx) * d.Cin + toff));
-                if (relu_in) {
-                    vx.x = fmaxf(vx.x, 0.f); vx.y = fmaxf(vx.y, 0.f); vx.z = fmaxf(vx.z, 0.f); vx.w = fmaxf(vx.w, 0.f);
-                }
+            const int m = c_begin * 32 + prow + RPP * p;
+            pb[p] = m / gHW;
+            const int rem = m - pb[p] * gHW;
+            py[p] = rem / d.gridW;
+            px[p] = rem - py[p] * d.gridW;
+        }
+    }
+    const float inv_gw = 1.f / (float)d.gridW, inv_gh = 1.f / (float)d.gridH;
+
+    f32x4 ry[NP], rx[NP];
+    auto load_chunk = [&]() {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int b = pb[p], y = py[p], x = px[p];
+            const bool rv = b < d.B;
+            const int pix = (b * d.outH + y * d.osy + d.oy0) * d.outW + x * d.osx + d.ox0;
+            const unsigned goff = ((unsigned)(pix * d.Cout + yco) * 4u) | ((unsigned)(rv & yv) - 1u);
+            ry[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_g, (int)goff, 0, 0));
+            const int iy = y * d.isy + dy, ix = x * d.isx + dx;
+            const unsigned ok = (unsigned)(rv & xtv) & (unsigned)((unsigned)iy < (unsigned)d.inH) &
+                                (unsigned)((unsigned)ix < (unsigned)d.inW);
+            const unsigned xoff = ((unsigned)(((b * d.inH + iy) * d.inW + ix) * d.Cin + xc4 * 4) * 4u) | (ok - 1u);
+            rx[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)xoff, 0, 0));
+            // advance 32 pixels: exact floor((v + .5) / n) for the small integers involved
+            int nx = x + 32;
+            const int qx = (int)(((float)nx + 0.5f) * inv_gw);
+            nx -= qx * d.gridW;
+            int ny = y + qx;
+            const int qy = (int)(((float)ny + 0.5f) * inv_gh);
+            ny -= qy * d.gridH;
+            px[p] = nx; py[p] = ny; pb[p] = b + qy;
+        }
+        if (relu_in) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) {
+                rx[p].x = fmaxf(rx[p].x, 0.f); rx[p].y = fmaxf(rx[p].y, 0.f);
+                rx[p].z = fmaxf(rx[p].z, 0.f); rx[p].w = fmaxf(rx[p].w, 0.f);
             }
-            ry[p] = vy;
-            rx[p] = vx;
         }
     };
     auto store_chunk = [&](int buf) {
@@ -396,14 +627,14 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
     if (c_begin < c_end) {
-        load_chunk(c_begin);
+        load_chunk();
         store_chunk(0);
     }
     __syncthreads();
     for (int c = c_begin; c < c_end; ++c) {
         const int buf = (c - c_begin) & 1;
         const bool more = (c + 1) < c_end;
-        if (more) load_chunk(c + 1);
+        if (more) load_chunk();
         const float* Yb = Ys + buf * 32 * BT + wm * T * 32 + r;
         const float* Xb = Xs + buf * 32 * BT + wn * T * 32 + r;
 #pragma unroll
@@ -503,6 +734,12 @@ extern "C" int loans_wgrad_f32(const float* x, const float* gy, float* dw, const
     a.x = x; a.gy = gy; a.dw = dw; a.d = *d;
     a.M = d->B * d->gridH * d->gridW;
     a.Ktot = d->ntaps * d->Cin;
+    {
+        const int64_t xb = (int64_t)d->B * d->inH * d->inW * d->Cin * 4, gb = (int64_t)d->B * d->outH * d->outW * d->Cout * 4;
+        if (xb >= 0xFFFFFFF0ll || gb >= 0xFFFFFFF0ll) return LOANS_ERANGE;
+        a.x_bytes = (unsigned)xb;
+        a.gy_bytes = (unsigned)gb;
+    }
     hipStream_t st = as_stream(stream);
     const bool small = (d->Cout <= 64) || (a.Ktot <= 64);
     int tile = d->tile;
@@ -527,3 +764,9 @@ extern "C" int loans_repack_dgrad_f32(const float* src, float* dst, int32_t Cout
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;
 }
+
+#ifdef LOANS_STAMPS
+extern "C" int loans_debug_read_stamps(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps), sizeof(unsigned long long) * n);
+}
+#endif

@@ -151,10 +151,10 @@ def conv_dgrad(gy, w, geo, out=None, mask_ref=None, addend=None, addend_mask_ref
     return out
 
 
-def conv_wgrad(x, gy, dw, geo, relu_in=False, splits=0):
+def conv_wgrad(x, gy, dw, geo, relu_in=False, splits=0, tile=0):
     """dw[Cout,k,k,Cin] += sum over pixels (atomic accumulate into the gradient arena)."""
     lib = _lib.load()
-    d = _with_flags(geo.fwd, F_RELU_IN if relu_in else 0, 0)
+    d = _with_flags(geo.fwd, F_RELU_IN if relu_in else 0, tile)
     assert dw.numel() == geo.Cout * geo.k * geo.k * geo.Cin
     check(lib.loans_wgrad_f32(_ptr(x), _ptr(gy), _ptr(dw), C.byref(d), splits, _stream()), 'loans_wgrad_f32')
 

@@ -80,14 +80,12 @@ def test_conv_fprop_dgrad_wgrad(case, tile):
         assert rel_err(_nchw(gx3, Cin), gx_ref + addx * (ref_t > 0)) < 2e-6
     if tile in (0, 1, 3):
         dw = torch.zeros_like(wd)
-        geo.fwd.tile = tile
-        ops.conv_wgrad(xd, gyd, dw, geo)
+        ops.conv_wgrad(xd, gyd, dw, geo, tile=tile)
         got = dw.cpu().numpy().transpose(0, 3, 1, 2)[:, :Cin]
         assert rel_err(got, gw_ref) < 5e-6
-        ops.conv_wgrad(xd, gyd, dw, geo, splits=3)       # accumulates
+        ops.conv_wgrad(xd, gyd, dw, geo, splits=3, tile=tile)       # accumulates
         got = dw.cpu().numpy().transpose(0, 3, 1, 2)[:, :Cin]
         assert rel_err(got, 2 * gw_ref) < 5e-6
-        geo.fwd.tile = 0
 
 
 def test_prep_images_exact():
