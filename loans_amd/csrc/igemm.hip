@@ -521,12 +521,13 @@ struct WgradArgs {
     unsigned x_bytes, gy_bytes;
 };
 
-template <int BT>   // square BT x BT block tile, 4 waves as 2 x 2
+template <int BT, bool RELU>   // square BT x BT block tile, 4 waves as 2 x 2
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     constexpr int T = BT / 2 / 32;          // MFMA tiles per wave per dim
     constexpr int UPR = BT / 4;             // float4 units per LDS row
     constexpr int RPP = 256 / UPR;          // rows per loader pass
-    constexpr int NP = 32 / RPP;            // passes per 32-row chunk
+    constexpr int NP = 32 / RPP;            // passes (rows per thread) per 32-row chunk
+    constexpr int NMMA = T * T;             // MFMAs per k step (2 reduction rows)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     float* Ys = reinterpret_cast<float*>(smem);     // [2][32][BT]
     float* Xs = Ys + 2 * 32 * BT;                   // [2][32][BT]
@@ -551,7 +552,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     const int dx = xtv ? (int)d.dx[xtap] : 0;
     const int yco = tco * BT + unit * 4;
     const bool yv = yco < d.Cout;        // Cout is a multiple of 4 for every layer on this path
-    const bool relu_in = d.flags & LOANS_F_RELU_IN;
 
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gy), 0, (int)a.gy_bytes, 0x00020000);
@@ -577,47 +577,50 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     const float inv_gw = 1.f / (float)d.gridW, inv_gh = 1.f / (float)d.gridH;
 
     f32x4 ry[NP], rx[NP];
-    auto load_chunk = [&]() {
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            const int b = pb[p], y = py[p], x = px[p];
-            const bool rv = b < d.B;
-            const int pix = (b * d.outH + y * d.osy + d.oy0) * d.outW + x * d.osx + d.ox0;
-            const unsigned goff = ((unsigned)(pix * d.Cout + yco) * 4u) | ((unsigned)(rv & yv) - 1u);
-            ry[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_g, (int)goff, 0, 0));
-            const int iy = y * d.isy + dy, ix = x * d.isx + dx;
-            const unsigned ok = (unsigned)(rv & xtv) & (unsigned)((unsigned)iy < (unsigned)d.inH) &
-                                (unsigned)((unsigned)ix < (unsigned)d.inW);
-            const unsigned xoff = ((unsigned)(((b * d.inH + iy) * d.inW + ix) * d.Cin + xc4 * 4) * 4u) | (ok - 1u);
-            rx[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)xoff, 0, 0));
-            // advance 32 pixels: exact floor((v + .5) / n) for the small integers involved
-            int nx = x + 32;
-            const int qx = (int)(((float)nx + 0.5f) * inv_gw);
-            nx -= qx * d.gridW;
-            int ny = y + qx;
-            const int qy = (int)(((float)ny + 0.5f) * inv_gh);
-            ny -= qy * d.gridH;
-            px[p] = nx; py[p] = ny; pb[p] = b + qy;
-        }
-        if (relu_in) {
-#pragma unroll
-            for (int p = 0; p < NP; ++p) {
-                rx[p].x = fmaxf(rx[p].x, 0.f); rx[p].y = fmaxf(rx[p].y, 0.f);
-                rx[p].z = fmaxf(rx[p].z, 0.f); rx[p].w = fmaxf(rx[p].w, 0.f);
-            }
-        }
+    // one loader piece = one chunk row of this thread: two bounds-checked loads + the coordinate advance
+    auto load_row = [&](int p) {
+        const int b = pb[p], y = py[p], x = px[p];
+        const bool rv = b < d.B;
+        const int pix = (b * d.outH + y * d.osy + d.oy0) * d.outW + x * d.osx + d.ox0;
+        const unsigned goff = ((unsigned)(pix * d.Cout + yco) * 4u) | ((unsigned)(rv & yv) - 1u);
+        ry[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_g, (int)goff, 0, 0));
+        const int iy = y * d.isy + dy, ix = x * d.isx + dx;
+        const unsigned ok = (unsigned)(rv & xtv) & (unsigned)((unsigned)iy < (unsigned)d.inH) &
+                            (unsigned)((unsigned)ix < (unsigned)d.inW);
+        const unsigned xoff = ((unsigned)(((b * d.inH + iy) * d.inW + ix) * d.Cin + xc4 * 4) * 4u) | (ok - 1u);
+        rx[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)xoff, 0, 0));
+        // advance 32 pixels: exact floor((v + .5) / n) for the small integers involved
+        int nx = x + 32;
+        const int qx = (int)(((float)nx + 0.5f) * inv_gw);
+        nx -= qx * d.gridW;
+        int ny = y + qx;
+        const int qy = (int)(((float)ny + 0.5f) * inv_gh);
+        ny -= qy * d.gridH;
+        px[p] = nx; py[p] = ny; pb[p] = b + qy;
     };
-    auto store_chunk = [&](int buf) {
-#pragma unroll
-        for (int p = 0; p < NP; ++p) {
-            const int row = prow + RPP * p;
-            *reinterpret_cast<f32x4*>(Ys + (buf * 32 + row) * BT + unit * 4) = ry[p];
-            *reinterpret_cast<f32x4*>(Xs + (buf * 32 + row) * BT + unit * 4) = rx[p];
+    auto store_y = [&](int buf, int p) {
+        *reinterpret_cast<f32x4*>(Ys + (buf * 32 + prow + RPP * p) * BT + unit * 4) = ry[p];
+    };
+    auto store_x = [&](int buf, int p) {
+        if (RELU) {
+            rx[p].x = fmaxf(rx[p].x, 0.f); rx[p].y = fmaxf(rx[p].y, 0.f);
+            rx[p].z = fmaxf(rx[p].z, 0.f); rx[p].w = fmaxf(rx[p].w, 0.f);
         }
+        *reinterpret_cast<f32x4*>(Xs + (buf * 32 + prow + RPP * p) * BT + unit * 4) = rx[p];
     };
 
     const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
+    const int fragY = h * BT + wm * T * 32 + r;
+    const int fragX = h * BT + wn * T * 32 + r;
+    auto read_k = [&](int buf, int s, float (&af)[T], float (&bf)[T]) {
+        const float* Yb = Ys + (buf * 32 + 2 * s) * BT + fragY;
+        const float* Xb = Xs + (buf * 32 + 2 * s) * BT + fragX;
+#pragma unroll
+        for (int i = 0; i < T; ++i) af[i] = Yb[i * 32];
+#pragma unroll
+        for (int j = 0; j < T; ++j) bf[j] = Xb[j * 32];
+    };
     f32x16 acc[T][T];
 #pragma unroll
     for (int i = 0; i < T; ++i)
@@ -625,35 +628,68 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
         for (int j = 0; j < T; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    auto mma_one = [&](int q, const float (&af)[T], const float (&bf)[T]) {
+        const int i = q / T, j = q % T;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+    };
 
+    // ---- software-pipelined reduction loop (same scheme as igemm_kernel) -------------------------
+    // 16 k steps per chunk; fragments of step s+1 are read while the MFMAs of step s run; loader rows of
+    // the next chunk ride in steps 0 .. NP-1, their LDS writes in steps 7 .. 7+2NP-1 (<= 14), and step 15's MFMAs
+    // run behind the barrier.
+    float fa0[T], fb0[T], fa1[T], fb1[T];
     if (c_begin < c_end) {
-        load_chunk();
-        store_chunk(0);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) load_row(p);
+#pragma unroll
+        for (int p = 0; p < NP; ++p) { store_y(0, p); store_x(0, p); }
     }
     __syncthreads();
-    for (int c = c_begin; c < c_end; ++c) {
-        const int buf = (c - c_begin) & 1;
-        const bool more = (c + 1) < c_end;
-        if (more) load_chunk();
-        const float* Yb = Ys + buf * 32 * BT + wm * T * 32 + r;
-        const float* Xb = Xs + buf * 32 * BT + wn * T * 32 + r;
+    if (c_begin < c_end) {
+        read_k(0, 0, fa0, fb0);
+        int c = c_begin;
+        for (; c + 1 < c_end; ++c) {
+            const int buf = (c - c_begin) & 1;
 #pragma unroll
-        for (int s = 0; s < 16; ++s) {
-            float af[T], bf[T];
+            for (int s = 0; s < 16; ++s) {
+                if (s == 15) __syncthreads();
+                if (s & 1) {
+                    if (s < 15) read_k(buf, s + 1, fa0, fb0); else read_k(buf ^ 1, 0, fa0, fb0);
+                } else {
+                    read_k(buf, s + 1, fa1, fb1);
+                }
+                __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int i = 0; i < T; ++i) af[i] = Yb[(2 * s + h) * BT + i * 32];
-#pragma unroll
-            for (int j = 0; j < T; ++j) bf[j] = Xb[(2 * s + h) * BT + j * 32];
-#pragma unroll
-            for (int i = 0; i < T; ++i)
-#pragma unroll
-                for (int j = 0; j < T; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
+                for (int q = 0; q < NMMA; ++q) {
+                    if (s & 1) mma_one(q, fa1, fb1); else mma_one(q, fa0, fb0);
+                    if (q == 0) {
+                        if (s < NP) load_row(s);
+                        if (s >= 7 && s < 7 + 2 * NP) {        // all LDS writes land before step 15's barrier
+                            const int w = s - 7;
+                            if (w & 1) store_x(buf ^ 1, w >> 1); else store_y(buf ^ 1, w >> 1);
+                        }
+                    }
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
         }
-        if (more) store_chunk(buf ^ 1);
-        __syncthreads();
+        {   // last chunk of this split
+            const int buf = (c - c_begin) & 1;
+#pragma unroll
+            for (int s = 0; s < 16; ++s) {
+                if (s < 15) {
+                    if (s & 1) read_k(buf, s + 1, fa0, fb0); else read_k(buf, s + 1, fa1, fb1);
+                }
+#pragma unroll
+                for (int q = 0; q < NMMA; ++q) {
+                    if (s & 1) mma_one(q, fa1, fb1); else mma_one(q, fa0, fb0);
+                }
+            }
+        }
     }
 
+    const __amdgpu_buffer_rsrc_t rs_dw = __builtin_amdgcn_make_buffer_rsrc(a.dw, 0, (int)((unsigned)d.Cout * (unsigned)a.Ktot * 4u), 0x00020000);
+    (void)rs_dw;
 #pragma unroll
     for (int i = 0; i < T; ++i)
 #pragma unroll
@@ -667,11 +703,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
         }
 }
 
-template <int BT>
-int launch_wgrad(WgradArgs& a, int splits_req, hipStream_t st) {
+template <int BT, bool RELU>
+int launch_wgrad_r(WgradArgs& a, int splits_req, hipStream_t st) {
     static bool attr_set = false;
     constexpr size_t lds = (size_t)4 * 32 * BT * 4;
-    auto kern = wgrad_kernel<BT>;
+    auto kern = wgrad_kernel<BT, RELU>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -696,6 +732,12 @@ int launch_wgrad(WgradArgs& a, int splits_req, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, st, a);
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;
+}
+
+template <int BT>
+int launch_wgrad(WgradArgs& a, int splits_req, hipStream_t st) {
+    return (a.d.flags & LOANS_F_RELU_IN) ? launch_wgrad_r<BT, true>(a, splits_req, st)
+                                         : launch_wgrad_r<BT, false>(a, splits_req, st);
 }
 
 struct RepackArgs {

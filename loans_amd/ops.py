@@ -6,6 +6,7 @@ float32 and contiguous unless a wrapper says otherwise.  Nothing here has a CPU
 fallback: without the built library ``_lib.load()`` raises.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -95,6 +96,7 @@ class ConvGeometry:
                 self.dgrad.append((g, tapsel, off))
                 off += Cin * len(taps) * Cout
         self.dgrad_weight_floats = off
+        self.tuned = {}
         self.flops_fwd = 2 * B * self.Ho * self.Wo * Cout * k * k * Cin
 
 
@@ -104,6 +106,47 @@ def _with_flags(desc, flags, tile=0):
     return desc
 
 
+# --------------------------------------------------------------------------- #
+# tile autotuning: the first time a geometry is used, every tile variant of the
+# kernel is timed on it (HIP events, scratch outputs) and the fastest is kept.
+# Results do not depend on the tile: K is accumulated in the same order by all.
+# --------------------------------------------------------------------------- #
+AUTOTUNE = os.environ.get('LOANS_AUTOTUNE', '1') != '0'
+_IGEMM_TILES = (1, 2, 3)
+_WGRAD_TILES = (1, 3)
+
+
+def _time_call(fn, reps=5):
+    fn()
+    best = float('inf')
+    for _ in range(reps):
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        fn()
+        e1.record()
+        e1.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    return best
+
+
+def _tuned_tile(geo, mode, run, candidates):
+    """run(tile) launches the op into scratch buffers."""
+    tile = geo.tuned.get(mode)
+    if tile is not None:
+        return tile
+    if not AUTOTUNE:
+        geo.tuned[mode] = 0
+        return 0
+    times = {t: _time_call(lambda: run(t)) for t in candidates}
+    tile = min(times, key=times.get)
+    geo.tuned[mode] = tile
+    if os.environ.get('LOANS_TUNE_VERBOSE'):
+        print('[tune] %-5s B=%d %dx%dx%d -> %d k%d s%d : %s -> tile %d' % (
+            mode, geo.B, geo.H, geo.W, geo.Cin, geo.Cout, geo.k, geo.stride,
+            ' '.join('%d:%.3fms' % kv for kv in sorted(times.items())), tile), flush=True)
+    return tile
+
+
 def conv_fprop(x, w, geo, out=None, bias=None, stats=None, relu_in=False, addend=None, tile=0):
     """out[B,Ho,Wo,Cout] = conv(x[B,H,W,Cin], w[Cout,k,k,Cin]) (+bias) (+addend); optional BN statistics."""
     lib = _lib.load()
@@ -111,8 +154,14 @@ def conv_fprop(x, w, geo, out=None, bias=None, stats=None, relu_in=False, addend
         out = torch.empty((geo.B, geo.Ho, geo.Wo, geo.Cout), device=x.device, dtype=torch.float32)
     flags = (F_RELU_IN if relu_in else 0) | (F_BIAS if bias is not None else 0) | \
             (F_STATS if stats is not None else 0) | (F_ADDEND if addend is not None else 0)
-    d = _with_flags(geo.fwd, flags, tile)
     assert x.numel() == geo.B * geo.H * geo.W * geo.Cin and w.numel() == geo.Cout * geo.k * geo.k * geo.Cin
+    if tile == 0:
+        def run(t):
+            scratch = torch.empty((geo.B, geo.Ho, geo.Wo, geo.Cout), device=x.device, dtype=torch.float32)
+            check(lib.loans_igemm_f32(_ptr(x), _ptr(w), _ptr(scratch), 0, 0, 0, 0,
+                                      C.byref(_with_flags(geo.fwd, flags & F_RELU_IN, t)), _stream()), 'loans_igemm_f32[tune]')
+        tile = _tuned_tile(geo, 'fprop', run, _IGEMM_TILES)
+    d = _with_flags(geo.fwd, flags, tile)
     log = EVENT_LOG
     if log is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -142,20 +191,71 @@ def conv_dgrad(gy, w, geo, out=None, mask_ref=None, addend=None, addend_mask_ref
     assert not (mask_ref is not None and addend_mask_ref is not None)
     st = _stream()
     for d, tapsel, off in geo.dgrad:
-        wcls = wp[off:]
-        check(lib.loans_repack_dgrad_f32(_ptr(w), _ptr(wcls), geo.Cout, geo.Cin, geo.k * geo.k, tapsel,
+        check(lib.loans_repack_dgrad_f32(_ptr(w), _ptr(wp[off:]), geo.Cout, geo.Cin, geo.k * geo.k, tapsel,
                                          d.ntaps, st), 'loans_repack_dgrad_f32')
+    if tile == 0:
+        def run(t):
+            scratch = torch.empty((geo.B, geo.H, geo.W, geo.Cin), device=gy.device, dtype=torch.float32)
+            for d, _, off in geo.dgrad:
+                check(lib.loans_igemm_f32(_ptr(gy), _ptr(wp[off:]), _ptr(scratch), 0, 0, 0, 0,
+                                          C.byref(_with_flags(d, 0, t)), st), 'loans_igemm_f32[tune]')
+        tile = _tuned_tile(geo, 'dgrad', run, _IGEMM_TILES)
+    for d, tapsel, off in geo.dgrad:
         _with_flags(d, flags, tile)
-        check(lib.loans_igemm_f32(_ptr(gy), _ptr(wcls), _ptr(out), 0, 0, _ptr(ref), _ptr(addend),
+        check(lib.loans_igemm_f32(_ptr(gy), _ptr(wp[off:]), _ptr(out), 0, 0, _ptr(ref), _ptr(addend),
                                   C.byref(d), st), 'loans_igemm_f32[dgrad]')
     return out
 
 
+# Weight gradients are consumed only by the optimiser, so they run on a second HIP stream: the
+# MFMA-bound wgrad kernels overlap the HBM-bound BN / ReLU passes of the data-gradient chain and
+# fill the tails of its dgrad launches.  `join_side_stream()` is the barrier the consumers call.
+ASYNC_WGRAD = os.environ.get('LOANS_ASYNC_WGRAD', '1') != '0'
+_side = {}
+_side_dirty = set()
+
+
+def _side_stream(device):
+    st = _side.get(device.index)
+    if st is None:
+        st = _side[device.index] = torch.cuda.Stream(device=device)
+    return st
+
+
+def join_side_stream(device=None):
+    """Make the current stream wait for every weight-gradient kernel issued so far."""
+    for idx in list(_side_dirty):
+        if device is not None and device.index != idx:
+            continue
+        torch.cuda.current_stream(idx).wait_stream(_side[idx])
+        _side_dirty.discard(idx)
+
+
 def conv_wgrad(x, gy, dw, geo, relu_in=False, splits=0, tile=0):
     """dw[Cout,k,k,Cin] += sum over pixels (atomic accumulate into the gradient arena)."""
+    if ASYNC_WGRAD and geo.tuned.get('wgrad') is not None and not torch.cuda.is_current_stream_capturing():
+        side = _side_stream(x.device)
+        side.wait_stream(torch.cuda.current_stream(x.device))
+        x.record_stream(side)
+        gy.record_stream(side)
+        _side_dirty.add(x.device.index)
+        with torch.cuda.stream(side):
+            _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile)
+        return
+    _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile)
+
+
+def _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile):
     lib = _lib.load()
-    d = _with_flags(geo.fwd, F_RELU_IN if relu_in else 0, tile)
     assert dw.numel() == geo.Cout * geo.k * geo.k * geo.Cin
+    fl = F_RELU_IN if relu_in else 0
+    if tile == 0:
+        def run(t):
+            scratch = torch.empty(dw.numel(), device=x.device, dtype=torch.float32)
+            check(lib.loans_wgrad_f32(_ptr(x), _ptr(gy), _ptr(scratch), C.byref(_with_flags(geo.fwd, fl, t)), splits,
+                                      _stream()), 'loans_wgrad_f32[tune]')
+        tile = _tuned_tile(geo, 'wgrad', run, _WGRAD_TILES)
+    d = _with_flags(geo.fwd, fl, tile)
     check(lib.loans_wgrad_f32(_ptr(x), _ptr(gy), _ptr(dw), C.byref(d), splits, _stream()), 'loans_wgrad_f32')
 
 

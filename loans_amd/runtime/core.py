@@ -263,6 +263,8 @@ class Parameter(Variable):
             self.data.copy_(torch.from_numpy(phys))
 
     def grad_logical(self):
+        from .. import ops
+        ops.join_side_stream()
         return np.ascontiguousarray(self._to_logical(self.grad_view.detach().cpu().numpy()))
 
 
@@ -465,6 +467,8 @@ class ParamArena:
         self._clean = True
 
     def zero_grads(self):
+        from .. import ops
+        ops.join_side_stream(self.device)      # weight-gradient kernels still in flight write here
         self.grad.zero_()
 
 

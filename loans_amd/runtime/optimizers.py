@@ -61,6 +61,7 @@ class Adam:
         if not any(p.update_rule.enabled for p in self.target.params()):
             return
         arena = self._ensure_state()
+        ops.join_side_stream(arena.device)     # all weight gradients of this step have landed
         grad_scale = 1.0
         if self.comm is not None and self.comm.size > 1:
             self.comm.allreduce_grad(arena)
