@@ -37,11 +37,12 @@ extern "C" {
 #define LOANS_ERANGE (-2)   /* size beyond what the kernel's 32-bit indexing supports */
 
 #define LOANS_MAX_TAPS 64
+#define LOANS_STATS_REPLICAS 32   /* BN-statistics accumulators are replicated to spread fp64 atomics */
 
 /* epilogue / loader flags of the implicit-GEMM kernels */
 #define LOANS_F_RELU_IN   1   /* gather relu(in) instead of in (pre-activation blocks, common/net.py:22,43,44,64,65) */
 #define LOANS_F_BIAS      2   /* out += bias[n]                         (sheep/resnet.py:43 conv1) */
-#define LOANS_F_STATS     4   /* stats[0][n] += sum_m out, stats[1][n] += sum_m out^2 (double)  */
+#define LOANS_F_STATS     4   /* stats[r][0][n] += sum_m out, stats[r][1][n] += sum_m out^2 (double), r = block % LOANS_STATS_REPLICAS */
 #define LOANS_F_MASK      8   /* out = (ref[m][n] > 0) ? out : 0        (ReLU backward folded into dgrad) */
 #define LOANS_F_ADDEND   16   /* out += addend[m][n]                    (residual sums; may alias out) */
 #define LOANS_F_ADDEND_MASK 32 /* with ADDEND: out += (ref[m][n] > 0) ? addend[m][n] : 0  (identity shortcut through a ReLU) */
@@ -87,6 +88,12 @@ int loans_igemm_f32(const float* in, const float* w, float* out,
 int loans_wgrad_f32(const float* x, const float* gy, float* dw,
                     const loans_igemm_desc* d, int32_t splits, void* stream);
 
+/* dgrad for convolutions whose input has 4 physical channels (the RGB crops, common/net.py:15,17):
+ * out[opix(m)][0..3] = sum_t sum_co gy[pix(m,t)][co] * w_ohwi[co][tapsel[t]][0..3]; same descriptor as
+ * loans_igemm_f32 (Cin = gy channels, Cout must be 4), flags MASK / ADDEND only. */
+int loans_dgrad_c4_f32(const float* gy, const float* w_ohwi, float* out, const float* ref, const float* addend,
+                       const loans_igemm_desc* d, const int32_t* tapsel_host, int32_t src_taps, void* stream);
+
 /* weight repack for dgrad: dst[ci][t][co] = src[co][tapsel[t]][ci]  (src is OHWI with `src_taps` taps) */
 int loans_repack_dgrad_f32(const float* src, float* dst, int32_t Cout, int32_t Cin, int32_t src_taps,
                            const int32_t* tapsel_host, int32_t ntaps, void* stream);
@@ -100,7 +107,7 @@ int loans_nchw3_to_nhwc4_f32(const float* in, float* out, int32_t B, int32_t H, 
 /* ---- batch normalisation (replaces cuDNN BatchNormalizationForwardTraining/Backward behind
  *      L.BatchNormalization, sheep/resnet.py:44,129-134,152-154; eps 2e-5, decay 0.9) ---- */
 
-/* stats (double [2][C]: sum, sum of squares over `count` rows) -> mean, rstd, scale=gamma*rstd,
+/* stats (double [LOANS_STATS_REPLICAS][2][C]: sum, sum of squares over `count` rows) -> mean, rstd, scale=gamma*rstd,
  * shift=beta-mean*scale; updates running stats in place (unbiased var, + eps if eps_in_running_var). */
 int loans_bn_finalize_f32(const double* stats, int32_t C, int64_t count, float eps, float decay,
                           const float* gamma, const float* beta, float* running_mean, float* running_var,

@@ -23,8 +23,13 @@ __global__ void bn_finalize_kernel(const double* stats, int C, double inv_count,
                                    int eps_in_rv, float* mean, float* rstd, float* scale, float* shift) {
     const int c = blockIdx.x * blockDim.x + threadIdx.x;
     if (c >= C) return;
-    const double mu = stats[c] * inv_count;
-    double var = stats[C + c] * inv_count - mu * mu;
+    double s1 = 0.0, s2 = 0.0;
+    for (int r = 0; r < LOANS_STATS_REPLICAS; ++r) {
+        s1 += stats[(size_t)r * 2 * C + c];
+        s2 += stats[(size_t)r * 2 * C + C + c];
+    }
+    const double mu = s1 * inv_count;
+    double var = s2 * inv_count - mu * mu;
     if (var < 0.0) var = 0.0;
     const double vpe = var + (double)eps;
     const float rs = (float)(1.0 / sqrt(vpe));

@@ -52,7 +52,10 @@ struct IgemmArgs {
     loans_igemm_desc d;
     int M, Ktot, nchunks, tiles_m, tiles_n;
     unsigned in_bytes, w_bytes, out_bytes;
-    int sep_nx;     // > 0: taps are an (ntaps / sep_nx) x sep_nx grid, dy constant per row, dx per column
+    struct {            // nx > 0: taps are an ny x nx grid, dy = dy0 + row*sdy, dx = dx0 + col*sdx, sd* = +-1
+        int nx, ny, dy0, sdy, dx0, sdx;
+        unsigned long long rowpat;      // bit (row * nx) set for every row
+    } ap;
 };
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -83,6 +86,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
 
     const loans_igemm_desc& d = a.d;
     const int tid = threadIdx.x;
+#ifdef LOANS_STAMPS
+    unsigned long long t_start = 0;
+    STAMP(t_start);
+#endif
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
     const int tn = logical % a.tiles_n;
     const int tm = logical / a.tiles_n;
@@ -94,31 +101,45 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     }
 
     // per row (fixed for the whole K loop): byte offset of its base pixel and a bitmask with bit t SET
-    // when tap t must read zero (outside the image, beyond ntaps, or the row does not exist)
+    // when tap t must read zero (outside the image, beyond ntaps, or the row does not exist).
+    // Every conv on this path has taps on an ny x nx grid whose dy / dx run in unit steps, so the in-bounds
+    // taps of a row are an index RANGE per axis and the mask is two shifts and a multiply -- no loops, no
+    // table reads.  (b, y, x) of the first row comes from two divisions, the others advance by 32 pixels.
     unsigned rowoff[RA];
     unsigned long long badmask[RA];
     {
         const int gHW = d.gridH * d.gridW;
+        const float inv_gw = 1.f / (float)d.gridW, inv_gh = 1.f / (float)d.gridH;
+        const int m0 = tm * BM + lrow;
+        int b = m0 / gHW;
+        int rem = m0 - b * gHW;
+        int y = rem / d.gridW;
+        int x = rem - y * d.gridW;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
-            const int m = tm * BM + lrow + 32 * i;
+            const int m = m0 + 32 * i;
             unsigned pixoff = 0xFFFFFFFFu;
             unsigned long long mask = 0;
             rowoff[i] = 0;
             if (m < a.M) {
-                const int b = m / gHW;
-                const int rem = m - b * gHW;
-                const int y = rem / d.gridW;
-                const int x = rem - y * d.gridW;
                 const int iy0 = y * d.isy, ix0 = x * d.isx;
                 rowoff[i] = (unsigned)(((b * d.inH + iy0) * d.inW + ix0) * d.Cin) * 4u;
                 pixoff = (unsigned)((b * d.outH + y * d.osy + d.oy0) * d.outW + x * d.osx + d.ox0) * (unsigned)d.Cout * 4u;
-                if (a.sep_nx > 0) {      // taps form an ny x nx grid (every conv here): O(ny + nx)
-                    unsigned colbits = 0;
-                    for (int s = 0; s < a.sep_nx; ++s)
-                        if ((unsigned)(ix0 + d.dx[s]) < (unsigned)d.inW) colbits |= 1u << s;
-                    for (int t = 0; t < d.ntaps; t += a.sep_nx)
-                        if ((unsigned)(iy0 + d.dy[t]) < (unsigned)d.inH) mask |= (unsigned long long)colbits << t;
+                if (a.ap.nx > 0) {
+                    // column j valid <=> 0 <= ix0 + dx0 + j*sdx < inW  (sdx = +-1): a contiguous j range
+                    const int cx = ix0 + a.ap.dx0, cy = iy0 + a.ap.dy0;
+                    int jlo, jhi, rlo, rhi;
+                    if (a.ap.sdx > 0) { jlo = max(0, -cx); jhi = min(a.ap.nx, d.inW - cx); }
+                    else { jlo = max(0, cx - d.inW + 1); jhi = min(a.ap.nx, cx + 1); }
+                    if (a.ap.sdy > 0) { rlo = max(0, -cy); rhi = min(a.ap.ny, d.inH - cy); }
+                    else { rlo = max(0, cy - d.inH + 1); rhi = min(a.ap.ny, cy + 1); }
+                    if (jhi > jlo && rhi > rlo) {
+                        const unsigned long long colbits = ((1ull << jhi) - 1ull) & ~((1ull << jlo) - 1ull);
+                        const int blo = rlo * a.ap.nx, bhi = rhi * a.ap.nx;     // bhi <= 64
+                        const unsigned long long below_hi = bhi >= 64 ? ~0ull : ((1ull << bhi) - 1ull);
+                        const unsigned long long rowsel = a.ap.rowpat & below_hi & ~((1ull << blo) - 1ull);
+                        mask = colbits * rowsel;       // colbits < 2^nx, rowsel bits nx apart: no carries
+                    }
                 } else {
                     for (int t = 0; t < d.ntaps; ++t) {
                         const int iy = iy0 + d.dy[t], ix = ix0 + d.dx[t];
@@ -128,6 +149,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
             }
             badmask[i] = ~mask;
             if (lu == 0) opix[lrow + 32 * i] = pixoff;
+            // advance 32 pixels: exact floor((v + .5) / n) for the small integers involved
+            x += 32;
+            const int qx = (int)(((float)x + 0.5f) * inv_gw);
+            x -= qx * d.gridW;
+            y += qx;
+            const int qy = (int)(((float)y + 0.5f) * inv_gh);
+            y -= qy * d.gridH;
+            b += qy;
         }
     }
     __syncthreads();
@@ -318,69 +347,95 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     STAMP(t_loop_end);
 #endif
 
-    // ---- epilogue: bounds-checked buffer stores, row offsets read once from LDS ----------------------
+    // ---- epilogue -----------------------------------------------------------------------------------
+    // BN statistics come straight from the accumulators; the tile itself is staged through LDS (the K-loop
+    // buffers are free now) so that every lane stores 16 contiguous bytes: BN/4 lanes cover one output row.
     const bool f_bias = d.flags & LOANS_F_BIAS, f_stats = d.flags & LOANS_F_STATS;
     const bool f_mask = d.flags & LOANS_F_MASK, f_add = d.flags & LOANS_F_ADDEND;
     const bool f_addmask = d.flags & LOANS_F_ADDEND_MASK;
+    constexpr int LDC = BN + 4;
+    float* Cs = reinterpret_cast<float*>(smem);          // [BM][LDC]
+    __syncthreads();                                     // every wave is done with the fragment buffers
+    if (f_stats) {
+        int nvalid = 0;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                nvalid += opix[wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h] != 0xFFFFFFFFu;
+        const float cnt = (float)nvalid;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = tn * BN + wn * TN * 32 + j * 32 + r;
+            const bool cok = col < d.Cout;
+            const float bv = (f_bias && cok) ? a.bias[col] : 0.f;
+            float s = 0.f, q2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {      // rows that do not exist gathered zeros: acc == 0 there
+                    s += acc[i][j][e];
+                    q2 += acc[i][j][e] * acc[i][j][e];
+                }
+            // statistics of (acc + bias) over the rows that exist, from the raw sums
+            q2 = q2 + 2.f * bv * s + cnt * bv * bv;
+            s = s + cnt * bv;
+            s += __shfl_xor(s, 32, 64);
+            q2 += __shfl_xor(q2, 32, 64);
+            if (h == 0 && cok) {       // LOANS_STATS_REPLICAS accumulators, picked by block, against contention
+                double* st = a.stats + (size_t)(blockIdx.x % LOANS_STATS_REPLICAS) * 2 * d.Cout;
+                atomic_add_f64(st + col, (double)s);
+                atomic_add_f64(st + d.Cout + col, (double)q2);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                Cs[(wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * LDC + wn * TN * 32 + j * 32 + r] = acc[i][j][e];
+    __syncthreads();
+
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)a.out_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_ref = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(a.ref ? a.ref : a.out), 0, (int)a.out_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_add = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(a.addend ? a.addend : a.out), 0, (int)a.out_bytes, 0x00020000);
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
-    u32x4 prow[TM][4];            // byte offsets of this lane's 16 rows per MFMA tile (~0u = no such row)
-    int nvalid = 0;
+    constexpr int CPR = BN / 4;                 // float4 columns per row
+    constexpr int RSTEP = 256 / CPR;            // rows covered by the block per pass
+    const int oc4 = tid % CPR, r0 = tid / CPR;
+    const int col0 = tn * BN + oc4 * 4;
+    const unsigned cbad = (col0 + 3 < d.Cout) ? 0u : 0xFFFFFFFFu;     // Cout % 4 == 0 on every layer here
+    const unsigned coff = (unsigned)col0 * 4u;
+    f32x4 bv4 = {0.f, 0.f, 0.f, 0.f};
+    if (f_bias && !cbad) bv4 = *reinterpret_cast<const f32x4*>(a.bias + col0);
 #pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            prow[i][q] = *reinterpret_cast<const u32x4*>(opix + wm * TM * 32 + i * 32 + 8 * q + 4 * h);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) nvalid += prow[i][q][e] != 0xFFFFFFFFu;
-        }
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-        const int col = tn * BN + wn * TN * 32 + j * 32 + r;
-        const bool cok = col < d.Cout;
-        const unsigned cbad = cok ? 0u : 0xFFFFFFFFu;
-        const unsigned coff = cok ? (unsigned)col * 4u : 0u;
-        const float bv = (f_bias && cok) ? a.bias[col] : 0.f;
-        float s = 0.f, q2 = 0.f;
-#pragma unroll
-        for (int i = 0; i < TM; ++i) {
-#pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const unsigned po = prow[i][e >> 2][e & 3];
-                const unsigned off = (po + coff) | (po == 0xFFFFFFFFu ? 0xFFFFFFFFu : 0u) | cbad;
-                const float raw = acc[i][j][e];       // rows that do not exist gathered zeros: raw == 0
-                s += raw;
-                q2 += raw * raw;
-                float v = raw + bv;
-                if (f_mask || f_addmask) {
-                    const float rf = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_ref, (int)off, 0, 0));
-                    if (f_mask) v = rf > 0.f ? v : 0.f;
-                    if (f_add) {
-                        const float ad = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_add, (int)off, 0, 0));
-                        v += (!f_addmask || rf > 0.f) ? ad : 0.f;
-                    }
-                } else if (f_add) {
-                    v += __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs_add, (int)off, 0, 0));
+    for (int p = 0; p < BM / RSTEP; ++p) {
+        const int row = r0 + p * RSTEP;
+        const unsigned po = opix[row];
+        const unsigned off = (po + coff) | (po == 0xFFFFFFFFu ? 0xFFFFFFFFu : 0u) | cbad;
+        f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * LDC + oc4 * 4) + bv4;
+        if (f_mask || f_addmask) {
+            const f32x4 rf = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_ref, (int)off, 0, 0));
+            if (f_mask) {
+                v.x = rf.x > 0.f ? v.x : 0.f; v.y = rf.y > 0.f ? v.y : 0.f;
+                v.z = rf.z > 0.f ? v.z : 0.f; v.w = rf.w > 0.f ? v.w : 0.f;
+            }
+            if (f_add) {
+                f32x4 ad = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_add, (int)off, 0, 0));
+                if (f_addmask) {
+                    ad.x = rf.x > 0.f ? ad.x : 0.f; ad.y = rf.y > 0.f ? ad.y : 0.f;
+                    ad.z = rf.z > 0.f ? ad.z : 0.f; ad.w = rf.w > 0.f ? ad.w : 0.f;
                 }
-                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), rs_out, (int)off, 0, 0);
+                v += ad;
             }
+        } else if (f_add) {
+            v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_add, (int)off, 0, 0));
         }
-        if (f_stats) {
-            // statistics of (raw + bias) over the rows that exist, from the raw sums
-            const float cnt = (float)nvalid;
-            q2 = q2 + 2.f * bv * s + cnt * bv * bv;
-            s = s + cnt * bv;
-            s += __shfl_xor(s, 32, 64);
-            q2 += __shfl_xor(q2, 32, 64);
-            if (h == 0 && cok) {
-                atomic_add_f64(a.stats + col, (double)s);
-                atomic_add_f64(a.stats + d.Cout + col, (double)q2);
-            }
-        }
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_out, (int)off, 0, 0);
     }
 #ifdef LOANS_STAMPS
     unsigned long long t_end = 0;
@@ -388,7 +443,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     if (logical < 64 && lane == 0) {
         unsigned long long* o = g_stamps + (logical * 4 + wave) * 8;
         o[0] = s_load; o[1] = s_mfma; o[2] = s_store; o[3] = s_bar;
-        o[4] = t_loop_end - t_begin; o[5] = t_end - t_loop_end; o[6] = a.nchunks; o[7] = t_begin;
+        o[4] = t_loop_end - t_begin; o[5] = t_end - t_loop_end; o[6] = a.nchunks; o[7] = t_begin - t_start;
     }
 #endif
 }
@@ -423,14 +478,20 @@ int launch_igemm_r(IgemmArgs& a, hipStream_t st) {
     return LOANS_OK;
 }
 
-// number of columns if the tap list is a row-major (dy) x (dx) grid, else 0
-int separable_nx(const loans_igemm_desc* d) {
+// recognise a row-major ny x nx tap grid with unit-step dy / dx (every conv of this path); nx = 0 otherwise
+void detect_tap_grid(const loans_igemm_desc* d, IgemmArgs& a) {
+    a.ap.nx = 0; a.ap.ny = 0; a.ap.dy0 = a.ap.dx0 = 0; a.ap.sdy = a.ap.sdx = 1; a.ap.rowpat = 0;
     int nx = 1;
     while (nx < d->ntaps && d->dy[nx] == d->dy[0]) ++nx;
-    if (d->ntaps % nx) return 0;
+    if (d->ntaps % nx) return;
+    const int ny = d->ntaps / nx;
+    const int sdx = nx > 1 ? d->dx[1] - d->dx[0] : 1;
+    const int sdy = ny > 1 ? d->dy[nx] - d->dy[0] : 1;
+    if ((sdx != 1 && sdx != -1) || (sdy != 1 && sdy != -1)) return;
     for (int t = 0; t < d->ntaps; ++t)
-        if (d->dy[t] != d->dy[(t / nx) * nx] || d->dx[t] != d->dx[t % nx]) return 0;
-    return nx;
+        if (d->dy[t] != d->dy[0] + (t / nx) * sdy || d->dx[t] != d->dx[0] + (t % nx) * sdx) return;
+    a.ap.nx = nx; a.ap.ny = ny; a.ap.dy0 = d->dy[0]; a.ap.sdy = sdy; a.ap.dx0 = d->dx[0]; a.ap.sdx = sdx;
+    for (int r = 0; r < ny; ++r) a.ap.rowpat |= 1ull << (r * nx);
 }
 
 template <int BM, int BN, int WM, int WN>
@@ -462,7 +523,7 @@ extern "C" int loans_igemm_f32(const float* in, const float* w, float* out, cons
                                const float* ref, const float* addend, const loans_igemm_desc* d, void* stream) {
     int rc = check_desc(d);
     if (rc) return rc;
-    if (!in || !w || !out) return LOANS_EINVAL;
+    if (!in || !w || !out || (d->Cout & 3)) return LOANS_EINVAL;
     if ((d->flags & LOANS_F_BIAS) && !bias) return LOANS_EINVAL;
     if ((d->flags & LOANS_F_STATS) && !stats) return LOANS_EINVAL;
     if ((d->flags & (LOANS_F_MASK | LOANS_F_ADDEND_MASK)) && !ref) return LOANS_EINVAL;
@@ -482,7 +543,7 @@ extern "C" int loans_igemm_f32(const float* in, const float* w, float* out, cons
         a.w_bytes = (unsigned)wb;
         a.out_bytes = (unsigned)ob;
     }
-    a.sep_nx = separable_nx(d);
+    detect_tap_grid(d, a);
     hipStream_t st = as_stream(stream);
     int tile = d->tile;
     if (tile == 0) {

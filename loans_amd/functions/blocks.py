@@ -13,8 +13,8 @@ from .. import ops
 from ..runtime.core import Function, config
 
 
-def _zeros_stats(C, device, rows=2):
-    return torch.zeros((rows, C), device=device, dtype=torch.float64)
+def _zeros_stats(C, device):
+    return ops.stats_buffer(C, device)
 
 
 def _wgrad_enabled(param):

@@ -156,11 +156,14 @@ def conv_fprop(x, w, geo, out=None, bias=None, stats=None, relu_in=False, addend
             (F_STATS if stats is not None else 0) | (F_ADDEND if addend is not None else 0)
     assert x.numel() == geo.B * geo.H * geo.W * geo.Cin and w.numel() == geo.Cout * geo.k * geo.k * geo.Cin
     if tile == 0:
+        tflags = flags & (F_RELU_IN | F_STATS)
+        sstats = stats_buffer(geo.Cout, x.device) if stats is not None else None
+
         def run(t):
             scratch = torch.empty((geo.B, geo.Ho, geo.Wo, geo.Cout), device=x.device, dtype=torch.float32)
-            check(lib.loans_igemm_f32(_ptr(x), _ptr(w), _ptr(scratch), 0, 0, 0, 0,
-                                      C.byref(_with_flags(geo.fwd, flags & F_RELU_IN, t)), _stream()), 'loans_igemm_f32[tune]')
-        tile = _tuned_tile(geo, 'fprop', run, _IGEMM_TILES)
+            check(lib.loans_igemm_f32(_ptr(x), _ptr(w), _ptr(scratch), 0, _ptr(sstats), 0, 0,
+                                      C.byref(_with_flags(geo.fwd, tflags, t)), _stream()), 'loans_igemm_f32[tune]')
+        tile = _tuned_tile(geo, 'fprop' + ('_stats' if stats is not None else ''), run, _IGEMM_TILES + (4,))
     d = _with_flags(geo.fwd, flags, tile)
     log = EVENT_LOG
     if log is not None:
@@ -184,6 +187,14 @@ def conv_dgrad(gy, w, geo, out=None, mask_ref=None, addend=None, addend_mask_ref
     if out is None:
         out = torch.empty((geo.B, geo.H, geo.W, geo.Cin), device=gy.device, dtype=torch.float32)
     assert gy.numel() == geo.B * geo.Ho * geo.Wo * geo.Cout
+    if geo.Cin == 4 and addend_mask_ref is None and geo.Cout % 32 == 0:
+        # gradient w.r.t. a 4-channel (RGB) input: dedicated VALU kernel, forward weights, no re-pack
+        fl = (F_MASK if mask_ref is not None else 0) | (F_ADDEND if addend is not None else 0)
+        for d, tapsel, _ in geo.dgrad:
+            check(lib.loans_dgrad_c4_f32(_ptr(gy), _ptr(w), _ptr(out), _ptr(mask_ref), _ptr(addend),
+                                         C.byref(_with_flags(d, fl, 0)), tapsel, geo.k * geo.k, _stream()),
+                  'loans_dgrad_c4_f32')
+        return out
     wp = torch.empty(geo.dgrad_weight_floats, device=gy.device, dtype=torch.float32)
     flags = (F_MASK if mask_ref is not None else 0) | (F_ADDEND if addend is not None else 0) | \
             (F_ADDEND_MASK if addend_mask_ref is not None else 0)
@@ -283,6 +294,14 @@ def nchw3_to_nhwc4(x):
 # --------------------------------------------------------------------------- #
 # batch normalisation
 # --------------------------------------------------------------------------- #
+STATS_REPLICAS = 32      # LOANS_STATS_REPLICAS
+
+
+def stats_buffer(C_, device):
+    """Zeroed fp64 accumulators for the conv epilogue's BN statistics: [replica][sum | sumsq][C]."""
+    return torch.zeros((STATS_REPLICAS, 2, C_), device=device, dtype=torch.float64)
+
+
 class BNState:
     """Per-call batch statistics + affine coefficients (device vectors of C floats)."""
     __slots__ = ('mean', 'rstd', 'scale', 'shift', 'count')

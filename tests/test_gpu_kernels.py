@@ -53,8 +53,9 @@ def test_conv_fprop_dgrad_wgrad(case, tile):
     xd, wd, bd = dev(_nhwc(x, cp)), dev(_ohwi(w, cp)), dev(b)
 
     y_ref, col = C.conv2d_fwd(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64), s, p)
-    stats = torch.zeros((2, Cout), device='cuda', dtype=torch.float64)
-    y = ops.conv_fprop(xd, wd, geo, bias=bd, stats=stats, tile=tile)
+    stats_r = ops.stats_buffer(Cout, 'cuda')
+    y = ops.conv_fprop(xd, wd, geo, bias=bd, stats=stats_r, tile=tile)
+    stats = stats_r.sum(dim=0)
     assert rel_err(_nchw(y), y_ref) < 2e-6          # exact-f32 MFMA chain vs f64
     np.testing.assert_allclose(stats[0].cpu().numpy(), y_ref.sum(axis=(0, 2, 3)), rtol=1e-5, atol=1e-4)
     np.testing.assert_allclose(stats[1].cpu().numpy(), (y_ref ** 2).sum(axis=(0, 2, 3)), rtol=1e-5)
@@ -111,7 +112,8 @@ def test_bn_forward_backward(C_):
     rm, rv = np.zeros(C_), np.ones(C_)
     y_ref, ctx = C.bn_fwd_train(x.astype(np.float64), gamma.astype(np.float64), beta.astype(np.float64), rm, rv)
     xd = dev(_nhwc(x))
-    stats = torch.stack([xd.double().sum(dim=(0, 1, 2)), (xd.double() ** 2).sum(dim=(0, 1, 2))])
+    stats = ops.stats_buffer(C_, 'cuda')
+    stats[3, 0] = xd.double().sum(dim=(0, 1, 2)); stats[7, 1] = (xd.double() ** 2).sum(dim=(0, 1, 2))
     rmd, rvd = torch.zeros(C_, device='cuda'), torch.ones(C_, device='cuda')
     st = ops.bn_finalize(stats, B * H * W, dev(gamma), dev(beta), rmd, rvd)
     np.testing.assert_allclose(rmd.cpu().numpy(), rm, rtol=1e-5, atol=1e-7)

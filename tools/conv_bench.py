@@ -59,7 +59,7 @@ def main():
         y = torch.empty_like(gy)
         gx = torch.empty_like(x)
         dw = torch.zeros_like(w)
-        stats = torch.zeros(2, Cout, device='cuda', dtype=torch.float64)
+        stats = ops.stats_buffer(Cout, 'cuda')
         cin = 3 if Cin == 4 else Cin
         flops = 2.0 * B * geo.Ho * geo.Wo * Cout * k * k * cin
         line = '%-8s M=%8d N=%4d K=%5d |' % (name, B * geo.Ho * geo.Wo, Cout, k * k * Cin)

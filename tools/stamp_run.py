@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 csrc = os.path.join(ROOT, 'loans_amd', 'csrc')
 dbg = '/tmp/libloans_hip_dbg.so'
 subprocess.check_call('/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -DLOANS_STAMPS '
-                      '-I%s/include -shared -o %s %s/igemm.hip %s/bn_pool.hip %s/misc.hip' % (ROOT, dbg, csrc, csrc, csrc), shell=True)
+                      '-I%s/include -shared -o %s %s/igemm.hip %s/smalln.hip %s/bn_pool.hip %s/misc.hip' % (ROOT, dbg, csrc, csrc, csrc, csrc), shell=True)
 from loans_amd import _lib
 _lib.LIB_PATH = dbg
 from loans_amd import ops
@@ -19,7 +19,7 @@ name, Cin, H, W, Cout, k, s, p = sys.argv[1], *[int(v) for v in sys.argv[2:9]]
 B = int(sys.argv[9]); tile = int(sys.argv[10])
 geo = ops.ConvGeometry(B, H, W, Cin, Cout, k, s, p)
 x = torch.randn(B, H, W, Cin, device='cuda'); w = torch.randn(Cout, k, k, Cin, device='cuda') * 0.05
-y = torch.empty(B, geo.Ho, geo.Wo, Cout, device='cuda'); stats = torch.zeros(2, Cout, device='cuda', dtype=torch.float64)
+y = torch.empty(B, geo.Ho, geo.Wo, Cout, device='cuda'); stats = ops.stats_buffer(Cout, 'cuda')
 for _ in range(3):
     ops.conv_fprop(x, w, geo, out=y, stats=stats, tile=tile)
 torch.cuda.synchronize()
@@ -28,6 +28,6 @@ assert lib.loans_debug_read_stamps(buf.ctypes.data, buf.size) == 0
 st = buf.reshape(64, 4, 8).astype(np.float64)
 n = st[..., 6]
 per = st[..., :4] / n[..., None]
-print('%s tile=%d chunks=%d  per-chunk cycles (median over 256 waves): load=%.0f mfma=%.0f store=%.0f barrier=%.0f | loop total/chunk=%.0f epilogue=%.0f' % (
-    name, tile, int(n[0, 0]), *np.median(per.reshape(-1, 4), axis=0), np.median(st[..., 4] / n), np.median(st[..., 5])))
+print('%s tile=%d chunks=%d  per-chunk cycles (median over 256 waves): g0+load=%.0f g1+g2+store=%.0f barrier=%.0f g3=%.0f | loop total/chunk=%.0f | prologue=%.0f loop=%.0f epilogue=%.0f' % (
+    name, tile, int(n[0, 0]), *np.median(per.reshape(-1, 4), axis=0), np.median(st[..., 4] / n), np.median(st[..., 7]), np.median(st[..., 4]), np.median(st[..., 5])))
 print('  spread of mfma phase per chunk: min %.0f max %.0f' % (per[..., 1].min(), per[..., 1].max()))
