@@ -148,20 +148,32 @@ def test_localizer_gradients_parity():
 
 
 def test_three_iteration_trajectory():
+    """Loss trajectory over 3 joint steps.  Adam's first steps are sign-like (|update| ~ lr whatever the
+    gradient magnitude), so fp32 rounding noise in near-zero gradients is amplified step by step; the
+    tolerance is therefore tied to how far the fp32 ORACLE itself drifts from the fp64 oracle."""
     B, H, W, crop = 4, 64, 64, (16, 16)
-    loc, dis = build_pair(7, crop)
+    np.random.seed(7)
+    loc = loans_amd.SheepLocalizer(crop)
+    dis = loans_amd.ResnetAssessor()
+    loc.param_predictor.W.set_logical((2e-3 * np.random.RandomState(3).standard_normal((6, 512))).astype(np.float32))
     frames, real, labels = inputs(8, B, H, W, crop)
     with loans_amd.using_config('enable_backprop', False):
         dis(dev(real))
-    lp, dp = oracle_params(loc, np.float32), oracle_params(dis, np.float32)
+    lp32, dp32 = oracle_params(loc, np.float32), oracle_params(dis, np.float32)
+    lp64, dp64 = oracle_params(loc, np.float64), oracle_params(dis, np.float64)
     upd = _updater(loc, dis, frames, real, labels)
-    og, od = M.AdamAMSGrad(lp), M.AdamAMSGrad(dp)
+    o32 = (M.AdamAMSGrad(lp32), M.AdamAMSGrad(dp32))
+    o64 = (M.AdamAMSGrad(lp64), M.AdamAMSGrad(dp64))
+    f64 = [a.astype(np.float64) for a in (frames, real, labels)]
     for it in range(3):
-        res = M.update_core(lp, dp, og, od, frames, real, labels, crop, rng=np.random.RandomState(0))
+        r32 = M.update_core(lp32, dp32, o32[0], o32[1], frames, real, labels, crop, rng=np.random.RandomState(0))
+        r64 = M.update_core(lp64, dp64, o64[0], o64[1], f64[0], f64[1], f64[2], crop, rng=np.random.RandomState(0))
         upd.update()
         obs = loans_amd.reporter.observation
-        np.testing.assert_allclose(float(obs['loss_localizer']), res['loss_localizer'], rtol=2e-3, atol=1e-5)
-        np.testing.assert_allclose(float(obs['loss_dis']), res['loss_dis'], rtol=2e-3, atol=1e-5)
+        for key in ('loss_localizer', 'loss_dis'):
+            got, ref = float(obs[key]), r64[key]
+            tol = max(5 * abs(r32[key] - ref), 5e-4 * abs(ref), 1e-5)
+            assert abs(got - ref) <= tol, (it, key, got, ref, r32[key], tol)
     assert upd.iteration == 3
 
 

@@ -1,0 +1,129 @@
+"""World-size-2 gloo tests (CPU) of the data-parallel path: the communicator sums the flat
+gradient arena in buckets, the optimiser folds 1/world_size into the Adam kernel's grad_scale, the
+batch-SUM regulariser (OutOfImageLoss, common/utils.py:315) is pre-scaled by the world size so that
+averaged gradients equal the global-batch gradient, and rank 0's parameters are broadcast."""
+import os
+import socket
+
+import numpy as np
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(('127.0.0.1', 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+class _FakeArena:
+    def __init__(self, n, rank):
+        self.numel = n
+        self.device = torch.device('cpu')
+        self.data = torch.full((n,), float(rank + 1))
+        self.grad = torch.arange(n, dtype=torch.float32) * (rank + 1)
+
+
+def _worker(rank, world, port, out):
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank))
+    from loans_amd import parallel
+    comm = parallel.init_from_env(backend='gloo')
+    assert (comm.size, comm.rank) == (world, rank)
+
+    # 1. bucketed all-reduce of the gradient arena (bucket smaller than the arena -> several collectives)
+    parallel.BUCKET_FLOATS = 1000
+    arena = _FakeArena(4097, rank)
+    comm.allreduce_grad(arena)
+    expect = torch.arange(4097, dtype=torch.float32) * sum(r + 1 for r in range(world))
+    assert torch.equal(arena.grad, expect)
+
+    # 2. gradient averaging == global-batch gradient for the CPU oracle's joint step, with the SUM-type
+    #    regulariser scaled by the world size on every rank and BN statistics local to the shard
+    from oracle import model as M
+    from oracle import chainer_ops as C
+    from loans_amd.datasets import synthetic
+    crop = (16, 16)
+    rng = np.random.RandomState(0)                       # identical initial weights on every rank
+    lp = M.cast_params(M.init_localizer_params(rng, predictor_w_std=5e-2), np.float64)
+    frames = synthetic.make_frames(10 + rank, 2, 64, 64).astype(np.float64)        # this rank's shard
+    loc = M.Localizer(lp, crop, train=True, rng=np.random.RandomState(0))
+    rois, points = loc.forward(frames)
+    l_dir, g_dir = C.direction_loss(points, (64, 64))
+    l_oob, g_oob = C.out_of_image_loss(points)
+    grads = {}
+    loc.backward(None, g_dir + world * g_oob, grads)      # OutOfImageLossCalculator.batch_sum_scale = world
+    keys = sorted(grads)
+    flat = torch.from_numpy(np.concatenate([grads[k].ravel() for k in keys]))
+    fake = _FakeArena(flat.numel(), rank)
+    fake.grad = flat.clone()
+    comm.allreduce_grad(fake)
+    averaged = (fake.grad / world).numpy()
+    # every rank can recompute all shards locally: mean of the mean-type loss + SUM of the sum-type loss
+    total = None
+    for r in range(world):
+        lpr = M.cast_params(M.init_localizer_params(np.random.RandomState(0), predictor_w_std=5e-2), np.float64)
+        fr = synthetic.make_frames(10 + r, 2, 64, 64).astype(np.float64)
+        lr = M.Localizer(lpr, crop, train=True, rng=np.random.RandomState(0))
+        _, pr = lr.forward(fr)
+        gd = C.direction_loss(pr, (64, 64))[1]
+        go = C.out_of_image_loss(pr)[1]
+        gr = {}
+        lr.backward(None, gd / world + go, gr)           # d/dtheta [ mean_r(dir_r) + sum_r(oob_r) ]
+        v = np.concatenate([gr[k].ravel() for k in keys])
+        total = v if total is None else total + v
+    np.testing.assert_allclose(averaged, total, rtol=1e-9, atol=1e-12)
+
+    # 3. max-reduce used by bench.py's timing, and the barrier
+    assert comm.allreduce_max(float(rank)) == float(world - 1)
+    comm.barrier()
+    if rank == 0:
+        out.put('ok')
+    dist.destroy_process_group()
+
+
+def test_two_rank_gloo_data_parallel():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=240)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    assert q.get(timeout=5) == 'ok'
+
+
+def test_updater_scales_batch_sum_regulariser_by_world_size():
+    import loans_amd
+    from loans_amd.runtime import training
+
+    class Comm:
+        size, rank = 4, 1
+
+    np.random.seed(0)
+    loc, dis = loans_amd.SheepLocalizer((16, 16)), loans_amd.ResnetAssessor()
+    upd = loans_amd.SheepAssessor(models=[loc, dis], iterator={'main': iter(()), 'real': iter(())},
+                                  optimizer={'opt_gen': loans_amd.Adam(amsgrad=True).setup(loc),
+                                             'opt_dis': loans_amd.Adam(amsgrad=True).setup(dis)},
+                                  converter=training.identity_converter, device=0, comm=Comm())
+    assert upd.regularizers[1].batch_sum_scale == 4.0
+    assert isinstance(upd.regularizers[0], loans_amd.DirectionLossCalculator)
+    upd1 = loans_amd.SheepAssessor(models=[loc, dis], iterator={'main': iter(()), 'real': iter(())},
+                                   optimizer={'opt_gen': loans_amd.Adam(amsgrad=True).setup(loc),
+                                              'opt_dis': loans_amd.Adam(amsgrad=True).setup(dis)},
+                                   converter=training.identity_converter, device=0)
+    assert upd1.regularizers[1].batch_sum_scale == 1.0
+
+
+def test_adam_lr_schedule_matches_chainer():
+    import loans_amd
+    from oracle import chainer_ops as C
+    opt = loans_amd.Adam(alpha=1e-3, amsgrad=True)
+    for t in (1, 2, 10, 1000):
+        opt.t = t
+        assert abs(opt.lr - C.adam_lr(1e-3, .9, .999, t)) < 1e-18
