@@ -132,6 +132,7 @@ def main():
     log, ops.EVENT_LOG = ops.EVENT_LOG, None
 
     if rank != 0:
+        parallel.shutdown()
         return
     ms_per_step = elapsed / args.steps * 1e3
     value = B * world * args.steps / elapsed
@@ -165,7 +166,8 @@ def main():
     }
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(args, hw, crop)
-    print(json.dumps(out))
+    print(json.dumps(out), flush=True)
+    parallel.shutdown()
 
 
 if __name__ == '__main__':

@@ -19,15 +19,20 @@ import torch.distributed as dist
 BUCKET_FLOATS = 16 * 1024 * 1024      # 64 MiB buckets: the localizer's active gradients are one bucket
 
 
+# LOANS_DIST_SELFTEST=1 issues every collective even at world size 1 (exercises the RCCL path on a 1-GPU box)
+_SELFTEST = os.environ.get('LOANS_DIST_SELFTEST', '0') == '1'
+
+
 class Communicator:
     def __init__(self, group=None):
         self.group = group
         self.size = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
+        self.active = dist.is_initialized() and (self.size > 1 or _SELFTEST)
 
     def bcast_data(self, link):
         """Rank 0's parameters and persistents to everyone (once, after construction)."""
-        if self.size == 1:
+        if not self.active:
             return
         arena = link.arena or link.finalize()
         dist.broadcast(arena.data, src=0, group=self.group)
@@ -38,7 +43,7 @@ class Communicator:
 
     def allreduce_grad(self, arena):
         """Sum the gradient arena over all ranks, in place, in large buckets."""
-        if self.size == 1:
+        if not self.active:
             return
         g = arena.grad[:getattr(arena, 'active_numel', arena.numel)]
         n = g.numel()
@@ -47,20 +52,20 @@ class Communicator:
 
     def allreduce_max(self, value):
         t = torch.tensor([value], dtype=torch.float64, device='cuda' if torch.cuda.is_available() else 'cpu')
-        if self.size > 1:
+        if self.active:
             dist.all_reduce(t, op=dist.ReduceOp.MAX, group=self.group)
         return float(t.item())
 
     def barrier(self):
-        if self.size > 1:
+        if self.active:
             dist.barrier(group=self.group)
 
 
 def init_from_env(backend=None):
     """Join the process group torchrun described (RANK / LOCAL_RANK / WORLD_SIZE / MASTER_*)."""
     world = int(os.environ.get('WORLD_SIZE', '1'))
-    if world == 1:
-        return Communicator() if not dist.is_initialized() else Communicator()
+    if world == 1 and not (_SELFTEST and 'RANK' in os.environ):
+        return Communicator()
     local_rank = int(os.environ.get('LOCAL_RANK', os.environ.get('RANK', '0')))
     if backend is None:
         backend = 'nccl' if torch.cuda.is_available() else 'gloo'
@@ -76,3 +81,8 @@ def create_multi_node_optimizer(optimizer, comm):
     """Attach a communicator to an optimiser (ChainerMN's name for the same thing)."""
     optimizer.comm = comm
     return optimizer
+
+
+def shutdown():
+    if dist.is_initialized():
+        dist.destroy_process_group()

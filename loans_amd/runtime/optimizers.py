@@ -63,7 +63,7 @@ class Adam:
         arena = self._ensure_state()
         ops.join_side_stream(arena.device)     # all weight gradients of this step have landed
         grad_scale = 1.0
-        if self.comm is not None and self.comm.size > 1:
+        if self.comm is not None and getattr(self.comm, 'active', self.comm.size > 1):
             self.comm.allreduce_grad(arena)
             grad_scale = 1.0 / self.comm.size
         self.t += 1

@@ -1,0 +1,130 @@
+#!/usr/bin/env python
+"""The reference's training driver (train_sheep_localizer.py:50-255) for the MI355X build: same wiring
+(datasets -> iterators -> SheepLocalizer / ResnetAssessor -> two Adam(amsgrad=True) -> SheepAssessor ->
+loop), same flags where they touch the hot path.  Datasets are the seeded synthetic paste-and-crop
+generator (the PIL / imgaug datasets are SURVEY §8f.2); the Trainer extensions that are not on the path
+(BBOXPlotter, Logger, interactive prompt, dump_graph) are intentionally absent.
+
+    python train_sheep_localizer.py --use-resnet-18 -b 64 --iterations 20
+    python -m torch.distributed.run --nproc-per-node 8 train_sheep_localizer.py --use-resnet-18 -b 128
+"""
+import argparse
+import os
+import time
+
+import numpy as np
+import torch
+
+import loans_amd
+from loans_amd import parallel
+from loans_amd.datasets import synthetic
+from loans_amd.runtime import training
+
+
+class SyntheticFrames:
+    """`ImageDataset` stand-in: float32 CHW RGB frames in [0,1] (common/datasets/image_dataset.py:47-98)."""
+
+    def __init__(self, n, image_size, seed=0):
+        self.frames = synthetic.make_frames(seed, n, image_size[0], image_size[1])
+
+    def __len__(self):
+        return len(self.frames)
+
+    def __getitem__(self, i):
+        return self.frames[i]
+
+
+class SyntheticAssessorSamples:
+    """`LabeledImageDataset` stand-in: (crop, IoU label, zeros(1)) triples (image_dataset.py:180-181)."""
+
+    def __init__(self, n, target_size, seed=1):
+        self.x, self.y = synthetic.make_assessor_batch(seed, n, target_size[0], target_size[1])
+
+    def __len__(self):
+        return len(self.x)
+
+    def __getitem__(self, i):
+        return self.x[i], self.y[i], np.zeros(1, np.float32)
+
+
+def load_pretrained_model(model_file, model):
+    loans_amd.load_npz(model_file, model, strict=False)       # NpzDeserializer(strict=False), reference :45-47
+
+
+def main():
+    parser = argparse.ArgumentParser(description="Train a sheep localizer (MI355X-native LoANs hot path)")
+    parser.add_argument("--image-size", type=int, nargs=2, default=(224, 224), help="input size for localizer")
+    parser.add_argument("--target-size", type=int, nargs=2, default=(75, 75), help="crop size for each image")
+    parser.add_argument("-b", "--batch-size", type=int, default=16, help="batch size for training (per GPU)")
+    parser.add_argument("-g", "--gpu", type=int, default=0, help="gpu id to use")
+    parser.add_argument("--lr", "--learning-rate", dest="learning_rate", type=float, default=0.001)
+    parser.add_argument("-l", "--log-dir", default='sheep_logs')
+    parser.add_argument("--iterations", type=int, default=20)
+    parser.add_argument("--dataset-size", type=int, default=256)
+    parser.add_argument("--snapshot-interval", type=int, default=0, help="0 = only at the end")
+    parser.add_argument("--log-interval", type=int, default=5)
+    parser.add_argument("--rl", dest="resume_localizer")
+    parser.add_argument("--rd", dest="resume_discriminator")
+    parser.add_argument("--use-resnet-18", action='store_true', default=False)
+    parser.add_argument("--localizer-target", type=float, default=1.0)
+    args = parser.parse_args()
+
+    comm = parallel.init_from_env()
+    if comm.size > 1:
+        args.gpu = int(os.environ.get('LOCAL_RANK', '0'))
+    torch.cuda.set_device(args.gpu)
+
+    train_dataset = SyntheticFrames(args.dataset_size, args.image_size, seed=10 + comm.rank)
+    reference_dataset = SyntheticAssessorSamples(args.dataset_size, args.target_size, seed=1000 + comm.rank)
+    data_iter = training.MultithreadIterator(train_dataset, args.batch_size)
+    reference_iter = training.MultithreadIterator(reference_dataset, args.batch_size)
+
+    if not args.use_resnet_18:
+        raise SystemExit("Resnet50SheepLocalizer (config 5) is not built yet: pass --use-resnet-18")
+    localizer = loans_amd.SheepLocalizer(args.target_size)
+    if args.resume_localizer is not None:
+        load_pretrained_model(args.resume_localizer, localizer)
+    discriminator = loans_amd.ResnetAssessor(output_dim=1)
+    with loans_amd.using_config('enable_backprop', False):      # resolves Linear(None, 1) like the first Chainer call
+        discriminator(torch.zeros((1, 3) + tuple(args.target_size), device='cuda'))
+    if args.resume_discriminator is not None:
+        load_pretrained_model(args.resume_discriminator, discriminator)
+    localizer.to_gpu(args.gpu)
+    comm.bcast_data(localizer)
+    comm.bcast_data(discriminator)
+
+    localizer_optimizer = loans_amd.Adam(alpha=args.learning_rate, amsgrad=True)
+    localizer_optimizer.setup(localizer)
+    discriminator_optimizer = loans_amd.Adam(alpha=args.learning_rate, amsgrad=True)
+    discriminator_optimizer.setup(discriminator)
+    parallel.create_multi_node_optimizer(localizer_optimizer, comm)
+    parallel.create_multi_node_optimizer(discriminator_optimizer, comm)
+
+    updater = loans_amd.SheepAssessor(
+        models=[localizer, discriminator],
+        iterator={'main': data_iter, 'real': reference_iter},
+        optimizer={'opt_gen': localizer_optimizer, 'opt_dis': discriminator_optimizer},
+        device=args.gpu, comm=comm, create_pca=False,
+        resume_discriminator=args.resume_discriminator, localizer_target=args.localizer_target)
+
+    os.makedirs(args.log_dir, exist_ok=True)
+    t0 = time.time()
+    for _ in range(args.iterations):
+        updater.update()
+        it = updater.iteration
+        if comm.rank == 0 and (it % args.log_interval == 0 or it == args.iterations):
+            obs = loans_amd.reporter.observation
+            print('iteration %4d  epoch %d  loss_localizer %.5f  loss_dis %.5f  (%.1f s)' % (
+                it, updater.epoch, float(obs['loss_localizer']), float(obs['loss_dis']), time.time() - t0), flush=True)
+        if comm.rank == 0 and args.snapshot_interval and it % args.snapshot_interval == 0:
+            for model in (localizer, discriminator):
+                loans_amd.save_npz(os.path.join(args.log_dir, '%s_%d.npz' % (model.__class__.__name__, it)), model)
+    if comm.rank == 0:
+        for model in (localizer, discriminator):
+            loans_amd.save_npz(os.path.join(args.log_dir, '%s_%d.npz' % (model.__class__.__name__, updater.iteration)), model)
+        bboxes, rois, scores, _ = localizer.predict([train_dataset[0]])
+        print('predict() on frame 0: bbox (top,left,bottom,right) =', np.round(bboxes[0], 2).tolist())
+
+
+if __name__ == "__main__":
+    main()
