@@ -1,0 +1,34 @@
+#!/usr/bin/env python
+"""Summarise a `rocprofv3 --kernel-trace --output-format csv` run of bench.py: per-kernel totals of the LAST
+step and the 21 ResNet-18 conv-forward launches (the ones bench.py's `roofline` times with HIP events)."""
+import collections
+import csv
+import glob
+import re
+import sys
+
+path = sys.argv[1]
+f = glob.glob(path + '/*/*kernel_trace.csv')[0]
+rows = list(csv.DictReader(open(f)))
+names = [r['Kernel_Name'] for r in rows]
+prep = [i for i, n in enumerate(names) if 'prep_kernel' in n]
+seg = rows[prep[-2]:prep[-1]]
+dur = lambda r: (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3     # noqa: E731
+short = lambda n: (re.search(r'(\w+_kernel(<[^>]*>)?)', n) or re.search(r'(.{0,40})', n)).group(1)   # noqa: E731
+tot, cnt = collections.Counter(), collections.Counter()
+for r in seg:
+    k = 'torch fill/copy' if 'at::native' in r['Kernel_Name'] else short(r['Kernel_Name'])
+    tot[k] += dur(r)
+    cnt[k] += 1
+span = (int(seg[-1]['End_Timestamp']) - int(seg[0]['Start_Timestamp'])) / 1e3
+print('one step (prep_kernel to prep_kernel): span %.1f us, sum of kernel durations %.1f us (two streams overlap)' % (span, sum(tot.values())))
+for k, v in tot.most_common(30):
+    print('%10.1f us %5d launches  avg %9.1f us  %s' % (v, cnt[k], v / cnt[k], k))
+fwd = [r for r in seg if 'igemm_kernel' in r['Kernel_Name']][:21]
+t = sum(dur(r) for r in fwd)
+B = 256
+flop = B * 4166615040
+print('\nResNet-18 conv forward: 21 igemm launches, %.1f us total, avg %.1f us per launch' % (t, t / 21))
+print('algorithmic FLOP per step %d -> %.2f TFLOP/s = %.1f %% of the 157.3 TFLOP/s fp32 MFMA peak' % (flop, flop / t / 1e6, flop / t / 1e6 / 157.3 * 100))
+for r in fwd:
+    print('   %-40s grid %9s  %8.1f us' % (short(r['Kernel_Name']), r['Grid_Size_X'], dur(r)))
