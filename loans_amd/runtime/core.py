@@ -446,7 +446,23 @@ class ParamArena:
 
     def __init__(self, root, device):
         self.device = device
-        self.params = [p for _, p in root.namedparams()]
+        named = list(root.namedparams())
+        # parameters of links listed in root.cold_links (e.g. res6 / res7, which only run on frames
+        # taller than 224 / 300 px) go to the END of the arena, so that memset / Adam / all-reduce can
+        # be restricted to the prefix that is in use (`active_numel`)
+        cold = tuple('/' + n + '/' for n in getattr(root, 'cold_links', ()))
+        hot = [(k, p) for k, p in named if not k.startswith(cold)]
+        self.cold_offsets = {}
+        self.params = [p for _, p in hot]
+        total = 0
+        for p in self.params:
+            total += (p.size + 3) // 4 * 4
+        for name in getattr(root, 'cold_links', ()):
+            self.cold_offsets[name] = total
+            grp = [p for k, p in named if k.startswith('/' + name + '/')]
+            self.params += grp
+            for p in grp:
+                total += (p.size + 3) // 4 * 4
         total = 0
         self.offsets = []
         for p in self.params:
@@ -464,12 +480,16 @@ class ParamArena:
             v = getattr(link, n)
             if isinstance(v, np.ndarray) and v.dtype.kind == 'f':
                 object.__setattr__(link, n, torch.from_numpy(v.astype(np.float32)).to(device))
-        self._clean = True
+        self.active_numel = total
+
+    def set_active(self, first_unused_cold_link=None):
+        """Everything from `first_unused_cold_link` on is not touched by the current graph."""
+        self.active_numel = self.cold_offsets.get(first_unused_cold_link, self.numel)
 
     def zero_grads(self):
         from .. import ops
         ops.join_side_stream(self.device)      # weight-gradient kernels still in flight write here
-        self.grad.zero_()
+        self.grad[:self.active_numel].zero_()
 
 
 # --------------------------------------------------------------------------- #

@@ -69,5 +69,6 @@ class Adam:
         self.t += 1
         hp = self.hyperparam
         m, v, vhat = self._state
-        ops.adam_amsgrad(arena.data, arena.grad, m, v, vhat, self.lr, hp.beta1, hp.beta2, hp.eps, hp.eta,
-                         hp.weight_decay_rate, grad_scale)
+        n = arena.active_numel       # parameters outside the active prefix have no gradient: Chainer skips them too
+        ops.adam_amsgrad(arena.data[:n], arena.grad[:n], m[:n], v[:n], vhat[:n], self.lr, hp.beta1, hp.beta2,
+                         hp.eps, hp.eta, hp.weight_decay_rate, grad_scale)

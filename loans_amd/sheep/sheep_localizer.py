@@ -46,6 +46,7 @@ class SheepLocalizer(Chain):
             transform_bias[[2, 5]] = 0
             self.param_predictor.W.host[...] = 0
 
+        self.cold_links = ('res6', 'res7')          # arena tail: only used on frames taller than 224 / 300 px
         self.visual_backprop_anchors = []
         self.out_size = tuple(out_size)
         self.transform_rois_to_grayscale = transform_rois_to_grayscale
@@ -57,6 +58,8 @@ class SheepLocalizer(Chain):
             images.device if torch.is_tensor(images) and images.is_cuda else torch.device('cuda', torch.cuda.current_device()))
         self.finalize(device)
         images = _as_device_batch(images, device)
+        height = images.shape[-2]
+        self.arena.set_active('res6' if height <= 224 else ('res7' if height <= 300 else None))
 
         input_images = self.prepare_images(images)
         h = self.feature_extractor(input_images)

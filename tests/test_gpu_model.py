@@ -27,7 +27,8 @@ def _updater(loc, dis, frames, real, labels, lr=1e-3, **kw):
         device=0, **kw)
 
 
-@pytest.mark.parametrize("shape", [(4, 64, 64, (16, 16)), (2, 224, 224, (75, 75)), (2, 256, 232, (32, 24))])
+@pytest.mark.parametrize("shape", [(4, 64, 64, (16, 16)), (2, 224, 224, (75, 75)), (2, 256, 232, (32, 24)),
+                                   (2, 320, 304, (20, 28))])    # > 224: res6 runs; > 300: res6 and res7 (sheep_localizer.py:51-55)
 def test_localizer_assessor_forward_parity(shape):
     B, H, W, crop = shape
     loc, dis = build_pair(0, crop)
