@@ -9,6 +9,7 @@ from .runtime.core import (Variable, Function, Link, Chain, ChainList, Parameter
 from .runtime.optimizers import Adam  # noqa: F401
 from .sheep.sheep_localizer import SheepLocalizer  # noqa: F401
 from .sheep.sheep_updater import SheepAssessor, SheepUpdater  # noqa: F401
+from .sheep.sheep_evaluator import SheepMAPEvaluator  # noqa: F401
 from .common.net import ResnetAssessor  # noqa: F401
 from .common.utils import Size, DirectionLossCalculator, OutOfImageLossCalculator  # noqa: F401
 from .functions.rotation_dropout import rotation_dropout, RotationDropout  # noqa: F401

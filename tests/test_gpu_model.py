@@ -229,3 +229,19 @@ def test_snapshot_roundtrip_chainer_keys(tmp_path):
     a, b = loc.state_dict_chainer(), loc2.state_dict_chainer()
     for k in a:
         np.testing.assert_array_equal(a[k], b[k], err_msg=k)
+
+
+def test_map_evaluator_on_fresh_localizer():
+    """sheep/sheep_evaluator.py:32-66: a fresh localizer predicts [22.4, 22.4, 201.6, 201.6] for any frame
+    (KAT 1), so ground truth equal to that box gives mean IoU 1 and AP 1; a disjoint box gives 0."""
+    np.random.seed(0)
+    loc = loans_amd.SheepLocalizer((75, 75))
+    frames, _, _ = inputs(21, 3, 224, 224, (75, 75))
+    ev = loans_amd.SheepMAPEvaluator(loc, 0)
+    gt = np.tile(np.array([[[22.4, 22.4, 201.6, 201.6]]], np.float32), (3, 1, 1))
+    res = ev(dev(frames), dev(gt))
+    np.testing.assert_allclose(res['mean_iou'], 1.0, rtol=1e-5)
+    assert res['map'] == 1.0 and loans_amd.reporter.observation['ap/sheep'] == 1.0
+    gt2 = np.tile(np.array([[[0.0, 0.0, 10.0, 10.0]]], np.float32), (3, 1, 1))
+    res = ev(dev(frames), dev(gt2))
+    assert res['mean_iou'] == 0.0 and res['map'] == 0.0
