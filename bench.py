@@ -40,6 +40,7 @@ def parse():
     ap.add_argument('--batch', type=int, default=0, help='per-GPU batch (default 256 at N=1, 128 at N>1)')
     ap.add_argument('--image-size', type=int, default=224)
     ap.add_argument('--target-size', type=int, default=75)
+    ap.add_argument('--resnet50', action='store_true', help='Resnet50SheepLocalizer backbone (BASELINE configs[4] architecture, fp32)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=8)
     ap.add_argument('--cpu-iters', type=int, default=2)
@@ -98,8 +99,9 @@ def main():
 
     # ---- models (random init; param_predictor.W seeded non-zero so the backbone gets gradients) ----
     np.random.seed(1234)
-    localizer = loans_amd.SheepLocalizer((crop, crop))
-    localizer.param_predictor.W.set_logical((1e-3 * np.random.standard_normal((6, 512))).astype(np.float32))
+    localizer = (loans_amd.Resnet50SheepLocalizer if args.resnet50 else loans_amd.SheepLocalizer)((crop, crop))
+    localizer.param_predictor.W.set_logical(
+        (1e-3 * np.random.standard_normal(localizer.param_predictor.W.logical_shape)).astype(np.float32))
     discriminator = loans_amd.ResnetAssessor()
     with loans_amd.using_config('enable_backprop', False):
         discriminator(real_d[:2])                     # materialise the lazy l4, build the arenas
@@ -147,24 +149,25 @@ def main():
         achieved = tot_flop / (tot_ms * 1e-3) / 1e12
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
                     "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
-                    "kernel": "igemm_kernel (ResNet-18 conv forward, %d launches/step)" % (n_launch // args.steps),
+                    "kernel": "igemm_kernel (localizer conv forward, %d launches/step)" % (n_launch // args.steps),
                     "avg_launch_ms": round(tot_ms / max(n_launch, 1), 4),
                     "conv_fwd_ms_per_step": round(tot_ms / args.steps, 3),
                     "algorithmic_flop_per_step": tot_flop // args.steps}
-        if hw == 224:
+        if hw == 224 and not args.resnet50:
             assert tot_flop // args.steps == B * CONV_FWD_FLOP_PER_IMAGE_224, (tot_flop // args.steps, B)
 
+    backbone = "ResNet-50" if args.resnet50 else "ResNet-18"
     out = {
         "metric": "localizer+assessor train images/sec", "value": round(value, 2), "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-        "config": {"workload": "LoANs joint step: ResNet-18 localizer + STN crop + assessor, fwd+bwd+2xAdam-AMSGrad",
+        "config": {"workload": "LoANs joint step: %s localizer + STN crop + assessor, fwd+bwd+2xAdam-AMSGrad" % backbone,
                    "per_gpu_batch": B, "global_batch": B * world, "frame": "3x%dx%d" % (hw, hw),
                    "crop": "3x%dx%d" % (crop, crop), "parallelism": "dp%d" % world,
                    "baseline_config": "configs[1]" if world == 1 else "configs[3]"},
         "roofline": roofline,
     }
-    if world == 1 and not args.no_cpu_baseline:
+    if world == 1 and not args.no_cpu_baseline and not args.resnet50:
         out["cpu_baseline"] = cpu_baseline(args, hw, crop)
     print(json.dumps(out), flush=True)
     parallel.shutdown()

@@ -7,7 +7,8 @@ Public surface mirrors the reference's (Bartzi/loans) for this path:
 from .runtime.core import (Variable, Function, Link, Chain, ChainList, Parameter, config, using_config,  # noqa: F401
                            report, reporter, save_npz, load_npz)
 from .runtime.optimizers import Adam  # noqa: F401
-from .sheep.sheep_localizer import SheepLocalizer  # noqa: F401
+from .sheep.sheep_localizer import SheepLocalizer, Resnet50SheepLocalizer  # noqa: F401
+from .iou.iou_regressor import MyResNet50Layers  # noqa: F401
 from .sheep.sheep_updater import SheepAssessor, SheepUpdater  # noqa: F401
 from .sheep.sheep_evaluator import SheepMAPEvaluator  # noqa: F401
 from .common.net import ResnetAssessor  # noqa: F401

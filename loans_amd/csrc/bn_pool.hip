@@ -140,11 +140,13 @@ template <bool DUAL, bool MASK>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* gy, const float* mask, const float* x,
                                                             const float* mean, const float* rstd, const float* x2,
                                                             const float* mean2, const float* rstd2, double* sums,
-                                                            int64_t rows, int C4, int rows_per_block) {
+                                                            int64_t rows, int C4, int C4T, int rows_per_block) {
     constexpr int NS = DUAL ? 3 : 2;
     __shared__ f32x4 red[NS][256];
+    // channels are processed in slabs of C4 (<= 256) float4 groups; blockIdx.y picks the slab, C4T = all groups
     const int tid = threadIdx.x;
-    const int cg = tid % C4, rl = tid / C4, RL = 256 / C4;
+    const int cl = tid % C4, rl = tid / C4, RL = 256 / C4;
+    const int cg = blockIdx.y * C4 + cl;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     int64_t r1 = r0 + rows_per_block;
     if (r1 > rows) r1 = rows;
@@ -154,7 +156,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* gy, con
     f32x4 sg = {0.f, 0.f, 0.f, 0.f}, sgx = sg, sgx2 = sg;
     if (rl < RL) {
         for (int64_t r = r0 + rl; r < r1; r += RL) {
-            const int64_t o = (r * C4 + cg) * 4;
+            const int64_t o = (r * C4T + cg) * 4;
             f32x4 g = ld4(gy + o);
             if (MASK) g = maskpos4(g, ld4(mask + o));
             sg += g;
@@ -172,7 +174,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* gy, con
             sgx += red[1][tid + k * C4];
             if (DUAL) sgx2 += red[2][tid + k * C4];
         }
-        const int C = C4 * 4;
+        const int C = C4T * 4;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             atomic_add_f64(sums + cg * 4 + e, (double)sg[e]);
@@ -212,16 +214,17 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* gy, cons
     }
 }
 
-__global__ __launch_bounds__(256) void colsum_kernel(const float* x, float* out, int64_t rows, int C4, int rows_per_block) {
+__global__ __launch_bounds__(256) void colsum_kernel(const float* x, float* out, int64_t rows, int C4, int C4T, int rows_per_block) {
     __shared__ f32x4 red[256];
     const int tid = threadIdx.x;
-    const int cg = tid % C4, rl = tid / C4, RL = 256 / C4;
+    const int cl = tid % C4, rl = tid / C4, RL = 256 / C4;
+    const int cg = blockIdx.y * C4 + cl;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     int64_t r1 = r0 + rows_per_block;
     if (r1 > rows) r1 = rows;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (rl < RL)
-        for (int64_t r = r0 + rl; r < r1; r += RL) s += ld4(x + (r * C4 + cg) * 4);
+        for (int64_t r = r0 + rl; r < r1; r += RL) s += ld4(x + (r * C4T + cg) * 4);
     red[tid] = s;
     __syncthreads();
     if (tid < C4) {
@@ -231,9 +234,12 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* x, float* out,
     }
 }
 
-int reduce_geometry(int64_t rows, int C, int* rows_per_block) {
-    // C4 must divide into a 256-thread block
-    const int C4 = C / 4;
+// channel slabs: C4 = float4 groups per block (<= 256, divides 256), *slabs = number of slabs
+int reduce_geometry(int64_t rows, int C, int* rows_per_block, int* c4_block, int* slabs) {
+    const int C4T = C / 4;
+    const int C4 = C4T > 256 ? 256 : C4T;
+    *c4_block = C4;
+    *slabs = C4T / C4;
     const int RL = 256 / C4;
     int64_t rpb = ((rows + 1023) / 1024 + RL - 1) / RL * RL;   // <= 1024 blocks
     if (rpb < 8 * RL) rpb = 8 * RL;
@@ -241,7 +247,12 @@ int reduce_geometry(int64_t rows, int C, int* rows_per_block) {
     return (int)((rows + rpb - 1) / rpb);
 }
 
-bool chan_ok(int C) { return C >= 4 && (C & 3) == 0 && C <= 1024 && (256 % (C / 4) == 0 || (C / 4) <= 256); }
+// C/4 float4 groups must tile 256-thread blocks: a divisor of 256, or a multiple of 256 (slabs)
+bool reduce_channels_ok(int C) {
+    if (C < 4 || (C & 3)) return false;
+    const int c4 = C / 4;
+    return c4 <= 256 ? (256 % c4 == 0) : (c4 % 256 == 0);
+}
 
 }  // namespace
 
@@ -311,13 +322,13 @@ extern "C" int loans_bn_bwd_reduce_f32(const float* gy, const float* mask, const
                                        const float* rstd, const float* x2, const float* mean2, const float* rstd2,
                                        double* sums, int64_t rows, int32_t C, void* stream) {
     if (!gy || !x || !mean || !rstd || !sums || rows <= 0) return LOANS_EINVAL;
-    if (C < 4 || (C & 3) || C > 1024 || 256 % (C / 4)) return LOANS_EINVAL;
+    if (!reduce_channels_ok(C)) return LOANS_EINVAL;
     if (x2 && (!mean2 || !rstd2)) return LOANS_EINVAL;
-    int rpb;
-    const int grid = reduce_geometry(rows, C, &rpb);
+    int rpb, c4b, slabs;
+    const int grid = reduce_geometry(rows, C, &rpb, &c4b, &slabs);
     hipStream_t st = as_stream(stream);
 #define LAUNCH_RED(D, M) \
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<D, M>), dim3(grid), dim3(256), 0, st, gy, mask, x, mean, rstd, x2, mean2, rstd2, sums, rows, C / 4, rpb)
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<D, M>), dim3(grid, slabs), dim3(256), 0, st, gy, mask, x, mean, rstd, x2, mean2, rstd2, sums, rows, c4b, C / 4, rpb)
     if (x2) { if (mask) LAUNCH_RED(true, true); else LAUNCH_RED(true, false); }
     else { if (mask) LAUNCH_RED(false, true); else LAUNCH_RED(false, false); }
 #undef LAUNCH_RED
@@ -354,10 +365,10 @@ extern "C" int loans_bn_bwd_apply_f32(const float* gy, const float* mask, const 
 }
 
 extern "C" int loans_colsum_f32(const float* x, float* out, int64_t rows, int32_t C, void* stream) {
-    if (!x || !out || rows <= 0 || C < 4 || (C & 3) || C > 1024 || 256 % (C / 4)) return LOANS_EINVAL;
-    int rpb;
-    const int grid = reduce_geometry(rows, C, &rpb);
-    hipLaunchKernelGGL(colsum_kernel, dim3(grid), dim3(256), 0, as_stream(stream), x, out, rows, C / 4, rpb);
+    if (!x || !out || rows <= 0 || !reduce_channels_ok(C)) return LOANS_EINVAL;
+    int rpb, c4b, slabs;
+    const int grid = reduce_geometry(rows, C, &rpb, &c4b, &slabs);
+    hipLaunchKernelGGL(colsum_kernel, dim3(grid, slabs), dim3(256), 0, as_stream(stream), x, out, rows, c4b, C / 4, rpb);
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;
 }

@@ -73,77 +73,79 @@ class StemFunction(Function):
         self.x = self.c = self.st = self.idx = None
 
 
-class BasicAFunction(Function):
-    """relu(bn2(conv2(relu(bn1(conv1(x))))) + bn3(conv3(x)))   (sheep/resnet.py:136-141).
-    inputs: x, W1, g1, b1, W2, g2, b2, W3, g3, b3."""
+class ResidualUnitFunction(Function):
+    """relu( bn_n(conv_n( ... relu(bn_1(conv_1(x))) ... )) + shortcut(x) ), shortcut = bn_s(conv_s(x)) or x.
 
-    def __init__(self, block):
-        self.blk = block
+    One node for every residual unit on the path:
+      BasicA / BasicB ............ sheep/resnet.py:136-141,156-160   (2 stages; 3x3-strided conv shortcut / identity)
+      BottleNeckA / BottleNeckB .. sheep/resnet.py:163-216 = chainer ResNet50Layers' blocks (3 stages; 1x1 shortcut / identity)
+      chainercv Bottleneck ....... Resnet50SheepLocalizer's res6 / res7 (sheep_localizer.py:131-132)
+    ``stages`` = [(conv_link, bn_link), ...], ``shortcut`` = (conv_link, bn_link) or None.
+    inputs: x, then (W, gamma, beta) per stage, then (W, gamma, beta) of the shortcut."""
+
+    def __init__(self, stages, shortcut=None):
+        self.stages, self.shortcut = list(stages), shortcut
 
     def forward(self, inputs):
-        x, W1, g1, b1, W2, g2, b2, W3, g3, b3 = inputs
-        k = self.blk
+        x = inputs[0]
+        n = len(self.stages)
         self.x = x
-        self.c1, self.st1, self.geo1 = _ConvBN.forward(x, k.conv1, k.bn1, W1, None, g1, b1)
-        self.h1 = ops.bn_apply(self.c1, self.st1, relu=True)
-        self.c2, self.st2, self.geo2 = _ConvBN.forward(self.h1, k.conv2, k.bn2, W2, None, g2, b2)
-        self.c3, self.st3, self.geo3 = _ConvBN.forward(x, k.conv3, k.bn3, W3, None, g3, b3)
-        self.out = ops.bn_apply(self.c2, self.st2, relu=True, x2=self.c3, st2=self.st3)
+        self.c, self.st, self.geo, self.h = [None] * n, [None] * n, [None] * n, [None] * n
+        h = x
+        for i, (conv, bn) in enumerate(self.stages):
+            W, g, b = inputs[1 + 3 * i:4 + 3 * i]
+            self.c[i], self.st[i], self.geo[i] = _ConvBN.forward(h, conv, bn, W, None, g, b)
+            if i < n - 1:
+                h = self.h[i] = ops.bn_apply(self.c[i], self.st[i], relu=True)
+        if self.shortcut is not None:
+            W, g, b = inputs[1 + 3 * n:4 + 3 * n]
+            self.cs, self.sts, self.geos = _ConvBN.forward(x, self.shortcut[0], self.shortcut[1], W, None, g, b)
+            self.out = ops.bn_apply(self.c[-1], self.st[-1], relu=True, x2=self.cs, st2=self.sts)
+        else:
+            self.out = ops.bn_apply(self.c[-1], self.st[-1], relu=True, residual=x)
         return self.out
 
     def backward(self, inputs, gys):
         _require_train()
-        xv, W1, g1, b1, W2, g2, b2, W3, g3, b3 = self.inputs
+        n = len(self.stages)
+        P = self.inputs
         gout = gys[0].contiguous()
-        gc2, gc3 = ops.bn_backward(gout, self.out, self.c2, self.st2, g2.data, g2.grad_view, b2.grad_view,
-                                   x2=self.c3, st2=self.st3, gamma2=g3.data, ggamma2=g3.grad_view, gbeta2=b3.grad_view)
-        ops.conv_wgrad(self.h1, gc2, W2.grad_view, self.geo2)
-        ops.conv_wgrad(self.x, gc3, W3.grad_view, self.geo3)
-        gh1 = ops.conv_dgrad(gc2, W2.data, self.geo2)
-        gc1 = ops.bn_backward(gh1, self.h1, self.c1, self.st1, g1.data, g1.grad_view, b1.grad_view)
-        ops.conv_wgrad(self.x, gc1, W1.grad_view, self.geo1)
+        Wl, gl, bl = P[1 + 3 * (n - 1):4 + 3 * (n - 1)]
+        gcs = None
+        if self.shortcut is not None:
+            Ws, gs, bs = P[1 + 3 * n:4 + 3 * n]
+            g, gcs = ops.bn_backward(gout, self.out, self.c[-1], self.st[-1], gl.data, gl.grad_view, bl.grad_view,
+                                     x2=self.cs, st2=self.sts, gamma2=gs.data, ggamma2=gs.grad_view, gbeta2=bs.grad_view)
+            ops.conv_wgrad(self.x, gcs, Ws.grad_view, self.geos)
+        else:
+            g = ops.bn_backward(gout, self.out, self.c[-1], self.st[-1], gl.data, gl.grad_view, bl.grad_view)
+        for i in range(n - 1, 0, -1):
+            W, _, _ = P[1 + 3 * i:4 + 3 * i]
+            ops.conv_wgrad(self.h[i - 1], g, W.grad_view, self.geo[i])
+            gh = ops.conv_dgrad(g, W.data, self.geo[i])
+            _, gp, bp = P[1 + 3 * (i - 1):4 + 3 * (i - 1)]
+            g = ops.bn_backward(gh, self.h[i - 1], self.c[i - 1], self.st[i - 1], gp.data, gp.grad_view, bp.grad_view)
+        W0 = P[1]
+        ops.conv_wgrad(self.x, g, W0.grad_view, self.geo[0])
         gx = None
-        if xv.requires_grad:
-            gx = ops.conv_dgrad(gc3, W3.data, self.geo3)
-            ops.conv_dgrad(gc1, W1.data, self.geo1, out=gx, addend=gx)
-        return (gx,) + (None,) * 9
+        if P[0].requires_grad:
+            if self.shortcut is not None:
+                gx = ops.conv_dgrad(gcs, P[1 + 3 * n].data, self.geos)
+                ops.conv_dgrad(g, W0.data, self.geo[0], out=gx, addend=gx)
+            else:
+                # gx = dgrad(g) + gout * (out > 0)     (identity shortcut through the final ReLU)
+                gx = ops.conv_dgrad(g, W0.data, self.geo[0], addend=gout, addend_mask_ref=self.out)
+        return (gx,) + (None,) * (len(P) - 1)
 
     def release(self):
-        self.x = self.c1 = self.c2 = self.c3 = self.h1 = self.out = None
+        self.x = self.c = self.h = self.st = self.out = self.cs = None
 
 
-class BasicBFunction(Function):
-    """relu(bn2(conv2(relu(bn1(conv1(x))))) + x)   (sheep/resnet.py:156-160).
-    inputs: x, W1, g1, b1, W2, g2, b2."""
-
-    def __init__(self, block):
-        self.blk = block
-
-    def forward(self, inputs):
-        x, W1, g1, b1, W2, g2, b2 = inputs
-        k = self.blk
-        self.x = x
-        self.c1, self.st1, self.geo1 = _ConvBN.forward(x, k.conv1, k.bn1, W1, None, g1, b1)
-        self.h1 = ops.bn_apply(self.c1, self.st1, relu=True)
-        self.c2, self.st2, self.geo2 = _ConvBN.forward(self.h1, k.conv2, k.bn2, W2, None, g2, b2)
-        self.out = ops.bn_apply(self.c2, self.st2, relu=True, residual=x)
-        return self.out
-
-    def backward(self, inputs, gys):
-        _require_train()
-        xv, W1, g1, b1, W2, g2, b2 = self.inputs
-        gout = gys[0].contiguous()
-        gc2 = ops.bn_backward(gout, self.out, self.c2, self.st2, g2.data, g2.grad_view, b2.grad_view)
-        ops.conv_wgrad(self.h1, gc2, W2.grad_view, self.geo2)
-        gh1 = ops.conv_dgrad(gc2, W2.data, self.geo2)
-        gc1 = ops.bn_backward(gh1, self.h1, self.c1, self.st1, g1.data, g1.grad_view, b1.grad_view)
-        ops.conv_wgrad(self.x, gc1, W1.grad_view, self.geo1)
-        # gx = dgrad(gc1) + gout * (out > 0)     (identity shortcut through the final ReLU)
-        gx = ops.conv_dgrad(gc1, W1.data, self.geo1, addend=gout, addend_mask_ref=self.out)
-        return (gx,) + (None,) * 6
-
-    def release(self):
-        self.x = self.c1 = self.c2 = self.h1 = self.out = None
+def residual_unit(x, stages, shortcut=None):
+    args = [x]
+    for conv, bn in list(stages) + ([shortcut] if shortcut is not None else []):
+        args += [conv.W, bn.gamma, bn.beta]
+    return ResidualUnitFunction(stages, shortcut)(*args)
 
 
 # --------------------------------------------------------------------------- #

@@ -70,6 +70,7 @@ class ConvGeometry:
         self.fwd = d
         # data gradient: gathered tensor = gy (Ho x Wo x Cout), output = gx (H x W x Cin)
         self.dgrad = []          # list of (desc, tapsel, weight_offset_in_floats)
+        self.dgrad_has_empty_class = False
         off = 0
         for cy in range(stride):
             for cx in range(stride):
@@ -79,8 +80,9 @@ class ConvGeometry:
                     continue
                 taps = [(r, s) for r in range(k) for s in range(k)
                         if (cy + pad - r) % stride == 0 and (cx + pad - s) % stride == 0]
-                if not taps:
-                    raise NotImplementedError('stride-parity class without taps (k < stride)')
+                if not taps:        # k < stride (1x1 / stride 2): this class of input pixels gets no gradient
+                    self.dgrad_has_empty_class = True
+                    continue
                 g = IgemmDesc()
                 g.B, g.inH, g.inW, g.Cin = B, self.Ho, self.Wo, Cout
                 g.outH, g.outW, g.Cout = H, W, Cin
@@ -187,6 +189,15 @@ def conv_dgrad(gy, w, geo, out=None, mask_ref=None, addend=None, addend_mask_ref
     if out is None:
         out = torch.empty((geo.B, geo.H, geo.W, geo.Cin), device=gy.device, dtype=torch.float32)
     assert gy.numel() == geo.B * geo.Ho * geo.Wo * geo.Cout
+    if geo.dgrad_has_empty_class:
+        # pixels of a tap-less stride class receive only the addend (or zero)
+        assert mask_ref is None and addend_mask_ref is None
+        if addend is None:
+            out.zero_()
+        elif addend.data_ptr() != out.data_ptr():
+            out.copy_(addend)
+        if addend is not None:
+            addend = out
     if geo.Cin == 4 and addend_mask_ref is None and geo.Cout % 32 == 0:
         # gradient w.r.t. a 4-channel (RGB) input: dedicated VALU kernel, forward weights, no re-pack
         fl = (F_MASK if mask_ref is not None else 0) | (F_ADDEND if addend is not None else 0)

@@ -89,9 +89,7 @@ class BasicA(Chain):
             self.bn3 = L.BatchNormalization(ch)
 
     def __call__(self, x):
-        return blocks.BasicAFunction(self)(
-            x, self.conv1.W, self.bn1.gamma, self.bn1.beta, self.conv2.W, self.bn2.gamma, self.bn2.beta,
-            self.conv3.W, self.bn3.gamma, self.bn3.beta)
+        return blocks.residual_unit(x, [(self.conv1, self.bn1), (self.conv2, self.bn2)], (self.conv3, self.bn3))
 
 
 class BasicB(Chain):
@@ -106,5 +104,4 @@ class BasicB(Chain):
             self.bn2 = L.BatchNormalization(ch)
 
     def __call__(self, x):
-        return blocks.BasicBFunction(self)(
-            x, self.conv1.W, self.bn1.gamma, self.bn1.beta, self.conv2.W, self.bn2.gamma, self.bn2.beta)
+        return blocks.residual_unit(x, [(self.conv1, self.bn1), (self.conv2, self.bn2)])

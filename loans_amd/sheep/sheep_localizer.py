@@ -18,6 +18,8 @@ from ..functions import (global_average_pooling_2d, linear, reshape, rotation_dr
                          spatial_transformer_grid, spatial_transformer_sampler)
 from ..functions.ops_small import ExposeNCHW
 from ..runtime.core import Chain, Variable, as_variable, config, using_config
+from ..chainercv_resnet import ResBlock
+from ..iou.iou_regressor import MyResNet50Layers
 from .resnet import BasicBlock, ResNet
 
 
@@ -116,3 +118,68 @@ class SheepLocalizer(Chain):
         bboxes = [bbox.cpu().numpy().reshape(1, -1) for bbox in bboxes]
 
         return bboxes, rois, np.ones((len(bboxes), 1)), visual_backprop
+
+
+class Resnet50SheepLocalizer(SheepLocalizer):
+    """ResNet-50 localizer (reference sheep/sheep_localizer.py:120-178): Chainer ``ResNet50Layers`` backbone
+    (taps ``res5`` / ``pool5``), chainercv ``ResBlock`` stages res6 / res7 on frames taller than 224 / 300 px,
+    ``Linear(2048, 6)``, the same STN tail."""
+
+    def __init__(self, out_size, transform_rois_to_grayscale=False, train_imagenet=False):
+        super(SheepLocalizer, self).__init__()
+        if train_imagenet:
+            raise NotImplementedError("ImageNet pre-training head is outside the LoANs training path")
+        initialW = L.HeNormal(scale=1., fan_option='fan_out')
+        keys_to_remove = ['fc6', 'prob']
+        with self.init_scope():
+            self.feature_extractor = MyResNet50Layers(keys_to_remove=keys_to_remove, pretrained_model='auto')
+            self.param_predictor = L.Linear(2048, 6)
+
+            self.res6 = ResBlock(2, 2048, 1024, 2048, 2, initialW=initialW)
+            self.res7 = ResBlock(2, 2048, 1024, 2048, 2, initialW=initialW)
+
+            transform_bias = self.param_predictor.b.host
+            transform_bias[[0, 4]] = 0.8
+            transform_bias[[2, 5]] = 0
+            self.param_predictor.W.host[...] = 0
+
+        self.cold_links = ('res6', 'res7', 'feature_extractor/fc6')
+        self.visual_backprop_anchors = []
+        self.out_size = tuple(out_size)
+        self.transform_rois_to_grayscale = transform_rois_to_grayscale
+        self.train_imagenet = train_imagenet
+
+    def __call__(self, images):
+        self.visual_backprop_anchors.clear()
+        device = images.data.device if isinstance(images, Variable) else (
+            images.device if torch.is_tensor(images) and images.is_cuda else torch.device('cuda', torch.cuda.current_device()))
+        self.finalize(device)
+        images = _as_device_batch(images, device)
+        height = images.shape[-2]
+        self.arena.set_active('res6' if height <= 224 else ('res7' if height <= 300 else 'feature_extractor/fc6'))
+
+        input_images = self.prepare_images(images)
+        h = self.feature_extractor(input_images, layers=['res5', 'pool5'])
+
+        self.visual_backprop_anchors.append(h['res5'])
+        if images.shape[-2] > 224:
+            h = h['res5']
+            h = self.res6(h)
+
+            if images.shape[-2] > 300:
+                h = self.res7(h)
+
+            h = global_average_pooling_2d(h)
+        else:
+            h = h['pool5']
+
+        transform_params = linear(h, self.param_predictor.W, self.param_predictor.b)
+        transform_params = rotation_dropout(reshape(transform_params, (-1, 2, 3)), ratio=0.0)
+        points = spatial_transformer_grid(transform_params, self.out_size)
+        rois = ExposeNCHW()(spatial_transformer_sampler(as_variable(images), points))
+        self.last_transform_params = transform_params
+
+        if self.transform_rois_to_grayscale:
+            raise NotImplementedError("grayscale rois are off on the training path (train_sheep_localizer.py:118-119)")
+
+        return rois, points

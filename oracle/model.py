@@ -179,6 +179,78 @@ class _BasicB:  # sheep/resnet.py:144-160
         return gz + self.c1.bwd(gh1 * (self.h1 > 0), grads)
 
 
+class _ResUnit:
+    """relu(bn_n(conv_n(... relu(bn_1(conv_1(x))))) + shortcut(x)); stages / shortcut = (conv_key, bn_key, stride, pad).
+    Bottleneck units of Chainer's ResNet50Layers (mirrored by sheep/resnet.py:163-216) and chainercv's ResBlock."""
+
+    def __init__(self, p, stages, shortcut, train):
+        self.stages = [_ConvBN(p, c, b, s, pad, train) for c, b, s, pad in stages]
+        self.shortcut = None if shortcut is None else _ConvBN(p, shortcut[0], shortcut[1], shortcut[2], shortcut[3], train)
+
+    def fwd(self, x):
+        self.hs = []
+        h = x
+        for i, st in enumerate(self.stages):
+            h = st.fwd(h)
+            if i < len(self.stages) - 1:
+                h = C.relu(h)
+                self.hs.append(h)
+        sc = self.shortcut.fwd(x) if self.shortcut is not None else x
+        self.out = C.relu(h + sc)
+        return self.out
+
+    def bwd(self, gy, grads):
+        gz = gy * (self.out > 0)
+        gx = self.shortcut.bwd(gz, grads) if self.shortcut is not None else gz
+        g = gz
+        for i in range(len(self.stages) - 1, 0, -1):
+            g = self.stages[i].bwd(g, grads) * (self.hs[i - 1] > 0)
+        return gx + self.stages[0].bwd(g, grads)
+
+
+RESNET50_STAGES = (('res2', 3, 64, 64, 256, 1), ('res3', 4, 256, 128, 512, 2),
+                   ('res4', 6, 512, 256, 1024, 2), ('res5', 3, 1024, 512, 2048, 2))
+
+
+def init_resnet50_localizer_params(rng, predictor_w_std=0.0):
+    """``Resnet50SheepLocalizer`` state (sheep_localizer.py:120-141): HeNormal(1.0) backbone (the Caffe
+    weights of pretrained_model='auto' are not available offline), HeNormal(fan_out) res6 / res7."""
+    p = {}
+    fe = 'feature_extractor'
+    p[fe + '/conv1/W'] = _he(rng, (64, 3, 7, 7))
+    p[fe + '/conv1/b'] = np.zeros(64, np.float32)
+    _bn(p, fe + '/bn1', 64)
+    for name, n, cin, mid, cout, _ in RESNET50_STAGES:
+        a = '%s/%s/a' % (fe, name)
+        p[a + '/conv1/W'] = _he(rng, (mid, cin, 1, 1)); _bn(p, a + '/bn1', mid)
+        p[a + '/conv2/W'] = _he(rng, (mid, mid, 3, 3)); _bn(p, a + '/bn2', mid)
+        p[a + '/conv3/W'] = _he(rng, (cout, mid, 1, 1)); _bn(p, a + '/bn3', cout)
+        p[a + '/conv4/W'] = _he(rng, (cout, cin, 1, 1)); _bn(p, a + '/bn4', cout)
+        for i in range(1, n):
+            b = '%s/%s/b%d' % (fe, name, i)
+            p[b + '/conv1/W'] = _he(rng, (mid, cout, 1, 1)); _bn(p, b + '/bn1', mid)
+            p[b + '/conv2/W'] = _he(rng, (mid, mid, 3, 3)); _bn(p, b + '/bn2', mid)
+            p[b + '/conv3/W'] = _he(rng, (cout, mid, 1, 1)); _bn(p, b + '/bn3', cout)
+
+    def he_out(shape):
+        fan_out = shape[0] * int(np.prod(shape[2:]))
+        return (rng.standard_normal(shape) * np.sqrt(2.0 / fan_out)).astype(np.float32)
+    for name in ('res6', 'res7'):
+        for blk, cin in (('a', 2048), ('b1', 2048)):
+            q = '%s/%s' % (name, blk)
+            p[q + '/conv1/conv/W'] = he_out((1024, cin, 1, 1)); _bn(p, q + '/conv1/bn', 1024)
+            p[q + '/conv2/conv/W'] = he_out((1024, 1024, 3, 3)); _bn(p, q + '/conv2/bn', 1024)
+            p[q + '/conv3/conv/W'] = he_out((2048, 1024, 1, 1)); _bn(p, q + '/conv3/bn', 2048)
+            if blk == 'a':
+                p[q + '/residual_conv/conv/W'] = he_out((2048, cin, 1, 1)); _bn(p, q + '/residual_conv/bn', 2048)
+    W = np.zeros((6, 2048), np.float32)
+    if predictor_w_std > 0:
+        W = (rng.standard_normal((6, 2048)) * predictor_w_std).astype(np.float32)
+    p['param_predictor/W'] = W
+    p['param_predictor/b'] = np.array([0.8, 0, 0, 0, 0.8, 0], np.float32)
+    return p
+
+
 class Localizer:
     """``SheepLocalizer.__call__`` with an explicit backward (sheep_localizer.py:41-70)."""
 
@@ -195,17 +267,9 @@ class Localizer:
         self.stem = _ConvBN(p, fe + '/conv1', fe + '/bn1', 2, 3, train)
         self.stem_relu = C.relu(self.stem.fwd(x))
         h, self.pool_idx = C.max_pool_fwd(self.stem_relu, 3, 2, 0)
-        names = [(fe + '/' + n, s) for n, _, s in STAGES]
-        if H > 224:
-            names.append(('res6', 2))
-            if H > 300:
-                names.append(('res7', 2))
-        for prefix, stride in names:
-            a = _BasicA(p, prefix + '/0', stride, train)
-            h = a.fwd(h)
-            b = _BasicB(p, prefix + '/1', train)
-            h = b.fwd(h)
-            self.blocks += [a, b]
+        for blk in self._make_blocks(H):
+            h = blk.fwd(h)
+            self.blocks.append(blk)
         self.feat = h
         self.pooled = C.gap_fwd(h)
         theta = C.linear_fwd(self.pooled, p['param_predictor/W'], p['param_predictor/b']).reshape(-1, 2, 3)
@@ -214,6 +278,18 @@ class Localizer:
         self.points, self.coords = C.st_grid_fwd(self.theta, self.out_size)
         self.rois = C.st_sampler_fwd(images, self.points)
         return self.rois, self.points
+
+    def _make_blocks(self, H):
+        p, train, fe = self.p, self.train, 'feature_extractor'
+        names = [(fe + '/' + n, s) for n, _, s in STAGES]
+        if H > 224:
+            names.append(('res6', 2))
+            if H > 300:
+                names.append(('res7', 2))
+        out = []
+        for prefix, stride in names:
+            out += [_BasicA(p, prefix + '/0', stride, train), _BasicB(p, prefix + '/1', train)]
+        return out
 
     def backward(self, g_rois, g_points, grads):
         p = self.p
@@ -242,6 +318,32 @@ class Localizer:
         bb[:, ::2] *= H
         bb[:, 1::2] *= W
         return bb
+
+
+class Localizer50(Localizer):
+    """``Resnet50SheepLocalizer.__call__`` (sheep_localizer.py:143-178): bottleneck backbone, stride on the
+    first 1x1 conv; res6 / res7 are chainercv ResBlocks with the stride on the 3x3 conv."""
+
+    def _make_blocks(self, H):
+        p, train, fe = self.p, self.train, 'feature_extractor'
+        out = []
+        for name, n, cin, mid, cout, stride in RESNET50_STAGES:
+            a = '%s/%s/a' % (fe, name)
+            out.append(_ResUnit(p, [(a + '/conv1', a + '/bn1', stride, 0), (a + '/conv2', a + '/bn2', 1, 1),
+                                    (a + '/conv3', a + '/bn3', 1, 0)], (a + '/conv4', a + '/bn4', stride, 0), train))
+            for i in range(1, n):
+                b = '%s/%s/b%d' % (fe, name, i)
+                out.append(_ResUnit(p, [(b + '/conv1', b + '/bn1', 1, 0), (b + '/conv2', b + '/bn2', 1, 1),
+                                        (b + '/conv3', b + '/bn3', 1, 0)], None, train))
+        extra = (['res6'] if H > 224 else []) + (['res7'] if H > 300 else [])
+        for name in extra:
+            for blk in ('a', 'b1'):
+                q = '%s/%s' % (name, blk)
+                s = 2 if blk == 'a' else 1
+                sc = (q + '/residual_conv/conv', q + '/residual_conv/bn', 2, 0) if blk == 'a' else None
+                out.append(_ResUnit(p, [(q + '/conv1/conv', q + '/conv1/bn', 1, 0), (q + '/conv2/conv', q + '/conv2/bn', s, 1),
+                                        (q + '/conv3/conv', q + '/conv3/bn', 1, 0)], sc, train))
+        return out
 
 
 class Assessor:
@@ -332,7 +434,7 @@ class AdamAMSGrad:
 
 def update_core(loc_params, dis_params, opt_gen, opt_dis, fake_images, real_images, labels,
                 out_size, localizer_target=1.0, freeze_discriminator=False, rng=None,
-                return_grads=False):
+                return_grads=False, localizer_cls=None):
     """One ``SheepAssessor.update_core`` (sheep_updater.py:26-68).  Mutates the
     parameter dicts / optimiser states in place; returns the reported losses and
     the tensors the parity tests compare."""
@@ -341,7 +443,7 @@ def update_core(loc_params, dis_params, opt_gen, opt_dis, fake_images, real_imag
     y_real = dis.forward(real_images)                                   # :35
     dis_real = dis
 
-    loc = Localizer(loc_params, out_size, train=True, rng=rng)
+    loc = (localizer_cls or Localizer)(loc_params, out_size, train=True, rng=rng)
     x_fake, bboxes = loc.forward(fake_images)                           # :39
     dis_fake = Assessor(dis_params)
     y_fake = dis_fake.forward(x_fake)                                   # :40

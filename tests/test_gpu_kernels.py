@@ -36,6 +36,8 @@ CONV_CASES = [
     (2, 3, 19, 19, 128, 4, 2, 1),     # assessor cs on rgb
     (1, 256, 7, 7, 512, 3, 2, 1),     # res5 entry
     (5, 128, 6, 6, 200, 3, 1, 1),     # Cout not a multiple of the tile
+    (2, 64, 9, 10, 128, 1, 2, 0),     # 1x1 / stride 2 (bottleneck shortcut): three of four dgrad classes have no tap
+    (3, 256, 7, 7, 64, 1, 1, 0),      # 1x1 bottleneck reduce
 ]
 
 
@@ -72,13 +74,24 @@ def test_conv_fprop_dgrad_wgrad(case, tile):
     if tile in (0, 1, 2, 3, 4):
         gx = ops.conv_dgrad(gyd, wd, geo, tile=tile)
         assert rel_err(_nchw(gx, Cin), gx_ref) < 2e-6
+        if geo.dgrad_has_empty_class:
+            addx = rng.standard_normal(x.shape).astype(np.float32)
+            gx2 = ops.conv_dgrad(gyd, wd, geo, addend=dev(_nhwc(addx, cp)), tile=tile)
+            assert rel_err(_nchw(gx2, Cin), gx_ref + addx) < 2e-6
+            acc = dev(_nhwc(addx, cp))
+            ops.conv_dgrad(gyd, wd, geo, out=acc, addend=acc, tile=tile)      # in-place accumulate
+            assert rel_err(_nchw(acc, Cin), gx_ref + addx) < 2e-6
+            return_early = True
+        else:
+            return_early = False
         # mask + addend epilogues
         ref_t = rng.standard_normal(x.shape).astype(np.float32)
         addx = rng.standard_normal(x.shape).astype(np.float32)
-        gx2 = ops.conv_dgrad(gyd, wd, geo, mask_ref=dev(_nhwc(ref_t, cp)), addend=dev(_nhwc(addx, cp)), tile=tile)
-        assert rel_err(_nchw(gx2, Cin), gx_ref * (ref_t > 0) + addx) < 2e-6
-        gx3 = ops.conv_dgrad(gyd, wd, geo, addend=dev(_nhwc(addx, cp)), addend_mask_ref=dev(_nhwc(ref_t, cp)), tile=tile)
-        assert rel_err(_nchw(gx3, Cin), gx_ref + addx * (ref_t > 0)) < 2e-6
+        if not return_early:
+            gx2 = ops.conv_dgrad(gyd, wd, geo, mask_ref=dev(_nhwc(ref_t, cp)), addend=dev(_nhwc(addx, cp)), tile=tile)
+            assert rel_err(_nchw(gx2, Cin), gx_ref * (ref_t > 0) + addx) < 2e-6
+            gx3 = ops.conv_dgrad(gyd, wd, geo, addend=dev(_nhwc(addx, cp)), addend_mask_ref=dev(_nhwc(ref_t, cp)), tile=tile)
+            assert rel_err(_nchw(gx3, Cin), gx_ref + addx * (ref_t > 0)) < 2e-6
     if tile in (0, 1, 3):
         dw = torch.zeros_like(wd)
         ops.conv_wgrad(xd, gyd, dw, geo, tile=tile)
@@ -101,7 +114,7 @@ def test_prep_images_exact():
     assert not out[..., 3].any()
 
 
-@pytest.mark.parametrize("C_", [64, 128, 512])
+@pytest.mark.parametrize("C_", [64, 128, 512, 2048])
 def test_bn_forward_backward(C_):
     from loans_amd import ops
     rng = np.random.RandomState(1)

@@ -92,3 +92,48 @@ def step_losses(lp, dp, frames, real, labels, out_size, target=1.0):
     y_real = assessor(dp, real)
     loss_dis = F.mse_loss(y_real, labels)
     return loss_loc, loss_dis, dict(rois=rois, points=points, theta=theta, y_fake=y_fake, y_real=y_real)
+
+
+# ---- ResNet-50 localizer (Resnet50SheepLocalizer, sheep_localizer.py:120-178) ----
+R50 = (('res2', 3, 1), ('res3', 4, 2), ('res4', 6, 2), ('res5', 3, 2))
+
+
+def _unit(p, x, stages, shortcut, train):
+    h = x
+    for i, (c, b, s, pad) in enumerate(stages):
+        h = _cbn(p, h, c, b, s, pad, train)
+        if i < len(stages) - 1:
+            h = F.relu(h)
+    sc = x if shortcut is None else _cbn(p, x, shortcut[0], shortcut[1], shortcut[2], shortcut[3], train)
+    return F.relu(h + sc)
+
+
+def localizer50(p, images, out_size, train=True):
+    dtype = images.dtype
+    x = (images.float() * 255).to(torch.uint8).float()
+    x = (x.flip(1) - torch.tensor(MEAN, dtype=torch.float32).view(1, 3, 1, 1)).to(dtype)
+    fe = 'feature_extractor'
+    h = F.relu(_cbn(p, x, fe + '/conv1', fe + '/bn1', 2, 3, train))
+    h = F.max_pool2d(h, 3, 2, ceil_mode=True)
+    for name, n, stride in R50:
+        a = '%s/%s/a' % (fe, name)
+        h = _unit(p, h, [(a + '/conv1', a + '/bn1', stride, 0), (a + '/conv2', a + '/bn2', 1, 1), (a + '/conv3', a + '/bn3', 1, 0)],
+                  (a + '/conv4', a + '/bn4', stride, 0), train)
+        for i in range(1, n):
+            b = '%s/%s/b%d' % (fe, name, i)
+            h = _unit(p, h, [(b + '/conv1', b + '/bn1', 1, 0), (b + '/conv2', b + '/bn2', 1, 1), (b + '/conv3', b + '/bn3', 1, 0)], None, train)
+    H = images.shape[-2]
+    for name in (['res6'] if H > 224 else []) + (['res7'] if H > 300 else []):
+        for blk in ('a', 'b1'):
+            q = '%s/%s' % (name, blk)
+            s = 2 if blk == 'a' else 1
+            sc = (q + '/residual_conv/conv', q + '/residual_conv/bn', 2, 0) if blk == 'a' else None
+            h = _unit(p, h, [(q + '/conv1/conv', q + '/conv1/bn', 1, 0), (q + '/conv2/conv', q + '/conv2/bn', s, 1),
+                             (q + '/conv3/conv', q + '/conv3/bn', 1, 0)], sc, train)
+    h = h.mean(dim=(2, 3))
+    theta = F.linear(h, p['param_predictor/W'], p['param_predictor/b']).view(-1, 2, 3)
+    mask = torch.ones(2, 3, dtype=dtype); mask[0, 1] = 0; mask[1, 0] = 0
+    theta = theta * mask
+    grid = F.affine_grid(theta, (len(images), 3) + tuple(out_size), align_corners=True)
+    rois = F.grid_sample(images, grid, mode='bilinear', padding_mode='zeros', align_corners=True)
+    return rois, grid.permute(0, 3, 1, 2), theta

@@ -79,9 +79,8 @@ def main():
     data_iter = training.MultithreadIterator(train_dataset, args.batch_size)
     reference_iter = training.MultithreadIterator(reference_dataset, args.batch_size)
 
-    if not args.use_resnet_18:
-        raise SystemExit("Resnet50SheepLocalizer (config 5) is not built yet: pass --use-resnet-18")
-    localizer = loans_amd.SheepLocalizer(args.target_size)
+    localizer_class = loans_amd.SheepLocalizer if args.use_resnet_18 else loans_amd.Resnet50SheepLocalizer
+    localizer = localizer_class(args.target_size)
     if args.resume_localizer is not None:
         load_pretrained_model(args.resume_localizer, localizer)
     discriminator = loans_amd.ResnetAssessor(output_dim=1)
