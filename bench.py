@@ -153,6 +153,12 @@ def main():
                     "avg_launch_ms": round(tot_ms / max(n_launch, 1), 4),
                     "conv_fwd_ms_per_step": round(tot_ms / args.steps, 3),
                     "algorithmic_flop_per_step": tot_flop // args.steps}
+        # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE, separate
+        # rocprofv3 runs of this same command); only valid for the configuration they were taken on
+        tpath = os.path.join(ROOT, 'profiles', 'r1_conv_fwd_hbm_traffic.json')
+        if hw == 224 and B == 256 and world == 1 and not args.resnet50 and os.path.exists(tpath):
+            roofline["traffic"] = round(json.load(open(tpath))["bytes_per_launch"])
+            roofline["traffic_unit"] = "bytes/launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r1_conv_fwd_hbm_traffic.json)"
         if hw == 224 and not args.resnet50:
             assert tot_flop // args.steps == B * CONV_FWD_FLOP_PER_IMAGE_224, (tot_flop // args.steps, B)
 
