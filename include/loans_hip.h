@@ -72,6 +72,7 @@ typedef struct loans_igemm_desc {
 #define LOANS_TILE_128x64  2
 #define LOANS_TILE_64x64   3
 #define LOANS_TILE_256x64  4
+#define LOANS_TILE_64x128  5   /* wgrad only: 64 output channels x 128 tap-channel columns */
 
 /* ---- convolution (replaces cuDNN ConvolutionForward / BackwardData / BackwardFilter behind
  *      L.Convolution2D: sheep/resnet.py:43,128-133,151-153 ; common/net.py:15-17,37-39,59-60) ---- */

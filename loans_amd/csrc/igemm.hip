@@ -582,16 +582,17 @@ struct WgradArgs {
     unsigned x_bytes, gy_bytes;
 };
 
-template <int BT, bool RELU>   // square BT x BT block tile, 4 waves as 2 x 2
+template <int BCO, int BJ, bool RELU>   // BCO (output channels) x BJ (tap-channel columns) block tile, 4 waves as 2 x 2
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
-    constexpr int T = BT / 2 / 32;          // MFMA tiles per wave per dim
-    constexpr int UPR = BT / 4;             // float4 units per LDS row
+    static_assert(BCO <= BJ, "the loader's thread map follows the wider (X) tile");
+    constexpr int TM = BCO / 2 / 32, TN = BJ / 2 / 32;   // MFMA tiles per wave
+    constexpr int UPR = BJ / 4;             // float4 units per X row (thread map); Y rows use the first BCO/4
     constexpr int RPP = 256 / UPR;          // rows per loader pass
     constexpr int NP = 32 / RPP;            // passes (rows per thread) per 32-row chunk
-    constexpr int NMMA = T * T;             // MFMAs per k step (2 reduction rows)
+    constexpr int NMMA = TM * TN;           // MFMAs per k step (2 reduction rows)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* Ys = reinterpret_cast<float*>(smem);     // [2][32][BT]
-    float* Xs = Ys + 2 * 32 * BT;                   // [2][32][BT]
+    float* Ys = reinterpret_cast<float*>(smem);     // [2][32][BCO]
+    float* Xs = Ys + 2 * 32 * BCO;                  // [2][32][BJ]
 
     const loans_igemm_desc& d = a.d;
     const int tid = threadIdx.x;
@@ -611,8 +612,9 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     const bool xtv = xtap < d.ntaps;
     const int dy = xtv ? (int)d.dy[xtap] : 0;
     const int dx = xtv ? (int)d.dx[xtap] : 0;
-    const int yco = tco * BT + unit * 4;
-    const bool yv = yco < d.Cout;        // Cout is a multiple of 4 for every layer on this path
+    const int yco = tco * BCO + unit * 4;
+    const bool ythread = unit < BCO / 4;                 // this thread also stages a piece of the Y tile
+    const bool yv = ythread && yco < d.Cout;             // Cout is a multiple of 4 for every layer on this path
 
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.x), 0, (int)a.x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(a.gy), 0, (int)a.gy_bytes, 0x00020000);
@@ -660,37 +662,37 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
         px[p] = nx; py[p] = ny; pb[p] = b + qy;
     };
     auto store_y = [&](int buf, int p) {
-        *reinterpret_cast<f32x4*>(Ys + (buf * 32 + prow + RPP * p) * BT + unit * 4) = ry[p];
+        if (ythread) *reinterpret_cast<f32x4*>(Ys + (buf * 32 + prow + RPP * p) * BCO + unit * 4) = ry[p];
     };
     auto store_x = [&](int buf, int p) {
         if (RELU) {
             rx[p].x = fmaxf(rx[p].x, 0.f); rx[p].y = fmaxf(rx[p].y, 0.f);
             rx[p].z = fmaxf(rx[p].z, 0.f); rx[p].w = fmaxf(rx[p].w, 0.f);
         }
-        *reinterpret_cast<f32x4*>(Xs + (buf * 32 + prow + RPP * p) * BT + unit * 4) = rx[p];
+        *reinterpret_cast<f32x4*>(Xs + (buf * 32 + prow + RPP * p) * BJ + unit * 4) = rx[p];
     };
 
     const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int wm = wave >> 1, wn = wave & 1;
-    const int fragY = h * BT + wm * T * 32 + r;
-    const int fragX = h * BT + wn * T * 32 + r;
-    auto read_k = [&](int buf, int s, float (&af)[T], float (&bf)[T]) {
-        const float* Yb = Ys + (buf * 32 + 2 * s) * BT + fragY;
-        const float* Xb = Xs + (buf * 32 + 2 * s) * BT + fragX;
+    const int fragY = h * BCO + wm * TM * 32 + r;
+    const int fragX = h * BJ + wn * TN * 32 + r;
+    auto read_k = [&](int buf, int s, float (&af)[TM], float (&bf)[TN]) {
+        const float* Yb = Ys + (buf * 32 + 2 * s) * BCO + fragY;
+        const float* Xb = Xs + (buf * 32 + 2 * s) * BJ + fragX;
 #pragma unroll
-        for (int i = 0; i < T; ++i) af[i] = Yb[i * 32];
+        for (int i = 0; i < TM; ++i) af[i] = Yb[i * 32];
 #pragma unroll
-        for (int j = 0; j < T; ++j) bf[j] = Xb[j * 32];
+        for (int j = 0; j < TN; ++j) bf[j] = Xb[j * 32];
     };
-    f32x16 acc[T][T];
+    f32x16 acc[TM][TN];
 #pragma unroll
-    for (int i = 0; i < T; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < T; ++j)
+        for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-    auto mma_one = [&](int q, const float (&af)[T], const float (&bf)[T]) {
-        const int i = q / T, j = q % T;
+    auto mma_one = [&](int q, const float (&af)[TM], const float (&bf)[TN]) {
+        const int i = q / TN, j = q % TN;
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i], bf[j], acc[i][j], 0, 0, 0);
     };
 
@@ -698,7 +700,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     // 16 k steps per chunk; fragments of step s+1 are read while the MFMAs of step s run; loader rows of
     // the next chunk ride in steps 0 .. NP-1, their LDS writes in steps 7 .. 7+2NP-1 (<= 14), and step 15's MFMAs
     // run behind the barrier.
-    float fa0[T], fb0[T], fa1[T], fb1[T];
+    float fa0[TM], fb0[TN], fa1[TM], fb1[TN];
     if (c_begin < c_end) {
 #pragma unroll
         for (int p = 0; p < NP; ++p) load_row(p);
@@ -752,31 +754,31 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     const __amdgpu_buffer_rsrc_t rs_dw = __builtin_amdgcn_make_buffer_rsrc(a.dw, 0, (int)((unsigned)d.Cout * (unsigned)a.Ktot * 4u), 0x00020000);
     (void)rs_dw;
 #pragma unroll
-    for (int i = 0; i < T; ++i)
+    for (int i = 0; i < TM; ++i)
 #pragma unroll
-        for (int j = 0; j < T; ++j) {
-            const int jc = tj * BT + wn * T * 32 + j * 32 + r;
+        for (int j = 0; j < TN; ++j) {
+            const int jc = tj * BJ + wn * TN * 32 + j * 32 + r;
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
-                const int co = tco * BT + wm * T * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                const int co = tco * BCO + wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
                 if (co < d.Cout && jc < a.Ktot) atomic_add_f32(a.dw + (int64_t)co * a.Ktot + jc, acc[i][j][e]);
             }
         }
 }
 
-template <int BT, bool RELU>
+template <int BCO, int BJ, bool RELU>
 int launch_wgrad_r(WgradArgs& a, int splits_req, hipStream_t st) {
     static bool attr_set = false;
-    constexpr size_t lds = (size_t)4 * 32 * BT * 4;
-    auto kern = wgrad_kernel<BT, RELU>;
+    constexpr size_t lds = (size_t)2 * 32 * (BCO + BJ) * 4;
+    auto kern = wgrad_kernel<BCO, BJ, RELU>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    a.tiles_co = (a.d.Cout + BT - 1) / BT;
-    a.tiles_j = (a.Ktot + BT - 1) / BT;
+    a.tiles_co = (a.d.Cout + BCO - 1) / BCO;
+    a.tiles_j = (a.Ktot + BJ - 1) / BJ;
     const int total_chunks = (a.M + 31) / 32;
     int splits = splits_req;
     if (splits <= 0) {
@@ -795,10 +797,10 @@ int launch_wgrad_r(WgradArgs& a, int splits_req, hipStream_t st) {
     return LOANS_OK;
 }
 
-template <int BT>
+template <int BCO, int BJ>
 int launch_wgrad(WgradArgs& a, int splits_req, hipStream_t st) {
-    return (a.d.flags & LOANS_F_RELU_IN) ? launch_wgrad_r<BT, true>(a, splits_req, st)
-                                         : launch_wgrad_r<BT, false>(a, splits_req, st);
+    return (a.d.flags & LOANS_F_RELU_IN) ? launch_wgrad_r<BCO, BJ, true>(a, splits_req, st)
+                                         : launch_wgrad_r<BCO, BJ, false>(a, splits_req, st);
 }
 
 struct RepackArgs {
@@ -847,8 +849,9 @@ extern "C" int loans_wgrad_f32(const float* x, const float* gy, float* dw, const
     const bool small = (d->Cout <= 64) || (a.Ktot <= 64);
     int tile = d->tile;
     if (tile == 0) tile = small ? LOANS_TILE_64x64 : LOANS_TILE_128x128;
-    if (tile == LOANS_TILE_64x64) return launch_wgrad<64>(a, splits, st);
-    if (tile == LOANS_TILE_128x128) return launch_wgrad<128>(a, splits, st);
+    if (tile == LOANS_TILE_64x64) return launch_wgrad<64, 64>(a, splits, st);
+    if (tile == LOANS_TILE_128x128) return launch_wgrad<128, 128>(a, splits, st);
+    if (tile == LOANS_TILE_64x128) return launch_wgrad<64, 128>(a, splits, st);
     return LOANS_EINVAL;
 }
 

@@ -115,7 +115,7 @@ def _with_flags(desc, flags, tile=0):
 # --------------------------------------------------------------------------- #
 AUTOTUNE = os.environ.get('LOANS_AUTOTUNE', '1') != '0'
 _IGEMM_TILES = (1, 2, 3)
-_WGRAD_TILES = (1, 3)
+_WGRAD_TILES = (1, 3, 5)
 
 
 def _time_call(fn, reps=5):

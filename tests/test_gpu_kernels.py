@@ -42,7 +42,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
 def test_conv_fprop_dgrad_wgrad(case, tile):
     from loans_amd import ops
     B, Cin, H, W, Cout, k, s, p = case
@@ -56,7 +56,8 @@ def test_conv_fprop_dgrad_wgrad(case, tile):
 
     y_ref, col = C.conv2d_fwd(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64), s, p)
     stats_r = ops.stats_buffer(Cout, 'cuda')
-    y = ops.conv_fprop(xd, wd, geo, bias=bd, stats=stats_r, tile=tile)
+    itile = tile if tile != 5 else 0        # tile 5 exists for wgrad only
+    y = ops.conv_fprop(xd, wd, geo, bias=bd, stats=stats_r, tile=itile)
     stats = stats_r.sum(dim=0)
     assert rel_err(_nchw(y), y_ref) < 2e-6          # exact-f32 MFMA chain vs f64
     np.testing.assert_allclose(stats[0].cpu().numpy(), y_ref.sum(axis=(0, 2, 3)), rtol=1e-5, atol=1e-4)
@@ -65,7 +66,7 @@ def test_conv_fprop_dgrad_wgrad(case, tile):
     # relu_in + addend epilogue
     add = rng.standard_normal(y_ref.shape).astype(np.float32)
     y2_ref, _ = C.conv2d_fwd(np.maximum(x, 0).astype(np.float64), w.astype(np.float64), None, s, p)
-    y2 = ops.conv_fprop(xd, wd, geo, relu_in=True, addend=dev(_nhwc(add)), tile=tile)
+    y2 = ops.conv_fprop(xd, wd, geo, relu_in=True, addend=dev(_nhwc(add)), tile=itile)
     assert rel_err(_nchw(y2), y2_ref + add) < 2e-6
 
     gy = rng.standard_normal(y_ref.shape).astype(np.float32)
@@ -92,7 +93,7 @@ def test_conv_fprop_dgrad_wgrad(case, tile):
             assert rel_err(_nchw(gx2, Cin), gx_ref * (ref_t > 0) + addx) < 2e-6
             gx3 = ops.conv_dgrad(gyd, wd, geo, addend=dev(_nhwc(addx, cp)), addend_mask_ref=dev(_nhwc(ref_t, cp)), tile=tile)
             assert rel_err(_nchw(gx3, Cin), gx_ref + addx * (ref_t > 0)) < 2e-6
-    if tile in (0, 1, 3):
+    if tile in (0, 1, 3, 5):
         dw = torch.zeros_like(wd)
         ops.conv_wgrad(xd, gyd, dw, geo, tile=tile)
         got = dw.cpu().numpy().transpose(0, 3, 1, 2)[:, :Cin]
