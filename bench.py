@@ -30,6 +30,7 @@ sys.path.insert(0, ROOT)
 
 CONV_FWD_FLOP_PER_IMAGE_224 = 4166615040        # 21 conv contractions, 2 FLOP per MAC
 FP32_MFMA_PEAK_TFLOPS = 157.3                   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
+BF16_MFMA_PEAK_TFLOPS = 2500.0                  # MI355X_MICROARCH.md: dense bf16 MFMA (not the 2:1-sparsity figure)
 
 
 def parse():
@@ -41,6 +42,8 @@ def parse():
     ap.add_argument('--image-size', type=int, default=224)
     ap.add_argument('--target-size', type=int, default=75)
     ap.add_argument('--resnet50', action='store_true', help='Resnet50SheepLocalizer backbone (BASELINE configs[4] architecture, fp32)')
+    ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
+                    help="arithmetic of the conv contractions: exact fp32 MFMA (parity path) or bf16 MFMA with fp32 accumulate")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=8)
     ap.add_argument('--cpu-iters', type=int, default=2)
@@ -77,6 +80,7 @@ def main():
     from loans_amd.datasets import synthetic
     from loans_amd.runtime import training
 
+    ops.set_compute_dtype(args.dtype)
     comm = parallel.init_from_env()
     world, rank = comm.size, comm.rank
     if world != args.gpus:
@@ -147,8 +151,9 @@ def main():
         tot_flop = sum(x[1] for x in loc)
         n_launch = len(loc)
         achieved = tot_flop / (tot_ms * 1e-3) / 1e12
-        roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": FP32_MFMA_PEAK_TFLOPS, "unit": "TFLOP/s",
-                    "frac": round(achieved / FP32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+        peak = BF16_MFMA_PEAK_TFLOPS if args.dtype == 'bf16' else FP32_MFMA_PEAK_TFLOPS
+        roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                    "frac": round(achieved / peak, 4), "traffic": None,
                     "kernel": "igemm_kernel (localizer conv forward, %d launches/step)" % (n_launch // args.steps),
                     "avg_launch_ms": round(tot_ms / max(n_launch, 1), 4),
                     "conv_fwd_ms_per_step": round(tot_ms / args.steps, 3),
@@ -156,24 +161,32 @@ def main():
         # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE, separate
         # rocprofv3 runs of this same command); only valid for the configuration they were taken on
         tpath = os.path.join(ROOT, 'profiles', 'r1_conv_fwd_hbm_traffic.json')
-        if hw == 224 and B == 256 and world == 1 and not args.resnet50 and os.path.exists(tpath):
+        if hw == 224 and B == 256 and world == 1 and not args.resnet50 and args.dtype == 'f32' and os.path.exists(tpath):
             roofline["traffic"] = round(json.load(open(tpath))["bytes_per_launch"])
             roofline["traffic_unit"] = "bytes/launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r1_conv_fwd_hbm_traffic.json)"
         if hw == 224 and not args.resnet50:
             assert tot_flop // args.steps == B * CONV_FWD_FLOP_PER_IMAGE_224, (tot_flop // args.steps, B)
 
+    if world > 1:
+        cfg_label = "configs[3]" if (hw == 224 and B == 128 and not args.resnet50) else "custom"
+    elif hw == 224 and B == 256 and not args.resnet50 and args.dtype == 'f32':
+        cfg_label = "configs[1]"
+    elif hw == 512 and B == 128 and not args.resnet50 and args.dtype == 'bf16':
+        cfg_label = "configs[2]"
+    else:
+        cfg_label = "custom"
     backbone = "ResNet-50" if args.resnet50 else "ResNet-18"
     out = {
         "metric": "localizer+assessor train images/sec", "value": round(value, 2), "unit": "images/s",
         "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "LoANs joint step: %s localizer + STN crop + assessor, fwd+bwd+2xAdam-AMSGrad" % backbone,
                    "per_gpu_batch": B, "global_batch": B * world, "frame": "3x%dx%d" % (hw, hw),
                    "crop": "3x%dx%d" % (crop, crop), "parallelism": "dp%d" % world,
-                   "baseline_config": "configs[1]" if world == 1 else "configs[3]"},
+                   "baseline_config": cfg_label},
         "roofline": roofline,
     }
-    if world == 1 and not args.no_cpu_baseline and not args.resnet50:
+    if world == 1 and not args.no_cpu_baseline and not args.resnet50 and args.dtype == 'f32':
         out["cpu_baseline"] = cpu_baseline(args, hw, crop)
     print(json.dumps(out), flush=True)
     parallel.shutdown()

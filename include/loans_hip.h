@@ -83,11 +83,22 @@ int loans_igemm_f32(const float* in, const float* w, float* out,
                     const float* bias, double* stats, const float* ref, const float* addend,
                     const loans_igemm_desc* d, void* stream);
 
+/* Same problem with the operands rounded to bf16 (round-to-nearest-even, done while the fp32 tensors are staged
+ * into LDS) and contracted on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; every tensor stays fp32 in memory.
+ * The "bf16" arm of BASELINE configs 3 / 5 (compute dtype bf16, fp32 accumulate). */
+int loans_igemm_bf16_f32(const float* in, const float* w, float* out,
+                         const float* bias, double* stats, const float* ref, const float* addend,
+                         const loans_igemm_desc* d, void* stream);
+
 /* wgrad: dw[n][t][c] += sum_m gy[opix(m)][n] * x[pix(m,t)][c]   (atomic accumulation into dw).
  * The descriptor is the FORWARD conv's (Cin = x channels, Cout = gy channels; LOANS_F_RELU_IN gathers
  * relu(x)). `splits` = number of m-slices (0 = auto). */
 int loans_wgrad_f32(const float* x, const float* gy, float* dw,
                     const loans_igemm_desc* d, int32_t splits, void* stream);
+
+/* wgrad with both operands rounded to bf16 (RNE) and the bf16 MFMA; fp32 accumulation into dw. */
+int loans_wgrad_bf16_f32(const float* x, const float* gy, float* dw,
+                         const loans_igemm_desc* d, int32_t splits, void* stream);
 
 /* dgrad for convolutions whose input has 4 physical channels (the RGB crops, common/net.py:15,17):
  * out[opix(m)][0..3] = sum_t sum_co gy[pix(m,t)][co] * w_ohwi[co][tapsel[t]][0..3]; same descriptor as

@@ -34,7 +34,9 @@ _i32, _i64, _f32, _f64 = C.c_int32, C.c_int64, C.c_float, C.c_double
 # name -> argtypes, exactly the prototypes of include/loans_hip.h
 SIGNATURES = {
     'loans_igemm_f32': [_p, _p, _p, _p, _p, _p, _p, C.POINTER(IgemmDesc), _p],
+    'loans_igemm_bf16_f32': [_p, _p, _p, _p, _p, _p, _p, C.POINTER(IgemmDesc), _p],
     'loans_wgrad_f32': [_p, _p, _p, C.POINTER(IgemmDesc), _i32, _p],
+    'loans_wgrad_bf16_f32': [_p, _p, _p, C.POINTER(IgemmDesc), _i32, _p],
     'loans_dgrad_c4_f32': [_p, _p, _p, _p, _p, C.POINTER(IgemmDesc), C.POINTER(_i32), _i32, _p],
     'loans_repack_dgrad_f32': [_p, _p, _i32, _i32, _i32, C.POINTER(_i32), _i32, _p],
     'loans_prep_images_f32': [_p, _p, _i32, _i32, _i32, _p],

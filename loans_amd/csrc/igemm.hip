@@ -51,6 +51,7 @@ struct IgemmArgs {
     const float* addend;
     loans_igemm_desc d;
     int M, Ktot, nchunks, tiles_m, tiles_n;
+    int bf16;           // 1: round the operands to bf16 and use the bf16 MFMA (fp32 accumulate)
     unsigned in_bytes, w_bytes, out_bytes;
     struct {            // nx > 0: taps are an ny x nx grid, dy = dy0 + row*sdy, dx = dx0 + col*sdx, sd* = +-1
         int nx, ny, dy0, sdy, dx0, sdx;
@@ -73,7 +74,13 @@ __device__ __forceinline__ int xcd_remap(int id, int nblk) {
 #define SG_DS_READ 0x100
 #define SG_DS_WRITE 0x200
 
-template <int BM, int BN, int WM, int WN, bool RELU>
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+constexpr int LDKH = BK + 8;      // bf16 LDS row (halves): 80 bytes, ds_read_b128 conflict-free
+
+// BF16 = true: the fp32 operands are rounded to bf16 (RNE) while they are staged into LDS and contracted on
+// v_mfma_f32_32x32x16_bf16 (fp32 accumulate, 16x the fp32 MFMA rate); prologue, epilogue and the C ABI are shared.
+template <int BM, int BN, int WM, int WN, bool RELU, bool BF16>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int RA = BM / 32, RB = BN / 32;
@@ -220,10 +227,20 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
             ra[i].x = fmaxf(ra[i].x, 0.f); ra[i].y = fmaxf(ra[i].y, 0.f);
             ra[i].z = fmaxf(ra[i].z, 0.f); ra[i].w = fmaxf(ra[i].w, 0.f);
         }
-        *reinterpret_cast<f32x4*>(As + buf * BM * LDK + (lrow + 32 * i) * LDK + lu * 4) = ra[i];
+        if constexpr (BF16) {
+            __bf16* Ah = reinterpret_cast<__bf16*>(smem);
+            *reinterpret_cast<bf16x4_t*>(Ah + buf * BM * LDKH + (lrow + 32 * i) * LDKH + lu * 4) = __builtin_convertvector(ra[i], bf16x4_t);
+        } else {
+            *reinterpret_cast<f32x4*>(As + buf * BM * LDK + (lrow + 32 * i) * LDK + lu * 4) = ra[i];
+        }
     };
     auto store_b = [&](int buf, int i) {
-        *reinterpret_cast<f32x4*>(Bs + buf * BN * LDK + (lrow + 32 * i) * LDK + lu * 4) = rb[i];
+        if constexpr (BF16) {
+            __bf16* Bh = reinterpret_cast<__bf16*>(smem) + 2 * BM * LDKH;
+            *reinterpret_cast<bf16x4_t*>(Bh + buf * BN * LDKH + (lrow + 32 * i) * LDKH + lu * 4) = __builtin_convertvector(rb[i], bf16x4_t);
+        } else {
+            *reinterpret_cast<f32x4*>(Bs + buf * BN * LDK + (lrow + 32 * i) * LDK + lu * 4) = rb[i];
+        }
     };
     auto store_chunk = [&](int buf) {
 #pragma unroll
@@ -252,6 +269,43 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
         for (int j = 0; j < TN; ++j)
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+#ifdef LOANS_STAMPS
+    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, s_load = 0, s_mfma = 0, s_store = 0, s_bar = 0, t_begin = 0;
+#endif
+    if constexpr (BF16) {
+        // ---- bf16 MFMA K loop: a chunk (32 of K) is two 32x32x16 steps per tile; the loop is bound by the
+        // operand traffic, not the matrix pipe, so it stays simple: next chunk's loads in flight across the
+        // MFMAs of the current one, conversion + LDS write behind them, one barrier per chunk.
+        const __bf16* Ah = reinterpret_cast<const __bf16*>(smem);
+        const __bf16* Bh = Ah + 2 * BM * LDKH;
+        const int hA = (wm * TM * 32 + r) * LDKH + h * 8;
+        const int hB = (wn * TN * 32 + r) * LDKH + h * 8;
+        load_chunk();
+        store_chunk(0);
+        __syncthreads();
+        for (int c = 0; c < a.nchunks; ++c) {
+            const int buf = c & 1;
+            const bool more = (c + 1) < a.nchunks;
+            if (more) load_chunk();
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                bf16x8_t af[TM], bf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+                    af[i] = *reinterpret_cast<const bf16x8_t*>(Ah + buf * BM * LDKH + hA + i * 32 * LDKH + s * 16);
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    bf[j] = *reinterpret_cast<const bf16x8_t*>(Bh + buf * BN * LDKH + hB + j * 32 * LDKH + s * 16);
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+            if (more) store_chunk(buf ^ 1);
+            __syncthreads();
+        }
+    } else {
     // MFMA number s (0 .. NMMA-1) of a k group
     auto mma_one = [&](int s, const f32x4 (&af)[TM], const f32x4 (&bf)[TN]) {
         const int kk = s / (TM * TN), i = (s / TN) % TM, j = s % TN;
@@ -285,10 +339,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     __syncthreads();
     read_frag(0, 0, fa0, fb0);
 
-#ifdef LOANS_STAMPS
-    unsigned long long t0 = 0, t1 = 0, t2 = 0, t3 = 0, t4 = 0, s_load = 0, s_mfma = 0, s_store = 0, s_bar = 0, t_begin = 0;
     STAMP(t_begin);
-#endif
     int c = 0;
     for (; c + 1 < a.nchunks; ++c) {
         const int buf = c & 1;
@@ -342,6 +393,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
         mma(fa0, fb0);
         mma(fa1, fb1);
     }
+    }   // fp32 / bf16 K loop
 #ifdef LOANS_STAMPS
     unsigned long long t_loop_end = 0;
     STAMP(t_loop_end);
@@ -453,7 +505,7 @@ constexpr size_t igemm_lds_bytes() {
     return (size_t)(2 * BM * LDK + 2 * BN * LDK) * 4 + LOANS_MAX_TAPS * 4 + BM * 4;
 }
 
-template <int BM, int BN, int WM, int WN, bool RELU>
+template <int BM, int BN, int WM, int WN, bool RELU, bool BF16>
 int launch_igemm_r(IgemmArgs& a, hipStream_t st) {
     static bool attr_set = false;
 #ifdef LOANS_STAMPS
@@ -463,7 +515,7 @@ int launch_igemm_r(IgemmArgs& a, hipStream_t st) {
 #else
     constexpr size_t lds = igemm_lds_bytes<BM, BN>();
 #endif
-    auto kern = igemm_kernel<BM, BN, WM, WN, RELU>;
+    auto kern = igemm_kernel<BM, BN, WM, WN, RELU, BF16>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -496,8 +548,9 @@ void detect_tap_grid(const loans_igemm_desc* d, IgemmArgs& a) {
 
 template <int BM, int BN, int WM, int WN>
 int launch_igemm(IgemmArgs& a, hipStream_t st) {
-    return (a.d.flags & LOANS_F_RELU_IN) ? launch_igemm_r<BM, BN, WM, WN, true>(a, st)
-                                         : launch_igemm_r<BM, BN, WM, WN, false>(a, st);
+    const bool relu = a.d.flags & LOANS_F_RELU_IN;
+    if (a.bf16) return relu ? launch_igemm_r<BM, BN, WM, WN, true, true>(a, st) : launch_igemm_r<BM, BN, WM, WN, false, true>(a, st);
+    return relu ? launch_igemm_r<BM, BN, WM, WN, true, false>(a, st) : launch_igemm_r<BM, BN, WM, WN, false, false>(a, st);
 }
 
 int check_desc(const loans_igemm_desc* d) {
@@ -519,8 +572,8 @@ int check_desc(const loans_igemm_desc* d) {
 
 }  // namespace
 
-extern "C" int loans_igemm_f32(const float* in, const float* w, float* out, const float* bias, double* stats,
-                               const float* ref, const float* addend, const loans_igemm_desc* d, void* stream) {
+static int igemm_impl(const float* in, const float* w, float* out, const float* bias, double* stats,
+                      const float* ref, const float* addend, const loans_igemm_desc* d, void* stream, int bf16) {
     int rc = check_desc(d);
     if (rc) return rc;
     if (!in || !w || !out || (d->Cout & 3)) return LOANS_EINVAL;
@@ -532,6 +585,7 @@ extern "C" int loans_igemm_f32(const float* in, const float* w, float* out, cons
     IgemmArgs a;
     a.in = in; a.w = w; a.out = out; a.bias = bias; a.stats = stats; a.ref = ref; a.addend = addend;
     a.d = *d;
+    a.bf16 = bf16;
     a.M = d->B * d->gridH * d->gridW;
     a.Ktot = d->ntaps * d->Cin;
     a.nchunks = (a.Ktot + BK - 1) / BK;
@@ -565,6 +619,16 @@ extern "C" int loans_igemm_f32(const float* in, const float* w, float* out, cons
     }
 }
 
+extern "C" int loans_igemm_f32(const float* in, const float* w, float* out, const float* bias, double* stats,
+                               const float* ref, const float* addend, const loans_igemm_desc* d, void* stream) {
+    return igemm_impl(in, w, out, bias, stats, ref, addend, d, stream, 0);
+}
+
+extern "C" int loans_igemm_bf16_f32(const float* in, const float* w, float* out, const float* bias, double* stats,
+                                    const float* ref, const float* addend, const loans_igemm_desc* d, void* stream) {
+    return igemm_impl(in, w, out, bias, stats, ref, addend, d, stream, 1);
+}
+
 // ------------------------------------------------------------------------------------------
 // weight gradient:  dw[co][t][c] += sum_m gy[opix(m)][co] * x[pix(m,t)][c]
 // GEMM rows = co, columns = (t,c), reduction = m (split over blocks, fp32 atomics into dw).
@@ -579,10 +643,13 @@ struct WgradArgs {
     float* dw;
     loans_igemm_desc d;
     int M, Ktot, tiles_co, tiles_j, splits, chunks_per_split;
+    int bf16;
     unsigned x_bytes, gy_bytes;
 };
 
-template <int BCO, int BJ, bool RELU>   // BCO (output channels) x BJ (tap-channel columns) block tile, 4 waves as 2 x 2
+// BF16 = true: fragments are packed to bf16 after the (fp32, conflict-free) LDS reads and contracted on the
+// 32x32x16 bf16 MFMA; staging and accumulation stay fp32.
+template <int BCO, int BJ, bool RELU, bool BF16>   // BCO (output channels) x BJ (tap-channel columns) block tile, 4 waves as 2 x 2
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     static_assert(BCO <= BJ, "the loader's thread map follows the wider (X) tile");
     constexpr int TM = BCO / 2 / 32, TN = BJ / 2 / 32;   // MFMA tiles per wave
@@ -708,7 +775,42 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
         for (int p = 0; p < NP; ++p) { store_y(0, p); store_x(0, p); }
     }
     __syncthreads();
-    if (c_begin < c_end) {
+    if constexpr (BF16) {
+        // lane (r, h) of a 32x32x16 step needs reduction rows 16s + 8h .. + 7 of its column: eight b32 reads
+        // (32 consecutive lanes = 32 consecutive banks), packed to bf16 in registers
+        for (int c = c_begin; c < c_end; ++c) {
+            const int buf = (c - c_begin) & 1;
+            const bool more = (c + 1) < c_end;
+            if (more) {
+#pragma unroll
+                for (int p = 0; p < NP; ++p) load_row(p);
+            }
+#pragma unroll
+            for (int s = 0; s < 2; ++s) {
+                const float* Yb = Ys + (buf * 32 + 16 * s + 8 * h) * BCO + wm * TM * 32 + r;
+                const float* Xb = Xs + (buf * 32 + 16 * s + 8 * h) * BJ + wn * TN * 32 + r;
+                bf16x8_t af[TM], bf[TN];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) af[i][e] = (__bf16)Yb[e * BCO + i * 32];
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 8; ++e) bf[j][e] = (__bf16)Xb[e * BJ + j * 32];
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            }
+            if (more) {
+#pragma unroll
+                for (int p = 0; p < NP; ++p) { store_y(buf ^ 1, p); store_x(buf ^ 1, p); }
+            }
+            __syncthreads();
+        }
+    } else if (c_begin < c_end) {
         read_k(0, 0, fa0, fb0);
         int c = c_begin;
         for (; c + 1 < c_end; ++c) {
@@ -766,11 +868,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
         }
 }
 
-template <int BCO, int BJ, bool RELU>
+template <int BCO, int BJ, bool RELU, bool BF16>
 int launch_wgrad_r(WgradArgs& a, int splits_req, hipStream_t st) {
     static bool attr_set = false;
     constexpr size_t lds = (size_t)2 * 32 * (BCO + BJ) * 4;
-    auto kern = wgrad_kernel<BCO, BJ, RELU>;
+    auto kern = wgrad_kernel<BCO, BJ, RELU, BF16>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -799,8 +901,9 @@ int launch_wgrad_r(WgradArgs& a, int splits_req, hipStream_t st) {
 
 template <int BCO, int BJ>
 int launch_wgrad(WgradArgs& a, int splits_req, hipStream_t st) {
-    return (a.d.flags & LOANS_F_RELU_IN) ? launch_wgrad_r<BCO, BJ, true>(a, splits_req, st)
-                                         : launch_wgrad_r<BCO, BJ, false>(a, splits_req, st);
+    const bool relu = a.d.flags & LOANS_F_RELU_IN;
+    if (a.bf16) return relu ? launch_wgrad_r<BCO, BJ, true, true>(a, splits_req, st) : launch_wgrad_r<BCO, BJ, false, true>(a, splits_req, st);
+    return relu ? launch_wgrad_r<BCO, BJ, true, false>(a, splits_req, st) : launch_wgrad_r<BCO, BJ, false, false>(a, splits_req, st);
 }
 
 struct RepackArgs {
@@ -830,13 +933,14 @@ __global__ __launch_bounds__(256) void repack_dgrad_kernel(const RepackArgs a) {
 
 }  // namespace
 
-extern "C" int loans_wgrad_f32(const float* x, const float* gy, float* dw, const loans_igemm_desc* d,
-                               int32_t splits, void* stream) {
+static int wgrad_impl(const float* x, const float* gy, float* dw, const loans_igemm_desc* d, int32_t splits,
+                      void* stream, int bf16) {
     int rc = check_desc(d);
     if (rc) return rc;
     if (!x || !gy || !dw || (d->Cout & 3)) return LOANS_EINVAL;
     WgradArgs a;
     a.x = x; a.gy = gy; a.dw = dw; a.d = *d;
+    a.bf16 = bf16;
     a.M = d->B * d->gridH * d->gridW;
     a.Ktot = d->ntaps * d->Cin;
     {
@@ -853,6 +957,16 @@ extern "C" int loans_wgrad_f32(const float* x, const float* gy, float* dw, const
     if (tile == LOANS_TILE_128x128) return launch_wgrad<128, 128>(a, splits, st);
     if (tile == LOANS_TILE_64x128) return launch_wgrad<64, 128>(a, splits, st);
     return LOANS_EINVAL;
+}
+
+extern "C" int loans_wgrad_f32(const float* x, const float* gy, float* dw, const loans_igemm_desc* d,
+                               int32_t splits, void* stream) {
+    return wgrad_impl(x, gy, dw, d, splits, stream, 0);
+}
+
+extern "C" int loans_wgrad_bf16_f32(const float* x, const float* gy, float* dw, const loans_igemm_desc* d,
+                                    int32_t splits, void* stream) {
+    return wgrad_impl(x, gy, dw, d, splits, stream, 1);
 }
 
 extern "C" int loans_repack_dgrad_f32(const float* src, float* dst, int32_t Cout, int32_t Cin, int32_t src_taps,

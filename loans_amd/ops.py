@@ -13,6 +13,22 @@ import torch
 from . import _lib
 from ._lib import (F_ADDEND, F_ADDEND_MASK, F_BIAS, F_MASK, F_RELU_IN, F_STATS, IgemmDesc, check)
 
+# Arithmetic of the convolution contractions: 'f32' (exact fp32 MFMA, the parity path) or 'bf16' (operands rounded
+# to bf16 while staged into LDS, bf16 MFMA, fp32 accumulate; tensors stay fp32 in memory).  BASELINE configs 3 / 5.
+COMPUTE = os.environ.get('LOANS_COMPUTE', 'f32')
+
+
+def set_compute_dtype(name):
+    global COMPUTE
+    if name not in ('f32', 'bf16'):
+        raise ValueError("compute dtype must be 'f32' or 'bf16'")
+    COMPUTE = name
+
+
+def _igemm_fn(lib):
+    return lib.loans_igemm_bf16_f32 if COMPUTE == 'bf16' else lib.loans_igemm_f32
+
+
 # When bench.py sets this to a list, conv_fprop brackets each launch with HIP events recorded on the
 # launch stream and appends (tag, algorithmic_flops, start_event, end_event).
 EVENT_LOG = None
@@ -163,16 +179,16 @@ def conv_fprop(x, w, geo, out=None, bias=None, stats=None, relu_in=False, addend
 
         def run(t):
             scratch = torch.empty((geo.B, geo.Ho, geo.Wo, geo.Cout), device=x.device, dtype=torch.float32)
-            check(lib.loans_igemm_f32(_ptr(x), _ptr(w), _ptr(scratch), 0, _ptr(sstats), 0, 0,
+            check(_igemm_fn(lib)(_ptr(x), _ptr(w), _ptr(scratch), 0, _ptr(sstats), 0, 0,
                                       C.byref(_with_flags(geo.fwd, tflags, t)), _stream()), 'loans_igemm_f32[tune]')
-        tile = _tuned_tile(geo, 'fprop' + ('_stats' if stats is not None else ''), run, _IGEMM_TILES + (4,))
+        tile = _tuned_tile(geo, COMPUTE + 'fprop' + ('_stats' if stats is not None else ''), run, _IGEMM_TILES + (4,))
     d = _with_flags(geo.fwd, flags, tile)
     log = EVENT_LOG
     if log is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    check(lib.loans_igemm_f32(_ptr(x), _ptr(w), _ptr(out), _ptr(bias), _ptr(stats), 0, _ptr(addend),
-                              C.byref(d), _stream()), 'loans_igemm_f32[fprop]')
+    check(_igemm_fn(lib)(_ptr(x), _ptr(w), _ptr(out), _ptr(bias), _ptr(stats), 0, _ptr(addend),
+                         C.byref(d), _stream()), 'loans_igemm[fprop]')
     if log is not None:
         ev1.record()
         # algorithmic FLOPs: logical input channels (3 for the RGB stem), no padding, no im2col redundancy
@@ -219,13 +235,13 @@ def conv_dgrad(gy, w, geo, out=None, mask_ref=None, addend=None, addend_mask_ref
         def run(t):
             scratch = torch.empty((geo.B, geo.H, geo.W, geo.Cin), device=gy.device, dtype=torch.float32)
             for d, _, off in geo.dgrad:
-                check(lib.loans_igemm_f32(_ptr(gy), _ptr(wp[off:]), _ptr(scratch), 0, 0, 0, 0,
-                                          C.byref(_with_flags(d, 0, t)), st), 'loans_igemm_f32[tune]')
-        tile = _tuned_tile(geo, 'dgrad', run, _IGEMM_TILES)
+                check(_igemm_fn(lib)(_ptr(gy), _ptr(wp[off:]), _ptr(scratch), 0, 0, 0, 0,
+                                     C.byref(_with_flags(d, 0, t)), st), 'loans_igemm[tune]')
+        tile = _tuned_tile(geo, COMPUTE + 'dgrad', run, _IGEMM_TILES)
     for d, tapsel, off in geo.dgrad:
         _with_flags(d, flags, tile)
-        check(lib.loans_igemm_f32(_ptr(gy), _ptr(wp[off:]), _ptr(out), 0, 0, _ptr(ref), _ptr(addend),
-                                  C.byref(d), st), 'loans_igemm_f32[dgrad]')
+        check(_igemm_fn(lib)(_ptr(gy), _ptr(wp[off:]), _ptr(out), 0, 0, _ptr(ref), _ptr(addend),
+                             C.byref(d), st), 'loans_igemm[dgrad]')
     return out
 
 
@@ -255,7 +271,7 @@ def join_side_stream(device=None):
 
 def conv_wgrad(x, gy, dw, geo, relu_in=False, splits=0, tile=0):
     """dw[Cout,k,k,Cin] += sum over pixels (atomic accumulate into the gradient arena)."""
-    if ASYNC_WGRAD and geo.tuned.get('wgrad') is not None and not torch.cuda.is_current_stream_capturing():
+    if ASYNC_WGRAD and geo.tuned.get(COMPUTE + 'wgrad') is not None and not torch.cuda.is_current_stream_capturing():
         side = _side_stream(x.device)
         side.wait_stream(torch.cuda.current_stream(x.device))
         x.record_stream(side)
@@ -271,14 +287,15 @@ def _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile):
     lib = _lib.load()
     assert dw.numel() == geo.Cout * geo.k * geo.k * geo.Cin
     fl = F_RELU_IN if relu_in else 0
+    wfn = lib.loans_wgrad_bf16_f32 if COMPUTE == 'bf16' else lib.loans_wgrad_f32
     if tile == 0:
         def run(t):
             scratch = torch.empty(dw.numel(), device=x.device, dtype=torch.float32)
-            check(lib.loans_wgrad_f32(_ptr(x), _ptr(gy), _ptr(scratch), C.byref(_with_flags(geo.fwd, fl, t)), splits,
-                                      _stream()), 'loans_wgrad_f32[tune]')
-        tile = _tuned_tile(geo, 'wgrad', run, _WGRAD_TILES)
+            check(wfn(_ptr(x), _ptr(gy), _ptr(scratch), C.byref(_with_flags(geo.fwd, fl, t)), splits,
+                      _stream()), 'loans_wgrad[tune]')
+        tile = _tuned_tile(geo, COMPUTE + 'wgrad', run, _WGRAD_TILES)
     d = _with_flags(geo.fwd, fl, tile)
-    check(lib.loans_wgrad_f32(_ptr(x), _ptr(gy), _ptr(dw), C.byref(d), splits, _stream()), 'loans_wgrad_f32')
+    check(wfn(_ptr(x), _ptr(gy), _ptr(dw), C.byref(d), splits, _stream()), 'loans_wgrad')
 
 
 # --------------------------------------------------------------------------- #

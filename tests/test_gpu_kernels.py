@@ -263,3 +263,45 @@ def test_adam_amsgrad_matches_chainer_placement():
         ops.adam_amsgrad(pd, dev(g), md, vd, vhd, C.adam_lr(1e-3, .9, .999, t), .9, .999, 1e-8, 1.0, 0.0)
         np.testing.assert_allclose(pd.cpu().numpy(), pr, rtol=0, atol=2e-7)
         np.testing.assert_allclose(vhd.cpu().numpy(), vh, rtol=1e-5, atol=1e-30)
+
+
+def _bf16_round(a):
+    """Round-to-nearest-even fp32 -> bf16 -> fp32 (the conversion v_cvt_pk_bf16_f32 performs)."""
+    return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(torch.bfloat16).to(torch.float32).numpy()
+
+
+@pytest.mark.parametrize("case", [(2, 64, 15, 13, 128, 3, 2, 1), (3, 128, 9, 9, 128, 4, 2, 1), (2, 3, 32, 32, 64, 7, 2, 3),
+                                  (2, 256, 7, 7, 512, 3, 1, 1), (2, 64, 9, 10, 128, 1, 2, 0)])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4])
+def test_conv_bf16_compute_fprop_dgrad(case, tile):
+    """bf16 compute arm: operands rounded to bf16 (RNE), products exact in fp32, fp32 accumulation -- so the
+    result equals an fp64 convolution of the bf16-rounded tensors to fp32 accumulation accuracy."""
+    from loans_amd import ops
+    B, Cin, H, W, Cout, k, s, p = case
+    rng = np.random.RandomState(7)
+    x = rng.standard_normal((B, Cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
+    cp = (Cin + 3) // 4 * 4
+    geo = ops.ConvGeometry(B, H, W, cp, Cout, k, s, p)
+    xd, wd = dev(_nhwc(x, cp)), dev(_ohwi(w, cp))
+    xr, wr = _bf16_round(x).astype(np.float64), _bf16_round(w).astype(np.float64)
+    y_ref, col = C.conv2d_fwd(xr, wr, None, s, p)
+    ops.set_compute_dtype('bf16')
+    try:
+        stats_r = ops.stats_buffer(Cout, 'cuda')
+        y = ops.conv_fprop(xd, wd, geo, stats=stats_r, tile=tile)
+        assert rel_err(_nchw(y), y_ref) < 3e-6
+        np.testing.assert_allclose(stats_r.sum(dim=0)[0].cpu().numpy(), y_ref.sum(axis=(0, 2, 3)), rtol=1e-4, atol=1e-3)
+        assert rel_err(_nchw(y), C.conv2d_fwd(x.astype(np.float64), w.astype(np.float64), None, s, p)[0]) < 2e-2   # vs unrounded: bf16-level
+        gy = rng.standard_normal(y_ref.shape).astype(np.float32)
+        gx_ref, _, _ = C.conv2d_bwd(x.shape, col, wr, _bf16_round(gy).astype(np.float64), s, p, False)
+        if Cin >= 32:
+            gx = ops.conv_dgrad(dev(_nhwc(gy)), wd, geo, tile=tile)
+            assert rel_err(_nchw(gx, Cin), gx_ref) < 3e-6
+        if tile in (0, 1, 3):
+            _, gw_ref, _ = C.conv2d_bwd(x.shape, col, wr, _bf16_round(gy).astype(np.float64), s, p, False, need_gx=False)
+            dw = torch.zeros_like(wd)
+            ops._conv_wgrad(xd, dev(_nhwc(gy)), dw, geo, False, 0, tile)
+            assert rel_err(dw.cpu().numpy().transpose(0, 3, 1, 2)[:, :Cin], gw_ref) < 5e-6
+    finally:
+        ops.set_compute_dtype('f32')

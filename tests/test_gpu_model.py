@@ -362,3 +362,36 @@ def test_bottleneck_unit_forward_backward(kind):
     assert rel_err(xv.grad.cpu().numpy().transpose(0, 3, 1, 2), gx_ref) < 1e-4
     for key, p in blk.namedparams():
         assert rel_err(p.grad_logical(), grads[key[1:]]) < 1e-4, key
+
+
+def test_bf16_compute_step_against_oracle():
+    """BASELINE configs 3 / 5 arithmetic: conv contractions on the bf16 MFMA (operands rounded to bf16, fp32
+    accumulate), everything else fp32.  Tolerance: bf16 has 8 significant bits (2^-9 = 2e-3 relative rounding per
+    operand); through 21 BN-normalised layers the localizer's theta / boxes land within 3e-2 of the fp32 oracle
+    and the assessor scores within 3e-2 (the north star states a tolerance for fp32 only)."""
+    B, H, W, crop = 4, 96, 96, (16, 16)
+    loc, dis = build_pair(41, crop)
+    frames, real, labels = inputs(42, B, H, W, crop)
+    with loans_amd.using_config('enable_backprop', False):
+        dis(dev(real))
+    lp, dp = oracle_params(loc, np.float32), oracle_params(dis, np.float32)
+    loans_amd.set_compute_dtype('bf16')
+    try:
+        upd = _updater(loc, dis, frames, real, labels)
+        rois, points = loc(dev(frames))
+        y_fake = dis(rois)
+        oloc = M.Localizer(lp, crop, train=True, rng=np.random.RandomState(0))
+        o_rois, o_points = oloc.forward(frames)
+        o_y = M.Assessor(dp).forward(o_rois)
+        dt = np.abs(loc.last_transform_params.data.cpu().numpy() - oloc.theta).max()
+        dp_ = np.abs(points.data.cpu().numpy() - o_points).max()
+        dy = np.abs(y_fake.data.cpu().numpy() - o_y).max()
+        print('bf16 compute: |dtheta| %.2e |dpoints| %.2e |dscore| %.2e' % (dt, dp_, dy))
+        assert dt < 3e-2 and dp_ < 3e-2 and dy < 3e-2
+        rois.unchain_backward(); points.unchain_backward()
+        for _ in range(2):                       # the joint step runs end to end (dgrad / wgrad / Adam in this mode)
+            upd.update()
+        obs = loans_amd.reporter.observation
+        assert np.isfinite(float(obs['loss_localizer'])) and np.isfinite(float(obs['loss_dis']))
+    finally:
+        loans_amd.set_compute_dtype('f32')

@@ -45,8 +45,10 @@ def main():
     ap.add_argument('--modes', default='fprop,dgrad,wgrad')
     ap.add_argument('--layers', default='')
     ap.add_argument('--tiles', default='0,1,2,3,4,5')
+    ap.add_argument('--compute', default='f32')
     args = ap.parse_args()
     B = args.batch
+    ops.set_compute_dtype(args.compute)
     tiles = [int(t) for t in args.tiles.split(',')]
     names = {0: 'auto', 1: '128x128', 2: '128x64', 3: '64x64', 4: '256x64', 5: '64x128'}
     for name, Cin, H, W, Cout, k, s, p in LAYERS:
