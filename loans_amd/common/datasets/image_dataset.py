@@ -1,0 +1,179 @@
+"""``ImageDataset`` / ``LabeledImageDataset`` (reference common/datasets/image_dataset.py:47-182): the input
+contract of the hot path -- float32 CHW RGB in [0,1] (exactly ``uint8 / 255``), PIL load, LANCZOS resize,
+labelled variant returning ``(image, label, zeros(1))`` with bounding boxes rescaled to the resized image.
+
+Same constructor keywords and ``get_example`` behaviour.  ``imgaug`` is not available here: with
+``use_imgaug=True`` (the reference default) the naive crop / flip augmentation of the reference's own fallback
+branch (:86-90) is used instead and a note is printed once; the hue / contrast jitter of the imgaug branch is
+not reproduced.  Decode and augmentation stay on host threads (a GPU-side decode path is future work,
+SURVEY §8f.2)."""
+import csv
+import os
+import random
+import warnings
+
+import numpy
+from PIL import Image
+
+
+def _read_image_as_array(path, dtype):
+    with Image.open(path) as f:
+        image = numpy.asarray(f, dtype=dtype)
+    if image.ndim == 2:
+        return image[numpy.newaxis]                      # (1, H, W)
+    return image.transpose(2, 0, 1)                     # CHW
+
+
+def resize_image(image, image_size, image_mode='RGB'):
+    if len(image.shape) == 2:
+        pil_image = Image.fromarray(image.astype('uint8'))
+    else:
+        pil_image = Image.fromarray(image.transpose(1, 2, 0).astype('uint8'))
+    pil_image = pil_image.convert(image_mode)
+    pil_image = pil_image.resize((image_size[1], image_size[0]), Image.LANCZOS)
+    if image_mode == 'L':
+        return numpy.asarray(pil_image).astype(numpy.float32)
+    return numpy.asarray(pil_image).transpose(2, 0, 1).astype(numpy.float32)
+
+
+def random_crop(image, size):
+    H, W = image.shape[-2:]
+    y = random.randint(0, H - size[0]) if H > size[0] else 0
+    x = random.randint(0, W - size[1]) if W > size[1] else 0
+    return image[:, y:y + size[0], x:x + size[1]]
+
+
+def random_flip(image, x_random=False):
+    if x_random and random.choice([True, False]):
+        image = image[:, :, ::-1]
+    return image
+
+
+def resize_bbox(bbox, in_size, out_size):
+    """chainercv.transforms.resize_bbox: boxes (y_min, x_min, y_max, x_max)."""
+    bbox = bbox.copy()
+    y_scale = float(out_size[0]) / in_size[0]
+    x_scale = float(out_size[1]) / in_size[1]
+    bbox[:, 0] = y_scale * bbox[:, 0]
+    bbox[:, 2] = y_scale * bbox[:, 2]
+    bbox[:, 1] = x_scale * bbox[:, 1]
+    bbox[:, 3] = x_scale * bbox[:, 3]
+    return bbox
+
+
+_warned = []
+
+
+def _no_imgaug():
+    if not _warned:
+        warnings.warn("imgaug is not installed: using the reference's naive crop/flip augmentation branch")
+        _warned.append(1)
+
+
+class ImageDataset:
+
+    def __init__(self, paths, root='.', dtype=numpy.float32, **kwargs):
+        self.image_size = kwargs.pop('image_size', None)
+        self.image_mode = kwargs.pop('image_mode', 'RGB')
+        self.transform_probability = kwargs.pop('transform_probability', 0)
+        self.use_imgaug = kwargs.pop('use_imgaug', True)
+        self.min_crop_ratio = kwargs.pop('min_crop_ratio', 0.6)
+        self.max_crop_ratio = kwargs.pop('max_crop_ratio', 0.9)
+        self.crop_always = kwargs.pop('crop_always', False)
+        if self.transform_probability > 0 and self.use_imgaug:
+            _no_imgaug()
+        if isinstance(paths, str):
+            with open(paths) as paths_file:
+                paths = [path.strip() for path in paths_file]
+        self._paths, self._root, self._dtype = paths, root, dtype
+
+    def __len__(self):
+        return len(self._paths)
+
+    def __getitem__(self, i):
+        return self.get_example(i)
+
+    def get_example(self, i):
+        image = _read_image_as_array(os.path.join(self._root, self._paths[i]), self._dtype)
+        if image.shape[0] == 1:
+            image = numpy.tile(image, (3, 1, 1))
+        image = image[:3]
+        if random.random() < self.transform_probability:
+            if self.crop_always or random.random() <= 0.5:
+                crop_ratio = random.uniform(self.min_crop_ratio, self.max_crop_ratio)
+                image = random_crop(image, tuple([int(size * crop_ratio) for size in image.shape[-2:]]))
+            image = random_flip(image, x_random=True)
+        if self.image_size is not None:
+            image = resize_image(image, self.image_size, image_mode=self.image_mode)
+        if len(image.shape) == 2:
+            image = image[None, ...]
+        return numpy.ascontiguousarray(image / 255, dtype=numpy.float32)
+
+
+class LabeledImageDataset:
+
+    def __init__(self, pairs, root='.', dtype=numpy.float32, label_dtype=numpy.int32, image_size=None,
+                 image_mode='RGB', transform_probability=0, return_dummy_scores=True):
+        if isinstance(pairs, str):
+            with open(pairs) as pairs_file:
+                reader = csv.reader(pairs_file, delimiter='\t')
+                pairs = [(pair[0], list(map(label_dtype, pair[1:]))) for pair in reader]
+        if transform_probability > 0:
+            _no_imgaug()
+        self.transform_probability = transform_probability
+        self._pairs, self._root, self._dtype, self._label_dtype = pairs, root, dtype, label_dtype
+        self.image_size, self.image_mode, self.return_dummy_scores = image_size, image_mode, return_dummy_scores
+
+    def __len__(self):
+        return len(self._pairs)
+
+    def __getitem__(self, i):
+        return self.get_example(i)
+
+    def shrink_dataset(self, new_size):
+        self._pairs = self._pairs[:new_size]
+
+    def check_for_bad_label(self, label, image_size):
+        error_text = ("Label can not be scaled correctly are you sure you created the dataset correctly, and provided "
+                      f"the correct sizes? Image size: {image_size}, label: {label}")
+        ten_percent_extra = [size * 0.1 for size in image_size]
+        assert (label[:, 0] >= 0 - ten_percent_extra[0]).all(), error_text
+        assert (label[:, 1] >= 0 - ten_percent_extra[1]).all(), error_text
+        assert (label[:, 2] <= image_size[0] + ten_percent_extra[0]).all(), error_text
+        assert (label[:, 3] <= image_size[1] + ten_percent_extra[1]).all(), error_text
+
+    def _base_example(self, i):
+        path, label = self._pairs[i]
+        image = _read_image_as_array(os.path.join(self._root, path), self._dtype)
+        return image, numpy.array(label, dtype=self._label_dtype)
+
+    def get_example(self, i):
+        try:
+            image, label = self._base_example(i)
+        except Exception as e:          # reference :148-152: fall back to sample 0
+            print(e)
+            image, label = self._base_example(0)
+
+        if len(label.shape) > 0 and len(label) % 4 == 0:
+            num_bboxes = len(label) // 4
+            label = numpy.reshape(label, (num_bboxes, -1))
+
+        if image.shape[0] == 1:
+            image = numpy.tile(image, (3, 1, 1))
+        image = image[:3]
+
+        if self.image_size is not None:
+            image_size = image.shape[-2:]
+            if len(label.shape) > 1:
+                self.check_for_bad_label(label, image_size)
+                label = resize_bbox(label.astype(numpy.float32), image_size, self.image_size)
+            image = resize_image(image, self.image_size, image_mode=self.image_mode)
+            label = label.astype(self._label_dtype)
+
+        if len(image.shape) == 2:
+            image = image[None, ...]
+
+        image = numpy.ascontiguousarray(image / 255, dtype=numpy.float32)
+        if self.return_dummy_scores:
+            return image, label, numpy.zeros((1,))
+        return image, label

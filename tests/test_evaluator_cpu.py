@@ -27,3 +27,17 @@ def test_voc_ap_single_class_all_hits_and_half_hits():
     # hits ranked first -> AP = recall reached at precision 1
     r = eval_detection_voc([miss, miss, hit, hit], zeros, ones, gt, zeros)
     np.testing.assert_allclose(r['ap'][0], 0.5)
+
+
+def test_get_aabb_corners_clips_and_orders():
+    import evaluate
+    import loans_amd
+    from oracle import chainer_ops as C
+    theta = np.array([[[0.5, 0.2, 0.1], [-0.1, 0.6, 0.0]], [[1.5, 0, 0], [0, 1.5, 0]]], np.float32)
+    grid, _ = C.st_grid_fwd(theta, (5, 7))
+    top, left, bottom, right = evaluate.get_aabb_corners(grid, loans_amd.Size(100, 200))
+    g = (grid + 1) / 2
+    xs, ys = np.clip(g[:, 0] * 200, 0, 200), np.clip(g[:, 1] * 100, 0, 100)
+    np.testing.assert_allclose(top, np.minimum(ys[:, 0, 0], ys[:, 0, -1]))
+    np.testing.assert_allclose(right, np.maximum(xs[:, 0, -1], xs[:, -1, -1]))
+    assert (top[1], left[1], bottom[1], right[1]) == (0.0, 0.0, 100.0, 200.0)      # scale 1.5 -> clipped to the frame
