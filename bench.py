@@ -5,9 +5,10 @@ One "step" = one ``SheepAssessor.update_core`` (reference sheep/sheep_updater.py
 assessor forward on the labelled batch, localizer forward, STN crop, assessor forward on the
 crops, localizer-chain backward + Adam-AMSGrad, assessor-chain backward + Adam-AMSGrad.
 
-Workload (BASELINE.json): N=1 -> configs[1] shape, batch 256 x 3 x 224 x 224 fp32 on one GPU
-(the full joint step, a superset of "localizer forward+backward only"); N>1 -> configs[3],
-128 frames per GPU (global 1024 at N=8), gradients all-reduced over RCCL.  Synthetic
+Workload (BASELINE.json): configs[1] shape per GPU -- batch 256 x 3 x 224 x 224 fp32 (the full joint step, a
+superset of "localizer forward+backward only").  For N>1 every rank keeps that per-GPU batch (weak scaling, the
+per-GPU work is identical at every N so the driver's efficiency compares like with like) and gradients are
+all-reduced over RCCL; `--batch 128` gives configs[3] exactly (global 1024 at N=8).  Synthetic
 paste-and-crop frames, random-init weights; inputs are resident in HBM before timing.
 
 Prints ONE JSON line (rank 0) with the contract keys plus
@@ -38,7 +39,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=0, help='per-GPU batch (default 256 at N=1, 128 at N>1)')
+    ap.add_argument('--batch', type=int, default=0, help='per-GPU batch (default 256 = configs[1] for every N: weak scaling; 128 reproduces configs[3])')
     ap.add_argument('--image-size', type=int, default=224)
     ap.add_argument('--target-size', type=int, default=75)
     ap.add_argument('--resnet50', action='store_true', help='Resnet50SheepLocalizer backbone (BASELINE configs[4] architecture, fp32)')
@@ -89,7 +90,7 @@ def main():
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
 
-    B = args.batch or (256 if world == 1 else 128)
+    B = args.batch or 256
     hw, crop = args.image_size, args.target_size
 
     # ---- synthetic inputs, resident in HBM ----
@@ -168,7 +169,7 @@ def main():
             assert tot_flop // args.steps == B * CONV_FWD_FLOP_PER_IMAGE_224, (tot_flop // args.steps, B)
 
     if world > 1:
-        cfg_label = "configs[3]" if (hw == 224 and B == 128 and not args.resnet50) else "custom"
+        cfg_label = ("configs[3]" if B == 128 else "configs[1] per GPU, data parallel") if (hw == 224 and not args.resnet50 and args.dtype == 'f32') else "custom"
     elif hw == 224 and B == 256 and not args.resnet50 and args.dtype == 'f32':
         cfg_label = "configs[1]"
     elif hw == 512 and B == 128 and not args.resnet50 and args.dtype == 'bf16':
