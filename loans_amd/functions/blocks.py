@@ -116,17 +116,18 @@ class ResidualUnitFunction(Function):
             Ws, gs, bs = P[1 + 3 * n:4 + 3 * n]
             g, gcs = ops.bn_backward(gout, self.out, self.c[-1], self.st[-1], gl.data, gl.grad_view, bl.grad_view,
                                      x2=self.cs, st2=self.sts, gamma2=gs.data, ggamma2=gs.grad_view, gbeta2=bs.grad_view)
-            ops.conv_wgrad(self.x, gcs, Ws.grad_view, self.geos)
         else:
             g = ops.bn_backward(gout, self.out, self.c[-1], self.st[-1], gl.data, gl.grad_view, bl.grad_view)
         for i in range(n - 1, 0, -1):
             W, _, _ = P[1 + 3 * i:4 + 3 * i]
-            ops.conv_wgrad(self.h[i - 1], g, W.grad_view, self.geo[i])
+            # dgrad first: the weight gradient goes to the side stream and, enqueued after the dgrad, starts when
+            # that finishes -- it then overlaps the HBM-bound BN passes that follow instead of fighting the dgrad
+            # for the matrix pipes
             gh = ops.conv_dgrad(g, W.data, self.geo[i])
+            ops.conv_wgrad(self.h[i - 1], g, W.grad_view, self.geo[i])
             _, gp, bp = P[1 + 3 * (i - 1):4 + 3 * (i - 1)]
             g = ops.bn_backward(gh, self.h[i - 1], self.c[i - 1], self.st[i - 1], gp.data, gp.grad_view, bp.grad_view)
         W0 = P[1]
-        ops.conv_wgrad(self.x, g, W0.grad_view, self.geo[0])
         gx = None
         if P[0].requires_grad:
             if self.shortcut is not None:
@@ -135,6 +136,9 @@ class ResidualUnitFunction(Function):
             else:
                 # gx = dgrad(g) + gout * (out > 0)     (identity shortcut through the final ReLU)
                 gx = ops.conv_dgrad(g, W0.data, self.geo[0], addend=gout, addend_mask_ref=self.out)
+        ops.conv_wgrad(self.x, g, W0.grad_view, self.geo[0])
+        if self.shortcut is not None:
+            ops.conv_wgrad(self.x, gcs, P[1 + 3 * n].grad_view, self.geos)
         return (gx,) + (None,) * (len(P) - 1)
 
     def release(self):
@@ -174,14 +178,13 @@ class DownResBlock1Function(Function):
         xv, W0, W1, Ws = self.inputs
         g = gys[0].contiguous()
         wg = _wgrad_enabled(W0)
-        if wg:
-            ops.conv_wgrad(self.h1, g, W1.grad_view, self.g1, relu_in=True)
-            ops.conv_wgrad(self.x, g, Ws.grad_view, self.gs)
         need_gx = xv.requires_grad
         if not (wg or need_gx):
             return None, None, None, None
         gh1 = ops.conv_dgrad(g, W1.data, self.g1, mask_ref=self.h1)
         if wg:
+            ops.conv_wgrad(self.h1, g, W1.grad_view, self.g1, relu_in=True)
+            ops.conv_wgrad(self.x, g, Ws.grad_view, self.gs)
             ops.conv_wgrad(self.x, gh1, W0.grad_view, self.g0)
         gx = None
         if need_gx:
@@ -216,11 +219,10 @@ class DownResBlock2Function(Function):
         xv, W0, W1, Ws = self.inputs
         g = gys[0].contiguous()
         wg = _wgrad_enabled(W0)
+        gh1 = ops.conv_dgrad(g, W1.data, self.g1, mask_ref=self.h1)
         if wg:
             ops.conv_wgrad(self.h1, g, W1.grad_view, self.g1, relu_in=True)
             ops.conv_wgrad(self.x, g, Ws.grad_view, self.gs)
-        gh1 = ops.conv_dgrad(g, W1.data, self.g1, mask_ref=self.h1)
-        if wg:
             ops.conv_wgrad(self.x, gh1, W0.grad_view, self.g0, relu_in=True)
         gx = ops.conv_dgrad(g, Ws.data, self.gs)
         ops.conv_dgrad(gh1, W0.data, self.g0, out=gx, mask_ref=self.x, addend=gx)
@@ -250,12 +252,12 @@ class DownResBlock3Function(Function):
         xv, W0, W1 = self.inputs
         g = gys[0].contiguous()
         wg = _wgrad_enabled(W0)
-        if wg:
-            ops.conv_wgrad(self.h1, g, W1.grad_view, self.g1, relu_in=True)
         gh1 = ops.conv_dgrad(g, W1.data, self.g1, mask_ref=self.h1)
         if wg:
-            ops.conv_wgrad(self.x, gh1, W0.grad_view, self.g0, relu_in=True)
+            ops.conv_wgrad(self.h1, g, W1.grad_view, self.g1, relu_in=True)
         gx = ops.conv_dgrad(gh1, W0.data, self.g0, mask_ref=self.x, addend=g)
+        if wg:
+            ops.conv_wgrad(self.x, gh1, W0.grad_view, self.g0, relu_in=True)
         return gx, None, None
 
     def release(self):
