@@ -51,6 +51,7 @@ struct IgemmArgs {
     const float* addend;
     loans_igemm_desc d;
     int M, Ktot, nchunks, tiles_m, tiles_n;
+    int tail_groups;    // 8-deep k groups of the last chunk that hold any real K (1..4)
     int bf16;           // 1: round the operands to bf16 and use the bf16 MFMA (fp32 accumulate)
     unsigned in_bytes, w_bytes, out_bytes;
     struct {            // nx > 0: taps are an ny x nx grid, dy = dy0 + row*sdy, dx = dx0 + col*sdx, sd* = +-1
@@ -383,15 +384,21 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
         s_load += t1 - t0; s_mfma += t2 - t1; s_store += t3 - t2; s_bar += t4 - t3;
 #endif
     }
-    {   // last chunk: nothing left to stage
+    {   // last chunk: nothing left to stage; 8-deep groups that lie wholly beyond Ktot hold zeros on both sides
+        // and are skipped (block-uniform branch): exact, and a quarter of the stem's K is such padding
         const int buf = c & 1;
-        read_frag(buf, 1, fa1, fb1);
+        const int tg = a.tail_groups;
+        if (tg > 1) read_frag(buf, 1, fa1, fb1);
         mma(fa0, fb0);
-        read_frag(buf, 2, fa0, fb0);
-        mma(fa1, fb1);
-        read_frag(buf, 3, fa1, fb1);
-        mma(fa0, fb0);
-        mma(fa1, fb1);
+        if (tg > 1) {
+            if (tg > 2) read_frag(buf, 2, fa0, fb0);
+            mma(fa1, fb1);
+            if (tg > 2) {
+                if (tg > 3) read_frag(buf, 3, fa1, fb1);
+                mma(fa0, fb0);
+                if (tg > 3) mma(fa1, fb1);
+            }
+        }
     }
     }   // fp32 / bf16 K loop
 #ifdef LOANS_STAMPS
@@ -589,6 +596,7 @@ static int igemm_impl(const float* in, const float* w, float* out, const float* 
     a.M = d->B * d->gridH * d->gridW;
     a.Ktot = d->ntaps * d->Cin;
     a.nchunks = (a.Ktot + BK - 1) / BK;
+    a.tail_groups = (a.Ktot - (a.nchunks - 1) * BK + 7) / 8;
     {
         const int64_t ib = (int64_t)d->B * d->inH * d->inW * d->Cin * 4, wb = (int64_t)d->Cout * a.Ktot * 4;
         const int64_t ob = (int64_t)d->B * d->outH * d->outW * d->Cout * 4;

@@ -32,3 +32,26 @@ print('\nResNet-18 conv forward: 21 igemm launches, %.1f us total, avg %.1f us p
 print('algorithmic FLOP per step %d -> %.2f TFLOP/s = %.1f %% of the 157.3 TFLOP/s fp32 MFMA peak' % (flop, flop / t / 1e6, flop / t / 1e6 / 157.3 * 100))
 for r in fwd:
     print('   %-40s grid %9s  %8.1f us' % (short(r['Kernel_Name']), r['Grid_Size_X'], dur(r)))
+
+
+def union(iv):
+    iv = sorted(iv)
+    out, cs, ce = 0, None, None
+    for s, e in iv:
+        if cs is None or s > ce:
+            if cs is not None:
+                out += ce - cs
+            cs, ce = s, e
+        else:
+            ce = max(ce, e)
+    return out + (ce - cs if cs is not None else 0)
+
+
+iv = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']) for r in seg]
+mf = [(s, e) for s, e, n in iv if 'igemm_kernel' in n or 'wgrad_kernel' in n]
+al = [(s, e) for s, e, n in iv]
+t0, t1 = min(s for s, _ in al), max(e for _, e in al)
+print('\ntimeline of the step: %.2f ms; some kernel running %.2f ms (%.1f %%); an MFMA GEMM running %.2f ms (%.1f %%); '
+      'only non-GEMM kernels running %.2f ms; idle %.2f ms'
+      % ((t1 - t0) / 1e6, union(al) / 1e6, union(al) / (t1 - t0) * 100, union(mf) / 1e6, union(mf) / (t1 - t0) * 100,
+         (union(al) - union(mf)) / 1e6, (t1 - t0 - union(al)) / 1e6))
