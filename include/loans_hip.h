@@ -46,6 +46,10 @@ extern "C" {
 #define LOANS_F_MASK      8   /* out = (ref[m][n] > 0) ? out : 0        (ReLU backward folded into dgrad) */
 #define LOANS_F_ADDEND   16   /* out += addend[m][n]                    (residual sums; may alias out) */
 #define LOANS_F_ADDEND_MASK 32 /* with ADDEND: out += (ref[m][n] > 0) ? addend[m][n] : 0  (identity shortcut through a ReLU) */
+#define LOANS_F_DENSE     64   /* dense K rows for packed 3-channel images (conv1 7x7/2, sheep/resnet.py:43): `in` is a zero-padded
+                                 [B][inH][inW floats] buffer (loans_prep_images_dense_f32), inW / isx / dx[] count FLOATS,
+                                 tap t is the run of Cin consecutive floats at row y*isy + dy[t], float x*isx + dx[t]; w is
+                                 [Cout][ntaps][Cin].  No bounds masks: every run must lie inside its row (checked). */
 
 /*
  * One implicit-GEMM problem:  out[m][n] = sum_{t<ntaps} sum_{c<Cin} in[pix(m,t)][c] * w[n][t][c]
@@ -113,6 +117,10 @@ int loans_repack_dgrad_f32(const float* src, float* dst, int32_t Cout, int32_t C
 /* ---- preprocessing (replaces the per-image PIL round trip of resnet.prepare,
  *      sheep/sheep_localizer.py:45,72-82): NCHW RGB [0,1] -> trunc_u8(x*255) -> BGR - mean -> NHWC4 ---- */
 int loans_prep_images_f32(const float* images_nchw, float* out_nhwc4, int32_t B, int32_t H, int32_t W, void* stream);
+/* same arithmetic, written as packed 3-channel rows into a zero-padded [B][Hp][Wp][3] buffer with the image at
+ * (pad, pad): the LOANS_F_DENSE input of conv1.  Every element of the buffer is written. */
+int loans_prep_images_dense_f32(const float* images_nchw, float* out_padded, int32_t B, int32_t H, int32_t W,
+                                int32_t pad, int32_t Hp, int32_t Wp, void* stream);
 /* NCHW (C=3) -> NHWC4 without arithmetic (the assessor's `real` batch, sheep_updater.py:32-35) */
 int loans_nchw3_to_nhwc4_f32(const float* in, float* out, int32_t B, int32_t H, int32_t W, void* stream);
 

@@ -13,6 +13,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libloans_hip.so')
 
 MAX_TAPS = 64
 F_RELU_IN, F_BIAS, F_STATS, F_MASK, F_ADDEND, F_ADDEND_MASK = 1, 2, 4, 8, 16, 32
+F_DENSE = 64
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_256x64 = 0, 1, 2, 3, 4
 
 
@@ -40,6 +41,7 @@ SIGNATURES = {
     'loans_dgrad_c4_f32': [_p, _p, _p, _p, _p, C.POINTER(IgemmDesc), C.POINTER(_i32), _i32, _p],
     'loans_repack_dgrad_f32': [_p, _p, _i32, _i32, _i32, C.POINTER(_i32), _i32, _p],
     'loans_prep_images_f32': [_p, _p, _i32, _i32, _i32, _p],
+    'loans_prep_images_dense_f32': [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p],
     'loans_nchw3_to_nhwc4_f32': [_p, _p, _i32, _i32, _i32, _p],
     'loans_bn_finalize_f32': [_p, _i32, _i64, _f32, _f32, _p, _p, _p, _p, _i32, _p, _p, _p, _p, _p],
     'loans_bn_eval_coeffs_f32': [_i32, _f32, _p, _p, _p, _p, _p, _p, _p, _p, _p],

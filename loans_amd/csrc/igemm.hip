@@ -103,9 +103,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     const int tm = logical / a.tiles_n;
     const int lu = tid & 7, lrow = tid >> 3;
     // tap table in LDS: byte offset of tap t relative to the row's base pixel
+    // LOANS_F_DENSE: inW / isx / dx count floats (packed 3-channel rows), a "tap" is a run of Cin consecutive
+    // floats of one input row, and the caller's zero padding makes every tap of every pixel readable
+    const bool dense = d.flags & LOANS_F_DENSE;
+    const int ubytes = dense ? 4 : d.Cin * 4;          // bytes per unit of inW / ix
     if (tid < LOANS_MAX_TAPS) {
         const int t = tid < d.ntaps ? tid : 0;
-        taps[tid] = (int(d.dy[t]) * d.inW + int(d.dx[t])) * d.Cin * 4;
+        taps[tid] = (int(d.dy[t]) * d.inW + int(d.dx[t])) * ubytes;
     }
 
     // per row (fixed for the whole K loop): byte offset of its base pixel and a bitmask with bit t SET
@@ -131,9 +135,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
             rowoff[i] = 0;
             if (m < a.M) {
                 const int iy0 = y * d.isy, ix0 = x * d.isx;
-                rowoff[i] = (unsigned)(((b * d.inH + iy0) * d.inW + ix0) * d.Cin) * 4u;
+                rowoff[i] = (unsigned)((b * d.inH + iy0) * d.inW + ix0) * (unsigned)ubytes;
                 pixoff = (unsigned)((b * d.outH + y * d.osy + d.oy0) * d.outW + x * d.osx + d.ox0) * (unsigned)d.Cout * 4u;
-                if (a.ap.nx > 0) {
+                if (dense) {
+                    mask = ~0ull;
+                } else if (a.ap.nx > 0) {
                     // column j valid <=> 0 <= ix0 + dx0 + j*sdx < inW  (sdx = +-1): a contiguous j range
                     const int cx = ix0 + a.ap.dx0, cy = iy0 + a.ap.dy0;
                     int jlo, jhi, rlo, rhi;
@@ -570,10 +576,18 @@ int check_desc(const loans_igemm_desc* d) {
     if ((d->gridW - 1) * d->osx + d->ox0 >= d->outW) return LOANS_EINVAL;
     if (d->ntaps < 1 || d->ntaps > LOANS_MAX_TAPS) return LOANS_EINVAL;
     const int64_t lim = (int64_t)1 << 31;
-    if ((int64_t)d->B * d->inH * d->inW * d->Cin >= lim) return LOANS_ERANGE;
+    if ((int64_t)d->B * d->inH * d->inW * ((d->flags & LOANS_F_DENSE) ? 1 : d->Cin) >= lim) return LOANS_ERANGE;
     if ((int64_t)d->B * d->outH * d->outW * d->Cout >= lim) return LOANS_ERANGE;
     if ((int64_t)d->B * d->gridH * d->gridW >= lim) return LOANS_ERANGE;
     if ((int64_t)d->ntaps * d->Cin * d->Cout >= lim) return LOANS_ERANGE;
+    if (d->flags & LOANS_F_DENSE) {
+        // no bounds masks in this mode: every K-row of every grid pixel has to lie inside its input row
+        for (int t = 0; t < d->ntaps; ++t) {
+            if (d->dy[t] < 0 || d->dx[t] < 0) return LOANS_EINVAL;
+            if ((d->gridH - 1) * d->isy + d->dy[t] >= d->inH) return LOANS_EINVAL;
+            if ((d->gridW - 1) * d->isx + d->dx[t] + d->Cin > d->inW) return LOANS_EINVAL;
+        }
+    }
     return LOANS_OK;
 }
 
@@ -598,7 +612,8 @@ static int igemm_impl(const float* in, const float* w, float* out, const float* 
     a.nchunks = (a.Ktot + BK - 1) / BK;
     a.tail_groups = (a.Ktot - (a.nchunks - 1) * BK + 7) / 8;
     {
-        const int64_t ib = (int64_t)d->B * d->inH * d->inW * d->Cin * 4, wb = (int64_t)d->Cout * a.Ktot * 4;
+        const int64_t ib = (int64_t)d->B * d->inH * d->inW * ((d->flags & LOANS_F_DENSE) ? 1 : d->Cin) * 4;
+        const int64_t wb = (int64_t)d->Cout * a.Ktot * 4;
         const int64_t ob = (int64_t)d->B * d->outH * d->outW * d->Cout * 4;
         if (ib >= 0xFFFFFFF0ll || wb >= 0xFFFFFFF0ll || ob >= 0xFFFFFFF0ll) return LOANS_ERANGE;   // 32-bit buffer offsets
         a.in_bytes = (unsigned)ib;
@@ -680,6 +695,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     const int unit = tid % UPR, prow = tid / UPR;
 
     // this thread's fixed column of the X tile: (tap, c4)
+    const int ucin = (d.flags & LOANS_F_DENSE) ? 1 : d.Cin;     // floats per unit of inW / ix (see igemm_kernel)
     const int cpt = d.Cin >> 2;
     const int ug = tj * UPR + unit;
     const int xtap = ug / cpt;
@@ -725,7 +741,7 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
         const int iy = y * d.isy + dy, ix = x * d.isx + dx;
         const unsigned ok = (unsigned)(rv & xtv) & (unsigned)((unsigned)iy < (unsigned)d.inH) &
                             (unsigned)((unsigned)ix < (unsigned)d.inW);
-        const unsigned xoff = ((unsigned)(((b * d.inH + iy) * d.inW + ix) * d.Cin + xc4 * 4) * 4u) | (ok - 1u);
+        const unsigned xoff = ((unsigned)(((b * d.inH + iy) * d.inW + ix) * ucin + xc4 * 4) * 4u) | (ok - 1u);
         rx[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)xoff, 0, 0));
         // advance 32 pixels: exact floor((v + .5) / n) for the small integers involved
         int nx = x + 32;
@@ -952,7 +968,8 @@ static int wgrad_impl(const float* x, const float* gy, float* dw, const loans_ig
     a.M = d->B * d->gridH * d->gridW;
     a.Ktot = d->ntaps * d->Cin;
     {
-        const int64_t xb = (int64_t)d->B * d->inH * d->inW * d->Cin * 4, gb = (int64_t)d->B * d->outH * d->outW * d->Cout * 4;
+        const int64_t xb = (int64_t)d->B * d->inH * d->inW * ((d->flags & LOANS_F_DENSE) ? 1 : d->Cin) * 4;
+        const int64_t gb = (int64_t)d->B * d->outH * d->outW * d->Cout * 4;
         if (xb >= 0xFFFFFFF0ll || gb >= 0xFFFFFFF0ll) return LOANS_ERANGE;
         a.x_bytes = (unsigned)xb;
         a.gy_bytes = (unsigned)gb;

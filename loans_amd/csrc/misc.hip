@@ -32,6 +32,29 @@ __global__ __launch_bounds__(256) void prep_kernel(const float* img, float* out,
     }
 }
 
+// packed 3-channel rows inside a zero border: one thread per (b, yp, xp) of the padded buffer
+__global__ __launch_bounds__(256) void prep_dense_kernel(const float* img, float* out, int B, int H, int W, int pad, int Hp, int Wp) {
+    const int64_t total = (int64_t)B * Hp * Wp;
+    const int64_t HW = (int64_t)H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int xp = (int)(i % Wp);
+        const int64_t t = i / Wp;
+        const int yp = (int)(t % Hp);
+        const int64_t b = t / Hp;
+        const int y = yp - pad, x = xp - pad;
+        float v0 = 0.f, v1 = 0.f, v2 = 0.f;
+        if ((unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W) {
+            const float* src = img + b * 3 * HW + (int64_t)y * W + x;
+            const float r = (float)(((int)(src[0] * 255.f)) & 255);
+            const float g = (float)(((int)(src[HW] * 255.f)) & 255);
+            const float bl = (float)(((int)(src[2 * HW] * 255.f)) & 255);
+            v0 = bl - 103.063f; v1 = g - 115.903f; v2 = r - 123.152f;
+        }
+        float* o = out + i * 3;
+        o[0] = v0; o[1] = v1; o[2] = v2;
+    }
+}
+
 __global__ __launch_bounds__(256) void nchw3_to_nhwc4_kernel(const float* in, float* out, int B, int HW) {
     const int64_t total = (int64_t)B * HW;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -395,6 +418,17 @@ extern "C" int loans_prep_images_f32(const float* images_nchw, float* out_nhwc4,
     if (!images_nchw || !out_nhwc4 || B <= 0 || H <= 0 || W <= 0) return LOANS_EINVAL;
     if ((int64_t)H * W >= ((int64_t)1 << 31)) return LOANS_ERANGE;
     hipLaunchKernelGGL(prep_kernel, dim3(grid_for((int64_t)B * H * W, 256)), dim3(256), 0, as_stream(stream), images_nchw, out_nhwc4, B, H * W);
+    LOANS_LAUNCH_CHECK();
+    return LOANS_OK;
+}
+
+extern "C" int loans_prep_images_dense_f32(const float* images_nchw, float* out_padded, int32_t B, int32_t H, int32_t W,
+                                           int32_t pad, int32_t Hp, int32_t Wp, void* stream) {
+    if (!images_nchw || !out_padded || B <= 0 || H <= 0 || W <= 0 || pad < 0) return LOANS_EINVAL;
+    if (Hp < H + pad || Wp < W + pad) return LOANS_EINVAL;
+    if ((int64_t)B * Hp * Wp * 3 >= ((int64_t)1 << 31)) return LOANS_ERANGE;
+    hipLaunchKernelGGL(prep_dense_kernel, dim3(grid_for((int64_t)B * Hp * Wp, 256)), dim3(256), 0, as_stream(stream),
+                       images_nchw, out_padded, B, H, W, pad, Hp, Wp);
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;
 }

@@ -30,6 +30,10 @@ class _ConvBN:
     @staticmethod
     def forward(x, conv, bn, W, b, gamma, beta):
         B, H, Wd, _ = x.shape
+        if conv.dense_rows:
+            if not hasattr(x, 'frame_hw'):
+                raise ValueError('a dense-row stem takes the padded frame buffer of ops.prep_images(images, geometry)')
+            H, Wd = x.frame_hw
         geo = conv.geometry(B, H, Wd)
         if config.train:
             stats = _zeros_stats(conv.out_channels, x.device)
@@ -48,7 +52,8 @@ def _require_train():
 
 class StemFunction(Function):
     """conv1(7x7/2, bias) -> bn1 -> relu -> max_pool(3, 2, cover_all)   (sheep/resnet.py:72-73).
-    inputs: x (NHWC4 preprocessed frames, no gradient), W, b, gamma, beta."""
+    inputs: x (preprocessed frames: the zero-padded packed-RGB buffer of ops.prep_images(images, geometry) for a
+    dense-row conv1, NHWC4 otherwise; no gradient), W, b, gamma, beta."""
 
     def __init__(self, conv, bn):
         self.conv, self.bn = conv, bn

@@ -71,7 +71,7 @@ class ResNet50Layers(Chain):
         super().__init__()
         w = L.HeNormal(scale=1.0)
         with self.init_scope():
-            self.conv1 = L.Convolution2D(3, 64, 7, 2, 3, initialW=w)
+            self.conv1 = L.Convolution2D(3, 64, 7, 2, 3, initialW=w, dense_rows=True)
             self.bn1 = L.BatchNormalization(64)
             self.res2 = BuildingBlock(3, 64, 64, 256, 1, w)
             self.res3 = BuildingBlock(4, 256, 128, 512, 2, w)

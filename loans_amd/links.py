@@ -48,24 +48,40 @@ class Convolution2D(Link):
     """``L.Convolution2D(in_channels, out_channels, ksize, stride, pad, nobias, initialW)``.
     W is stored OHWI with the input channels padded to a multiple of 4."""
 
-    def __init__(self, in_channels, out_channels, ksize=None, stride=1, pad=0, nobias=False, initialW=None):
+    def __init__(self, in_channels, out_channels, ksize=None, stride=1, pad=0, nobias=False, initialW=None,
+                 dense_rows=False):
         super().__init__()
         if in_channels is None:
             raise ValueError('lazy in_channels is not supported: pass the channel count')
         self.in_channels, self.out_channels = in_channels, out_channels
         self.ksize, self.stride, self.pad = ksize, stride, pad
         self.cin_phys = _pad4(in_channels)
+        # dense_rows (RGB stem): the input is the zero-padded packed-RGB frame buffer of ops.prep_images(..., geo)
+        # and W is stored [Cout][kh][kwp][3] with zero weights on the kwp - kw window-padding pixels
+        self.dense_rows = dense_rows
         init = initialW if initialW is not None else LeCunNormal()
         w = init((out_channels, in_channels, ksize, ksize))
         cin, cp = in_channels, self.cin_phys
 
-        def to_logical(phys):
-            return phys.transpose(0, 3, 1, 2)[:, :cin]
+        if dense_rows:
+            assert in_channels == 3
+            kwp = ops.dense_window(ksize)
 
-        def from_logical(a):
-            out = np.zeros((a.shape[0], a.shape[2], a.shape[3], cp), np.float32)
-            out[..., :cin] = a.transpose(0, 2, 3, 1)
-            return out
+            def to_logical(phys):
+                return phys[:, :, :ksize, :].transpose(0, 3, 1, 2)
+
+            def from_logical(a):
+                out = np.zeros((a.shape[0], ksize, kwp, 3), np.float32)
+                out[:, :, :ksize, :] = a.transpose(0, 2, 3, 1)
+                return out
+        else:
+            def to_logical(phys):
+                return phys.transpose(0, 3, 1, 2)[:, :cin]
+
+            def from_logical(a):
+                out = np.zeros((a.shape[0], a.shape[2], a.shape[3], cp), np.float32)
+                out[..., :cin] = a.transpose(0, 2, 3, 1)
+                return out
 
         with self.init_scope():
             self.W = Parameter(from_logical(w), w.shape, to_logical, from_logical)
@@ -78,7 +94,10 @@ class Convolution2D(Link):
         key = (B, H, W)
         g = self._geo.get(key)
         if g is None:
-            g = ops.ConvGeometry(B, H, W, self.cin_phys, self.out_channels, self.ksize, self.stride, self.pad)
+            if self.dense_rows:
+                g = ops.ConvGeometry(B, H, W, 3, self.out_channels, self.ksize, self.stride, self.pad, dense=True)
+            else:
+                g = ops.ConvGeometry(B, H, W, self.cin_phys, self.out_channels, self.ksize, self.stride, self.pad)
             self._geo[key] = g
         return g
 

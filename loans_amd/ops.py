@@ -8,10 +8,12 @@ fallback: without the built library ``_lib.load()`` raises.
 import ctypes as C
 import os
 
+import numpy as np
+
 import torch
 
 from . import _lib
-from ._lib import (F_ADDEND, F_ADDEND_MASK, F_BIAS, F_MASK, F_RELU_IN, F_STATS, IgemmDesc, check)
+from ._lib import (F_ADDEND, F_ADDEND_MASK, F_BIAS, F_DENSE, F_MASK, F_RELU_IN, F_STATS, IgemmDesc, check)
 
 # Arithmetic of the convolution contractions: 'f32' (exact fp32 MFMA, the parity path) or 'bf16' (operands rounded
 # to bf16 while staged into LDS, bf16 MFMA, fp32 accumulate; tensors stay fp32 in memory).  BASELINE configs 3 / 5.
@@ -66,10 +68,19 @@ class ConvGeometry:
     caller): forward, weight-gradient and the per-stride-parity-class data
     gradient launches.  Channels are the PHYSICAL (multiple-of-4) counts."""
 
-    def __init__(self, B, H, W, Cin, Cout, k, stride, pad):
+    def __init__(self, B, H, W, Cin, Cout, k, stride, pad, dense=False):
         self.B, self.H, self.W, self.Cin, self.Cout = B, H, W, Cin, Cout
         self.k, self.stride, self.pad = k, stride, pad
         self.Ho, self.Wo = conv_outsize(H, k, stride, pad), conv_outsize(W, k, stride, pad)
+        self.dense = dense
+        self.base_flags = 0
+        self.cin_logical = 3 if Cin == 4 else Cin
+        self.tuned = {}
+        if dense:
+            self._init_dense()
+            return
+        self.in_numel = B * H * W * Cin
+        self.w_numel = Cout * k * k * Cin
         d = IgemmDesc()
         d.B, d.inH, d.inW, d.Cin = B, H, W, Cin
         d.outH, d.outW, d.Cout = self.Ho, self.Wo, Cout
@@ -114,8 +125,51 @@ class ConvGeometry:
                 self.dgrad.append((g, tapsel, off))
                 off += Cin * len(taps) * Cout
         self.dgrad_weight_floats = off
-        self.tuned = {}
         self.flops_fwd = 2 * B * self.Ho * self.Wo * Cout * k * k * Cin
+
+    def _init_dense(self):
+        """LOANS_F_DENSE (include/loans_hip.h): the RGB stem reads packed 3-channel rows of a zero-padded frame, so
+        its K is k rows x (kwp pixels x 3) = 7 x 24 = 168 instead of 49 taps x 4 padded channels = 196 and the
+        loader needs no bounds masks.  kwp - k extra window pixels meet zero weights."""
+        B, H, W, k, s, p = self.B, self.H, self.W, self.k, self.stride, self.pad
+        assert self.Cin == 3
+        self.kwp = dense_window(k)
+        self.Hp = H + 2 * p
+        self.Wp = max(W + 2 * p, s * (self.Wo - 1) + self.kwp)
+        self.Wp += self.Wp & 1                  # even: every K row starts on an 8-byte boundary
+        self.in_numel = B * self.Hp * self.Wp * 3
+        self.w_numel = self.Cout * k * self.kwp * 3
+        self.base_flags = F_DENSE
+        d = IgemmDesc()
+        d.B, d.inH, d.inW, d.Cin = B, self.Hp, self.Wp * 3, self.kwp * 3
+        d.outH, d.outW, d.Cout = self.Ho, self.Wo, self.Cout
+        d.gridH, d.gridW = self.Ho, self.Wo
+        d.osy = d.osx = 1
+        d.oy0 = d.ox0 = 0
+        d.isy, d.isx = s, s * 3
+        d.ntaps = k
+        for t in range(k):
+            d.dy[t], d.dx[t] = t, 0
+        self.fwd = d
+        self.dgrad, self.dgrad_has_empty_class, self.dgrad_weight_floats = [], False, 0      # frames get no gradient
+        self.flops_fwd = 2 * B * self.Ho * self.Wo * self.Cout * k * k * 3
+        self._wmask = None
+
+    def wmask(self, device):
+        """1 on the real weights, 0 on the window-padding columns (kx >= k) of the dense layout."""
+        if self._wmask is None or self._wmask.device != device:
+            m = np.zeros((self.Cout, self.k, self.kwp, 3), np.float32)
+            m[:, :, :self.k] = 1.0
+            self._wmask = torch.from_numpy(m).to(device)
+        return self._wmask
+
+
+def dense_window(k):
+    """Pixels per K row of the dense RGB layout: the smallest window >= k whose 3-channel run is whole float4s."""
+    kwp = k
+    while (kwp * 3) % 4:
+        kwp += 1
+    return kwp
 
 
 def _with_flags(desc, flags, tile=0):
@@ -171,10 +225,10 @@ def conv_fprop(x, w, geo, out=None, bias=None, stats=None, relu_in=False, addend
     if out is None:
         out = torch.empty((geo.B, geo.Ho, geo.Wo, geo.Cout), device=x.device, dtype=torch.float32)
     flags = (F_RELU_IN if relu_in else 0) | (F_BIAS if bias is not None else 0) | \
-            (F_STATS if stats is not None else 0) | (F_ADDEND if addend is not None else 0)
-    assert x.numel() == geo.B * geo.H * geo.W * geo.Cin and w.numel() == geo.Cout * geo.k * geo.k * geo.Cin
+            (F_STATS if stats is not None else 0) | (F_ADDEND if addend is not None else 0) | geo.base_flags
+    assert x.numel() == geo.in_numel and w.numel() == geo.w_numel
     if tile == 0:
-        tflags = flags & (F_RELU_IN | F_STATS)
+        tflags = flags & (F_RELU_IN | F_STATS | F_DENSE)
         sstats = stats_buffer(geo.Cout, x.device) if stats is not None else None
 
         def run(t):
@@ -192,9 +246,8 @@ def conv_fprop(x, w, geo, out=None, bias=None, stats=None, relu_in=False, addend
     if log is not None:
         ev1.record()
         # algorithmic FLOPs: logical input channels (3 for the RGB stem), no padding, no im2col redundancy
-        cin = 3 if geo.Cin == 4 else geo.Cin
-        log.append(('fprop_bn' if stats is not None else 'fprop', 2 * geo.B * geo.Ho * geo.Wo * geo.Cout * geo.k * geo.k * cin,
-                    ev0, ev1))
+        log.append(('fprop_bn' if stats is not None else 'fprop',
+                    2 * geo.B * geo.Ho * geo.Wo * geo.Cout * geo.k * geo.k * geo.cin_logical, ev0, ev1))
     return out
 
 
@@ -285,8 +338,8 @@ def conv_wgrad(x, gy, dw, geo, relu_in=False, splits=0, tile=0):
 
 def _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile):
     lib = _lib.load()
-    assert dw.numel() == geo.Cout * geo.k * geo.k * geo.Cin
-    fl = F_RELU_IN if relu_in else 0
+    assert dw.numel() == geo.w_numel and x.numel() == geo.in_numel
+    fl = (F_RELU_IN if relu_in else 0) | geo.base_flags
     wfn = lib.loans_wgrad_bf16_f32 if COMPUTE == 'bf16' else lib.loans_wgrad_f32
     if tile == 0:
         def run(t):
@@ -296,15 +349,27 @@ def _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile):
         tile = _tuned_tile(geo, COMPUTE + 'wgrad', run, _WGRAD_TILES)
     d = _with_flags(geo.fwd, fl, tile)
     check(wfn(_ptr(x), _ptr(gy), _ptr(dw), C.byref(d), splits, _stream()), 'loans_wgrad')
+    if geo.dense:
+        # the window-padding columns of the dense layout saw real pixels: their "gradient" is not one
+        check(lib.loans_mul_f32(_ptr(dw), _ptr(geo.wmask(x.device)), _ptr(dw), dw.numel(), _stream()), 'loans_mul_f32')
 
 
 # --------------------------------------------------------------------------- #
 # preprocessing / layout
 # --------------------------------------------------------------------------- #
-def prep_images(images_nchw):
+def prep_images(images_nchw, geo=None):
+    """NHWC4 frames, or -- for a dense-row stem geometry -- the zero-padded packed-RGB buffer [B][Hp][Wp][3]
+    (tagged with the frame size, which the padded shape alone does not determine)."""
     B, c, H, W = images_nchw.shape
     assert c == 3
     _chk(images_nchw, 'images')
+    if geo is not None and geo.dense:
+        assert (geo.B, geo.H, geo.W) == (B, H, W)
+        out = torch.empty((B, geo.Hp, geo.Wp, 3), device=images_nchw.device, dtype=torch.float32)
+        check(_lib.load().loans_prep_images_dense_f32(_ptr(images_nchw), _ptr(out), B, H, W, geo.pad, geo.Hp, geo.Wp,
+                                                      _stream()), 'loans_prep_images_dense_f32')
+        out.frame_hw = (H, W)
+        return out
     out = torch.empty((B, H, W, 4), device=images_nchw.device, dtype=torch.float32)
     check(_lib.load().loans_prep_images_f32(_ptr(images_nchw), _ptr(out), B, H, W, _stream()), 'loans_prep_images_f32')
     return out

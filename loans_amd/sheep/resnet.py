@@ -30,7 +30,7 @@ class ResNet(Chain):
             raise NotImplementedError("the ImageNet classification head is outside the LoANs training path")
 
         with self.init_scope():
-            self.conv1 = L.Convolution2D(3, 64, 7, 2, 3, initialW=w)
+            self.conv1 = L.Convolution2D(3, 64, 7, 2, 3, initialW=w, dense_rows=True)
             self.bn1 = L.BatchNormalization(64)
             self.res2 = BasicBlock(block[0], 64, 1, in_ch=64)
             self.res3 = BasicBlock(block[1], 128, in_ch=64)
@@ -44,7 +44,7 @@ class ResNet(Chain):
         self.class_labels = class_labels
 
     def __call__(self, x):
-        """x: preprocessed frames, NHWC4.  Returns the NHWC feature map."""
+        """x: preprocessed frames (``prepare_images``: the padded packed-RGB buffer conv1 reads).  Returns the NHWC feature map."""
         h = blocks.StemFunction(self.conv1, self.bn1)(x, self.conv1.W, self.conv1.b, self.bn1.gamma, self.bn1.beta)
         h = self.res2(h)
         h = self.res3(h)

@@ -88,8 +88,9 @@ class SheepLocalizer(Chain):
 
     def prepare_images(self, images):
         """``images * 255`` -> uint8 truncation -> BGR -> minus mean, cutting the graph
-        (sheep_localizer.py:45,72-82); returns NHWC4."""
-        return Variable(ops.prep_images(images), requires_grad=False)
+        (sheep_localizer.py:45,72-82); returns the zero-padded packed-RGB buffer conv1's dense K rows read."""
+        B, _, H, W = images.shape
+        return Variable(ops.prep_images(images, self.feature_extractor.conv1.geometry(B, H, W)), requires_grad=False)
 
     def extract_corners(self, bboxes):
         data = bboxes.data if isinstance(bboxes, Variable) else bboxes

@@ -115,6 +115,61 @@ def test_prep_images_exact():
     assert not out[..., 3].any()
 
 
+def test_prep_images_dense_exact():
+    """the padded packed-RGB buffer conv1 reads: same arithmetic, zero border, every element written"""
+    from loans_amd import ops
+    rng = np.random.RandomState(1)
+    for (B, H, W) in [(3, 20, 24), (2, 9, 11)]:
+        k = rng.randint(0, 256, size=(B, 3, H, W)).astype(np.float32)
+        x = (k / np.float32(255)).astype(np.float32)
+        x[0, 0, 0, :8] = np.clip((k[0, 0, 0, :8] + 0.5) / 255, 0, 1)
+        ref = C.prepare_images(x)
+        geo = ops.ConvGeometry(B, H, W, 3, 64, 7, 2, 3, dense=True)
+        out = ops.prep_images(dev(x), geo)
+        assert out.frame_hw == (H, W) and out.shape == (B, geo.Hp, geo.Wp, 3) and geo.Wp % 2 == 0
+        out = out.cpu().numpy()
+        np.testing.assert_array_equal(out[:, 3:3 + H, 3:3 + W].transpose(0, 3, 1, 2), ref)
+        border = out.copy()
+        border[:, 3:3 + H, 3:3 + W] = 0
+        assert not border.any()
+
+
+@pytest.mark.parametrize("case", [(2, 32, 32, 64, 7, 2, 3), (3, 17, 23, 64, 7, 2, 3), (2, 12, 12, 128, 3, 1, 1),
+                                  (1, 40, 36, 64, 7, 2, 3)])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
+def test_conv_dense_rows(case, tile):
+    """LOANS_F_DENSE: the RGB stem on packed 3-channel rows of a zero-padded frame (K = kh x 24 instead of kh*kw x 4)"""
+    from loans_amd import ops
+    B, H, W, Cout, k, s, p = case
+    rng = np.random.RandomState(sum(case))
+    x = rng.standard_normal((B, 3, H, W)).astype(np.float32)
+    w = (rng.standard_normal((Cout, 3, k, k)) / np.sqrt(3 * k * k)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    geo = ops.ConvGeometry(B, H, W, 3, Cout, k, s, p, dense=True)
+    xp = np.zeros((B, geo.Hp, geo.Wp, 3), np.float32)
+    xp[:, p:p + H, p:p + W] = x.transpose(0, 2, 3, 1)
+    wp = np.zeros((Cout, k, geo.kwp, 3), np.float32)
+    wp[:, :, :k] = w.transpose(0, 2, 3, 1)
+    xd, wd, bd = dev(xp), dev(wp), dev(b)
+    y_ref, col = C.conv2d_fwd(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64), s, p)
+    stats_r = ops.stats_buffer(Cout, 'cuda')
+    itile = tile if tile != 5 else 0
+    y = ops.conv_fprop(xd, wd, geo, bias=bd, stats=stats_r, tile=itile)
+    stats = stats_r.sum(dim=0)
+    assert rel_err(_nchw(y), y_ref) < 2e-6
+    np.testing.assert_allclose(stats[0].cpu().numpy(), y_ref.sum(axis=(0, 2, 3)), rtol=1e-5, atol=1e-4)
+    np.testing.assert_allclose(stats[1].cpu().numpy(), (y_ref ** 2).sum(axis=(0, 2, 3)), rtol=1e-5)
+    if tile in (0, 1, 3, 5):
+        gy = rng.standard_normal(y_ref.shape).astype(np.float32)
+        _, gw_ref, _ = C.conv2d_bwd(x.shape, col, w.astype(np.float64), gy.astype(np.float64), s, p, False)
+        dw = torch.zeros_like(wd)
+        ops.conv_wgrad(xd, dev(_nhwc(gy)), dw, geo, tile=tile)
+        ops.conv_wgrad(xd, dev(_nhwc(gy)), dw, geo, splits=3, tile=tile)          # accumulates
+        got = dw.cpu().numpy()
+        assert rel_err(got[:, :, :k].transpose(0, 3, 1, 2), 2 * gw_ref) < 5e-6
+        assert not got[:, :, k:].any()          # window-padding columns carry no gradient
+
+
 @pytest.mark.parametrize("C_", [64, 128, 512, 2048])
 def test_bn_forward_backward(C_):
     from loans_amd import ops

@@ -82,7 +82,7 @@ def test_link_tree_matches_reference_paths_and_counts():
     assert n224 == 12592902
     assert logical['/feature_extractor/conv1/W'] == (64, 3, 7, 7)
     w = loc.feature_extractor.conv1.W
-    assert w.physical_shape == (64, 7, 7, 4) and not w.host[..., 3].any()
+    assert w.physical_shape == (64, 7, 8, 3) and not w.host[:, :, 7].any()       # dense K rows: 8-pixel RGB windows, the 8th weightless
     np.testing.assert_array_equal(loc.param_predictor.b.host, np.array([0.8, 0, 0, 0, 0.8, 0], np.float32))
     assert not loc.param_predictor.W.host.any()
     st = loc.state_dict_chainer()

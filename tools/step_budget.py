@@ -30,9 +30,13 @@ tot = {'fprop': 0.0, 'dgrad': 0.0, 'wgrad': 0.0}
 totf = {'fprop': 0.0, 'dgrad': 0.0, 'wgrad': 0.0}
 print('%-8s | %-22s | %-22s | %-22s' % ('layer', 'fprop  n x ms (TF)', 'dgrad  n x ms (TF)', 'wgrad  n x ms (TF)'))
 for name, Cin, H, W, Cout, k, s, p, nf, nd, nw in L:
-    geo = ops.ConvGeometry(B, H, W, Cin, Cout, k, s, p)
-    x = torch.randn(B, H, W, Cin, device='cuda'); w = torch.randn(Cout, k, k, Cin, device='cuda') * 0.05
-    gy = torch.randn(B, geo.Ho, geo.Wo, Cout, device='cuda'); y = torch.empty_like(gy); gx = torch.empty_like(x); dw = torch.zeros_like(w)
+    if name == 'stem':          # dense K rows on the padded packed-RGB frame buffer (LOANS_F_DENSE)
+        geo = ops.ConvGeometry(B, H, W, 3, Cout, k, s, p, dense=True)
+        x = torch.randn(B, geo.Hp, geo.Wp, 3, device='cuda'); w = torch.randn(Cout, k, geo.kwp, 3, device='cuda') * 0.05
+    else:
+        geo = ops.ConvGeometry(B, H, W, Cin, Cout, k, s, p)
+        x = torch.randn(B, H, W, Cin, device='cuda'); w = torch.randn(Cout, k, k, Cin, device='cuda') * 0.05
+    gy = torch.randn(B, geo.Ho, geo.Wo, Cout, device='cuda'); y = torch.empty_like(gy); gx = torch.empty(B, H, W, Cin, device='cuda'); dw = torch.zeros_like(w)
     stats = ops.stats_buffer(Cout, 'cuda') if name[0] != 'a' else None
     cin = 3 if Cin == 4 else Cin
     flops = 2.0 * B * geo.Ho * geo.Wo * Cout * k * k * cin

@@ -11,7 +11,7 @@ path = sys.argv[1]
 f = glob.glob(path + '/*/*kernel_trace.csv')[0]
 rows = list(csv.DictReader(open(f)))
 names = [r['Kernel_Name'] for r in rows]
-prep = [i for i, n in enumerate(names) if 'prep_kernel' in n]
+prep = [i for i, n in enumerate(names) if 'prep_kernel' in n or 'prep_dense_kernel' in n]
 seg = rows[prep[-2]:prep[-1]]
 dur = lambda r: (int(r['End_Timestamp']) - int(r['Start_Timestamp'])) / 1e3     # noqa: E731
 short = lambda n: (re.search(r'(\w+_kernel(<[^>]*>)?)', n) or re.search(r'(.{0,40})', n)).group(1)   # noqa: E731
