@@ -77,6 +77,7 @@ typedef struct loans_igemm_desc {
 #define LOANS_TILE_64x64   3
 #define LOANS_TILE_256x64  4
 #define LOANS_TILE_64x128  5   /* wgrad only: 64 output channels x 128 tap-channel columns */
+#define LOANS_TILE_SPLIT   6   /* igemm only: 128x128 tiles over the rows that fill whole machine rounds, 64x64 over the rest (two launches) */
 
 /* ---- convolution (replaces cuDNN ConvolutionForward / BackwardData / BackwardFilter behind
  *      L.Convolution2D: sheep/resnet.py:43,128-133,151-153 ; common/net.py:15-17,37-39,59-60) ---- */

@@ -51,6 +51,7 @@ struct IgemmArgs {
     const float* addend;
     loans_igemm_desc d;
     int M, Ktot, nchunks, tiles_m, tiles_n;
+    int m_begin;        // first GEMM row of this launch (LOANS_TILE_SPLIT runs a row range per tile shape); rows end at M
     int tail_groups;    // 8-deep k groups of the last chunk that hold any real K (1..4)
     int bf16;           // 1: round the operands to bf16 and use the bf16 MFMA (fp32 accumulate)
     unsigned in_bytes, w_bytes, out_bytes;
@@ -122,7 +123,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     {
         const int gHW = d.gridH * d.gridW;
         const float inv_gw = 1.f / (float)d.gridW, inv_gh = 1.f / (float)d.gridH;
-        const int m0 = tm * BM + lrow;
+        const int m0 = a.m_begin + tm * BM + lrow;
         int b = m0 / gHW;
         int rem = m0 - b * gHW;
         int y = rem / d.gridW;
@@ -535,7 +536,7 @@ int launch_igemm_r(IgemmArgs& a, hipStream_t st) {
         if (e != hipSuccess) return (int)e;
         attr_set = true;
     }
-    a.tiles_m = (a.M + BM - 1) / BM;
+    a.tiles_m = (a.M - a.m_begin + BM - 1) / BM;
     a.tiles_n = (a.d.Cout + BN - 1) / BN;
     const int nblk = a.tiles_m * a.tiles_n;
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, st, a);
@@ -608,6 +609,7 @@ static int igemm_impl(const float* in, const float* w, float* out, const float* 
     a.d = *d;
     a.bf16 = bf16;
     a.M = d->B * d->gridH * d->gridW;
+    a.m_begin = 0;
     a.Ktot = d->ntaps * d->Cin;
     a.nchunks = (a.Ktot + BK - 1) / BK;
     a.tail_groups = (a.Ktot - (a.nchunks - 1) * BK + 7) / 8;
@@ -632,6 +634,29 @@ static int igemm_impl(const float* in, const float* w, float* out, const float* 
             tile = big >= 1024 ? LOANS_TILE_128x128 : LOANS_TILE_128x64;
             if ((int64_t)((a.M + 127) / 128) * ((d->Cout + 63) / 64) < 512) tile = LOANS_TILE_64x64;
         }
+    }
+    if (tile == LOANS_TILE_SPLIT) {
+        // 128x128 tiles for as many rows as fill the machine in whole rounds (2 blocks per CU), 64x64 tiles for the
+        // remaining rows: the big tile's better MFMA rate without its last, mostly empty round
+        static int slots = 0;
+        if (!slots) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return LOANS_EINVAL;
+            slots = 2 * prop.multiProcessorCount;
+        }
+        const int tiles_n = (d->Cout + 127) / 128;
+        const int64_t full = ((int64_t)(a.M / 128) * tiles_n / slots) * slots;      // big tiles in whole rounds
+        const int rows_big = (int)(full / tiles_n) * 128;
+        if (rows_big > 0) {
+            IgemmArgs b = a;
+            b.M = rows_big;
+            rc = launch_igemm<128, 128, 2, 2>(b, st);
+            if (rc) return rc;
+        }
+        if (rows_big == a.M) return LOANS_OK;
+        a.m_begin = rows_big;
+        return launch_igemm<64, 64, 2, 2>(a, st);
     }
     switch (tile) {
         case LOANS_TILE_128x128: return launch_igemm<128, 128, 2, 2>(a, st);

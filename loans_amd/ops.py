@@ -63,6 +63,9 @@ def conv_outsize(size, k, s, p, cover_all=False):
     return (size + p * 2 - k) // s + 1
 
 
+_TUNE_CACHE = {}
+
+
 class ConvGeometry:
     """Descriptors for one Convolution2D at a fixed input shape (cached by the
     caller): forward, weight-gradient and the per-stride-parity-class data
@@ -75,7 +78,8 @@ class ConvGeometry:
         self.dense = dense
         self.base_flags = 0
         self.cin_logical = 3 if Cin == 4 else Cin
-        self.tuned = {}
+        # tile choices are a property of the problem shape, not of the layer: equal convs share one table
+        self.tuned = _TUNE_CACHE.setdefault((B, H, W, Cin, Cout, k, stride, pad, dense), {})
         if dense:
             self._init_dense()
             return
@@ -184,7 +188,10 @@ def _with_flags(desc, flags, tile=0):
 # Results do not depend on the tile: K is accumulated in the same order by all.
 # --------------------------------------------------------------------------- #
 AUTOTUNE = os.environ.get('LOANS_AUTOTUNE', '1') != '0'
-_IGEMM_TILES = (1, 2, 3)
+# candidates.  LOANS_TILE_SPLIT (6) only pays where nothing else shares the machine: in backward the dgrad launches run
+# beside the weight-gradient GEMMs of the side stream and the two-launch split measured slower there
+_FPROP_TILES = tuple(int(t) for t in os.environ.get('LOANS_FPROP_TILES', '1,2,3,4,6').split(','))
+_IGEMM_TILES = tuple(int(t) for t in os.environ.get('LOANS_DGRAD_TILES', '1,2,3').split(','))
 _WGRAD_TILES = (1, 3, 5)
 
 
@@ -235,7 +242,7 @@ def conv_fprop(x, w, geo, out=None, bias=None, stats=None, relu_in=False, addend
             scratch = torch.empty((geo.B, geo.Ho, geo.Wo, geo.Cout), device=x.device, dtype=torch.float32)
             check(_igemm_fn(lib)(_ptr(x), _ptr(w), _ptr(scratch), 0, _ptr(sstats), 0, 0,
                                       C.byref(_with_flags(geo.fwd, tflags, t)), _stream()), 'loans_igemm_f32[tune]')
-        tile = _tuned_tile(geo, COMPUTE + 'fprop' + ('_stats' if stats is not None else ''), run, _IGEMM_TILES + (4,))
+        tile = _tuned_tile(geo, COMPUTE + 'fprop' + ('_stats' if stats is not None else ''), run, _FPROP_TILES)
     d = _with_flags(geo.fwd, flags, tile)
     log = EVENT_LOG
     if log is not None:

@@ -42,7 +42,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6])
 def test_conv_fprop_dgrad_wgrad(case, tile):
     from loans_amd import ops
     B, Cin, H, W, Cout, k, s, p = case
@@ -72,7 +72,7 @@ def test_conv_fprop_dgrad_wgrad(case, tile):
     gy = rng.standard_normal(y_ref.shape).astype(np.float32)
     gx_ref, gw_ref, _ = C.conv2d_bwd(x.shape, col, w.astype(np.float64), gy.astype(np.float64), s, p, False)
     gyd = dev(_nhwc(gy))
-    if tile in (0, 1, 2, 3, 4):
+    if tile in (0, 1, 2, 3, 4, 6):
         gx = ops.conv_dgrad(gyd, wd, geo, tile=tile)
         assert rel_err(_nchw(gx, Cin), gx_ref) < 2e-6
         if geo.dgrad_has_empty_class:
@@ -96,9 +96,11 @@ def test_conv_fprop_dgrad_wgrad(case, tile):
     if tile in (0, 1, 3, 5):
         dw = torch.zeros_like(wd)
         ops.conv_wgrad(xd, gyd, dw, geo, tile=tile)
+        ops.join_side_stream()
         got = dw.cpu().numpy().transpose(0, 3, 1, 2)[:, :Cin]
         assert rel_err(got, gw_ref) < 5e-6
         ops.conv_wgrad(xd, gyd, dw, geo, splits=3, tile=tile)       # accumulates
+        ops.join_side_stream()
         got = dw.cpu().numpy().transpose(0, 3, 1, 2)[:, :Cin]
         assert rel_err(got, 2 * gw_ref) < 5e-6
 
@@ -113,6 +115,34 @@ def test_prep_images_exact():
     out = ops.prep_images(dev(x)).cpu().numpy()
     np.testing.assert_array_equal(out[..., :3].transpose(0, 3, 1, 2), ref)
     assert not out[..., 3].any()
+
+
+def test_conv_split_tile():
+    """LOANS_TILE_SPLIT: 128x128 tiles over the rows that fill whole rounds of the machine, 64x64 over the rest --
+    needs more than 2 x CUs big tiles to take the two-launch path, so a wide, shallow problem"""
+    from loans_amd import ops
+    B, Cin, H, W, Cout, k, s, p = 24, 8, 56, 56, 32, 1, 1, 0
+    rng = np.random.RandomState(11)
+    x = rng.standard_normal((B, Cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin)).astype(np.float32)
+    geo = ops.ConvGeometry(B, H, W, Cin, Cout, k, s, p)
+    assert B * H * W > 2 * torch.cuda.get_device_properties(0).multi_processor_count * 128
+    xd, wd = dev(_nhwc(x)), dev(_ohwi(w))
+    y_ref = np.einsum('bchw,oc->bohw', x.astype(np.float64), w[:, :, 0, 0].astype(np.float64))
+    add = rng.standard_normal(y_ref.shape).astype(np.float32)
+    stats_r = ops.stats_buffer(Cout, 'cuda')
+    y = ops.conv_fprop(xd, wd, geo, stats=stats_r, addend=dev(_nhwc(add)), tile=6)
+    assert rel_err(_nchw(y), y_ref + add) < 2e-6
+    stats = stats_r.sum(dim=0)
+    np.testing.assert_allclose(stats[0].cpu().numpy(), y_ref.sum(axis=(0, 2, 3)), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(stats[1].cpu().numpy(), (y_ref ** 2).sum(axis=(0, 2, 3)), rtol=1e-5)
+    y1 = ops.conv_fprop(xd, wd, geo, addend=dev(_nhwc(add)), tile=3)
+    assert torch.equal(y, y1)                       # K is accumulated in the same order by every tile shape
+    gy = rng.standard_normal(y_ref.shape).astype(np.float32)
+    gx_ref = np.einsum('bohw,oc->bchw', gy.astype(np.float64), w[:, :, 0, 0].astype(np.float64))
+    ref_t = rng.standard_normal(x.shape).astype(np.float32)
+    gx = ops.conv_dgrad(dev(_nhwc(gy)), wd, geo, mask_ref=dev(_nhwc(ref_t)), tile=6)
+    assert rel_err(_nchw(gx), gx_ref * (ref_t > 0)) < 2e-6
 
 
 def test_prep_images_dense_exact():
@@ -165,6 +195,7 @@ def test_conv_dense_rows(case, tile):
         dw = torch.zeros_like(wd)
         ops.conv_wgrad(xd, dev(_nhwc(gy)), dw, geo, tile=tile)
         ops.conv_wgrad(xd, dev(_nhwc(gy)), dw, geo, splits=3, tile=tile)          # accumulates
+        ops.join_side_stream()
         got = dw.cpu().numpy()
         assert rel_err(got[:, :, :k].transpose(0, 3, 1, 2), 2 * gw_ref) < 5e-6
         assert not got[:, :, k:].any()          # window-padding columns carry no gradient
