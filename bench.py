@@ -13,7 +13,7 @@ paste-and-crop frames, random-init weights; inputs are resident in HBM before ti
 
 Prints ONE JSON line (rank 0) with the contract keys plus
   roofline     : the ResNet-18 conv-forward MFMA roofline, measured live with HIP events
-                 around the 21 forward implicit-GEMM launches of every timed step
+                 around the forward implicit-GEMM launches (21 convs) of every timed step
   cpu_baseline : the CPU oracle ("port": NumPy restatement of the Chainer graph) timed on
                  the host cores on a bounded sample (B=8) of the same workload (N=1 only).
 """
@@ -147,15 +147,16 @@ def main():
     # ---- conv-forward roofline from the events of the timed steps ----
     roofline = None
     if log:
-        loc = [(tag, flops, s.elapsed_time(e)) for tag, flops, s, e in log if tag == 'fprop_bn']
+        loc = [(tag, flops, s.elapsed_time(e), nl) for tag, flops, s, e, nl in log if tag == 'fprop_bn']
         tot_ms = sum(x[2] for x in loc)
         tot_flop = sum(x[1] for x in loc)
-        n_launch = len(loc)
+        n_launch = sum(x[3] for x in loc)          # a LOANS_TILE_SPLIT conv is two launches
         achieved = tot_flop / (tot_ms * 1e-3) / 1e12
         peak = BF16_MFMA_PEAK_TFLOPS if args.dtype == 'bf16' else FP32_MFMA_PEAK_TFLOPS
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": None,
-                    "kernel": "igemm_kernel (localizer conv forward, %d launches/step)" % (n_launch // args.steps),
+                    "kernel": "igemm_kernel (localizer conv forward: %d convs = %d launches per step)"
+                              % (len(loc) // args.steps, n_launch // args.steps),
                     "avg_launch_ms": round(tot_ms / max(n_launch, 1), 4),
                     "conv_fwd_ms_per_step": round(tot_ms / args.steps, 3),
                     "algorithmic_flop_per_step": tot_flop // args.steps}
@@ -163,7 +164,7 @@ def main():
         # rocprofv3 runs of this same command); only valid for the configuration they were taken on
         tpath = os.path.join(ROOT, 'profiles', 'r1_conv_fwd_hbm_traffic.json')
         if hw == 224 and B == 256 and world == 1 and not args.resnet50 and args.dtype == 'f32' and os.path.exists(tpath):
-            roofline["traffic"] = round(json.load(open(tpath))["bytes_per_launch"])
+            roofline["traffic"] = round(json.load(open(tpath))["total_bytes_per_step"] / (n_launch // args.steps))
             roofline["traffic_unit"] = "bytes/launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r1_conv_fwd_hbm_traffic.json)"
         if hw == 224 and not args.resnet50:
             assert tot_flop // args.steps == B * CONV_FWD_FLOP_PER_IMAGE_224, (tot_flop // args.steps, B)

@@ -226,6 +226,17 @@ def _tuned_tile(geo, mode, run, candidates):
     return tile
 
 
+def _igemm_launches(M, Cout, tile, device):
+    """Kernel launches behind one loans_igemm call: LOANS_TILE_SPLIT is two when both row ranges are non-empty
+    (same arithmetic as igemm_impl)."""
+    if tile != 6:
+        return 1
+    slots = 2 * torch.cuda.get_device_properties(device).multi_processor_count
+    tiles_n = (Cout + 127) // 128
+    rows_big = ((M // 128) * tiles_n // slots) * slots // tiles_n * 128
+    return 2 if 0 < rows_big < M else 1
+
+
 def conv_fprop(x, w, geo, out=None, bias=None, stats=None, relu_in=False, addend=None, tile=0):
     """out[B,Ho,Wo,Cout] = conv(x[B,H,W,Cin], w[Cout,k,k,Cin]) (+bias) (+addend); optional BN statistics."""
     lib = _lib.load()
@@ -254,7 +265,8 @@ def conv_fprop(x, w, geo, out=None, bias=None, stats=None, relu_in=False, addend
         ev1.record()
         # algorithmic FLOPs: logical input channels (3 for the RGB stem), no padding, no im2col redundancy
         log.append(('fprop_bn' if stats is not None else 'fprop',
-                    2 * geo.B * geo.Ho * geo.Wo * geo.Cout * geo.k * geo.k * geo.cin_logical, ev0, ev1))
+                    2 * geo.B * geo.Ho * geo.Wo * geo.Cout * geo.k * geo.k * geo.cin_logical, ev0, ev1,
+                    _igemm_launches(geo.B * geo.Ho * geo.Wo, geo.Cout, tile, x.device)))
     return out
 
 

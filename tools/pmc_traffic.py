@@ -17,20 +17,23 @@ def conv_fwd_sum(path, counter):
     rows.sort(key=lambda r: int(r['Dispatch_Id']))
     prep = [i for i, r in enumerate(rows) if 'prep_' in r['Kernel_Name']]
     seg = rows[prep[-2]:prep[-1]]
-    fwd = [r for r in seg if 'igemm_kernel' in r['Kernel_Name']][:21]
-    assert len(fwd) == 21
-    return sum(float(r['Counter_Value']) for r in fwd) * 1024.0
+    gap = next(i for i, r in enumerate(seg) if 'gap_fwd_kernel' in r['Kernel_Name'])      # end of the backbone forward
+    fwd = [r for r in seg[:gap] if 'igemm_kernel' in r['Kernel_Name']]      # 21 convs; a LOANS_TILE_SPLIT conv is two launches
+    assert len(fwd) >= 21
+    return sum(float(r['Counter_Value']) for r in fwd) * 1024.0, len(fwd)
 
 
-fetch = 2.0 * conv_fwd_sum(sys.argv[1], 'FETCH_SIZE')
-write = conv_fwd_sum(sys.argv[2], 'WRITE_SIZE')
+fetch, n = conv_fwd_sum(sys.argv[1], 'FETCH_SIZE')
+fetch *= 2.0
+write, n2 = conv_fwd_sum(sys.argv[2], 'WRITE_SIZE')
+assert n == n2
 out = {
-    "what": "HBM bytes of the 21 ResNet-18 conv-forward igemm launches of one bench.py step (B=256, 224^2, fp32)",
+    "what": "HBM bytes of the ResNet-18 conv-forward igemm launches (21 convs) of one bench.py step (B=256, 224^2, fp32)",
     "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes of `python3 bench.py --steps 2 "
               "--warmup 2 --no-cpu-baseline`; KB -> bytes x1024; FETCH_SIZE doubled (gfx950 reports half the bytes of "
               "wide coalesced reads, MI355X_MICROARCH.md HBM section); tools/pmc_traffic.py",
     "fetch_bytes_corrected": fetch, "write_bytes": write, "total_bytes_per_step": fetch + write,
-    "bytes_per_launch": (fetch + write) / 21, "launches": 21,
+    "bytes_per_launch": (fetch + write) / n, "launches": n, "convs": 21,
 }
 json.dump(out, open(sys.argv[3], 'w'), indent=1)
 print(json.dumps(out))

@@ -24,11 +24,12 @@ span = (int(seg[-1]['End_Timestamp']) - int(seg[0]['Start_Timestamp'])) / 1e3
 print('one step (prep_kernel to prep_kernel): span %.1f us, sum of kernel durations %.1f us (two streams overlap)' % (span, sum(tot.values())))
 for k, v in tot.most_common(30):
     print('%10.1f us %5d launches  avg %9.1f us  %s' % (v, cnt[k], v / cnt[k], k))
-fwd = [r for r in seg if 'igemm_kernel' in r['Kernel_Name']][:21]
+gap = next(i for i, r in enumerate(seg) if 'gap_fwd_kernel' in r['Kernel_Name'])      # end of the backbone forward
+fwd = [r for r in seg[:gap] if 'igemm_kernel' in r['Kernel_Name']]     # 21 convs; a LOANS_TILE_SPLIT conv is two launches
 t = sum(dur(r) for r in fwd)
 B = 256
 flop = B * 4166615040
-print('\nResNet-18 conv forward: 21 igemm launches, %.1f us total, avg %.1f us per launch' % (t, t / 21))
+print('\nResNet-18 conv forward: 21 convs = %d igemm launches, %.1f us total, avg %.1f us per launch' % (len(fwd), t, t / len(fwd)))
 print('algorithmic FLOP per step %d -> %.2f TFLOP/s = %.1f %% of the 157.3 TFLOP/s fp32 MFMA peak' % (flop, flop / t / 1e6, flop / t / 1e6 / 157.3 * 100))
 for r in fwd:
     print('   %-40s grid %9s  %8.1f us' % (short(r['Kernel_Name']), r['Grid_Size_X'], dur(r)))
