@@ -45,6 +45,7 @@ def parse():
     ap.add_argument('--resnet50', action='store_true', help='Resnet50SheepLocalizer backbone (BASELINE configs[4] architecture, fp32)')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
                     help="arithmetic of the conv contractions: exact fp32 MFMA (parity path) or bf16 MFMA with fp32 accumulate")
+    ap.add_argument('--graph', action='store_true', help='capture the step into a hipGraph after warm-up (small, launch-bound batches)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=8)
     ap.add_argument('--cpu-iters', type=int, default=2)
@@ -121,7 +122,7 @@ def main():
         iterator={'main': training.DeviceBatchIterator([frames_d]),
                   'real': training.DeviceBatchIterator([(real_d, labels_d)])},
         optimizer={'opt_gen': opt_gen, 'opt_dis': opt_dis},
-        converter=training.identity_converter, device=local_rank, comm=comm)
+        converter=training.identity_converter, device=local_rank, comm=comm, use_graph=args.graph)
 
     for _ in range(args.warmup):
         updater.update()
@@ -185,7 +186,7 @@ def main():
         "config": {"workload": "LoANs joint step: %s localizer + STN crop + assessor, fwd+bwd+2xAdam-AMSGrad" % backbone,
                    "per_gpu_batch": B, "global_batch": B * world, "frame": "3x%dx%d" % (hw, hw),
                    "crop": "3x%dx%d" % (crop, crop), "parallelism": "dp%d" % world,
-                   "baseline_config": cfg_label},
+                   "baseline_config": cfg_label, "hip_graph": bool(args.graph)},
         "roofline": roofline,
     }
     if world == 1 and not args.no_cpu_baseline and not args.resnet50 and args.dtype == 'f32':

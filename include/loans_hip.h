@@ -220,6 +220,11 @@ int loans_grid_loss_bwd_f32(const float* grid, const float* gloss, float* ggrid,
 int loans_adam_amsgrad_f32(float* p, const float* g, float* m, float* v, float* vhat, int64_t n,
                            double lr_t, double beta1, double beta2, double eps, double eta, double weight_decay_rate,
                            double grad_scale, void* stream);
+/* same update with lr_t read from device memory at execution time (one float): the launch is then independent of the
+ * step count and can be captured once in a hipGraph; the caller refreshes *lr_t_dev before each replay */
+int loans_adam_amsgrad_devlr_f32(float* p, const float* g, float* m, float* v, float* vhat, int64_t n,
+                                 const float* lr_t_dev, double beta1, double beta2, double eps, double eta,
+                                 double weight_decay_rate, double grad_scale, void* stream);
 
 /* library / build identification */
 const char* loans_hip_version(void);

@@ -394,7 +394,8 @@ __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, flo
 }
 
 __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, float* vh, int64_t n,
-                                                   AdamHyper h) {
+                                                   AdamHyper h, const float* lr_dev) {
+    if (lr_dev) h.lr_t = *lr_dev;       // step-dependent rate read from device memory: the launch can live in a hipGraph
     const int64_t n4 = n >> 2;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         f32x4 pp = ld4(p + i * 4), gg = ld4(g + i * 4), mm = ld4(m + i * 4), vv = ld4(v + i * 4), hh = ld4(vh + i * 4);
@@ -573,7 +574,21 @@ extern "C" int loans_adam_amsgrad_f32(float* p, const float* g, float* m, float*
     AdamHyper h;
     h.lr_t = (float)lr_t; h.omb1 = (float)(1.0 - beta1); h.omb2 = (float)(1.0 - beta2);
     h.eps = (float)eps; h.eta = (float)eta; h.wd = (float)weight_decay_rate; h.gscale = (float)grad_scale;
-    hipLaunchKernelGGL(adam_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, as_stream(stream), p, g, m, v, vhat, n, h);
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, as_stream(stream), p, g, m, v, vhat, n, h,
+                       (const float*)nullptr);
+    LOANS_LAUNCH_CHECK();
+    return LOANS_OK;
+}
+
+extern "C" int loans_adam_amsgrad_devlr_f32(float* p, const float* g, float* m, float* v, float* vhat, int64_t n,
+                                            const float* lr_t_dev, double beta1, double beta2, double eps, double eta,
+                                            double weight_decay_rate, double grad_scale, void* stream) {
+    if (!p || !g || !m || !v || !vhat || !lr_t_dev || n <= 0) return LOANS_EINVAL;
+    AdamHyper h;
+    h.lr_t = 0.f; h.omb1 = (float)(1.0 - beta1); h.omb2 = (float)(1.0 - beta2);
+    h.eps = (float)eps; h.eta = (float)eta; h.wd = (float)weight_decay_rate; h.gscale = (float)grad_scale;
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, as_stream(stream), p, g, m, v, vhat, n, h,
+                       lr_t_dev);
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;
 }

@@ -636,6 +636,13 @@ def grid_loss_bwd(grid, gloss, kind, img_h=0.0, img_w=0.0, oob_scale=1.0):
 
 
 def adam_amsgrad(p, g, m, v, vhat, lr_t, beta1, beta2, eps, eta, weight_decay_rate, grad_scale=1.0):
+    """lr_t: a Python float, or a 1-element device tensor read by the kernel when it runs (graph-capturable)."""
+    if torch.is_tensor(lr_t):
+        assert lr_t.dtype == torch.float32 and lr_t.numel() == 1 and lr_t.is_cuda
+        check(_lib.load().loans_adam_amsgrad_devlr_f32(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(vhat), p.numel(), _ptr(lr_t),
+                                                       beta1, beta2, eps, eta, weight_decay_rate, grad_scale, _stream()),
+              'loans_adam_amsgrad_devlr_f32')
+        return
     check(_lib.load().loans_adam_amsgrad_f32(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(vhat), p.numel(), lr_t, beta1,
                                              beta2, eps, eta, weight_decay_rate, grad_scale, _stream()),
           'loans_adam_amsgrad_f32')

@@ -66,9 +66,31 @@ class Adam:
         if self.comm is not None and getattr(self.comm, 'active', self.comm.size > 1):
             self.comm.allreduce_grad(arena)
             grad_scale = 1.0 / self.comm.size
-        self.t += 1
         hp = self.hyperparam
         m, v, vhat = self._state
         n = arena.active_numel       # parameters outside the active prefix have no gradient: Chainer skips them too
-        ops.adam_amsgrad(arena.data[:n], arena.grad[:n], m[:n], v[:n], vhat[:n], self.lr, hp.beta1, hp.beta2,
+        if torch.cuda.is_current_stream_capturing():
+            # being recorded into a hipGraph (SheepAssessor(use_graph=True)): nothing executes now, and the replays
+            # must not bake in this step's rate -- the kernel reads it from device memory, `begin_replay()` advances it
+            if getattr(self, '_lr_dev', None) is None:
+                raise RuntimeError('call prepare_capture() before recording Adam.update() into a graph')
+            lr = self._lr_dev
+            self._captured = True
+        else:
+            self.t += 1
+            lr = self.lr
+        ops.adam_amsgrad(arena.data[:n], arena.grad[:n], m[:n], v[:n], vhat[:n], lr, hp.beta1, hp.beta2,
                          hp.eps, hp.eta, hp.weight_decay_rate, grad_scale)
+
+    def prepare_capture(self):
+        """Allocate what a captured update reads at replay time -- outside the capture, so that neither the buffer nor
+        its initialisation belongs to the graph."""
+        arena = self._ensure_state()
+        if getattr(self, '_lr_dev', None) is None:
+            self._lr_dev = torch.zeros(1, device=arena.device, dtype=torch.float32)
+
+    def begin_replay(self):
+        """Before replaying a captured step: count it and publish its bias-corrected rate to the kernel."""
+        if getattr(self, '_captured', False):
+            self.t += 1
+            self._lr_dev.fill_(self.lr)

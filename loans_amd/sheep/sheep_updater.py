@@ -6,10 +6,11 @@ statement order, optimiser names (``opt_gen`` / ``opt_dis``), iterator names
 ``SheepUpdater`` is an alias (the name BASELINE.json uses)."""
 import torch
 
+from .. import ops
 from ..common.utils import DirectionLossCalculator, OutOfImageLossCalculator, Size
 from ..functions import mean_squared_error
 from ..runtime import training
-from ..runtime.core import report
+from ..runtime.core import Variable, report, reporter
 
 
 class SheepAssessor(training.StandardUpdater):
@@ -22,6 +23,12 @@ class SheepAssessor(training.StandardUpdater):
         self.pca = None
         self.freeze_discriminator = kwargs.pop('resume_discriminator', None) is not None
         self.localizer_target = kwargs.pop('localizer_target', 1.0)
+        # use_graph (not in the reference): after `graph_warmup` eager iterations the whole step -- ~600 kernel launches --
+        # is captured once into a hipGraph and replayed; at the reference's default batch of 16 the eager step is bound
+        # by host launch overhead, not by the GPU
+        self.use_graph = kwargs.pop('use_graph', False)
+        self.graph_warmup = kwargs.pop('graph_warmup', 2)
+        self._graph = None
 
         super().__init__(*args, **kwargs)
 
@@ -32,49 +39,83 @@ class SheepAssessor(training.StandardUpdater):
         self.regularizers[1].batch_sum_scale = float(self.comm.size) if self.comm is not None else 1.0
 
     def update_core(self):
+        with torch.cuda.device(self.device):
+            batch = next(self.get_iterator('real'))
+            real_images, labels = self.converter(batch, self.device)[:2]
+            batch = next(self.get_iterator('main'))
+            fake_images = self.converter(batch, self.device)
+            if self.use_graph and not (self.comm is not None and getattr(self.comm, 'active', False)):
+                self._graph_step(real_images, labels, fake_images)
+            else:
+                self._step(real_images, labels, fake_images)
+
+    def _graph_step(self, real_images, labels, fake_images):
+        """Eager for the first iterations (tile autotuning, lazy links, first-launch attributes), then capture the step on
+        static input buffers and replay it.  A change of input shapes falls back to eager execution."""
+        ins = [t.data if isinstance(t, Variable) else t for t in (real_images, labels, fake_images)]
+        g = self._graph
+        if g is None:
+            if self.iteration < self.graph_warmup:
+                return self._step(real_images, labels, fake_images)
+            dev = torch.device('cuda', self.device) if isinstance(self.device, int) else self.device
+            static = [t.to(dev, torch.float32).contiguous().clone() for t in ins]
+            for opt in self.get_all_optimizers().values():
+                opt.prepare_capture()
+            ops.join_side_stream()
+            torch.cuda.synchronize()
+            graph = torch.cuda.CUDAGraph()
+            before = dict(reporter.observation)
+            with torch.cuda.graph(graph):
+                self._step(*static)
+            obs = {k: v for k, v in reporter.observation.items() if before.get(k) is not v}
+            g = self._graph = {'graph': graph, 'static': static, 'obs': obs, 'shapes': [tuple(t.shape) for t in static]}
+        if [tuple(t.shape) for t in ins] != g['shapes']:
+            return self._step(real_images, labels, fake_images)
+        for s, t in zip(g['static'], ins):
+            s.copy_(t, non_blocking=True)
+        for opt in self.get_all_optimizers().values():
+            opt.begin_replay()
+        g['graph'].replay()
+        report(g['obs'])
+
+    def _step(self, real_images, labels, fake_images):
         localizer_optimizer = self.get_optimizer('opt_gen')
         discriminator_optimizer = self.get_optimizer('opt_dis')
         xp = self.localizer.xp
 
-        with torch.cuda.device(self.device):
-            batch = next(self.get_iterator('real'))
-            real_images, labels = self.converter(batch, self.device)[:2]
+        y_real = self.discriminator(real_images)
 
-            y_real = self.discriminator(real_images)
+        x_fake, bboxes = self.localizer(fake_images)
+        y_fake = self.discriminator(x_fake)
 
-            batch = next(self.get_iterator('main'))
-            fake_images = self.converter(batch, self.device)
-            x_fake, bboxes = self.localizer(fake_images)
-            y_fake = self.discriminator(x_fake)
+        localization_labels = xp.full((len(y_fake), 1), self.localizer_target, dtype=xp.float32,
+                                      device=y_fake.data.device)
+        loss_localizer = mean_squared_error(y_fake, localization_labels)
 
-            localization_labels = xp.full((len(y_fake), 1), self.localizer_target, dtype=xp.float32,
-                                          device=y_fake.data.device)
-            loss_localizer = mean_squared_error(y_fake, localization_labels)
+        for regularizer in self.regularizers:
+            loss_localizer += regularizer.calc_loss(bboxes, Size._make(fake_images.shape[-2:]))
 
-            for regularizer in self.regularizers:
-                loss_localizer += regularizer.calc_loss(bboxes, Size._make(fake_images.shape[-2:]))
+        self.discriminator.disable_update()
 
-            self.discriminator.disable_update()
+        self.localizer.cleargrads()
+        loss_localizer.backward()
+        localizer_optimizer.update()
+        report({'loss_localizer': loss_localizer})
 
+        self.discriminator.enable_update()
+
+        x_fake.unchain_backward()
+        bboxes.unchain_backward()
+
+        loss_dis = mean_squared_error(y_real, labels)
+
+        if not self.freeze_discriminator:
+            self.discriminator.cleargrads()
             self.localizer.cleargrads()
-            loss_localizer.backward()
-            localizer_optimizer.update()
-            report({'loss_localizer': loss_localizer})
+            loss_dis.backward()
+            discriminator_optimizer.update()
 
-            self.discriminator.enable_update()
-
-            x_fake.unchain_backward()
-            bboxes.unchain_backward()
-
-            loss_dis = mean_squared_error(y_real, labels)
-
-            if not self.freeze_discriminator:
-                self.discriminator.cleargrads()
-                self.localizer.cleargrads()
-                loss_dis.backward()
-                discriminator_optimizer.update()
-
-            report({'loss_dis': loss_dis})
+        report({'loss_dis': loss_dis})
 
 
 SheepUpdater = SheepAssessor

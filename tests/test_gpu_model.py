@@ -395,3 +395,38 @@ def test_bf16_compute_step_against_oracle():
         assert np.isfinite(float(obs['loss_localizer'])) and np.isfinite(float(obs['loss_dis']))
     finally:
         loans_amd.set_compute_dtype('f32')
+
+
+def test_graph_captured_step_matches_eager():
+    """SheepAssessor(use_graph=True): after two eager iterations the step is one hipGraph replay.  Same losses, same
+    parameters as the eager updater over 6 iterations (Adam's step-dependent rate reaches the captured kernel through
+    device memory); the weight-gradient atomics make both runs differ in the last bits only."""
+    B, H, W, crop = 4, 64, 64, (16, 16)
+    frames, real, labels = inputs(21, 3 * B, H, W, crop)          # three different batches, cycled
+    runs = []
+    for use_graph in (False, True):
+        np.random.seed(5)
+        loc = loans_amd.SheepLocalizer(crop)
+        dis = loans_amd.ResnetAssessor()
+        loc.param_predictor.W.set_logical((2e-3 * np.random.RandomState(3).standard_normal((6, 512))).astype(np.float32))
+        with loans_amd.using_config('enable_backprop', False):
+            dis(dev(real[:B]))
+        upd = _updater(loc, dis, frames[:B], real[:B], labels[:B], lr=1e-4, use_graph=use_graph)
+        sl = [slice(i * B, (i + 1) * B) for i in range(3)]
+        upd.get_iterator('main').batches = [dev(frames[s]) for s in sl]
+        upd.get_iterator('real').batches = [(dev(real[s]), dev(labels[s])) for s in sl]
+        losses = []
+        for it in range(6):
+            upd.update()
+            obs = loans_amd.reporter.observation
+            losses.append((float(obs['loss_localizer']), float(obs['loss_dis'])))
+        assert upd.get_optimizer('opt_gen').t == 6 and upd.get_optimizer('opt_dis').t == 6
+        assert (upd._graph is not None) == use_graph
+        runs.append((losses, loc.state_dict_chainer(), dis.state_dict_chainer()))
+    (l0, p0, d0), (l1, p1, d1) = runs
+    np.testing.assert_allclose(np.array(l1), np.array(l0), rtol=2e-4, atol=1e-6)
+    for k in ('param_predictor/W', 'param_predictor/b', 'feature_extractor/conv1/W', 'feature_extractor/res5/1/conv2/W',
+              'feature_extractor/bn1/avg_mean'):
+        assert rel_err(p1[k], p0[k]) < 2e-3, k
+    for k in ('r0/c0/W', 'l4/W'):
+        assert rel_err(d1[k], d0[k]) < 2e-3, k

@@ -67,6 +67,8 @@ def main():
     parser.add_argument("--rd", dest="resume_discriminator")
     parser.add_argument("--use-resnet-18", action='store_true', default=False)
     parser.add_argument("--localizer-target", type=float, default=1.0)
+    parser.add_argument("--use-graph", action='store_true', default=False,
+                        help="capture the step into a hipGraph after two eager iterations (launch-bound small batches)")
     args = parser.parse_args()
 
     comm = parallel.init_from_env()
@@ -104,7 +106,8 @@ def main():
         iterator={'main': data_iter, 'real': reference_iter},
         optimizer={'opt_gen': localizer_optimizer, 'opt_dis': discriminator_optimizer},
         device=args.gpu, comm=comm, create_pca=False,
-        resume_discriminator=args.resume_discriminator, localizer_target=args.localizer_target)
+        resume_discriminator=args.resume_discriminator, localizer_target=args.localizer_target,
+        use_graph=args.use_graph)
 
     os.makedirs(args.log_dir, exist_ok=True)
     t0 = time.time()
