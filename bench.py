@@ -87,7 +87,7 @@ def main():
     world, rank = comm.size, comm.rank
     if world != args.gpus:
         raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run' % (args.gpus, world))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
 
@@ -171,7 +171,8 @@ def main():
             assert tot_flop // args.steps == B * CONV_FWD_FLOP_PER_IMAGE_224, (tot_flop // args.steps, B)
 
     if world > 1:
-        cfg_label = ("configs[3]" if B == 128 else "configs[1] per GPU, data parallel") if (hw == 224 and not args.resnet50 and args.dtype == 'f32') else "custom"
+        std = hw == 224 and not args.resnet50 and args.dtype == 'f32'
+        cfg_label = "configs[3]" if (std and B == 128) else ("configs[1] per GPU, data parallel" if (std and B == 256) else "custom")
     elif hw == 224 and B == 256 and not args.resnet50 and args.dtype == 'f32':
         cfg_label = "configs[1]"
     elif hw == 512 and B == 128 and not args.resnet50 and args.dtype == 'bf16':

@@ -68,9 +68,11 @@ def init_from_env(backend=None):
         return Communicator()
     local_rank = int(os.environ.get('LOCAL_RANK', os.environ.get('RANK', '0')))
     if backend is None:
-        backend = 'nccl' if torch.cuda.is_available() else 'gloo'
-    if backend == 'nccl':
-        torch.cuda.set_device(local_rank)
+        # LOANS_DIST_BACKEND=gloo lets several ranks share one GPU (gloo moves CUDA tensors through the host): the
+        # whole multi-rank flow can then be exercised on a 1-GPU box; RCCL wants one device per rank
+        backend = os.environ.get('LOANS_DIST_BACKEND') or ('nccl' if torch.cuda.is_available() else 'gloo')
+    if torch.cuda.is_available():
+        torch.cuda.set_device(local_rank % torch.cuda.device_count())
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     if not dist.is_initialized():
         dist.init_process_group(backend=backend)
