@@ -434,7 +434,7 @@ class AdamAMSGrad:
 
 def update_core(loc_params, dis_params, opt_gen, opt_dis, fake_images, real_images, labels,
                 out_size, localizer_target=1.0, freeze_discriminator=False, rng=None,
-                return_grads=False, localizer_cls=None):
+                return_grads=False, localizer_cls=None, oob_scale=1.0):
     """One ``SheepAssessor.update_core`` (sheep_updater.py:26-68).  Mutates the
     parameter dicts / optimiser states in place; returns the reported losses and
     the tensors the parity tests compare."""
@@ -453,6 +453,9 @@ def update_core(loc_params, dis_params, opt_gen, opt_dis, fake_images, real_imag
     H, W = fake_images.shape[-2:]
     l_dir, g_dir = C.direction_loss(bboxes, (H, W))                     # :45-46
     l_out, g_out = C.out_of_image_loss(bboxes)
+    # oob_scale != 1 only in the data-parallel tests: OutOfImageLoss is a SUM over the batch (common/utils.py:315), a
+    # rank of a k-way data-parallel run scales it by k so that the averaged gradients equal the global-batch gradient
+    l_out, g_out = l_out * oob_scale, g_out * oob_scale
     loss_localizer = loss_localizer + l_dir + l_out
 
     loc_grads = {}
