@@ -184,6 +184,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
         const_cast<float*>(a.w), 0, (int)a.w_bytes, 0x00020000);
 
     const int cpt = d.Cin >> 2;   // float4 units per tap
+    const int q8 = 8 / cpt, r8 = 8 - q8 * cpt;
     int u = lu;                   // this thread's K unit in the chunk being loaded
     int tap = lu / cpt, c4 = lu - tap * cpt;
     unsigned woff[RB], wbad[RB];
@@ -211,16 +212,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
         rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)off, 0, 0));
     };
     auto advance = [&]() {      // to the following chunk (8 units further along K); prefetch its tap offset
-        u += 8;
-        if (cpt >= 8) {
-            c4 += 8;
-            const int wrap = c4 >= cpt;
-            c4 -= wrap ? cpt : 0;
-            tap += wrap;
-        } else {
-            tap = u / cpt;
-            c4 = u - tap * cpt;
-        }
+        u += 8;                 // 8 = q8 * cpt + r8: whole taps, then at most one wrap -- no branch, no division
+        tap += q8;
+        c4 += r8;
+        const int wrap = c4 >= cpt;
+        c4 -= wrap ? cpt : 0;
+        tap += wrap;
         toff = (unsigned)taps[min(tap, LOANS_MAX_TAPS - 1)] + (unsigned)c4 * 16u;
     };
     auto load_chunk = [&]() {
