@@ -226,6 +226,21 @@ int loans_adam_amsgrad_devlr_f32(float* p, const float* g, float* m, float* v, f
                                  const float* lr_t_dev, double beta1, double beta2, double eps, double eta,
                                  double weight_decay_rate, double grad_scale, void* stream);
 
+/* ---- input contract on the GPU (common/datasets/image_dataset.py:16-28 `resize_image` -> Pillow
+ *      Image.resize(LANCZOS); :98 `image / 255`).  Bit-exact restatement of Pillow's 8-bit two-pass resampler
+ *      (libImaging/Resample.c): per output coordinate a window bounds[2*i] = first input index, bounds[2*i+1] = taps, and
+ *      ks int32 coefficients in 22-bit fixed point (tables from loans_amd/common/datasets/resample.py); horizontal pass
+ *      into tmp [B][inH][outW][3], vertical pass into dst.  src is [B][inH][inW][3] uint8 RGB.
+ *      _u8: dst [B][outH][outW][3] uint8;  _u8_f32: dst [B][3][outH][outW] float32 = resized / 255 (the hot path's frames). ---- */
+int loans_resize_lanczos_u8(const uint8_t* src, uint8_t* tmp, uint8_t* dst, int32_t B, int32_t inH, int32_t inW,
+                            int32_t outH, int32_t outW, const int32_t* hbounds, const int32_t* hk, int32_t hks,
+                            const int32_t* vbounds, const int32_t* vk, int32_t vks, void* stream);
+int loans_resize_lanczos_u8_f32(const uint8_t* src, uint8_t* tmp, float* dst, int32_t B, int32_t inH, int32_t inW,
+                                int32_t outH, int32_t outW, const int32_t* hbounds, const int32_t* hk, int32_t hks,
+                                const int32_t* vbounds, const int32_t* vk, int32_t vks, void* stream);
+/* [B][H][W][3] uint8 -> [B][3][H][W] float32 / 255 (frames that need no resize) */
+int loans_u8hwc3_to_f32chw(const uint8_t* src, float* dst, int32_t B, int32_t H, int32_t W, void* stream);
+
 /* library / build identification */
 const char* loans_hip_version(void);
 

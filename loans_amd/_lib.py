@@ -40,6 +40,9 @@ SIGNATURES = {
     'loans_wgrad_bf16_f32': [_p, _p, _p, C.POINTER(IgemmDesc), _i32, _p],
     'loans_dgrad_c4_f32': [_p, _p, _p, _p, _p, C.POINTER(IgemmDesc), C.POINTER(_i32), _i32, _p],
     'loans_repack_dgrad_f32': [_p, _p, _i32, _i32, _i32, C.POINTER(_i32), _i32, _p],
+    'loans_resize_lanczos_u8': [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _i32, _p, _p, _i32, _p],
+    'loans_resize_lanczos_u8_f32': [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _i32, _p, _p, _i32, _p],
+    'loans_u8hwc3_to_f32chw': [_p, _p, _i32, _i32, _i32, _p],
     'loans_prep_images_f32': [_p, _p, _i32, _i32, _i32, _p],
     'loans_prep_images_dense_f32': [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p],
     'loans_nchw3_to_nhwc4_f32': [_p, _p, _i32, _i32, _i32, _p],

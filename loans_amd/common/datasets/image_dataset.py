@@ -5,8 +5,8 @@ labelled variant returning ``(image, label, zeros(1))`` with bounding boxes resc
 Same constructor keywords and ``get_example`` behaviour.  ``imgaug`` is not available here: with
 ``use_imgaug=True`` (the reference default) the naive crop / flip augmentation of the reference's own fallback
 branch (:86-90) is used instead and a note is printed once; the hue / contrast jitter of the imgaug branch is
-not reproduced.  Decode and augmentation stay on host threads (a GPU-side decode path is future work,
-SURVEY §8f.2)."""
+not reproduced.  Decode and the crop / flip stay on host threads; ``ImageDataset.device_batch`` moves the LANCZOS resize,
+``/ 255`` and the layout change to the GPU (resample.py, bit-identical to Pillow)."""
 import csv
 import os
 import random
@@ -93,7 +93,8 @@ class ImageDataset:
     def __getitem__(self, i):
         return self.get_example(i)
 
-    def get_example(self, i):
+    def _decoded(self, i):
+        """Decode + the naive crop / flip augmentation (reference :76-90): CHW in the dataset's dtype, values 0..255."""
         image = _read_image_as_array(os.path.join(self._root, self._paths[i]), self._dtype)
         if image.shape[0] == 1:
             image = numpy.tile(image, (3, 1, 1))
@@ -103,11 +104,28 @@ class ImageDataset:
                 crop_ratio = random.uniform(self.min_crop_ratio, self.max_crop_ratio)
                 image = random_crop(image, tuple([int(size * crop_ratio) for size in image.shape[-2:]]))
             image = random_flip(image, x_random=True)
+        return image
+
+    def get_example(self, i):
+        image = self._decoded(i)
         if self.image_size is not None:
             image = resize_image(image, self.image_size, image_mode=self.image_mode)
         if len(image.shape) == 2:
             image = image[None, ...]
         return numpy.ascontiguousarray(image / 255, dtype=numpy.float32)
+
+    def get_raw_example(self, i):
+        """The frame as it stands before ``resize_image``: uint8 HWC RGB (what ``Image.fromarray(...astype('uint8'))``
+        sees at reference :20).  ``device_batch`` finishes the example on the GPU."""
+        return numpy.ascontiguousarray(self._decoded(i).transpose(1, 2, 0).astype(numpy.uint8))
+
+    def device_batch(self, indices, device):
+        """``concat_examples([self.get_example(i) for i in indices])`` with the LANCZOS resize, ``/ 255`` and the CHW
+        layout done on the GPU (bit-identical, see resample.py): uint8 frames cross PCIe, not float32 ones."""
+        from .resample import frames_to_device
+        if self.image_mode != 'RGB' or self.image_size is None:
+            raise ValueError('device_batch covers the training configuration: RGB frames resized to image_size')
+        return frames_to_device([self.get_raw_example(i) for i in indices], self.image_size, device)
 
 
 class LabeledImageDataset:

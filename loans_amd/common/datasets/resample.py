@@ -1,0 +1,134 @@
+"""The LANCZOS resize of the input contract on the GPU (reference common/datasets/image_dataset.py:16-28: ``resize_image``
+= ``PIL.Image.resize((w, h), Image.LANCZOS)``; :98 ``image / 255``).
+
+Pillow's 8-bit resampler is integer arithmetic on per-coordinate coefficient windows (libImaging/Resample.c:
+``precompute_coeffs`` in double precision, ``normalize_coeffs_8bpc`` to 22-bit fixed point, a horizontal then a vertical
+pass that each round to uint8).  ``lanczos_coeffs`` restates the coefficient computation operation by operation with
+``math.sin`` (the same libm call), the two passes are HIP kernels (csrc/resample.hip), and the result is bit-identical to
+Pillow (tests/test_resample_cpu.py pins the tables, tests/test_gpu_resample.py the kernels, both against Pillow itself
+and against committed vectors).
+
+Decode stays on the host (there is no GPU JPEG decoder in this ROCm image); what moves to the GPU is everything after
+it: uint8 frames go up as they are (a quarter of the float bytes), resize + ``/ 255`` + CHW layout happen there."""
+import functools
+import math
+
+import numpy as np
+import torch
+
+from ... import _lib
+from ...ops import _ptr, _stream, check
+
+PRECISION_BITS = 32 - 8 - 2
+LANCZOS_SUPPORT = 3.0
+
+
+def _sinc(x):
+    if x == 0.0:
+        return 1.0
+    x = x * math.pi
+    return math.sin(x) / x
+
+
+def _lanczos(x):
+    if -3.0 <= x < 3.0:
+        return _sinc(x) * _sinc(x / 3)
+    return 0.0
+
+
+@functools.lru_cache(maxsize=256)
+def lanczos_coeffs(in_size, out_size):
+    """(bounds int32 [out_size][2] = (first input index, taps), coefficients int32 [out_size][ksize], ksize) of one axis."""
+    in0, in1 = 0.0, float(in_size)
+    scale = filterscale = (in1 - in0) / out_size
+    if filterscale < 1.0:
+        filterscale = 1.0
+    support = LANCZOS_SUPPORT * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), np.int32)
+    kk = np.zeros((out_size, ksize), np.int32)
+    one = float(1 << PRECISION_BITS)
+    for xx in range(out_size):
+        center = in0 + (xx + 0.5) * scale
+        ww = 0.0
+        ss = 1.0 / filterscale
+        xmin = int(center - support + 0.5)
+        if xmin < 0:
+            xmin = 0
+        xmax = int(center + support + 0.5)
+        if xmax > in_size:
+            xmax = in_size
+        xmax -= xmin
+        k = [0.0] * xmax
+        for x in range(xmax):
+            w = _lanczos((x + xmin - center + 0.5) * ss)
+            k[x] = w
+            ww += w
+        for x in range(xmax):
+            v = k[x] / ww if ww != 0.0 else k[x]
+            kk[xx, x] = int(-0.5 + v * one) if v < 0 else int(0.5 + v * one)
+        bounds[xx] = (xmin, xmax)
+    return bounds, kk, ksize
+
+
+_tables = {}
+
+
+def _device_tables(in_size, out_size, device):
+    key = (in_size, out_size, device)
+    t = _tables.get(key)
+    if t is None:
+        b, k, ks = lanczos_coeffs(in_size, out_size)
+        t = _tables[key] = (torch.from_numpy(b).to(device), torch.from_numpy(k).to(device), ks)
+    return t
+
+
+def resize_lanczos(frames_u8, out_hw, as_float=True):
+    """frames_u8: device uint8 tensor [B][H][W][3] (RGB).  Returns [B][3][oh][ow] float32 in [0,1] (= Pillow's LANCZOS
+    resize, then ``/ 255``) or, with ``as_float=False``, the resized uint8 [B][oh][ow][3]."""
+    if not (frames_u8.is_cuda and frames_u8.dtype == torch.uint8 and frames_u8.is_contiguous() and frames_u8.dim() == 4
+            and frames_u8.shape[3] == 3):
+        raise ValueError('frames must be a contiguous device uint8 tensor [B][H][W][3]')
+    B, H, W, _ = frames_u8.shape
+    oh, ow = int(out_hw[0]), int(out_hw[1])
+    dev = frames_u8.device
+    lib = _lib.load()
+    if (H, W) == (oh, ow):                  # Image.resize returns a copy when the size does not change
+        if not as_float:
+            return frames_u8.clone()
+        out = torch.empty((B, 3, oh, ow), device=dev, dtype=torch.float32)
+        check(lib.loans_u8hwc3_to_f32chw(_ptr(frames_u8), _ptr(out), B, H, W, _stream()), 'loans_u8hwc3_to_f32chw')
+        return out
+    hb, hk, hks = _device_tables(W, ow, dev)
+    vb, vk, vks = _device_tables(H, oh, dev)
+    tmp = torch.empty((B, H, ow, 3), device=dev, dtype=torch.uint8)
+    if as_float:
+        out = torch.empty((B, 3, oh, ow), device=dev, dtype=torch.float32)
+        fn, name = lib.loans_resize_lanczos_u8_f32, 'loans_resize_lanczos_u8_f32'
+    else:
+        out = torch.empty((B, oh, ow, 3), device=dev, dtype=torch.uint8)
+        fn, name = lib.loans_resize_lanczos_u8, 'loans_resize_lanczos_u8'
+    check(fn(_ptr(frames_u8), _ptr(tmp), _ptr(out), B, H, W, oh, ow, _ptr(hb), _ptr(hk), hks, _ptr(vb), _ptr(vk), vks,
+             _stream()), name)
+    return out
+
+
+def frames_to_device(images, out_hw, device):
+    """``[ImageDataset.get_example(i) for i in batch]`` for decoded frames: a list of uint8 HWC RGB arrays of any sizes
+    -> one device batch [N][3][oh][ow] float32 in [0,1], in input order.  Frames of equal size are uploaded (pinned,
+    asynchronous) and resized together."""
+    device = torch.device(device)
+    out = torch.empty((len(images), 3, int(out_hw[0]), int(out_hw[1])), device=device, dtype=torch.float32)
+    groups = {}
+    for i, im in enumerate(images):
+        im = np.asarray(im)
+        if im.dtype != np.uint8 or im.ndim != 3 or im.shape[2] != 3:
+            raise ValueError('frames must be uint8 HWC RGB arrays')
+        groups.setdefault(im.shape[:2], []).append(i)
+    for (H, W), idx in groups.items():
+        host = torch.empty((len(idx), H, W, 3), dtype=torch.uint8).pin_memory()
+        for j, i in enumerate(idx):
+            host[j] = torch.from_numpy(np.ascontiguousarray(images[i]))
+        batch = resize_lanczos(host.to(device, non_blocking=True), out_hw)
+        out[torch.as_tensor(idx, device=device)] = batch
+    return out

@@ -1,0 +1,55 @@
+"""-m gpu: the HIP resampler (csrc/resample.hip) against Pillow -- the implementation the reference calls
+(common/datasets/image_dataset.py:22) -- bit for bit: committed golden vectors, the installed Pillow on fresh inputs,
+and the dataset-level contract ``ImageDataset.device_batch == stack(get_example)``."""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'resample_lanczos.npz')
+
+
+def test_kernels_reproduce_the_golden_vectors():
+    from loans_amd.common.datasets.resample import resize_lanczos
+    g = np.load(GOLDEN)
+    n = 0
+    while 'src_%d' % n in g.files:
+        src, dst = g['src_%d' % n], g['dst_%d' % n]
+        x = torch.from_numpy(src[None]).cuda()
+        got = resize_lanczos(x, dst.shape[:2], as_float=False)[0].cpu().numpy()
+        np.testing.assert_array_equal(got, dst)
+        gotf = resize_lanczos(x, dst.shape[:2])[0].cpu().numpy()
+        np.testing.assert_array_equal(gotf, (dst.transpose(2, 0, 1).astype(np.float32) / 255))
+        n += 1
+    assert n >= 7
+
+
+@pytest.mark.parametrize("shape", [(3, 37, 53, 20, 24), (2, 480, 640, 224, 224), (4, 100, 30, 30, 100), (1, 300, 1000, 75, 75),
+                                   (2, 224, 224, 224, 224), (2, 64, 64, 512, 512), (1, 1, 1, 4, 4)])
+def test_kernels_against_installed_pillow(shape):
+    from PIL import Image
+    from loans_amd.common.datasets.resample import resize_lanczos
+    B, H, W, oh, ow = shape
+    a = np.random.RandomState(H + 7 * W).randint(0, 256, (B, H, W, 3)).astype(np.uint8)
+    ref = np.stack([np.asarray(Image.fromarray(a[b]).resize((ow, oh), Image.LANCZOS)) for b in range(B)])
+    x = torch.from_numpy(a).cuda()
+    np.testing.assert_array_equal(resize_lanczos(x, (oh, ow), as_float=False).cpu().numpy(), ref)
+    np.testing.assert_array_equal(resize_lanczos(x, (oh, ow)).cpu().numpy(), ref.transpose(0, 3, 1, 2).astype(np.float32) / 255)
+
+
+def test_device_batch_equals_get_example(tmp_path):
+    """frames of three different sizes on disk -> the same float32 CHW batch from the host path and the GPU path"""
+    from PIL import Image
+    from loans_amd.common.datasets.image_dataset import ImageDataset
+    rng = np.random.RandomState(5)
+    names = []
+    for i, (H, W) in enumerate([(120, 160), (90, 90), (120, 160), (224, 224), (301, 200)]):
+        Image.fromarray(rng.randint(0, 256, (H, W, 3)).astype(np.uint8)).save(str(tmp_path / ('f%d.png' % i)))
+        names.append('f%d.png' % i)
+    ds = ImageDataset(names, root=str(tmp_path), image_size=(224, 224))
+    host = np.stack([ds.get_example(i) for i in range(len(ds))])
+    dev = ds.device_batch(range(len(ds)), 'cuda:0')
+    assert dev.shape == (5, 3, 224, 224) and dev.dtype == torch.float32
+    np.testing.assert_array_equal(dev.cpu().numpy(), host)
