@@ -1,0 +1,134 @@
+"""-m gpu: BASELINE.json's full configuration (256 x 3 x 224 x 224, crop 75 x 75) is far beyond what the CPU oracle
+finishes in seconds, so at that size the HIP path is checked through size-independent properties of the operators
+(linearity, BN normalisation identities, gradient orthogonality, batch-concatenation consistency) and the
+reference-derived known answers, which hold for any batch."""
+import numpy as np
+import pytest
+import torch
+
+import loans_amd
+from loans_amd import ops
+from loans_amd.runtime import training
+from tests.gpu_util import dev
+
+pytestmark = pytest.mark.gpu
+B, HW, CROP = 256, 224, (75, 75)
+
+
+def _rel(a, b):
+    return float((a - b).abs().max() / (b.abs().max() + 1e-30))
+
+
+def test_conv_linearity_and_batch_consistency_res2_full_size():
+    """res2 geometry at B = 256 (M = 802 816 rows): conv(a x1 + b x2) = a conv(x1) + b conv(x2); a batch is the
+    concatenation of its halves; dgrad is the adjoint of fprop (<conv(x), g> = <x, dgrad(g)>); wgrad is linear in g."""
+    g = torch.Generator(device='cuda').manual_seed(0)
+    geo = ops.ConvGeometry(B, 56, 56, 64, 64, 3, 1, 1)
+    half = ops.ConvGeometry(B // 2, 56, 56, 64, 64, 3, 1, 1)
+    x1 = torch.randn(B, 56, 56, 64, device='cuda', generator=g)
+    x2 = torch.randn(B, 56, 56, 64, device='cuda', generator=g)
+    w = torch.randn(64, 3, 3, 64, device='cuda', generator=g) * 0.05
+    y1, y2 = ops.conv_fprop(x1, w, geo), ops.conv_fprop(x2, w, geo)
+    y = ops.conv_fprop(0.5 * x1 - 2.0 * x2, w, geo)
+    assert _rel(y, 0.5 * y1 - 2.0 * y2) < 2e-6
+    ya = ops.conv_fprop(x1[:B // 2].contiguous(), w, half)
+    assert torch.equal(ya, y1[:B // 2])                       # per-row results do not depend on the batch they sit in
+    gy = torch.randn_like(y1)
+    gx = ops.conv_dgrad(gy, w, geo)
+    lhs, rhs = (y1.double() * gy.double()).sum(), (x1.double() * gx.double()).sum()
+    # both sides are sums of 51 M random-sign terms, each carrying the fp32 rounding of a K = 576 accumulation:
+    # the difference is a random walk of ~ sqrt(K) eps per term
+    assert abs(float(lhs - rhs)) < 4e-6 * float(((y1.double() * gy.double()) ** 2).sum().sqrt())
+    dw1, dw2, dw = torch.zeros_like(w), torch.zeros_like(w), torch.zeros_like(w)
+    ops._conv_wgrad(x1, gy, dw1, geo, False, 0, 0)
+    ops._conv_wgrad(x1, y2, dw2, geo, False, 0, 0)
+    ops._conv_wgrad(x1, gy + 3.0 * y2, dw, geo, False, 0, 0)
+    assert _rel(dw, dw1 + 3.0 * dw2) < 1e-5
+    # <dw, w'> = <conv_{w'}(x), gy>: wgrad is the adjoint of the conv in its weights
+    wp = torch.randn_like(w)
+    yp = ops.conv_fprop(x1, wp, geo).double()
+    assert abs(float((dw1.double() * wp.double()).sum() - (yp * gy.double()).sum())) < 4e-6 * float(((yp * gy.double()) ** 2).sum().sqrt())
+
+
+def test_batchnorm_identities_full_size():
+    """train-mode BN over 802 816 positions: the output has mean beta and variance gamma^2 * var/(var+eps) per channel;
+    the input gradient sums to zero and is orthogonal to the normalised input (the two projections of BN backward)."""
+    C_ = 64
+    g = torch.Generator(device='cuda').manual_seed(1)
+    x = torch.randn(B, 56, 56, C_, device='cuda', generator=g) * 3 + 1.5
+    gamma = 1 + 0.1 * torch.randn(C_, device='cuda', generator=g)
+    beta = 0.1 * torch.randn(C_, device='cuda', generator=g)
+    stats = ops.stats_buffer(C_, 'cuda')
+    xd = x.double()
+    stats[0, 0] = xd.sum(dim=(0, 1, 2)); stats[0, 1] = (xd ** 2).sum(dim=(0, 1, 2))
+    rm, rv = torch.zeros(C_, device='cuda'), torch.ones(C_, device='cuda')
+    st = ops.bn_finalize(stats, B * 56 * 56, gamma, beta, rm, rv)
+    y = ops.bn_apply(x, st, relu=False).double()
+    var = xd.var(dim=(0, 1, 2), unbiased=False)
+    np.testing.assert_allclose(y.mean(dim=(0, 1, 2)).cpu().numpy(), beta.double().cpu().numpy(), atol=2e-5)
+    np.testing.assert_allclose(y.var(dim=(0, 1, 2), unbiased=False).cpu().numpy(),
+                               (gamma.double() ** 2 * var / (var + ops.BN_EPS)).cpu().numpy(), rtol=1e-4)
+    np.testing.assert_allclose(rm.cpu().numpy(), 0.1 * xd.mean(dim=(0, 1, 2)).cpu().numpy(), rtol=1e-4, atol=1e-6)
+    gy = torch.randn(x.shape, device='cuda', generator=g)
+    gg, gb = torch.zeros(C_, device='cuda'), torch.zeros(C_, device='cuda')
+    gx = ops.bn_backward(gy, None, x, st, gamma, gg, gb).double()
+    scale = float(gy.abs().sum(dim=(0, 1, 2)).max())
+    assert float(gx.sum(dim=(0, 1, 2)).abs().max()) < 1e-5 * scale
+    xhat = (xd - xd.mean(dim=(0, 1, 2))) / (var + ops.BN_EPS).sqrt()
+    assert float((gx * xhat).sum(dim=(0, 1, 2)).abs().max()) < 1e-5 * scale
+    np.testing.assert_allclose(gb.cpu().numpy(), gy.double().sum(dim=(0, 1, 2)).cpu().numpy(), rtol=1e-4, atol=1e-2)
+
+
+def test_fresh_localizer_known_answers_full_batch():
+    """SURVEY §8c KAT 1 / 4 at B = 256, 224^2: theta = [[.8,0,0],[0,.8,0]] for any input, boxes [22.4, 22.4, 201.6, 201.6],
+    both regularisers zero, and after one joint step only param_predictor has moved in the localizer."""
+    from loans_amd.datasets import synthetic
+    frames = synthetic.make_frames(3, 32, HW, HW)
+    real, labels = synthetic.make_assessor_batch(4, 32, CROP[0], CROP[1])
+    tile = lambda a: dev(np.tile(a, (B // 32,) + (1,) * (a.ndim - 1)))            # noqa: E731
+    np.random.seed(0)
+    loc, dis = loans_amd.SheepLocalizer(CROP), loans_amd.ResnetAssessor()
+    with loans_amd.using_config('enable_backprop', False):
+        dis(dev(real[:2]))                  # draw the lazily created l4 now: same RNG position in both models below
+    rois, points = loc(tile(frames))
+    th = loc.last_transform_params.data
+    assert torch.equal(th, torch.tensor([[.8, 0, 0], [0, .8, 0]], device='cuda').expand(B, 2, 3))
+    bb = loc.scale_bboxes(loc.extract_corners(points), loans_amd.Size(HW, HW))
+    np.testing.assert_allclose(bb.cpu().numpy(), np.tile([[22.4, 22.4, 201.6, 201.6]], (B, 1)), atol=1e-4)
+    assert tuple(rois.shape) == (B, 3) + CROP
+    # the crop of frame b is the same whatever batch it sits in
+    rois32, _ = loc(dev(frames))
+    assert torch.equal(rois32.data, rois.data[:32])
+
+    before = {k: v.copy() for k, v in loc.state_dict_chainer().items()}
+    og = loans_amd.Adam(alpha=1e-3, amsgrad=True).setup(loc)
+    od = loans_amd.Adam(alpha=1e-3, amsgrad=True).setup(dis)
+    upd = loans_amd.SheepAssessor(
+        models=[loc, dis], iterator={'main': training.DeviceBatchIterator([tile(frames)]),
+                                     'real': training.DeviceBatchIterator([(tile(real), tile(labels))])},
+        optimizer={'opt_gen': og, 'opt_dis': od}, converter=training.identity_converter, device=0)
+    upd.update()
+    obs = loans_amd.reporter.observation
+    assert np.isfinite(float(obs['loss_localizer'])) and np.isfinite(float(obs['loss_dis']))
+    after = loc.state_dict_chainer()
+    for k in before:
+        if 'avg_' in k or k.endswith('/N'):
+            continue
+        moved = not np.array_equal(before[k], after[k])
+        assert moved == k.startswith('param_predictor/'), k
+    # a batch made of 8 copies of 32 frames gives every copy the same crop, score and per-sample gradient: the loss
+    # equals the loss of the 32-frame batch (means are over the batch)
+    np.random.seed(0)
+    loc2, dis2 = loans_amd.SheepLocalizer(CROP), loans_amd.ResnetAssessor()
+    with loans_amd.using_config('enable_backprop', False):
+        dis2(dev(real[:2]))
+    upd2 = loans_amd.SheepAssessor(
+        models=[loc2, dis2], iterator={'main': training.DeviceBatchIterator([dev(frames)]),
+                                       'real': training.DeviceBatchIterator([(dev(real), dev(labels))])},
+        optimizer={'opt_gen': loans_amd.Adam(alpha=1e-3, amsgrad=True).setup(loc2),
+                   'opt_dis': loans_amd.Adam(alpha=1e-3, amsgrad=True).setup(dis2)},
+        converter=training.identity_converter, device=0)
+    l256 = (float(obs['loss_localizer']), float(obs['loss_dis']))
+    upd2.update()
+    obs2 = loans_amd.reporter.observation
+    np.testing.assert_allclose(l256, (float(obs2['loss_localizer']), float(obs2['loss_dis'])), rtol=2e-5)
