@@ -1,5 +1,6 @@
 #!/usr/bin/env python
-"""Generates tests/golden/step_b2_64.npz: expected outputs of ONE joint LoANs step on seeded inputs.
+"""Generates tests/golden/step_b2_64.npz: expected outputs of ONE joint LoANs step on seeded inputs, the losses of the
+first three steps, and one B = 8, 224 x 224 forward vector.
 
 Provenance: the reference (Bartzi/loans) has no tests / golden vectors and its arithmetic (Chainer
 4.1.0 / CuPy) is not installable here, so these vectors come from THIS repo's CPU oracle
@@ -48,8 +49,43 @@ def run(dtype=np.float64):
     return out
 
 
+CROP224 = (75, 75)
+
+
+def setup224(dtype=np.float64):
+    """one B = 8, 3 x 224 x 224 forward vector with a non-zero seeded param_predictor.W."""
+    rng = np.random.RandomState(224)
+    lp = M.cast_params(M.init_localizer_params(rng, predictor_w_std=2e-2), dtype)
+    dp = M.cast_params(M.init_assessor_params(rng, CROP224), dtype)
+    frames = synthetic.make_frames(79, 8, 224, 224).astype(dtype)
+    return lp, dp, frames
+
+
+def run224(dtype=np.float64):
+    lp, dp, frames = setup224(dtype)
+    loc = M.Localizer(lp, CROP224, train=True, rng=np.random.RandomState(0))
+    rois, points = loc.forward(frames)
+    y = M.Assessor(dp).forward(rois)
+    return dict(theta224=loc.theta, corners224=loc.corners_px(points, (224, 224)), y_fake224=y,
+                rois224_mean=rois.mean(axis=(1, 2, 3)), points224_corner=points[:, :, [0, 0, -1, -1], [0, -1, 0, -1]])
+
+
+def run_trajectory(dtype=np.float64, iterations=3):
+    """losses and parameter check-sums of 3 consecutive joint steps of the B = 2 case."""
+    lp, dp, frames, real, labels = setup(dtype)
+    og, od = M.AdamAMSGrad(lp), M.AdamAMSGrad(dp)
+    losses = []
+    for _ in range(iterations):
+        r = M.update_core(lp, dp, og, od, frames, real, labels, CROP, rng=np.random.RandomState(0))
+        losses.append((r['loss_localizer'], r['loss_dis']))
+    return dict(traj_losses=np.array(losses), traj_param_predictor_b=lp['param_predictor/b'],
+                traj_l4_W_sum=np.float64(dp['l4/W'].sum()), traj_bn1_avg_var=lp['feature_extractor/bn1/avg_var'])
+
+
 if __name__ == '__main__':
     out = run()
+    out.update(run224())
+    out.update(run_trajectory())
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'step_b2_64.npz')
     np.savez_compressed(path, **out)
     print('wrote', path, {k: np.asarray(v).shape for k, v in out.items()})

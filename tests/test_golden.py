@@ -13,7 +13,8 @@ GOLD = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'golden', 'step_
 def test_oracle_reproduces_golden():
     gold = np.load(GOLD)
     out = G.run(np.float64)
-    for k in gold.files:
+    out.update(G.run_trajectory(np.float64))
+    for k in out:
         np.testing.assert_allclose(out[k], gold[k], rtol=1e-9, atol=1e-12, err_msg=k)
     out32 = G.run(np.float32)
     for k in ('theta', 'points', 'y_fake', 'y_real', 'bboxes_px'):
@@ -58,3 +59,72 @@ def test_hip_step_matches_golden():
     st = loc.state_dict_chainer()
     np.testing.assert_allclose(st['feature_extractor/bn1/avg_mean'], gold['new_bn1_avg_mean'], rtol=1e-4, atol=1e-5)
     np.testing.assert_allclose(st['param_predictor/b'], gold['new_param_predictor_b'], atol=2e-4, rtol=0)
+
+
+def test_oracle_reproduces_golden_224():
+    """the B = 8, 3 x 224 x 224 forward vector in the oracle's fp32 arm: BASELINE's 1e-4 against the stored
+    fp64 values"""
+    gold = np.load(GOLD)
+    out = G.run224(np.float32)
+    np.testing.assert_allclose(out['theta224'], gold['theta224'], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(out['y_fake224'], gold['y_fake224'], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(out['corners224'], gold['corners224'], rtol=0, atol=1e-4 * 224)
+    np.testing.assert_allclose(out['points224_corner'], gold['points224_corner'], rtol=0, atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_hip_forward_matches_golden_224():
+    """HIP forward at B = 8, 3 x 224 x 224, crop 75 x 75 against the stored vector -- no oracle at run time"""
+    import torch
+    import loans_amd
+    gold = np.load(GOLD)
+    lp, dp, frames = G.setup224(np.float32)
+    np.random.seed(0)
+    loc, dis = loans_amd.SheepLocalizer(G.CROP224), loans_amd.ResnetAssessor()
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()     # noqa: E731
+    with loans_amd.using_config('enable_backprop', False):
+        dis(torch.zeros(2, 3, 75, 75, device='cuda'))                     # materialise l4
+    loc.load_state_dict_chainer(lp)
+    dis.load_state_dict_chainer(dp)
+    rois, points = loc(d(frames))
+    y = dis(rois)
+    np.testing.assert_allclose(loc.last_transform_params.data.cpu().numpy(), gold['theta224'], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(y.data.cpu().numpy(), gold['y_fake224'], rtol=0, atol=1e-4)
+    px = loc.scale_bboxes(loc.extract_corners(points), loans_amd.Size(224, 224)).cpu().numpy()
+    np.testing.assert_allclose(px, gold['corners224'], rtol=0, atol=1e-4 * 224)
+    p = points.data.cpu().numpy()
+    np.testing.assert_allclose(p[:, :, [0, 0, -1, -1], [0, -1, 0, -1]], gold['points224_corner'], rtol=0, atol=1e-4)
+    np.testing.assert_allclose(rois.data.cpu().numpy().mean(axis=(1, 2, 3)), gold['rois224_mean'], rtol=0, atol=1e-4)
+
+
+@pytest.mark.gpu
+def test_hip_trajectory_matches_golden():
+    """three consecutive joint steps of the B = 2 case: losses against the stored fp64 trajectory (Adam's sign-like first
+    steps amplify rounding, so the bound is the one the fp32 oracle itself needs, see test_three_iteration_trajectory)"""
+    import torch
+    import loans_amd
+    from loans_amd.runtime import training
+    gold = np.load(GOLD)
+    lp, dp, frames, real, labels = G.setup(np.float32)
+    np.random.seed(0)
+    loc, dis = loans_amd.SheepLocalizer(G.CROP), loans_amd.ResnetAssessor()
+    d = lambda a: torch.from_numpy(np.ascontiguousarray(a)).cuda()     # noqa: E731
+    with loans_amd.using_config('enable_backprop', False):
+        dis(d(real))
+    loc.load_state_dict_chainer(lp)
+    dis.load_state_dict_chainer(dp)
+    upd = loans_amd.SheepAssessor(
+        models=[loc, dis], iterator={'main': training.DeviceBatchIterator([d(frames)]),
+                                     'real': training.DeviceBatchIterator([(d(real), d(labels))])},
+        optimizer={'opt_gen': loans_amd.Adam(alpha=1e-3, amsgrad=True).setup(loc),
+                   'opt_dis': loans_amd.Adam(alpha=1e-3, amsgrad=True).setup(dis)},
+        converter=training.identity_converter, device=0)
+    got = []
+    for _ in range(3):
+        upd.update()
+        obs = loans_amd.reporter.observation
+        got.append((float(obs['loss_localizer']), float(obs['loss_dis'])))
+    got, ref = np.array(got), gold['traj_losses']
+    np.testing.assert_allclose(got[0], ref[0], rtol=1e-4)
+    np.testing.assert_allclose(got[1:], ref[1:], rtol=5e-2, atol=1e-3)
+    np.testing.assert_allclose(float(dis.state_dict_chainer()['l4/W'].sum()), float(gold['traj_l4_W_sum']), rtol=5e-2, atol=5e-2)
