@@ -104,3 +104,30 @@ def test_product_never_imports_oracle():
                 if re.search(r'^\s*(from|import)\s+oracle\b', src, re.M) or 'from oracle' in src:
                     bad.append(os.path.join(dirpath, f))
     assert not bad, bad
+
+
+def test_every_entry_point_rejects_null_pointers(lib):
+    """each launcher validates before it launches: with every pointer NULL (and otherwise sane scalars) it returns
+    LOANS_EINVAL / LOANS_ERANGE, never a hipError and never a crash -- on a machine without a GPU"""
+    from loans_amd import _lib
+    desc = _lib.IgemmDesc()
+    desc.B = desc.inH = desc.inW = desc.outH = desc.outW = desc.gridH = desc.gridW = 4
+    desc.Cin = desc.Cout = 8
+    desc.osy = desc.osx = desc.isy = desc.isx = 1
+    desc.ntaps = 1
+    tapsel = (ctypes.c_int32 * 1)(0)
+    for name, argtypes in sorted(_lib.SIGNATURES.items()):
+        args = []
+        for t in argtypes:
+            if t is ctypes.c_void_p:
+                args.append(0)
+            elif t is ctypes.POINTER(_lib.IgemmDesc):
+                args.append(ctypes.byref(desc))
+            elif t is ctypes.POINTER(ctypes.c_int32):
+                args.append(tapsel)
+            elif t in (ctypes.c_float, ctypes.c_double):
+                args.append(1.0)
+            else:
+                args.append(4)
+        rc = getattr(lib, name)(*args)
+        assert rc in (-1, -2), (name, rc)
