@@ -507,11 +507,6 @@ def bn_backward(gy, mask, x, st, gamma, ggamma, gbeta, x2=None, st2=None, gamma2
     return (gx, gx2) if dual else gx
 
 
-def bn_backward_fixed(gy, mask, st_eval_scale):
-    """Test-mode (fixed statistics) backward: gx = scale * gy * (mask > 0)."""
-    raise NotImplementedError('backward through test-mode BatchNormalization is not on the training path')
-
-
 def colsum_acc(x, out):
     C_ = x.shape[-1]
     check(_lib.load().loans_colsum_f32(_ptr(x), _ptr(out), x.numel() // C_, C_, _stream()), 'loans_colsum_f32')
