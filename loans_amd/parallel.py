@@ -41,14 +41,19 @@ class Communicator:
             if torch.is_tensor(v):
                 dist.broadcast(v, src=0, group=self.group)
 
-    def allreduce_grad(self, arena):
-        """Sum the gradient arena over all ranks, in place, in large buckets."""
+    def allreduce_grad(self, arena, async_op=False):
+        """Sum the gradient arena over all ranks, in place, in large buckets.  ``async_op``: return the work handles
+        instead of making the current stream wait (the collectives then overlap what is launched next)."""
         if not self.active:
-            return
+            return []
         g = arena.grad[:getattr(arena, 'active_numel', arena.numel)]
         n = g.numel()
+        works = []
         for lo in range(0, n, BUCKET_FLOATS):
-            dist.all_reduce(g[lo:min(lo + BUCKET_FLOATS, n)], op=dist.ReduceOp.SUM, group=self.group)
+            w = dist.all_reduce(g[lo:min(lo + BUCKET_FLOATS, n)], op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+            if async_op:
+                works.append(w)
+        return works
 
     def allreduce_max(self, value):
         t = torch.tensor([value], dtype=torch.float64, device='cuda' if torch.cuda.is_available() else 'cpu')

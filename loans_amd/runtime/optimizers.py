@@ -61,11 +61,17 @@ class Adam:
         if not any(p.update_rule.enabled for p in self.target.params()):
             return
         arena = self._ensure_state()
-        ops.join_side_stream(arena.device)     # all weight gradients of this step have landed
+        pending, self._pending = getattr(self, '_pending', None), None
         grad_scale = 1.0
-        if self.comm is not None and getattr(self.comm, 'active', self.comm.size > 1):
-            self.comm.allreduce_grad(arena)
+        if pending is not None:                 # update_begin() already started the exchange of this step
+            for work in pending:
+                work.wait()                     # the current stream waits for RCCL's
             grad_scale = 1.0 / self.comm.size
+        else:
+            ops.join_side_stream(arena.device)  # all weight gradients of this step have landed
+            if self.comm is not None and getattr(self.comm, 'active', self.comm.size > 1):
+                self.comm.allreduce_grad(arena)
+                grad_scale = 1.0 / self.comm.size
         hp = self.hyperparam
         m, v, vhat = self._state
         n = arena.active_numel       # parameters outside the active prefix have no gradient: Chainer skips them too
@@ -81,6 +87,18 @@ class Adam:
             lr = self.lr
         ops.adam_amsgrad(arena.data[:n], arena.grad[:n], m[:n], v[:n], vhat[:n], lr, hp.beta1, hp.beta2,
                          hp.eps, hp.eta, hp.weight_decay_rate, grad_scale)
+
+    def update_begin(self):
+        """Data parallel only: start the gradient all-reduce now and return, so that it runs beside whatever the
+        caller issues next; the following ``update()`` waits for it and applies the step.  The gradients must not be
+        touched (no ``cleargrads``) in between.  Without an active communicator this is a no-op."""
+        if self.comm is None or not getattr(self.comm, 'active', self.comm.size > 1):
+            return
+        if not any(p.update_rule.enabled for p in self.target.params()):
+            return
+        arena = self._ensure_state()
+        ops.join_side_stream(arena.device)
+        self._pending = self.comm.allreduce_grad(arena, async_op=True)
 
     def prepare_capture(self):
         """Allocate what a captured update reads at replay time -- outside the capture, so that neither the buffer nor

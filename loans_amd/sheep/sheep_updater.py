@@ -99,7 +99,14 @@ class SheepAssessor(training.StandardUpdater):
 
         self.localizer.cleargrads()
         loss_localizer.backward()
-        localizer_optimizer.update()
+        # Data parallel: the localizer's gradient all-reduce (50 MB) is started here and overlaps the assessor's backward
+        # below, which touches neither those gradients nor the localizer's parameters; the Adam step then lands where
+        # the reference has it in effect (both updates are independent) -- `overlap` is False on a single GPU
+        overlap = self.comm is not None and getattr(self.comm, 'active', False) and not self.freeze_discriminator
+        if overlap:
+            localizer_optimizer.update_begin()
+        else:
+            localizer_optimizer.update()
         report({'loss_localizer': loss_localizer})
 
         self.discriminator.enable_update()
@@ -111,8 +118,12 @@ class SheepAssessor(training.StandardUpdater):
 
         if not self.freeze_discriminator:
             self.discriminator.cleargrads()
-            self.localizer.cleargrads()
+            if not overlap:
+                self.localizer.cleargrads()
             loss_dis.backward()
+            if overlap:
+                localizer_optimizer.update()        # waits for the exchange started above
+                self.localizer.cleargrads()
             discriminator_optimizer.update()
 
         report({'loss_dis': loss_dis})
