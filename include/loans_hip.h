@@ -78,6 +78,8 @@ typedef struct loans_igemm_desc {
 #define LOANS_TILE_256x64  4
 #define LOANS_TILE_64x128  5   /* wgrad only: 64 output channels x 128 tap-channel columns */
 #define LOANS_TILE_SPLIT   6   /* igemm only: 128x128 tiles over the rows that fill whole machine rounds, 64x64 over the rest (two launches) */
+#define LOANS_TILE_DMA    16   /* igemm, fp32 arm, OR-ed onto a tile shape: operand tiles staged by LDS-DMA (buffer_load ... lds)
+                                  into XOR-swizzled unpadded LDS rows instead of through registers; same results bit for bit */
 
 /* ---- convolution (replaces cuDNN ConvolutionForward / BackwardData / BackwardFilter behind
  *      L.Convolution2D: sheep/resnet.py:43,128-133,151-153 ; common/net.py:15-17,37-39,59-60) ---- */

@@ -33,6 +33,12 @@ __device__ unsigned long long g_stamps[64 * 4 * 8];
 #define STAMP(t) do { } while (0)
 #endif
 
+#ifdef LOANS_EXPERIMENT
+#define DBGSKIP(bit) (a.dbg & (bit))
+#else
+#define DBGSKIP(bit) false
+#endif
+
 namespace {
 
 constexpr int BK = 32;
@@ -54,6 +60,8 @@ struct IgemmArgs {
     int m_begin;        // first GEMM row of this launch (LOANS_TILE_SPLIT runs a row range per tile shape); rows end at M
     int tail_groups;    // 8-deep k groups of the last chunk that hold any real K (1..4)
     int bf16;           // 1: round the operands to bf16 and use the bf16 MFMA (fp32 accumulate)
+    int dma;            // 1: LDS-DMA staging of the operand tiles (LOANS_TILE_DMA; fp32 arm)
+    int dbg;            // experiment bits (LOANS_EXPERIMENT builds only; 0 in the product library)
     unsigned in_bytes, w_bytes, out_bytes;
     struct {            // nx > 0: taps are an ny x nx grid, dy = dy0 + row*sdy, dx = dx0 + col*sdx, sd* = +-1
         int nx, ny, dy0, sdy, dx0, sdx;
@@ -82,15 +90,29 @@ constexpr int LDKH = BK + 8;      // bf16 LDS row (halves): 80 bytes, ds_read_b1
 
 // BF16 = true: the fp32 operands are rounded to bf16 (RNE) while they are staged into LDS and contracted on
 // v_mfma_f32_32x32x16_bf16 (fp32 accumulate, 16x the fp32 MFMA rate); prologue, epilogue and the C ABI are shared.
-template <int BM, int BN, int WM, int WN, bool RELU, bool BF16>
+// DMA = true (fp32 arm): the operand tiles are staged by LDS-DMA (`buffer_load_dwordx4 ... lds`): no staging
+// registers, no ds_write pass.  A wave-instruction writes 64 x 16 B contiguously, so LDS rows are unpadded
+// [row][32 floats] and bank conflicts are avoided by an XOR swizzle instead: the 16-byte unit u of row r lives in
+// slot u ^ ((r >> 1) & 7) -- applied to the per-lane SOURCE address by the loader and to the fragment reads
+// (every 16-lane group of a ds_read_b128 then covers all 64 banks once).
+template <int BM, int BN, bool DMA>
+constexpr size_t igemm_aux_floats() {       // offset (floats) of the tap table / row table behind the tiles
+    constexpr size_t stage = (size_t)2 * (BM + BN) * (DMA ? BK : LDK);
+    constexpr size_t cs = (size_t)BM * (BN + 4);             // epilogue staging tile
+    return stage > cs ? stage : cs;
+}
+
+template <int BM, int BN, int WM, int WN, bool RELU, bool BF16, bool DMA>
 __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
+    static_assert(!(DMA && BF16), "the bf16 arm converts while it stages through registers");
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int RA = BM / 32, RB = BN / 32;
     constexpr int NMMA = TM * TN * 4;          // MFMAs per 8-deep k group
+    constexpr int LDR = DMA ? BK : LDK;        // LDS row stride (floats)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    float* As = reinterpret_cast<float*>(smem);        // [2][BM][LDK]
-    float* Bs = As + 2 * BM * LDK;                     // [2][BN][LDK]
-    int* taps = reinterpret_cast<int*>(Bs + 2 * BN * LDK);
+    float* As = reinterpret_cast<float*>(smem);        // [2][BM][LDR]
+    float* Bs = As + 2 * BM * LDR;                     // [2][BN][LDR]
+    int* taps = reinterpret_cast<int*>(As + igemm_aux_floats<BM, BN, DMA>());
     unsigned* opix = reinterpret_cast<unsigned*>(taps + LOANS_MAX_TAPS);   // [BM] output row byte offset, ~0u = no row
 
     const loans_igemm_desc& d = a.d;
@@ -99,10 +121,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     unsigned long long t_start = 0;
     STAMP(t_start);
 #endif
+#ifdef LOANS_EXPERIMENT
+    if (a.dbg & 1) __builtin_amdgcn_s_setprio(3);
+#endif
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
     const int tn = logical % a.tiles_n;
     const int tm = logical / a.tiles_n;
-    const int lu = tid & 7, lrow = tid >> 3;
+    const int lrow = tid >> 3;
+    const int lu = DMA ? ((tid & 7) ^ ((tid >> 4) & 7)) : (tid & 7);   // K unit this thread stages (DMA: slot ^ row key)
     // tap table in LDS: byte offset of tap t relative to the row's base pixel
     // LOANS_F_DENSE: inW / isx / dx count floats (packed 3-channel rows), a "tap" is a run of Cin consecutive
     // floats of one input row, and the caller's zero padding makes every tap of every pixel readable
@@ -163,6 +189,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
                 }
             }
             badmask[i] = ~mask;
+#ifdef LOANS_EXPERIMENT
+            if (a.dbg & 4) { rowoff[i] = (unsigned)((d.inW + 1) * ubytes) + (rowoff[i] & 0xFFFu); badmask[i] = 0; }   // cache-hot gathers
+#endif
             if (lu == 0) opix[lrow + 32 * i] = pixoff;
             // advance 32 pixels: exact floor((v + .5) / n) for the small integers involved
             x += 32;
@@ -211,6 +240,20 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
         const unsigned off = (woff[i] + (unsigned)u * 16u) | wbad[i] | kbad;
         rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)off, 0, 0));
     };
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    auto dma_a = [&](int buf, int i) {      // one 1 KiB LDS-DMA piece: 8 rows x 128 B of the A tile
+        const int tc = min(tap, LOANS_MAX_TAPS - 1);
+        const unsigned kbad = (unsigned)(u * 4 < a.Ktot) - 1u;
+        const unsigned bad = 0u - ((unsigned)(badmask[i] >> tc) & 1u);
+        const unsigned off = (rowoff[i] + toff) | bad | kbad;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(As + (buf * BM + 32 * i + 8 * wave_u) * BK), 16, (int)off, 0, 0, 0);
+    };
+    auto dma_b = [&](int buf, int i) {
+        const unsigned kbad = (unsigned)(u * 4 < a.Ktot) - 1u;
+        const unsigned off = (woff[i] + (unsigned)u * 16u) | wbad[i] | kbad;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(Bs + (buf * BN + 32 * i + 8 * wave_u) * BK), 16, (int)off, 0, 0, 0);
+    };
     auto advance = [&]() {      // to the following chunk (8 units further along K); prefetch its tap offset
         u += 8;                 // 8 = q8 * cpt + r8: whole taps, then at most one wrap -- no branch, no division
         tap += q8;
@@ -256,15 +299,27 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
 
     const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int wm = wave / WN, wn = wave % WN;
-    const int fragA = (wm * TM * 32 + r) * LDK + h * 4;
-    const int fragB = (wn * TN * 32 + r) * LDK + h * 4;
+    // DMA: unit 2g + h of row r sits in slot (2g + h) ^ key, key = (r >> 1) & 7: the address of group g is the
+    // address of group 0 with g XOR-ed into the slot's upper two bits
+    const int fkey = (r >> 1) & 7;
+    const int fragA = DMA ? (wm * TM * 32 + r) * BK + ((h ^ fkey) & 7) * 4 : (wm * TM * 32 + r) * LDK + h * 4;
+    const int fragB = DMA ? (wn * TN * 32 + r) * BK + ((h ^ fkey) & 7) * 4 : (wn * TN * 32 + r) * LDK + h * 4;
     auto read_frag = [&](int buf, int g, f32x4 (&af)[TM], f32x4 (&bf)[TN]) {
-        const float* Ab = As + buf * BM * LDK + fragA + g * 8;
-        const float* Bb = Bs + buf * BN * LDK + fragB + g * 8;
+        const float* Ab = DMA ? As + buf * BM * BK + (fragA ^ (g * 8)) : As + buf * BM * LDK + fragA + g * 8;
+        const float* Bb = DMA ? Bs + buf * BN * BK + (fragB ^ (g * 8)) : Bs + buf * BN * LDK + fragB + g * 8;
 #pragma unroll
-        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDK);
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const f32x4*>(Ab + i * 32 * LDR);
 #pragma unroll
-        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDK);
+        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const f32x4*>(Bb + j * 32 * LDR);
+    };
+    auto relu_frag = [&](f32x4 (&af)[TM]) {      // DMA arm: relu(in) is applied to the fragments (no staging registers)
+        if constexpr (DMA && RELU) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                af[i].x = fmaxf(af[i].x, 0.f); af[i].y = fmaxf(af[i].y, 0.f);
+                af[i].z = fmaxf(af[i].z, 0.f); af[i].w = fmaxf(af[i].w, 0.f);
+            }
+        }
     };
 
     f32x16 acc[TM][TN];
@@ -310,6 +365,85 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
             if (more) store_chunk(buf ^ 1);
             __syncthreads();
         }
+    } else if constexpr (DMA) {
+    // ---- LDS-DMA K loop: the pieces of chunk c+1 are issued one behind each of the first MFMAs of chunk c,
+    // straight into the other LDS stage (free since the barrier that ended chunk c-1); they land while groups
+    // 0..2 compute, __syncthreads() drains them (hipcc puts vmcnt(0) in front of the barrier while an LDS-DMA is
+    // outstanding) and group 3's MFMAs run behind the barrier as in the register-staged loop.
+    auto mma_one = [&](int s, const f32x4 (&af)[TM], const f32x4 (&bf)[TN]) {
+        const int kk = s / (TM * TN), i = (s / TN) % TM, j = s % TN;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i][kk], bf[j][kk], acc[i][j], 0, 0, 0);
+    };
+    auto mma = [&](const f32x4 (&af)[TM], const f32x4 (&bf)[TN]) {
+#pragma unroll
+        for (int s = 0; s < NMMA; ++s) mma_one(s, af, bf);
+    };
+    constexpr int NPIECE = RA + RB + 1;
+    static_assert(NPIECE <= 2 * NMMA, "one piece per MFMA gap of groups 0 and 1");
+    auto dma_piece = [&](int buf, int p) {
+        if (p < RA) dma_a(buf, p);
+        else if (p < RA + RB) dma_b(buf, p - RA);
+        else if (p == RA + RB) advance();
+    };
+    f32x4 fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+#pragma unroll
+    for (int p = 0; p < NPIECE; ++p) dma_piece(0, p);
+    __syncthreads();
+    read_frag(0, 0, fa0, fb0);
+#ifdef LOANS_EXPERIMENT
+    if (a.dbg & 1) __builtin_amdgcn_s_setprio(0);
+#endif
+    int c = 0;
+    for (; c + 1 < a.nchunks; ++c) {
+        const int buf = c & 1;
+        read_frag(buf, 1, fa1, fb1);
+        relu_frag(fa0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < NMMA; ++s) {
+            mma_one(s, fa0, fb0);
+            dma_piece(buf ^ 1, s);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        read_frag(buf, 2, fa0, fb0);
+        relu_frag(fa1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < NMMA; ++s) {
+            mma_one(s, fa1, fb1);
+            dma_piece(buf ^ 1, NMMA + s);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        read_frag(buf, 3, fa1, fb1);
+        relu_frag(fa0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        relu_frag(fa1);
+        __syncthreads();
+        read_frag(buf ^ 1, 0, fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    {   // last chunk (see the register-staged loop)
+        const int buf = c & 1;
+        const int tg = a.tail_groups;
+        if (tg > 1) read_frag(buf, 1, fa1, fb1);
+        relu_frag(fa0);
+        mma(fa0, fb0);
+        if (tg > 1) {
+            if (tg > 2) read_frag(buf, 2, fa0, fb0);
+            relu_frag(fa1);
+            mma(fa1, fb1);
+            if (tg > 2) {
+                if (tg > 3) read_frag(buf, 3, fa1, fb1);
+                relu_frag(fa0);
+                mma(fa0, fb0);
+                if (tg > 3) { relu_frag(fa1); mma(fa1, fb1); }
+            }
+        }
+    }
     } else {
     // MFMA number s (0 .. NMMA-1) of a k group
     auto mma_one = [&](int s, const f32x4 (&af)[TM], const f32x4 (&bf)[TN]) {
@@ -330,11 +464,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     constexpr int NPIECE = RA + RB + 1;                       // loader pieces (last = advance)
     constexpr int PPG = (NPIECE + NMMA - 1) / NMMA;           // pieces per MFMA gap
     auto load_piece = [&](int p) {
-        if (p < RA) load_a(p);
-        else if (p < RA + RB) load_b(p - RA);
+        if (p < RA) { if (!DBGSKIP(16)) load_a(p); }
+        else if (p < RA + RB) { if (!DBGSKIP(16)) load_b(p - RA); }
         else if (p == RA + RB) advance();
     };
     auto store_piece = [&](int buf, int p) {
+        if (DBGSKIP(32)) return;
         if (p < RA) store_a(buf, p);
         else if (p < RA + RB) store_b(buf, p - RA);
     };
@@ -343,6 +478,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     store_chunk(0);
     __syncthreads();
     read_frag(0, 0, fa0, fb0);
+#ifdef LOANS_EXPERIMENT
+    if (a.dbg & 1) __builtin_amdgcn_s_setprio(0);
+#endif
 
     STAMP(t_begin);
     int c = 0;
@@ -350,7 +488,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
         const int buf = c & 1;
         STAMP(t0);
         // group 0 (+ loader)
-        read_frag(buf, 1, fa1, fb1);
+        if (!DBGSKIP(128)) read_frag(buf, 1, fa1, fb1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < NMMA; ++s) {
@@ -361,12 +499,12 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
         }
         STAMP(t1);
         // group 1
-        read_frag(buf, 2, fa0, fb0);
+        if (!DBGSKIP(128)) read_frag(buf, 2, fa0, fb0);
         __builtin_amdgcn_sched_barrier(0);
         mma(fa1, fb1);
         __builtin_amdgcn_sched_barrier(0);
         // group 2 (+ LDS writes of the staged chunk into the other buffer)
-        read_frag(buf, 3, fa1, fb1);
+        if (!DBGSKIP(128)) read_frag(buf, 3, fa1, fb1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int s = 0; s < NMMA; ++s) {
@@ -377,9 +515,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
         }
         STAMP(t2);
         // group 3 runs behind the barrier with operands that are already in registers
-        __syncthreads();
+        if (!DBGSKIP(64)) __syncthreads();
         STAMP(t3);
-        read_frag(buf ^ 1, 0, fa0, fb0);
+        if (!DBGSKIP(128)) read_frag(buf ^ 1, 0, fa0, fb0);
         __builtin_amdgcn_sched_barrier(0);
         mma(fa1, fb1);
         __builtin_amdgcn_sched_barrier(0);
@@ -418,6 +556,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     const bool f_addmask = d.flags & LOANS_F_ADDEND_MASK;
     constexpr int LDC = BN + 4;
     float* Cs = reinterpret_cast<float*>(smem);          // [BM][LDC]
+#ifdef LOANS_EXPERIMENT
+    if (a.dbg & 2) __builtin_amdgcn_s_setprio(3);
+#endif
     __syncthreads();                                     // every wave is done with the fragment buffers
     if (f_stats) {
         int nvalid = 0;
@@ -498,6 +639,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
         } else if (f_add) {
             v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_add, (int)off, 0, 0));
         }
+#ifdef LOANS_EXPERIMENT
+        if ((a.dbg & 8) && v.x != 12345.f) continue;      // no output stores
+#endif
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_out, (int)off, 0, 0);
     }
 #ifdef LOANS_STAMPS
@@ -511,22 +655,22 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
 #endif
 }
 
-template <int BM, int BN>
+template <int BM, int BN, bool DMA>
 constexpr size_t igemm_lds_bytes() {
-    return (size_t)(2 * BM * LDK + 2 * BN * LDK) * 4 + LOANS_MAX_TAPS * 4 + BM * 4;
+    return igemm_aux_floats<BM, BN, DMA>() * 4 + LOANS_MAX_TAPS * 4 + BM * 4;
 }
 
-template <int BM, int BN, int WM, int WN, bool RELU, bool BF16>
+template <int BM, int BN, int WM, int WN, bool RELU, bool BF16, bool DMA>
 int launch_igemm_r(IgemmArgs& a, hipStream_t st) {
     static bool attr_set = false;
 #ifdef LOANS_STAMPS
     // diagnostic: LOANS_DBG_LDS=<bytes> pads the LDS request to force fewer blocks per CU
     const char* dbg_lds = getenv("LOANS_DBG_LDS");
-    const size_t lds = dbg_lds ? (size_t)atol(dbg_lds) : igemm_lds_bytes<BM, BN>();
+    const size_t lds = dbg_lds ? (size_t)atol(dbg_lds) : igemm_lds_bytes<BM, BN, DMA>();
 #else
-    constexpr size_t lds = igemm_lds_bytes<BM, BN>();
+    constexpr size_t lds = igemm_lds_bytes<BM, BN, DMA>();
 #endif
-    auto kern = igemm_kernel<BM, BN, WM, WN, RELU, BF16>;
+    auto kern = igemm_kernel<BM, BN, WM, WN, RELU, BF16, DMA>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -560,8 +704,9 @@ void detect_tap_grid(const loans_igemm_desc* d, IgemmArgs& a) {
 template <int BM, int BN, int WM, int WN>
 int launch_igemm(IgemmArgs& a, hipStream_t st) {
     const bool relu = a.d.flags & LOANS_F_RELU_IN;
-    if (a.bf16) return relu ? launch_igemm_r<BM, BN, WM, WN, true, true>(a, st) : launch_igemm_r<BM, BN, WM, WN, false, true>(a, st);
-    return relu ? launch_igemm_r<BM, BN, WM, WN, true, false>(a, st) : launch_igemm_r<BM, BN, WM, WN, false, false>(a, st);
+    if (a.bf16) return relu ? launch_igemm_r<BM, BN, WM, WN, true, true, false>(a, st) : launch_igemm_r<BM, BN, WM, WN, false, true, false>(a, st);
+    if (a.dma) return relu ? launch_igemm_r<BM, BN, WM, WN, true, false, true>(a, st) : launch_igemm_r<BM, BN, WM, WN, false, false, true>(a, st);
+    return relu ? launch_igemm_r<BM, BN, WM, WN, true, false, false>(a, st) : launch_igemm_r<BM, BN, WM, WN, false, false, false>(a, st);
 }
 
 int check_desc(const loans_igemm_desc* d) {
@@ -605,6 +750,10 @@ static int igemm_impl(const float* in, const float* w, float* out, const float* 
     a.in = in; a.w = w; a.out = out; a.bias = bias; a.stats = stats; a.ref = ref; a.addend = addend;
     a.d = *d;
     a.bf16 = bf16;
+    a.dbg = 0;
+#ifdef LOANS_EXPERIMENT
+    if (const char* e = getenv("LOANS_DBG")) a.dbg = atoi(e);
+#endif
     a.M = d->B * d->gridH * d->gridW;
     a.m_begin = 0;
     a.Ktot = d->ntaps * d->Cin;
@@ -622,6 +771,9 @@ static int igemm_impl(const float* in, const float* w, float* out, const float* 
     detect_tap_grid(d, a);
     hipStream_t st = as_stream(stream);
     int tile = d->tile;
+    a.dma = (tile & LOANS_TILE_DMA) ? 1 : 0;
+    if (a.dma && bf16) return LOANS_EINVAL;
+    tile &= ~LOANS_TILE_DMA;
     if (tile == 0) {
         if (d->Cout <= 64) {
             tile = LOANS_TILE_128x64;

@@ -190,8 +190,9 @@ def _with_flags(desc, flags, tile=0):
 AUTOTUNE = os.environ.get('LOANS_AUTOTUNE', '1') != '0'
 # candidates.  LOANS_TILE_SPLIT (6) only pays where nothing else shares the machine: in backward the dgrad launches run
 # beside the weight-gradient GEMMs of the side stream and the two-launch split measured slower there
-_FPROP_TILES = tuple(int(t) for t in os.environ.get('LOANS_FPROP_TILES', '1,2,3,4,6').split(','))
-_IGEMM_TILES = tuple(int(t) for t in os.environ.get('LOANS_DGRAD_TILES', '1,2,3').split(','))
+# +16 (LOANS_TILE_DMA): the same tile shape with its operands staged by LDS-DMA (fp32 arm only)
+_FPROP_TILES = tuple(int(t) for t in os.environ.get('LOANS_FPROP_TILES', '1,2,3,4,6,17,18,19,20,22').split(','))
+_IGEMM_TILES = tuple(int(t) for t in os.environ.get('LOANS_DGRAD_TILES', '1,2,3,17,18,19').split(','))
 _WGRAD_TILES = (1, 3, 5)
 
 
@@ -216,6 +217,8 @@ def _tuned_tile(geo, mode, run, candidates):
     if not AUTOTUNE:
         geo.tuned[mode] = 0
         return 0
+    if COMPUTE == 'bf16':
+        candidates = [t for t in candidates if not (t & 16)]
     times = {t: _time_call(lambda: run(t)) for t in candidates}
     tile = min(times, key=times.get)
     geo.tuned[mode] = tile
@@ -229,7 +232,7 @@ def _tuned_tile(geo, mode, run, candidates):
 def _igemm_launches(M, Cout, tile, device):
     """Kernel launches behind one loans_igemm call: LOANS_TILE_SPLIT is two when both row ranges are non-empty
     (same arithmetic as igemm_impl)."""
-    if tile != 6:
+    if (tile & 15) != 6:
         return 1
     slots = 2 * torch.cuda.get_device_properties(device).multi_processor_count
     tiles_n = (Cout + 127) // 128

@@ -42,7 +42,7 @@ CONV_CASES = [
 
 
 @pytest.mark.parametrize("case", CONV_CASES)
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 6, 17, 18, 19, 20, 22])     # +16 = LOANS_TILE_DMA
 def test_conv_fprop_dgrad_wgrad(case, tile):
     from loans_amd import ops
     B, Cin, H, W, Cout, k, s, p = case
@@ -72,7 +72,7 @@ def test_conv_fprop_dgrad_wgrad(case, tile):
     gy = rng.standard_normal(y_ref.shape).astype(np.float32)
     gx_ref, gw_ref, _ = C.conv2d_bwd(x.shape, col, w.astype(np.float64), gy.astype(np.float64), s, p, False)
     gyd = dev(_nhwc(gy))
-    if tile in (0, 1, 2, 3, 4, 6):
+    if tile in (0, 1, 2, 3, 4, 6, 17, 18, 19, 20, 22):
         gx = ops.conv_dgrad(gyd, wd, geo, tile=tile)
         assert rel_err(_nchw(gx, Cin), gx_ref) < 2e-6
         if geo.dgrad_has_empty_class:
@@ -138,6 +138,8 @@ def test_conv_split_tile():
     np.testing.assert_allclose(stats[1].cpu().numpy(), (y_ref ** 2).sum(axis=(0, 2, 3)), rtol=1e-5)
     y1 = ops.conv_fprop(xd, wd, geo, addend=dev(_nhwc(add)), tile=3)
     assert torch.equal(y, y1)                       # K is accumulated in the same order by every tile shape
+    for t in (17, 19, 22):                          # ... and by the LDS-DMA staged variants
+        assert torch.equal(y, ops.conv_fprop(xd, wd, geo, addend=dev(_nhwc(add)), tile=t)), t
     gy = rng.standard_normal(y_ref.shape).astype(np.float32)
     gx_ref = np.einsum('bohw,oc->bchw', gy.astype(np.float64), w[:, :, 0, 0].astype(np.float64))
     ref_t = rng.standard_normal(x.shape).astype(np.float32)
@@ -166,7 +168,7 @@ def test_prep_images_dense_exact():
 
 @pytest.mark.parametrize("case", [(2, 32, 32, 64, 7, 2, 3), (3, 17, 23, 64, 7, 2, 3), (2, 12, 12, 128, 3, 1, 1),
                                   (1, 40, 36, 64, 7, 2, 3)])
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 5, 17, 18, 19, 20])
 def test_conv_dense_rows(case, tile):
     """LOANS_F_DENSE: the RGB stem on packed 3-channel rows of a zero-padded frame (K = kh x 24 instead of kh*kw x 4)"""
     from loans_amd import ops

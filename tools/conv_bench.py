@@ -8,6 +8,9 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if '--exp' in sys.argv:      # experiment build (make -C loans_amd/csrc exp): LOANS_DBG bits are read per launch
+    from loans_amd import _lib
+    _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), 'libloans_hip_exp.so')
 from loans_amd import ops  # noqa: E402
 
 LAYERS = [
@@ -46,11 +49,15 @@ def main():
     ap.add_argument('--layers', default='')
     ap.add_argument('--tiles', default='0,1,2,3,4,5')
     ap.add_argument('--compute', default='f32')
+    ap.add_argument('--inner', type=int, default=3, help='launches per timed sample')
+    ap.add_argument('--exp', action='store_true')
+    ap.add_argument('--dbg', default='0', help='comma list of LOANS_DBG values to interleave (needs --exp)')
     args = ap.parse_args()
     B = args.batch
     ops.set_compute_dtype(args.compute)
     tiles = [int(t) for t in args.tiles.split(',')]
-    names = {0: 'auto', 1: '128x128', 2: '128x64', 3: '64x64', 4: '256x64', 5: '64x128'}
+    names = {0: 'auto', 1: '128x128', 2: '128x64', 3: '64x64', 4: '256x64', 5: '64x128', 6: 'split'}
+    names.update({t + 16: n + 'D' for t, n in list(names.items()) if t in (1, 2, 3, 4, 6)})
     for name, Cin, H, W, Cout, k, s, p in LAYERS:
         if args.layers and name not in args.layers.split(','):
             continue
@@ -65,21 +72,38 @@ def main():
         cin = 3 if Cin == 4 else Cin
         flops = 2.0 * B * geo.Ho * geo.Wo * Cout * k * k * cin
         line = '%-8s M=%8d N=%4d K=%5d |' % (name, B * geo.Ho * geo.Wo, Cout, k * k * Cin)
+        cases = []
         for mode in args.modes.split(','):
-            for t in tiles:
+            for t, dbg in [(t, g) for t in tiles for g in args.dbg.split(',')]:
                 if mode == 'wgrad' and t not in (0, 1, 3, 5):
                     continue
-                if mode != 'wgrad' and t == 5:
+                if mode != 'wgrad' and t == 5 or (mode == 'dgrad' and (t & 15) in (4, 6)):
                     continue
                 if mode == 'fprop':
-                    fn = lambda: ops.conv_fprop(x, w, geo, out=y, stats=stats, tile=t)   # noqa: E731
+                    fn = lambda t=t: ops.conv_fprop(x, w, geo, out=y, stats=stats, tile=t)   # noqa: E731
                 elif mode == 'dgrad':
-                    fn = lambda: ops.conv_dgrad(gy, w, geo, out=gx, tile=t)              # noqa: E731
+                    fn = lambda t=t: ops.conv_dgrad(gy, w, geo, out=gx, tile=t)              # noqa: E731
                 else:
-                    fn = lambda: ops._conv_wgrad(x, gy, dw, geo, False, 0, t)             # noqa: E731  (sync path: the public op goes to a side stream)
-                ms = timeit(fn, args.reps)
-                line += ' %s/%s %6.1f TF' % (mode[0], names[t], flops / ms / 1e9)
-            line += ' |'
+                    fn = lambda t=t: ops._conv_wgrad(x, gy, dw, geo, False, 0, t)             # noqa: E731  (sync path: the public op goes to a side stream)
+                cases.append((mode, t, dbg, fn, []))
+        # every case once per round, rounds repeated: clock / thermal drift hits all cases alike
+        for rnd in range(args.reps + 1):
+            for mode, t, dbg, fn, ts in cases:
+                os.environ['LOANS_DBG'] = dbg
+                a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                for _ in range(args.inner):
+                    fn()
+                a.record()
+                for _ in range(args.inner):
+                    fn()
+                b.record()
+                torch.cuda.synchronize()
+                if rnd:
+                    ts.append(a.elapsed_time(b) / args.inner)
+        for mode, t, dbg, fn, ts in cases:
+            ms = float(np.median(ts))
+            line += ' %s/%s%s %6.1f TF' % (mode[0], names[t], ('#' + dbg) if args.exp else '', flops / ms / 1e9)
+        line += ' |'
         print(line, flush=True)
 
 
