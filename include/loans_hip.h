@@ -78,6 +78,7 @@ typedef struct loans_igemm_desc {
 #define LOANS_TILE_256x64  4
 #define LOANS_TILE_64x128  5   /* wgrad only: 64 output channels x 128 tap-channel columns */
 #define LOANS_TILE_SPLIT   6   /* igemm only: 128x128 tiles over the rows that fill whole machine rounds, 64x64 over the rest (two launches) */
+#define LOANS_TILE_256x128 7   /* loans_igemm_bf16s only */
 #define LOANS_TILE_DMA    16   /* igemm, fp32 arm, OR-ed onto a tile shape: operand tiles staged by LDS-DMA (buffer_load ... lds)
                                   into XOR-swizzled unpadded LDS rows instead of through registers; same results bit for bit */
 
@@ -106,6 +107,23 @@ int loans_wgrad_f32(const float* x, const float* gy, float* dw,
 /* wgrad with both operands rounded to bf16 (RNE) and the bf16 MFMA; fp32 accumulation into dw. */
 int loans_wgrad_bf16_f32(const float* x, const float* gy, float* dw,
                          const loans_igemm_desc* d, int32_t splits, void* stream);
+
+/* ---- bf16 STORAGE arm (BASELINE configs 3 / 5: "bf16", "bf16 with fp32 grad accumulate").  Activations and
+ *      gradients of the localizer's residual stages live in HBM as bf16 NHWC with C % 8 == 0; parameters, their
+ *      gradients, BN statistics / coefficients and every accumulation stay fp32.  `void*` = bf16 tensor. ---- */
+
+/* fprop / dgrad on bf16 tensors: in, w ([Cout][ntaps][Cin], see loans_cast_bf16 / loans_repack_dgrad_bf16), out, ref and
+ * addend are bf16; bias and stats as in loans_igemm_f32 (statistics are taken from the fp32 accumulators, the output
+ * is rounded to bf16 once).  Flags BIAS / STATS / MASK / ADDEND / ADDEND_MASK; tiles 128x128, 128x64, 64x64,
+ * 256x64, 256x128 (0 = auto).  Operand tiles are staged by LDS-DMA, contraction on v_mfma_f32_32x32x16_bf16. */
+int loans_igemm_bf16s(const void* in, const void* w, void* out, const float* bias, double* stats,
+                      const void* ref, const void* addend, const loans_igemm_desc* d, void* stream);
+/* wgrad with bf16 x and gy, fp32 atomic accumulation into dw ("fp32 grad accumulate") */
+int loans_wgrad_bf16s(const void* x, const void* gy, float* dw, const loans_igemm_desc* d, int32_t splits, void* stream);
+/* fp32 master weights -> bf16 operand copies: plain cast (n % 4 == 0), and the dgrad re-pack with the cast folded in */
+int loans_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
+int loans_repack_dgrad_bf16(const float* src, void* dst, int32_t Cout, int32_t Cin, int32_t src_taps,
+                            const int32_t* tapsel_host, int32_t ntaps, void* stream);
 
 /* dgrad for convolutions whose input has 4 physical channels (the RGB crops, common/net.py:15,17):
  * out[opix(m)][0..3] = sum_t sum_co gy[pix(m,t)][co] * w_ohwi[co][tapsel[t]][0..3]; same descriptor as
@@ -155,6 +173,17 @@ int loans_maxpool_relu_bwd_f32(const float* gy, const uint8_t* idx, const float*
                                const float* shift, float* gx,
                                int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream);
 
+/* the same three passes on bf16 tensors (x, x2, y / gy, idx as above; coefficients fp32); the stem's pool writes bf16
+ * from its fp32 conv output, its backward reads a bf16 gradient and writes the fp32 one the stem's BN / wgrad consume */
+int loans_bn_apply_bf16(const void* x, const float* scale, const float* shift,
+                        const void* x2, const float* scale2, const float* shift2,
+                        void* y, int64_t rows, int32_t C, int32_t mode, int32_t relu, void* stream);
+int loans_bn_relu_maxpool_f32_bf16(const float* x, const float* scale, const float* shift, void* y, uint8_t* idx,
+                                   int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream);
+int loans_maxpool_relu_bwd_bf16_f32(const void* gy, const uint8_t* idx, const float* x, const float* scale,
+                                    const float* shift, float* gx,
+                                    int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream);
+
 /* backward reductions: sums[0][c] += sum g, sums[1][c] += sum g*xhat  with g = gy*(mask>0) (mask may be
  * NULL), xhat = (x-mean)*rstd. If x2 != NULL also sums[2], sums[3] for (x2, mean2, rstd2). */
 int loans_bn_bwd_reduce_f32(const float* gy, const float* mask, const float* x, const float* mean,
@@ -170,12 +199,24 @@ int loans_bn_bwd_apply_f32(const float* gy, const float* mask, const float* x,
                            const float* x2, const float* k1b, const float* k2b, const float* k3b, float* gx2,
                            int64_t rows, int32_t C, void* stream);
 
+/* bf16 tensors (gy, mask, x, x2, gx, gx2), fp32 sums and coefficients */
+int loans_bn_bwd_reduce_bf16(const void* gy, const void* mask, const void* x, const float* mean,
+                             const float* rstd, const void* x2, const float* mean2, const float* rstd2,
+                             double* sums, int64_t rows, int32_t C, void* stream);
+int loans_bn_bwd_apply_bf16(const void* gy, const void* mask, const void* x,
+                            const float* k1, const float* k2, const float* k3, void* gx,
+                            const void* x2, const float* k1b, const float* k2b, const float* k3b, void* gx2,
+                            int64_t rows, int32_t C, void* stream);
+
 /* ---- small dense ops ---- */
 /* out[c] += sum_rows x[row][c]   (conv bias gradient) */
 int loans_colsum_f32(const float* x, float* out, int64_t rows, int32_t C, void* stream);
 /* _global_average_pooling_2d (sheep_localizer.py:58): x [B][HW][C] -> y [B][C] ; backward broadcast */
 int loans_gap_fwd_f32(const float* x, float* y, int32_t B, int32_t HW, int32_t C, void* stream);
 int loans_gap_bwd_f32(const float* gy, float* gx, int32_t B, int32_t HW, int32_t C, void* stream);
+/* the boundary of the bf16 region: pooled features leave it as fp32, their gradient enters it as bf16 */
+int loans_gap_fwd_bf16_f32(const void* x, float* y, int32_t B, int32_t HW, int32_t C, void* stream);
+int loans_gap_bwd_f32_bf16(const float* gy, void* gx, int32_t B, int32_t HW, int32_t C, void* stream);
 /* L.Linear (sheep_localizer.py:60 ; common/net.py:81,90). act_in: 1 = relu(x) on load; act_out: 1 = sigmoid */
 int loans_linear_fwd_f32(const float* x, const float* W, const float* b, float* y,
                          int32_t B, int32_t K, int32_t N, int32_t act_in, int32_t act_out, void* stream);

@@ -15,6 +15,7 @@ MAX_TAPS = 64
 F_RELU_IN, F_BIAS, F_STATS, F_MASK, F_ADDEND, F_ADDEND_MASK = 1, 2, 4, 8, 16, 32
 F_DENSE = 64
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_256x64 = 0, 1, 2, 3, 4
+TILE_256x128, TILE_DMA = 7, 16
 
 
 class HipKernelError(RuntimeError):
@@ -38,6 +39,17 @@ SIGNATURES = {
     'loans_igemm_bf16_f32': [_p, _p, _p, _p, _p, _p, _p, C.POINTER(IgemmDesc), _p],
     'loans_wgrad_f32': [_p, _p, _p, C.POINTER(IgemmDesc), _i32, _p],
     'loans_wgrad_bf16_f32': [_p, _p, _p, C.POINTER(IgemmDesc), _i32, _p],
+    'loans_igemm_bf16s': [_p, _p, _p, _p, _p, _p, _p, C.POINTER(IgemmDesc), _p],
+    'loans_wgrad_bf16s': [_p, _p, _p, C.POINTER(IgemmDesc), _i32, _p],
+    'loans_cast_bf16': [_p, _p, _i64, _p],
+    'loans_repack_dgrad_bf16': [_p, _p, _i32, _i32, _i32, C.POINTER(_i32), _i32, _p],
+    'loans_bn_apply_bf16': [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p],
+    'loans_bn_relu_maxpool_f32_bf16': [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p],
+    'loans_maxpool_relu_bwd_bf16_f32': [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p],
+    'loans_bn_bwd_reduce_bf16': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p],
+    'loans_bn_bwd_apply_bf16': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p],
+    'loans_gap_fwd_bf16_f32': [_p, _p, _i32, _i32, _i32, _p],
+    'loans_gap_bwd_f32_bf16': [_p, _p, _i32, _i32, _i32, _p],
     'loans_dgrad_c4_f32': [_p, _p, _p, _p, _p, C.POINTER(IgemmDesc), C.POINTER(_i32), _i32, _p],
     'loans_repack_dgrad_f32': [_p, _p, _i32, _i32, _i32, C.POINTER(_i32), _i32, _p],
     'loans_resize_lanczos_u8': [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _i32, _p, _p, _i32, _p],

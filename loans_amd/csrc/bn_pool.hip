@@ -1,4 +1,5 @@
-// Batch-normalisation, ReLU, residual-add and max-pool kernels (NHWC, C % 4 == 0, fp32).
+// Batch-normalisation, ReLU, residual-add and max-pool kernels (NHWC, C % 4 == 0; activations fp32 or bf16 storage,
+// arithmetic and per-channel coefficients always fp32).
 // All of them are HBM-bound streaming passes: 16-byte accesses, grid-stride over float4
 // elements, per-channel coefficients re-read from L1/L2.  Reductions go per-thread (fp32)
 // -> LDS across the block -> one fp64 atomic per channel per block.
@@ -55,24 +56,25 @@ __global__ void bn_eval_coeffs_kernel(int C, float eps, const float* gamma, cons
     shift[c] = beta[c] - rmean[c] * sc;
 }
 
-template <int MODE>
-__global__ __launch_bounds__(256) void bn_apply_kernel(const float* x, const float* scale, const float* shift,
-                                                       const float* x2, const float* scale2, const float* shift2,
-                                                       float* y, int64_t n4, int C4, int relu) {
+template <int MODE, typename T>
+__global__ __launch_bounds__(256) void bn_apply_kernel(const T* x, const float* scale, const float* shift,
+                                                       const T* x2, const float* scale2, const float* shift2,
+                                                       T* y, int64_t n4, int C4, int relu) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % C4) * 4;
-        f32x4 v = ld4(x + i * 4);
+        f32x4 v = io4<T>::ld(x + i * 4);
         const f32x4 s = ld4(scale + c), t = ld4(shift + c);
         v = v * s + t;
-        if (MODE == 1) v += ld4(x2 + i * 4);
-        if (MODE == 2) v += ld4(x2 + i * 4) * ld4(scale2 + c) + ld4(shift2 + c);
+        if (MODE == 1) v += io4<T>::ld(x2 + i * 4);
+        if (MODE == 2) v += io4<T>::ld(x2 + i * 4) * ld4(scale2 + c) + ld4(shift2 + c);
         if (relu) v = relu4(v);
-        st4(y + i * 4, v);
+        io4<T>::st(y + i * 4, v);
     }
 }
 
+template <typename TO>
 __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const float* x, const float* scale, const float* shift,
-                                                              float* y, uint8_t* idx, int B, int H, int W, int C4,
+                                                              TO* y, uint8_t* idx, int B, int H, int W, int C4,
                                                               int OH, int OW) {
     const int64_t total = (int64_t)B * OH * OW * C4;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -100,12 +102,13 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const float* x, co
                 if (v.w > best.w) { best.w = v.w; a3 = k; }
             }
         }
-        st4(y + i * 4, best);
+        io4<TO>::st(y + i * 4, best);
         *reinterpret_cast<uchar4*>(idx + i * 4) = make_uchar4(a0, a1, a2, a3);
     }
 }
 
-__global__ __launch_bounds__(256) void maxpool_relu_bwd_kernel(const float* gy, const uint8_t* idx, const float* x,
+template <typename TG>
+__global__ __launch_bounds__(256) void maxpool_relu_bwd_kernel(const TG* gy, const uint8_t* idx, const float* x,
                                                                const float* scale, const float* shift, float* gx,
                                                                int B, int H, int W, int C4, int OH, int OW) {
     const int64_t total = (int64_t)B * H * W * C4;
@@ -123,7 +126,7 @@ __global__ __launch_bounds__(256) void maxpool_relu_bwd_kernel(const float* gy, 
                 const int k = (ih - 2 * oh) * 3 + (iw - 2 * ow);
                 const int64_t o = (((int64_t)b * OH + oh) * OW + ow) * C4 + c4;
                 const uchar4 a = *reinterpret_cast<const uchar4*>(idx + o * 4);
-                const f32x4 gv = ld4(gy + o * 4);
+                const f32x4 gv = io4<TG>::ld(gy + o * 4);
                 if (a.x == k) g.x += gv.x;
                 if (a.y == k) g.y += gv.y;
                 if (a.z == k) g.z += gv.z;
@@ -136,9 +139,9 @@ __global__ __launch_bounds__(256) void maxpool_relu_bwd_kernel(const float* gy, 
 
 // Per-channel reductions over rows.  Thread (cg = tid % C4, rl = tid / C4) walks rows rl, rl+RL, ...
 // of the block's slab; NS = number of sums per channel.
-template <bool DUAL, bool MASK>
-__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* gy, const float* mask, const float* x,
-                                                            const float* mean, const float* rstd, const float* x2,
+template <bool DUAL, bool MASK, typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* gy, const T* mask, const T* x,
+                                                            const float* mean, const float* rstd, const T* x2,
                                                             const float* mean2, const float* rstd2, double* sums,
                                                             int64_t rows, int C4, int C4T, int rows_per_block) {
     constexpr int NS = DUAL ? 3 : 2;
@@ -157,11 +160,11 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const float* gy, con
     if (rl < RL) {
         for (int64_t r = r0 + rl; r < r1; r += RL) {
             const int64_t o = (r * C4T + cg) * 4;
-            f32x4 g = ld4(gy + o);
-            if (MASK) g = maskpos4(g, ld4(mask + o));
+            f32x4 g = io4<T>::ld(gy + o);
+            if (MASK) g = maskpos4(g, io4<T>::ld(mask + o));
             sg += g;
-            sgx += g * ((ld4(x + o) - mu) * rs);
-            if (DUAL) sgx2 += g * ((ld4(x2 + o) - mu2) * rs2);
+            sgx += g * ((io4<T>::ld(x + o) - mu) * rs);
+            if (DUAL) sgx2 += g * ((io4<T>::ld(x2 + o) - mu2) * rs2);
         }
     }
     red[0][tid] = sg;
@@ -200,17 +203,17 @@ __global__ void bn_bwd_coeffs_kernel(const double* sums, int C, double inv_count
     k3[c] = (float)(a * ((double)mean[c] * (double)rstd[c] * dg - db) * inv_count);
 }
 
-template <bool DUAL, bool MASK>
-__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const float* gy, const float* mask, const float* x,
-                                                           const float* k1, const float* k2, const float* k3, float* gx,
-                                                           const float* x2, const float* k1b, const float* k2b,
-                                                           const float* k3b, float* gx2, int64_t n4, int C4) {
+template <bool DUAL, bool MASK, typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* gy, const T* mask, const T* x,
+                                                           const float* k1, const float* k2, const float* k3, T* gx,
+                                                           const T* x2, const float* k1b, const float* k2b,
+                                                           const float* k3b, T* gx2, int64_t n4, int C4) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % C4) * 4;
-        f32x4 g = ld4(gy + i * 4);
-        if (MASK) g = maskpos4(g, ld4(mask + i * 4));
-        st4(gx + i * 4, ld4(k1 + c) * g + ld4(k2 + c) * ld4(x + i * 4) + ld4(k3 + c));
-        if (DUAL) st4(gx2 + i * 4, ld4(k1b + c) * g + ld4(k2b + c) * ld4(x2 + i * 4) + ld4(k3b + c));
+        f32x4 g = io4<T>::ld(gy + i * 4);
+        if (MASK) g = maskpos4(g, io4<T>::ld(mask + i * 4));
+        io4<T>::st(gx + i * 4, ld4(k1 + c) * g + ld4(k2 + c) * io4<T>::ld(x + i * 4) + ld4(k3 + c));
+        if (DUAL) io4<T>::st(gx2 + i * 4, ld4(k1b + c) * g + ld4(k2b + c) * io4<T>::ld(x2 + i * 4) + ld4(k3b + c));
     }
 }
 
@@ -280,28 +283,66 @@ extern "C" int loans_bn_eval_coeffs_f32(int32_t C, float eps, const float* gamma
     return LOANS_OK;
 }
 
-extern "C" int loans_bn_apply_f32(const float* x, const float* scale, const float* shift, const float* x2,
-                                  const float* scale2, const float* shift2, float* y, int64_t rows, int32_t C,
-                                  int32_t mode, int32_t relu, void* stream) {
+template <typename T>
+static int bn_apply_impl(const T* x, const float* scale, const float* shift, const T* x2,
+                         const float* scale2, const float* shift2, T* y, int64_t rows, int32_t C,
+                         int32_t mode, int32_t relu, void* stream) {
     if (!x || !scale || !shift || !y || rows <= 0 || C <= 0 || (C & 3)) return LOANS_EINVAL;
     if (mode < 0 || mode > 2 || (mode >= 1 && !x2) || (mode == 2 && (!scale2 || !shift2))) return LOANS_EINVAL;
     const int64_t n4 = rows * (C / 4);
     const int grid = grid_for(n4, 256);
     hipStream_t st = as_stream(stream);
-    if (mode == 0) hipLaunchKernelGGL(bn_apply_kernel<0>, dim3(grid), dim3(256), 0, st, x, scale, shift, x2, scale2, shift2, y, n4, C / 4, relu);
-    if (mode == 1) hipLaunchKernelGGL(bn_apply_kernel<1>, dim3(grid), dim3(256), 0, st, x, scale, shift, x2, scale2, shift2, y, n4, C / 4, relu);
-    if (mode == 2) hipLaunchKernelGGL(bn_apply_kernel<2>, dim3(grid), dim3(256), 0, st, x, scale, shift, x2, scale2, shift2, y, n4, C / 4, relu);
+    if (mode == 0) hipLaunchKernelGGL((bn_apply_kernel<0, T>), dim3(grid), dim3(256), 0, st, x, scale, shift, x2, scale2, shift2, y, n4, C / 4, relu);
+    if (mode == 1) hipLaunchKernelGGL((bn_apply_kernel<1, T>), dim3(grid), dim3(256), 0, st, x, scale, shift, x2, scale2, shift2, y, n4, C / 4, relu);
+    if (mode == 2) hipLaunchKernelGGL((bn_apply_kernel<2, T>), dim3(grid), dim3(256), 0, st, x, scale, shift, x2, scale2, shift2, y, n4, C / 4, relu);
+    LOANS_LAUNCH_CHECK();
+    return LOANS_OK;
+}
+
+extern "C" int loans_bn_apply_f32(const float* x, const float* scale, const float* shift, const float* x2,
+                                  const float* scale2, const float* shift2, float* y, int64_t rows, int32_t C,
+                                  int32_t mode, int32_t relu, void* stream) {
+    return bn_apply_impl<float>(x, scale, shift, x2, scale2, shift2, y, rows, C, mode, relu, stream);
+}
+
+extern "C" int loans_bn_apply_bf16(const void* x, const float* scale, const float* shift, const void* x2,
+                                   const float* scale2, const float* shift2, void* y, int64_t rows, int32_t C,
+                                   int32_t mode, int32_t relu, void* stream) {
+    return bn_apply_impl<__bf16>(static_cast<const __bf16*>(x), scale, shift, static_cast<const __bf16*>(x2), scale2, shift2,
+                                 static_cast<__bf16*>(y), rows, C, mode, relu, stream);
+}
+
+template <typename TO>
+static int bn_relu_maxpool_impl(const float* x, const float* scale, const float* shift, TO* y, uint8_t* idx,
+                                int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream) {
+    if (!x || !scale || !shift || !y || !idx || B <= 0 || H < 3 || W < 3 || C <= 0 || (C & 3)) return LOANS_EINVAL;
+    if (OH != (H - 2) / 2 + 1 || OW != (W - 2) / 2 + 1) return LOANS_EINVAL;   // cover_all out size, k=3 s=2 p=0
+    const int64_t total = (int64_t)B * OH * OW * (C / 4);
+    hipLaunchKernelGGL(bn_relu_maxpool_kernel<TO>, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), x, scale,
+                       shift, y, idx, B, H, W, C / 4, OH, OW);
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;
 }
 
 extern "C" int loans_bn_relu_maxpool_f32(const float* x, const float* scale, const float* shift, float* y, uint8_t* idx,
                                          int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream) {
-    if (!x || !scale || !shift || !y || !idx || B <= 0 || H < 3 || W < 3 || C <= 0 || (C & 3)) return LOANS_EINVAL;
-    if (OH != (H - 2) / 2 + 1 || OW != (W - 2) / 2 + 1) return LOANS_EINVAL;   // cover_all out size, k=3 s=2 p=0
-    const int64_t total = (int64_t)B * OH * OW * (C / 4);
-    hipLaunchKernelGGL(bn_relu_maxpool_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), x, scale,
-                       shift, y, idx, B, H, W, C / 4, OH, OW);
+    return bn_relu_maxpool_impl<float>(x, scale, shift, y, idx, B, H, W, C, OH, OW, stream);
+}
+
+extern "C" int loans_bn_relu_maxpool_f32_bf16(const float* x, const float* scale, const float* shift, void* y, uint8_t* idx,
+                                              int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream) {
+    return bn_relu_maxpool_impl<__bf16>(x, scale, shift, static_cast<__bf16*>(y), idx, B, H, W, C, OH, OW, stream);
+}
+
+template <typename TG>
+static int maxpool_relu_bwd_impl(const TG* gy, const uint8_t* idx, const float* x, const float* scale,
+                                 const float* shift, float* gx, int32_t B, int32_t H, int32_t W, int32_t C,
+                                 int32_t OH, int32_t OW, void* stream) {
+    if (!gy || !idx || !x || !scale || !shift || !gx || B <= 0 || H < 3 || W < 3 || C <= 0 || (C & 3)) return LOANS_EINVAL;
+    if (OH != (H - 2) / 2 + 1 || OW != (W - 2) / 2 + 1) return LOANS_EINVAL;
+    const int64_t total = (int64_t)B * H * W * (C / 4);
+    hipLaunchKernelGGL(maxpool_relu_bwd_kernel<TG>, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), gy, idx, x,
+                       scale, shift, gx, B, H, W, C / 4, OH, OW);
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;
 }
@@ -309,18 +350,19 @@ extern "C" int loans_bn_relu_maxpool_f32(const float* x, const float* scale, con
 extern "C" int loans_maxpool_relu_bwd_f32(const float* gy, const uint8_t* idx, const float* x, const float* scale,
                                           const float* shift, float* gx, int32_t B, int32_t H, int32_t W, int32_t C,
                                           int32_t OH, int32_t OW, void* stream) {
-    if (!gy || !idx || !x || !scale || !shift || !gx || B <= 0 || H < 3 || W < 3 || C <= 0 || (C & 3)) return LOANS_EINVAL;
-    if (OH != (H - 2) / 2 + 1 || OW != (W - 2) / 2 + 1) return LOANS_EINVAL;
-    const int64_t total = (int64_t)B * H * W * (C / 4);
-    hipLaunchKernelGGL(maxpool_relu_bwd_kernel, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), gy, idx, x,
-                       scale, shift, gx, B, H, W, C / 4, OH, OW);
-    LOANS_LAUNCH_CHECK();
-    return LOANS_OK;
+    return maxpool_relu_bwd_impl<float>(gy, idx, x, scale, shift, gx, B, H, W, C, OH, OW, stream);
 }
 
-extern "C" int loans_bn_bwd_reduce_f32(const float* gy, const float* mask, const float* x, const float* mean,
-                                       const float* rstd, const float* x2, const float* mean2, const float* rstd2,
-                                       double* sums, int64_t rows, int32_t C, void* stream) {
+extern "C" int loans_maxpool_relu_bwd_bf16_f32(const void* gy, const uint8_t* idx, const float* x, const float* scale,
+                                               const float* shift, float* gx, int32_t B, int32_t H, int32_t W, int32_t C,
+                                               int32_t OH, int32_t OW, void* stream) {
+    return maxpool_relu_bwd_impl<__bf16>(static_cast<const __bf16*>(gy), idx, x, scale, shift, gx, B, H, W, C, OH, OW, stream);
+}
+
+template <typename T>
+static int bn_bwd_reduce_impl(const T* gy, const T* mask, const T* x, const float* mean,
+                              const float* rstd, const T* x2, const float* mean2, const float* rstd2,
+                              double* sums, int64_t rows, int32_t C, void* stream) {
     if (!gy || !x || !mean || !rstd || !sums || rows <= 0) return LOANS_EINVAL;
     if (!reduce_channels_ok(C)) return LOANS_EINVAL;
     if (x2 && (!mean2 || !rstd2)) return LOANS_EINVAL;
@@ -328,12 +370,25 @@ extern "C" int loans_bn_bwd_reduce_f32(const float* gy, const float* mask, const
     const int grid = reduce_geometry(rows, C, &rpb, &c4b, &slabs);
     hipStream_t st = as_stream(stream);
 #define LAUNCH_RED(D, M) \
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<D, M>), dim3(grid, slabs), dim3(256), 0, st, gy, mask, x, mean, rstd, x2, mean2, rstd2, sums, rows, c4b, C / 4, rpb)
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<D, M, T>), dim3(grid, slabs), dim3(256), 0, st, gy, mask, x, mean, rstd, x2, mean2, rstd2, sums, rows, c4b, C / 4, rpb)
     if (x2) { if (mask) LAUNCH_RED(true, true); else LAUNCH_RED(true, false); }
     else { if (mask) LAUNCH_RED(false, true); else LAUNCH_RED(false, false); }
 #undef LAUNCH_RED
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;
+}
+
+extern "C" int loans_bn_bwd_reduce_f32(const float* gy, const float* mask, const float* x, const float* mean,
+                                       const float* rstd, const float* x2, const float* mean2, const float* rstd2,
+                                       double* sums, int64_t rows, int32_t C, void* stream) {
+    return bn_bwd_reduce_impl<float>(gy, mask, x, mean, rstd, x2, mean2, rstd2, sums, rows, C, stream);
+}
+
+extern "C" int loans_bn_bwd_reduce_bf16(const void* gy, const void* mask, const void* x, const float* mean,
+                                        const float* rstd, const void* x2, const float* mean2, const float* rstd2,
+                                        double* sums, int64_t rows, int32_t C, void* stream) {
+    return bn_bwd_reduce_impl<__bf16>(static_cast<const __bf16*>(gy), static_cast<const __bf16*>(mask), static_cast<const __bf16*>(x),
+                                      mean, rstd, static_cast<const __bf16*>(x2), mean2, rstd2, sums, rows, C, stream);
 }
 
 extern "C" int loans_bn_bwd_coeffs_f32(const double* sums, int32_t C, int64_t count, const float* gamma,
@@ -346,22 +401,39 @@ extern "C" int loans_bn_bwd_coeffs_f32(const double* sums, int32_t C, int64_t co
     return LOANS_OK;
 }
 
-extern "C" int loans_bn_bwd_apply_f32(const float* gy, const float* mask, const float* x, const float* k1,
-                                      const float* k2, const float* k3, float* gx, const float* x2, const float* k1b,
-                                      const float* k2b, const float* k3b, float* gx2, int64_t rows, int32_t C,
-                                      void* stream) {
+template <typename T>
+static int bn_bwd_apply_impl(const T* gy, const T* mask, const T* x, const float* k1,
+                             const float* k2, const float* k3, T* gx, const T* x2, const float* k1b,
+                             const float* k2b, const float* k3b, T* gx2, int64_t rows, int32_t C,
+                             void* stream) {
     if (!gy || !x || !k1 || !k2 || !k3 || !gx || rows <= 0 || C <= 0 || (C & 3)) return LOANS_EINVAL;
     if (x2 && (!k1b || !k2b || !k3b || !gx2)) return LOANS_EINVAL;
     const int64_t n4 = rows * (C / 4);
     const int grid = grid_for(n4, 256);
     hipStream_t st = as_stream(stream);
 #define LAUNCH_APP(D, M) \
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<D, M>), dim3(grid), dim3(256), 0, st, gy, mask, x, k1, k2, k3, gx, x2, k1b, k2b, k3b, gx2, n4, C / 4)
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<D, M, T>), dim3(grid), dim3(256), 0, st, gy, mask, x, k1, k2, k3, gx, x2, k1b, k2b, k3b, gx2, n4, C / 4)
     if (x2) { if (mask) LAUNCH_APP(true, true); else LAUNCH_APP(true, false); }
     else { if (mask) LAUNCH_APP(false, true); else LAUNCH_APP(false, false); }
 #undef LAUNCH_APP
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;
+}
+
+extern "C" int loans_bn_bwd_apply_f32(const float* gy, const float* mask, const float* x, const float* k1,
+                                      const float* k2, const float* k3, float* gx, const float* x2, const float* k1b,
+                                      const float* k2b, const float* k3b, float* gx2, int64_t rows, int32_t C,
+                                      void* stream) {
+    return bn_bwd_apply_impl<float>(gy, mask, x, k1, k2, k3, gx, x2, k1b, k2b, k3b, gx2, rows, C, stream);
+}
+
+extern "C" int loans_bn_bwd_apply_bf16(const void* gy, const void* mask, const void* x, const float* k1,
+                                       const float* k2, const float* k3, void* gx, const void* x2, const float* k1b,
+                                       const float* k2b, const float* k3b, void* gx2, int64_t rows, int32_t C,
+                                       void* stream) {
+    return bn_bwd_apply_impl<__bf16>(static_cast<const __bf16*>(gy), static_cast<const __bf16*>(mask), static_cast<const __bf16*>(x),
+                                     k1, k2, k3, static_cast<__bf16*>(gx), static_cast<const __bf16*>(x2), k1b, k2b, k3b,
+                                     static_cast<__bf16*>(gx2), rows, C, stream);
 }
 
 extern "C" int loans_colsum_f32(const float* x, float* out, int64_t rows, int32_t C, void* stream) {

@@ -7,6 +7,23 @@
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
+typedef __bf16 loans_bf16x4 __attribute__((ext_vector_type(4)));
+
+// four consecutive elements of an activation tensor as fp32, whatever its storage type (float: 16 bytes, bf16: 8)
+template <typename T> struct io4;
+template <> struct io4<float> {
+    static __device__ __forceinline__ f32x4 ld(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+    static __device__ __forceinline__ void st(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+};
+template <> struct io4<__bf16> {
+    static __device__ __forceinline__ f32x4 ld(const __bf16* p) {
+        return __builtin_convertvector(*reinterpret_cast<const loans_bf16x4*>(p), f32x4);
+    }
+    static __device__ __forceinline__ void st(__bf16* p, f32x4 v) {      // round to nearest even
+        *reinterpret_cast<loans_bf16x4*>(p) = __builtin_convertvector(v, loans_bf16x4);
+    }
+};
+
 #define LOANS_LAUNCH_CHECK()                         \
     do {                                             \
         hipError_t e__ = hipGetLastError();          \

@@ -1,0 +1,512 @@
+// Implicit-GEMM convolution on bf16 STORAGE (BASELINE configs 3 / 5): activations, gradients and weights are bf16
+// in HBM, the contraction runs on v_mfma_f32_32x32x16_bf16 with fp32 accumulation, BN statistics come from the
+// fp32 accumulators, the result is rounded to bf16 (RNE) once, in the epilogue.
+//
+//   out[m][n] = sum_k A[m][k] * Wp[n][k],   k = (tap, channel),   NHWC with C % 8 == 0
+//
+// A K chunk is 64 elements = eight 16-byte units (8 channels each) = one 128-byte LDS row per tile row.  The
+// operand tiles are staged by LDS-DMA (`buffer_load_dwordx4 ... lds`: 64 lanes x 16 B written contiguously, no
+// staging registers, no ds_write pass) into unpadded rows; bank conflicts are avoided by an XOR swizzle on the
+// SOURCE side (lane (row, slot) fetches unit slot ^ key(row), key = (row >> 1) & 7) that the fragment reads undo:
+// lane (r, h) of MFMA step s reads unit (2s + h) ^ key(r) as ONE ds_read_b128 = its eight k values.
+// Same problem descriptor, tap masks, XCD-aware tile order and epilogue flags as igemm.hip; forward convolution and
+// data gradient are the same kernel (dgrad: one launch per stride-parity class on re-packed weights).
+#include "common.h"
+
+namespace {
+
+constexpr int BKH = 64;                 // K elements per chunk (8 units of 16 bytes)
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+struct Igemm16Args {
+    const __bf16* in;
+    const __bf16* w;
+    __bf16* out;
+    const float* bias;
+    double* stats;
+    const __bf16* ref;
+    const __bf16* addend;
+    loans_igemm_desc d;
+    int M, Ktot, nchunks, tiles_m, tiles_n;
+    unsigned in_bytes, w_bytes, out_bytes;
+    struct {            // nx > 0: taps are an ny x nx grid, dy = dy0 + row*sdy, dx = dx0 + col*sdx, sd* = +-1
+        int nx, ny, dy0, sdy, dx0, sdx;
+        unsigned long long rowpat;
+    } ap;
+};
+
+__device__ __forceinline__ int xcd_remap16(int id, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, xcd = id & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+}
+
+__device__ __forceinline__ f32x4 cvt_lo(bf16x8_t v) {
+    return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
+}
+__device__ __forceinline__ f32x4 cvt_hi(bf16x8_t v) {
+    return f32x4{(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
+}
+
+template <int BM, int BN>
+constexpr size_t igemm16_aux_bytes() {      // offset of the tap table / row table behind the tiles
+    constexpr size_t stage = (size_t)2 * (BM + BN) * BKH * 2;
+    constexpr size_t cs = (size_t)BM * (BN + 4) * 4;          // fp32 epilogue staging tile
+    return stage > cs ? stage : cs;
+}
+template <int BM, int BN>
+constexpr size_t igemm16_lds_bytes() { return igemm16_aux_bytes<BM, BN>() + LOANS_MAX_TAPS * 4 + BM * 4; }
+
+template <int BM, int BN, int WM, int WN>
+__global__ __launch_bounds__(256) void igemm16_kernel(const Igemm16Args a) {
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int RA = BM / 32, RB = BN / 32;
+    constexpr int NMMA = TM * TN;              // MFMAs per 16-deep k step
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __bf16* As = reinterpret_cast<__bf16*>(smem);      // [2][BM][64]
+    __bf16* Bs = As + 2 * BM * BKH;                    // [2][BN][64]
+    int* taps = reinterpret_cast<int*>(smem + igemm16_aux_bytes<BM, BN>());
+    unsigned* opix = reinterpret_cast<unsigned*>(taps + LOANS_MAX_TAPS);   // [BM] output row byte offset, ~0u = no row
+
+    const loans_igemm_desc& d = a.d;
+    const int tid = threadIdx.x;
+    const int logical = xcd_remap16(blockIdx.x, gridDim.x);
+    const int tn = logical % a.tiles_n;
+    const int tm = logical / a.tiles_n;
+    const int lrow = tid >> 3;
+    const int lu = (tid & 7) ^ ((tid >> 4) & 7);       // K unit this thread stages: slot ^ key(row)
+    const int pbytes = d.Cin * 2;                       // bytes per gathered pixel
+    if (tid < LOANS_MAX_TAPS) {
+        const int t = tid < d.ntaps ? tid : 0;
+        taps[tid] = (int(d.dy[t]) * d.inW + int(d.dx[t])) * pbytes;
+    }
+
+    // per row: byte offset of its base pixel and the bitmask of taps that must read zero (see igemm.hip)
+    unsigned rowoff[RA];
+    unsigned long long badmask[RA];
+    {
+        const int gHW = d.gridH * d.gridW;
+        const float inv_gw = 1.f / (float)d.gridW, inv_gh = 1.f / (float)d.gridH;
+        const int m0 = tm * BM + lrow;
+        int b = m0 / gHW;
+        int rem = m0 - b * gHW;
+        int y = rem / d.gridW;
+        int x = rem - y * d.gridW;
+#pragma unroll
+        for (int i = 0; i < RA; ++i) {
+            const int m = m0 + 32 * i;
+            unsigned pixoff = 0xFFFFFFFFu;
+            unsigned long long mask = 0;
+            rowoff[i] = 0;
+            if (m < a.M) {
+                const int iy0 = y * d.isy, ix0 = x * d.isx;
+                rowoff[i] = (unsigned)((b * d.inH + iy0) * d.inW + ix0) * (unsigned)pbytes;
+                pixoff = (unsigned)((b * d.outH + y * d.osy + d.oy0) * d.outW + x * d.osx + d.ox0) * (unsigned)d.Cout * 2u;
+                if (a.ap.nx > 0) {
+                    const int cx = ix0 + a.ap.dx0, cy = iy0 + a.ap.dy0;
+                    int jlo, jhi, rlo, rhi;
+                    if (a.ap.sdx > 0) { jlo = max(0, -cx); jhi = min(a.ap.nx, d.inW - cx); }
+                    else { jlo = max(0, cx - d.inW + 1); jhi = min(a.ap.nx, cx + 1); }
+                    if (a.ap.sdy > 0) { rlo = max(0, -cy); rhi = min(a.ap.ny, d.inH - cy); }
+                    else { rlo = max(0, cy - d.inH + 1); rhi = min(a.ap.ny, cy + 1); }
+                    if (jhi > jlo && rhi > rlo) {
+                        const unsigned long long colbits = ((1ull << jhi) - 1ull) & ~((1ull << jlo) - 1ull);
+                        const int blo = rlo * a.ap.nx, bhi = rhi * a.ap.nx;
+                        const unsigned long long below_hi = bhi >= 64 ? ~0ull : ((1ull << bhi) - 1ull);
+                        const unsigned long long rowsel = a.ap.rowpat & below_hi & ~((1ull << blo) - 1ull);
+                        mask = colbits * rowsel;
+                    }
+                } else {
+                    for (int t = 0; t < d.ntaps; ++t) {
+                        const int iy = iy0 + d.dy[t], ix = ix0 + d.dx[t];
+                        if ((unsigned)iy < (unsigned)d.inH && (unsigned)ix < (unsigned)d.inW) mask |= 1ull << t;
+                    }
+                }
+            }
+            badmask[i] = ~mask;
+            if (lu == 0) opix[lrow + 32 * i] = pixoff;
+            x += 32;
+            const int qx = (int)(((float)x + 0.5f) * inv_gw);
+            x -= qx * d.gridW;
+            y += qx;
+            const int qy = (int)(((float)y + 0.5f) * inv_gh);
+            y -= qy * d.gridH;
+            b += qy;
+        }
+    }
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.in), 0, (int)a.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.w), 0, (int)a.w_bytes, 0x00020000);
+
+    const int cpt = d.Cin >> 3;   // 16-byte units per tap
+    const int q8 = 8 / cpt, r8 = 8 - q8 * cpt;
+    const int kunits = a.Ktot >> 3;
+    int u = lu;                   // this thread's K unit in the chunk being loaded
+    int tap = lu / cpt, c8 = lu - tap * cpt;
+    unsigned woff[RB], wbad[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const int n = tn * BN + lrow + 32 * i;
+        wbad[i] = n < d.Cout ? 0u : 0xFFFFFFFFu;
+        woff[i] = n < d.Cout ? (unsigned)n * (unsigned)a.Ktot * 2u : 0u;
+    }
+    unsigned toff = (unsigned)taps[min(tap, LOANS_MAX_TAPS - 1)] + (unsigned)c8 * 16u;
+
+    const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    auto dma_a = [&](int buf, int i) {      // one 1 KiB LDS-DMA piece: 8 rows x 128 B of the A tile
+        const int tc = min(tap, LOANS_MAX_TAPS - 1);
+        const unsigned kbad = (unsigned)(u < kunits) - 1u;
+        const unsigned bad = 0u - ((unsigned)(badmask[i] >> tc) & 1u);
+        const unsigned off = (rowoff[i] + toff) | bad | kbad;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(As + (buf * BM + 32 * i + 8 * wave_u) * BKH), 16, (int)off, 0, 0, 0);
+    };
+    auto dma_b = [&](int buf, int i) {
+        const unsigned kbad = (unsigned)(u < kunits) - 1u;
+        const unsigned off = (woff[i] + (unsigned)u * 16u) | wbad[i] | kbad;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(Bs + (buf * BN + 32 * i + 8 * wave_u) * BKH), 16, (int)off, 0, 0, 0);
+    };
+    auto advance = [&]() {      // to the following chunk (8 units further along K)
+        u += 8;
+        tap += q8;
+        c8 += r8;
+        const int wrap = c8 >= cpt;
+        c8 -= wrap ? cpt : 0;
+        tap += wrap;
+        toff = (unsigned)taps[min(tap, LOANS_MAX_TAPS - 1)] + (unsigned)c8 * 16u;
+    };
+    constexpr int NPIECE = RA + RB + 1;
+    auto dma_piece = [&](int buf, int p) {
+        if (p < RA) dma_a(buf, p);
+        else if (p < RA + RB) dma_b(buf, p - RA);
+        else if (p == RA + RB) advance();
+    };
+
+    const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wm = wave / WN, wn = wave % WN;
+    const int fkey = (r >> 1) & 7;
+    const int fragA = (wm * TM * 32 + r) * BKH + ((h ^ fkey) & 7) * 8;
+    const int fragB = (wn * TN * 32 + r) * BKH + ((h ^ fkey) & 7) * 8;
+    auto read_frag = [&](int buf, int s, bf16x8_t (&af)[TM], bf16x8_t (&bf)[TN]) {
+        const __bf16* Ab = As + buf * BM * BKH + (fragA ^ (s * 16));
+        const __bf16* Bb = Bs + buf * BN * BKH + (fragB ^ (s * 16));
+#pragma unroll
+        for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8_t*>(Ab + i * 32 * BKH);
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const bf16x8_t*>(Bb + j * 32 * BKH);
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    auto mma_one = [&](int q, const bf16x8_t (&af)[TM], const bf16x8_t (&bf)[TN]) {
+        const int i = q / TN, j = q % TN;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    };
+    auto mma = [&](const bf16x8_t (&af)[TM], const bf16x8_t (&bf)[TN]) {
+#pragma unroll
+        for (int q = 0; q < NMMA; ++q) mma_one(q, af, bf);
+    };
+
+    // ---- K loop: a chunk = four 16-deep steps; the DMA pieces of chunk c+1 ride behind the MFMAs of steps 0 and 1
+    // of chunk c into the other LDS stage (free since the barrier that ended chunk c-1), fragments of step s+1 are read
+    // while step s computes, __syncthreads() drains the DMA (vmcnt(0)) and step 3's MFMAs run behind the barrier.
+    constexpr int PPG = (NPIECE + 2 * NMMA - 1) / (2 * NMMA);      // pieces per MFMA gap
+    bf16x8_t fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+#pragma unroll
+    for (int p = 0; p < NPIECE; ++p) dma_piece(0, p);
+    __syncthreads();
+    read_frag(0, 0, fa0, fb0);
+    int c = 0;
+    for (; c + 1 < a.nchunks; ++c) {
+        const int buf = c & 1;
+        read_frag(buf, 1, fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < NMMA; ++q) {
+            mma_one(q, fa0, fb0);
+#pragma unroll
+            for (int p = q * PPG; p < (q + 1) * PPG; ++p) dma_piece(buf ^ 1, p);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        read_frag(buf, 2, fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < NMMA; ++q) {
+            mma_one(q, fa1, fb1);
+#pragma unroll
+            for (int p = (NMMA + q) * PPG; p < (NMMA + q + 1) * PPG; ++p) dma_piece(buf ^ 1, p);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        read_frag(buf, 3, fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        __syncthreads();
+        read_frag(buf ^ 1, 0, fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    {   // last chunk: steps that lie wholly beyond Ktot hold zeros on both sides and are skipped
+        const int buf = c & 1;
+        const int ts = (a.Ktot - (a.nchunks - 1) * BKH + 15) / 16;      // 1..4
+        if (ts > 1) read_frag(buf, 1, fa1, fb1);
+        mma(fa0, fb0);
+        if (ts > 1) {
+            if (ts > 2) read_frag(buf, 2, fa0, fb0);
+            mma(fa1, fb1);
+            if (ts > 2) {
+                if (ts > 3) read_frag(buf, 3, fa1, fb1);
+                mma(fa0, fb0);
+                if (ts > 3) mma(fa1, fb1);
+            }
+        }
+    }
+
+    // ---- epilogue: BN statistics from the fp32 accumulators, tile staged through LDS (fp32) so that every lane
+    // converts and stores 8 contiguous channels (16 bytes of bf16)
+    const bool f_bias = d.flags & LOANS_F_BIAS, f_stats = d.flags & LOANS_F_STATS;
+    const bool f_mask = d.flags & LOANS_F_MASK, f_add = d.flags & LOANS_F_ADDEND;
+    const bool f_addmask = d.flags & LOANS_F_ADDEND_MASK;
+    constexpr int LDC = BN + 4;
+    float* Cs = reinterpret_cast<float*>(smem);          // [BM][LDC]
+    __syncthreads();
+    if (f_stats) {
+        int nvalid = 0;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                nvalid += opix[wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h] != 0xFFFFFFFFu;
+        const float cnt = (float)nvalid;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = tn * BN + wn * TN * 32 + j * 32 + r;
+            const bool cok = col < d.Cout;
+            const float bv = (f_bias && cok) ? a.bias[col] : 0.f;
+            float s = 0.f, q2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    s += acc[i][j][e];
+                    q2 += acc[i][j][e] * acc[i][j][e];
+                }
+            q2 = q2 + 2.f * bv * s + cnt * bv * bv;
+            s = s + cnt * bv;
+            s += __shfl_xor(s, 32, 64);
+            q2 += __shfl_xor(q2, 32, 64);
+            if (h == 0 && cok) {
+                double* st = a.stats + (size_t)(blockIdx.x % LOANS_STATS_REPLICAS) * 2 * d.Cout;
+                atomic_add_f64(st + col, (double)s);
+                atomic_add_f64(st + d.Cout + col, (double)q2);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                Cs[(wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * LDC + wn * TN * 32 + j * 32 + r] = acc[i][j][e];
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)a.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_ref = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<__bf16*>(a.ref ? a.ref : a.out), 0, (int)a.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_add = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<__bf16*>(a.addend ? a.addend : a.out), 0, (int)a.out_bytes, 0x00020000);
+    constexpr int CPR = BN / 8;                 // 8-channel units per row
+    constexpr int RSTEP = 256 / CPR;            // rows covered by the block per pass
+    const int oc8 = tid % CPR, r0 = tid / CPR;
+    const int col0 = tn * BN + oc8 * 8;
+    const unsigned cbad = (col0 + 7 < d.Cout) ? 0u : 0xFFFFFFFFu;     // Cout % 8 == 0 (checked)
+    const unsigned coff = (unsigned)col0 * 2u;
+    f32x4 b_lo = {0.f, 0.f, 0.f, 0.f}, b_hi = b_lo;
+    if (f_bias && !cbad) {
+        b_lo = *reinterpret_cast<const f32x4*>(a.bias + col0);
+        b_hi = *reinterpret_cast<const f32x4*>(a.bias + col0 + 4);
+    }
+    auto keep_pos = [](f32x4 v, f32x4 m) {
+        v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
+        v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+        return v;
+    };
+#pragma unroll
+    for (int p = 0; p < BM / RSTEP; ++p) {
+        const int row = r0 + p * RSTEP;
+        const unsigned po = opix[row];
+        const unsigned off = (po + coff) | (po == 0xFFFFFFFFu ? 0xFFFFFFFFu : 0u) | cbad;
+        f32x4 lo = *reinterpret_cast<const f32x4*>(Cs + row * LDC + oc8 * 8) + b_lo;
+        f32x4 hi = *reinterpret_cast<const f32x4*>(Cs + row * LDC + oc8 * 8 + 4) + b_hi;
+        if (f_mask || f_addmask) {
+            const bf16x8_t rf = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_ref, (int)off, 0, 0));
+            const f32x4 rl = cvt_lo(rf), rh = cvt_hi(rf);
+            if (f_mask) { lo = keep_pos(lo, rl); hi = keep_pos(hi, rh); }
+            if (f_add) {
+                const bf16x8_t ad = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_add, (int)off, 0, 0));
+                f32x4 al = cvt_lo(ad), ah = cvt_hi(ad);
+                if (f_addmask) { al = keep_pos(al, rl); ah = keep_pos(ah, rh); }
+                lo += al; hi += ah;
+            }
+        } else if (f_add) {
+            const bf16x8_t ad = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_add, (int)off, 0, 0));
+            lo += cvt_lo(ad); hi += cvt_hi(ad);
+        }
+        bf16x8_t o;
+        const bf16x4_t ol = __builtin_convertvector(lo, bf16x4_t), oh = __builtin_convertvector(hi, bf16x4_t);
+        o[0] = ol[0]; o[1] = ol[1]; o[2] = ol[2]; o[3] = ol[3];
+        o[4] = oh[0]; o[5] = oh[1]; o[6] = oh[2]; o[7] = oh[3];
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_out, (int)off, 0, 0);
+    }
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_igemm16(Igemm16Args& a, hipStream_t st) {
+    static bool attr_set = false;
+    constexpr size_t lds = igemm16_lds_bytes<BM, BN>();
+    static_assert(lds <= 160 * 1024, "tile does not fit the LDS");
+    auto kern = igemm16_kernel<BM, BN, WM, WN>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    a.tiles_m = (a.M + BM - 1) / BM;
+    a.tiles_n = (a.d.Cout + BN - 1) / BN;
+    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(256), lds, st, a);
+    LOANS_LAUNCH_CHECK();
+    return LOANS_OK;
+}
+
+void detect_tap_grid16(const loans_igemm_desc* d, Igemm16Args& a) {
+    a.ap.nx = 0; a.ap.ny = 0; a.ap.dy0 = a.ap.dx0 = 0; a.ap.sdy = a.ap.sdx = 1; a.ap.rowpat = 0;
+    int nx = 1;
+    while (nx < d->ntaps && d->dy[nx] == d->dy[0]) ++nx;
+    if (d->ntaps % nx) return;
+    const int ny = d->ntaps / nx;
+    const int sdx = nx > 1 ? d->dx[1] - d->dx[0] : 1;
+    const int sdy = ny > 1 ? d->dy[nx] - d->dy[0] : 1;
+    if ((sdx != 1 && sdx != -1) || (sdy != 1 && sdy != -1)) return;
+    for (int t = 0; t < d->ntaps; ++t)
+        if (d->dy[t] != d->dy[0] + (t / nx) * sdy || d->dx[t] != d->dx[0] + (t % nx) * sdx) return;
+    a.ap.nx = nx; a.ap.ny = ny; a.ap.dy0 = d->dy[0]; a.ap.sdy = sdy; a.ap.dx0 = d->dx[0]; a.ap.sdx = sdx;
+    for (int r = 0; r < ny; ++r) a.ap.rowpat |= 1ull << (r * nx);
+}
+
+// fp32 -> bf16 (RNE), n a multiple of 4; dst[co][tapsel..] re-pack variant below
+__global__ __launch_bounds__(256) void cast_bf16_kernel(const float* src, __bf16* dst, int64_t n4) {
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x)
+        *reinterpret_cast<bf16x4_t*>(dst + i * 4) = __builtin_convertvector(*reinterpret_cast<const f32x4*>(src + i * 4), bf16x4_t);
+}
+
+struct Repack16Args {
+    const float* src;
+    __bf16* dst;
+    int Cout, Cin, src_taps, ntaps;
+    int tapsel[LOANS_MAX_TAPS];
+};
+
+// dst[ci][t][co] = bf16(src[co][tapsel[t]][ci]) through a 32x33 LDS tile (both sides coalesced)
+__global__ __launch_bounds__(256) void repack_dgrad16_kernel(const Repack16Args a) {
+    __shared__ float tile[32][33];
+    const int t = blockIdx.z;
+    const int co0 = blockIdx.x * 32, ci0 = blockIdx.y * 32;
+    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+    const int st = a.tapsel[t];
+    for (int k = ty; k < 32; k += 8) {
+        const int co = co0 + k, ci = ci0 + tx;
+        tile[k][tx] = (co < a.Cout && ci < a.Cin) ? a.src[((int64_t)co * a.src_taps + st) * a.Cin + ci] : 0.f;
+    }
+    __syncthreads();
+    for (int k = ty; k < 32; k += 8) {
+        const int ci = ci0 + k, co = co0 + tx;
+        if (ci < a.Cin && co < a.Cout) a.dst[((int64_t)ci * a.ntaps + t) * a.Cout + co] = (__bf16)tile[tx][k];
+    }
+}
+
+}  // namespace
+
+extern "C" int loans_igemm_bf16s(const void* in, const void* w, void* out, const float* bias, double* stats,
+                                 const void* ref, const void* addend, const loans_igemm_desc* d, void* stream) {
+    if (!d || !in || !w || !out) return LOANS_EINVAL;
+    if (d->B <= 0 || d->inH <= 0 || d->inW <= 0 || d->Cin <= 0 || (d->Cin & 7)) return LOANS_EINVAL;
+    if (d->outH <= 0 || d->outW <= 0 || d->Cout <= 0 || (d->Cout & 7)) return LOANS_EINVAL;
+    if (d->gridH <= 0 || d->gridW <= 0 || d->osy <= 0 || d->osx <= 0 || d->isy <= 0 || d->isx <= 0) return LOANS_EINVAL;
+    if (d->oy0 < 0 || d->ox0 < 0) return LOANS_EINVAL;
+    if ((d->gridH - 1) * d->osy + d->oy0 >= d->outH) return LOANS_EINVAL;
+    if ((d->gridW - 1) * d->osx + d->ox0 >= d->outW) return LOANS_EINVAL;
+    if (d->ntaps < 1 || d->ntaps > LOANS_MAX_TAPS) return LOANS_EINVAL;
+    if (d->flags & (LOANS_F_DENSE | LOANS_F_RELU_IN)) return LOANS_EINVAL;       // fp32-storage layers only
+    if ((d->flags & LOANS_F_BIAS) && !bias) return LOANS_EINVAL;
+    if ((d->flags & LOANS_F_STATS) && !stats) return LOANS_EINVAL;
+    if ((d->flags & (LOANS_F_MASK | LOANS_F_ADDEND_MASK)) && !ref) return LOANS_EINVAL;
+    if ((d->flags & LOANS_F_ADDEND_MASK) && !(d->flags & LOANS_F_ADDEND)) return LOANS_EINVAL;
+    if ((d->flags & LOANS_F_ADDEND) && !addend) return LOANS_EINVAL;
+    const int64_t lim = (int64_t)1 << 31;
+    if ((int64_t)d->B * d->gridH * d->gridW >= lim) return LOANS_ERANGE;
+    Igemm16Args a;
+    a.in = static_cast<const __bf16*>(in); a.w = static_cast<const __bf16*>(w); a.out = static_cast<__bf16*>(out);
+    a.bias = bias; a.stats = stats;
+    a.ref = static_cast<const __bf16*>(ref); a.addend = static_cast<const __bf16*>(addend);
+    a.d = *d;
+    a.M = d->B * d->gridH * d->gridW;
+    a.Ktot = d->ntaps * d->Cin;
+    a.nchunks = (a.Ktot + BKH - 1) / BKH;
+    {
+        const int64_t ib = (int64_t)d->B * d->inH * d->inW * d->Cin * 2;
+        const int64_t wb = (int64_t)d->Cout * a.Ktot * 2;
+        const int64_t ob = (int64_t)d->B * d->outH * d->outW * d->Cout * 2;
+        if (ib >= 0xFFFFFFF0ll || wb >= 0xFFFFFFF0ll || ob >= 0xFFFFFFF0ll) return LOANS_ERANGE;   // 32-bit buffer offsets
+        a.in_bytes = (unsigned)ib; a.w_bytes = (unsigned)wb; a.out_bytes = (unsigned)ob;
+    }
+    detect_tap_grid16(d, a);
+    hipStream_t st = as_stream(stream);
+    int tile = d->tile;
+    if (tile == 0) {
+        const int64_t big = (int64_t)((a.M + 127) / 128) * ((d->Cout + 127) / 128);
+        tile = d->Cout <= 64 ? LOANS_TILE_128x64 : (big >= 512 ? LOANS_TILE_128x128 : LOANS_TILE_64x64);
+    }
+    switch (tile) {
+        case LOANS_TILE_128x128: return launch_igemm16<128, 128, 2, 2>(a, st);
+        case LOANS_TILE_128x64: return launch_igemm16<128, 64, 2, 2>(a, st);
+        case LOANS_TILE_64x64: return launch_igemm16<64, 64, 2, 2>(a, st);
+        case LOANS_TILE_256x64: return launch_igemm16<256, 64, 4, 1>(a, st);
+        case LOANS_TILE_256x128: return launch_igemm16<256, 128, 2, 2>(a, st);
+        default: return LOANS_EINVAL;
+    }
+}
+
+extern "C" int loans_cast_bf16(const float* src, void* dst, int64_t n, void* stream) {
+    if (!src || !dst || n <= 0 || (n & 3)) return LOANS_EINVAL;
+    hipLaunchKernelGGL(cast_bf16_kernel, dim3(grid_for(n / 4, 256)), dim3(256), 0, as_stream(stream), src,
+                       static_cast<__bf16*>(dst), n / 4);
+    LOANS_LAUNCH_CHECK();
+    return LOANS_OK;
+}
+
+extern "C" int loans_repack_dgrad_bf16(const float* src, void* dst, int32_t Cout, int32_t Cin, int32_t src_taps,
+                                       const int32_t* tapsel_host, int32_t ntaps, void* stream) {
+    if (!src || !dst || !tapsel_host || Cout <= 0 || Cin <= 0 || src_taps <= 0) return LOANS_EINVAL;
+    if (ntaps < 1 || ntaps > LOANS_MAX_TAPS) return LOANS_EINVAL;
+    Repack16Args a;
+    a.src = src; a.dst = static_cast<__bf16*>(dst); a.Cout = Cout; a.Cin = Cin; a.src_taps = src_taps; a.ntaps = ntaps;
+    for (int i = 0; i < ntaps; ++i) {
+        if (tapsel_host[i] < 0 || tapsel_host[i] >= src_taps) return LOANS_EINVAL;
+        a.tapsel[i] = tapsel_host[i];
+    }
+    dim3 grid((Cout + 31) / 32, (Cin + 31) / 32, ntaps);
+    hipLaunchKernelGGL(repack_dgrad16_kernel, grid, dim3(256), 0, as_stream(stream), a);
+    LOANS_LAUNCH_CHECK();
+    return LOANS_OK;
+}

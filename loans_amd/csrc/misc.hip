@@ -66,23 +66,25 @@ __global__ __launch_bounds__(256) void nchw3_to_nhwc4_kernel(const float* in, fl
 }
 
 // ---- global average pooling ----------------------------------------------------------------
-__global__ __launch_bounds__(256) void gap_fwd_kernel(const float* x, float* y, int B, int HW, int C4) {
+template <typename T>
+__global__ __launch_bounds__(256) void gap_fwd_kernel(const T* x, float* y, int B, int HW, int C4) {
     const int64_t total = (int64_t)B * C4;
     const float inv = 1.f / (float)HW;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t b = i / C4, c = i - b * C4;
         f32x4 s = {0.f, 0.f, 0.f, 0.f};
-        for (int p = 0; p < HW; ++p) s += ld4(x + ((b * HW + p) * C4 + c) * 4);
+        for (int p = 0; p < HW; ++p) s += io4<T>::ld(x + ((b * HW + p) * C4 + c) * 4);
         st4(y + i * 4, s * inv);
     }
 }
 
-__global__ __launch_bounds__(256) void gap_bwd_kernel(const float* gy, float* gx, int B, int HW, int C4) {
+template <typename T>
+__global__ __launch_bounds__(256) void gap_bwd_kernel(const float* gy, T* gx, int B, int HW, int C4) {
     const int64_t total = (int64_t)B * HW * C4;
     const float inv = 1.f / (float)HW;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
         const int64_t c = i % C4, b = i / ((int64_t)HW * C4);
-        st4(gx + i * 4, ld4(gy + (b * C4 + c) * 4) * inv);
+        io4<T>::st(gx + i * 4, ld4(gy + (b * C4 + c) * 4) * inv);
     }
 }
 
@@ -444,14 +446,30 @@ extern "C" int loans_nchw3_to_nhwc4_f32(const float* in, float* out, int32_t B, 
 
 extern "C" int loans_gap_fwd_f32(const float* x, float* y, int32_t B, int32_t HW, int32_t C, void* stream) {
     if (!x || !y || B <= 0 || HW <= 0 || C <= 0 || (C & 3)) return LOANS_EINVAL;
-    hipLaunchKernelGGL(gap_fwd_kernel, dim3(grid_for((int64_t)B * (C / 4), 256)), dim3(256), 0, as_stream(stream), x, y, B, HW, C / 4);
+    hipLaunchKernelGGL(gap_fwd_kernel<float>, dim3(grid_for((int64_t)B * (C / 4), 256)), dim3(256), 0, as_stream(stream), x, y, B, HW, C / 4);
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;
 }
 
 extern "C" int loans_gap_bwd_f32(const float* gy, float* gx, int32_t B, int32_t HW, int32_t C, void* stream) {
     if (!gy || !gx || B <= 0 || HW <= 0 || C <= 0 || (C & 3)) return LOANS_EINVAL;
-    hipLaunchKernelGGL(gap_bwd_kernel, dim3(grid_for((int64_t)B * HW * (C / 4), 256)), dim3(256), 0, as_stream(stream), gy, gx, B, HW, C / 4);
+    hipLaunchKernelGGL(gap_bwd_kernel<float>, dim3(grid_for((int64_t)B * HW * (C / 4), 256)), dim3(256), 0, as_stream(stream), gy, gx, B, HW, C / 4);
+    LOANS_LAUNCH_CHECK();
+    return LOANS_OK;
+}
+
+extern "C" int loans_gap_fwd_bf16_f32(const void* x, float* y, int32_t B, int32_t HW, int32_t C, void* stream) {
+    if (!x || !y || B <= 0 || HW <= 0 || C <= 0 || (C & 3)) return LOANS_EINVAL;
+    hipLaunchKernelGGL(gap_fwd_kernel<__bf16>, dim3(grid_for((int64_t)B * (C / 4), 256)), dim3(256), 0, as_stream(stream),
+                       static_cast<const __bf16*>(x), y, B, HW, C / 4);
+    LOANS_LAUNCH_CHECK();
+    return LOANS_OK;
+}
+
+extern "C" int loans_gap_bwd_f32_bf16(const float* gy, void* gx, int32_t B, int32_t HW, int32_t C, void* stream) {
+    if (!gy || !gx || B <= 0 || HW <= 0 || C <= 0 || (C & 3)) return LOANS_EINVAL;
+    hipLaunchKernelGGL(gap_bwd_kernel<__bf16>, dim3(grid_for((int64_t)B * HW * (C / 4), 256)), dim3(256), 0, as_stream(stream),
+                       gy, static_cast<__bf16*>(gx), B, HW, C / 4);
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;
 }

@@ -13,11 +13,11 @@ class GlobalAveragePooling2D(Function):
     """x: NHWC (B,H,W,C) -> (B,C)."""
 
     def forward(self, inputs):
-        self.shape = tuple(inputs[0].shape)
+        self.shape, self.dtype = tuple(inputs[0].shape), inputs[0].dtype
         return ops.gap_fwd(inputs[0])
 
     def backward(self, inputs, gys):
-        return ops.gap_bwd(gys[0].contiguous(), self.shape)
+        return ops.gap_bwd(gys[0].contiguous(), self.shape, self.dtype)
 
 
 def global_average_pooling_2d(x):

@@ -20,11 +20,41 @@ from ._lib import (F_ADDEND, F_ADDEND_MASK, F_BIAS, F_DENSE, F_MASK, F_RELU_IN, 
 COMPUTE = os.environ.get('LOANS_COMPUTE', 'f32')
 
 
+# Storage of the activations / gradients inside the localizer's residual stages: 'f32', or 'bf16' (needs COMPUTE ==
+# 'bf16'): the stem's pool then writes bf16, every conv / BN pass of the stages reads and writes bf16 (their wrappers
+# below dispatch on the tensor's dtype) and the pooled features return to fp32.  Parameters, their gradients
+# ("fp32 grad accumulate"), BN statistics and the assessor stay fp32.
+STORAGE = os.environ.get('LOANS_STORAGE', 'f32')
+BF16 = torch.bfloat16
+
+
 def set_compute_dtype(name):
-    global COMPUTE
+    global COMPUTE, STORAGE
     if name not in ('f32', 'bf16'):
         raise ValueError("compute dtype must be 'f32' or 'bf16'")
     COMPUTE = name
+    if name == 'f32':
+        STORAGE = 'f32'
+
+
+def set_storage_dtype(name):
+    global STORAGE
+    if name not in ('f32', 'bf16'):
+        raise ValueError("storage dtype must be 'f32' or 'bf16'")
+    if name == 'bf16' and COMPUTE != 'bf16':
+        raise ValueError("bf16 storage needs set_compute_dtype('bf16') first")
+    STORAGE = name
+
+
+def _is16(t):
+    return t is not None and t.dtype == BF16
+
+
+def cast_bf16(w):
+    """bf16 operand copy of an fp32 parameter tensor (weights change every step: made per use, ~microseconds)."""
+    out = torch.empty(w.shape, device=w.device, dtype=BF16)
+    check(_lib.load().loans_cast_bf16(_ptr(w), _ptr(out), w.numel(), _stream()), 'loans_cast_bf16')
+    return out
 
 
 def _igemm_fn(lib):
@@ -194,6 +224,7 @@ AUTOTUNE = os.environ.get('LOANS_AUTOTUNE', '1') != '0'
 _FPROP_TILES = tuple(int(t) for t in os.environ.get('LOANS_FPROP_TILES', '1,2,3,4,6,17,18,19,20,22').split(','))
 _IGEMM_TILES = tuple(int(t) for t in os.environ.get('LOANS_DGRAD_TILES', '1,2,3,17,18,19').split(','))
 _WGRAD_TILES = (1, 3, 5)
+_IGEMM16_TILES = tuple(int(t) for t in os.environ.get('LOANS_BF16S_TILES', '1,2,3,4,7').split(','))
 
 
 def _time_call(fn, reps=5):
@@ -243,6 +274,8 @@ def _igemm_launches(M, Cout, tile, device):
 def conv_fprop(x, w, geo, out=None, bias=None, stats=None, relu_in=False, addend=None, tile=0):
     """out[B,Ho,Wo,Cout] = conv(x[B,H,W,Cin], w[Cout,k,k,Cin]) (+bias) (+addend); optional BN statistics."""
     lib = _lib.load()
+    if _is16(x):
+        return _conv_fprop16(lib, x, w, geo, out, bias, stats, relu_in, addend, tile)
     if out is None:
         out = torch.empty((geo.B, geo.Ho, geo.Wo, geo.Cout), device=x.device, dtype=torch.float32)
     flags = (F_RELU_IN if relu_in else 0) | (F_BIAS if bias is not None else 0) | \
@@ -273,13 +306,82 @@ def conv_fprop(x, w, geo, out=None, bias=None, stats=None, relu_in=False, addend
     return out
 
 
+def _conv_fprop16(lib, x, w, geo, out, bias, stats, relu_in, addend, tile):
+    """bf16-storage forward conv: x / out / addend bf16, w fp32 master weights (cast per call) or already bf16."""
+    assert not relu_in and not geo.dense
+    if out is None:
+        out = torch.empty((geo.B, geo.Ho, geo.Wo, geo.Cout), device=x.device, dtype=BF16)
+    assert out.dtype == BF16 and (addend is None or addend.dtype == BF16)
+    assert x.numel() == geo.in_numel and w.numel() == geo.w_numel
+    w16 = w if _is16(w) else cast_bf16(w)
+    flags = (F_BIAS if bias is not None else 0) | (F_STATS if stats is not None else 0) | (F_ADDEND if addend is not None else 0)
+    if tile == 0:
+        tflags = flags & F_STATS
+        sstats = stats_buffer(geo.Cout, x.device) if stats is not None else None
+
+        def run(t):
+            scratch = torch.empty((geo.B, geo.Ho, geo.Wo, geo.Cout), device=x.device, dtype=BF16)
+            check(lib.loans_igemm_bf16s(_ptr(x), _ptr(w16), _ptr(scratch), 0, _ptr(sstats), 0, 0,
+                                        C.byref(_with_flags(geo.fwd, tflags, t)), _stream()), 'loans_igemm_bf16s[tune]')
+        tile = _tuned_tile(geo, 'bf16s_fprop' + ('_stats' if stats is not None else ''), run, _IGEMM16_TILES)
+    d = _with_flags(geo.fwd, flags, tile)
+    log = EVENT_LOG
+    if log is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(lib.loans_igemm_bf16s(_ptr(x), _ptr(w16), _ptr(out), _ptr(bias), _ptr(stats), 0, _ptr(addend),
+                                C.byref(d), _stream()), 'loans_igemm_bf16s[fprop]')
+    if log is not None:
+        ev1.record()
+        log.append(('fprop_bn' if stats is not None else 'fprop',
+                    2 * geo.B * geo.Ho * geo.Wo * geo.Cout * geo.k * geo.k * geo.cin_logical, ev0, ev1, 1))
+    return out
+
+
+def _conv_dgrad16(lib, gy, w, geo, out, mask_ref, addend, addend_mask_ref, tile):
+    if out is None:
+        out = torch.empty((geo.B, geo.H, geo.W, geo.Cin), device=gy.device, dtype=BF16)
+    assert out.dtype == BF16 and not _is16(w)
+    if geo.dgrad_has_empty_class:
+        assert mask_ref is None and addend_mask_ref is None
+        if addend is None:
+            out.zero_()
+        elif addend.data_ptr() != out.data_ptr():
+            out.copy_(addend)
+        if addend is not None:
+            addend = out
+    wp = torch.empty(geo.dgrad_weight_floats, device=gy.device, dtype=BF16)
+    flags = (F_MASK if mask_ref is not None else 0) | (F_ADDEND if addend is not None else 0) | \
+            (F_ADDEND_MASK if addend_mask_ref is not None else 0)
+    ref = mask_ref if mask_ref is not None else addend_mask_ref
+    assert not (mask_ref is not None and addend_mask_ref is not None)
+    st = _stream()
+    for d, tapsel, off in geo.dgrad:
+        check(lib.loans_repack_dgrad_bf16(_ptr(w), _ptr(wp[off:]), geo.Cout, geo.Cin, geo.k * geo.k, tapsel,
+                                          d.ntaps, st), 'loans_repack_dgrad_bf16')
+    if tile == 0:
+        def run(t):
+            scratch = torch.empty((geo.B, geo.H, geo.W, geo.Cin), device=gy.device, dtype=BF16)
+            for d, _, off in geo.dgrad:
+                check(lib.loans_igemm_bf16s(_ptr(gy), _ptr(wp[off:]), _ptr(scratch), 0, 0, 0, 0,
+                                            C.byref(_with_flags(d, 0, t)), st), 'loans_igemm_bf16s[tune]')
+        tile = _tuned_tile(geo, 'bf16s_dgrad', run, _IGEMM16_TILES)
+    for d, tapsel, off in geo.dgrad:
+        _with_flags(d, flags, tile)
+        check(lib.loans_igemm_bf16s(_ptr(gy), _ptr(wp[off:]), _ptr(out), 0, 0, _ptr(ref), _ptr(addend),
+                                    C.byref(d), st), 'loans_igemm_bf16s[dgrad]')
+    return out
+
+
 def conv_dgrad(gy, w, geo, out=None, mask_ref=None, addend=None, addend_mask_ref=None, tile=0):
     """gx[B,H,W,Cin] = conv_transpose(gy, w); epilogue: (* (mask_ref>0)), (+ addend [masked by addend_mask_ref>0]).
     Re-packs w per stride-parity class first (weights change every step)."""
     lib = _lib.load()
+    assert gy.numel() == geo.B * geo.Ho * geo.Wo * geo.Cout
+    if _is16(gy):
+        return _conv_dgrad16(lib, gy, w, geo, out, mask_ref, addend, addend_mask_ref, tile)
     if out is None:
         out = torch.empty((geo.B, geo.H, geo.W, geo.Cin), device=gy.device, dtype=torch.float32)
-    assert gy.numel() == geo.B * geo.Ho * geo.Wo * geo.Cout
     if geo.dgrad_has_empty_class:
         # pixels of a tap-less stride class receive only the addend (or zero)
         assert mask_ref is None and addend_mask_ref is None
@@ -346,7 +448,8 @@ def join_side_stream(device=None):
 
 def conv_wgrad(x, gy, dw, geo, relu_in=False, splits=0, tile=0):
     """dw[Cout,k,k,Cin] += sum over pixels (atomic accumulate into the gradient arena)."""
-    if ASYNC_WGRAD and geo.tuned.get(COMPUTE + 'wgrad') is not None and not torch.cuda.is_current_stream_capturing():
+    if ASYNC_WGRAD and geo.tuned.get(('bf16s_' if _is16(x) else COMPUTE) + 'wgrad') is not None \
+            and not torch.cuda.is_current_stream_capturing():
         side = _side_stream(x.device)
         side.wait_stream(torch.cuda.current_stream(x.device))
         x.record_stream(side)
@@ -362,13 +465,15 @@ def _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile):
     lib = _lib.load()
     assert dw.numel() == geo.w_numel and x.numel() == geo.in_numel
     fl = (F_RELU_IN if relu_in else 0) | geo.base_flags
-    wfn = lib.loans_wgrad_bf16_f32 if COMPUTE == 'bf16' else lib.loans_wgrad_f32
+    s16 = _is16(x)
+    assert _is16(gy) == s16, 'x and gy must share their storage type'
+    wfn = lib.loans_wgrad_bf16s if s16 else (lib.loans_wgrad_bf16_f32 if COMPUTE == 'bf16' else lib.loans_wgrad_f32)
     if tile == 0:
         def run(t):
             scratch = torch.empty(dw.numel(), device=x.device, dtype=torch.float32)
             check(wfn(_ptr(x), _ptr(gy), _ptr(scratch), C.byref(_with_flags(geo.fwd, fl, t)), splits,
                       _stream()), 'loans_wgrad[tune]')
-        tile = _tuned_tile(geo, COMPUTE + 'wgrad', run, _WGRAD_TILES)
+        tile = _tuned_tile(geo, ('bf16s_' if s16 else COMPUTE) + 'wgrad', run, _WGRAD_TILES)
     d = _with_flags(geo.fwd, fl, tile)
     check(wfn(_ptr(x), _ptr(gy), _ptr(dw), C.byref(d), splits, _stream()), 'loans_wgrad')
     if geo.dense:
@@ -457,19 +562,25 @@ def bn_apply(x, st, relu=True, residual=None, x2=None, st2=None):
         mode, second = 1, residual
     elif x2 is not None:
         mode, second = 2, x2
-    check(_lib.load().loans_bn_apply_f32(_ptr(x), _ptr(st.scale), _ptr(st.shift), _ptr(second),
-                                         _ptr(st2.scale if st2 else None), _ptr(st2.shift if st2 else None),
-                                         _ptr(y), rows, C_, mode, 1 if relu else 0, _stream()), 'loans_bn_apply_f32')
+    lib = _lib.load()
+    assert second is None or second.dtype == x.dtype
+    fn = lib.loans_bn_apply_bf16 if _is16(x) else lib.loans_bn_apply_f32
+    check(fn(_ptr(x), _ptr(st.scale), _ptr(st.shift), _ptr(second),
+             _ptr(st2.scale if st2 else None), _ptr(st2.shift if st2 else None),
+             _ptr(y), rows, C_, mode, 1 if relu else 0, _stream()), 'loans_bn_apply')
     return y
 
 
 def bn_relu_maxpool(x, st):
     B, H, W, C_ = x.shape
     OH, OW = conv_outsize(H, 3, 2, 0, True), conv_outsize(W, 3, 2, 0, True)
-    y = torch.empty((B, OH, OW, C_), device=x.device, dtype=torch.float32)
+    s16 = STORAGE == 'bf16'          # the stem's pool is where the bf16 region begins
+    y = torch.empty((B, OH, OW, C_), device=x.device, dtype=BF16 if s16 else torch.float32)
     idx = torch.empty((B, OH, OW, C_), device=x.device, dtype=torch.uint8)
-    check(_lib.load().loans_bn_relu_maxpool_f32(_ptr(x), _ptr(st.scale), _ptr(st.shift), _ptr(y), _ptr(idx),
-                                                B, H, W, C_, OH, OW, _stream()), 'loans_bn_relu_maxpool_f32')
+    lib = _lib.load()
+    fn = lib.loans_bn_relu_maxpool_f32_bf16 if s16 else lib.loans_bn_relu_maxpool_f32
+    check(fn(_ptr(x), _ptr(st.scale), _ptr(st.shift), _ptr(y), _ptr(idx), B, H, W, C_, OH, OW, _stream()),
+          'loans_bn_relu_maxpool')
     return y, idx
 
 
@@ -477,8 +588,10 @@ def maxpool_relu_bwd(gy, idx, x, st):
     B, H, W, C_ = x.shape
     OH, OW = gy.shape[1], gy.shape[2]
     gx = torch.empty_like(x)
-    check(_lib.load().loans_maxpool_relu_bwd_f32(_ptr(gy), _ptr(idx), _ptr(x), _ptr(st.scale), _ptr(st.shift),
-                                                 _ptr(gx), B, H, W, C_, OH, OW, _stream()), 'loans_maxpool_relu_bwd_f32')
+    lib = _lib.load()
+    fn = lib.loans_maxpool_relu_bwd_bf16_f32 if _is16(gy) else lib.loans_maxpool_relu_bwd_f32
+    check(fn(_ptr(gy), _ptr(idx), _ptr(x), _ptr(st.scale), _ptr(st.shift), _ptr(gx), B, H, W, C_, OH, OW, _stream()),
+          'loans_maxpool_relu_bwd')
     return gx
 
 
@@ -491,7 +604,11 @@ def bn_backward(gy, mask, x, st, gamma, ggamma, gbeta, x2=None, st2=None, gamma2
     dual = x2 is not None
     sums = torch.zeros((4 if dual else 2, C_), device=x.device, dtype=torch.float64)
     s = _stream()
-    check(lib.loans_bn_bwd_reduce_f32(_ptr(gy), _ptr(mask), _ptr(x), _ptr(st.mean), _ptr(st.rstd), _ptr(x2),
+    s16 = _is16(x)
+    assert _is16(gy) == s16 and (mask is None or _is16(mask) == s16) and (x2 is None or _is16(x2) == s16)
+    red_fn = lib.loans_bn_bwd_reduce_bf16 if s16 else lib.loans_bn_bwd_reduce_f32
+    app_fn = lib.loans_bn_bwd_apply_bf16 if s16 else lib.loans_bn_bwd_apply_f32
+    check(red_fn(_ptr(gy), _ptr(mask), _ptr(x), _ptr(st.mean), _ptr(st.rstd), _ptr(x2),
                                       _ptr(st2.mean if dual else None), _ptr(st2.rstd if dual else None),
                                       _ptr(sums), rows, C_, s), 'loans_bn_bwd_reduce_f32')
     k = torch.empty((6 if dual else 3, C_), device=x.device, dtype=torch.float32)
@@ -504,7 +621,7 @@ def bn_backward(gy, mask, x, st, gamma, ggamma, gbeta, x2=None, st2=None, gamma2
                                           _ptr(ggamma2), _ptr(gbeta2), _ptr(k[3]), _ptr(k[4]), _ptr(k[5]), s),
               'loans_bn_bwd_coeffs_f32')
         gx2 = torch.empty_like(x2)
-    check(lib.loans_bn_bwd_apply_f32(_ptr(gy), _ptr(mask), _ptr(x), _ptr(k[0]), _ptr(k[1]), _ptr(k[2]), _ptr(gx),
+    check(app_fn(_ptr(gy), _ptr(mask), _ptr(x), _ptr(k[0]), _ptr(k[1]), _ptr(k[2]), _ptr(gx),
                                      _ptr(x2), _ptr(k[3]) if dual else 0, _ptr(k[4]) if dual else 0,
                                      _ptr(k[5]) if dual else 0, _ptr(gx2), rows, C_, s), 'loans_bn_bwd_apply_f32')
     return (gx, gx2) if dual else gx
@@ -521,14 +638,18 @@ def colsum_acc(x, out):
 def gap_fwd(x):
     B, H, W, C_ = x.shape
     y = torch.empty((B, C_), device=x.device, dtype=torch.float32)
-    check(_lib.load().loans_gap_fwd_f32(_ptr(x), _ptr(y), B, H * W, C_, _stream()), 'loans_gap_fwd_f32')
+    lib = _lib.load()
+    fn = lib.loans_gap_fwd_bf16_f32 if _is16(x) else lib.loans_gap_fwd_f32
+    check(fn(_ptr(x), _ptr(y), B, H * W, C_, _stream()), 'loans_gap_fwd')
     return y
 
 
-def gap_bwd(gy, shape):
+def gap_bwd(gy, shape, dtype=torch.float32):
     B, H, W, C_ = shape
-    gx = torch.empty(shape, device=gy.device, dtype=torch.float32)
-    check(_lib.load().loans_gap_bwd_f32(_ptr(gy), _ptr(gx), B, H * W, C_, _stream()), 'loans_gap_bwd_f32')
+    gx = torch.empty(shape, device=gy.device, dtype=dtype)
+    lib = _lib.load()
+    fn = lib.loans_gap_bwd_f32_bf16 if dtype == BF16 else lib.loans_gap_bwd_f32
+    check(fn(_ptr(gy), _ptr(gx), B, H * W, C_, _stream()), 'loans_gap_bwd')
     return gx
 
 

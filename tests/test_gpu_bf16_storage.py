@@ -1,0 +1,172 @@
+"""-m gpu: the bf16 STORAGE arm (BASELINE configs 3 / 5) -- every kernel that reads or writes bf16 tensors, through the
+C ABI, against the CPU oracle evaluated on the bf16-rounded operands.  A bf16 result is the fp32 result rounded once
+(relative 2^-9 at most), so comparisons of bf16 outputs use 2^-8; fp32 outputs (weight gradients, statistics) keep
+fp32-accumulation tolerances."""
+import numpy as np
+import pytest
+import torch
+
+from oracle import chainer_ops as C
+from tests.gpu_util import dev, rel_err
+
+pytestmark = pytest.mark.gpu
+
+BF16_EPS = 2.0 ** -8
+
+
+def _nhwc(x):
+    return np.ascontiguousarray(np.transpose(x, (0, 2, 3, 1)))
+
+
+def _nchw(t):
+    return t.detach().float().cpu().numpy().transpose(0, 3, 1, 2)
+
+
+def _r(a):
+    """round an fp32 array to bf16 (RNE) and return it as fp32"""
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).to(torch.bfloat16).float().numpy()
+
+
+def d16(a):
+    return torch.from_numpy(np.ascontiguousarray(a, dtype=np.float32)).cuda().to(torch.bfloat16).contiguous()
+
+
+CASES = [
+    # B, Cin, H, W, Cout, k, stride, pad
+    (3, 64, 14, 14, 64, 3, 1, 1),      # res2-like
+    (2, 64, 15, 13, 128, 3, 2, 1),     # strided, odd sizes
+    (5, 128, 6, 6, 200, 3, 1, 1),      # Cout not a multiple of the tile
+    (2, 256, 7, 7, 512, 3, 2, 1),      # deep, strided
+    (3, 256, 7, 7, 64, 1, 1, 0),       # 1x1 bottleneck reduce
+    (2, 64, 9, 9, 256, 1, 2, 0),       # 1x1 strided (ResNet-50 shortcut)
+    (2, 8, 11, 11, 16, 3, 1, 1),       # a single 16-byte unit per tap, K tail
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 7])
+def test_conv_bf16_storage(case, tile):
+    from loans_amd import ops
+    B, Cin, H, W, Cout, k, s, p = case
+    rng = np.random.RandomState(3)
+    x = _r(rng.standard_normal((B, Cin, H, W)))
+    w = (rng.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
+    wr = _r(w)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    geo = ops.ConvGeometry(B, H, W, Cin, Cout, k, s, p)
+    xd, wd = d16(_nhwc(x)), dev(_nhwc(w))
+    y_ref, col = C.conv2d_fwd(x.astype(np.float64), wr.astype(np.float64), b.astype(np.float64), s, p)
+    stats_r = ops.stats_buffer(Cout, 'cuda')
+    y = ops.conv_fprop(xd, wd, geo, bias=dev(b), stats=stats_r, tile=tile)
+    assert y.dtype == torch.bfloat16
+    assert np.abs(_nchw(y) - y_ref).max() <= BF16_EPS * np.abs(y_ref).max()
+    assert rel_err(_nchw(y), y_ref) < BF16_EPS
+    # statistics come from the fp32 accumulators, not from the rounded output
+    st = stats_r.sum(dim=0).cpu().numpy()
+    np.testing.assert_allclose(st[0], y_ref.sum(axis=(0, 2, 3)), rtol=1e-4, atol=1e-3)
+    np.testing.assert_allclose(st[1], (y_ref ** 2).sum(axis=(0, 2, 3)), rtol=1e-4)
+    # + addend
+    add = _r(rng.standard_normal(y_ref.shape))
+    y2 = ops.conv_fprop(xd, wd, geo, addend=d16(_nhwc(add)), tile=tile)
+    y2_ref = C.conv2d_fwd(x.astype(np.float64), wr.astype(np.float64), None, s, p)[0] + add
+    assert rel_err(_nchw(y2), y2_ref) < BF16_EPS
+
+    # data gradient and its fused epilogues
+    gy = _r(rng.standard_normal(y_ref.shape))
+    gx_ref, gw_ref, _ = C.conv2d_bwd(x.shape, col, wr.astype(np.float64), gy.astype(np.float64), s, p, False)
+    gyd = d16(_nhwc(gy))
+    gx = ops.conv_dgrad(gyd, wd, geo, tile=tile)
+    assert gx.dtype == torch.bfloat16
+    assert rel_err(_nchw(gx), gx_ref) < BF16_EPS
+    ref_t = _r(rng.standard_normal(x.shape))
+    addx = _r(rng.standard_normal(x.shape))
+    if geo.dgrad_has_empty_class:       # strided 1x1: tap-less pixels only take the plain addend (as in fp32 storage)
+        gx2 = ops.conv_dgrad(gyd, wd, geo, addend=d16(_nhwc(addx)), tile=tile)
+        assert rel_err(_nchw(gx2), gx_ref + addx) < BF16_EPS
+        return
+    gx2 = ops.conv_dgrad(gyd, wd, geo, mask_ref=d16(_nhwc(ref_t)), addend=d16(_nhwc(addx)), tile=tile)
+    assert rel_err(_nchw(gx2), gx_ref * (ref_t > 0) + addx) < BF16_EPS
+    gx3 = ops.conv_dgrad(gyd, wd, geo, addend=d16(_nhwc(addx)), addend_mask_ref=d16(_nhwc(ref_t)), tile=tile)
+    assert rel_err(_nchw(gx3), gx_ref + addx * (ref_t > 0)) < BF16_EPS
+
+    # weight gradient: bf16 operands, fp32 accumulation into the fp32 gradient
+    if tile in (0, 1, 3):
+        dw = torch.zeros_like(wd)
+        ops._conv_wgrad(xd, gyd, dw, geo, False, 0, tile)
+        assert dw.dtype == torch.float32
+        assert rel_err(dw.cpu().numpy().transpose(0, 3, 1, 2), gw_ref) < 1e-5
+
+
+def test_bn_passes_bf16_storage():
+    """bn_apply (3 modes), bn_backward (single / dual, with and without the ReLU mask) on bf16 tensors against the
+    fp32 kernels fed the same (already rounded) values"""
+    from loans_amd import ops
+    rng = np.random.RandomState(5)
+    B, H, W, Cc = 4, 9, 7, 64
+    mk = lambda: _r(rng.standard_normal((B, H, W, Cc)))      # noqa: E731
+    x, x2, res, gy, out = mk(), mk(), mk(), mk(), mk()
+    gamma = (1 + 0.1 * rng.standard_normal(Cc)).astype(np.float32)
+    beta = (0.1 * rng.standard_normal(Cc)).astype(np.float32)
+
+    def state(a):
+        stats = torch.zeros((ops.STATS_REPLICAS, 2, Cc), device='cuda', dtype=torch.float64)
+        flat = torch.from_numpy(a.reshape(-1, Cc).astype(np.float64)).cuda()
+        stats[0, 0], stats[0, 1] = flat.sum(0), (flat * flat).sum(0)
+        return ops.bn_finalize(stats, B * H * W, dev(gamma), dev(beta), dev(np.zeros(Cc, np.float32)), dev(np.ones(Cc, np.float32)))
+    st, st2 = state(x), state(x2)
+    for kw32, kw16 in [({}, {}),
+                       ({'residual': dev(res)}, {'residual': d16(res)}),
+                       ({'x2': dev(x2), 'st2': st2}, {'x2': d16(x2), 'st2': st2})]:
+        y32 = ops.bn_apply(dev(x), st, relu=True, **kw32)
+        y16 = ops.bn_apply(d16(x), st, relu=True, **kw16)
+        assert y16.dtype == torch.bfloat16
+        assert rel_err(y16.float().cpu().numpy(), y32.cpu().numpy()) < BF16_EPS
+
+    for mask32, mask16 in [(None, None), (dev(out), d16(out))]:
+        gg32, gb32 = torch.zeros(Cc, device='cuda'), torch.zeros(Cc, device='cuda')
+        gg16, gb16 = torch.zeros(Cc, device='cuda'), torch.zeros(Cc, device='cuda')
+        g32 = ops.bn_backward(dev(gy), mask32, dev(x), st, dev(gamma), gg32, gb32)
+        g16 = ops.bn_backward(d16(gy), mask16, d16(x), st, dev(gamma), gg16, gb16)
+        assert g16.dtype == torch.bfloat16
+        assert rel_err(g16.float().cpu().numpy(), g32.cpu().numpy()) < BF16_EPS
+        np.testing.assert_allclose(gg16.cpu().numpy(), gg32.cpu().numpy(), rtol=1e-5, atol=1e-4)
+        np.testing.assert_allclose(gb16.cpu().numpy(), gb32.cpu().numpy(), rtol=1e-5, atol=1e-4)
+    z = lambda: torch.zeros(Cc, device='cuda')      # noqa: E731
+    a32, b32 = ops.bn_backward(dev(gy), dev(out), dev(x), st, dev(gamma), z(), z(),
+                               x2=dev(x2), st2=st2, gamma2=dev(gamma), ggamma2=z(), gbeta2=z())
+    a16, b16 = ops.bn_backward(d16(gy), d16(out), d16(x), st, dev(gamma), z(), z(),
+                               x2=d16(x2), st2=st2, gamma2=dev(gamma), ggamma2=z(), gbeta2=z())
+    assert rel_err(a16.float().cpu().numpy(), a32.cpu().numpy()) < BF16_EPS
+    assert rel_err(b16.float().cpu().numpy(), b32.cpu().numpy()) < BF16_EPS
+
+
+def test_region_boundaries_bf16_storage():
+    """where the bf16 region begins and ends: the stem's pool (fp32 conv output -> bf16 pooled activations, argmax
+    unchanged), its backward (bf16 gradient -> fp32), global average pooling (bf16 -> fp32 features, fp32 -> bf16)"""
+    from loans_amd import ops
+    rng = np.random.RandomState(6)
+    B, H, W, Cc = 2, 13, 12, 64
+    x = rng.standard_normal((B, H, W, Cc)).astype(np.float32)
+    stats = torch.zeros((ops.STATS_REPLICAS, 2, Cc), device='cuda', dtype=torch.float64)
+    flat = torch.from_numpy(x.reshape(-1, Cc).astype(np.float64)).cuda()
+    stats[0, 0], stats[0, 1] = flat.sum(0), (flat * flat).sum(0)
+    st = ops.bn_finalize(stats, B * H * W, dev(np.ones(Cc, np.float32)), dev(np.zeros(Cc, np.float32)),
+                         dev(np.zeros(Cc, np.float32)), dev(np.ones(Cc, np.float32)))
+    y32, idx32 = ops.bn_relu_maxpool(dev(x), st)
+    ops.set_compute_dtype('bf16')
+    ops.set_storage_dtype('bf16')
+    try:
+        y16, idx16 = ops.bn_relu_maxpool(dev(x), st)
+    finally:
+        ops.set_compute_dtype('f32')
+    assert y16.dtype == torch.bfloat16 and torch.equal(idx16, idx32)
+    assert torch.equal(y16, y32.to(torch.bfloat16))                 # the fp32 result, rounded once
+    gy = _r(rng.standard_normal(tuple(y32.shape)))
+    g32 = ops.maxpool_relu_bwd(dev(gy), idx32, dev(x), st)
+    g16 = ops.maxpool_relu_bwd(d16(gy), idx32, dev(x), st)
+    assert g16.dtype == torch.float32 and torch.allclose(g16, g32, rtol=1e-6, atol=1e-6)
+    f = _r(rng.standard_normal((B, 7, 7, 512)))
+    assert torch.allclose(ops.gap_fwd(d16(f)), ops.gap_fwd(dev(f)), rtol=1e-6, atol=1e-6)
+    gf = rng.standard_normal((B, 512)).astype(np.float32)
+    g16 = ops.gap_bwd(dev(gf), (B, 7, 7, 512), torch.bfloat16)
+    assert torch.equal(g16, ops.gap_bwd(dev(gf), (B, 7, 7, 512)).to(torch.bfloat16))
