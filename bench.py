@@ -45,6 +45,8 @@ def parse():
     ap.add_argument('--resnet50', action='store_true', help='Resnet50SheepLocalizer backbone (BASELINE configs[4] architecture, fp32)')
     ap.add_argument('--dtype', default='f32', choices=['f32', 'bf16'],
                     help="arithmetic of the conv contractions: exact fp32 MFMA (parity path) or bf16 MFMA with fp32 accumulate")
+    ap.add_argument('--storage', default=None, choices=['f32', 'bf16'],
+                    help="storage of the localizer's stage activations / gradients (default: bf16 with --dtype bf16, else f32)")
     ap.add_argument('--graph', action='store_true', help='capture the step into a hipGraph after warm-up (small, launch-bound batches)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--cpu-batch', type=int, default=8)
@@ -88,6 +90,8 @@ def main():
     from loans_amd.runtime import training
 
     ops.set_compute_dtype(args.dtype)
+    storage = args.storage or ('bf16' if args.dtype == 'bf16' else 'f32')
+    ops.set_storage_dtype(storage)
     comm = parallel.init_from_env()
     world, rank = comm.size, comm.rank
     if world != args.gpus:
@@ -195,7 +199,8 @@ def main():
         "config": {"workload": "LoANs joint step: %s localizer + STN crop + assessor, fwd+bwd+2xAdam-AMSGrad" % backbone,
                    "per_gpu_batch": B, "global_batch": B * world, "frame": "3x%dx%d" % (hw, hw),
                    "crop": "3x%dx%d" % (crop, crop), "parallelism": "dp%d" % world,
-                   "baseline_config": cfg_label, "hip_graph": bool(args.graph), "init_steps": init_steps},
+                   "baseline_config": cfg_label, "hip_graph": bool(args.graph), "init_steps": init_steps,
+                   "activation_storage": storage},
         "roofline": roofline,
     }
     if world == 1 and not args.no_cpu_baseline and not args.resnet50 and args.dtype == 'f32':

@@ -16,4 +16,4 @@ from .common.utils import Size, DirectionLossCalculator, OutOfImageLossCalculato
 from .functions.rotation_dropout import rotation_dropout, RotationDropout  # noqa: F401
 
 __version__ = '0.1.0'
-from .ops import set_compute_dtype  # noqa: F401,E402
+from .ops import set_compute_dtype, set_storage_dtype  # noqa: F401,E402
