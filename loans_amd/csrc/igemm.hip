@@ -835,21 +835,18 @@ extern "C" int loans_igemm_bf16_f32(const float* in, const float* w, float* out,
 namespace {
 
 struct WgradArgs {
-    const float* x;         // IN16: both operands are bf16 tensors behind these pointers
+    const float* x;
     const float* gy;
     float* dw;
     loans_igemm_desc d;
     int M, Ktot, tiles_co, tiles_j, splits, chunks_per_split;
     int bf16;
-    int in16;
     unsigned x_bytes, gy_bytes;
 };
 
 // BF16 = true: fragments are packed to bf16 after the (fp32, conflict-free) LDS reads and contracted on the
 // 32x32x16 bf16 MFMA; staging and accumulation stay fp32.
-// IN16 = true (bf16 storage, loans_wgrad_bf16s): x and gy are bf16 in memory; a thread fetches its four channels
-// as 8 bytes and widens them while staging, so the LDS image and everything behind it are unchanged.
-template <int BCO, int BJ, bool RELU, bool BF16, bool IN16 = false>   // BCO (output channels) x BJ (tap-channel columns) block tile, 4 waves as 2 x 2
+template <int BCO, int BJ, bool RELU, bool BF16>   // BCO (output channels) x BJ (tap-channel columns) block tile, 4 waves as 2 x 2
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     static_assert(BCO <= BJ, "the loader's thread map follows the wider (X) tile");
     constexpr int TM = BCO / 2 / 32, TN = BJ / 2 / 32;   // MFMA tiles per wave
@@ -913,22 +910,13 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
         const int b = pb[p], y = py[p], x = px[p];
         const bool rv = b < d.B;
         const int pix = (b * d.outH + y * d.osy + d.oy0) * d.outW + x * d.osx + d.ox0;
-        constexpr unsigned ES = IN16 ? 2u : 4u;       // bytes per stored element
-        const unsigned goff = ((unsigned)(pix * d.Cout + yco) * ES) | ((unsigned)(rv & yv) - 1u);
-        if constexpr (IN16) {
-            ry[p] = __builtin_convertvector(__builtin_bit_cast(bf16x4_t, __builtin_amdgcn_raw_buffer_load_b64(rs_g, (int)goff, 0, 0)), f32x4);
-        } else {
-            ry[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_g, (int)goff, 0, 0));
-        }
+        const unsigned goff = ((unsigned)(pix * d.Cout + yco) * 4u) | ((unsigned)(rv & yv) - 1u);
+        ry[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_g, (int)goff, 0, 0));
         const int iy = y * d.isy + dy, ix = x * d.isx + dx;
         const unsigned ok = (unsigned)(rv & xtv) & (unsigned)((unsigned)iy < (unsigned)d.inH) &
                             (unsigned)((unsigned)ix < (unsigned)d.inW);
-        const unsigned xoff = ((unsigned)(((b * d.inH + iy) * d.inW + ix) * ucin + xc4 * 4) * ES) | (ok - 1u);
-        if constexpr (IN16) {
-            rx[p] = __builtin_convertvector(__builtin_bit_cast(bf16x4_t, __builtin_amdgcn_raw_buffer_load_b64(rs_x, (int)xoff, 0, 0)), f32x4);
-        } else {
-            rx[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)xoff, 0, 0));
-        }
+        const unsigned xoff = ((unsigned)(((b * d.inH + iy) * d.inW + ix) * ucin + xc4 * 4) * 4u) | (ok - 1u);
+        rx[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)xoff, 0, 0));
         // advance 32 pixels: exact floor((v + .5) / n) for the small integers involved
         int nx = x + 32;
         const int qx = (int)(((float)nx + 0.5f) * inv_gw);
@@ -1078,11 +1066,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
         }
 }
 
-template <int BCO, int BJ, bool RELU, bool BF16, bool IN16 = false>
+template <int BCO, int BJ, bool RELU, bool BF16>
 int launch_wgrad_r(WgradArgs& a, int splits_req, hipStream_t st) {
     static bool attr_set = false;
     constexpr size_t lds = (size_t)2 * 32 * (BCO + BJ) * 4;
-    auto kern = wgrad_kernel<BCO, BJ, RELU, BF16, IN16>;
+    auto kern = wgrad_kernel<BCO, BJ, RELU, BF16>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1112,7 +1100,6 @@ int launch_wgrad_r(WgradArgs& a, int splits_req, hipStream_t st) {
 template <int BCO, int BJ>
 int launch_wgrad(WgradArgs& a, int splits_req, hipStream_t st) {
     const bool relu = a.d.flags & LOANS_F_RELU_IN;
-    if (a.in16) return relu ? LOANS_EINVAL : launch_wgrad_r<BCO, BJ, false, true, true>(a, splits_req, st);
     if (a.bf16) return relu ? launch_wgrad_r<BCO, BJ, true, true>(a, splits_req, st) : launch_wgrad_r<BCO, BJ, false, true>(a, splits_req, st);
     return relu ? launch_wgrad_r<BCO, BJ, true, false>(a, splits_req, st) : launch_wgrad_r<BCO, BJ, false, false>(a, splits_req, st);
 }
@@ -1145,21 +1132,18 @@ __global__ __launch_bounds__(256) void repack_dgrad_kernel(const RepackArgs a) {
 }  // namespace
 
 static int wgrad_impl(const float* x, const float* gy, float* dw, const loans_igemm_desc* d, int32_t splits,
-                      void* stream, int bf16, int in16 = 0) {
+                      void* stream, int bf16) {
     int rc = check_desc(d);
     if (rc) return rc;
     if (!x || !gy || !dw || (d->Cout & 3)) return LOANS_EINVAL;
-    if (in16 && (d->flags & LOANS_F_DENSE)) return LOANS_EINVAL;
     WgradArgs a;
     a.x = x; a.gy = gy; a.dw = dw; a.d = *d;
     a.bf16 = bf16;
-    a.in16 = in16;
     a.M = d->B * d->gridH * d->gridW;
     a.Ktot = d->ntaps * d->Cin;
     {
-        const int es = in16 ? 2 : 4;
-        const int64_t xb = (int64_t)d->B * d->inH * d->inW * ((d->flags & LOANS_F_DENSE) ? 1 : d->Cin) * es;
-        const int64_t gb = (int64_t)d->B * d->outH * d->outW * d->Cout * es;
+        const int64_t xb = (int64_t)d->B * d->inH * d->inW * ((d->flags & LOANS_F_DENSE) ? 1 : d->Cin) * 4;
+        const int64_t gb = (int64_t)d->B * d->outH * d->outW * d->Cout * 4;
         if (xb >= 0xFFFFFFF0ll || gb >= 0xFFFFFFF0ll) return LOANS_ERANGE;
         a.x_bytes = (unsigned)xb;
         a.gy_bytes = (unsigned)gb;
@@ -1182,11 +1166,6 @@ extern "C" int loans_wgrad_f32(const float* x, const float* gy, float* dw, const
 extern "C" int loans_wgrad_bf16_f32(const float* x, const float* gy, float* dw, const loans_igemm_desc* d,
                                     int32_t splits, void* stream) {
     return wgrad_impl(x, gy, dw, d, splits, stream, 1);
-}
-
-extern "C" int loans_wgrad_bf16s(const void* x, const void* gy, float* dw, const loans_igemm_desc* d,
-                                 int32_t splits, void* stream) {
-    return wgrad_impl(static_cast<const float*>(x), static_cast<const float*>(gy), dw, d, splits, stream, 1, 1);
 }
 
 extern "C" int loans_repack_dgrad_f32(const float* src, float* dst, int32_t Cout, int32_t Cin, int32_t src_taps,

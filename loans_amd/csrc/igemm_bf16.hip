@@ -435,6 +435,210 @@ __global__ __launch_bounds__(256) void repack_dgrad16_kernel(const Repack16Args 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// weight gradient on bf16 tensors:  dw[co][t][c] += sum_m gy[opix(m)][co] * x[pix(m,t)][c]   (fp32 atomics into dw)
+// GEMM rows = co, columns = (t, c), reduction = pixels m, split over blocks.  Both operands are pixel-major in
+// memory (channels contiguous), i.e. TRANSPOSED for the MFMA, whose lane wants 8 consecutive reduction indices of
+// one channel: the tiles are staged as they lie ([pixel][channel] rows, 16-byte units) and the fragments are read
+// with ds_read_b64_tr_b16, the hardware transpose read (per 16 lanes: a 4-pixel x 16-channel block, column-major
+// to registers) -- two of them are one 32x32x16 operand.  Rows are padded by 32 elements: the 4 pixel rows a
+// 32-lane half touches then start 16 banks apart (row strides of 192 / 320 / 576 bytes) and the reads are
+// conflict-free.
+// ------------------------------------------------------------------------------------------
+struct Wgrad16Args {
+    const __bf16* x;
+    const __bf16* gy;
+    float* dw;
+    loans_igemm_desc d;
+    int M, Ktot, tiles_co, tiles_j, splits, chunks_per_split;
+    unsigned x_bytes, gy_bytes;
+};
+
+template <int BCO, int BJ>   // BCO (output channels) x BJ (tap-channel columns) block tile, 4 waves as 2 x 2
+__global__ __launch_bounds__(256) void wgrad16_kernel(const Wgrad16Args a) {
+    static_assert(BCO <= BJ, "the loader's thread map follows the wider (X) tile");
+    constexpr int TM = BCO / 2 / 32, TN = BJ / 2 / 32;   // MFMA tiles per wave
+    constexpr int UPR = BJ / 8;             // 16-byte units per X row (thread map); Y rows use the first BCO/8
+    constexpr int RPP = 256 / UPR;          // rows per loader pass
+    constexpr int NP = 32 / RPP;            // passes (rows per thread) per 32-pixel chunk
+    constexpr int SY = BCO + 32, SX = BJ + 32;      // padded LDS row strides (elements)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __bf16* Ys = reinterpret_cast<__bf16*>(smem);   // [2][32][SY]
+    __bf16* Xs = Ys + 2 * 32 * SY;                  // [2][32][SX]
+
+    const loans_igemm_desc& d = a.d;
+    const int tid = threadIdx.x;
+    const int logical = xcd_remap16(blockIdx.x, gridDim.x);
+    const int ntile = a.tiles_co * a.tiles_j;
+    const int split = logical / ntile;
+    const int tile = logical - split * ntile;
+    const int tco = tile % a.tiles_co;
+    const int tj = tile / a.tiles_co;
+    const int unit = tid % UPR, prow = tid / UPR;
+
+    // this thread's fixed column unit of the X tile: (tap, 8 channels)
+    const int cpt = d.Cin >> 3;
+    const int ug = tj * UPR + unit;
+    const int xtap = ug / cpt;
+    const int xc8 = ug - xtap * cpt;
+    const bool xtv = xtap < d.ntaps;
+    const int dy = xtv ? (int)d.dy[xtap] : 0;
+    const int dx = xtv ? (int)d.dx[xtap] : 0;
+    const int yco = tco * BCO + unit * 8;
+    const bool ythread = unit < BCO / 8;
+    const bool yv = ythread && yco < d.Cout;             // Cout % 8 == 0 (checked)
+
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.x), 0, (int)a.x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.gy), 0, (int)a.gy_bytes, 0x00020000);
+
+    const int c_begin = split * a.chunks_per_split;
+    int c_end = c_begin + a.chunks_per_split;
+    const int total_chunks = (a.M + 31) / 32;
+    if (c_end > total_chunks) c_end = total_chunks;
+
+    int pb[NP], py[NP], px[NP];
+    {
+        const int gHW = d.gridH * d.gridW;
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            const int m = c_begin * 32 + prow + RPP * p;
+            pb[p] = m / gHW;
+            const int rem = m - pb[p] * gHW;
+            py[p] = rem / d.gridW;
+            px[p] = rem - py[p] * d.gridW;
+        }
+    }
+    const float inv_gw = 1.f / (float)d.gridW, inv_gh = 1.f / (float)d.gridH;
+
+    u32x4 ry[NP], rx[NP];
+    auto load_row = [&](int p) {
+        const int b = pb[p], y = py[p], x = px[p];
+        const bool rv = b < d.B;
+        const int pix = (b * d.outH + y * d.osy + d.oy0) * d.outW + x * d.osx + d.ox0;
+        const unsigned goff = ((unsigned)(pix * d.Cout + yco) * 2u) | ((unsigned)(rv & yv) - 1u);
+        ry[p] = __builtin_amdgcn_raw_buffer_load_b128(rs_g, (int)goff, 0, 0);
+        const int iy = y * d.isy + dy, ix = x * d.isx + dx;
+        const unsigned ok = (unsigned)(rv & xtv) & (unsigned)((unsigned)iy < (unsigned)d.inH) &
+                            (unsigned)((unsigned)ix < (unsigned)d.inW);
+        const unsigned xoff = ((unsigned)(((b * d.inH + iy) * d.inW + ix) * d.Cin + xc8 * 8) * 2u) | (ok - 1u);
+        rx[p] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)xoff, 0, 0);
+        int nx = x + 32;                        // advance 32 pixels: exact floor((v + .5) / n) for these small integers
+        const int qx = (int)(((float)nx + 0.5f) * inv_gw);
+        nx -= qx * d.gridW;
+        int ny = y + qx;
+        const int qy = (int)(((float)ny + 0.5f) * inv_gh);
+        ny -= qy * d.gridH;
+        px[p] = nx; py[p] = ny; pb[p] = b + qy;
+    };
+    auto store_rows = [&](int buf) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) {
+            if (ythread) *reinterpret_cast<u32x4*>(Ys + (buf * 32 + prow + RPP * p) * SY + unit * 8) = ry[p];
+            *reinterpret_cast<u32x4*>(Xs + (buf * 32 + prow + RPP * p) * SX + unit * 8) = rx[p];
+        }
+    };
+
+    // transposed fragment reads: 16-lane group g = lane >> 4 takes the block of pixels 8*(g>>1) + 4t .. +3 (MFMA half h =
+    // g >> 1) and channels 16*(g&1) .. +15 of its 32-wide MFMA tile; lane 4q + p of the group addresses pixel row q,
+    // channels 4p .. 4p+3, and receives channel (lane & 15) of the four pixels
+    const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wm = wave >> 1, wn = wave & 1;
+    const int li = lane & 15, fq = li >> 2, fp = li & 3, cg = (lane >> 4) & 1;
+    const int trY = (8 * h + fq) * SY + wm * TM * 32 + 16 * cg + 4 * fp;
+    const int trX = (8 * h + fq) * SX + wn * TN * 32 + 16 * cg + 4 * fp;
+    typedef __attribute__((address_space(3))) bf16x4_t* lds_b64_t;
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+    if (c_begin < c_end) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) load_row(p);
+        store_rows(0);
+    }
+    __syncthreads();
+    for (int c = c_begin; c < c_end; ++c) {
+        const int buf = (c - c_begin) & 1;
+        const bool more = (c + 1) < c_end;
+        if (more) {
+#pragma unroll
+            for (int p = 0; p < NP; ++p) load_row(p);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s) {
+            const __bf16* Yb = Ys + (buf * 32 + 16 * s) * SY + trY;
+            const __bf16* Xb = Xs + (buf * 32 + 16 * s) * SX + trX;
+            bf16x8_t af[TM], bf[TN];
+#pragma unroll
+            for (int i = 0; i < TM; ++i) {
+                const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64_t)(Yb + i * 32));
+                const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64_t)(Yb + i * 32 + 4 * SY));
+                af[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int j = 0; j < TN; ++j) {
+                const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64_t)(Xb + j * 32));
+                const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64_t)(Xb + j * 32 + 4 * SX));
+                bf[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+        if (more) store_rows(buf ^ 1);
+        __syncthreads();
+    }
+
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int jc = tj * BJ + wn * TN * 32 + j * 32 + r;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int co = tco * BCO + wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+                if (co < d.Cout && jc < a.Ktot) atomic_add_f32(a.dw + (int64_t)co * a.Ktot + jc, acc[i][j][e]);
+            }
+        }
+}
+
+template <int BCO, int BJ>
+int launch_wgrad16(Wgrad16Args& a, int splits_req, hipStream_t st) {
+    static bool attr_set = false;
+    constexpr size_t lds = (size_t)2 * 32 * ((BCO + 32) + (BJ + 32)) * 2;
+    auto kern = wgrad16_kernel<BCO, BJ>;
+    if (!attr_set) {
+        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
+                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+        if (e != hipSuccess) return (int)e;
+        attr_set = true;
+    }
+    a.tiles_co = (a.d.Cout + BCO - 1) / BCO;
+    a.tiles_j = (a.Ktot + BJ - 1) / BJ;
+    const int total_chunks = (a.M + 31) / 32;
+    int splits = splits_req;
+    if (splits <= 0) {
+        const int ntile = a.tiles_co * a.tiles_j;
+        splits = (1024 + ntile - 1) / ntile;            // ~4 blocks per CU in flight
+        const int max_splits = (total_chunks + 15) / 16; // >= 16 chunks (512 pixels) per block
+        if (splits > max_splits) splits = max_splits;
+        if (splits < 1) splits = 1;
+    }
+    if (splits > total_chunks) splits = total_chunks;
+    a.chunks_per_split = (total_chunks + splits - 1) / splits;
+    a.splits = (total_chunks + a.chunks_per_split - 1) / a.chunks_per_split;
+    hipLaunchKernelGGL(kern, dim3(a.tiles_co * a.tiles_j * a.splits), dim3(256), lds, st, a);
+    LOANS_LAUNCH_CHECK();
+    return LOANS_OK;
+}
+
 }  // namespace
 
 extern "C" int loans_igemm_bf16s(const void* in, const void* w, void* out, const float* bias, double* stats,
@@ -509,4 +713,35 @@ extern "C" int loans_repack_dgrad_bf16(const float* src, void* dst, int32_t Cout
     hipLaunchKernelGGL(repack_dgrad16_kernel, grid, dim3(256), 0, as_stream(stream), a);
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;
+}
+
+extern "C" int loans_wgrad_bf16s(const void* x, const void* gy, float* dw, const loans_igemm_desc* d,
+                                 int32_t splits, void* stream) {
+    if (!d || !x || !gy || !dw) return LOANS_EINVAL;
+    if (d->B <= 0 || d->inH <= 0 || d->inW <= 0 || d->Cin <= 0 || (d->Cin & 7)) return LOANS_EINVAL;
+    if (d->outH <= 0 || d->outW <= 0 || d->Cout <= 0 || (d->Cout & 7)) return LOANS_EINVAL;
+    if (d->gridH <= 0 || d->gridW <= 0 || d->osy <= 0 || d->osx <= 0 || d->isy <= 0 || d->isx <= 0) return LOANS_EINVAL;
+    if (d->oy0 < 0 || d->ox0 < 0) return LOANS_EINVAL;
+    if ((d->gridH - 1) * d->osy + d->oy0 >= d->outH) return LOANS_EINVAL;
+    if ((d->gridW - 1) * d->osx + d->ox0 >= d->outW) return LOANS_EINVAL;
+    if (d->ntaps < 1 || d->ntaps > LOANS_MAX_TAPS) return LOANS_EINVAL;
+    if (d->flags & (LOANS_F_DENSE | LOANS_F_RELU_IN)) return LOANS_EINVAL;
+    if ((int64_t)d->B * d->gridH * d->gridW >= ((int64_t)1 << 31)) return LOANS_ERANGE;
+    Wgrad16Args a;
+    a.x = static_cast<const __bf16*>(x); a.gy = static_cast<const __bf16*>(gy); a.dw = dw; a.d = *d;
+    a.M = d->B * d->gridH * d->gridW;
+    a.Ktot = d->ntaps * d->Cin;
+    {
+        const int64_t xb = (int64_t)d->B * d->inH * d->inW * d->Cin * 2;
+        const int64_t gb = (int64_t)d->B * d->outH * d->outW * d->Cout * 2;
+        if (xb >= 0xFFFFFFF0ll || gb >= 0xFFFFFFF0ll) return LOANS_ERANGE;
+        a.x_bytes = (unsigned)xb; a.gy_bytes = (unsigned)gb;
+    }
+    hipStream_t st = as_stream(stream);
+    int tile = d->tile;
+    if (tile == 0) tile = (d->Cout <= 64) ? (a.Ktot <= 64 ? LOANS_TILE_64x64 : LOANS_TILE_64x128) : LOANS_TILE_128x128;
+    if (tile == LOANS_TILE_64x64) return launch_wgrad16<64, 64>(a, splits, st);
+    if (tile == LOANS_TILE_128x128) return launch_wgrad16<128, 128>(a, splits, st);
+    if (tile == LOANS_TILE_64x128) return launch_wgrad16<64, 128>(a, splits, st);
+    return LOANS_EINVAL;
 }

@@ -50,6 +50,7 @@ def main():
     ap.add_argument('--tiles', default='0,1,2,3,4,5')
     ap.add_argument('--compute', default='f32')
     ap.add_argument('--inner', type=int, default=3, help='launches per timed sample')
+    ap.add_argument('--storage', default='f32', help="bf16: the bf16-storage kernels (loans_igemm_bf16s / loans_wgrad_bf16s); tiles 1,2,3,4,7")
     ap.add_argument('--exp', action='store_true')
     ap.add_argument('--dbg', default='0', help='comma list of LOANS_DBG values to interleave (needs --exp)')
     args = ap.parse_args()
@@ -58,13 +59,22 @@ def main():
     tiles = [int(t) for t in args.tiles.split(',')]
     names = {0: 'auto', 1: '128x128', 2: '128x64', 3: '64x64', 4: '256x64', 5: '64x128', 6: 'split'}
     names.update({t + 16: n + 'D' for t, n in list(names.items()) if t in (1, 2, 3, 4, 6)})
+    names[7] = '256x128'
+    s16 = args.storage == 'bf16'
+    if s16:
+        ops.set_compute_dtype('bf16')
+        ops.set_storage_dtype('bf16')
     for name, Cin, H, W, Cout, k, s, p in LAYERS:
         if args.layers and name not in args.layers.split(','):
             continue
         geo = ops.ConvGeometry(B, H, W, Cin, Cout, k, s, p)
+        if s16 and Cin % 8:
+            continue
         x = torch.randn(B, H, W, Cin, device='cuda')
         w = torch.randn(Cout, k, k, Cin, device='cuda') * 0.05
         gy = torch.randn(B, geo.Ho, geo.Wo, Cout, device='cuda')
+        if s16:
+            x, gy = x.to(torch.bfloat16), gy.to(torch.bfloat16)
         y = torch.empty_like(gy)
         gx = torch.empty_like(x)
         dw = torch.zeros_like(w)
@@ -77,7 +87,7 @@ def main():
             for t, dbg in [(t, g) for t in tiles for g in args.dbg.split(',')]:
                 if mode == 'wgrad' and t not in (0, 1, 3, 5):
                     continue
-                if mode != 'wgrad' and t == 5 or (mode == 'dgrad' and (t & 15) in (4, 6)):
+                if mode != 'wgrad' and t == 5 or (mode == 'dgrad' and (t & 15) in (4, 6) and not s16):
                     continue
                 if mode == 'fprop':
                     fn = lambda t=t: ops.conv_fprop(x, w, geo, out=y, stats=stats, tile=t)   # noqa: E731
