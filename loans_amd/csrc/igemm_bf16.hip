@@ -454,17 +454,21 @@ struct Wgrad16Args {
     unsigned x_bytes, gy_bytes;
 };
 
+constexpr int WPC = 32;     // pixels (reduction rows) per staged chunk
+constexpr int WDEPTH = 4;   // register sets: global loads run WDEPTH - 1 chunks ahead of the chunk being computed
+
 template <int BCO, int BJ>   // BCO (output channels) x BJ (tap-channel columns) block tile, 4 waves as 2 x 2
 __global__ __launch_bounds__(256) void wgrad16_kernel(const Wgrad16Args a) {
     static_assert(BCO <= BJ, "the loader's thread map follows the wider (X) tile");
+    static_assert(WDEPTH % 2 == 0, "LDS stage = chunk parity = register-set parity");
     constexpr int TM = BCO / 2 / 32, TN = BJ / 2 / 32;   // MFMA tiles per wave
     constexpr int UPR = BJ / 8;             // 16-byte units per X row (thread map); Y rows use the first BCO/8
     constexpr int RPP = 256 / UPR;          // rows per loader pass
-    constexpr int NP = 32 / RPP;            // passes (rows per thread) per 32-pixel chunk
+    constexpr int NP = WPC / RPP;           // passes (rows per thread) per chunk
     constexpr int SY = BCO + 32, SX = BJ + 32;      // padded LDS row strides (elements)
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __bf16* Ys = reinterpret_cast<__bf16*>(smem);   // [2][32][SY]
-    __bf16* Xs = Ys + 2 * 32 * SY;                  // [2][32][SX]
+    __bf16* Ys = reinterpret_cast<__bf16*>(smem);   // [2][WPC][SY]
+    __bf16* Xs = Ys + 2 * WPC * SY;                 // [2][WPC][SX]
 
     const loans_igemm_desc& d = a.d;
     const int tid = threadIdx.x;
@@ -493,7 +497,7 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const Wgrad16Args a) {
 
     const int c_begin = split * a.chunks_per_split;
     int c_end = c_begin + a.chunks_per_split;
-    const int total_chunks = (a.M + 31) / 32;
+    const int total_chunks = (a.M + WPC - 1) / WPC;
     if (c_end > total_chunks) c_end = total_chunks;
 
     int pb[NP], py[NP], px[NP];
@@ -501,7 +505,7 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const Wgrad16Args a) {
         const int gHW = d.gridH * d.gridW;
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-            const int m = c_begin * 32 + prow + RPP * p;
+            const int m = c_begin * WPC + prow + RPP * p;
             pb[p] = m / gHW;
             const int rem = m - pb[p] * gHW;
             py[p] = rem / d.gridW;
@@ -510,19 +514,25 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const Wgrad16Args a) {
     }
     const float inv_gw = 1.f / (float)d.gridW, inv_gh = 1.f / (float)d.gridH;
 
-    u32x4 ry[NP], rx[NP];
-    auto load_row = [&](int p) {
+    // A chunk's compute (a few hundred MFMA cycles) is far shorter than a global load's latency, so the loads run
+    // WDEPTH - 1 chunks ahead through a ring of register sets (chunk c in set c % WDEPTH); the wait in front of a
+    // set's LDS write is a counted vmcnt that leaves the younger sets' loads in flight.
+    // The loop is branch-free (hipcc keeps counted waits only along straight-line code): every block runs a multiple
+    // of WDEPTH chunks, the ones beyond its slice load nothing (masked like rows beyond the last image) and add zeros.
+    u32x4 ry[WDEPTH][NP], rx[WDEPTH][NP];
+    int lc = c_begin;           // chunk the next load_chunk() fetches
+    auto load_row = [&](int k, int p) {
         const int b = pb[p], y = py[p], x = px[p];
-        const bool rv = b < d.B;
+        const bool rv = (b < d.B) & (lc < c_end);
         const int pix = (b * d.outH + y * d.osy + d.oy0) * d.outW + x * d.osx + d.ox0;
         const unsigned goff = ((unsigned)(pix * d.Cout + yco) * 2u) | ((unsigned)(rv & yv) - 1u);
-        ry[p] = __builtin_amdgcn_raw_buffer_load_b128(rs_g, (int)goff, 0, 0);
+        ry[k][p] = __builtin_amdgcn_raw_buffer_load_b128(rs_g, (int)goff, 0, 0);
         const int iy = y * d.isy + dy, ix = x * d.isx + dx;
         const unsigned ok = (unsigned)(rv & xtv) & (unsigned)((unsigned)iy < (unsigned)d.inH) &
                             (unsigned)((unsigned)ix < (unsigned)d.inW);
         const unsigned xoff = ((unsigned)(((b * d.inH + iy) * d.inW + ix) * d.Cin + xc8 * 8) * 2u) | (ok - 1u);
-        rx[p] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)xoff, 0, 0);
-        int nx = x + 32;                        // advance 32 pixels: exact floor((v + .5) / n) for these small integers
+        rx[k][p] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)xoff, 0, 0);
+        int nx = x + WPC;                       // advance one chunk: exact floor((v + .5) / n) for these small integers
         const int qx = (int)(((float)nx + 0.5f) * inv_gw);
         nx -= qx * d.gridW;
         int ny = y + qx;
@@ -530,11 +540,16 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const Wgrad16Args a) {
         ny -= qy * d.gridH;
         px[p] = nx; py[p] = ny; pb[p] = b + qy;
     };
-    auto store_rows = [&](int buf) {
+    auto load_chunk = [&](int k) {
+#pragma unroll
+        for (int p = 0; p < NP; ++p) load_row(k, p);
+        ++lc;
+    };
+    auto store_rows = [&](int buf, int k) {
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
-            if (ythread) *reinterpret_cast<u32x4*>(Ys + (buf * 32 + prow + RPP * p) * SY + unit * 8) = ry[p];
-            *reinterpret_cast<u32x4*>(Xs + (buf * 32 + prow + RPP * p) * SX + unit * 8) = rx[p];
+            if (ythread) *reinterpret_cast<u32x4*>(Ys + (buf * WPC + prow + RPP * p) * SY + unit * 8) = ry[k][p];
+            *reinterpret_cast<u32x4*>(Xs + (buf * WPC + prow + RPP * p) * SX + unit * 8) = rx[k][p];
         }
     };
 
@@ -556,44 +571,41 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const Wgrad16Args a) {
 #pragma unroll
             for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-    if (c_begin < c_end) {
 #pragma unroll
-        for (int p = 0; p < NP; ++p) load_row(p);
-        store_rows(0);
-    }
+    for (int k = 0; k < WDEPTH - 1; ++k) load_chunk(k);
+    store_rows(0, 0);
     __syncthreads();
-    for (int c = c_begin; c < c_end; ++c) {
-        const int buf = (c - c_begin) & 1;
-        const bool more = (c + 1) < c_end;
-        if (more) {
+    for (int c0 = c_begin; c0 < c_end; c0 += WDEPTH) {
 #pragma unroll
-            for (int p = 0; p < NP; ++p) load_row(p);
-        }
+        for (int k = 0; k < WDEPTH; ++k) {
+            const int buf = k & 1;                      // WDEPTH is even: chunk parity = k parity
+            load_chunk((k + WDEPTH - 1) % WDEPTH);      // that set went to LDS in the previous step
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
-            const __bf16* Yb = Ys + (buf * 32 + 16 * s) * SY + trY;
-            const __bf16* Xb = Xs + (buf * 32 + 16 * s) * SX + trX;
-            bf16x8_t af[TM], bf[TN];
+            for (int s = 0; s < WPC / 16; ++s) {
+                const __bf16* Yb = Ys + (buf * WPC + 16 * s) * SY + trY;
+                const __bf16* Xb = Xs + (buf * WPC + 16 * s) * SX + trX;
+                bf16x8_t af[TM], bf[TN];
 #pragma unroll
-            for (int i = 0; i < TM; ++i) {
-                const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64_t)(Yb + i * 32));
-                const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64_t)(Yb + i * 32 + 4 * SY));
-                af[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                for (int i = 0; i < TM; ++i) {
+                    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64_t)(Yb + i * 32));
+                    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64_t)(Yb + i * 32 + 4 * SY));
+                    af[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+#pragma unroll
+                for (int j = 0; j < TN; ++j) {
+                    const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64_t)(Xb + j * 32));
+                    const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64_t)(Xb + j * 32 + 4 * SX));
+                    bf[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
+#pragma unroll
+                for (int i = 0; i < TM; ++i)
+#pragma unroll
+                    for (int j = 0; j < TN; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
             }
-#pragma unroll
-            for (int j = 0; j < TN; ++j) {
-                const bf16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64_t)(Xb + j * 32));
-                const bf16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64_t)(Xb + j * 32 + 4 * SX));
-                bf[j] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
-            }
-#pragma unroll
-            for (int i = 0; i < TM; ++i)
-#pragma unroll
-                for (int j = 0; j < TN; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+            store_rows(buf ^ 1, (k + 1) % WDEPTH);
+            __syncthreads();
         }
-        if (more) store_rows(buf ^ 1);
-        __syncthreads();
     }
 
 #pragma unroll
@@ -612,7 +624,7 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const Wgrad16Args a) {
 template <int BCO, int BJ>
 int launch_wgrad16(Wgrad16Args& a, int splits_req, hipStream_t st) {
     static bool attr_set = false;
-    constexpr size_t lds = (size_t)2 * 32 * ((BCO + 32) + (BJ + 32)) * 2;
+    constexpr size_t lds = (size_t)2 * WPC * ((BCO + 32) + (BJ + 32)) * 2;
     auto kern = wgrad16_kernel<BCO, BJ>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
@@ -622,12 +634,12 @@ int launch_wgrad16(Wgrad16Args& a, int splits_req, hipStream_t st) {
     }
     a.tiles_co = (a.d.Cout + BCO - 1) / BCO;
     a.tiles_j = (a.Ktot + BJ - 1) / BJ;
-    const int total_chunks = (a.M + 31) / 32;
+    const int total_chunks = (a.M + WPC - 1) / WPC;
     int splits = splits_req;
     if (splits <= 0) {
         const int ntile = a.tiles_co * a.tiles_j;
         splits = (1024 + ntile - 1) / ntile;            // ~4 blocks per CU in flight
-        const int max_splits = (total_chunks + 15) / 16; // >= 16 chunks (512 pixels) per block
+        const int max_splits = (total_chunks + 7) / 8;   // >= 8 chunks (512 pixels) per block
         if (splits > max_splits) splits = max_splits;
         if (splits < 1) splits = 1;
     }
@@ -743,5 +755,7 @@ extern "C" int loans_wgrad_bf16s(const void* x, const void* gy, float* dw, const
     if (tile == LOANS_TILE_64x64) return launch_wgrad16<64, 64>(a, splits, st);
     if (tile == LOANS_TILE_128x128) return launch_wgrad16<128, 128>(a, splits, st);
     if (tile == LOANS_TILE_64x128) return launch_wgrad16<64, 128>(a, splits, st);
+    if (tile == LOANS_TILE_64x256) return launch_wgrad16<64, 256>(a, splits, st);
+    if (tile == LOANS_TILE_128x256) return launch_wgrad16<128, 256>(a, splits, st);
     return LOANS_EINVAL;
 }

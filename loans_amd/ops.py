@@ -224,6 +224,7 @@ AUTOTUNE = os.environ.get('LOANS_AUTOTUNE', '1') != '0'
 _FPROP_TILES = tuple(int(t) for t in os.environ.get('LOANS_FPROP_TILES', '1,2,3,4,6,17,18,19,20,22').split(','))
 _IGEMM_TILES = tuple(int(t) for t in os.environ.get('LOANS_DGRAD_TILES', '1,2,3,17,18,19').split(','))
 _WGRAD_TILES = (1, 3, 5)
+_WGRAD16_TILES = (1, 3, 5, 8, 9)
 _IGEMM16_TILES = tuple(int(t) for t in os.environ.get('LOANS_BF16S_TILES', '1,2,3,4,7').split(','))
 
 
@@ -473,7 +474,7 @@ def _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile):
             scratch = torch.empty(dw.numel(), device=x.device, dtype=torch.float32)
             check(wfn(_ptr(x), _ptr(gy), _ptr(scratch), C.byref(_with_flags(geo.fwd, fl, t)), splits,
                       _stream()), 'loans_wgrad[tune]')
-        tile = _tuned_tile(geo, ('bf16s_' if s16 else COMPUTE) + 'wgrad', run, _WGRAD_TILES)
+        tile = _tuned_tile(geo, ('bf16s_' if s16 else COMPUTE) + 'wgrad', run, _WGRAD16_TILES if s16 else _WGRAD_TILES)
     d = _with_flags(geo.fwd, fl, tile)
     check(wfn(_ptr(x), _ptr(gy), _ptr(dw), C.byref(d), splits, _stream()), 'loans_wgrad')
     if geo.dense:

@@ -44,7 +44,7 @@ CASES = [
 
 
 @pytest.mark.parametrize("case", CASES)
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 7])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 7, 5, 8, 9])     # 5, 8, 9: weight-gradient tiles
 def test_conv_bf16_storage(case, tile):
     from loans_amd import ops
     B, Cin, H, W, Cout, k, s, p = case
@@ -57,6 +57,7 @@ def test_conv_bf16_storage(case, tile):
     xd, wd = d16(_nhwc(x)), dev(_nhwc(w))
     y_ref, col = C.conv2d_fwd(x.astype(np.float64), wr.astype(np.float64), b.astype(np.float64), s, p)
     stats_r = ops.stats_buffer(Cout, 'cuda')
+    wtile, tile = tile, (tile if tile in (0, 1, 2, 3, 4, 7) else 0)
     y = ops.conv_fprop(xd, wd, geo, bias=dev(b), stats=stats_r, tile=tile)
     assert y.dtype == torch.bfloat16
     assert np.abs(_nchw(y) - y_ref).max() <= BF16_EPS * np.abs(y_ref).max()
@@ -83,18 +84,19 @@ def test_conv_bf16_storage(case, tile):
     if geo.dgrad_has_empty_class:       # strided 1x1: tap-less pixels only take the plain addend (as in fp32 storage)
         gx2 = ops.conv_dgrad(gyd, wd, geo, addend=d16(_nhwc(addx)), tile=tile)
         assert rel_err(_nchw(gx2), gx_ref + addx) < BF16_EPS
-        return
-    gx2 = ops.conv_dgrad(gyd, wd, geo, mask_ref=d16(_nhwc(ref_t)), addend=d16(_nhwc(addx)), tile=tile)
-    assert rel_err(_nchw(gx2), gx_ref * (ref_t > 0) + addx) < BF16_EPS
-    gx3 = ops.conv_dgrad(gyd, wd, geo, addend=d16(_nhwc(addx)), addend_mask_ref=d16(_nhwc(ref_t)), tile=tile)
-    assert rel_err(_nchw(gx3), gx_ref + addx * (ref_t > 0)) < BF16_EPS
+    else:
+        gx2 = ops.conv_dgrad(gyd, wd, geo, mask_ref=d16(_nhwc(ref_t)), addend=d16(_nhwc(addx)), tile=tile)
+        assert rel_err(_nchw(gx2), gx_ref * (ref_t > 0) + addx) < BF16_EPS
+        gx3 = ops.conv_dgrad(gyd, wd, geo, addend=d16(_nhwc(addx)), addend_mask_ref=d16(_nhwc(ref_t)), tile=tile)
+        assert rel_err(_nchw(gx3), gx_ref + addx * (ref_t > 0)) < BF16_EPS
 
     # weight gradient: bf16 operands, fp32 accumulation into the fp32 gradient
-    if tile in (0, 1, 3):
+    if wtile in (0, 1, 3, 5, 8, 9):
         dw = torch.zeros_like(wd)
-        ops._conv_wgrad(xd, gyd, dw, geo, False, 0, tile)
+        ops._conv_wgrad(xd, gyd, dw, geo, False, 0, wtile)
+        ops._conv_wgrad(xd, gyd, dw, geo, False, 3, wtile)          # accumulates; explicit split count
         assert dw.dtype == torch.float32
-        assert rel_err(dw.cpu().numpy().transpose(0, 3, 1, 2), gw_ref) < 1e-5
+        assert rel_err(dw.cpu().numpy().transpose(0, 3, 1, 2), 2 * gw_ref) < 1e-5
 
 
 def test_bn_passes_bf16_storage():
