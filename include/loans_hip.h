@@ -51,6 +51,10 @@ extern "C" {
                                  tap t is the run of Cin consecutive floats at row y*isy + dy[t], float x*isx + dx[t]; w is
                                  [Cout][ntaps][Cin].  No bounds masks: every run must lie inside its row (checked). */
 
+#define LOANS_F_OUT_BF16 128   /* loans_igemm_bf16_f32 only: `out` is a bf16 tensor (fp32 in, bf16 out: the stem conv of the bf16
+                                  storage arm); not with MASK / ADDEND */
+#define LOANS_F_GY_BF16  256   /* loans_wgrad_bf16_f32 only: `gy` is a bf16 tensor, x stays fp32 (the stem's weight gradient) */
+
 /*
  * One implicit-GEMM problem:  out[m][n] = sum_{t<ntaps} sum_{c<Cin} in[pix(m,t)][c] * w[n][t][c]
  * m enumerates (b, y, x) over B x gridH x gridW;
@@ -176,16 +180,15 @@ int loans_maxpool_relu_bwd_f32(const float* gy, const uint8_t* idx, const float*
                                const float* shift, float* gx,
                                int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream);
 
-/* the same three passes on bf16 tensors (x, x2, y / gy, idx as above; coefficients fp32); the stem's pool writes bf16
- * from its fp32 conv output, its backward reads a bf16 gradient and writes the fp32 one the stem's BN / wgrad consume */
+/* the same three passes on bf16 tensors (x, x2, y / gy, gx, idx as above; coefficients fp32) */
 int loans_bn_apply_bf16(const void* x, const float* scale, const float* shift,
                         const void* x2, const float* scale2, const float* shift2,
                         void* y, int64_t rows, int32_t C, int32_t mode, int32_t relu, void* stream);
-int loans_bn_relu_maxpool_f32_bf16(const float* x, const float* scale, const float* shift, void* y, uint8_t* idx,
-                                   int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream);
-int loans_maxpool_relu_bwd_bf16_f32(const void* gy, const uint8_t* idx, const float* x, const float* scale,
-                                    const float* shift, float* gx,
-                                    int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream);
+int loans_bn_relu_maxpool_bf16(const void* x, const float* scale, const float* shift, void* y, uint8_t* idx,
+                               int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream);
+int loans_maxpool_relu_bwd_bf16(const void* gy, const uint8_t* idx, const void* x, const float* scale,
+                                const float* shift, void* gx,
+                                int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream);
 
 /* backward reductions: sums[0][c] += sum g, sums[1][c] += sum g*xhat  with g = gy*(mask>0) (mask may be
  * NULL), xhat = (x-mean)*rstd. If x2 != NULL also sums[2], sums[3] for (x2, mean2, rstd2). */
@@ -214,6 +217,7 @@ int loans_bn_bwd_apply_bf16(const void* gy, const void* mask, const void* x,
 /* ---- small dense ops ---- */
 /* out[c] += sum_rows x[row][c]   (conv bias gradient) */
 int loans_colsum_f32(const float* x, float* out, int64_t rows, int32_t C, void* stream);
+int loans_colsum_bf16(const void* x, float* out, int64_t rows, int32_t C, void* stream);
 /* _global_average_pooling_2d (sheep_localizer.py:58): x [B][HW][C] -> y [B][C] ; backward broadcast */
 int loans_gap_fwd_f32(const float* x, float* y, int32_t B, int32_t HW, int32_t C, void* stream);
 int loans_gap_bwd_f32(const float* gy, float* gx, int32_t B, int32_t HW, int32_t C, void* stream);

@@ -14,6 +14,7 @@ LIB_PATH = os.path.join(_HERE, 'csrc', 'libloans_hip.so')
 MAX_TAPS = 64
 F_RELU_IN, F_BIAS, F_STATS, F_MASK, F_ADDEND, F_ADDEND_MASK = 1, 2, 4, 8, 16, 32
 F_DENSE = 64
+F_OUT_BF16, F_GY_BF16 = 128, 256
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_256x64 = 0, 1, 2, 3, 4
 TILE_256x128, TILE_DMA = 7, 16
 
@@ -44,10 +45,11 @@ SIGNATURES = {
     'loans_cast_bf16': [_p, _p, _i64, _p],
     'loans_repack_dgrad_bf16': [_p, _p, _i32, _i32, _i32, C.POINTER(_i32), _i32, _p],
     'loans_bn_apply_bf16': [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p],
-    'loans_bn_relu_maxpool_f32_bf16': [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p],
-    'loans_maxpool_relu_bwd_bf16_f32': [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p],
+    'loans_bn_relu_maxpool_bf16': [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p],
+    'loans_maxpool_relu_bwd_bf16': [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p],
     'loans_bn_bwd_reduce_bf16': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p],
     'loans_bn_bwd_apply_bf16': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p],
+    'loans_colsum_bf16': [_p, _p, _i64, _i32, _p],
     'loans_gap_fwd_bf16_f32': [_p, _p, _i32, _i32, _i32, _p],
     'loans_gap_bwd_f32_bf16': [_p, _p, _i32, _i32, _i32, _p],
     'loans_dgrad_c4_f32': [_p, _p, _p, _p, _p, C.POINTER(IgemmDesc), C.POINTER(_i32), _i32, _p],

@@ -73,7 +73,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* x, const float* 
 }
 
 template <typename TO>
-__global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const float* x, const float* scale, const float* shift,
+__global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const TO* x, const float* scale, const float* shift,
                                                               TO* y, uint8_t* idx, int B, int H, int W, int C4,
                                                               int OH, int OW) {
     const int64_t total = (int64_t)B * OH * OW * C4;
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const float* x, co
             for (int q = 0; q < 3; ++q) {
                 const int iw = ow * 2 + q;
                 if (iw >= W) continue;
-                f32x4 v = relu4(ld4(x + (((int64_t)b * H + ih) * W + iw) * C4 * 4 + c4 * 4) * s + t);
+                f32x4 v = relu4(io4<TO>::ld(x + (((int64_t)b * H + ih) * W + iw) * C4 * 4 + c4 * 4) * s + t);
                 const int k = r * 3 + q;
                 if (v.x > best.x) { best.x = v.x; a0 = k; }
                 if (v.y > best.y) { best.y = v.y; a1 = k; }
@@ -108,8 +108,8 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const float* x, co
 }
 
 template <typename TG>
-__global__ __launch_bounds__(256) void maxpool_relu_bwd_kernel(const TG* gy, const uint8_t* idx, const float* x,
-                                                               const float* scale, const float* shift, float* gx,
+__global__ __launch_bounds__(256) void maxpool_relu_bwd_kernel(const TG* gy, const uint8_t* idx, const TG* x,
+                                                               const float* scale, const float* shift, TG* gx,
                                                                int B, int H, int W, int C4, int OH, int OW) {
     const int64_t total = (int64_t)B * H * W * C4;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -132,8 +132,8 @@ __global__ __launch_bounds__(256) void maxpool_relu_bwd_kernel(const TG* gy, con
                 if (a.z == k) g.z += gv.z;
                 if (a.w == k) g.w += gv.w;
             }
-        const f32x4 pre = ld4(x + i * 4) * ld4(scale + c4 * 4) + ld4(shift + c4 * 4);
-        st4(gx + i * 4, maskpos4(g, pre));
+        const f32x4 pre = io4<TG>::ld(x + i * 4) * ld4(scale + c4 * 4) + ld4(shift + c4 * 4);
+        io4<TG>::st(gx + i * 4, maskpos4(g, pre));
     }
 }
 
@@ -217,7 +217,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* gy, const T*
     }
 }
 
-__global__ __launch_bounds__(256) void colsum_kernel(const float* x, float* out, int64_t rows, int C4, int C4T, int rows_per_block) {
+template <typename T>
+__global__ __launch_bounds__(256) void colsum_kernel(const T* x, float* out, int64_t rows, int C4, int C4T, int rows_per_block) {
     __shared__ f32x4 red[256];
     const int tid = threadIdx.x;
     const int cl = tid % C4, rl = tid / C4, RL = 256 / C4;
@@ -227,7 +228,7 @@ __global__ __launch_bounds__(256) void colsum_kernel(const float* x, float* out,
     if (r1 > rows) r1 = rows;
     f32x4 s = {0.f, 0.f, 0.f, 0.f};
     if (rl < RL)
-        for (int64_t r = r0 + rl; r < r1; r += RL) s += ld4(x + (r * C4T + cg) * 4);
+        for (int64_t r = r0 + rl; r < r1; r += RL) s += io4<T>::ld(x + (r * C4T + cg) * 4);
     red[tid] = s;
     __syncthreads();
     if (tid < C4) {
@@ -313,7 +314,7 @@ extern "C" int loans_bn_apply_bf16(const void* x, const float* scale, const floa
 }
 
 template <typename TO>
-static int bn_relu_maxpool_impl(const float* x, const float* scale, const float* shift, TO* y, uint8_t* idx,
+static int bn_relu_maxpool_impl(const TO* x, const float* scale, const float* shift, TO* y, uint8_t* idx,
                                 int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream) {
     if (!x || !scale || !shift || !y || !idx || B <= 0 || H < 3 || W < 3 || C <= 0 || (C & 3)) return LOANS_EINVAL;
     if (OH != (H - 2) / 2 + 1 || OW != (W - 2) / 2 + 1) return LOANS_EINVAL;   // cover_all out size, k=3 s=2 p=0
@@ -329,14 +330,14 @@ extern "C" int loans_bn_relu_maxpool_f32(const float* x, const float* scale, con
     return bn_relu_maxpool_impl<float>(x, scale, shift, y, idx, B, H, W, C, OH, OW, stream);
 }
 
-extern "C" int loans_bn_relu_maxpool_f32_bf16(const float* x, const float* scale, const float* shift, void* y, uint8_t* idx,
-                                              int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream) {
-    return bn_relu_maxpool_impl<__bf16>(x, scale, shift, static_cast<__bf16*>(y), idx, B, H, W, C, OH, OW, stream);
+extern "C" int loans_bn_relu_maxpool_bf16(const void* x, const float* scale, const float* shift, void* y, uint8_t* idx,
+                                          int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream) {
+    return bn_relu_maxpool_impl<__bf16>(static_cast<const __bf16*>(x), scale, shift, static_cast<__bf16*>(y), idx, B, H, W, C, OH, OW, stream);
 }
 
 template <typename TG>
-static int maxpool_relu_bwd_impl(const TG* gy, const uint8_t* idx, const float* x, const float* scale,
-                                 const float* shift, float* gx, int32_t B, int32_t H, int32_t W, int32_t C,
+static int maxpool_relu_bwd_impl(const TG* gy, const uint8_t* idx, const TG* x, const float* scale,
+                                 const float* shift, TG* gx, int32_t B, int32_t H, int32_t W, int32_t C,
                                  int32_t OH, int32_t OW, void* stream) {
     if (!gy || !idx || !x || !scale || !shift || !gx || B <= 0 || H < 3 || W < 3 || C <= 0 || (C & 3)) return LOANS_EINVAL;
     if (OH != (H - 2) / 2 + 1 || OW != (W - 2) / 2 + 1) return LOANS_EINVAL;
@@ -353,10 +354,11 @@ extern "C" int loans_maxpool_relu_bwd_f32(const float* gy, const uint8_t* idx, c
     return maxpool_relu_bwd_impl<float>(gy, idx, x, scale, shift, gx, B, H, W, C, OH, OW, stream);
 }
 
-extern "C" int loans_maxpool_relu_bwd_bf16_f32(const void* gy, const uint8_t* idx, const float* x, const float* scale,
-                                               const float* shift, float* gx, int32_t B, int32_t H, int32_t W, int32_t C,
-                                               int32_t OH, int32_t OW, void* stream) {
-    return maxpool_relu_bwd_impl<__bf16>(static_cast<const __bf16*>(gy), idx, x, scale, shift, gx, B, H, W, C, OH, OW, stream);
+extern "C" int loans_maxpool_relu_bwd_bf16(const void* gy, const uint8_t* idx, const void* x, const float* scale,
+                                           const float* shift, void* gx, int32_t B, int32_t H, int32_t W, int32_t C,
+                                           int32_t OH, int32_t OW, void* stream) {
+    return maxpool_relu_bwd_impl<__bf16>(static_cast<const __bf16*>(gy), idx, static_cast<const __bf16*>(x), scale, shift,
+                                         static_cast<__bf16*>(gx), B, H, W, C, OH, OW, stream);
 }
 
 template <typename T>
@@ -440,7 +442,16 @@ extern "C" int loans_colsum_f32(const float* x, float* out, int64_t rows, int32_
     if (!x || !out || rows <= 0 || !reduce_channels_ok(C)) return LOANS_EINVAL;
     int rpb, c4b, slabs;
     const int grid = reduce_geometry(rows, C, &rpb, &c4b, &slabs);
-    hipLaunchKernelGGL(colsum_kernel, dim3(grid, slabs), dim3(256), 0, as_stream(stream), x, out, rows, c4b, C / 4, rpb);
+    hipLaunchKernelGGL(colsum_kernel<float>, dim3(grid, slabs), dim3(256), 0, as_stream(stream), x, out, rows, c4b, C / 4, rpb);
+    LOANS_LAUNCH_CHECK();
+    return LOANS_OK;
+}
+
+extern "C" int loans_colsum_bf16(const void* x, float* out, int64_t rows, int32_t C, void* stream) {
+    if (!x || !out || rows <= 0 || !reduce_channels_ok(C)) return LOANS_EINVAL;
+    int rpb, c4b, slabs;
+    const int grid = reduce_geometry(rows, C, &rpb, &c4b, &slabs);
+    hipLaunchKernelGGL(colsum_kernel<__bf16>, dim3(grid, slabs), dim3(256), 0, as_stream(stream), static_cast<const __bf16*>(x), out, rows, c4b, C / 4, rpb);
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;
 }

@@ -163,7 +163,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
             if (m < a.M) {
                 const int iy0 = y * d.isy, ix0 = x * d.isx;
                 rowoff[i] = (unsigned)((b * d.inH + iy0) * d.inW + ix0) * (unsigned)ubytes;
-                pixoff = (unsigned)((b * d.outH + y * d.osy + d.oy0) * d.outW + x * d.osx + d.ox0) * (unsigned)d.Cout * 4u;
+                pixoff = (unsigned)((b * d.outH + y * d.osy + d.oy0) * d.outW + x * d.osx + d.ox0) * (unsigned)d.Cout *
+                         ((d.flags & LOANS_F_OUT_BF16) ? 2u : 4u);
                 if (dense) {
                     mask = ~0ull;
                 } else if (a.ap.nx > 0) {
@@ -613,7 +614,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     const int oc4 = tid % CPR, r0 = tid / CPR;
     const int col0 = tn * BN + oc4 * 4;
     const unsigned cbad = (col0 + 3 < d.Cout) ? 0u : 0xFFFFFFFFu;     // Cout % 4 == 0 on every layer here
-    const unsigned coff = (unsigned)col0 * 4u;
+    const bool f_out16 = d.flags & LOANS_F_OUT_BF16;      // bf16 output tensor (no ref / addend in this mode: checked)
+    const unsigned coff = (unsigned)col0 * (f_out16 ? 2u : 4u);
     f32x4 bv4 = {0.f, 0.f, 0.f, 0.f};
     if (f_bias && !cbad) bv4 = *reinterpret_cast<const f32x4*>(a.bias + col0);
 #pragma unroll
@@ -642,6 +644,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
 #ifdef LOANS_EXPERIMENT
         if ((a.dbg & 8) && v.x != 12345.f) continue;      // no output stores
 #endif
+        if (f_out16) {
+            typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, __builtin_convertvector(v, bf16x4_t)), rs_out, (int)off, 0, 0);
+            continue;
+        }
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_out, (int)off, 0, 0);
     }
 #ifdef LOANS_STAMPS
@@ -746,6 +753,7 @@ static int igemm_impl(const float* in, const float* w, float* out, const float* 
     if ((d->flags & (LOANS_F_MASK | LOANS_F_ADDEND_MASK)) && !ref) return LOANS_EINVAL;
     if ((d->flags & LOANS_F_ADDEND_MASK) && !(d->flags & LOANS_F_ADDEND)) return LOANS_EINVAL;
     if ((d->flags & LOANS_F_ADDEND) && !addend) return LOANS_EINVAL;
+    if ((d->flags & LOANS_F_OUT_BF16) && (d->flags & (LOANS_F_MASK | LOANS_F_ADDEND | LOANS_F_ADDEND_MASK))) return LOANS_EINVAL;
     IgemmArgs a;
     a.in = in; a.w = w; a.out = out; a.bias = bias; a.stats = stats; a.ref = ref; a.addend = addend;
     a.d = *d;
@@ -762,7 +770,7 @@ static int igemm_impl(const float* in, const float* w, float* out, const float* 
     {
         const int64_t ib = (int64_t)d->B * d->inH * d->inW * ((d->flags & LOANS_F_DENSE) ? 1 : d->Cin) * 4;
         const int64_t wb = (int64_t)d->Cout * a.Ktot * 4;
-        const int64_t ob = (int64_t)d->B * d->outH * d->outW * d->Cout * 4;
+        const int64_t ob = (int64_t)d->B * d->outH * d->outW * d->Cout * ((d->flags & LOANS_F_OUT_BF16) ? 2 : 4);
         if (ib >= 0xFFFFFFF0ll || wb >= 0xFFFFFFF0ll || ob >= 0xFFFFFFF0ll) return LOANS_ERANGE;   // 32-bit buffer offsets
         a.in_bytes = (unsigned)ib;
         a.w_bytes = (unsigned)wb;
@@ -846,7 +854,9 @@ struct WgradArgs {
 
 // BF16 = true: fragments are packed to bf16 after the (fp32, conflict-free) LDS reads and contracted on the
 // 32x32x16 bf16 MFMA; staging and accumulation stay fp32.
-template <int BCO, int BJ, bool RELU, bool BF16>   // BCO (output channels) x BJ (tap-channel columns) block tile, 4 waves as 2 x 2
+// GY16 = true (LOANS_F_GY_BF16, the stem of the bf16-storage arm): gy is a bf16 tensor; a thread fetches its four
+// channels as 8 bytes and widens them while staging, the LDS image and everything behind it are unchanged.
+template <int BCO, int BJ, bool RELU, bool BF16, bool GY16 = false>   // BCO (output channels) x BJ (tap-channel columns) block tile, 4 waves as 2 x 2
 __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
     static_assert(BCO <= BJ, "the loader's thread map follows the wider (X) tile");
     constexpr int TM = BCO / 2 / 32, TN = BJ / 2 / 32;   // MFMA tiles per wave
@@ -910,8 +920,12 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
         const int b = pb[p], y = py[p], x = px[p];
         const bool rv = b < d.B;
         const int pix = (b * d.outH + y * d.osy + d.oy0) * d.outW + x * d.osx + d.ox0;
-        const unsigned goff = ((unsigned)(pix * d.Cout + yco) * 4u) | ((unsigned)(rv & yv) - 1u);
-        ry[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_g, (int)goff, 0, 0));
+        const unsigned goff = ((unsigned)(pix * d.Cout + yco) * (GY16 ? 2u : 4u)) | ((unsigned)(rv & yv) - 1u);
+        if constexpr (GY16) {
+            ry[p] = __builtin_convertvector(__builtin_bit_cast(bf16x4_t, __builtin_amdgcn_raw_buffer_load_b64(rs_g, (int)goff, 0, 0)), f32x4);
+        } else {
+            ry[p] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_g, (int)goff, 0, 0));
+        }
         const int iy = y * d.isy + dy, ix = x * d.isx + dx;
         const unsigned ok = (unsigned)(rv & xtv) & (unsigned)((unsigned)iy < (unsigned)d.inH) &
                             (unsigned)((unsigned)ix < (unsigned)d.inW);
@@ -1066,11 +1080,11 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
         }
 }
 
-template <int BCO, int BJ, bool RELU, bool BF16>
+template <int BCO, int BJ, bool RELU, bool BF16, bool GY16 = false>
 int launch_wgrad_r(WgradArgs& a, int splits_req, hipStream_t st) {
     static bool attr_set = false;
     constexpr size_t lds = (size_t)2 * 32 * (BCO + BJ) * 4;
-    auto kern = wgrad_kernel<BCO, BJ, RELU, BF16>;
+    auto kern = wgrad_kernel<BCO, BJ, RELU, BF16, GY16>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -1100,6 +1114,7 @@ int launch_wgrad_r(WgradArgs& a, int splits_req, hipStream_t st) {
 template <int BCO, int BJ>
 int launch_wgrad(WgradArgs& a, int splits_req, hipStream_t st) {
     const bool relu = a.d.flags & LOANS_F_RELU_IN;
+    if (a.d.flags & LOANS_F_GY_BF16) return (relu || !a.bf16) ? LOANS_EINVAL : launch_wgrad_r<BCO, BJ, false, true, true>(a, splits_req, st);
     if (a.bf16) return relu ? launch_wgrad_r<BCO, BJ, true, true>(a, splits_req, st) : launch_wgrad_r<BCO, BJ, false, true>(a, splits_req, st);
     return relu ? launch_wgrad_r<BCO, BJ, true, false>(a, splits_req, st) : launch_wgrad_r<BCO, BJ, false, false>(a, splits_req, st);
 }
@@ -1143,7 +1158,7 @@ static int wgrad_impl(const float* x, const float* gy, float* dw, const loans_ig
     a.Ktot = d->ntaps * d->Cin;
     {
         const int64_t xb = (int64_t)d->B * d->inH * d->inW * ((d->flags & LOANS_F_DENSE) ? 1 : d->Cin) * 4;
-        const int64_t gb = (int64_t)d->B * d->outH * d->outW * d->Cout * 4;
+        const int64_t gb = (int64_t)d->B * d->outH * d->outW * d->Cout * ((d->flags & LOANS_F_GY_BF16) ? 2 : 4);
         if (xb >= 0xFFFFFFF0ll || gb >= 0xFFFFFFF0ll) return LOANS_ERANGE;
         a.x_bytes = (unsigned)xb;
         a.gy_bytes = (unsigned)gb;

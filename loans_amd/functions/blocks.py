@@ -29,6 +29,8 @@ class _ConvBN:
 
     @staticmethod
     def forward(x, conv, bn, W, b, gamma, beta):
+        # the stem (fp32 frames) is where the bf16 region of ops.STORAGE == 'bf16' begins: its conv writes bf16
+        o16 = ops.STORAGE == 'bf16' and x.dtype == torch.float32
         B, H, Wd, _ = x.shape
         if conv.dense_rows:
             if not hasattr(x, 'frame_hw'):
@@ -37,10 +39,10 @@ class _ConvBN:
         geo = conv.geometry(B, H, Wd)
         if config.train:
             stats = _zeros_stats(conv.out_channels, x.device)
-            c = ops.conv_fprop(x, W, geo, bias=b, stats=stats)
+            c = ops.conv_fprop(x, W, geo, bias=b, stats=stats, out_bf16=o16)
             st = ops.bn_finalize(stats, B * geo.Ho * geo.Wo, gamma, beta, bn.avg_mean, bn.avg_var)
         else:
-            c = ops.conv_fprop(x, W, geo, bias=b)
+            c = ops.conv_fprop(x, W, geo, bias=b, out_bf16=o16)
             st = ops.bn_eval_coeffs(gamma, beta, bn.avg_mean, bn.avg_var)
         return c, st, geo
 

@@ -13,7 +13,8 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (F_ADDEND, F_ADDEND_MASK, F_BIAS, F_DENSE, F_MASK, F_RELU_IN, F_STATS, IgemmDesc, check)
+from ._lib import (F_ADDEND, F_ADDEND_MASK, F_BIAS, F_DENSE, F_GY_BF16, F_MASK, F_OUT_BF16, F_RELU_IN, F_STATS, IgemmDesc,
+                   check)
 
 # Arithmetic of the convolution contractions: 'f32' (exact fp32 MFMA, the parity path) or 'bf16' (operands rounded
 # to bf16 while staged into LDS, bf16 MFMA, fp32 accumulate; tensors stay fp32 in memory).  BASELINE configs 3 / 5.
@@ -272,14 +273,18 @@ def _igemm_launches(M, Cout, tile, device):
     return 2 if 0 < rows_big < M else 1
 
 
-def conv_fprop(x, w, geo, out=None, bias=None, stats=None, relu_in=False, addend=None, tile=0):
-    """out[B,Ho,Wo,Cout] = conv(x[B,H,W,Cin], w[Cout,k,k,Cin]) (+bias) (+addend); optional BN statistics."""
+def conv_fprop(x, w, geo, out=None, bias=None, stats=None, relu_in=False, addend=None, tile=0, out_bf16=False):
+    """out[B,Ho,Wo,Cout] = conv(x[B,H,W,Cin], w[Cout,k,k,Cin]) (+bias) (+addend); optional BN statistics.
+    out_bf16 (bf16 compute arm, fp32 input): write a bf16 tensor -- the stem conv of the bf16-storage arm."""
     lib = _lib.load()
     if _is16(x):
         return _conv_fprop16(lib, x, w, geo, out, bias, stats, relu_in, addend, tile)
+    if out_bf16:
+        assert COMPUTE == 'bf16' and addend is None and out is None
+        out = torch.empty((geo.B, geo.Ho, geo.Wo, geo.Cout), device=x.device, dtype=BF16)
     if out is None:
         out = torch.empty((geo.B, geo.Ho, geo.Wo, geo.Cout), device=x.device, dtype=torch.float32)
-    flags = (F_RELU_IN if relu_in else 0) | (F_BIAS if bias is not None else 0) | \
+    flags = (F_RELU_IN if relu_in else 0) | (F_BIAS if bias is not None else 0) | (F_OUT_BF16 if out_bf16 else 0) | \
             (F_STATS if stats is not None else 0) | (F_ADDEND if addend is not None else 0) | geo.base_flags
     assert x.numel() == geo.in_numel and w.numel() == geo.w_numel
     if tile == 0:
@@ -290,7 +295,7 @@ def conv_fprop(x, w, geo, out=None, bias=None, stats=None, relu_in=False, addend
             scratch = torch.empty((geo.B, geo.Ho, geo.Wo, geo.Cout), device=x.device, dtype=torch.float32)
             check(_igemm_fn(lib)(_ptr(x), _ptr(w), _ptr(scratch), 0, _ptr(sstats), 0, 0,
                                       C.byref(_with_flags(geo.fwd, tflags, t)), _stream()), 'loans_igemm_f32[tune]')
-        tile = _tuned_tile(geo, COMPUTE + 'fprop' + ('_stats' if stats is not None else ''), run, _FPROP_TILES)
+        tile = _tuned_tile(geo, COMPUTE + 'fprop' + ('_stats' if stats is not None else ''), run, _FPROP_TILES)   # fp32 scratch output: the tile choice carries over
     d = _with_flags(geo.fwd, flags, tile)
     log = EVENT_LOG
     if log is not None:
@@ -449,7 +454,8 @@ def join_side_stream(device=None):
 
 def conv_wgrad(x, gy, dw, geo, relu_in=False, splits=0, tile=0):
     """dw[Cout,k,k,Cin] += sum over pixels (atomic accumulate into the gradient arena)."""
-    if ASYNC_WGRAD and geo.tuned.get(('bf16s_' if _is16(x) else COMPUTE) + 'wgrad') is not None \
+    if ASYNC_WGRAD and geo.tuned.get(('bf16s_' if _is16(x) else COMPUTE) + ('g16' if _is16(gy) and not _is16(x) else '')
+                                     + 'wgrad') is not None \
             and not torch.cuda.is_current_stream_capturing():
         side = _side_stream(x.device)
         side.wait_stream(torch.cuda.current_stream(x.device))
@@ -467,14 +473,19 @@ def _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile):
     assert dw.numel() == geo.w_numel and x.numel() == geo.in_numel
     fl = (F_RELU_IN if relu_in else 0) | geo.base_flags
     s16 = _is16(x)
-    assert _is16(gy) == s16, 'x and gy must share their storage type'
+    if _is16(gy) and not s16:           # the stem of the bf16-storage arm: fp32 frames, bf16 gradient
+        assert COMPUTE == 'bf16'
+        fl |= F_GY_BF16
+    else:
+        assert _is16(gy) == s16, 'x and gy must share their storage type'
     wfn = lib.loans_wgrad_bf16s if s16 else (lib.loans_wgrad_bf16_f32 if COMPUTE == 'bf16' else lib.loans_wgrad_f32)
     if tile == 0:
         def run(t):
             scratch = torch.empty(dw.numel(), device=x.device, dtype=torch.float32)
             check(wfn(_ptr(x), _ptr(gy), _ptr(scratch), C.byref(_with_flags(geo.fwd, fl, t)), splits,
                       _stream()), 'loans_wgrad[tune]')
-        tile = _tuned_tile(geo, ('bf16s_' if s16 else COMPUTE) + 'wgrad', run, _WGRAD16_TILES if s16 else _WGRAD_TILES)
+        tile = _tuned_tile(geo, ('bf16s_' if s16 else COMPUTE) + ('g16' if fl & F_GY_BF16 else '') + 'wgrad', run,
+                           _WGRAD16_TILES if s16 else _WGRAD_TILES)
     d = _with_flags(geo.fwd, fl, tile)
     check(wfn(_ptr(x), _ptr(gy), _ptr(dw), C.byref(d), splits, _stream()), 'loans_wgrad')
     if geo.dense:
@@ -575,11 +586,11 @@ def bn_apply(x, st, relu=True, residual=None, x2=None, st2=None):
 def bn_relu_maxpool(x, st):
     B, H, W, C_ = x.shape
     OH, OW = conv_outsize(H, 3, 2, 0, True), conv_outsize(W, 3, 2, 0, True)
-    s16 = STORAGE == 'bf16'          # the stem's pool is where the bf16 region begins
-    y = torch.empty((B, OH, OW, C_), device=x.device, dtype=BF16 if s16 else torch.float32)
+    s16 = _is16(x)
+    y = torch.empty((B, OH, OW, C_), device=x.device, dtype=x.dtype)
     idx = torch.empty((B, OH, OW, C_), device=x.device, dtype=torch.uint8)
     lib = _lib.load()
-    fn = lib.loans_bn_relu_maxpool_f32_bf16 if s16 else lib.loans_bn_relu_maxpool_f32
+    fn = lib.loans_bn_relu_maxpool_bf16 if s16 else lib.loans_bn_relu_maxpool_f32
     check(fn(_ptr(x), _ptr(st.scale), _ptr(st.shift), _ptr(y), _ptr(idx), B, H, W, C_, OH, OW, _stream()),
           'loans_bn_relu_maxpool')
     return y, idx
@@ -590,7 +601,8 @@ def maxpool_relu_bwd(gy, idx, x, st):
     OH, OW = gy.shape[1], gy.shape[2]
     gx = torch.empty_like(x)
     lib = _lib.load()
-    fn = lib.loans_maxpool_relu_bwd_bf16_f32 if _is16(gy) else lib.loans_maxpool_relu_bwd_f32
+    assert gy.dtype == x.dtype
+    fn = lib.loans_maxpool_relu_bwd_bf16 if _is16(gy) else lib.loans_maxpool_relu_bwd_f32
     check(fn(_ptr(gy), _ptr(idx), _ptr(x), _ptr(st.scale), _ptr(st.shift), _ptr(gx), B, H, W, C_, OH, OW, _stream()),
           'loans_maxpool_relu_bwd')
     return gx
@@ -630,7 +642,9 @@ def bn_backward(gy, mask, x, st, gamma, ggamma, gbeta, x2=None, st2=None, gamma2
 
 def colsum_acc(x, out):
     C_ = x.shape[-1]
-    check(_lib.load().loans_colsum_f32(_ptr(x), _ptr(out), x.numel() // C_, C_, _stream()), 'loans_colsum_f32')
+    lib = _lib.load()
+    fn = lib.loans_colsum_bf16 if _is16(x) else lib.loans_colsum_f32
+    check(fn(_ptr(x), _ptr(out), x.numel() // C_, C_, _stream()), 'loans_colsum')
 
 
 # --------------------------------------------------------------------------- #

@@ -143,32 +143,55 @@ def test_bn_passes_bf16_storage():
 
 
 def test_region_boundaries_bf16_storage():
-    """where the bf16 region begins and ends: the stem's pool (fp32 conv output -> bf16 pooled activations, argmax
-    unchanged), its backward (bf16 gradient -> fp32), global average pooling (bf16 -> fp32 features, fp32 -> bf16)"""
+    """where the bf16 region begins and ends: the stem (fp32 frames -> bf16 conv output with fp32 statistics; pool and
+    its backward on bf16; weight gradient from fp32 frames and a bf16 gradient; bias gradient) and global average
+    pooling (bf16 -> fp32 features, fp32 -> bf16 gradient)"""
     from loans_amd import ops
     rng = np.random.RandomState(6)
+    # --- pool forward / backward on bf16 against the fp32 kernels on the same (rounded) values
     B, H, W, Cc = 2, 13, 12, 64
-    x = rng.standard_normal((B, H, W, Cc)).astype(np.float32)
+    x = _r(rng.standard_normal((B, H, W, Cc)))
     stats = torch.zeros((ops.STATS_REPLICAS, 2, Cc), device='cuda', dtype=torch.float64)
     flat = torch.from_numpy(x.reshape(-1, Cc).astype(np.float64)).cuda()
     stats[0, 0], stats[0, 1] = flat.sum(0), (flat * flat).sum(0)
     st = ops.bn_finalize(stats, B * H * W, dev(np.ones(Cc, np.float32)), dev(np.zeros(Cc, np.float32)),
                          dev(np.zeros(Cc, np.float32)), dev(np.ones(Cc, np.float32)))
     y32, idx32 = ops.bn_relu_maxpool(dev(x), st)
-    ops.set_compute_dtype('bf16')
-    ops.set_storage_dtype('bf16')
-    try:
-        y16, idx16 = ops.bn_relu_maxpool(dev(x), st)
-    finally:
-        ops.set_compute_dtype('f32')
+    y16, idx16 = ops.bn_relu_maxpool(d16(x), st)
     assert y16.dtype == torch.bfloat16 and torch.equal(idx16, idx32)
     assert torch.equal(y16, y32.to(torch.bfloat16))                 # the fp32 result, rounded once
     gy = _r(rng.standard_normal(tuple(y32.shape)))
     g32 = ops.maxpool_relu_bwd(dev(gy), idx32, dev(x), st)
-    g16 = ops.maxpool_relu_bwd(d16(gy), idx32, dev(x), st)
-    assert g16.dtype == torch.float32 and torch.allclose(g16, g32, rtol=1e-6, atol=1e-6)
+    g16 = ops.maxpool_relu_bwd(d16(gy), idx32, d16(x), st)
+    assert g16.dtype == torch.bfloat16 and torch.equal(g16, g32.to(torch.bfloat16))
+    cs32, cs16 = torch.zeros(Cc, device='cuda'), torch.zeros(Cc, device='cuda')
+    ops.colsum_acc(dev(x), cs32)
+    ops.colsum_acc(d16(x), cs16)
+    assert torch.allclose(cs16, cs32, rtol=1e-5, atol=1e-4)
+    # --- global average pooling
     f = _r(rng.standard_normal((B, 7, 7, 512)))
     assert torch.allclose(ops.gap_fwd(d16(f)), ops.gap_fwd(dev(f)), rtol=1e-6, atol=1e-6)
     gf = rng.standard_normal((B, 512)).astype(np.float32)
     g16 = ops.gap_bwd(dev(gf), (B, 7, 7, 512), torch.bfloat16)
     assert torch.equal(g16, ops.gap_bwd(dev(gf), (B, 7, 7, 512)).to(torch.bfloat16))
+    # --- stem conv (dense-row fp32 frames) with a bf16 output, and its weight gradient from a bf16 gradient
+    Bs, Hs = 2, 32
+    frames = rng.uniform(0, 1, (Bs, 3, Hs, Hs)).astype(np.float32)
+    geo = ops.ConvGeometry(Bs, Hs, Hs, 3, 64, 7, 2, 3, dense=True)
+    xp = ops.prep_images(dev(frames), geo)
+    wd = dev((0.05 * rng.standard_normal((64, 7, geo.kwp, 3))).astype(np.float32))
+    bias = dev(rng.standard_normal(64).astype(np.float32))
+    ops.set_compute_dtype('bf16')
+    try:
+        s32, s16 = ops.stats_buffer(64, 'cuda'), ops.stats_buffer(64, 'cuda')
+        c32 = ops.conv_fprop(xp, wd, geo, bias=bias, stats=s32, tile=3)
+        c16 = ops.conv_fprop(xp, wd, geo, bias=bias, stats=s16, tile=3, out_bf16=True)
+        assert c16.dtype == torch.bfloat16 and torch.equal(c16, c32.to(torch.bfloat16))
+        assert torch.equal(s16, s32)
+        gc = _r(rng.standard_normal(tuple(c32.shape)))
+        dw32, dw16 = torch.zeros_like(wd), torch.zeros_like(wd)
+        ops._conv_wgrad(xp, dev(gc), dw32, geo, False, 0, 3)
+        ops._conv_wgrad(xp, d16(gc), dw16, geo, False, 0, 3)
+        assert rel_err(dw16.cpu().numpy(), dw32.cpu().numpy()) < 1e-5
+    finally:
+        ops.set_compute_dtype('f32')

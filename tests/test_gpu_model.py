@@ -399,8 +399,10 @@ def test_bf16_compute_step_against_oracle():
 
 def test_bf16_storage_step_against_oracle():
     """bf16 STORAGE arm (set_storage_dtype('bf16')): the localizer's stage activations and gradients live in bf16.
-    Forward lands within the same 3e-2 of the fp32 oracle as the compute-only arm, and the joint step (dgrad / wgrad
-    on bf16 tensors, fp32 gradient accumulation, Adam) runs end to end and moves the parameters."""
+    Every conv / BN pass then rounds its output to 8 significant bits once more than the compute-only arm does: theta
+    stays within the same 3e-2 of the fp32 oracle (measured 1.7e-2), a grid point is a sum of up to three theta entries
+    times coordinates in [-1, 1] (bound 6e-2, measured 3.3e-2), scores within 3e-2; the joint step (dgrad / wgrad on
+    bf16 tensors, fp32 gradient accumulation, Adam) runs end to end and moves the parameters."""
     B, H, W, crop = 4, 96, 96, (16, 16)
     frames, real, labels = inputs(42, B, H, W, crop)
     loc, dis = build_pair(41, crop)
@@ -420,7 +422,7 @@ def test_bf16_storage_step_against_oracle():
         dp_ = np.abs(points.data.cpu().numpy() - o_points).max()
         dy = np.abs(y_fake.data.cpu().numpy() - o_y).max()
         print('bf16 storage: |dtheta| %.2e |dpoints| %.2e |dscore| %.2e' % (dt, dp_, dy))
-        assert dt < 3e-2 and dp_ < 3e-2 and dy < 3e-2
+        assert dt < 3e-2 and dp_ < 6e-2 and dy < 3e-2
         rois.unchain_backward(); points.unchain_backward()
         w_before = loc.feature_extractor.res3[0].conv1.W.data.clone()
         for _ in range(2):
