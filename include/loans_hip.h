@@ -120,7 +120,7 @@ int loans_wgrad_bf16_f32(const float* x, const float* gy, float* dw,
 
 /* fprop / dgrad on bf16 tensors: in, w ([Cout][ntaps][Cin], see loans_cast_bf16 / loans_repack_dgrad_bf16), out, ref and
  * addend are bf16; bias and stats as in loans_igemm_f32 (statistics are taken from the fp32 accumulators, the output
- * is rounded to bf16 once).  Flags BIAS / STATS / MASK / ADDEND / ADDEND_MASK; tiles 128x128, 128x64, 64x64,
+ * is rounded to bf16 once).  Flags RELU_IN / BIAS / STATS / MASK / ADDEND / ADDEND_MASK; tiles 128x128, 128x64, 64x64,
  * 256x64, 256x128 (0 = auto).  Operand tiles are staged by LDS-DMA, contraction on v_mfma_f32_32x32x16_bf16. */
 int loans_igemm_bf16s(const void* in, const void* w, void* out, const float* bias, double* stats,
                       const void* ref, const void* addend, const loans_igemm_desc* d, void* stream);
@@ -137,6 +137,10 @@ int loans_repack_dgrad_bf16(const float* src, void* dst, int32_t Cout, int32_t C
  * loans_igemm_f32 (Cin = gy channels, Cout must be 4), flags MASK / ADDEND only. */
 int loans_dgrad_c4_f32(const float* gy, const float* w_ohwi, float* out, const float* ref, const float* addend,
                        const loans_igemm_desc* d, const int32_t* tapsel_host, int32_t src_taps, void* stream);
+
+/* same with a bf16 gradient tensor (the assessor's first block in the bf16-storage arm); w, out, ref, addend fp32 */
+int loans_dgrad_c4_bf16_f32(const void* gy, const float* w_ohwi, float* out, const float* ref, const float* addend,
+                            const loans_igemm_desc* d, const int32_t* tapsel_host, int32_t src_taps, void* stream);
 
 /* weight repack for dgrad: dst[ci][t][co] = src[co][tapsel[t]][ci]  (src is OHWI with `src_taps` taps) */
 int loans_repack_dgrad_f32(const float* src, float* dst, int32_t Cout, int32_t Cin, int32_t src_taps,
@@ -232,6 +236,12 @@ int loans_linear_fwd_f32(const float* x, const float* W, const float* b, float* 
 int loans_linear_bwd_f32(const float* x, const float* W, const float* y, const float* gy,
                          float* gx, float* gW, float* gb,
                          int32_t B, int32_t K, int32_t N, int32_t act_in, int32_t act_out, void* stream);
+/* the same layer with x (and gx) as bf16 tensors; W, y, gy, gW, gb fp32 */
+int loans_linear_fwd_bf16(const void* x, const float* W, const float* b, float* y,
+                          int32_t B, int32_t K, int32_t N, int32_t act_in, int32_t act_out, void* stream);
+int loans_linear_bwd_bf16(const void* x, const float* W, const float* y, const float* gy,
+                          void* gx, float* gW, float* gb,
+                          int32_t B, int32_t K, int32_t N, int32_t act_in, int32_t act_out, void* stream);
 /* y = x * mask (elementwise, n floats) -- RotationDropout forward/backward (functions/rotation_droput.py:26-48) */
 int loans_mul_f32(const float* x, const float* mask, float* y, int64_t n, void* stream);
 /* y = a*x + b*y */

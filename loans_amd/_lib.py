@@ -52,6 +52,9 @@ SIGNATURES = {
     'loans_colsum_bf16': [_p, _p, _i64, _i32, _p],
     'loans_gap_fwd_bf16_f32': [_p, _p, _i32, _i32, _i32, _p],
     'loans_gap_bwd_f32_bf16': [_p, _p, _i32, _i32, _i32, _p],
+    'loans_dgrad_c4_bf16_f32': [_p, _p, _p, _p, _p, C.POINTER(IgemmDesc), C.POINTER(_i32), _i32, _p],
+    'loans_linear_fwd_bf16': [_p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p],
+    'loans_linear_bwd_bf16': [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p],
     'loans_dgrad_c4_f32': [_p, _p, _p, _p, _p, C.POINTER(IgemmDesc), C.POINTER(_i32), _i32, _p],
     'loans_repack_dgrad_f32': [_p, _p, _i32, _i32, _i32, C.POINTER(_i32), _i32, _p],
     'loans_resize_lanczos_u8': [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _i32, _p, _p, _i32, _p],

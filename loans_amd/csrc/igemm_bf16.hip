@@ -43,6 +43,13 @@ __device__ __forceinline__ int xcd_remap16(int id, int nblk) {
     return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
 }
 
+// relu on packed bf16: as signed 16-bit integers the negative floats (and -0) are negative, so max(v, 0) is relu
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8_t relu_bf16x8(bf16x8_t v) {
+    const s16x8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+    return __builtin_bit_cast(bf16x8_t, __builtin_elementwise_max(__builtin_bit_cast(s16x8_t, v), z));
+}
+
 __device__ __forceinline__ f32x4 cvt_lo(bf16x8_t v) {
     return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]};
 }
@@ -59,7 +66,8 @@ constexpr size_t igemm16_aux_bytes() {      // offset of the tap table / row tab
 template <int BM, int BN>
 constexpr size_t igemm16_lds_bytes() { return igemm16_aux_bytes<BM, BN>() + LOANS_MAX_TAPS * 4 + BM * 4; }
 
-template <int BM, int BN, int WM, int WN>
+// RELU: gather relu(in) (LOANS_F_RELU_IN, the assessor's pre-activation convs): applied to the A fragments
+template <int BM, int BN, int WM, int WN, bool RELU>
 __global__ __launch_bounds__(256) void igemm16_kernel(const Igemm16Args a) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int RA = BM / 32, RB = BN / 32;
@@ -198,6 +206,12 @@ __global__ __launch_bounds__(256) void igemm16_kernel(const Igemm16Args a) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const bf16x8_t*>(Bb + j * 32 * BKH);
     };
+    auto relu_frag = [&](bf16x8_t (&af)[TM]) {
+        if constexpr (RELU) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = relu_bf16x8(af[i]);
+        }
+    };
 
     f32x16 acc[TM][TN];
 #pragma unroll
@@ -210,6 +224,7 @@ __global__ __launch_bounds__(256) void igemm16_kernel(const Igemm16Args a) {
         const int i = q / TN, j = q % TN;
         acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
     };
+    // (RELU) a fragment set is rectified once, right before its MFMAs
     auto mma = [&](const bf16x8_t (&af)[TM], const bf16x8_t (&bf)[TN]) {
 #pragma unroll
         for (int q = 0; q < NMMA; ++q) mma_one(q, af, bf);
@@ -228,6 +243,7 @@ __global__ __launch_bounds__(256) void igemm16_kernel(const Igemm16Args a) {
     for (; c + 1 < a.nchunks; ++c) {
         const int buf = c & 1;
         read_frag(buf, 1, fa1, fb1);
+        relu_frag(fa0);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < NMMA; ++q) {
@@ -237,6 +253,7 @@ __global__ __launch_bounds__(256) void igemm16_kernel(const Igemm16Args a) {
             __builtin_amdgcn_sched_barrier(0);
         }
         read_frag(buf, 2, fa0, fb0);
+        relu_frag(fa1);
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int q = 0; q < NMMA; ++q) {
@@ -246,9 +263,11 @@ __global__ __launch_bounds__(256) void igemm16_kernel(const Igemm16Args a) {
             __builtin_amdgcn_sched_barrier(0);
         }
         read_frag(buf, 3, fa1, fb1);
+        relu_frag(fa0);
         __builtin_amdgcn_sched_barrier(0);
         mma(fa0, fb0);
         __builtin_amdgcn_sched_barrier(0);
+        relu_frag(fa1);
         __syncthreads();
         read_frag(buf ^ 1, 0, fa0, fb0);
         __builtin_amdgcn_sched_barrier(0);
@@ -259,14 +278,17 @@ __global__ __launch_bounds__(256) void igemm16_kernel(const Igemm16Args a) {
         const int buf = c & 1;
         const int ts = (a.Ktot - (a.nchunks - 1) * BKH + 15) / 16;      // 1..4
         if (ts > 1) read_frag(buf, 1, fa1, fb1);
+        relu_frag(fa0);
         mma(fa0, fb0);
         if (ts > 1) {
             if (ts > 2) read_frag(buf, 2, fa0, fb0);
+            relu_frag(fa1);
             mma(fa1, fb1);
             if (ts > 2) {
                 if (ts > 3) read_frag(buf, 3, fa1, fb1);
+                relu_frag(fa0);
                 mma(fa0, fb0);
-                if (ts > 3) mma(fa1, fb1);
+                if (ts > 3) { relu_frag(fa1); mma(fa1, fb1); }
             }
         }
     }
@@ -370,12 +392,12 @@ __global__ __launch_bounds__(256) void igemm16_kernel(const Igemm16Args a) {
     }
 }
 
-template <int BM, int BN, int WM, int WN>
-int launch_igemm16(Igemm16Args& a, hipStream_t st) {
+template <int BM, int BN, int WM, int WN, bool RELU>
+int launch_igemm16_r(Igemm16Args& a, hipStream_t st) {
     static bool attr_set = false;
     constexpr size_t lds = igemm16_lds_bytes<BM, BN>();
     static_assert(lds <= 160 * 1024, "tile does not fit the LDS");
-    auto kern = igemm16_kernel<BM, BN, WM, WN>;
+    auto kern = igemm16_kernel<BM, BN, WM, WN, RELU>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -387,6 +409,11 @@ int launch_igemm16(Igemm16Args& a, hipStream_t st) {
     hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(256), lds, st, a);
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;
+}
+
+template <int BM, int BN, int WM, int WN>
+int launch_igemm16(Igemm16Args& a, hipStream_t st) {
+    return (a.d.flags & LOANS_F_RELU_IN) ? launch_igemm16_r<BM, BN, WM, WN, true>(a, st) : launch_igemm16_r<BM, BN, WM, WN, false>(a, st);
 }
 
 void detect_tap_grid16(const loans_igemm_desc* d, Igemm16Args& a) {
@@ -457,7 +484,7 @@ struct Wgrad16Args {
 constexpr int WPC = 32;     // pixels (reduction rows) per staged chunk
 constexpr int WDEPTH = 4;   // register sets: global loads run WDEPTH - 1 chunks ahead of the chunk being computed
 
-template <int BCO, int BJ>   // BCO (output channels) x BJ (tap-channel columns) block tile, 4 waves as 2 x 2
+template <int BCO, int BJ, bool RELU>   // BCO (output channels) x BJ (tap-channel columns) block tile, 4 waves as 2 x 2; RELU: relu(x)
 __global__ __launch_bounds__(256) void wgrad16_kernel(const Wgrad16Args a) {
     static_assert(BCO <= BJ, "the loader's thread map follows the wider (X) tile");
     static_assert(WDEPTH % 2 == 0, "LDS stage = chunk parity = register-set parity");
@@ -549,6 +576,7 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const Wgrad16Args a) {
 #pragma unroll
         for (int p = 0; p < NP; ++p) {
             if (ythread) *reinterpret_cast<u32x4*>(Ys + (buf * WPC + prow + RPP * p) * SY + unit * 8) = ry[k][p];
+            if constexpr (RELU) rx[k][p] = __builtin_bit_cast(u32x4, relu_bf16x8(__builtin_bit_cast(bf16x8_t, rx[k][p])));
             *reinterpret_cast<u32x4*>(Xs + (buf * WPC + prow + RPP * p) * SX + unit * 8) = rx[k][p];
         }
     };
@@ -621,11 +649,11 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const Wgrad16Args a) {
         }
 }
 
-template <int BCO, int BJ>
-int launch_wgrad16(Wgrad16Args& a, int splits_req, hipStream_t st) {
+template <int BCO, int BJ, bool RELU>
+int launch_wgrad16_r(Wgrad16Args& a, int splits_req, hipStream_t st) {
     static bool attr_set = false;
     constexpr size_t lds = (size_t)2 * WPC * ((BCO + 32) + (BJ + 32)) * 2;
-    auto kern = wgrad16_kernel<BCO, BJ>;
+    auto kern = wgrad16_kernel<BCO, BJ, RELU>;
     if (!attr_set) {
         hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
                                            hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
@@ -651,6 +679,11 @@ int launch_wgrad16(Wgrad16Args& a, int splits_req, hipStream_t st) {
     return LOANS_OK;
 }
 
+template <int BCO, int BJ>
+int launch_wgrad16(Wgrad16Args& a, int splits_req, hipStream_t st) {
+    return (a.d.flags & LOANS_F_RELU_IN) ? launch_wgrad16_r<BCO, BJ, true>(a, splits_req, st) : launch_wgrad16_r<BCO, BJ, false>(a, splits_req, st);
+}
+
 }  // namespace
 
 extern "C" int loans_igemm_bf16s(const void* in, const void* w, void* out, const float* bias, double* stats,
@@ -663,7 +696,7 @@ extern "C" int loans_igemm_bf16s(const void* in, const void* w, void* out, const
     if ((d->gridH - 1) * d->osy + d->oy0 >= d->outH) return LOANS_EINVAL;
     if ((d->gridW - 1) * d->osx + d->ox0 >= d->outW) return LOANS_EINVAL;
     if (d->ntaps < 1 || d->ntaps > LOANS_MAX_TAPS) return LOANS_EINVAL;
-    if (d->flags & (LOANS_F_DENSE | LOANS_F_RELU_IN)) return LOANS_EINVAL;       // fp32-storage layers only
+    if (d->flags & LOANS_F_DENSE) return LOANS_EINVAL;       // the RGB stem reads fp32 frames (loans_igemm_bf16_f32 + LOANS_F_OUT_BF16)
     if ((d->flags & LOANS_F_BIAS) && !bias) return LOANS_EINVAL;
     if ((d->flags & LOANS_F_STATS) && !stats) return LOANS_EINVAL;
     if ((d->flags & (LOANS_F_MASK | LOANS_F_ADDEND_MASK)) && !ref) return LOANS_EINVAL;
@@ -737,7 +770,7 @@ extern "C" int loans_wgrad_bf16s(const void* x, const void* gy, float* dw, const
     if ((d->gridH - 1) * d->osy + d->oy0 >= d->outH) return LOANS_EINVAL;
     if ((d->gridW - 1) * d->osx + d->ox0 >= d->outW) return LOANS_EINVAL;
     if (d->ntaps < 1 || d->ntaps > LOANS_MAX_TAPS) return LOANS_EINVAL;
-    if (d->flags & (LOANS_F_DENSE | LOANS_F_RELU_IN)) return LOANS_EINVAL;
+    if (d->flags & LOANS_F_DENSE) return LOANS_EINVAL;
     if ((int64_t)d->B * d->gridH * d->gridW >= ((int64_t)1 << 31)) return LOANS_ERANGE;
     Wgrad16Args a;
     a.x = static_cast<const __bf16*>(x); a.gy = static_cast<const __bf16*>(gy); a.dw = dw; a.d = *d;

@@ -92,16 +92,17 @@ __global__ __launch_bounds__(256) void gap_bwd_kernel(const float* gy, T* gx, in
 __device__ __forceinline__ float sigmoidf_chainer(float x) { return tanhf(x * 0.5f) * 0.5f + 0.5f; }
 
 // one block per sample; N small (<= 8)
-__global__ __launch_bounds__(256) void linear_fwd_kernel(const float* x, const float* W, const float* b, float* y,
+template <typename T>
+__global__ __launch_bounds__(256) void linear_fwd_kernel(const T* x, const float* W, const float* b, float* y,
                                                          int K, int N, int act_in, int act_out) {
     __shared__ float sh[4];
     const int s = blockIdx.x;
-    const float* xr = x + (int64_t)s * K;
+    const T* xr = x + (int64_t)s * K;
     for (int n = 0; n < N; ++n) {
         const float* wr = W + (int64_t)n * K;
         float acc = 0.f;
         for (int k = threadIdx.x * 4; k < K; k += 256 * 4) {
-            f32x4 xv = ld4(xr + k);
+            f32x4 xv = io4<T>::ld(xr + k);
             if (act_in) { xv.x = fmaxf(xv.x, 0.f); xv.y = fmaxf(xv.y, 0.f); xv.z = fmaxf(xv.z, 0.f); xv.w = fmaxf(xv.w, 0.f); }
             const f32x4 wv = ld4(wr + k);
             acc += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
@@ -123,8 +124,9 @@ __device__ __forceinline__ float gz_of(const float* y, const float* gy, int64_t 
 }
 
 // gx[s][k] = sum_n gz[s][n] W[n][k]  (* (x > 0) when act_in)
-__global__ __launch_bounds__(256) void linear_bwd_x_kernel(const float* x, const float* W, const float* y,
-                                                           const float* gy, float* gx, int B, int K4, int N,
+template <typename T>
+__global__ __launch_bounds__(256) void linear_bwd_x_kernel(const T* x, const float* W, const float* y,
+                                                           const float* gy, T* gx, int B, int K4, int N,
                                                            int act_in, int act_out) {
     const int64_t total = (int64_t)B * K4;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -132,17 +134,17 @@ __global__ __launch_bounds__(256) void linear_bwd_x_kernel(const float* x, const
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
         for (int n = 0; n < N; ++n) acc += ld4(W + (int64_t)n * K4 * 4 + k) * gz_of(y, gy, s * N + n, act_out);
         if (act_in) {
-            const f32x4 xv = ld4(x + i * 4);
+            const f32x4 xv = io4<T>::ld(x + i * 4);
             acc.x = xv.x > 0.f ? acc.x : 0.f; acc.y = xv.y > 0.f ? acc.y : 0.f;
             acc.z = xv.z > 0.f ? acc.z : 0.f; acc.w = xv.w > 0.f ? acc.w : 0.f;
         }
-        st4(gx + i * 4, acc);
+        io4<T>::st(gx + i * 4, acc);
     }
 }
 
 // gW[n][k] += sum_{s in slab} gz[s][n] act(x[s][k]);  grid = (k-blocks, sample slabs)
-template <int NMAX>
-__global__ __launch_bounds__(256) void linear_bwd_w_kernel(const float* x, const float* y, const float* gy, float* gW,
+template <int NMAX, typename T>
+__global__ __launch_bounds__(256) void linear_bwd_w_kernel(const T* x, const float* y, const float* gy, float* gW,
                                                            int B, int K4, int N, int act_in, int act_out, int slab) {
     const int kq = blockIdx.x * blockDim.x + threadIdx.x;
     if (kq >= K4) return;
@@ -152,7 +154,7 @@ __global__ __launch_bounds__(256) void linear_bwd_w_kernel(const float* x, const
 #pragma unroll
     for (int n = 0; n < NMAX; ++n) acc[n] = f32x4{0.f, 0.f, 0.f, 0.f};
     for (int s = s0; s < s1; ++s) {
-        f32x4 xv = ld4(x + ((int64_t)s * K4 + kq) * 4);
+        f32x4 xv = io4<T>::ld(x + ((int64_t)s * K4 + kq) * 4);
         if (act_in) { xv.x = fmaxf(xv.x, 0.f); xv.y = fmaxf(xv.y, 0.f); xv.z = fmaxf(xv.z, 0.f); xv.w = fmaxf(xv.w, 0.f); }
 #pragma unroll
         for (int n = 0; n < NMAX; ++n)
@@ -474,30 +476,32 @@ extern "C" int loans_gap_bwd_f32_bf16(const float* gy, void* gx, int32_t B, int3
     return LOANS_OK;
 }
 
-extern "C" int loans_linear_fwd_f32(const float* x, const float* W, const float* b, float* y, int32_t B, int32_t K,
-                                    int32_t N, int32_t act_in, int32_t act_out, void* stream) {
+template <typename T>
+static int linear_fwd_impl(const T* x, const float* W, const float* b, float* y, int32_t B, int32_t K,
+                           int32_t N, int32_t act_in, int32_t act_out, void* stream) {
     if (!x || !W || !y || B <= 0 || K <= 0 || (K & 3) || N <= 0 || N > 8) return LOANS_EINVAL;
-    hipLaunchKernelGGL(linear_fwd_kernel, dim3(B), dim3(256), 0, as_stream(stream), x, W, b, y, K, N, act_in, act_out);
+    hipLaunchKernelGGL(linear_fwd_kernel<T>, dim3(B), dim3(256), 0, as_stream(stream), x, W, b, y, K, N, act_in, act_out);
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;
 }
 
-extern "C" int loans_linear_bwd_f32(const float* x, const float* W, const float* y, const float* gy, float* gx,
-                                    float* gW, float* gb, int32_t B, int32_t K, int32_t N, int32_t act_in,
-                                    int32_t act_out, void* stream) {
+template <typename T>
+static int linear_bwd_impl(const T* x, const float* W, const float* y, const float* gy, T* gx,
+                           float* gW, float* gb, int32_t B, int32_t K, int32_t N, int32_t act_in,
+                           int32_t act_out, void* stream) {
     if (!x || !W || !gy || B <= 0 || K <= 0 || (K & 3) || N <= 0 || N > 8) return LOANS_EINVAL;
     if (act_out && !y) return LOANS_EINVAL;
     hipStream_t st = as_stream(stream);
     const int K4 = K / 4;
     if (gx) {
-        hipLaunchKernelGGL(linear_bwd_x_kernel, dim3(grid_for((int64_t)B * K4, 256)), dim3(256), 0, st, x, W, y, gy, gx, B, K4, N, act_in, act_out);
+        hipLaunchKernelGGL(linear_bwd_x_kernel<T>, dim3(grid_for((int64_t)B * K4, 256)), dim3(256), 0, st, x, W, y, gy, gx, B, K4, N, act_in, act_out);
         LOANS_LAUNCH_CHECK();
     }
     if (gW) {
         const int slab = 16;
         dim3 grid((K4 + 255) / 256, (B + slab - 1) / slab);
-        if (N == 1) hipLaunchKernelGGL(linear_bwd_w_kernel<1>, grid, dim3(256), 0, st, x, y, gy, gW, B, K4, N, act_in, act_out, slab);
-        else hipLaunchKernelGGL(linear_bwd_w_kernel<8>, grid, dim3(256), 0, st, x, y, gy, gW, B, K4, N, act_in, act_out, slab);
+        if (N == 1) hipLaunchKernelGGL((linear_bwd_w_kernel<1, T>), grid, dim3(256), 0, st, x, y, gy, gW, B, K4, N, act_in, act_out, slab);
+        else hipLaunchKernelGGL((linear_bwd_w_kernel<8, T>), grid, dim3(256), 0, st, x, y, gy, gW, B, K4, N, act_in, act_out, slab);
         LOANS_LAUNCH_CHECK();
     }
     if (gb) {
@@ -505,6 +509,29 @@ extern "C" int loans_linear_bwd_f32(const float* x, const float* W, const float*
         LOANS_LAUNCH_CHECK();
     }
     return LOANS_OK;
+}
+
+extern "C" int loans_linear_fwd_f32(const float* x, const float* W, const float* b, float* y, int32_t B, int32_t K,
+                                    int32_t N, int32_t act_in, int32_t act_out, void* stream) {
+    return linear_fwd_impl<float>(x, W, b, y, B, K, N, act_in, act_out, stream);
+}
+
+extern "C" int loans_linear_bwd_f32(const float* x, const float* W, const float* y, const float* gy, float* gx,
+                                    float* gW, float* gb, int32_t B, int32_t K, int32_t N, int32_t act_in,
+                                    int32_t act_out, void* stream) {
+    return linear_bwd_impl<float>(x, W, y, gy, gx, gW, gb, B, K, N, act_in, act_out, stream);
+}
+
+extern "C" int loans_linear_fwd_bf16(const void* x, const float* W, const float* b, float* y, int32_t B, int32_t K,
+                                     int32_t N, int32_t act_in, int32_t act_out, void* stream) {
+    return linear_fwd_impl<__bf16>(static_cast<const __bf16*>(x), W, b, y, B, K, N, act_in, act_out, stream);
+}
+
+extern "C" int loans_linear_bwd_bf16(const void* x, const float* W, const float* y, const float* gy, void* gx,
+                                     float* gW, float* gb, int32_t B, int32_t K, int32_t N, int32_t act_in,
+                                     int32_t act_out, void* stream) {
+    return linear_bwd_impl<__bf16>(static_cast<const __bf16*>(x), W, y, gy, static_cast<__bf16*>(gx), gW, gb, B, K, N,
+                                   act_in, act_out, stream);
 }
 
 extern "C" int loans_mul_f32(const float* x, const float* mask, float* y, int64_t n, void* stream) {

@@ -11,7 +11,7 @@
 namespace {
 
 struct SmallNArgs {
-    const float* gy;
+    const void* gy;         // float or bf16 tensor (template parameter of the kernel)
     const float* w;
     float* out;
     const float* ref;
@@ -21,6 +21,7 @@ struct SmallNArgs {
     int tapsel[LOANS_MAX_TAPS];
 };
 
+template <typename TG>
 __global__ __launch_bounds__(256) void dgrad_c4_kernel(const SmallNArgs a) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     f32x4* Wl = reinterpret_cast<f32x4*>(smem);        // [ntaps][C + C/16] float4
@@ -50,10 +51,10 @@ __global__ __launch_bounds__(256) void dgrad_c4_kernel(const SmallNArgs a) {
         const int iy = y * d.isy + d.dy[t], ix = x * d.isx + d.dx[t];
         const bool ok = live && (unsigned)iy < (unsigned)d.inH && (unsigned)ix < (unsigned)d.inW;
         if (!ok) continue;
-        const float* g = a.gy + (int64_t)((b * d.inH + iy) * d.inW + ix) * C + c0;
+        const TG* g = static_cast<const TG*>(a.gy) + (int64_t)((b * d.inH + iy) * d.inW + ix) * C + c0;
         const f32x4* wt = Wl + t * CP + c0 + (c0 >> 4);
         for (int c = 0; c < cpl; c += 4) {
-            const f32x4 gv = *reinterpret_cast<const f32x4*>(g + c);
+            const f32x4 gv = io4<TG>::ld(g + c);
             const f32x4* wc = wt + c + ((c0 + c) >> 4) - (c0 >> 4);
             acc += wc[0] * gv.x + wc[1] * gv.y + wc[2] * gv.z + wc[3] * gv.w;
         }
@@ -76,9 +77,10 @@ __global__ __launch_bounds__(256) void dgrad_c4_kernel(const SmallNArgs a) {
 
 }  // namespace
 
-extern "C" int loans_dgrad_c4_f32(const float* gy, const float* w_ohwi, float* out, const float* ref,
-                                  const float* addend, const loans_igemm_desc* d, const int32_t* tapsel_host,
-                                  int32_t src_taps, void* stream) {
+template <typename TG>
+static int dgrad_c4_impl(const void* gy, const float* w_ohwi, float* out, const float* ref,
+                         const float* addend, const loans_igemm_desc* d, const int32_t* tapsel_host,
+                         int32_t src_taps, void* stream) {
     if (!gy || !w_ohwi || !out || !d || !tapsel_host) return LOANS_EINVAL;
     if (d->Cout != 4 || d->Cin <= 0 || (d->Cin & 31) || d->ntaps < 1 || d->ntaps > LOANS_MAX_TAPS || src_taps < 1) return LOANS_EINVAL;
     if (d->B <= 0 || d->inH <= 0 || d->inW <= 0 || d->outH <= 0 || d->outW <= 0 || d->gridH <= 0 || d->gridW <= 0) return LOANS_EINVAL;
@@ -99,7 +101,19 @@ extern "C" int loans_dgrad_c4_f32(const float* gy, const float* w_ohwi, float* o
         if (tapsel_host[i] < 0 || tapsel_host[i] >= src_taps) return LOANS_EINVAL;
         a.tapsel[i] = tapsel_host[i];
     }
-    hipLaunchKernelGGL(dgrad_c4_kernel, dim3((a.M + 31) / 32), dim3(256), lds, as_stream(stream), a);
+    hipLaunchKernelGGL(dgrad_c4_kernel<TG>, dim3((a.M + 31) / 32), dim3(256), lds, as_stream(stream), a);
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;
+}
+
+extern "C" int loans_dgrad_c4_f32(const float* gy, const float* w_ohwi, float* out, const float* ref,
+                                  const float* addend, const loans_igemm_desc* d, const int32_t* tapsel_host,
+                                  int32_t src_taps, void* stream) {
+    return dgrad_c4_impl<float>(gy, w_ohwi, out, ref, addend, d, tapsel_host, src_taps, stream);
+}
+
+extern "C" int loans_dgrad_c4_bf16_f32(const void* gy, const float* w_ohwi, float* out, const float* ref,
+                                       const float* addend, const loans_igemm_desc* d, const int32_t* tapsel_host,
+                                       int32_t src_taps, void* stream) {
+    return dgrad_c4_impl<__bf16>(gy, w_ohwi, out, ref, addend, d, tapsel_host, src_taps, stream);
 }

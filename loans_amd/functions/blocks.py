@@ -175,9 +175,10 @@ class DownResBlock1Function(Function):
         self.x = x
         self.g0 = k.c0.geometry(B, H, Wd)
         self.gs = k.cs.geometry(B, H, Wd)
-        self.h1 = ops.conv_fprop(x, W0, self.g0)
+        o16 = ops.STORAGE == 'bf16' and x.dtype == torch.float32      # the crops stay fp32; the bf16 region starts here
+        self.h1 = ops.conv_fprop(x, W0, self.g0, out_bf16=o16)
         self.g1 = k.c1.geometry(B, self.g0.Ho, self.g0.Wo)
-        out = ops.conv_fprop(x, Ws, self.gs)
+        out = ops.conv_fprop(x, Ws, self.gs, out_bf16=o16)
         ops.conv_fprop(self.h1, W1, self.g1, out=out, relu_in=True, addend=out)
         return out
 

@@ -314,15 +314,16 @@ def conv_fprop(x, w, geo, out=None, bias=None, stats=None, relu_in=False, addend
 
 def _conv_fprop16(lib, x, w, geo, out, bias, stats, relu_in, addend, tile):
     """bf16-storage forward conv: x / out / addend bf16, w fp32 master weights (cast per call) or already bf16."""
-    assert not relu_in and not geo.dense
+    assert not geo.dense
     if out is None:
         out = torch.empty((geo.B, geo.Ho, geo.Wo, geo.Cout), device=x.device, dtype=BF16)
     assert out.dtype == BF16 and (addend is None or addend.dtype == BF16)
     assert x.numel() == geo.in_numel and w.numel() == geo.w_numel
     w16 = w if _is16(w) else cast_bf16(w)
-    flags = (F_BIAS if bias is not None else 0) | (F_STATS if stats is not None else 0) | (F_ADDEND if addend is not None else 0)
+    flags = (F_RELU_IN if relu_in else 0) | (F_BIAS if bias is not None else 0) | (F_STATS if stats is not None else 0) | \
+            (F_ADDEND if addend is not None else 0)
     if tile == 0:
-        tflags = flags & F_STATS
+        tflags = flags & (F_STATS | F_RELU_IN)
         sstats = stats_buffer(geo.Cout, x.device) if stats is not None else None
 
         def run(t):
@@ -384,7 +385,7 @@ def conv_dgrad(gy, w, geo, out=None, mask_ref=None, addend=None, addend_mask_ref
     Re-packs w per stride-parity class first (weights change every step)."""
     lib = _lib.load()
     assert gy.numel() == geo.B * geo.Ho * geo.Wo * geo.Cout
-    if _is16(gy):
+    if _is16(gy) and geo.Cin != 4:
         return _conv_dgrad16(lib, gy, w, geo, out, mask_ref, addend, addend_mask_ref, tile)
     if out is None:
         out = torch.empty((geo.B, geo.H, geo.W, geo.Cin), device=gy.device, dtype=torch.float32)
@@ -398,12 +399,15 @@ def conv_dgrad(gy, w, geo, out=None, mask_ref=None, addend=None, addend_mask_ref
         if addend is not None:
             addend = out
     if geo.Cin == 4 and addend_mask_ref is None and geo.Cout % 32 == 0:
-        # gradient w.r.t. a 4-channel (RGB) input: dedicated VALU kernel, forward weights, no re-pack
+        # gradient w.r.t. a 4-channel (RGB) input: dedicated VALU kernel, forward weights, no re-pack; the crops and
+        # their gradient stay fp32 in every arm, the incoming gradient may be a bf16 tensor
         fl = (F_MASK if mask_ref is not None else 0) | (F_ADDEND if addend is not None else 0)
+        fn = lib.loans_dgrad_c4_bf16_f32 if _is16(gy) else lib.loans_dgrad_c4_f32
+        if out is None:
+            out = torch.empty((geo.B, geo.H, geo.W, geo.Cin), device=gy.device, dtype=torch.float32)
         for d, tapsel, _ in geo.dgrad:
-            check(lib.loans_dgrad_c4_f32(_ptr(gy), _ptr(w), _ptr(out), _ptr(mask_ref), _ptr(addend),
-                                         C.byref(_with_flags(d, fl, 0)), tapsel, geo.k * geo.k, _stream()),
-                  'loans_dgrad_c4_f32')
+            check(fn(_ptr(gy), _ptr(w), _ptr(out), _ptr(mask_ref), _ptr(addend),
+                     C.byref(_with_flags(d, fl, 0)), tapsel, geo.k * geo.k, _stream()), 'loans_dgrad_c4')
         return out
     wp = torch.empty(geo.dgrad_weight_floats, device=gy.device, dtype=torch.float32)
     flags = (F_MASK if mask_ref is not None else 0) | (F_ADDEND if addend is not None else 0) | \
@@ -673,8 +677,9 @@ def linear_fwd(x, W, b, act_in=False, act_out=False):
     K = x.numel() // B
     N = W.numel() // K
     y = torch.empty((B, N), device=x.device, dtype=torch.float32)
-    check(_lib.load().loans_linear_fwd_f32(_ptr(x), _ptr(W), _ptr(b), _ptr(y), B, K, N, int(act_in), int(act_out),
-                                           _stream()), 'loans_linear_fwd_f32')
+    lib = _lib.load()
+    fn = lib.loans_linear_fwd_bf16 if _is16(x) else lib.loans_linear_fwd_f32
+    check(fn(_ptr(x), _ptr(W), _ptr(b), _ptr(y), B, K, N, int(act_in), int(act_out), _stream()), 'loans_linear_fwd')
     return y
 
 
@@ -683,8 +688,10 @@ def linear_bwd(x, W, y, gy, gW=None, gb=None, need_gx=True, act_in=False, act_ou
     K = x.numel() // B
     N = W.numel() // K
     gx = torch.empty_like(x) if need_gx else None
-    check(_lib.load().loans_linear_bwd_f32(_ptr(x), _ptr(W), _ptr(y), _ptr(gy), _ptr(gx), _ptr(gW), _ptr(gb),
-                                           B, K, N, int(act_in), int(act_out), _stream()), 'loans_linear_bwd_f32')
+    lib = _lib.load()
+    fn = lib.loans_linear_bwd_bf16 if _is16(x) else lib.loans_linear_bwd_f32
+    check(fn(_ptr(x), _ptr(W), _ptr(y), _ptr(gy), _ptr(gx), _ptr(gW), _ptr(gb),
+             B, K, N, int(act_in), int(act_out), _stream()), 'loans_linear_bwd')
     return gx
 
 

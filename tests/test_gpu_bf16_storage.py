@@ -72,6 +72,12 @@ def test_conv_bf16_storage(case, tile):
     y2_ref = C.conv2d_fwd(x.astype(np.float64), wr.astype(np.float64), None, s, p)[0] + add
     assert rel_err(_nchw(y2), y2_ref) < BF16_EPS
 
+    # pre-activation form (the assessor's blocks): conv(relu(x)) + addend
+    xr_ = np.maximum(x, 0)
+    y3 = ops.conv_fprop(xd, wd, geo, relu_in=True, addend=d16(_nhwc(add)), tile=tile)
+    y3_ref, col_relu = C.conv2d_fwd(xr_.astype(np.float64), wr.astype(np.float64), None, s, p)
+    assert rel_err(_nchw(y3), y3_ref + add) < BF16_EPS
+
     # data gradient and its fused epilogues
     gy = _r(rng.standard_normal(y_ref.shape))
     gx_ref, gw_ref, _ = C.conv2d_bwd(x.shape, col, wr.astype(np.float64), gy.astype(np.float64), s, p, False)
@@ -97,6 +103,10 @@ def test_conv_bf16_storage(case, tile):
         ops._conv_wgrad(xd, gyd, dw, geo, False, 3, wtile)          # accumulates; explicit split count
         assert dw.dtype == torch.float32
         assert rel_err(dw.cpu().numpy().transpose(0, 3, 1, 2), 2 * gw_ref) < 1e-5
+        _, gwr_ref, _ = C.conv2d_bwd(x.shape, col_relu, wr.astype(np.float64), gy.astype(np.float64), s, p, False, need_gx=False)
+        dw.zero_()
+        ops._conv_wgrad(xd, gyd, dw, geo, True, 0, wtile)           # weight gradient w.r.t. conv(relu(x))
+        assert rel_err(dw.cpu().numpy().transpose(0, 3, 1, 2), gwr_ref) < 1e-5
 
 
 def test_bn_passes_bf16_storage():
@@ -195,3 +205,31 @@ def test_region_boundaries_bf16_storage():
         assert rel_err(dw16.cpu().numpy(), dw32.cpu().numpy()) < 1e-5
     finally:
         ops.set_compute_dtype('f32')
+
+
+def test_assessor_edges_bf16_storage():
+    """the assessor's ends in the bf16-storage arm: the gradient w.r.t. the 4-channel fp32 crops from a bf16 gradient
+    (loans_dgrad_c4_bf16_f32), and the sigmoid(Linear(relu(h))) head on a bf16 feature map"""
+    from loans_amd import ops
+    rng = np.random.RandomState(9)
+    B, H, W, Cout, k, s, p = 2, 19, 19, 128, 4, 2, 1
+    geo = ops.ConvGeometry(B, H, W, 4, Cout, k, s, p)
+    w = (rng.standard_normal((Cout, k, k, 4)) * 0.05).astype(np.float32)
+    w[..., 3] = 0
+    gy = _r(rng.standard_normal((B, geo.Ho, geo.Wo, Cout)))
+    ref_t = rng.standard_normal((B, H, W, 4)).astype(np.float32)
+    g32 = ops.conv_dgrad(dev(gy), dev(w), geo, mask_ref=dev(ref_t))
+    g16 = ops.conv_dgrad(d16(gy), dev(w), geo, mask_ref=dev(ref_t))
+    assert g16.dtype == torch.float32 and torch.allclose(g16, g32, rtol=1e-5, atol=1e-5)
+    K = 18 * 18 * 128
+    x = _r(rng.standard_normal((3, K)))
+    Wl = (rng.standard_normal((1, K)) * 0.02).astype(np.float32)
+    y32 = ops.linear_fwd(dev(x), dev(Wl), None, act_in=True, act_out=True)
+    y16 = ops.linear_fwd(d16(x), dev(Wl), None, act_in=True, act_out=True)
+    assert torch.allclose(y16, y32, rtol=1e-5, atol=1e-6)
+    gyl = rng.standard_normal((3, 1)).astype(np.float32)
+    gW32, gW16 = torch.zeros(1, K, device='cuda'), torch.zeros(1, K, device='cuda')
+    gx32 = ops.linear_bwd(dev(x), dev(Wl), y32, dev(gyl), gW=gW32, act_in=True, act_out=True)
+    gx16 = ops.linear_bwd(d16(x), dev(Wl), y16, dev(gyl), gW=gW16, act_in=True, act_out=True)
+    assert gx16.dtype == torch.bfloat16 and torch.equal(gx16, gx32.to(torch.bfloat16))
+    assert torch.allclose(gW16, gW32, rtol=1e-5, atol=1e-6)
