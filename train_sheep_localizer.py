@@ -69,7 +69,13 @@ def main():
     parser.add_argument("--localizer-target", type=float, default=1.0)
     parser.add_argument("--use-graph", action='store_true', default=False,
                         help="capture the step into a hipGraph after two eager iterations (launch-bound small batches)")
+    parser.add_argument("--dtype", default='f32', choices=['f32', 'bf16'],
+                        help="f32: the parity path; bf16: bf16 activations / gradients in HBM and bf16 MFMA, fp32 master "
+                             "weights and gradient accumulation (not in the reference, which is fp32 only)")
     args = parser.parse_args()
+    if args.dtype == 'bf16':
+        loans_amd.set_compute_dtype('bf16')
+        loans_amd.set_storage_dtype('bf16')
 
     comm = parallel.init_from_env()
     if comm.size > 1:
