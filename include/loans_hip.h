@@ -83,8 +83,6 @@ typedef struct loans_igemm_desc {
 #define LOANS_TILE_64x128  5   /* wgrad only: 64 output channels x 128 tap-channel columns */
 #define LOANS_TILE_SPLIT   6   /* igemm only: 128x128 tiles over the rows that fill whole machine rounds, 64x64 over the rest (two launches) */
 #define LOANS_TILE_256x128 7   /* loans_igemm_bf16s only */
-#define LOANS_TILE_64x256  8   /* loans_wgrad_bf16s only: output channels x tap-channel columns */
-#define LOANS_TILE_128x256 9   /* loans_wgrad_bf16s only */
 #define LOANS_TILE_DMA    16   /* igemm, fp32 arm, OR-ed onto a tile shape: operand tiles staged by LDS-DMA (buffer_load ... lds)
                                   into XOR-swizzled unpadded LDS rows instead of through registers; same results bit for bit */
 
@@ -125,7 +123,7 @@ int loans_wgrad_bf16_f32(const float* x, const float* gy, float* dw,
 int loans_igemm_bf16s(const void* in, const void* w, void* out, const float* bias, double* stats,
                       const void* ref, const void* addend, const loans_igemm_desc* d, void* stream);
 /* wgrad with bf16 x and gy, fp32 atomic accumulation into dw ("fp32 grad accumulate"); the pixel-major tiles are staged as
- * they lie and transposed by the fragment reads (ds_read_b64_tr_b16).  Tiles 128x128, 64x64, 64x128, 64x256, 128x256. */
+ * they lie and transposed by the fragment reads (ds_read_b64_tr_b16).  Tiles 128x128, 64x64, 64x128. */
 int loans_wgrad_bf16s(const void* x, const void* gy, float* dw, const loans_igemm_desc* d, int32_t splits, void* stream);
 /* fp32 master weights -> bf16 operand copies: plain cast (n % 4 == 0), and the dgrad re-pack with the cast folded in */
 int loans_cast_bf16(const float* src, void* dst, int64_t n, void* stream);

@@ -788,7 +788,5 @@ extern "C" int loans_wgrad_bf16s(const void* x, const void* gy, float* dw, const
     if (tile == LOANS_TILE_64x64) return launch_wgrad16<64, 64>(a, splits, st);
     if (tile == LOANS_TILE_128x128) return launch_wgrad16<128, 128>(a, splits, st);
     if (tile == LOANS_TILE_64x128) return launch_wgrad16<64, 128>(a, splits, st);
-    if (tile == LOANS_TILE_64x256) return launch_wgrad16<64, 256>(a, splits, st);
-    if (tile == LOANS_TILE_128x256) return launch_wgrad16<128, 256>(a, splits, st);
     return LOANS_EINVAL;
 }

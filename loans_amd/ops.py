@@ -225,7 +225,7 @@ AUTOTUNE = os.environ.get('LOANS_AUTOTUNE', '1') != '0'
 _FPROP_TILES = tuple(int(t) for t in os.environ.get('LOANS_FPROP_TILES', '1,2,3,4,6,17,18,19,20,22').split(','))
 _IGEMM_TILES = tuple(int(t) for t in os.environ.get('LOANS_DGRAD_TILES', '1,2,3,17,18,19').split(','))
 _WGRAD_TILES = (1, 3, 5)
-_WGRAD16_TILES = (1, 3, 5, 8, 9)
+_WGRAD16_TILES = (1, 3, 5)
 _IGEMM16_TILES = tuple(int(t) for t in os.environ.get('LOANS_BF16S_TILES', '1,2,3,4,7').split(','))
 
 
@@ -456,10 +456,15 @@ def join_side_stream(device=None):
         _side_dirty.discard(idx)
 
 
+def _wgrad_key(x, gy, relu_in):
+    """autotune table key of a weight-gradient problem: arm, operand storage, relu(x) or not"""
+    return ('bf16s_' if _is16(x) else COMPUTE) + ('g16' if _is16(gy) and not _is16(x) else '') + \
+           ('relu_' if relu_in else '') + 'wgrad'
+
+
 def conv_wgrad(x, gy, dw, geo, relu_in=False, splits=0, tile=0):
     """dw[Cout,k,k,Cin] += sum over pixels (atomic accumulate into the gradient arena)."""
-    if ASYNC_WGRAD and geo.tuned.get(('bf16s_' if _is16(x) else COMPUTE) + ('g16' if _is16(gy) and not _is16(x) else '')
-                                     + 'wgrad') is not None \
+    if ASYNC_WGRAD and geo.tuned.get(_wgrad_key(x, gy, relu_in)) is not None \
             and not torch.cuda.is_current_stream_capturing():
         side = _side_stream(x.device)
         side.wait_stream(torch.cuda.current_stream(x.device))
@@ -488,8 +493,7 @@ def _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile):
             scratch = torch.empty(dw.numel(), device=x.device, dtype=torch.float32)
             check(wfn(_ptr(x), _ptr(gy), _ptr(scratch), C.byref(_with_flags(geo.fwd, fl, t)), splits,
                       _stream()), 'loans_wgrad[tune]')
-        tile = _tuned_tile(geo, ('bf16s_' if s16 else COMPUTE) + ('g16' if fl & F_GY_BF16 else '') + 'wgrad', run,
-                           _WGRAD16_TILES if s16 else _WGRAD_TILES)
+        tile = _tuned_tile(geo, _wgrad_key(x, gy, relu_in), run, _WGRAD16_TILES if s16 else _WGRAD_TILES)
     d = _with_flags(geo.fwd, fl, tile)
     check(wfn(_ptr(x), _ptr(gy), _ptr(dw), C.byref(d), splits, _stream()), 'loans_wgrad')
     if geo.dense:

@@ -44,7 +44,7 @@ CASES = [
 
 
 @pytest.mark.parametrize("case", CASES)
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 7, 5, 8, 9])     # 5, 8, 9: weight-gradient tiles
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 7, 5])     # 5: a weight-gradient tile
 def test_conv_bf16_storage(case, tile):
     from loans_amd import ops
     B, Cin, H, W, Cout, k, s, p = case
@@ -97,7 +97,7 @@ def test_conv_bf16_storage(case, tile):
         assert rel_err(_nchw(gx3), gx_ref + addx * (ref_t > 0)) < BF16_EPS
 
     # weight gradient: bf16 operands, fp32 accumulation into the fp32 gradient
-    if wtile in (0, 1, 3, 5, 8, 9):
+    if wtile in (0, 1, 3, 5):
         dw = torch.zeros_like(wd)
         ops._conv_wgrad(xd, gyd, dw, geo, False, 0, wtile)
         ops._conv_wgrad(xd, gyd, dw, geo, False, 3, wtile)          # accumulates; explicit split count

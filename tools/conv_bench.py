@@ -60,7 +60,6 @@ def main():
     names = {0: 'auto', 1: '128x128', 2: '128x64', 3: '64x64', 4: '256x64', 5: '64x128', 6: 'split'}
     names.update({t + 16: n + 'D' for t, n in list(names.items()) if t in (1, 2, 3, 4, 6)})
     names[7] = '256x128'
-    names[8], names[9] = '64x256', '128x256'
     s16 = args.storage == 'bf16'
     if s16:
         ops.set_compute_dtype('bf16')
@@ -86,9 +85,9 @@ def main():
         cases = []
         for mode in args.modes.split(','):
             for t, dbg in [(t, g) for t in tiles for g in args.dbg.split(',')]:
-                if mode == 'wgrad' and t not in ((0, 1, 3, 5, 8, 9) if s16 else (0, 1, 3, 5)):
+                if mode == 'wgrad' and t not in (0, 1, 3, 5):
                     continue
-                if mode != 'wgrad' and t in (5, 8, 9) or (mode == 'dgrad' and (t & 15) in (4, 6) and not s16):
+                if mode != 'wgrad' and t == 5 or (mode == 'dgrad' and (t & 15) in (4, 6) and not s16):
                     continue
                 if mode == 'fprop':
                     fn = lambda t=t: ops.conv_fprop(x, w, geo, out=y, stats=stats, tile=t)   # noqa: E731
