@@ -72,38 +72,40 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* x, const float* 
     }
 }
 
+// One block row = one output image row (blockIdx.y walks b * OH + oh, wave-uniform: scalar divisions only); threads
+// cover its OW x C4 four-channel elements with 32-bit index math (64-bit div / mod per element cost more than the loads).
 template <typename TO>
 __global__ __launch_bounds__(256) void bn_relu_maxpool_kernel(const TO* x, const float* scale, const float* shift,
                                                               TO* y, uint8_t* idx, int B, int H, int W, int C4,
                                                               int OH, int OW) {
-    const int64_t total = (int64_t)B * OH * OW * C4;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int c4 = (int)(i % C4);
-        int64_t p = i / C4;
-        const int ow = (int)(p % OW); p /= OW;
-        const int oh = (int)(p % OH);
-        const int b = (int)(p / OH);
-        const f32x4 s = ld4(scale + c4 * 4), t = ld4(shift + c4 * 4);
-        f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
-        int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
+    const int rowlen = OW * C4;
+    for (int row = blockIdx.y; row < B * OH; row += gridDim.y) {
+        const int b = row / OH, oh = row - b * OH;
+        for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < rowlen; e += gridDim.x * blockDim.x) {
+            const int ow = e / C4, c4 = e - ow * C4;
+            const f32x4 s = ld4(scale + c4 * 4), t = ld4(shift + c4 * 4);
+            f32x4 best = {-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            int a0 = 0, a1 = 0, a2 = 0, a3 = 0;
 #pragma unroll
-        for (int r = 0; r < 3; ++r) {
-            const int ih = oh * 2 + r;
-            if (ih >= H) continue;
+            for (int r = 0; r < 3; ++r) {
+                const int ih = oh * 2 + r;
+                if (ih >= H) continue;
 #pragma unroll
-            for (int q = 0; q < 3; ++q) {
-                const int iw = ow * 2 + q;
-                if (iw >= W) continue;
-                f32x4 v = relu4(io4<TO>::ld(x + (((int64_t)b * H + ih) * W + iw) * C4 * 4 + c4 * 4) * s + t);
-                const int k = r * 3 + q;
-                if (v.x > best.x) { best.x = v.x; a0 = k; }
-                if (v.y > best.y) { best.y = v.y; a1 = k; }
-                if (v.z > best.z) { best.z = v.z; a2 = k; }
-                if (v.w > best.w) { best.w = v.w; a3 = k; }
+                for (int q = 0; q < 3; ++q) {
+                    const int iw = ow * 2 + q;
+                    if (iw >= W) continue;
+                    f32x4 v = relu4(io4<TO>::ld(x + (((int64_t)b * H + ih) * W + iw) * C4 * 4 + c4 * 4) * s + t);
+                    const int k = r * 3 + q;
+                    if (v.x > best.x) { best.x = v.x; a0 = k; }
+                    if (v.y > best.y) { best.y = v.y; a1 = k; }
+                    if (v.z > best.z) { best.z = v.z; a2 = k; }
+                    if (v.w > best.w) { best.w = v.w; a3 = k; }
+                }
             }
+            const int64_t o = ((int64_t)row * OW + ow) * C4 + c4;
+            io4<TO>::st(y + o * 4, best);
+            *reinterpret_cast<uchar4*>(idx + o * 4) = make_uchar4(a0, a1, a2, a3);
         }
-        io4<TO>::st(y + i * 4, best);
-        *reinterpret_cast<uchar4*>(idx + i * 4) = make_uchar4(a0, a1, a2, a3);
     }
 }
 
@@ -111,29 +113,29 @@ template <typename TG>
 __global__ __launch_bounds__(256) void maxpool_relu_bwd_kernel(const TG* gy, const uint8_t* idx, const TG* x,
                                                                const float* scale, const float* shift, TG* gx,
                                                                int B, int H, int W, int C4, int OH, int OW) {
-    const int64_t total = (int64_t)B * H * W * C4;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int c4 = (int)(i % C4);
-        int64_t p = i / C4;
-        const int iw = (int)(p % W); p /= W;
-        const int ih = (int)(p % H);
-        const int b = (int)(p / H);
-        f32x4 g = {0.f, 0.f, 0.f, 0.f};
+    const int rowlen = W * C4;
+    for (int row = blockIdx.y; row < B * H; row += gridDim.y) {     // one input image row per block row (see the forward)
+        const int b = row / H, ih = row - b * H;
         const int oh_lo = ih >= 2 ? (ih - 1) >> 1 : 0, oh_hi = min(ih >> 1, OH - 1);
-        const int ow_lo = iw >= 2 ? (iw - 1) >> 1 : 0, ow_hi = min(iw >> 1, OW - 1);
-        for (int oh = oh_lo; oh <= oh_hi; ++oh)
-            for (int ow = ow_lo; ow <= ow_hi; ++ow) {
-                const int k = (ih - 2 * oh) * 3 + (iw - 2 * ow);
-                const int64_t o = (((int64_t)b * OH + oh) * OW + ow) * C4 + c4;
-                const uchar4 a = *reinterpret_cast<const uchar4*>(idx + o * 4);
-                const f32x4 gv = io4<TG>::ld(gy + o * 4);
-                if (a.x == k) g.x += gv.x;
-                if (a.y == k) g.y += gv.y;
-                if (a.z == k) g.z += gv.z;
-                if (a.w == k) g.w += gv.w;
-            }
-        const f32x4 pre = io4<TG>::ld(x + i * 4) * ld4(scale + c4 * 4) + ld4(shift + c4 * 4);
-        io4<TG>::st(gx + i * 4, maskpos4(g, pre));
+        for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < rowlen; e += gridDim.x * blockDim.x) {
+            const int iw = e / C4, c4 = e - iw * C4;
+            f32x4 g = {0.f, 0.f, 0.f, 0.f};
+            const int ow_lo = iw >= 2 ? (iw - 1) >> 1 : 0, ow_hi = min(iw >> 1, OW - 1);
+            for (int oh = oh_lo; oh <= oh_hi; ++oh)
+                for (int ow = ow_lo; ow <= ow_hi; ++ow) {
+                    const int k = (ih - 2 * oh) * 3 + (iw - 2 * ow);
+                    const int64_t o = (((int64_t)b * OH + oh) * OW + ow) * C4 + c4;
+                    const uchar4 a = *reinterpret_cast<const uchar4*>(idx + o * 4);
+                    const f32x4 gv = io4<TG>::ld(gy + o * 4);
+                    if (a.x == k) g.x += gv.x;
+                    if (a.y == k) g.y += gv.y;
+                    if (a.z == k) g.z += gv.z;
+                    if (a.w == k) g.w += gv.w;
+                }
+            const int64_t i = (int64_t)row * rowlen + e;
+            const f32x4 pre = io4<TG>::ld(x + i * 4) * ld4(scale + c4 * 4) + ld4(shift + c4 * 4);
+            io4<TG>::st(gx + i * 4, maskpos4(g, pre));
+        }
     }
 }
 
@@ -318,8 +320,9 @@ static int bn_relu_maxpool_impl(const TO* x, const float* scale, const float* sh
                                 int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream) {
     if (!x || !scale || !shift || !y || !idx || B <= 0 || H < 3 || W < 3 || C <= 0 || (C & 3)) return LOANS_EINVAL;
     if (OH != (H - 2) / 2 + 1 || OW != (W - 2) / 2 + 1) return LOANS_EINVAL;   // cover_all out size, k=3 s=2 p=0
-    const int64_t total = (int64_t)B * OH * OW * (C / 4);
-    hipLaunchKernelGGL(bn_relu_maxpool_kernel<TO>, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), x, scale,
+    if ((int64_t)B * H >= ((int64_t)1 << 31) || (int64_t)W * (C / 4) >= ((int64_t)1 << 31)) return LOANS_ERANGE;
+    const dim3 grid((OW * (C / 4) + 255) / 256, (unsigned)min((int64_t)B * OH, (int64_t)65535));
+    hipLaunchKernelGGL(bn_relu_maxpool_kernel<TO>, grid, dim3(256), 0, as_stream(stream), x, scale,
                        shift, y, idx, B, H, W, C / 4, OH, OW);
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;
@@ -341,8 +344,9 @@ static int maxpool_relu_bwd_impl(const TG* gy, const uint8_t* idx, const TG* x, 
                                  int32_t OH, int32_t OW, void* stream) {
     if (!gy || !idx || !x || !scale || !shift || !gx || B <= 0 || H < 3 || W < 3 || C <= 0 || (C & 3)) return LOANS_EINVAL;
     if (OH != (H - 2) / 2 + 1 || OW != (W - 2) / 2 + 1) return LOANS_EINVAL;
-    const int64_t total = (int64_t)B * H * W * (C / 4);
-    hipLaunchKernelGGL(maxpool_relu_bwd_kernel<TG>, dim3(grid_for(total, 256)), dim3(256), 0, as_stream(stream), gy, idx, x,
+    if ((int64_t)B * H >= ((int64_t)1 << 31) || (int64_t)W * (C / 4) >= ((int64_t)1 << 31)) return LOANS_ERANGE;
+    const dim3 grid((W * (C / 4) + 255) / 256, (unsigned)min((int64_t)B * H, (int64_t)65535));
+    hipLaunchKernelGGL(maxpool_relu_bwd_kernel<TG>, grid, dim3(256), 0, as_stream(stream), gy, idx, x,
                        scale, shift, gx, B, H, W, C / 4, OH, OW);
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;

@@ -79,6 +79,13 @@ class SheepAssessor(training.StandardUpdater):
         report(g['obs'])
 
     def _step(self, real_images, labels, fake_images):
+        ops.begin_step(torch.device('cuda', torch.cuda.current_device()))     # one memset for the step's accumulators
+        try:
+            self._step_body(real_images, labels, fake_images)
+        finally:
+            ops.end_step()
+
+    def _step_body(self, real_images, labels, fake_images):
         localizer_optimizer = self.get_optimizer('opt_gen')
         discriminator_optimizer = self.get_optimizer('opt_dis')
         xp = self.localizer.xp

@@ -44,3 +44,21 @@ for dt in (torch.float32, torch.bfloat16):
     ms = t(lambda: ops.check(app(g.data_ptr(), m.data_ptr(), x.data_ptr(), k[0].data_ptr(), k[1].data_ptr(), k[2].data_ptr(),
                                  gx.data_ptr(), 0, 0, 0, 0, 0, B * H * W, C, ops._stream()), 'app'))
     print('%-8s bn_bwd_apply    %7.3f ms  %6.2f TB/s' % (dt, ms, 4 * nbytes / ms / 1e9))
+
+# the stem's pool (conv1 output of config 3: 128 x 256 x 256 x 64 is 2 GB in bf16 -- use a quarter batch)
+for dt in (torch.float32, torch.bfloat16):
+    es = 4 if dt == torch.float32 else 2
+    Bp, Hp, Cp = 32, 256, 64
+    x = torch.randn(Bp, Hp, Hp, Cp, device='cuda').to(dt)
+    stats = torch.zeros((ops.STATS_REPLICAS, 2, Cp), device='cuda', dtype=torch.float64)
+    stats[0, 1] = float(Bp * Hp * Hp)
+    ones, zeros = torch.ones(Cp, device='cuda'), torch.zeros(Cp, device='cuda')
+    st = ops.bn_finalize(stats, Bp * Hp * Hp, ones, zeros, zeros.clone(), ones.clone())
+    y, idx = ops.bn_relu_maxpool(x, st)
+    ms = t(lambda: ops.bn_relu_maxpool(x, st))
+    nb = x.numel() * es + y.numel() * (es + 1)
+    print('%-8s bn_relu_maxpool %7.3f ms  %6.2f TB/s' % (dt, ms, nb / ms / 1e9))
+    gy = torch.randn_like(y)
+    ms = t(lambda: ops.maxpool_relu_bwd(gy, idx, x, st))
+    nb = 2 * x.numel() * es + y.numel() * (es + 1)
+    print('%-8s maxpool_relu_bwd %6.3f ms  %6.2f TB/s' % (dt, ms, nb / ms / 1e9))
