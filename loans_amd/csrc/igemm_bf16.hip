@@ -12,6 +12,7 @@
 // Same problem descriptor, tap masks, XCD-aware tile order and epilogue flags as igemm.hip; forward convolution and
 // data gradient are the same kernel (dgrad: one launch per stride-parity class on re-packed weights).
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -31,6 +32,7 @@ struct Igemm16Args {
     const __bf16* addend;
     loans_igemm_desc d;
     int M, Ktot, nchunks, tiles_m, tiles_n;
+    int dbg;            // experiment bits (LOANS_EXPERIMENT builds only)
     unsigned in_bytes, w_bytes, out_bytes;
     struct {            // nx > 0: taps are an ny x nx grid, dy = dy0 + row*sdy, dx = dx0 + col*sdx, sd* = +-1
         int nx, ny, dy0, sdy, dx0, sdx;
@@ -134,6 +136,9 @@ __global__ __launch_bounds__(256) void igemm16_kernel(const Igemm16Args a) {
                 }
             }
             badmask[i] = ~mask;
+#ifdef LOANS_EXPERIMENT
+            if (a.dbg & 4) { rowoff[i] = (unsigned)((d.inW + 1) * pbytes) + (rowoff[i] & 0x3FFu); badmask[i] = 0; }   // cache-hot gathers
+#endif
             if (lu == 0) opix[lrow + 32 * i] = pixoff;
             x += 32;
             const int qx = (int)(((float)x + 0.5f) * inv_gw);
@@ -160,6 +165,9 @@ __global__ __launch_bounds__(256) void igemm16_kernel(const Igemm16Args a) {
         const int n = tn * BN + lrow + 32 * i;
         wbad[i] = n < d.Cout ? 0u : 0xFFFFFFFFu;
         woff[i] = n < d.Cout ? (unsigned)n * (unsigned)a.Ktot * 2u : 0u;
+#ifdef LOANS_EXPERIMENT
+        if (a.dbg & 4) woff[i] = (unsigned)(lrow & 7) * (unsigned)a.Ktot * 2u;
+#endif
     }
     unsigned toff = (unsigned)taps[min(tap, LOANS_MAX_TAPS - 1)] + (unsigned)c8 * 16u;
 
@@ -711,6 +719,10 @@ extern "C" int loans_igemm_bf16s(const void* in, const void* w, void* out, const
     a.d = *d;
     a.M = d->B * d->gridH * d->gridW;
     a.Ktot = d->ntaps * d->Cin;
+    a.dbg = 0;
+#ifdef LOANS_EXPERIMENT
+    if (const char* e = getenv("LOANS_DBG")) a.dbg = atoi(e);
+#endif
     a.nchunks = (a.Ktot + BKH - 1) / BKH;
     {
         const int64_t ib = (int64_t)d->B * d->inH * d->inW * d->Cin * 2;
