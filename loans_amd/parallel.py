@@ -80,7 +80,11 @@ def init_from_env(backend=None):
         torch.cuda.set_device(local_rank % torch.cuda.device_count())
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     if not dist.is_initialized():
-        dist.init_process_group(backend=backend)
+        if backend == 'nccl' and torch.cuda.is_available():
+            # bind the communicator to this rank's GPU up front (barrier() and the first collective then need no guess)
+            dist.init_process_group(backend=backend, device_id=torch.device('cuda', local_rank % torch.cuda.device_count()))
+        else:
+            dist.init_process_group(backend=backend)
     return Communicator()
 
 
