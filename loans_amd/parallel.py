@@ -80,11 +80,10 @@ def init_from_env(backend=None):
         torch.cuda.set_device(local_rank % torch.cuda.device_count())
     os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
     if not dist.is_initialized():
-        if backend == 'nccl' and torch.cuda.is_available():
-            # bind the communicator to this rank's GPU up front (barrier() and the first collective then need no guess)
-            dist.init_process_group(backend=backend, device_id=torch.device('cuda', local_rank % torch.cuda.device_count()))
-        else:
-            dist.init_process_group(backend=backend)
+        # no `device_id=`: binding the communicator eagerly mutes torch's barrier() warning (the device is already
+        # current, set above) but measured 6 % slower steps at world size 1 with the collectives on (4368 vs 4644
+        # images/s): the lazily created communicator's streams overlap the backward better
+        dist.init_process_group(backend=backend)
     return Communicator()
 
 
