@@ -14,6 +14,7 @@ paste-and-crop frames, random-init weights; inputs are resident in HBM before ti
 Prints ONE JSON line (rank 0) with the contract keys plus
   roofline     : the ResNet-18 conv-forward MFMA roofline, measured live with HIP events
                  around the forward implicit-GEMM launches (21 convs) of every timed step
+                 (minus the time a bracket of two events takes with nothing in it)
   cpu_baseline : the CPU oracle ("port": NumPy restatement of the Chainer graph) timed on
                  the host cores on a bounded sample (B=8) of the same workload (N=1 only).
 """
@@ -151,6 +152,19 @@ def main():
     elapsed = comm.allreduce_max(time.perf_counter() - t0)
     log, ops.EVENT_LOG = ops.EVENT_LOG, None
 
+    # what a bracket of two HIP events measures with NOTHING between them: the events are packets of their own in the
+    # queue, and that time is not the kernel's (rocprofv3's per-kernel durations do not contain it either)
+    ev_overhead_ms = 0.0
+    if rank == 0 and log:
+        nulls = []
+        for _ in range(50):
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            e1.record()
+            e1.synchronize()
+            nulls.append(e0.elapsed_time(e1))
+        ev_overhead_ms = float(np.median(nulls))
+
     if rank != 0:
         parallel.shutdown()
         return
@@ -160,7 +174,8 @@ def main():
     # ---- conv-forward roofline from the events of the timed steps ----
     roofline = None
     if log:
-        loc = [(tag, flops, s.elapsed_time(e), nl) for tag, flops, s, e, nl in log if tag == 'fprop_bn']
+        loc = [(tag, flops, max(s.elapsed_time(e) - ev_overhead_ms, 0.0), nl) for tag, flops, s, e, nl in log if tag == 'fprop_bn']
+        raw_ms = sum(s.elapsed_time(e) for tag, flops, s, e, nl in log if tag == 'fprop_bn')
         tot_ms = sum(x[2] for x in loc)
         tot_flop = sum(x[1] for x in loc)
         n_launch = sum(x[3] for x in loc)          # a LOANS_TILE_SPLIT conv is two launches
@@ -172,6 +187,8 @@ def main():
                               % (len(loc) // args.steps, n_launch // args.steps),
                     "avg_launch_ms": round(tot_ms / max(n_launch, 1), 4),
                     "conv_fwd_ms_per_step": round(tot_ms / args.steps, 3),
+                    "conv_fwd_ms_per_step_raw_brackets": round(raw_ms / args.steps, 3),
+                    "event_pair_overhead_us": round(ev_overhead_ms * 1e3, 2),
                     "algorithmic_flop_per_step": tot_flop // args.steps}
         # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE, separate
         # rocprofv3 runs of this same command); only valid for the configuration they were taken on
