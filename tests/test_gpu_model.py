@@ -435,6 +435,31 @@ def test_bf16_storage_step_against_oracle():
         loans_amd.set_compute_dtype('f32')
 
 
+@pytest.mark.parametrize("which", ["resnet18_224", "resnet18_320", "resnet50_256"])
+def test_bf16_storage_predict_known_answer(which):
+    """SURVEY 8c KAT 1 in the bf16-storage arm, test mode (running statistics, no graph): a fresh localizer has
+    param_predictor.W = 0, so theta is exactly [[.8,0,0],[0,.8,0]] whatever the (bf16) backbone computes, predict()
+    returns [0.1 H, 0.1 W, 0.9 H, 0.9 W]; the assessor runs in test mode on the crops (res6 at 320, ResNet-50 at 256)."""
+    cls, hw = {'resnet18_224': (loans_amd.SheepLocalizer, 224), 'resnet18_320': (loans_amd.SheepLocalizer, 320),
+               'resnet50_256': (loans_amd.Resnet50SheepLocalizer, 256)}[which]
+    loans_amd.set_compute_dtype('bf16')
+    loans_amd.set_storage_dtype('bf16')
+    try:
+        np.random.seed(0)
+        loc = cls((75, 75))
+        frames, _, _ = inputs(3, 3, hw, hw, (75, 75))
+        boxes, rois, scores, _ = loc.predict(list(frames))
+        for b in boxes:
+            np.testing.assert_allclose(b[0], [0.1 * hw, 0.1 * hw, 0.9 * hw, 0.9 * hw], rtol=1e-6)
+        dis = loans_amd.ResnetAssessor()
+        with loans_amd.using_config('train', False), loans_amd.using_config('enable_backprop', False):
+            y = dis(rois)
+        yv = y.data.cpu().numpy()
+        assert yv.shape == (3, 1) and np.all((yv > 0) & (yv < 1))
+    finally:
+        loans_amd.set_compute_dtype('f32')
+
+
 @pytest.mark.parametrize("kind", ["basic_a", "chainer_b"])
 def test_residual_unit_bf16_storage(kind):
     """One residual unit on bf16 tensors against the fp64 oracle unit: output within bf16 rounding of a few layers
