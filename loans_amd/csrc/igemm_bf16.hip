@@ -14,6 +14,19 @@
 #include "common.h"
 #include <stdlib.h>
 
+#ifdef LOANS_STAMPS
+// Diagnostic build only (tools/stamp_run16.py): per-wave cycle sums of the K-loop phases of the first 64 blocks.
+__device__ unsigned long long g_stamps16[64 * 4 * 8];
+#define STAMP16(t)                                                                       \
+    do {                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+        asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(t)::"memory");       \
+        __builtin_amdgcn_sched_barrier(0);                                               \
+    } while (0)
+#else
+#define STAMP16(t) do { } while (0)
+#endif
+
 namespace {
 
 constexpr int BKH = 64;                 // K elements per chunk (8 units of 16 bytes)
@@ -248,8 +261,13 @@ __global__ __launch_bounds__(256) void igemm16_kernel(const Igemm16Args a) {
     __syncthreads();
     read_frag(0, 0, fa0, fb0);
     int c = 0;
+#ifdef LOANS_STAMPS
+    unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0, p_s0 = 0, p_s1 = 0, p_s2 = 0, p_bar = 0, p_s3 = 0, q_begin = 0;
+    STAMP16(q_begin);
+#endif
     for (; c + 1 < a.nchunks; ++c) {
         const int buf = c & 1;
+        STAMP16(q0);
         read_frag(buf, 1, fa1, fb1);
         relu_frag(fa0);
         __builtin_amdgcn_sched_barrier(0);
@@ -260,6 +278,7 @@ __global__ __launch_bounds__(256) void igemm16_kernel(const Igemm16Args a) {
             for (int p = q * PPG; p < (q + 1) * PPG; ++p) dma_piece(buf ^ 1, p);
             __builtin_amdgcn_sched_barrier(0);
         }
+        STAMP16(q1);
         read_frag(buf, 2, fa0, fb0);
         relu_frag(fa1);
         __builtin_amdgcn_sched_barrier(0);
@@ -270,18 +289,31 @@ __global__ __launch_bounds__(256) void igemm16_kernel(const Igemm16Args a) {
             for (int p = (NMMA + q) * PPG; p < (NMMA + q + 1) * PPG; ++p) dma_piece(buf ^ 1, p);
             __builtin_amdgcn_sched_barrier(0);
         }
+        STAMP16(q2);
         read_frag(buf, 3, fa1, fb1);
         relu_frag(fa0);
         __builtin_amdgcn_sched_barrier(0);
         mma(fa0, fb0);
         __builtin_amdgcn_sched_barrier(0);
         relu_frag(fa1);
+        STAMP16(q3);
         __syncthreads();
+        STAMP16(q4);
         read_frag(buf ^ 1, 0, fa0, fb0);
         __builtin_amdgcn_sched_barrier(0);
         mma(fa1, fb1);
         __builtin_amdgcn_sched_barrier(0);
+        STAMP16(q5);
+#ifdef LOANS_STAMPS
+        p_s0 += q1 - q0; p_s1 += q2 - q1; p_s2 += q3 - q2; p_bar += q4 - q3; p_s3 += q5 - q4;
+#endif
     }
+#ifdef LOANS_STAMPS
+    if (logical < 64 && (tid & 63) == 0) {
+        unsigned long long* o = g_stamps16 + (logical * 4 + (tid >> 6)) * 8;
+        o[0] = p_s0; o[1] = p_s1; o[2] = p_s2; o[3] = p_bar; o[4] = p_s3; o[5] = q5 - q_begin; o[6] = a.nchunks - 1; o[7] = 0;
+    }
+#endif
     {   // last chunk: steps that lie wholly beyond Ktot hold zeros on both sides and are skipped
         const int buf = c & 1;
         const int ts = (a.Ktot - (a.nchunks - 1) * BKH + 15) / 16;      // 1..4
@@ -802,3 +834,9 @@ extern "C" int loans_wgrad_bf16s(const void* x, const void* gy, float* dw, const
     if (tile == LOANS_TILE_64x128) return launch_wgrad16<64, 128>(a, splits, st);
     return LOANS_EINVAL;
 }
+
+#ifdef LOANS_STAMPS
+extern "C" int loans_debug_read_stamps16(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps16), sizeof(unsigned long long) * n);
+}
+#endif
