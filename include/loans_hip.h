@@ -83,6 +83,11 @@ typedef struct loans_igemm_desc {
 #define LOANS_TILE_64x128  5   /* wgrad only: 64 output channels x 128 tap-channel columns */
 #define LOANS_TILE_SPLIT   6   /* igemm only: 128x128 tiles over the rows that fill whole machine rounds, 64x64 over the rest (two launches) */
 #define LOANS_TILE_256x128 7   /* loans_igemm_bf16s only */
+#define LOANS_TILE_SPLITK(s) ((s) << 8) /* loans_igemm_f32, OR-ed onto a tile shape, s = 2..255: split-K for small grids (few tiles, long K:
+                                  the deep layers at small batch, single-image inference).  Block (tile, i) contracts every s-th
+                                  part of K and ADDS its raw partial tile to `out` with fp32 atomics: the caller zero-fills `out`
+                                  first (or leaves the addend in it), passes no epilogue flag here, and applies bias / statistics /
+                                  mask / addend to the finished sums with loans_igemm_finalize_f32 */
 #define LOANS_TILE_DMA    16   /* igemm, fp32 arm, OR-ed onto a tile shape: operand tiles staged by LDS-DMA (buffer_load ... lds)
                                   into XOR-swizzled unpadded LDS rows instead of through registers; same results bit for bit */
 
@@ -94,6 +99,11 @@ typedef struct loans_igemm_desc {
 int loans_igemm_f32(const float* in, const float* w, float* out,
                     const float* bias, double* stats, const float* ref, const float* addend,
                     const loans_igemm_desc* d, void* stream);
+
+/* epilogue of a split-K convolution (LOANS_TILE_SPLITK) over the finished sums, in place on the whole tensor
+ * out [rows][C]: (+ bias) (* (ref > 0)) (+ addend [masked by ref > 0]) and the BN statistics of the result; flags as above */
+int loans_igemm_finalize_f32(float* out, const float* bias, double* stats, const float* ref, const float* addend,
+                             int32_t flags, int64_t rows, int32_t C, void* stream);
 
 /* Same problem with the operands rounded to bf16 (round-to-nearest-even, done while the fp32 tensors are staged
  * into LDS) and contracted on v_mfma_f32_32x32x16_bf16 with fp32 accumulation; every tensor stays fp32 in memory.

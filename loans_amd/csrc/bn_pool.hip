@@ -240,6 +240,59 @@ __global__ __launch_bounds__(256) void colsum_kernel(const T* x, float* out, int
     }
 }
 
+// Epilogue of a split-K convolution over the finished sums, in place: v = out (+ bias); MASK: v *= (ref > 0);
+// ADDEND (masked by ref > 0 with ADDEND_MASK): v += addend; STATS: per-channel sum / sum of squares of v (fp64 atomics).
+// Same thread map as the reductions above.
+__global__ __launch_bounds__(256) void igemm_finalize_kernel(float* out, const float* bias, double* stats, const float* ref,
+                                                             const float* addend, int flags, int64_t rows, int C4, int C4T,
+                                                             int rows_per_block) {
+    __shared__ f32x4 red[2][256];
+    const int tid = threadIdx.x;
+    const int cl = tid % C4, rl = tid / C4, RL = 256 / C4;
+    const int cg = blockIdx.y * C4 + cl;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    const bool f_bias = flags & LOANS_F_BIAS, f_stats = flags & LOANS_F_STATS, f_mask = flags & LOANS_F_MASK;
+    const bool f_add = flags & LOANS_F_ADDEND, f_addmask = flags & LOANS_F_ADDEND_MASK;
+    f32x4 bv = {0.f, 0.f, 0.f, 0.f};
+    if (f_bias) bv = ld4(bias + cg * 4);
+    f32x4 s1 = {0.f, 0.f, 0.f, 0.f}, s2 = s1;
+    if (rl < RL) {
+        for (int64_t r = r0 + rl; r < r1; r += RL) {
+            const int64_t o = (r * C4T + cg) * 4;
+            f32x4 v = ld4(out + o) + bv;
+            if (f_mask || f_addmask) {
+                const f32x4 m = ld4(ref + o);
+                if (f_mask) v = maskpos4(v, m);
+                if (f_add) v += f_addmask ? maskpos4(ld4(addend + o), m) : ld4(addend + o);
+            } else if (f_add) {
+                v += ld4(addend + o);
+            }
+            st4(out + o, v);
+            s1 += v;
+            s2 += v * v;
+        }
+    }
+    if (!f_stats) return;
+    red[0][tid] = s1;
+    red[1][tid] = s2;
+    __syncthreads();
+    if (tid < C4) {
+        for (int k = 1; k < RL; ++k) {
+            s1 += red[0][tid + k * C4];
+            s2 += red[1][tid + k * C4];
+        }
+        const int C = C4T * 4;
+        double* st = stats + (size_t)(blockIdx.x % LOANS_STATS_REPLICAS) * 2 * C;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            atomic_add_f64(st + cg * 4 + e, (double)s1[e]);
+            atomic_add_f64(st + C + cg * 4 + e, (double)s2[e]);
+        }
+    }
+}
+
 // channel slabs: C4 = float4 groups per block (<= 256, divides 256), *slabs = number of slabs
 int reduce_geometry(int64_t rows, int C, int* rows_per_block, int* c4_block, int* slabs) {
     const int C4T = C / 4;
@@ -395,6 +448,23 @@ extern "C" int loans_bn_bwd_reduce_bf16(const void* gy, const void* mask, const 
                                         double* sums, int64_t rows, int32_t C, void* stream) {
     return bn_bwd_reduce_impl<__bf16>(static_cast<const __bf16*>(gy), static_cast<const __bf16*>(mask), static_cast<const __bf16*>(x),
                                       mean, rstd, static_cast<const __bf16*>(x2), mean2, rstd2, sums, rows, C, stream);
+}
+
+extern "C" int loans_igemm_finalize_f32(float* out, const float* bias, double* stats, const float* ref, const float* addend,
+                                        int32_t flags, int64_t rows, int32_t C, void* stream) {
+    if (!out || rows <= 0 || !reduce_channels_ok(C)) return LOANS_EINVAL;
+    if ((flags & LOANS_F_BIAS) && !bias) return LOANS_EINVAL;
+    if ((flags & LOANS_F_STATS) && !stats) return LOANS_EINVAL;
+    if ((flags & (LOANS_F_MASK | LOANS_F_ADDEND_MASK)) && !ref) return LOANS_EINVAL;
+    if ((flags & LOANS_F_ADDEND_MASK) && !(flags & LOANS_F_ADDEND)) return LOANS_EINVAL;
+    if ((flags & LOANS_F_ADDEND) && !addend) return LOANS_EINVAL;
+    if (flags & ~(LOANS_F_BIAS | LOANS_F_STATS | LOANS_F_MASK | LOANS_F_ADDEND | LOANS_F_ADDEND_MASK)) return LOANS_EINVAL;
+    int rpb, c4b, slabs;
+    const int grid = reduce_geometry(rows, C, &rpb, &c4b, &slabs);
+    hipLaunchKernelGGL(igemm_finalize_kernel, dim3(grid, slabs), dim3(256), 0, as_stream(stream), out, bias, stats, ref, addend,
+                       flags, rows, c4b, C / 4, rpb);
+    LOANS_LAUNCH_CHECK();
+    return LOANS_OK;
 }
 
 extern "C" int loans_bn_bwd_coeffs_f32(const double* sums, int32_t C, int64_t count, const float* gamma,

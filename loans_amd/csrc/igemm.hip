@@ -57,6 +57,7 @@ struct IgemmArgs {
     const float* addend;
     loans_igemm_desc d;
     int M, Ktot, nchunks, tiles_m, tiles_n;
+    int splits, chunks_per_split;   // split-K (LOANS_TILE_SPLITK): block (tile, s) contracts chunks [s * cps, (s + 1) * cps) and ADDS its tile
     int m_begin;        // first GEMM row of this launch (LOANS_TILE_SPLIT runs a row range per tile shape); rows end at M
     int tail_groups;    // 8-deep k groups of the last chunk that hold any real K (1..4)
     int bf16;           // 1: round the operands to bf16 and use the bf16 MFMA (fp32 accumulate)
@@ -125,8 +126,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     // MFMA streams of the co-resident blocks (+1.5 % on the short-K stem / res2 tiles, neutral elsewhere)
     __builtin_amdgcn_s_setprio(3);
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
-    const int tn = logical % a.tiles_n;
-    const int tm = logical / a.tiles_n;
+    const int ntile = a.tiles_m * a.tiles_n;
+    const int split = logical / ntile;                  // 0 unless split-K
+    const int ltile = logical - split * ntile;
+    const int tn = ltile % a.tiles_n;
+    const int tm = ltile / a.tiles_n;
+    const int c_begin = split * a.chunks_per_split;     // this block's K chunks
+    const int c_end = min(c_begin + a.chunks_per_split, a.nchunks);
+    const int nch = c_end - c_begin;
+    const int tail_groups = c_end == a.nchunks ? a.tail_groups : 4;
     const int lrow = tid >> 3;
     const int lu = DMA ? ((tid & 7) ^ ((tid >> 4) & 7)) : (tid & 7);   // K unit this thread stages (DMA: slot ^ row key)
     // tap table in LDS: byte offset of tap t relative to the row's base pixel
@@ -215,8 +223,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
 
     const int cpt = d.Cin >> 2;   // float4 units per tap
     const int q8 = 8 / cpt, r8 = 8 - q8 * cpt;
-    int u = lu;                   // this thread's K unit in the chunk being loaded
-    int tap = lu / cpt, c4 = lu - tap * cpt;
+    int u = lu + 8 * c_begin;     // this thread's K unit in the chunk being loaded
+    int tap = u / cpt, c4 = u - tap * cpt;
     unsigned woff[RB], wbad[RB];
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
@@ -345,9 +353,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
         store_chunk(0);
         __syncthreads();
         __builtin_amdgcn_s_setprio(0);
-        for (int c = 0; c < a.nchunks; ++c) {
+        for (int c = 0; c < nch; ++c) {
             const int buf = c & 1;
-            const bool more = (c + 1) < a.nchunks;
+            const bool more = (c + 1) < nch;
             if (more) load_chunk();
 #pragma unroll
             for (int s = 0; s < 2; ++s) {
@@ -394,7 +402,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     read_frag(0, 0, fa0, fb0);
     __builtin_amdgcn_s_setprio(0);
     int c = 0;
-    for (; c + 1 < a.nchunks; ++c) {
+    for (; c + 1 < nch; ++c) {
         const int buf = c & 1;
         read_frag(buf, 1, fa1, fb1);
         relu_frag(fa0);
@@ -428,7 +436,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     }
     {   // last chunk (see the register-staged loop)
         const int buf = c & 1;
-        const int tg = a.tail_groups;
+        const int tg = tail_groups;
         if (tg > 1) read_frag(buf, 1, fa1, fb1);
         relu_frag(fa0);
         mma(fa0, fb0);
@@ -482,7 +490,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
 
     STAMP(t_begin);
     int c = 0;
-    for (; c + 1 < a.nchunks; ++c) {
+    for (; c + 1 < nch; ++c) {
         const int buf = c & 1;
         STAMP(t0);
         // group 0 (+ loader)
@@ -527,7 +535,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     {   // last chunk: nothing left to stage; 8-deep groups that lie wholly beyond Ktot hold zeros on both sides
         // and are skipped (block-uniform branch): exact, and a quarter of the stem's K is such padding
         const int buf = c & 1;
-        const int tg = a.tail_groups;
+        const int tg = tail_groups;
         if (tg > 1) read_frag(buf, 1, fa1, fb1);
         mma(fa0, fb0);
         if (tg > 1) {
@@ -556,7 +564,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     float* Cs = reinterpret_cast<float*>(smem);          // [BM][LDC]
     __builtin_amdgcn_s_setprio(3);
     __syncthreads();                                     // every wave is done with the fragment buffers
-    if (f_stats) {
+    if (f_stats && a.splits == 1) {
         int nvalid = 0;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -613,6 +621,21 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     const unsigned coff = (unsigned)col0 * (f_out16 ? 2u : 4u);
     f32x4 bv4 = {0.f, 0.f, 0.f, 0.f};
     if (f_bias && !cbad) bv4 = *reinterpret_cast<const f32x4*>(a.bias + col0);
+    if (a.splits > 1) {
+        // split-K: the raw partial tile is added to `out` (zeroed, or holding the addend, by the caller); bias, statistics,
+        // mask and addend are applied to the finished sums by loans_igemm_finalize_f32
+#pragma unroll
+        for (int p = 0; p < BM / RSTEP; ++p) {
+            const int row = r0 + p * RSTEP;
+            const unsigned po = opix[row];
+            if (po == 0xFFFFFFFFu || cbad) continue;
+            const f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * LDC + oc4 * 4);
+            float* dst = a.out + ((po + coff) >> 2);
+            atomic_add_f32(dst + 0, v.x); atomic_add_f32(dst + 1, v.y);
+            atomic_add_f32(dst + 2, v.z); atomic_add_f32(dst + 3, v.w);
+        }
+        return;
+    }
 #pragma unroll
     for (int p = 0; p < BM / RSTEP; ++p) {
         const int row = r0 + p * RSTEP;
@@ -681,7 +704,10 @@ int launch_igemm_r(IgemmArgs& a, hipStream_t st) {
     }
     a.tiles_m = (a.M - a.m_begin + BM - 1) / BM;
     a.tiles_n = (a.d.Cout + BN - 1) / BN;
-    const int nblk = a.tiles_m * a.tiles_n;
+    if (a.splits > a.nchunks) a.splits = a.nchunks;
+    a.chunks_per_split = (a.nchunks + a.splits - 1) / a.splits;
+    a.splits = (a.nchunks + a.chunks_per_split - 1) / a.chunks_per_split;
+    const int nblk = a.tiles_m * a.tiles_n * a.splits;
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, st, a);
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;
@@ -774,6 +800,11 @@ static int igemm_impl(const float* in, const float* w, float* out, const float* 
     detect_tap_grid(d, a);
     hipStream_t st = as_stream(stream);
     int tile = d->tile;
+    a.splits = (tile >> 8) & 0xFF;          // LOANS_TILE_SPLITK(s)
+    if (a.splits < 1) a.splits = 1;
+    tile &= 0xFF;
+    if (a.splits > 1 && (bf16 || (d->flags & ~(LOANS_F_DENSE | LOANS_F_RELU_IN)) || tile == LOANS_TILE_SPLIT))
+        return LOANS_EINVAL;                // raw partial sums only: the epilogue flags belong to loans_igemm_finalize_f32
     a.dma = (tile & LOANS_TILE_DMA) ? 1 : 0;
     if (a.dma && bf16) return LOANS_EINVAL;
     tile &= ~LOANS_TILE_DMA;

@@ -262,6 +262,39 @@ def _tuned_tile(geo, mode, run, candidates):
     return tile
 
 
+def reduce_channels_ok(C_):
+    """channel counts the row-reduction kernels (and loans_igemm_finalize_f32) tile: C/4 divides 256 or is a multiple of it"""
+    c4 = C_ // 4
+    return C_ % 4 == 0 and c4 >= 1 and ((256 % c4 == 0) if c4 <= 256 else (c4 % 256 == 0))
+
+
+def _splitk_candidates(M, Cout, nchunks):
+    """split-K forms of the 64x64 tile (LOANS_TILE_SPLITK) for grids that cannot fill the machine: few tiles, long K --
+    the deep layers at small batch and single-image inference.  tile id = 3 | (splits << 8)."""
+    tiles = ((M + 63) // 64) * ((Cout + 63) // 64)
+    if COMPUTE != 'f32' or tiles >= 512 or nchunks < 16:
+        return ()
+    return tuple(3 | (s << 8) for s in (2, 4, 8, 16) if tiles * s <= 4096 and nchunks // s >= 4)
+
+
+def _igemm_splitk(lib, fn_in, w, out, d_list, flags, tile, bias, stats, ref, addend, rows, Cout, st):
+    """A split-K convolution: zero the output (unless it already holds the addend), the launches ADD raw partial tiles,
+    one finalize pass applies the epilogue flags to the finished sums.  d_list = [(desc, weight_tensor)]."""
+    inplace = addend is not None and addend.data_ptr() == out.data_ptr()
+    if not inplace:
+        out.zero_()
+    for d, wt in d_list:
+        check(lib.loans_igemm_f32(_ptr(fn_in), _ptr(wt), _ptr(out), 0, 0, 0, 0,
+                                  C.byref(_with_flags(d, flags & (F_RELU_IN | F_DENSE), tile)), st), 'loans_igemm_f32[split-K]')
+    fin = flags & (F_BIAS | F_STATS | F_MASK | F_ADDEND | F_ADDEND_MASK)
+    if inplace:
+        assert not (fin & (F_MASK | F_ADDEND_MASK)), 'a masked conv term cannot be summed into an aliased addend'
+        fin &= ~F_ADDEND
+    if fin:
+        check(lib.loans_igemm_finalize_f32(_ptr(out), _ptr(bias), _ptr(stats), _ptr(ref), _ptr(None if inplace else addend),
+                                           fin, rows, Cout, st), 'loans_igemm_finalize_f32')
+
+
 def _igemm_launches(M, Cout, tile, device):
     """Kernel launches behind one loans_igemm call: LOANS_TILE_SPLIT is two when both row ranges are non-empty
     (same arithmetic as igemm_impl)."""
@@ -293,16 +326,27 @@ def conv_fprop(x, w, geo, out=None, bias=None, stats=None, relu_in=False, addend
 
         def run(t):
             scratch = torch.empty((geo.B, geo.Ho, geo.Wo, geo.Cout), device=x.device, dtype=torch.float32)
+            if t >> 8:
+                _igemm_splitk(lib, x, w, scratch, [(geo.fwd, w)], tflags, t, None, sstats, None, None,
+                              geo.B * geo.Ho * geo.Wo, geo.Cout, _stream())
+                return
             check(_igemm_fn(lib)(_ptr(x), _ptr(w), _ptr(scratch), 0, _ptr(sstats), 0, 0,
                                       C.byref(_with_flags(geo.fwd, tflags, t)), _stream()), 'loans_igemm_f32[tune]')
-        tile = _tuned_tile(geo, COMPUTE + 'fprop' + ('_stats' if stats is not None else ''), run, _FPROP_TILES)   # fp32 scratch output: the tile choice carries over
+        M_ = geo.B * geo.Ho * geo.Wo
+        cands = _FPROP_TILES + (() if (out_bf16 or not reduce_channels_ok(geo.Cout)) else
+                                _splitk_candidates(M_, geo.Cout, (geo.w_numel // geo.Cout + 31) // 32))
+        tile = _tuned_tile(geo, COMPUTE + 'fprop' + ('_stats' if stats is not None else ''), run, cands)   # fp32 scratch output: the tile choice carries over
     d = _with_flags(geo.fwd, flags, tile)
     log = EVENT_LOG
     if log is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    check(_igemm_fn(lib)(_ptr(x), _ptr(w), _ptr(out), _ptr(bias), _ptr(stats), 0, _ptr(addend),
-                         C.byref(d), _stream()), 'loans_igemm[fprop]')
+    if tile >> 8:
+        _igemm_splitk(lib, x, w, out, [(geo.fwd, w)], flags, tile, bias, stats, None, addend,
+                      geo.B * geo.Ho * geo.Wo, geo.Cout, _stream())
+    else:
+        check(_igemm_fn(lib)(_ptr(x), _ptr(w), _ptr(out), _ptr(bias), _ptr(stats), 0, _ptr(addend),
+                             C.byref(d), _stream()), 'loans_igemm[fprop]')
     if log is not None:
         ev1.record()
         # algorithmic FLOPs: logical input channels (3 for the RGB stem), no padding, no im2col redundancy
@@ -418,13 +462,29 @@ def conv_dgrad(gy, w, geo, out=None, mask_ref=None, addend=None, addend_mask_ref
     for d, tapsel, off in geo.dgrad:
         check(lib.loans_repack_dgrad_f32(_ptr(w), _ptr(wp[off:]), geo.Cout, geo.Cin, geo.k * geo.k, tapsel,
                                          d.ntaps, st), 'loans_repack_dgrad_f32')
+    # split-K adds raw partial sums: a masked conv term cannot land on an addend that already sits in `out`
+    inplace_masked = addend is not None and addend.data_ptr() == out.data_ptr() and mask_ref is not None
+    dl = [(d, wp[off:]) for d, _, off in geo.dgrad]
+    rows_in = geo.B * geo.H * geo.W
     if tile == 0:
         def run(t):
             scratch = torch.empty((geo.B, geo.H, geo.W, geo.Cin), device=gy.device, dtype=torch.float32)
+            if t >> 8:
+                _igemm_splitk(lib, gy, None, scratch, dl, 0, t, None, None, None, None, rows_in, geo.Cin, st)
+                return
             for d, _, off in geo.dgrad:
                 check(_igemm_fn(lib)(_ptr(gy), _ptr(wp[off:]), _ptr(scratch), 0, 0, 0, 0,
                                      C.byref(_with_flags(d, 0, t)), st), 'loans_igemm[tune]')
-        tile = _tuned_tile(geo, COMPUTE + 'dgrad', run, _IGEMM_TILES)
+        cands, key = _IGEMM_TILES, COMPUTE + 'dgrad'
+        if not inplace_masked and reduce_channels_ok(geo.Cin):
+            # the smallest class grid decides: (Ho x Wo pixels of one parity class) x Cin columns, K = its taps x Cout
+            cls_rows = geo.B * geo.dgrad[0][0].gridH * geo.dgrad[0][0].gridW
+            cands = cands + _splitk_candidates(cls_rows, geo.Cin, (min(d.ntaps for d, _, _ in geo.dgrad) * geo.Cout + 31) // 32)
+            key += '_sk'
+        tile = _tuned_tile(geo, key, run, cands)
+    if tile >> 8:
+        _igemm_splitk(lib, gy, None, out, dl, flags, tile, None, None, ref, addend, rows_in, geo.Cin, st)
+        return out
     for d, tapsel, off in geo.dgrad:
         _with_flags(d, flags, tile)
         check(_igemm_fn(lib)(_ptr(gy), _ptr(wp[off:]), _ptr(out), 0, 0, _ptr(ref), _ptr(addend),

@@ -147,6 +147,48 @@ def test_conv_split_tile():
     assert rel_err(_nchw(gx), gx_ref * (ref_t > 0)) < 2e-6
 
 
+@pytest.mark.parametrize("case", [(2, 64, 14, 14, 64, 3, 1, 1), (2, 64, 15, 13, 128, 3, 2, 1), (3, 256, 7, 7, 64, 1, 1, 0),
+                                  (1, 128, 9, 9, 128, 4, 2, 1)])
+@pytest.mark.parametrize("splits", [2, 4, 16])
+def test_conv_split_k(case, splits):
+    """LOANS_TILE_SPLITK: blocks contract slices of K and add raw partial tiles; loans_igemm_finalize_f32 applies bias /
+    statistics / mask / addend to the finished sums.  Same results as the one-pass kernel up to the fp32 summation order
+    (1e-6), for the forward conv (+ bias + stats, relu_in + aliased addend) and the data gradient (mask + addend, masked
+    addend, in-place accumulation)."""
+    from loans_amd import ops
+    B, Cin, H, W, Cout, k, s, p = case
+    rng = np.random.RandomState(17)
+    x = rng.standard_normal((B, Cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    geo = ops.ConvGeometry(B, H, W, Cin, Cout, k, s, p)
+    xd, wd, bd = dev(_nhwc(x)), dev(_ohwi(w)), dev(b)
+    tile = 3 | (splits << 8)
+    st1, stk = ops.stats_buffer(Cout, 'cuda'), ops.stats_buffer(Cout, 'cuda')
+    y1 = ops.conv_fprop(xd, wd, geo, bias=bd, stats=st1, tile=3)
+    yk = ops.conv_fprop(xd, wd, geo, bias=bd, stats=stk, tile=tile)
+    assert rel_err(yk.cpu().numpy(), y1.cpu().numpy()) < 2e-6
+    np.testing.assert_allclose(stk.sum(0).cpu().numpy(), st1.sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3)
+    add = dev(_nhwc(rng.standard_normal((B, Cout, geo.Ho, geo.Wo)).astype(np.float32)))
+    a1, ak = add.clone(), add.clone()
+    ops.conv_fprop(xd, wd, geo, out=a1, relu_in=True, addend=a1, tile=3)          # in place: out = conv(relu(x)) + out
+    ops.conv_fprop(xd, wd, geo, out=ak, relu_in=True, addend=ak, tile=tile)
+    assert rel_err(ak.cpu().numpy(), a1.cpu().numpy()) < 2e-6
+    gy = dev(_nhwc(rng.standard_normal((B, Cout, geo.Ho, geo.Wo)).astype(np.float32)))
+    ref_t = dev(_nhwc(rng.standard_normal(x.shape).astype(np.float32)))
+    addx = dev(_nhwc(rng.standard_normal(x.shape).astype(np.float32)))
+    g1 = ops.conv_dgrad(gy, wd, geo, mask_ref=ref_t, addend=addx, tile=3)
+    gk = ops.conv_dgrad(gy, wd, geo, mask_ref=ref_t, addend=addx, tile=tile)
+    assert rel_err(gk.cpu().numpy(), g1.cpu().numpy()) < 2e-6
+    g1 = ops.conv_dgrad(gy, wd, geo, addend=addx, addend_mask_ref=ref_t, tile=3)
+    gk = ops.conv_dgrad(gy, wd, geo, addend=addx, addend_mask_ref=ref_t, tile=tile)
+    assert rel_err(gk.cpu().numpy(), g1.cpu().numpy()) < 2e-6
+    a1, ak = addx.clone(), addx.clone()
+    ops.conv_dgrad(gy, wd, geo, out=a1, addend=a1, tile=3)
+    ops.conv_dgrad(gy, wd, geo, out=ak, addend=ak, tile=tile)
+    assert rel_err(ak.cpu().numpy(), a1.cpu().numpy()) < 2e-6
+
+
 def test_prep_images_dense_exact():
     """the padded packed-RGB buffer conv1 reads: same arithmetic, zero border, every element written"""
     from loans_amd import ops
