@@ -131,3 +131,28 @@ def test_every_entry_point_rejects_null_pointers(lib):
                 args.append(4)
         rc = getattr(lib, name)(*args)
         assert rc in (-1, -2), (name, rc)
+
+
+def test_tile_selection_host_logic():
+    """pure host logic of loans_amd/ops.py that decides which kernel variants are offered (no GPU): split-K candidates
+    only for small grids with a long K in the fp32 arm, channel counts the finalize / reduction kernels tile, the keys
+    that keep the autotune tables of differently-staged weight gradients apart"""
+    import torch
+    from loans_amd import ops
+    assert ops._splitk_candidates(16 * 49, 512, 144) == tuple(3 | (s << 8) for s in (2, 4, 8, 16))      # res5 at B = 16
+    assert ops._splitk_candidates(256 * 49, 512, 144) == ()                                               # ... at B = 256
+    assert ops._splitk_candidates(16 * 49, 512, 8) == ()                                                  # short K
+    assert all((t >> 8) * 4 <= 18 for t in ops._splitk_candidates(49, 64, 18))                            # >= 4 chunks per slice
+    ops.set_compute_dtype('bf16')
+    try:
+        assert ops._splitk_candidates(16 * 49, 512, 144) == ()                                            # fp32 arm only
+    finally:
+        ops.set_compute_dtype('f32')
+    for c, ok in ((4, True), (64, True), (96, False), (1024, True), (2048, True), (1536, False), (6, False)):
+        assert ops.reduce_channels_ok(c) is ok, c
+    f32, b16 = torch.zeros(1), torch.zeros(1, dtype=torch.bfloat16)
+    keys = {ops._wgrad_key(f32, f32, False), ops._wgrad_key(f32, f32, True), ops._wgrad_key(b16, b16, False),
+            ops._wgrad_key(b16, b16, True), ops._wgrad_key(f32, b16, False)}
+    assert len(keys) == 5
+    with __import__('pytest').raises(ValueError):
+        ops.set_storage_dtype('bf16')            # bf16 storage needs the bf16 compute arm first
