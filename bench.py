@@ -174,8 +174,9 @@ def main():
     # ---- conv-forward roofline from the events of the timed steps ----
     roofline = None
     if log:
-        loc = [(tag, flops, max(s.elapsed_time(e) - ev_overhead_ms, 0.0), nl) for tag, flops, s, e, nl in log if tag == 'fprop_bn']
-        raw_ms = sum(s.elapsed_time(e) for tag, flops, s, e, nl in log if tag == 'fprop_bn')
+        log = [tuple(x) + (1,) * (6 - len(x)) for x in log]          # (tag, flops, ev0, ev1, launches, convolutions)
+        loc = [(tag, flops, max(s.elapsed_time(e) - ev_overhead_ms, 0.0), nl, nc) for tag, flops, s, e, nl, nc in log if tag == 'fprop_bn']
+        raw_ms = sum(s.elapsed_time(e) for tag, flops, s, e, nl, nc in log if tag == 'fprop_bn')
         tot_ms = sum(x[2] for x in loc)
         tot_flop = sum(x[1] for x in loc)
         n_launch = sum(x[3] for x in loc)          # a LOANS_TILE_SPLIT conv is two launches
@@ -184,7 +185,7 @@ def main():
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": None,
                     "kernel": "igemm_kernel (localizer conv forward: %d convs = %d launches per step)"
-                              % (len(loc) // args.steps, n_launch // args.steps),
+                              % (sum(x[4] for x in loc) // args.steps, n_launch // args.steps),
                     "avg_launch_ms": round(tot_ms / max(n_launch, 1), 4),
                     "conv_fwd_ms_per_step": round(tot_ms / args.steps, 3),
                     "conv_fwd_ms_per_step_raw_brackets": round(raw_ms / args.steps, 3),

@@ -100,6 +100,14 @@ int loans_igemm_f32(const float* in, const float* w, float* out,
                     const float* bias, double* stats, const float* ref, const float* addend,
                     const loans_igemm_desc* d, void* stream);
 
+/* Two forward convolutions of the SAME input with the same geometry (kernel, stride, padding, Cin) in ONE launch: BasicA's
+ * conv1 and its strided conv shortcut (sheep/resnet.py:128-133), a bottleneck's conv1 and conv4.  `d` describes
+ * convolution a (Cout = Cout_a); b differs in weights, Cout_b, output and statistics.  The second one's tiles take the
+ * blocks behind the first one's, so the two share one grid and one tail.  Flags STATS / RELU_IN; fp32 arm; tile shapes
+ * without LOANS_TILE_SPLIT / LOANS_TILE_SPLITK. */
+int loans_igemm_pair_f32(const float* in, const float* w_a, float* out_a, double* stats_a, const float* w_b,
+                         float* out_b, double* stats_b, int32_t Cout_b, const loans_igemm_desc* d, void* stream);
+
 /* epilogue of a split-K convolution (LOANS_TILE_SPLITK) over the finished sums, in place on the whole tensor
  * out [rows][C]: (+ bias) (* (ref > 0)) (+ addend [masked by ref > 0]) and the BN statistics of the result; flags as above */
 int loans_igemm_finalize_f32(float* out, const float* bias, double* stats, const float* ref, const float* addend,

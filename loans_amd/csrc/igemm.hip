@@ -57,6 +57,13 @@ struct IgemmArgs {
     const float* addend;
     loans_igemm_desc d;
     int M, Ktot, nchunks, tiles_m, tiles_n;
+    // pair launch (loans_igemm_pair_f32): a second convolution of the SAME input and geometry (other weights / Cout / output /
+    // statistics) takes the blocks behind the first one's: one grid, one tail
+    const float* w2;
+    float* out2;
+    double* stats2;
+    int Cout2, tiles_n2;
+    unsigned w2_bytes, out2_bytes;
     int splits, chunks_per_split;   // split-K (LOANS_TILE_SPLITK): block (tile, s) contracts chunks [s * cps, (s + 1) * cps) and ADDS its tile
     int m_begin;        // first GEMM row of this launch (LOANS_TILE_SPLIT runs a row range per tile shape); rows end at M
     int tail_groups;    // 8-deep k groups of the last chunk that hold any real K (1..4)
@@ -126,11 +133,20 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     // MFMA streams of the co-resident blocks (+1.5 % on the short-K stem / res2 tiles, neutral elsewhere)
     __builtin_amdgcn_s_setprio(3);
     const int logical = xcd_remap(blockIdx.x, gridDim.x);
-    const int ntile = a.tiles_m * a.tiles_n;
-    const int split = logical / ntile;                  // 0 unless split-K
-    const int ltile = logical - split * ntile;
-    const int tn = ltile % a.tiles_n;
-    const int tm = ltile / a.tiles_n;
+    // pair launch: the blocks behind the first convolution's tiles belong to the second one (block-uniform selection)
+    const bool second = a.w2 != nullptr && logical >= a.tiles_m * a.tiles_n;
+    const int Cout = second ? a.Cout2 : d.Cout;
+    const int tiles_n = second ? a.tiles_n2 : a.tiles_n;
+    const float* const w_sel = second ? a.w2 : a.w;
+    float* const out_sel = second ? a.out2 : a.out;
+    double* const stats_sel = second ? a.stats2 : a.stats;
+    const unsigned w_bytes = second ? a.w2_bytes : a.w_bytes, out_bytes = second ? a.out2_bytes : a.out_bytes;
+    const int lfirst = second ? logical - a.tiles_m * a.tiles_n : logical;
+    const int ntile = a.tiles_m * tiles_n;
+    const int split = a.w2 ? 0 : lfirst / ntile;        // 0 unless split-K
+    const int ltile = lfirst - split * ntile;
+    const int tn = ltile % tiles_n;
+    const int tm = ltile / tiles_n;
     const int c_begin = split * a.chunks_per_split;     // this block's K chunks
     const int c_end = min(c_begin + a.chunks_per_split, a.nchunks);
     const int nch = c_end - c_begin;
@@ -171,7 +187,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
             if (m < a.M) {
                 const int iy0 = y * d.isy, ix0 = x * d.isx;
                 rowoff[i] = (unsigned)((b * d.inH + iy0) * d.inW + ix0) * (unsigned)ubytes;
-                pixoff = (unsigned)((b * d.outH + y * d.osy + d.oy0) * d.outW + x * d.osx + d.ox0) * (unsigned)d.Cout *
+                pixoff = (unsigned)((b * d.outH + y * d.osy + d.oy0) * d.outW + x * d.osx + d.ox0) * (unsigned)Cout *
                          ((d.flags & LOANS_F_OUT_BF16) ? 2u : 4u);
                 if (dense) {
                     mask = ~0ull;
@@ -219,7 +235,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<float*>(a.in), 0, (int)a.in_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.w), 0, (int)a.w_bytes, 0x00020000);
+        const_cast<float*>(w_sel), 0, (int)w_bytes, 0x00020000);
 
     const int cpt = d.Cin >> 2;   // float4 units per tap
     const int q8 = 8 / cpt, r8 = 8 - q8 * cpt;
@@ -229,8 +245,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
         const int n = tn * BN + lrow + 32 * i;
-        wbad[i] = n < d.Cout ? 0u : 0xFFFFFFFFu;
-        woff[i] = n < d.Cout ? (unsigned)n * (unsigned)a.Ktot * 4u : 0u;
+        wbad[i] = n < Cout ? 0u : 0xFFFFFFFFu;
+        woff[i] = n < Cout ? (unsigned)n * (unsigned)a.Ktot * 4u : 0u;
     }
     unsigned toff = (unsigned)taps[min(tap, LOANS_MAX_TAPS - 1)] + (unsigned)c4 * 16u;   // prefetched one chunk ahead
 
@@ -575,7 +591,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
             const int col = tn * BN + wn * TN * 32 + j * 32 + r;
-            const bool cok = col < d.Cout;
+            const bool cok = col < Cout;
             const float bv = (f_bias && cok) ? a.bias[col] : 0.f;
             float s = 0.f, q2 = 0.f;
 #pragma unroll
@@ -591,9 +607,9 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
             s += __shfl_xor(s, 32, 64);
             q2 += __shfl_xor(q2, 32, 64);
             if (h == 0 && cok) {       // LOANS_STATS_REPLICAS accumulators, picked by block, against contention
-                double* st = a.stats + (size_t)(blockIdx.x % LOANS_STATS_REPLICAS) * 2 * d.Cout;
+                double* st = stats_sel + (size_t)(blockIdx.x % LOANS_STATS_REPLICAS) * 2 * Cout;
                 atomic_add_f64(st + col, (double)s);
-                atomic_add_f64(st + d.Cout + col, (double)q2);
+                atomic_add_f64(st + Cout + col, (double)q2);
             }
         }
     }
@@ -606,17 +622,17 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
                 Cs[(wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * LDC + wn * TN * 32 + j * 32 + r] = acc[i][j][e];
     __syncthreads();
 
-    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)a.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(out_sel, 0, (int)out_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_ref = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.ref ? a.ref : a.out), 0, (int)a.out_bytes, 0x00020000);
+        const_cast<float*>(a.ref ? a.ref : out_sel), 0, (int)out_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_add = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<float*>(a.addend ? a.addend : a.out), 0, (int)a.out_bytes, 0x00020000);
+        const_cast<float*>(a.addend ? a.addend : out_sel), 0, (int)out_bytes, 0x00020000);
     typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
     constexpr int CPR = BN / 4;                 // float4 columns per row
     constexpr int RSTEP = 256 / CPR;            // rows covered by the block per pass
     const int oc4 = tid % CPR, r0 = tid / CPR;
     const int col0 = tn * BN + oc4 * 4;
-    const unsigned cbad = (col0 + 3 < d.Cout) ? 0u : 0xFFFFFFFFu;     // Cout % 4 == 0 on every layer here
+    const unsigned cbad = (col0 + 3 < Cout) ? 0u : 0xFFFFFFFFu;       // Cout % 4 == 0 on every layer here
     const bool f_out16 = d.flags & LOANS_F_OUT_BF16;      // bf16 output tensor (no ref / addend in this mode: checked)
     const unsigned coff = (unsigned)col0 * (f_out16 ? 2u : 4u);
     f32x4 bv4 = {0.f, 0.f, 0.f, 0.f};
@@ -630,7 +646,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
             const unsigned po = opix[row];
             if (po == 0xFFFFFFFFu || cbad) continue;
             const f32x4 v = *reinterpret_cast<const f32x4*>(Cs + row * LDC + oc4 * 4);
-            float* dst = a.out + ((po + coff) >> 2);
+            float* dst = out_sel + ((po + coff) >> 2);
             atomic_add_f32(dst + 0, v.x); atomic_add_f32(dst + 1, v.y);
             atomic_add_f32(dst + 2, v.z); atomic_add_f32(dst + 3, v.w);
         }
@@ -704,10 +720,11 @@ int launch_igemm_r(IgemmArgs& a, hipStream_t st) {
     }
     a.tiles_m = (a.M - a.m_begin + BM - 1) / BM;
     a.tiles_n = (a.d.Cout + BN - 1) / BN;
+    a.tiles_n2 = a.w2 ? (a.Cout2 + BN - 1) / BN : 0;
     if (a.splits > a.nchunks) a.splits = a.nchunks;
     a.chunks_per_split = (a.nchunks + a.splits - 1) / a.splits;
     a.splits = (a.nchunks + a.chunks_per_split - 1) / a.chunks_per_split;
-    const int nblk = a.tiles_m * a.tiles_n * a.splits;
+    const int nblk = a.w2 ? a.tiles_m * (a.tiles_n + a.tiles_n2) : a.tiles_m * a.tiles_n * a.splits;
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, st, a);
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;
@@ -764,8 +781,16 @@ int check_desc(const loans_igemm_desc* d) {
 
 }  // namespace
 
+struct IgemmPair {       // second convolution of a pair launch
+    const float* w;
+    float* out;
+    double* stats;
+    int Cout;
+};
+
 static int igemm_impl(const float* in, const float* w, float* out, const float* bias, double* stats,
-                      const float* ref, const float* addend, const loans_igemm_desc* d, void* stream, int bf16) {
+                      const float* ref, const float* addend, const loans_igemm_desc* d, void* stream, int bf16,
+                      const IgemmPair* pair = nullptr) {
     int rc = check_desc(d);
     if (rc) return rc;
     if (!in || !w || !out || (d->Cout & 3)) return LOANS_EINVAL;
@@ -779,6 +804,7 @@ static int igemm_impl(const float* in, const float* w, float* out, const float* 
     a.in = in; a.w = w; a.out = out; a.bias = bias; a.stats = stats; a.ref = ref; a.addend = addend;
     a.d = *d;
     a.bf16 = bf16;
+    a.w2 = nullptr; a.out2 = nullptr; a.stats2 = nullptr; a.Cout2 = 0; a.tiles_n2 = 0; a.w2_bytes = a.out2_bytes = 0;
     a.dbg = 0;
 #ifdef LOANS_EXPERIMENT
     if (const char* e = getenv("LOANS_DBG")) a.dbg = atoi(e);
@@ -798,8 +824,16 @@ static int igemm_impl(const float* in, const float* w, float* out, const float* 
         a.out_bytes = (unsigned)ob;
     }
     detect_tap_grid(d, a);
+    if (pair) {
+        const int64_t wb2 = (int64_t)pair->Cout * a.Ktot * 4;
+        const int64_t ob2 = (int64_t)d->B * d->outH * d->outW * pair->Cout * 4;
+        if (wb2 >= 0xFFFFFFF0ll || ob2 >= 0xFFFFFFF0ll) return LOANS_ERANGE;
+        a.w2 = pair->w; a.out2 = pair->out; a.stats2 = pair->stats; a.Cout2 = pair->Cout;
+        a.w2_bytes = (unsigned)wb2; a.out2_bytes = (unsigned)ob2;
+    }
     hipStream_t st = as_stream(stream);
     int tile = d->tile;
+    if (pair && ((tile >> 8) || (tile & 0xFF) == LOANS_TILE_SPLIT)) return LOANS_EINVAL;
     a.splits = (tile >> 8) & 0xFF;          // LOANS_TILE_SPLITK(s)
     if (a.splits < 1) a.splits = 1;
     tile &= 0xFF;
@@ -853,6 +887,15 @@ static int igemm_impl(const float* in, const float* w, float* out, const float* 
 extern "C" int loans_igemm_f32(const float* in, const float* w, float* out, const float* bias, double* stats,
                                const float* ref, const float* addend, const loans_igemm_desc* d, void* stream) {
     return igemm_impl(in, w, out, bias, stats, ref, addend, d, stream, 0);
+}
+
+extern "C" int loans_igemm_pair_f32(const float* in, const float* w_a, float* out_a, double* stats_a, const float* w_b,
+                                    float* out_b, double* stats_b, int32_t Cout_b, const loans_igemm_desc* d, void* stream) {
+    if (!d || !w_b || !out_b || Cout_b <= 0 || (Cout_b & 3)) return LOANS_EINVAL;
+    if (d->flags & ~(LOANS_F_STATS | LOANS_F_RELU_IN)) return LOANS_EINVAL;
+    if ((d->flags & LOANS_F_STATS) && !stats_b) return LOANS_EINVAL;
+    const IgemmPair p = {w_b, out_b, stats_b, Cout_b};
+    return igemm_impl(in, w_a, out_a, nullptr, stats_a, nullptr, nullptr, d, stream, 0, &p);
 }
 
 extern "C" int loans_igemm_bf16_f32(const float* in, const float* w, float* out, const float* bias, double* stats,

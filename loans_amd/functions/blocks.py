@@ -99,18 +99,40 @@ class ResidualUnitFunction(Function):
         self.x = x
         self.c, self.st, self.geo, self.h = [None] * n, [None] * n, [None] * n, [None] * n
         h = x
+        paired = self._forward_pair(x, inputs) if self.shortcut is not None else False
         for i, (conv, bn) in enumerate(self.stages):
             W, g, b = inputs[1 + 3 * i:4 + 3 * i]
-            self.c[i], self.st[i], self.geo[i] = _ConvBN.forward(h, conv, bn, W, None, g, b)
+            if not (paired and i == 0):
+                self.c[i], self.st[i], self.geo[i] = _ConvBN.forward(h, conv, bn, W, None, g, b)
             if i < n - 1:
                 h = self.h[i] = ops.bn_apply(self.c[i], self.st[i], relu=True)
         if self.shortcut is not None:
             W, g, b = inputs[1 + 3 * n:4 + 3 * n]
-            self.cs, self.sts, self.geos = _ConvBN.forward(x, self.shortcut[0], self.shortcut[1], W, None, g, b)
+            if not paired:
+                self.cs, self.sts, self.geos = _ConvBN.forward(x, self.shortcut[0], self.shortcut[1], W, None, g, b)
             self.out = ops.bn_apply(self.c[-1], self.st[-1], relu=True, x2=self.cs, st2=self.sts)
         else:
             self.out = ops.bn_apply(self.c[-1], self.st[-1], relu=True, residual=x)
         return self.out
+
+    def _forward_pair(self, x, inputs):
+        """the first stage's conv and the shortcut conv read the same x with the same kernel / stride / padding
+        (BasicA: sheep/resnet.py:128-133; a bottleneck's conv1 / conv4): in training, fp32, they go out as ONE launch
+        whose two tile sets share a grid and a tail (ops.conv_fprop_pair).  Sets c[0], st[0], geo[0], cs, sts, geos."""
+        n = len(self.stages)
+        (conv, bn), (convs, bns) = self.stages[0], self.shortcut
+        B, H, Wd, _ = x.shape
+        geo, geos = conv.geometry(B, H, Wd), convs.geometry(B, H, Wd)
+        if not config.train or conv.dense_rows or not ops.fprop_pair_ok(x, geo, geos):
+            return False
+        W, g, b = inputs[1:4]
+        Ws, gs, bs = inputs[1 + 3 * n:4 + 3 * n]
+        sa, sb = _zeros_stats(conv.out_channels, x.device), _zeros_stats(convs.out_channels, x.device)
+        self.c[0], self.cs = ops.conv_fprop_pair(x, W, Ws, geo, geos, sa, sb)
+        self.st[0] = ops.bn_finalize(sa, B * geo.Ho * geo.Wo, g, b, bn.avg_mean, bn.avg_var)
+        self.sts = ops.bn_finalize(sb, B * geos.Ho * geos.Wo, gs, bs, bns.avg_mean, bns.avg_var)
+        self.geo[0], self.geos = geo, geos
+        return True
 
     def backward(self, inputs, gys):
         _require_train()

@@ -356,6 +356,46 @@ def conv_fprop(x, w, geo, out=None, bias=None, stats=None, relu_in=False, addend
     return out
 
 
+def fprop_pair_ok(x, geo_a, geo_b):
+    """conv_fprop_pair applies: fp32 tensors and arithmetic, same input / kernel / stride / padding, no dense rows"""
+    return (COMPUTE == 'f32' and not _is16(x) and not geo_a.dense and not geo_b.dense and
+            (geo_a.B, geo_a.H, geo_a.W, geo_a.Cin, geo_a.k, geo_a.stride, geo_a.pad) ==
+            (geo_b.B, geo_b.H, geo_b.W, geo_b.Cin, geo_b.k, geo_b.stride, geo_b.pad))
+
+
+_PAIR_TILES = tuple(t for t in _FPROP_TILES if (t & 15) != 6)
+
+
+def conv_fprop_pair(x, w_a, w_b, geo_a, geo_b, stats_a=None, stats_b=None, tile=0):
+    """Two forward convolutions of the same input in ONE launch (loans_igemm_pair_f32): BasicA's conv1 and conv shortcut,
+    a bottleneck's conv1 and conv4.  Returns (out_a, out_b); statistics for both or for neither."""
+    lib = _lib.load()
+    assert fprop_pair_ok(x, geo_a, geo_b) and (stats_a is None) == (stats_b is None)
+    mk = lambda g: torch.empty((g.B, g.Ho, g.Wo, g.Cout), device=x.device, dtype=torch.float32)      # noqa: E731
+    out_a, out_b = mk(geo_a), mk(geo_b)
+    flags = F_STATS if stats_a is not None else 0
+    if tile == 0:
+        sa = stats_buffer(geo_a.Cout, x.device) if flags else None
+        sb = stats_buffer(geo_b.Cout, x.device) if flags else None
+        ta, tb = mk(geo_a), mk(geo_b)
+
+        def run(t):
+            check(lib.loans_igemm_pair_f32(_ptr(x), _ptr(w_a), _ptr(ta), _ptr(sa), _ptr(w_b), _ptr(tb), _ptr(sb), geo_b.Cout,
+                                           C.byref(_with_flags(geo_a.fwd, flags, t)), _stream()), 'loans_igemm_pair_f32[tune]')
+        tile = _tuned_tile(geo_a, 'f32fprop_pair%d%s' % (geo_b.Cout, '_stats' if flags else ''), run, _PAIR_TILES)
+    log = EVENT_LOG
+    if log is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(lib.loans_igemm_pair_f32(_ptr(x), _ptr(w_a), _ptr(out_a), _ptr(stats_a), _ptr(w_b), _ptr(out_b), _ptr(stats_b),
+                                   geo_b.Cout, C.byref(_with_flags(geo_a.fwd, flags, tile)), _stream()), 'loans_igemm_pair_f32')
+    if log is not None:
+        ev1.record()
+        fl = 2 * geo_a.B * geo_a.Ho * geo_a.Wo * (geo_a.Cout + geo_b.Cout) * geo_a.k * geo_a.k * geo_a.cin_logical
+        log.append(('fprop_bn' if flags else 'fprop', fl, ev0, ev1, 1, 2))        # one launch, two convolutions
+    return out_a, out_b
+
+
 def _conv_fprop16(lib, x, w, geo, out, bias, stats, relu_in, addend, tile):
     """bf16-storage forward conv: x / out / addend bf16, w fp32 master weights (cast per call) or already bf16."""
     assert not geo.dense

@@ -189,6 +189,28 @@ def test_conv_split_k(case, splits):
     assert rel_err(ak.cpu().numpy(), a1.cpu().numpy()) < 2e-6
 
 
+@pytest.mark.parametrize("case", [(3, 64, 14, 14, 128, 128, 3, 2, 1), (2, 256, 9, 9, 64, 256, 1, 2, 0), (2, 64, 12, 12, 64, 200, 3, 1, 1)])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 17, 18, 19])
+def test_conv_fprop_pair(case, tile):
+    """loans_igemm_pair_f32: two convolutions of one input (BasicA's conv1 + conv shortcut; a bottleneck's conv1 + conv4,
+    different Cout) in one launch give bit-identical outputs and the same statistics as two launches"""
+    from loans_amd import ops
+    B, Cin, H, W, Ca, Cb, k, s, p = case
+    rng = np.random.RandomState(23)
+    x = dev(_nhwc(rng.standard_normal((B, Cin, H, W)).astype(np.float32)))
+    wa = dev(_ohwi((rng.standard_normal((Ca, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)))
+    wb = dev(_ohwi((rng.standard_normal((Cb, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)))
+    ga, gb = ops.ConvGeometry(B, H, W, Cin, Ca, k, s, p), ops.ConvGeometry(B, H, W, Cin, Cb, k, s, p)
+    assert ops.fprop_pair_ok(x, ga, gb)
+    sa, sb, sa1, sb1 = (ops.stats_buffer(c, 'cuda') for c in (Ca, Cb, Ca, Cb))
+    ya, yb = ops.conv_fprop_pair(x, wa, wb, ga, gb, sa, sb, tile=tile)
+    ya1 = ops.conv_fprop(x, wa, ga, stats=sa1, tile=tile if tile else 3)
+    yb1 = ops.conv_fprop(x, wb, gb, stats=sb1, tile=tile if tile else 3)
+    assert torch.equal(ya, ya1) and torch.equal(yb, yb1)
+    np.testing.assert_allclose(sa.sum(0).cpu().numpy(), sa1.sum(0).cpu().numpy(), rtol=1e-6, atol=1e-4)
+    np.testing.assert_allclose(sb.sum(0).cpu().numpy(), sb1.sum(0).cpu().numpy(), rtol=1e-6, atol=1e-4)
+
+
 def test_prep_images_dense_exact():
     """the padded packed-RGB buffer conv1 reads: same arithmetic, zero border, every element written"""
     from loans_amd import ops
