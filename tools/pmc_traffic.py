@@ -19,7 +19,7 @@ def conv_fwd_sum(path, counter):
     seg = rows[prep[-2]:prep[-1]]
     gap = next(i for i, r in enumerate(seg) if 'gap_fwd_kernel' in r['Kernel_Name'])      # end of the backbone forward
     fwd = [r for r in seg[:gap] if 'igemm' in r['Kernel_Name']]      # 21 convs; a LOANS_TILE_SPLIT conv is two launches
-    assert len(fwd) >= 21
+    assert len(fwd) >= 17          # 21 convs; BasicA pairs are one launch, a LOANS_TILE_SPLIT conv is two
     return sum(float(r['Counter_Value']) for r in fwd) * 1024.0, len(fwd)
 
 
@@ -28,7 +28,7 @@ fetch *= 2.0
 write, n2 = conv_fwd_sum(sys.argv[2], 'WRITE_SIZE')
 assert n == n2
 out = {
-    "what": "HBM bytes of the ResNet-18 conv-forward igemm launches (21 convs) of one bench.py step (B=256, 224^2, fp32)",
+    "what": "HBM bytes of the ResNet-18 conv-forward igemm launches (21 convs; a BasicA pair is one launch) of one bench.py step (B=256, 224^2, fp32)",
     "method": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE in two separate passes of `python3 bench.py --steps 2 "
               "--warmup 2 --no-cpu-baseline`; KB -> bytes x1024; FETCH_SIZE doubled (gfx950 reports half the bytes of "
               "wide coalesced reads, MI355X_MICROARCH.md HBM section); tools/pmc_traffic.py",
