@@ -268,11 +268,16 @@ def reduce_channels_ok(C_):
     return C_ % 4 == 0 and c4 >= 1 and ((256 % c4 == 0) if c4 <= 256 else (c4 % 256 == 0))
 
 
+# Split-K adds partial tiles with atomics: the summation order, hence the last bits of a small-batch forward, vary from
+# run to run.  LOANS_SPLITK=0 (or ops.SPLITK = False) keeps the forward convolutions bit-reproducible.
+SPLITK = os.environ.get('LOANS_SPLITK', '1') != '0'
+
+
 def _splitk_candidates(M, Cout, nchunks):
     """split-K forms of the 64x64 tile (LOANS_TILE_SPLITK) for grids that cannot fill the machine: few tiles, long K --
     the deep layers at small batch and single-image inference.  tile id = 3 | (splits << 8)."""
     tiles = ((M + 63) // 64) * ((Cout + 63) // 64)
-    if COMPUTE != 'f32' or tiles >= 512 or nchunks < 16:
+    if not SPLITK or COMPUTE != 'f32' or tiles >= 512 or nchunks < 16:
         return ()
     return tuple(3 | (s << 8) for s in (2, 4, 8, 16) if tiles * s <= 4096 and nchunks // s >= 4)
 
@@ -333,9 +338,10 @@ def conv_fprop(x, w, geo, out=None, bias=None, stats=None, relu_in=False, addend
             check(_igemm_fn(lib)(_ptr(x), _ptr(w), _ptr(scratch), 0, _ptr(sstats), 0, 0,
                                       C.byref(_with_flags(geo.fwd, tflags, t)), _stream()), 'loans_igemm_f32[tune]')
         M_ = geo.B * geo.Ho * geo.Wo
-        cands = _FPROP_TILES + (() if (out_bf16 or not reduce_channels_ok(geo.Cout)) else
-                                _splitk_candidates(M_, geo.Cout, (geo.w_numel // geo.Cout + 31) // 32))
-        tile = _tuned_tile(geo, COMPUTE + 'fprop' + ('_stats' if stats is not None else ''), run, cands)   # fp32 scratch output: the tile choice carries over
+        sk = () if (out_bf16 or not reduce_channels_ok(geo.Cout)) else \
+            _splitk_candidates(M_, geo.Cout, (geo.w_numel // geo.Cout + 31) // 32)
+        tile = _tuned_tile(geo, COMPUTE + 'fprop' + ('_stats' if stats is not None else '') + ('_sk' if sk else ''), run,
+                           _FPROP_TILES + sk)   # fp32 scratch output: the tile choice carries over
     d = _with_flags(geo.fwd, flags, tile)
     log = EVENT_LOG
     if log is not None:
@@ -519,8 +525,8 @@ def conv_dgrad(gy, w, geo, out=None, mask_ref=None, addend=None, addend_mask_ref
         if not inplace_masked and reduce_channels_ok(geo.Cin):
             # the smallest class grid decides: (Ho x Wo pixels of one parity class) x Cin columns, K = its taps x Cout
             cls_rows = geo.B * geo.dgrad[0][0].gridH * geo.dgrad[0][0].gridW
-            cands = cands + _splitk_candidates(cls_rows, geo.Cin, (min(d.ntaps for d, _, _ in geo.dgrad) * geo.Cout + 31) // 32)
-            key += '_sk'
+            sk = _splitk_candidates(cls_rows, geo.Cin, (min(d.ntaps for d, _, _ in geo.dgrad) * geo.Cout + 31) // 32)
+            cands, key = cands + sk, key + ('_sk' if sk else '')
         tile = _tuned_tile(geo, key, run, cands)
     if tile >> 8:
         _igemm_splitk(lib, gy, None, out, dl, flags, tile, None, None, ref, addend, rows_in, geo.Cin, st)

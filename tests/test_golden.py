@@ -98,7 +98,7 @@ def test_hip_forward_matches_golden_224():
 
 
 @pytest.mark.gpu
-def test_hip_trajectory_matches_golden():
+def test_hip_trajectory_matches_golden(deterministic_forward):
     """three consecutive joint steps of the B = 2 case: losses against the stored fp64 trajectory (Adam's sign-like first
     steps amplify rounding, so the bound is the one the fp32 oracle itself needs, see test_three_iteration_trajectory)"""
     import torch
