@@ -248,7 +248,7 @@ def test_map_evaluator_on_fresh_localizer():
 
 
 @pytest.mark.parametrize("shape", [(4, 128, 128, (12, 10)), (4, 232, 226, (16, 16))])
-def test_resnet50_localizer_forward_and_gradient_parity(shape):
+def test_resnet50_localizer_forward_and_gradient_parity(shape, deterministic_forward):
     """``Resnet50SheepLocalizer`` (bottleneck backbone, 1x1 convs incl. stride-2 ones whose
     dgrad leaves 3/4 of the pixels without taps, chainercv ResBlock res6 above 224 px) against the oracle."""
     B, H, W, crop = shape
@@ -305,6 +305,8 @@ def test_resnet50_localizer_forward_and_gradient_parity(shape):
         # cancellation: the fp32 ORACLE itself is off by e32 (1-20 % on some tensors), and the GPU's sequential
         # fp32 MFMA accumulation has a larger rounding constant than NumPy's blocked sums.  Correctness of the
         # bottleneck units is pinned at 1e-4 by test_bottleneck_unit_forward_backward; here only gross errors.
+        # (The bound was calibrated on the order-preserving kernels: the fixture keeps split-K, which re-associates
+        # the K sum of the small deep layers, out of this rounding-noise measurement.)
         assert e < max(5e-2, 15 * e32), (key, e, e32)
     print('resnet50 gradient relative error: worst %.3e median %.3e' % (worst, float(np.median(errs))))
     # measured along the backward chain: the fp32 oracle drifts 0.4-18 % from the fp64 one per unit, the HIP
