@@ -583,6 +583,31 @@ def conv_wgrad(x, gy, dw, geo, relu_in=False, splits=0, tile=0):
     _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile)
 
 
+_WGRAD_TILE_DIMS = {1: (128, 128, 2), 3: (64, 64, 4), 5: (64, 128, 3)}      # tile id -> (BCO, BJ, blocks per CU by LDS)
+
+
+def _wgrad_candidates(geo, tiles, chunk_px):
+    """(tile, splits) candidates of a weight gradient, encoded tile | splits << 8 (0 = the library's default).  The
+    reduction over pixels is cut into `splits` slices per output tile; how many blocks that makes against the machine's
+    block slots decides the tail (res4: 36 tiles x 29 slices = 2.04 rounds of 512 slots runs at 96 TFLOP/s, x 14 = 0.98
+    rounds at 118), so slot-aligned counts are offered beside the default and its half / double."""
+    K = geo.w_numel // geo.Cout
+    chunks = (geo.B * geo.Ho * geo.Wo + chunk_px - 1) // chunk_px
+    cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+    out = []
+    for t in tiles:
+        bco, bj, per_cu = _WGRAD_TILE_DIMS[t]
+        ntile = ((geo.Cout + bco - 1) // bco) * ((K + bj - 1) // bj)
+        auto = max(1, min((1024 + ntile - 1) // ntile, (chunks + 7) // 8))
+        cand = {0, max(1, auto // 2), auto * 2}
+        for rounds in (1, 2, 3, 4):
+            cand.add(max(1, rounds * per_cu * cus // ntile))
+        for sp in sorted(cand):
+            if sp == 0 or (sp != auto and chunks // sp >= 4):
+                out.append(t | (sp << 8))
+    return tuple(out)
+
+
 def _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile):
     lib = _lib.load()
     assert dw.numel() == geo.w_numel and x.numel() == geo.in_numel
@@ -597,9 +622,14 @@ def _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile):
     if tile == 0:
         def run(t):
             scratch = torch.empty(dw.numel(), device=x.device, dtype=torch.float32)
-            check(wfn(_ptr(x), _ptr(gy), _ptr(scratch), C.byref(_with_flags(geo.fwd, fl, t)), splits,
+            check(wfn(_ptr(x), _ptr(gy), _ptr(scratch), C.byref(_with_flags(geo.fwd, fl, t & 0xFF)), (t >> 8) or splits,
                       _stream()), 'loans_wgrad[tune]')
-        tile = _tuned_tile(geo, _wgrad_key(x, gy, relu_in), run, _WGRAD16_TILES if s16 else _WGRAD_TILES)
+        cands = _WGRAD16_TILES if s16 else _WGRAD_TILES
+        if splits == 0:
+            cands = _wgrad_candidates(geo, cands, 32)
+        tile = _tuned_tile(geo, _wgrad_key(x, gy, relu_in) + ('' if splits == 0 else '_s%d' % splits), run, cands)
+    if tile >> 8:
+        tile, splits = tile & 0xFF, tile >> 8
     d = _with_flags(geo.fwd, fl, tile)
     check(wfn(_ptr(x), _ptr(gy), _ptr(dw), C.byref(d), splits, _stream()), 'loans_wgrad')
     if geo.dense:
