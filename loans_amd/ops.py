@@ -584,9 +584,10 @@ def conv_wgrad(x, gy, dw, geo, relu_in=False, splits=0, tile=0):
 
 
 _WGRAD_TILE_DIMS = {1: (128, 128, 2), 3: (64, 64, 4), 5: (64, 128, 3)}      # tile id -> (BCO, BJ, blocks per CU by LDS)
+_WGRAD16_TILE_DIMS = {1: (128, 128, 3), 3: (64, 64, 5), 5: (64, 128, 4)}    # bf16 tiles: smaller LDS images, register-bound
 
 
-def _wgrad_candidates(geo, tiles, chunk_px):
+def _wgrad_candidates(geo, tiles, chunk_px, dims=None):
     """(tile, splits) candidates of a weight gradient, encoded tile | splits << 8 (0 = the library's default).  The
     reduction over pixels is cut into `splits` slices per output tile; how many blocks that makes against the machine's
     block slots decides the tail (res4: 36 tiles x 29 slices = 2.04 rounds of 512 slots runs at 96 TFLOP/s, x 14 = 0.98
@@ -596,7 +597,7 @@ def _wgrad_candidates(geo, tiles, chunk_px):
     cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
     out = []
     for t in tiles:
-        bco, bj, per_cu = _WGRAD_TILE_DIMS[t]
+        bco, bj, per_cu = (dims or _WGRAD_TILE_DIMS)[t]
         ntile = ((geo.Cout + bco - 1) // bco) * ((K + bj - 1) // bj)
         auto = max(1, min((1024 + ntile - 1) // ntile, (chunks + 7) // 8))
         cand = {0, max(1, auto // 2), auto * 2}
@@ -626,7 +627,7 @@ def _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile):
                       _stream()), 'loans_wgrad[tune]')
         cands = _WGRAD16_TILES if s16 else _WGRAD_TILES
         if splits == 0:
-            cands = _wgrad_candidates(geo, cands, 32)
+            cands = _wgrad_candidates(geo, cands, 32, _WGRAD16_TILE_DIMS if s16 else None)
         tile = _tuned_tile(geo, _wgrad_key(x, gy, relu_in) + ('' if splits == 0 else '_s%d' % splits), run, cands)
     if tile >> 8:
         tile, splits = tile & 0xFF, tile >> 8
