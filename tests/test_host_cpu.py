@@ -139,15 +139,20 @@ def test_tile_selection_host_logic():
     that keep the autotune tables of differently-staged weight gradients apart"""
     import torch
     from loans_amd import ops
-    assert ops._splitk_candidates(16 * 49, 512, 144) == tuple(3 | (s << 8) for s in (2, 4, 8, 16))      # res5 at B = 16
-    assert ops._splitk_candidates(256 * 49, 512, 144) == ()                                               # ... at B = 256
-    assert ops._splitk_candidates(16 * 49, 512, 8) == ()                                                  # short K
-    assert all((t >> 8) * 4 <= 18 for t in ops._splitk_candidates(49, 64, 18))                            # >= 4 chunks per slice
-    ops.set_compute_dtype('bf16')
+    assert ops._splitk_candidates(16 * 49, 512, 144) == ()        # the suite runs with LOANS_SPLITK=0 (tests/conftest.py)
+    old, ops.SPLITK = ops.SPLITK, True
     try:
-        assert ops._splitk_candidates(16 * 49, 512, 144) == ()                                            # fp32 arm only
+        assert ops._splitk_candidates(16 * 49, 512, 144) == tuple(3 | (s << 8) for s in (2, 4, 8, 16))  # res5 at B = 16
+        assert ops._splitk_candidates(256 * 49, 512, 144) == ()                                           # ... at B = 256
+        assert ops._splitk_candidates(16 * 49, 512, 8) == ()                                              # short K
+        assert all((t >> 8) * 4 <= 18 for t in ops._splitk_candidates(49, 64, 18))                        # >= 4 chunks per slice
+        ops.set_compute_dtype('bf16')
+        try:
+            assert ops._splitk_candidates(16 * 49, 512, 144) == ()                                        # fp32 arm only
+        finally:
+            ops.set_compute_dtype('f32')
     finally:
-        ops.set_compute_dtype('f32')
+        ops.SPLITK = old
     for c, ok in ((4, True), (64, True), (96, False), (1024, True), (2048, True), (1536, False), (6, False)):
         assert ops.reduce_channels_ok(c) is ok, c
     f32, b16 = torch.zeros(1), torch.zeros(1, dtype=torch.bfloat16)
