@@ -59,3 +59,25 @@ print('\ntimeline of the step: %.2f ms; some kernel running %.2f ms (%.1f %%); a
       'only non-GEMM kernels running %.2f ms; idle %.2f ms'
       % ((t1 - t0) / 1e6, union(al) / 1e6, union(al) / (t1 - t0) * 100, union(mf) / 1e6, union(mf) / (t1 - t0) * 100,
          (union(al) - union(mf)) / 1e6, (t1 - t0 - union(al)) / 1e6))
+
+# where no GEMM runs: the stretches of the step (>= 30 us) between MFMA kernels, with what runs there instead
+mf.sort()
+merged = []
+for s, e in mf:
+    if merged and s <= merged[-1][1]:
+        merged[-1][1] = max(merged[-1][1], e)
+    else:
+        merged.append([s, e])
+holes = [(merged[i][1], merged[i + 1][0]) for i in range(len(merged) - 1)]
+holes = [(t0, merged[0][0])] + holes + [(merged[-1][1], t1)]
+print('\nGEMM-free stretches of the step (>= 30 us): offset, length, kernels running inside')
+for s, e in holes:
+    if e - s < 30000:
+        continue
+    inside = collections.Counter()
+    for ks, ke, n in iv:
+        ov = min(e, ke) - max(s, ks)
+        if ov > 0 and not ('igemm' in n or 'wgrad' in n):
+            inside['torch fill/copy' if 'at::native' in n else short(n)] += ov
+    print('  +%8.1f us  %7.1f us  %s' % ((s - t0) / 1e3, (e - s) / 1e3,
+                                          ', '.join('%s %.0f' % (k, v / 1e3) for k, v in inside.most_common(4))))
