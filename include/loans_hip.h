@@ -225,6 +225,23 @@ int loans_bn_bwd_apply_f32(const float* gy, const float* mask, const float* x,
                            const float* x2, const float* k1b, const float* k2b, const float* k3b, float* gx2,
                            int64_t rows, int32_t C, void* stream);
 
+/* The stem's tail fused (sheep/resnet.py:72-73 backwards: max_pooling_2d -> relu -> bn1): with
+ * g = (sum over windows whose argmax is this pixel of gy) * (x*scale+shift > 0) never written to memory,
+ * reduce: sums[0][c] += sum g, sums[1][c] += sum g*xhat (one gather of x per pooled element);
+ * apply:  gx = k1*g + k2*x + k3 (k from loans_bn_bwd_coeffs_f32).  gy, idx: [B][OH][OW][C]; x, gx: [B][H][W][C]. */
+int loans_pool_bn_bwd_reduce_f32(const float* gy, const uint8_t* idx, const float* x, const float* scale,
+                                 const float* shift, const float* mean, const float* rstd, double* sums,
+                                 int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream);
+int loans_pool_bn_bwd_apply_f32(const float* gy, const uint8_t* idx, const float* x, const float* scale,
+                                const float* shift, const float* k1, const float* k2, const float* k3, float* gx,
+                                int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream);
+int loans_pool_bn_bwd_reduce_bf16(const void* gy, const uint8_t* idx, const void* x, const float* scale,
+                                  const float* shift, const float* mean, const float* rstd, double* sums,
+                                  int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream);
+int loans_pool_bn_bwd_apply_bf16(const void* gy, const uint8_t* idx, const void* x, const float* scale,
+                                 const float* shift, const float* k1, const float* k2, const float* k3, void* gx,
+                                 int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream);
+
 /* bf16 tensors (gy, mask, x, x2, gx, gx2), fp32 sums and coefficients */
 int loans_bn_bwd_reduce_bf16(const void* gy, const void* mask, const void* x, const float* mean,
                              const float* rstd, const void* x2, const float* mean2, const float* rstd2,

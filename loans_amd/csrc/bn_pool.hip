@@ -219,6 +219,130 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* gy, const T*
     }
 }
 
+// ---- the stem's tail, fused: max-pool backward + ReLU mask + BN backward without the dense pre-BN gradient ----
+// g[pixel] = (sum over the windows whose argmax is this pixel of gy) * (x*scale+shift > 0) is at most one quarter dense,
+// and materialising it costs a write and two reads of the largest activation of the network (B x 112 x 112 x 64 at 224^2).
+// Pass 1 takes the BN sums straight from the pooled gradient: every pooled element gathers the one x it came from.
+__device__ __forceinline__ float ldf(const float* p) { return *p; }
+__device__ __forceinline__ float ldf(const __bf16* p) { return (float)*p; }
+
+template <typename T>
+__global__ __launch_bounds__(256) void pool_bn_bwd_reduce_kernel(const T* gy, const uint8_t* idx, const T* x,
+                                                                 const float* scale, const float* shift,
+                                                                 const float* mean, const float* rstd, double* sums,
+                                                                 int rows, int H, int W, int OH, int OW,
+                                                                 int C4, int C4T, int rows_per_block) {
+    __shared__ f32x4 red[2][256];
+    const int tid = threadIdx.x;
+    const int cl = tid % C4, rl = tid / C4, RL = 256 / C4;
+    const int cg = blockIdx.y * C4 + cl;
+    const int r0 = blockIdx.x * rows_per_block;
+    const int r1 = min(r0 + rows_per_block, rows);
+    const f32x4 sc = ld4(scale + cg * 4), sh = ld4(shift + cg * 4), mu = ld4(mean + cg * 4), rs = ld4(rstd + cg * 4);
+    f32x4 sg = {0.f, 0.f, 0.f, 0.f}, sgx = sg;
+    if (rl < RL) {
+        for (int r = r0 + rl; r < r1; r += RL) {          // r = (b * OH + oh) * OW + ow
+            const int ow = r % OW, t = r / OW, oh = t % OH, b = t / OH;
+            const int64_t o = ((int64_t)r * C4T + cg) * 4;
+            const f32x4 g = io4<T>::ld(gy + o);
+            const uchar4 a = *reinterpret_cast<const uchar4*>(idx + o);
+            const int64_t base = (((int64_t)b * H + oh * 2) * W + ow * 2) * C4T * 4 + cg * 4;
+            const int ks[4] = {a.x, a.y, a.z, a.w};
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int kr = ks[e] / 3, kq = ks[e] - kr * 3;
+                const float xv = ldf(x + base + ((int64_t)kr * W + kq) * C4T * 4 + e);
+                const float ge = (xv * sc[e] + sh[e]) > 0.f ? g[e] : 0.f;
+                sg[e] += ge;
+                sgx[e] += ge * ((xv - mu[e]) * rs[e]);
+            }
+        }
+    }
+    red[0][tid] = sg;
+    red[1][tid] = sgx;
+    __syncthreads();
+    if (tid < C4) {
+        for (int k = 1; k < RL; ++k) {
+            sg += red[0][tid + k * C4];
+            sgx += red[1][tid + k * C4];
+        }
+        const int C = C4T * 4;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            atomic_add_f64(sums + cg * 4 + e, (double)sg[e]);
+            atomic_add_f64(sums + C + cg * 4 + e, (double)sgx[e]);
+        }
+    }
+}
+
+// Pass 2: gx = k1 * g + k2 * x + k3 with g rebuilt on the fly.  One thread owns a 2 x 2 patch of input pixels (4 channels):
+// the patch at (2a, 2b) is covered by the four windows (a-1 | a, b-1 | b) only, so each window's (idx, gy) is loaded once
+// per four outputs (a thread per pixel loads nine); contributions are added in the window order of maxpool_relu_bwd.
+template <typename T>
+__global__ __launch_bounds__(256) void pool_bn_bwd_apply_kernel(const T* gy, const uint8_t* idx, const T* x,
+                                                                const float* scale, const float* shift,
+                                                                const float* k1, const float* k2, const float* k3, T* gx,
+                                                                int B, int H, int W, int C4, int OH, int OW) {
+    const int PH = (H + 1) >> 1, PW = (W + 1) >> 1;
+    const int rowlen = PW * C4;
+    for (int row = blockIdx.y; row < B * PH; row += gridDim.y) {
+        const int b = row / PH, a = row - b * PH;
+        for (int el = blockIdx.x * blockDim.x + threadIdx.x; el < rowlen; el += gridDim.x * blockDim.x) {
+            const int pb = el / C4, c4 = el - pb * C4;
+            f32x4 g[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) g[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int wi = 0; wi < 2; ++wi) {
+                const int oh = a - 1 + wi;
+                if (oh < 0 || oh >= OH) continue;
+#pragma unroll
+                for (int wj = 0; wj < 2; ++wj) {
+                    const int ow = pb - 1 + wj;
+                    if (ow < 0 || ow >= OW) continue;
+                    const int64_t o = ((((int64_t)b * OH + oh) * OW + ow) * C4 + c4) * 4;
+                    const uchar4 av = *reinterpret_cast<const uchar4*>(idx + o);
+                    const f32x4 gv = io4<T>::ld(gy + o);
+                    // window (a-1+wi, pb-1+wj) starts at pixel (2a-2+2wi, 2pb-2+2wj): patch pixel (i, j) is its
+                    // position (i + 2 - 2wi, j + 2 - 2wj) where that is < 3
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int kr = i + 2 - 2 * wi;
+                        if (kr > 2) continue;
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int kq = j + 2 - 2 * wj;
+                            if (kq > 2) continue;
+                            const int k = kr * 3 + kq;
+                            if (av.x == k) g[i][j].x += gv.x;
+                            if (av.y == k) g[i][j].y += gv.y;
+                            if (av.z == k) g[i][j].z += gv.z;
+                            if (av.w == k) g[i][j].w += gv.w;
+                        }
+                    }
+                }
+            }
+            const f32x4 sc = ld4(scale + c4 * 4), sh = ld4(shift + c4 * 4);
+            const f32x4 c1 = ld4(k1 + c4 * 4), c2 = ld4(k2 + c4 * 4), c3 = ld4(k3 + c4 * 4);
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ih = 2 * a + i;
+                if (ih >= H) continue;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int iw = 2 * pb + j;
+                    if (iw >= W) continue;
+                    const int64_t p = ((((int64_t)b * H + ih) * W + iw) * C4 + c4) * 4;
+                    const f32x4 xv = io4<T>::ld(x + p);
+                    io4<T>::st(gx + p, c1 * maskpos4(g[i][j], xv * sc + sh) + c2 * xv + c3);
+                }
+            }
+        }
+    }
+}
+
 template <typename T>
 __global__ __launch_bounds__(256) void colsum_kernel(const T* x, float* out, int64_t rows, int C4, int C4T, int rows_per_block) {
     __shared__ f32x4 red[256];
@@ -416,6 +540,65 @@ extern "C" int loans_maxpool_relu_bwd_bf16(const void* gy, const uint8_t* idx, c
                                            int32_t OH, int32_t OW, void* stream) {
     return maxpool_relu_bwd_impl<__bf16>(static_cast<const __bf16*>(gy), idx, static_cast<const __bf16*>(x), scale, shift,
                                          static_cast<__bf16*>(gx), B, H, W, C, OH, OW, stream);
+}
+
+template <typename T>
+static int pool_bn_bwd_reduce_impl(const T* gy, const uint8_t* idx, const T* x, const float* scale, const float* shift,
+                                   const float* mean, const float* rstd, double* sums, int32_t B, int32_t H, int32_t W,
+                                   int32_t C, int32_t OH, int32_t OW, void* stream) {
+    if (!gy || !idx || !x || !scale || !shift || !mean || !rstd || !sums || B <= 0 || H < 3 || W < 3) return LOANS_EINVAL;
+    if (!reduce_channels_ok(C)) return LOANS_EINVAL;
+    if (OH != (H - 2) / 2 + 1 || OW != (W - 2) / 2 + 1) return LOANS_EINVAL;
+    const int64_t rows = (int64_t)B * OH * OW;
+    if (rows >= ((int64_t)1 << 31)) return LOANS_ERANGE;
+    int rpb, c4b, slabs;
+    const int grid = reduce_geometry(rows, C, &rpb, &c4b, &slabs);
+    hipLaunchKernelGGL(pool_bn_bwd_reduce_kernel<T>, dim3(grid, slabs), dim3(256), 0, as_stream(stream), gy, idx, x, scale,
+                       shift, mean, rstd, sums, (int)rows, H, W, OH, OW, c4b, C / 4, rpb);
+    LOANS_LAUNCH_CHECK();
+    return LOANS_OK;
+}
+
+template <typename T>
+static int pool_bn_bwd_apply_impl(const T* gy, const uint8_t* idx, const T* x, const float* scale, const float* shift,
+                                  const float* k1, const float* k2, const float* k3, T* gx, int32_t B, int32_t H,
+                                  int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream) {
+    if (!gy || !idx || !x || !scale || !shift || !k1 || !k2 || !k3 || !gx || B <= 0 || H < 3 || W < 3 || C <= 0 || (C & 3))
+        return LOANS_EINVAL;
+    if (OH != (H - 2) / 2 + 1 || OW != (W - 2) / 2 + 1) return LOANS_EINVAL;
+    const int PH = (H + 1) / 2, PW = (W + 1) / 2;
+    if ((int64_t)B * PH >= ((int64_t)1 << 31) || (int64_t)PW * (C / 4) >= ((int64_t)1 << 31)) return LOANS_ERANGE;
+    const dim3 grid((PW * (C / 4) + 255) / 256, (unsigned)min((int64_t)B * PH, (int64_t)65535));
+    hipLaunchKernelGGL(pool_bn_bwd_apply_kernel<T>, grid, dim3(256), 0, as_stream(stream), gy, idx, x, scale, shift, k1, k2,
+                       k3, gx, B, H, W, C / 4, OH, OW);
+    LOANS_LAUNCH_CHECK();
+    return LOANS_OK;
+}
+
+extern "C" int loans_pool_bn_bwd_reduce_f32(const float* gy, const uint8_t* idx, const float* x, const float* scale,
+                                            const float* shift, const float* mean, const float* rstd, double* sums,
+                                            int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream) {
+    return pool_bn_bwd_reduce_impl<float>(gy, idx, x, scale, shift, mean, rstd, sums, B, H, W, C, OH, OW, stream);
+}
+
+extern "C" int loans_pool_bn_bwd_reduce_bf16(const void* gy, const uint8_t* idx, const void* x, const float* scale,
+                                             const float* shift, const float* mean, const float* rstd, double* sums,
+                                             int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream) {
+    return pool_bn_bwd_reduce_impl<__bf16>(static_cast<const __bf16*>(gy), idx, static_cast<const __bf16*>(x), scale, shift,
+                                           mean, rstd, sums, B, H, W, C, OH, OW, stream);
+}
+
+extern "C" int loans_pool_bn_bwd_apply_f32(const float* gy, const uint8_t* idx, const float* x, const float* scale,
+                                           const float* shift, const float* k1, const float* k2, const float* k3, float* gx,
+                                           int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream) {
+    return pool_bn_bwd_apply_impl<float>(gy, idx, x, scale, shift, k1, k2, k3, gx, B, H, W, C, OH, OW, stream);
+}
+
+extern "C" int loans_pool_bn_bwd_apply_bf16(const void* gy, const uint8_t* idx, const void* x, const float* scale,
+                                            const float* shift, const float* k1, const float* k2, const float* k3, void* gx,
+                                            int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream) {
+    return pool_bn_bwd_apply_impl<__bf16>(static_cast<const __bf16*>(gy), idx, static_cast<const __bf16*>(x), scale, shift,
+                                          k1, k2, k3, static_cast<__bf16*>(gx), B, H, W, C, OH, OW, stream);
 }
 
 template <typename T>

@@ -70,8 +70,8 @@ class StemFunction(Function):
     def backward(self, inputs, gys):
         _require_train()
         _, W, b, gamma, beta = self.inputs
-        g = ops.maxpool_relu_bwd(gys[0].contiguous(), self.idx, self.c, self.st)
-        gc = ops.bn_backward(g, None, self.c, self.st, gamma.data, gamma.grad_view, beta.grad_view)
+        gc = ops.pool_bn_backward(gys[0].contiguous(), self.idx, self.c, self.st, gamma.data, gamma.grad_view,
+                                  beta.grad_view)
         ops.conv_wgrad(self.x, gc, W.grad_view, self.geo)
         ops.colsum_acc(gc, b.grad_view)
         return None, None, None, None, None

@@ -839,6 +839,37 @@ def bn_backward(gy, mask, x, st, gamma, ggamma, gbeta, x2=None, st2=None, gamma2
     return (gx, gx2) if dual else gx
 
 
+# LOANS_FUSED_STEM_TAIL=0 restores the three-pass form (maxpool_relu_bwd -> bn_backward)
+FUSED_STEM_TAIL = os.environ.get('LOANS_FUSED_STEM_TAIL', '1') != '0'
+
+
+def pool_bn_backward(gy, idx, x, st, gamma, ggamma, gbeta):
+    """The stem's tail backwards (max_pooling_2d -> relu -> bn1, sheep/resnet.py:72-73) without the dense gradient
+    between pool and BN: gx w.r.t. the conv output x from the pooled gradient gy and the argmax positions idx;
+    accumulates ggamma / gbeta in place.  Same result as bn_backward(maxpool_relu_bwd(gy, idx, x, st), None, x, st, ...)
+    up to summation order (and, on bf16 tensors, without the rounding of the intermediate)."""
+    B, H, W, C_ = x.shape
+    OH, OW = gy.shape[1], gy.shape[2]
+    if not (FUSED_STEM_TAIL and reduce_channels_ok(C_)):
+        return bn_backward(maxpool_relu_bwd(gy, idx, x, st), None, x, st, gamma, ggamma, gbeta)
+    lib = _lib.load()
+    s16 = _is16(x)
+    assert _is16(gy) == s16
+    s = _stream()
+    sums = _zeros_f64((2, C_), x.device)
+    red_fn = lib.loans_pool_bn_bwd_reduce_bf16 if s16 else lib.loans_pool_bn_bwd_reduce_f32
+    app_fn = lib.loans_pool_bn_bwd_apply_bf16 if s16 else lib.loans_pool_bn_bwd_apply_f32
+    check(red_fn(_ptr(gy), _ptr(idx), _ptr(x), _ptr(st.scale), _ptr(st.shift), _ptr(st.mean), _ptr(st.rstd), _ptr(sums),
+                 B, H, W, C_, OH, OW, s), 'loans_pool_bn_bwd_reduce')
+    k = torch.empty((3, C_), device=x.device, dtype=torch.float32)
+    check(lib.loans_bn_bwd_coeffs_f32(_ptr(sums), C_, B * H * W, _ptr(gamma), _ptr(st.mean), _ptr(st.rstd), _ptr(ggamma),
+                                      _ptr(gbeta), _ptr(k[0]), _ptr(k[1]), _ptr(k[2]), s), 'loans_bn_bwd_coeffs_f32')
+    gx = torch.empty_like(x)
+    check(app_fn(_ptr(gy), _ptr(idx), _ptr(x), _ptr(st.scale), _ptr(st.shift), _ptr(k[0]), _ptr(k[1]), _ptr(k[2]), _ptr(gx),
+                 B, H, W, C_, OH, OW, s), 'loans_pool_bn_bwd_apply')
+    return gx
+
+
 def colsum_acc(x, out):
     C_ = x.shape[-1]
     lib = _lib.load()

@@ -331,6 +331,51 @@ def test_stem_pool_forward_backward():
         np.testing.assert_allclose(_nchw(g), g_ref, rtol=1e-6, atol=1e-6)
 
 
+@pytest.mark.parametrize("dtype", ["f32", "bf16"])
+@pytest.mark.parametrize("shape", [(2, 16, 16, 64), (1, 9, 12, 64), (2, 8, 7, 128), (3, 13, 11, 64), (2, 3, 3, 64)])
+def test_stem_tail_fused_backward(shape, dtype):
+    """loans_pool_bn_bwd_reduce / _apply (max-pool backward + ReLU mask + BN backward without the dense gradient in
+    between) against the oracle's max_pool_bwd -> relu mask -> bn_bwd, and against the three-pass kernels"""
+    from loans_amd import ops
+    B, H, W, C_ = shape
+    rng = np.random.RandomState(5)
+    x = (rng.standard_normal((B, C_, H, W)) * 2 + 0.5).astype(np.float32)
+    if dtype == "bf16":
+        x = torch.from_numpy(x).bfloat16().float().numpy()
+    gamma = (1 + 0.1 * rng.standard_normal(C_)).astype(np.float32)
+    beta = (0.1 * rng.standard_normal(C_)).astype(np.float32)
+    y_bn, ctx = C.bn_fwd_train(x.astype(np.float64), gamma.astype(np.float64), beta.astype(np.float64),
+                               np.zeros(C_), np.ones(C_))
+    tdt = torch.bfloat16 if dtype == "bf16" else torch.float32
+    xd = dev(_nhwc(x)).to(tdt)
+    stats = ops.stats_buffer(C_, 'cuda')
+    stats[0, 0] = xd.double().sum(dim=(0, 1, 2)); stats[0, 1] = (xd.double() ** 2).sum(dim=(0, 1, 2))
+    st = ops.bn_finalize(stats, B * H * W, dev(gamma), dev(beta), torch.zeros(C_, device='cuda'), torch.ones(C_, device='cuda'))
+    y, idx = ops.bn_relu_maxpool(xd, st)
+    gy = rng.standard_normal(tuple(y.shape)).astype(np.float32)           # NHWC
+    if dtype == "bf16":
+        gy = torch.from_numpy(gy).bfloat16().float().numpy()
+    gyd = dev(gy).to(tdt)
+    # oracle on the GPU's own argmax (ties / the last bits of the pre-activation may pick another equal maximum)
+    pre = np.maximum(y_bn, 0)
+    idx_np = idx.cpu().numpy().transpose(0, 3, 1, 2)
+    g_ref = C.max_pool_bwd(pre.shape, idx_np, gy.transpose(0, 3, 1, 2).astype(np.float64)) * (y_bn > 0)
+    gx_ref, gg_ref, gb_ref = C.bn_bwd(ctx, gamma.astype(np.float64), g_ref)
+    gg, gb = torch.zeros(C_, device='cuda'), torch.zeros(C_, device='cuda')
+    gx = ops.pool_bn_backward(gyd, idx, xd, st, dev(gamma), gg, gb)
+    tol = 1e-2 if dtype == "bf16" else 2e-5
+    assert rel_err(_nchw(gx.float()), gx_ref) < tol
+    assert rel_err(gg.cpu().numpy(), gg_ref) < 1e-4 and rel_err(gb.cpu().numpy(), gb_ref) < 1e-4
+    # the three-pass form
+    gg3, gb3 = torch.zeros(C_, device='cuda'), torch.zeros(C_, device='cuda')
+    gx3 = ops.bn_backward(ops.maxpool_relu_bwd(gyd, idx, xd, st), None, xd, st, dev(gamma), gg3, gb3)
+    if dtype == "f32":
+        assert rel_err(gx.cpu().numpy(), gx3.cpu().numpy()) < 1e-6
+        assert rel_err(gg.cpu().numpy(), gg3.cpu().numpy()) < 1e-6 and rel_err(gb.cpu().numpy(), gb3.cpu().numpy()) < 1e-6
+    else:
+        assert rel_err(gx.float().cpu().numpy(), gx3.float().cpu().numpy()) < 1e-2
+
+
 def test_spatial_transformer_forward_backward():
     from loans_amd import ops
     rng = np.random.RandomState(3)
