@@ -228,19 +228,21 @@ int loans_bn_bwd_apply_f32(const float* gy, const float* mask, const float* x,
 /* The stem's tail fused (sheep/resnet.py:72-73 backwards: max_pooling_2d -> relu -> bn1): with
  * g = (sum over windows whose argmax is this pixel of gy) * (x*scale+shift > 0) never written to memory,
  * reduce: sums[0][c] += sum g, sums[1][c] += sum g*xhat (one gather of x per pooled element);
- * apply:  gx = k1*g + k2*x + k3 (k from loans_bn_bwd_coeffs_f32).  gy, idx: [B][OH][OW][C]; x, gx: [B][H][W][C]. */
+ * apply:  gx = k1*g + k2*x + k3 (k from loans_bn_bwd_coeffs_f32); gxsum (may be NULL; needs C/4 to divide 256):
+ *         gxsum[c] += sum of gx over pixels = the bias gradient of the convolution in front of the BN.
+ * gy, idx: [B][OH][OW][C]; x, gx: [B][H][W][C]. */
 int loans_pool_bn_bwd_reduce_f32(const float* gy, const uint8_t* idx, const float* x, const float* scale,
                                  const float* shift, const float* mean, const float* rstd, double* sums,
                                  int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream);
 int loans_pool_bn_bwd_apply_f32(const float* gy, const uint8_t* idx, const float* x, const float* scale,
                                 const float* shift, const float* k1, const float* k2, const float* k3, float* gx,
-                                int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream);
+                                float* gxsum, int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream);
 int loans_pool_bn_bwd_reduce_bf16(const void* gy, const uint8_t* idx, const void* x, const float* scale,
                                   const float* shift, const float* mean, const float* rstd, double* sums,
                                   int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream);
 int loans_pool_bn_bwd_apply_bf16(const void* gy, const uint8_t* idx, const void* x, const float* scale,
                                  const float* shift, const float* k1, const float* k2, const float* k3, void* gx,
-                                 int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream);
+                                 float* gxsum, int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream);
 
 /* bf16 tensors (gy, mask, x, x2, gx, gx2), fp32 sums and coefficients */
 int loans_bn_bwd_reduce_bf16(const void* gy, const void* mask, const void* x, const float* mean,

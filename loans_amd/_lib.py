@@ -54,8 +54,8 @@ SIGNATURES = {
     'loans_colsum_bf16': [_p, _p, _i64, _i32, _p],
     'loans_pool_bn_bwd_reduce_f32': [_p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p],
     'loans_pool_bn_bwd_reduce_bf16': [_p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p],
-    'loans_pool_bn_bwd_apply_f32': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p],
-    'loans_pool_bn_bwd_apply_bf16': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p],
+    'loans_pool_bn_bwd_apply_f32': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p],
+    'loans_pool_bn_bwd_apply_bf16': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p],
     'loans_gap_fwd_bf16_f32': [_p, _p, _i32, _i32, _i32, _p],
     'loans_gap_bwd_f32_bf16': [_p, _p, _i32, _i32, _i32, _p],
     'loans_dgrad_c4_bf16_f32': [_p, _p, _p, _p, _p, C.POINTER(IgemmDesc), C.POINTER(_i32), _i32, _p],

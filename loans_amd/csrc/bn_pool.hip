@@ -282,9 +282,12 @@ template <typename T>
 __global__ __launch_bounds__(256) void pool_bn_bwd_apply_kernel(const T* gy, const uint8_t* idx, const T* x,
                                                                 const float* scale, const float* shift,
                                                                 const float* k1, const float* k2, const float* k3, T* gx,
-                                                                int B, int H, int W, int C4, int OH, int OW) {
+                                                                float* gxsum, int B, int H, int W, int C4, int OH, int OW) {
     const int PH = (H + 1) >> 1, PW = (W + 1) >> 1;
     const int rowlen = PW * C4;
+    // gxsum (optional, C4 divides 256): per-channel sum of gx = the gradient of the bias of the convolution in front of
+    // this BN (conv1 has one, sheep/resnet.py:43); a thread's channel group is fixed (every stride is a multiple of C4)
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
     for (int row = blockIdx.y; row < B * PH; row += gridDim.y) {
         const int b = row / PH, a = row - b * PH;
         for (int el = blockIdx.x * blockDim.x + threadIdx.x; el < rowlen; el += gridDim.x * blockDim.x) {
@@ -336,9 +339,22 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_apply_kernel(const T* gy, con
                     if (iw >= W) continue;
                     const int64_t p = ((((int64_t)b * H + ih) * W + iw) * C4 + c4) * 4;
                     const f32x4 xv = io4<T>::ld(x + p);
-                    io4<T>::st(gx + p, c1 * maskpos4(g[i][j], xv * sc + sh) + c2 * xv + c3);
+                    const f32x4 v = c1 * maskpos4(g[i][j], xv * sc + sh) + c2 * xv + c3;
+                    io4<T>::st(gx + p, v);
+                    bsum += v;
                 }
             }
+        }
+    }
+    if (gxsum) {
+        __shared__ f32x4 red[256];
+        const int tid = threadIdx.x;
+        red[tid] = bsum;
+        __syncthreads();
+        if (tid < C4) {
+            for (int k = tid + C4; k < 256; k += C4) bsum += red[k];
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomic_add_f32(gxsum + tid * 4 + e, bsum[e]);
         }
     }
 }
@@ -561,16 +577,20 @@ static int pool_bn_bwd_reduce_impl(const T* gy, const uint8_t* idx, const T* x, 
 
 template <typename T>
 static int pool_bn_bwd_apply_impl(const T* gy, const uint8_t* idx, const T* x, const float* scale, const float* shift,
-                                  const float* k1, const float* k2, const float* k3, T* gx, int32_t B, int32_t H,
-                                  int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream) {
+                                  const float* k1, const float* k2, const float* k3, T* gx, float* gxsum, int32_t B,
+                                  int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream) {
     if (!gy || !idx || !x || !scale || !shift || !k1 || !k2 || !k3 || !gx || B <= 0 || H < 3 || W < 3 || C <= 0 || (C & 3))
         return LOANS_EINVAL;
+    if (gxsum && (C / 4 > 256 || 256 % (C / 4))) return LOANS_EINVAL;
     if (OH != (H - 2) / 2 + 1 || OW != (W - 2) / 2 + 1) return LOANS_EINVAL;
     const int PH = (H + 1) / 2, PW = (W + 1) / 2;
     if ((int64_t)B * PH >= ((int64_t)1 << 31) || (int64_t)PW * (C / 4) >= ((int64_t)1 << 31)) return LOANS_ERANGE;
-    const dim3 grid((PW * (C / 4) + 255) / 256, (unsigned)min((int64_t)B * PH, (int64_t)65535));
+    // <= ~2048 blocks (8 per CU; the loops are grid-stride): every block ends with C float atomics on the same two
+    // cache lines of gxsum, and 32 k blocks of them cost more than the pass itself
+    const int gx_blocks = (PW * (C / 4) + 255) / 256;
+    const dim3 grid(gx_blocks, (unsigned)min((int64_t)B * PH, (int64_t)max(1, 2048 / gx_blocks)));
     hipLaunchKernelGGL(pool_bn_bwd_apply_kernel<T>, grid, dim3(256), 0, as_stream(stream), gy, idx, x, scale, shift, k1, k2,
-                       k3, gx, B, H, W, C / 4, OH, OW);
+                       k3, gx, gxsum, B, H, W, C / 4, OH, OW);
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;
 }
@@ -590,15 +610,17 @@ extern "C" int loans_pool_bn_bwd_reduce_bf16(const void* gy, const uint8_t* idx,
 
 extern "C" int loans_pool_bn_bwd_apply_f32(const float* gy, const uint8_t* idx, const float* x, const float* scale,
                                            const float* shift, const float* k1, const float* k2, const float* k3, float* gx,
-                                           int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream) {
-    return pool_bn_bwd_apply_impl<float>(gy, idx, x, scale, shift, k1, k2, k3, gx, B, H, W, C, OH, OW, stream);
+                                           float* gxsum, int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW,
+                                           void* stream) {
+    return pool_bn_bwd_apply_impl<float>(gy, idx, x, scale, shift, k1, k2, k3, gx, gxsum, B, H, W, C, OH, OW, stream);
 }
 
 extern "C" int loans_pool_bn_bwd_apply_bf16(const void* gy, const uint8_t* idx, const void* x, const float* scale,
                                             const float* shift, const float* k1, const float* k2, const float* k3, void* gx,
-                                            int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream) {
+                                            float* gxsum, int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW,
+                                            void* stream) {
     return pool_bn_bwd_apply_impl<__bf16>(static_cast<const __bf16*>(gy), idx, static_cast<const __bf16*>(x), scale, shift,
-                                          k1, k2, k3, static_cast<__bf16*>(gx), B, H, W, C, OH, OW, stream);
+                                          k1, k2, k3, static_cast<__bf16*>(gx), gxsum, B, H, W, C, OH, OW, stream);
 }
 
 template <typename T>

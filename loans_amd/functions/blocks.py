@@ -71,9 +71,8 @@ class StemFunction(Function):
         _require_train()
         _, W, b, gamma, beta = self.inputs
         gc = ops.pool_bn_backward(gys[0].contiguous(), self.idx, self.c, self.st, gamma.data, gamma.grad_view,
-                                  beta.grad_view)
+                                  beta.grad_view, gbias=b.grad_view)
         ops.conv_wgrad(self.x, gc, W.grad_view, self.geo)
-        ops.colsum_acc(gc, b.grad_view)
         return None, None, None, None, None
 
     def release(self):

@@ -843,15 +843,18 @@ def bn_backward(gy, mask, x, st, gamma, ggamma, gbeta, x2=None, st2=None, gamma2
 FUSED_STEM_TAIL = os.environ.get('LOANS_FUSED_STEM_TAIL', '1') != '0'
 
 
-def pool_bn_backward(gy, idx, x, st, gamma, ggamma, gbeta):
+def pool_bn_backward(gy, idx, x, st, gamma, ggamma, gbeta, gbias=None):
     """The stem's tail backwards (max_pooling_2d -> relu -> bn1, sheep/resnet.py:72-73) without the dense gradient
     between pool and BN: gx w.r.t. the conv output x from the pooled gradient gy and the argmax positions idx;
-    accumulates ggamma / gbeta in place.  Same result as bn_backward(maxpool_relu_bwd(gy, idx, x, st), None, x, st, ...)
+    accumulates ggamma / gbeta (and gbias += per-channel sum of gx, conv1's bias gradient) in place.  Same result as bn_backward(maxpool_relu_bwd(gy, idx, x, st), None, x, st, ...)
     up to summation order (and, on bf16 tensors, without the rounding of the intermediate)."""
     B, H, W, C_ = x.shape
     OH, OW = gy.shape[1], gy.shape[2]
-    if not (FUSED_STEM_TAIL and reduce_channels_ok(C_)):
-        return bn_backward(maxpool_relu_bwd(gy, idx, x, st), None, x, st, gamma, ggamma, gbeta)
+    if not (FUSED_STEM_TAIL and reduce_channels_ok(C_) and C_ <= 1024):
+        gx = bn_backward(maxpool_relu_bwd(gy, idx, x, st), None, x, st, gamma, ggamma, gbeta)
+        if gbias is not None:
+            colsum_acc(gx, gbias)
+        return gx
     lib = _lib.load()
     s16 = _is16(x)
     assert _is16(gy) == s16
@@ -866,7 +869,7 @@ def pool_bn_backward(gy, idx, x, st, gamma, ggamma, gbeta):
                                       _ptr(gbeta), _ptr(k[0]), _ptr(k[1]), _ptr(k[2]), s), 'loans_bn_bwd_coeffs_f32')
     gx = torch.empty_like(x)
     check(app_fn(_ptr(gy), _ptr(idx), _ptr(x), _ptr(st.scale), _ptr(st.shift), _ptr(k[0]), _ptr(k[1]), _ptr(k[2]), _ptr(gx),
-                 B, H, W, C_, OH, OW, s), 'loans_pool_bn_bwd_apply')
+                 _ptr(gbias), B, H, W, C_, OH, OW, s), 'loans_pool_bn_bwd_apply')
     return gx
 
 

@@ -362,9 +362,12 @@ def test_stem_tail_fused_backward(shape, dtype):
     g_ref = C.max_pool_bwd(pre.shape, idx_np, gy.transpose(0, 3, 1, 2).astype(np.float64)) * (y_bn > 0)
     gx_ref, gg_ref, gb_ref = C.bn_bwd(ctx, gamma.astype(np.float64), g_ref)
     gg, gb = torch.zeros(C_, device='cuda'), torch.zeros(C_, device='cuda')
-    gx = ops.pool_bn_backward(gyd, idx, xd, st, dev(gamma), gg, gb)
+    gbias = torch.zeros(C_, device='cuda')
+    gx = ops.pool_bn_backward(gyd, idx, xd, st, dev(gamma), gg, gb, gbias=gbias)
     tol = 1e-2 if dtype == "bf16" else 2e-5
     assert rel_err(_nchw(gx.float()), gx_ref) < tol
+    # the bias gradient of the conv in front of a train-mode BN is analytically zero: compare on the scale of sum |gx|
+    assert np.abs(gbias.cpu().numpy() - gx_ref.sum(axis=(0, 2, 3))).max() < 1e-5 * np.abs(gx_ref).sum(axis=(0, 2, 3)).max() + 1e-6
     assert rel_err(gg.cpu().numpy(), gg_ref) < 1e-4 and rel_err(gb.cpu().numpy(), gb_ref) < 1e-4
     # the three-pass form
     gg3, gb3 = torch.zeros(C_, device='cuda'), torch.zeros(C_, device='cuda')
