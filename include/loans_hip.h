@@ -225,6 +225,19 @@ int loans_bn_bwd_apply_f32(const float* gy, const float* mask, const float* x,
                            const float* x2, const float* k1b, const float* k2b, const float* k3b, float* gx2,
                            int64_t rows, int32_t C, void* stream);
 
+/* The same two passes for a BN whose own ReLU supplies the mask (relu(bn(x)), the inner BNs of a residual unit,
+ * sheep/resnet.py:137,157): g = gy * (x*scale+shift > 0) with the pre-activation recomputed from x -- no mask tensor. */
+int loans_bn_bwd_reduce_xmask_f32(const float* gy, const float* x, const float* scale, const float* shift,
+                                  const float* mean, const float* rstd, double* sums, int64_t rows, int32_t C, void* stream);
+int loans_bn_bwd_apply_xmask_f32(const float* gy, const float* x, const float* scale, const float* shift,
+                                 const float* k1, const float* k2, const float* k3, float* gx, int64_t rows, int32_t C,
+                                 void* stream);
+int loans_bn_bwd_reduce_xmask_bf16(const void* gy, const void* x, const float* scale, const float* shift,
+                                   const float* mean, const float* rstd, double* sums, int64_t rows, int32_t C, void* stream);
+int loans_bn_bwd_apply_xmask_bf16(const void* gy, const void* x, const float* scale, const float* shift,
+                                  const float* k1, const float* k2, const float* k3, void* gx, int64_t rows, int32_t C,
+                                  void* stream);
+
 /* The stem's tail fused (sheep/resnet.py:72-73 backwards: max_pooling_2d -> relu -> bn1): with
  * g = (sum over windows whose argmax is this pixel of gy) * (x*scale+shift > 0) never written to memory,
  * reduce: sums[0][c] += sum g, sums[1][c] += sum g*xhat (one gather of x per pooled element);

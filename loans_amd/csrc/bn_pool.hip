@@ -141,11 +141,14 @@ __global__ __launch_bounds__(256) void maxpool_relu_bwd_kernel(const TG* gy, con
 
 // Per-channel reductions over rows.  Thread (cg = tid % C4, rl = tid / C4) walks rows rl, rl+RL, ...
 // of the block's slab; NS = number of sums per channel.
-template <bool DUAL, bool MASK, typename T>
+// MASK: 0 = g = gy; 1 = g = gy * (mask > 0); 2 = g = gy * (x*scale+shift > 0): the ReLU behind THIS BN, its output
+// recomputed from the x being read anyway instead of fetched (the inner BNs of a residual unit: one tensor less per pass)
+template <bool DUAL, int MASK, typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* gy, const T* mask, const T* x,
                                                             const float* mean, const float* rstd, const T* x2,
                                                             const float* mean2, const float* rstd2, double* sums,
-                                                            int64_t rows, int C4, int C4T, int rows_per_block) {
+                                                            int64_t rows, int C4, int C4T, int rows_per_block,
+                                                            const float* scale, const float* shift) {
     constexpr int NS = DUAL ? 3 : 2;
     __shared__ f32x4 red[NS][256];
     // channels are processed in slabs of C4 (<= 256) float4 groups; blockIdx.y picks the slab, C4T = all groups
@@ -158,14 +161,18 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* gy, const T
     const f32x4 mu = ld4(mean + cg * 4), rs = ld4(rstd + cg * 4);
     f32x4 mu2 = mu, rs2 = rs;
     if (DUAL) { mu2 = ld4(mean2 + cg * 4); rs2 = ld4(rstd2 + cg * 4); }
+    f32x4 sc = mu, sh = mu;
+    if (MASK == 2) { sc = ld4(scale + cg * 4); sh = ld4(shift + cg * 4); }
     f32x4 sg = {0.f, 0.f, 0.f, 0.f}, sgx = sg, sgx2 = sg;
     if (rl < RL) {
         for (int64_t r = r0 + rl; r < r1; r += RL) {
             const int64_t o = (r * C4T + cg) * 4;
             f32x4 g = io4<T>::ld(gy + o);
-            if (MASK) g = maskpos4(g, io4<T>::ld(mask + o));
+            const f32x4 xv = io4<T>::ld(x + o);
+            if (MASK == 1) g = maskpos4(g, io4<T>::ld(mask + o));
+            if (MASK == 2) g = maskpos4(g, xv * sc + sh);
             sg += g;
-            sgx += g * ((io4<T>::ld(x + o) - mu) * rs);
+            sgx += g * ((xv - mu) * rs);
             if (DUAL) sgx2 += g * ((io4<T>::ld(x2 + o) - mu2) * rs2);
         }
     }
@@ -205,16 +212,19 @@ __global__ void bn_bwd_coeffs_kernel(const double* sums, int C, double inv_count
     k3[c] = (float)(a * ((double)mean[c] * (double)rstd[c] * dg - db) * inv_count);
 }
 
-template <bool DUAL, bool MASK, typename T>
+template <bool DUAL, int MASK, typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* gy, const T* mask, const T* x,
                                                            const float* k1, const float* k2, const float* k3, T* gx,
                                                            const T* x2, const float* k1b, const float* k2b,
-                                                           const float* k3b, T* gx2, int64_t n4, int C4) {
+                                                           const float* k3b, T* gx2, int64_t n4, int C4,
+                                                           const float* scale, const float* shift) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % C4) * 4;
         f32x4 g = io4<T>::ld(gy + i * 4);
-        if (MASK) g = maskpos4(g, io4<T>::ld(mask + i * 4));
-        io4<T>::st(gx + i * 4, ld4(k1 + c) * g + ld4(k2 + c) * io4<T>::ld(x + i * 4) + ld4(k3 + c));
+        const f32x4 xv = io4<T>::ld(x + i * 4);
+        if (MASK == 1) g = maskpos4(g, io4<T>::ld(mask + i * 4));
+        if (MASK == 2) g = maskpos4(g, xv * ld4(scale + c) + ld4(shift + c));
+        io4<T>::st(gx + i * 4, ld4(k1 + c) * g + ld4(k2 + c) * xv + ld4(k3 + c));
         if (DUAL) io4<T>::st(gx2 + i * 4, ld4(k1b + c) * g + ld4(k2b + c) * io4<T>::ld(x2 + i * 4) + ld4(k3b + c));
     }
 }
@@ -626,17 +636,20 @@ extern "C" int loans_pool_bn_bwd_apply_bf16(const void* gy, const uint8_t* idx, 
 template <typename T>
 static int bn_bwd_reduce_impl(const T* gy, const T* mask, const T* x, const float* mean,
                               const float* rstd, const T* x2, const float* mean2, const float* rstd2,
-                              double* sums, int64_t rows, int32_t C, void* stream) {
+                              double* sums, int64_t rows, int32_t C, void* stream,
+                              const float* scale = nullptr, const float* shift = nullptr) {
     if (!gy || !x || !mean || !rstd || !sums || rows <= 0) return LOANS_EINVAL;
     if (!reduce_channels_ok(C)) return LOANS_EINVAL;
     if (x2 && (!mean2 || !rstd2)) return LOANS_EINVAL;
+    if (scale && (!shift || mask || x2)) return LOANS_EINVAL;
     int rpb, c4b, slabs;
     const int grid = reduce_geometry(rows, C, &rpb, &c4b, &slabs);
     hipStream_t st = as_stream(stream);
 #define LAUNCH_RED(D, M) \
-    hipLaunchKernelGGL((bn_bwd_reduce_kernel<D, M, T>), dim3(grid, slabs), dim3(256), 0, st, gy, mask, x, mean, rstd, x2, mean2, rstd2, sums, rows, c4b, C / 4, rpb)
-    if (x2) { if (mask) LAUNCH_RED(true, true); else LAUNCH_RED(true, false); }
-    else { if (mask) LAUNCH_RED(false, true); else LAUNCH_RED(false, false); }
+    hipLaunchKernelGGL((bn_bwd_reduce_kernel<D, M, T>), dim3(grid, slabs), dim3(256), 0, st, gy, mask, x, mean, rstd, x2, mean2, rstd2, sums, rows, c4b, C / 4, rpb, scale, shift)
+    if (x2) { if (mask) LAUNCH_RED(true, 1); else LAUNCH_RED(true, 0); }
+    else if (scale) LAUNCH_RED(false, 2);
+    else { if (mask) LAUNCH_RED(false, 1); else LAUNCH_RED(false, 0); }
 #undef LAUNCH_RED
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;
@@ -686,16 +699,18 @@ template <typename T>
 static int bn_bwd_apply_impl(const T* gy, const T* mask, const T* x, const float* k1,
                              const float* k2, const float* k3, T* gx, const T* x2, const float* k1b,
                              const float* k2b, const float* k3b, T* gx2, int64_t rows, int32_t C,
-                             void* stream) {
+                             void* stream, const float* scale = nullptr, const float* shift = nullptr) {
     if (!gy || !x || !k1 || !k2 || !k3 || !gx || rows <= 0 || C <= 0 || (C & 3)) return LOANS_EINVAL;
     if (x2 && (!k1b || !k2b || !k3b || !gx2)) return LOANS_EINVAL;
+    if (scale && (!shift || mask || x2)) return LOANS_EINVAL;
     const int64_t n4 = rows * (C / 4);
     const int grid = grid_for(n4, 256);
     hipStream_t st = as_stream(stream);
 #define LAUNCH_APP(D, M) \
-    hipLaunchKernelGGL((bn_bwd_apply_kernel<D, M, T>), dim3(grid), dim3(256), 0, st, gy, mask, x, k1, k2, k3, gx, x2, k1b, k2b, k3b, gx2, n4, C / 4)
-    if (x2) { if (mask) LAUNCH_APP(true, true); else LAUNCH_APP(true, false); }
-    else { if (mask) LAUNCH_APP(false, true); else LAUNCH_APP(false, false); }
+    hipLaunchKernelGGL((bn_bwd_apply_kernel<D, M, T>), dim3(grid), dim3(256), 0, st, gy, mask, x, k1, k2, k3, gx, x2, k1b, k2b, k3b, gx2, n4, C / 4, scale, shift)
+    if (x2) { if (mask) LAUNCH_APP(true, 1); else LAUNCH_APP(true, 0); }
+    else if (scale) LAUNCH_APP(false, 2);
+    else { if (mask) LAUNCH_APP(false, 1); else LAUNCH_APP(false, 0); }
 #undef LAUNCH_APP
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;
@@ -715,6 +730,39 @@ extern "C" int loans_bn_bwd_apply_bf16(const void* gy, const void* mask, const v
     return bn_bwd_apply_impl<__bf16>(static_cast<const __bf16*>(gy), static_cast<const __bf16*>(mask), static_cast<const __bf16*>(x),
                                      k1, k2, k3, static_cast<__bf16*>(gx), static_cast<const __bf16*>(x2), k1b, k2b, k3b,
                                      static_cast<__bf16*>(gx2), rows, C, stream);
+}
+
+// g = gy * (x*scale+shift > 0): the ReLU mask of the BN being differentiated, recomputed from x (no mask tensor)
+extern "C" int loans_bn_bwd_reduce_xmask_f32(const float* gy, const float* x, const float* scale, const float* shift,
+                                             const float* mean, const float* rstd, double* sums, int64_t rows, int32_t C,
+                                             void* stream) {
+    if (!scale || !shift) return LOANS_EINVAL;
+    return bn_bwd_reduce_impl<float>(gy, nullptr, x, mean, rstd, nullptr, nullptr, nullptr, sums, rows, C, stream, scale, shift);
+}
+
+extern "C" int loans_bn_bwd_reduce_xmask_bf16(const void* gy, const void* x, const float* scale, const float* shift,
+                                              const float* mean, const float* rstd, double* sums, int64_t rows, int32_t C,
+                                              void* stream) {
+    if (!scale || !shift) return LOANS_EINVAL;
+    return bn_bwd_reduce_impl<__bf16>(static_cast<const __bf16*>(gy), nullptr, static_cast<const __bf16*>(x), mean, rstd, nullptr,
+                                      nullptr, nullptr, sums, rows, C, stream, scale, shift);
+}
+
+extern "C" int loans_bn_bwd_apply_xmask_f32(const float* gy, const float* x, const float* scale, const float* shift,
+                                            const float* k1, const float* k2, const float* k3, float* gx, int64_t rows,
+                                            int32_t C, void* stream) {
+    if (!scale || !shift) return LOANS_EINVAL;
+    return bn_bwd_apply_impl<float>(gy, nullptr, x, k1, k2, k3, gx, nullptr, nullptr, nullptr, nullptr, nullptr, rows, C, stream,
+                                    scale, shift);
+}
+
+extern "C" int loans_bn_bwd_apply_xmask_bf16(const void* gy, const void* x, const float* scale, const float* shift,
+                                             const float* k1, const float* k2, const float* k3, void* gx, int64_t rows,
+                                             int32_t C, void* stream) {
+    if (!scale || !shift) return LOANS_EINVAL;
+    return bn_bwd_apply_impl<__bf16>(static_cast<const __bf16*>(gy), nullptr, static_cast<const __bf16*>(x), k1, k2, k3,
+                                     static_cast<__bf16*>(gx), nullptr, nullptr, nullptr, nullptr, nullptr, rows, C, stream,
+                                     scale, shift);
 }
 
 extern "C" int loans_colsum_f32(const float* x, float* out, int64_t rows, int32_t C, void* stream) {

@@ -154,7 +154,8 @@ class ResidualUnitFunction(Function):
             gh = ops.conv_dgrad(g, W.data, self.geo[i])
             ops.conv_wgrad(self.h[i - 1], g, W.grad_view, self.geo[i])
             _, gp, bp = P[1 + 3 * (i - 1):4 + 3 * (i - 1)]
-            g = ops.bn_backward(gh, self.h[i - 1], self.c[i - 1], self.st[i - 1], gp.data, gp.grad_view, bp.grad_view)
+            g = ops.bn_backward(gh, self.h[i - 1], self.c[i - 1], self.st[i - 1], gp.data, gp.grad_view, bp.grad_view,
+                                mask_is_own_relu=True)         # h[i-1] = relu(bn(c[i-1]))
         W0 = P[1]
         gx = None
         if P[0].requires_grad:

@@ -807,13 +807,36 @@ def maxpool_relu_bwd(gy, idx, x, st):
     return gx
 
 
-def bn_backward(gy, mask, x, st, gamma, ggamma, gbeta, x2=None, st2=None, gamma2=None, ggamma2=None, gbeta2=None):
+# LOANS_BN_XMASK=0: always read the ReLU mask from the stored activation
+BN_XMASK = os.environ.get('LOANS_BN_XMASK', '1') != '0'
+
+
+def bn_backward(gy, mask, x, st, gamma, ggamma, gbeta, x2=None, st2=None, gamma2=None, ggamma2=None, gbeta2=None,
+                mask_is_own_relu=False):
     """Training-mode BN backward for one or two BNs fed by the same upstream gradient
-    g = gy * (mask > 0).  Accumulates ggamma/gbeta in place, returns gx (and gx2)."""
+    g = gy * (mask > 0).  Accumulates ggamma/gbeta in place, returns gx (and gx2).
+    mask_is_own_relu: `mask` is relu(x*scale+shift), this BN's own activation -- its sign is recomputed from x and the
+    mask tensor is not read (one tensor less in both passes)."""
     lib = _lib.load()
     C_ = x.shape[-1]
     rows = x.numel() // C_
     dual = x2 is not None
+    if mask_is_own_relu and BN_XMASK and not dual and mask is not None:
+        s = _stream()
+        s16 = _is16(x)
+        assert _is16(gy) == s16
+        sums = _zeros_f64((2, C_), x.device)
+        red_fn = lib.loans_bn_bwd_reduce_xmask_bf16 if s16 else lib.loans_bn_bwd_reduce_xmask_f32
+        app_fn = lib.loans_bn_bwd_apply_xmask_bf16 if s16 else lib.loans_bn_bwd_apply_xmask_f32
+        check(red_fn(_ptr(gy), _ptr(x), _ptr(st.scale), _ptr(st.shift), _ptr(st.mean), _ptr(st.rstd), _ptr(sums), rows, C_, s),
+              'loans_bn_bwd_reduce_xmask')
+        k = torch.empty((3, C_), device=x.device, dtype=torch.float32)
+        check(lib.loans_bn_bwd_coeffs_f32(_ptr(sums), C_, rows, _ptr(gamma), _ptr(st.mean), _ptr(st.rstd), _ptr(ggamma),
+                                          _ptr(gbeta), _ptr(k[0]), _ptr(k[1]), _ptr(k[2]), s), 'loans_bn_bwd_coeffs_f32')
+        gx = torch.empty_like(x)
+        check(app_fn(_ptr(gy), _ptr(x), _ptr(st.scale), _ptr(st.shift), _ptr(k[0]), _ptr(k[1]), _ptr(k[2]), _ptr(gx), rows, C_,
+                     s), 'loans_bn_bwd_apply_xmask')
+        return gx
     sums = _zeros_f64((4 if dual else 2, C_), x.device)
     s = _stream()
     s16 = _is16(x)

@@ -300,6 +300,17 @@ def test_bn_forward_backward(C_):
     gx = ops.bn_backward(dev(_nhwc(gy)), dev(_nhwc(mask)), xd, st, dev(gamma), gg, gb)
     assert rel_err(_nchw(gx), gx_ref) < 2e-5
     assert rel_err(gg.cpu().numpy(), gg_ref) < 1e-5 and rel_err(gb.cpu().numpy(), gb_ref) < 1e-5
+    # the BN's own ReLU as the mask: sign recomputed from x (loans_bn_bwd_*_xmask) == mask tensor read from memory
+    for tdt in (torch.float32, torch.bfloat16):
+        xs, gys = xd.to(tdt), dev(_nhwc(gy)).to(tdt)
+        h = ops.bn_apply(xs, st, relu=True)
+        outs = []
+        for own in (False, True):
+            gga, gba = torch.zeros(C_, device='cuda'), torch.zeros(C_, device='cuda')
+            outs.append((ops.bn_backward(gys, h, xs, st, dev(gamma), gga, gba, mask_is_own_relu=own), gga, gba))
+        assert torch.equal(outs[0][0], outs[1][0])
+        assert rel_err(outs[1][1].cpu().numpy(), outs[0][1].cpu().numpy()) < 1e-6
+        assert rel_err(outs[1][2].cpu().numpy(), outs[0][2].cpu().numpy()) < 1e-6
     # dual form (BasicA's output feeds bn2 and bn3)
     gg2, gb2 = torch.zeros(C_, device='cuda'), torch.zeros(C_, device='cuda')
     gg.zero_(); gb.zero_()
