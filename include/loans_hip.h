@@ -137,7 +137,9 @@ int loans_wgrad_bf16_f32(const float* x, const float* gy, float* dw,
 /* fprop / dgrad on bf16 tensors: in, w ([Cout][ntaps][Cin], see loans_cast_bf16 / loans_repack_dgrad_bf16), out, ref and
  * addend are bf16; bias and stats as in loans_igemm_f32 (statistics are taken from the fp32 accumulators, the output
  * is rounded to bf16 once).  Flags RELU_IN / BIAS / STATS / MASK / ADDEND / ADDEND_MASK; tiles 128x128, 128x64, 64x64,
- * 256x64, 256x128 (0 = auto).  Operand tiles are staged by LDS-DMA, contraction on v_mfma_f32_32x32x16_bf16. */
+ * 256x64, 256x128 (0 = auto).  Operand tiles are staged by LDS-DMA, contraction on v_mfma_f32_32x32x16_bf16.
+ * LOANS_F_DENSE (here and in loans_wgrad_bf16s): `in` / `x` is the bf16 buffer of loans_prep_images_dense_bf16, inW / isx /
+ * dx[] count bf16 ELEMENTS and must be even (the 16-byte K units are then 4-byte aligned), Cin % 8 == 0. */
 int loans_igemm_bf16s(const void* in, const void* w, void* out, const float* bias, double* stats,
                       const void* ref, const void* addend, const loans_igemm_desc* d, void* stream);
 /* wgrad with bf16 x and gy, fp32 atomic accumulation into dw ("fp32 grad accumulate"); the pixel-major tiles are staged as
@@ -169,6 +171,10 @@ int loans_prep_images_f32(const float* images_nchw, float* out_nhwc4, int32_t B,
  * (pad, pad): the LOANS_F_DENSE input of conv1.  Every element of the buffer is written. */
 int loans_prep_images_dense_f32(const float* images_nchw, float* out_padded, int32_t B, int32_t H, int32_t W,
                                 int32_t pad, int32_t Hp, int32_t Wp, void* stream);
+/* the same buffer in bf16 (rounded to nearest even, exactly what the bf16 arm's operand staging does to the fp32 one):
+ * the LOANS_F_DENSE input of loans_igemm_bf16s / loans_wgrad_bf16s (bf16 storage arm, BASELINE configs 3 / 5) */
+int loans_prep_images_dense_bf16(const float* images_nchw, void* out_padded, int32_t B, int32_t H, int32_t W,
+                                 int32_t pad, int32_t Hp, int32_t Wp, void* stream);
 /* NCHW (C=3) -> NHWC4 without arithmetic (the assessor's `real` batch, sheep_updater.py:32-35) */
 int loans_nchw3_to_nhwc4_f32(const float* in, float* out, int32_t B, int32_t H, int32_t W, void* stream);
 

@@ -72,6 +72,7 @@ SIGNATURES = {
     'loans_u8hwc3_to_f32chw': [_p, _p, _i32, _i32, _i32, _p],
     'loans_prep_images_f32': [_p, _p, _i32, _i32, _i32, _p],
     'loans_prep_images_dense_f32': [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p],
+    'loans_prep_images_dense_bf16': [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p],
     'loans_nchw3_to_nhwc4_f32': [_p, _p, _i32, _i32, _i32, _p],
     'loans_bn_finalize_f32': [_p, _i32, _i64, _f32, _f32, _p, _p, _p, _p, _i32, _p, _p, _p, _p, _p],
     'loans_bn_eval_coeffs_f32': [_i32, _f32, _p, _p, _p, _p, _p, _p, _p, _p, _p],

@@ -100,7 +100,10 @@ __global__ __launch_bounds__(256) void igemm16_kernel(const Igemm16Args a) {
     const int tm = logical / a.tiles_n;
     const int lrow = tid >> 3;
     const int lu = (tid & 7) ^ ((tid >> 4) & 7);       // K unit this thread stages: slot ^ key(row)
-    const int pbytes = d.Cin * 2;                       // bytes per gathered pixel
+    // LOANS_F_DENSE (the RGB stem, see igemm.hip): inW / isx / dx count ELEMENTS of packed 3-channel rows inside a zero
+    // border, a "tap" is a run of Cin consecutive elements of one input row; no bounds masks; K units are 4-byte aligned
+    const bool dense = d.flags & LOANS_F_DENSE;
+    const int pbytes = dense ? 2 : d.Cin * 2;           // bytes per unit of inW / ix (a gathered pixel)
     if (tid < LOANS_MAX_TAPS) {
         const int t = tid < d.ntaps ? tid : 0;
         taps[tid] = (int(d.dy[t]) * d.inW + int(d.dx[t])) * pbytes;
@@ -127,7 +130,9 @@ __global__ __launch_bounds__(256) void igemm16_kernel(const Igemm16Args a) {
                 const int iy0 = y * d.isy, ix0 = x * d.isx;
                 rowoff[i] = (unsigned)((b * d.inH + iy0) * d.inW + ix0) * (unsigned)pbytes;
                 pixoff = (unsigned)((b * d.outH + y * d.osy + d.oy0) * d.outW + x * d.osx + d.ox0) * (unsigned)d.Cout * 2u;
-                if (a.ap.nx > 0) {
+                if (dense) {
+                    mask = ~0ull;
+                } else if (a.ap.nx > 0) {
                     const int cx = ix0 + a.ap.dx0, cy = iy0 + a.ap.dy0;
                     int jlo, jhi, rlo, rhi;
                     if (a.ap.sdx > 0) { jlo = max(0, -cx); jhi = min(a.ap.nx, d.inW - cx); }
@@ -548,6 +553,8 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const Wgrad16Args a) {
     const int unit = tid % UPR, prow = tid / UPR;
 
     // this thread's fixed column unit of the X tile: (tap, 8 channels)
+    // LOANS_F_DENSE: inW / isx / dx count elements of packed 3-channel rows, a tap is Cin consecutive elements of a row
+    const int ucin = (d.flags & LOANS_F_DENSE) ? 1 : d.Cin;
     const int cpt = d.Cin >> 3;
     const int ug = tj * UPR + unit;
     const int xtap = ug / cpt;
@@ -597,7 +604,7 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const Wgrad16Args a) {
         const int iy = y * d.isy + dy, ix = x * d.isx + dx;
         const unsigned ok = (unsigned)(rv & xtv) & (unsigned)((unsigned)iy < (unsigned)d.inH) &
                             (unsigned)((unsigned)ix < (unsigned)d.inW);
-        const unsigned xoff = ((unsigned)(((b * d.inH + iy) * d.inW + ix) * d.Cin + xc8 * 8) * 2u) | (ok - 1u);
+        const unsigned xoff = ((unsigned)(((b * d.inH + iy) * d.inW + ix) * ucin + xc8 * 8) * 2u) | (ok - 1u);
         rx[k][p] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)xoff, 0, 0);
         int nx = x + WPC;                       // advance one chunk: exact floor((v + .5) / n) for these small integers
         const int qx = (int)(((float)nx + 0.5f) * inv_gw);
@@ -736,7 +743,17 @@ extern "C" int loans_igemm_bf16s(const void* in, const void* w, void* out, const
     if ((d->gridH - 1) * d->osy + d->oy0 >= d->outH) return LOANS_EINVAL;
     if ((d->gridW - 1) * d->osx + d->ox0 >= d->outW) return LOANS_EINVAL;
     if (d->ntaps < 1 || d->ntaps > LOANS_MAX_TAPS) return LOANS_EINVAL;
-    if (d->flags & LOANS_F_DENSE) return LOANS_EINVAL;       // the RGB stem reads fp32 frames (loans_igemm_bf16_f32 + LOANS_F_OUT_BF16)
+    const bool dense = d->flags & LOANS_F_DENSE;
+    if (dense) {
+        // no bounds masks in this mode: every K-row of every grid pixel has to lie inside its input row; rows and row
+        // steps must keep the 16-byte loads 4-byte aligned (even element counts)
+        if ((d->inW & 1) || (d->isx & 1)) return LOANS_EINVAL;
+        for (int t = 0; t < d->ntaps; ++t) {
+            if (d->dy[t] < 0 || d->dx[t] < 0 || (d->dx[t] & 1)) return LOANS_EINVAL;
+            if ((d->gridH - 1) * d->isy + d->dy[t] >= d->inH) return LOANS_EINVAL;
+            if ((d->gridW - 1) * d->isx + d->dx[t] + d->Cin > d->inW) return LOANS_EINVAL;
+        }
+    }
     if ((d->flags & LOANS_F_BIAS) && !bias) return LOANS_EINVAL;
     if ((d->flags & LOANS_F_STATS) && !stats) return LOANS_EINVAL;
     if ((d->flags & (LOANS_F_MASK | LOANS_F_ADDEND_MASK)) && !ref) return LOANS_EINVAL;
@@ -757,7 +774,7 @@ extern "C" int loans_igemm_bf16s(const void* in, const void* w, void* out, const
 #endif
     a.nchunks = (a.Ktot + BKH - 1) / BKH;
     {
-        const int64_t ib = (int64_t)d->B * d->inH * d->inW * d->Cin * 2;
+        const int64_t ib = (int64_t)d->B * d->inH * d->inW * (dense ? 1 : d->Cin) * 2;
         const int64_t wb = (int64_t)d->Cout * a.Ktot * 2;
         const int64_t ob = (int64_t)d->B * d->outH * d->outW * d->Cout * 2;
         if (ib >= 0xFFFFFFF0ll || wb >= 0xFFFFFFF0ll || ob >= 0xFFFFFFF0ll) return LOANS_ERANGE;   // 32-bit buffer offsets
@@ -814,14 +831,22 @@ extern "C" int loans_wgrad_bf16s(const void* x, const void* gy, float* dw, const
     if ((d->gridH - 1) * d->osy + d->oy0 >= d->outH) return LOANS_EINVAL;
     if ((d->gridW - 1) * d->osx + d->ox0 >= d->outW) return LOANS_EINVAL;
     if (d->ntaps < 1 || d->ntaps > LOANS_MAX_TAPS) return LOANS_EINVAL;
-    if (d->flags & LOANS_F_DENSE) return LOANS_EINVAL;
+    const bool dense = d->flags & LOANS_F_DENSE;
+    if (dense) {            // as in loans_igemm_bf16s
+        if ((d->inW & 1) || (d->isx & 1)) return LOANS_EINVAL;
+        for (int t = 0; t < d->ntaps; ++t) {
+            if (d->dy[t] < 0 || d->dx[t] < 0 || (d->dx[t] & 1)) return LOANS_EINVAL;
+            if ((d->gridH - 1) * d->isy + d->dy[t] >= d->inH) return LOANS_EINVAL;
+            if ((d->gridW - 1) * d->isx + d->dx[t] + d->Cin > d->inW) return LOANS_EINVAL;
+        }
+    }
     if ((int64_t)d->B * d->gridH * d->gridW >= ((int64_t)1 << 31)) return LOANS_ERANGE;
     Wgrad16Args a;
     a.x = static_cast<const __bf16*>(x); a.gy = static_cast<const __bf16*>(gy); a.dw = dw; a.d = *d;
     a.M = d->B * d->gridH * d->gridW;
     a.Ktot = d->ntaps * d->Cin;
     {
-        const int64_t xb = (int64_t)d->B * d->inH * d->inW * d->Cin * 2;
+        const int64_t xb = (int64_t)d->B * d->inH * d->inW * (dense ? 1 : d->Cin) * 2;
         const int64_t gb = (int64_t)d->B * d->outH * d->outW * d->Cout * 2;
         if (xb >= 0xFFFFFFF0ll || gb >= 0xFFFFFFF0ll) return LOANS_ERANGE;
         a.x_bytes = (unsigned)xb; a.gy_bytes = (unsigned)gb;

@@ -33,7 +33,8 @@ __global__ __launch_bounds__(256) void prep_kernel(const float* img, float* out,
 }
 
 // packed 3-channel rows inside a zero border: one thread per (b, yp, xp) of the padded buffer
-__global__ __launch_bounds__(256) void prep_dense_kernel(const float* img, float* out, int B, int H, int W, int pad, int Hp, int Wp) {
+template <typename TO>
+__global__ __launch_bounds__(256) void prep_dense_kernel(const float* img, TO* out, int B, int H, int W, int pad, int Hp, int Wp) {
     const int64_t total = (int64_t)B * Hp * Wp;
     const int64_t HW = (int64_t)H * W;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
@@ -50,8 +51,8 @@ __global__ __launch_bounds__(256) void prep_dense_kernel(const float* img, float
             const float bl = (float)(((int)(src[2 * HW] * 255.f)) & 255);
             v0 = bl - 103.063f; v1 = g - 115.903f; v2 = r - 123.152f;
         }
-        float* o = out + i * 3;
-        o[0] = v0; o[1] = v1; o[2] = v2;
+        TO* o = out + i * 3;
+        o[0] = (TO)v0; o[1] = (TO)v1; o[2] = (TO)v2;         // bf16: round to nearest even, as the bf16 arm's staging does
     }
 }
 
@@ -432,8 +433,19 @@ extern "C" int loans_prep_images_dense_f32(const float* images_nchw, float* out_
     if (!images_nchw || !out_padded || B <= 0 || H <= 0 || W <= 0 || pad < 0) return LOANS_EINVAL;
     if (Hp < H + pad || Wp < W + pad) return LOANS_EINVAL;
     if ((int64_t)B * Hp * Wp * 3 >= ((int64_t)1 << 31)) return LOANS_ERANGE;
-    hipLaunchKernelGGL(prep_dense_kernel, dim3(grid_for((int64_t)B * Hp * Wp, 256)), dim3(256), 0, as_stream(stream),
+    hipLaunchKernelGGL(prep_dense_kernel<float>, dim3(grid_for((int64_t)B * Hp * Wp, 256)), dim3(256), 0, as_stream(stream),
                        images_nchw, out_padded, B, H, W, pad, Hp, Wp);
+    LOANS_LAUNCH_CHECK();
+    return LOANS_OK;
+}
+
+extern "C" int loans_prep_images_dense_bf16(const float* images_nchw, void* out_padded, int32_t B, int32_t H, int32_t W,
+                                            int32_t pad, int32_t Hp, int32_t Wp, void* stream) {
+    if (!images_nchw || !out_padded || B <= 0 || H <= 0 || W <= 0 || pad < 0) return LOANS_EINVAL;
+    if (Hp < H + pad || Wp < W + pad) return LOANS_EINVAL;
+    if ((int64_t)B * Hp * Wp * 3 >= ((int64_t)1 << 31)) return LOANS_ERANGE;
+    hipLaunchKernelGGL(prep_dense_kernel<__bf16>, dim3(grid_for((int64_t)B * Hp * Wp, 256)), dim3(256), 0, as_stream(stream),
+                       images_nchw, static_cast<__bf16*>(out_padded), B, H, W, pad, Hp, Wp);
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;
 }

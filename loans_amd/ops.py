@@ -404,16 +404,15 @@ def conv_fprop_pair(x, w_a, w_b, geo_a, geo_b, stats_a=None, stats_b=None, tile=
 
 def _conv_fprop16(lib, x, w, geo, out, bias, stats, relu_in, addend, tile):
     """bf16-storage forward conv: x / out / addend bf16, w fp32 master weights (cast per call) or already bf16."""
-    assert not geo.dense
     if out is None:
         out = torch.empty((geo.B, geo.Ho, geo.Wo, geo.Cout), device=x.device, dtype=BF16)
     assert out.dtype == BF16 and (addend is None or addend.dtype == BF16)
     assert x.numel() == geo.in_numel and w.numel() == geo.w_numel
     w16 = w if _is16(w) else cast_bf16(w)
     flags = (F_RELU_IN if relu_in else 0) | (F_BIAS if bias is not None else 0) | (F_STATS if stats is not None else 0) | \
-            (F_ADDEND if addend is not None else 0)
+            (F_ADDEND if addend is not None else 0) | geo.base_flags
     if tile == 0:
-        tflags = flags & (F_STATS | F_RELU_IN)
+        tflags = flags & (F_STATS | F_RELU_IN | F_DENSE)
         sstats = stats_buffer(geo.Cout, x.device) if stats is not None else None
 
         def run(t):
@@ -641,6 +640,10 @@ def _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile):
 # --------------------------------------------------------------------------- #
 # preprocessing / layout
 # --------------------------------------------------------------------------- #
+# LOANS_DENSE_BF16=0: the stem of the bf16 storage arm reads fp32 frames (loans_igemm_bf16_f32 + LOANS_F_OUT_BF16)
+DENSE_BF16 = os.environ.get('LOANS_DENSE_BF16', '1') != '0'
+
+
 def prep_images(images_nchw, geo=None):
     """NHWC4 frames, or -- for a dense-row stem geometry -- the zero-padded packed-RGB buffer [B][Hp][Wp][3]
     (tagged with the frame size, which the padded shape alone does not determine)."""
@@ -649,9 +652,12 @@ def prep_images(images_nchw, geo=None):
     _chk(images_nchw, 'images')
     if geo is not None and geo.dense:
         assert (geo.B, geo.H, geo.W) == (B, H, W)
-        out = torch.empty((B, geo.Hp, geo.Wp, 3), device=images_nchw.device, dtype=torch.float32)
-        check(_lib.load().loans_prep_images_dense_f32(_ptr(images_nchw), _ptr(out), B, H, W, geo.pad, geo.Hp, geo.Wp,
-                                                      _stream()), 'loans_prep_images_dense_f32')
+        # bf16 storage arm: the frames leave this kernel as bf16 (the same rounding the bf16 arm applies to fp32 frames
+        # while it stages them) and conv1 / its weight gradient run on the bf16-storage kernels
+        s16 = STORAGE == 'bf16' and DENSE_BF16
+        out = torch.empty((B, geo.Hp, geo.Wp, 3), device=images_nchw.device, dtype=BF16 if s16 else torch.float32)
+        fn = _lib.load().loans_prep_images_dense_bf16 if s16 else _lib.load().loans_prep_images_dense_f32
+        check(fn(_ptr(images_nchw), _ptr(out), B, H, W, geo.pad, geo.Hp, geo.Wp, _stream()), 'loans_prep_images_dense')
         out.frame_hw = (H, W)
         return out
     out = torch.empty((B, H, W, 4), device=images_nchw.device, dtype=torch.float32)

@@ -203,6 +203,22 @@ def test_region_boundaries_bf16_storage():
         ops._conv_wgrad(xp, dev(gc), dw32, geo, False, 0, 3)
         ops._conv_wgrad(xp, d16(gc), dw16, geo, False, 0, 3)
         assert rel_err(dw16.cpu().numpy(), dw32.cpu().numpy()) < 1e-5
+        # --- the same stem on bf16 FRAMES (loans_prep_images_dense_bf16 -> loans_igemm_bf16s / loans_wgrad_bf16s with
+        #     LOANS_F_DENSE): the operands are the ones the fp32-frame kernels round while staging, only the summation
+        #     order differs
+        ops.set_storage_dtype('bf16')
+        xp16 = ops.prep_images(dev(frames), geo)
+        assert xp16.dtype == torch.bfloat16 and xp16.frame_hw == (Hs, Hs) and torch.equal(xp16, xp.to(torch.bfloat16))
+        for t in (1, 2, 3, 4, 7):
+            sb = ops.stats_buffer(64, 'cuda')
+            cb = ops.conv_fprop(xp16, wd, geo, bias=bias, stats=sb, tile=t)
+            assert cb.dtype == torch.bfloat16
+            assert rel_err(cb.float().cpu().numpy(), c32.cpu().numpy()) < 2 ** -7, t
+            assert rel_err(sb.sum(0).cpu().numpy(), s32.sum(0).cpu().numpy()) < 1e-5, t
+        for t in (1, 3, 5):
+            dwb = torch.zeros_like(wd)
+            ops._conv_wgrad(xp16, d16(gc), dwb, geo, False, 0, t)
+            assert rel_err(dwb.cpu().numpy(), dw32.cpu().numpy()) < 1e-5, t
     finally:
         ops.set_compute_dtype('f32')
 
