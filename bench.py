@@ -142,6 +142,7 @@ def main():
 
     # ---- timed region: exactly K steps between barrier + synchronize ----
     ops.EVENT_LOG = [] if rank == 0 else None          # HIP events around the conv-forward launches
+    ops.FLOP_COUNT = {} if rank == 0 else None         # algorithmic FLOP of every convolution launch of the timed steps
     comm.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
@@ -151,6 +152,7 @@ def main():
     comm.barrier()
     elapsed = comm.allreduce_max(time.perf_counter() - t0)
     log, ops.EVENT_LOG = ops.EVENT_LOG, None
+    flop_count, ops.FLOP_COUNT = ops.FLOP_COUNT, None
 
     # what a bracket of two HIP events measures with NOTHING between them: the events are packets of their own in the
     # queue, and that time is not the kernel's (rocprofv3's per-kernel durations do not contain it either)
@@ -199,6 +201,15 @@ def main():
             roofline["traffic_unit"] = "bytes/launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r1_conv_fwd_hbm_traffic.json)"
         if hw == 224 and not args.resnet50:
             assert tot_flop // args.steps == B * CONV_FWD_FLOP_PER_IMAGE_224, (tot_flop // args.steps, B)
+        # the whole step against the same peak: algorithmic FLOP of EVERY convolution launch (localizer and assessor;
+        # forward, data gradient, weight gradient) over the step's wall time -- what the three streams together sustain
+        if flop_count:
+            step_flop = sum(flop_count.values()) // args.steps
+            roofline["whole_step"] = {
+                "algorithmic_flop_per_step": step_flop,
+                "by_kind": {k: v // args.steps for k, v in sorted(flop_count.items())},
+                "achieved": round(step_flop / (ms_per_step * 1e-3) / 1e12, 2),
+                "frac": round(step_flop / (ms_per_step * 1e-3) / 1e12 / peak, 4)}
 
     if world > 1:
         std = hw == 224 and not args.resnet50 and args.dtype == 'f32'

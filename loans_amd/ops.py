@@ -65,6 +65,14 @@ def _igemm_fn(lib):
 # When bench.py sets this to a list, conv_fprop brackets each launch with HIP events recorded on the
 # launch stream and appends (tag, algorithmic_flops, start_event, end_event).
 EVENT_LOG = None
+# When bench.py sets this to a dict, every convolution launch (forward, data gradient, weight gradient) adds its ALGORITHMIC
+# FLOP (2 per MAC, logical input channels, no padding / im2col redundancy) under 'fprop' / 'dgrad' / 'wgrad'.
+FLOP_COUNT = None
+
+
+def _count_flops(kind, geo):
+    if FLOP_COUNT is not None:
+        FLOP_COUNT[kind] = FLOP_COUNT.get(kind, 0) + 2 * geo.B * geo.Ho * geo.Wo * geo.Cout * geo.k * geo.k * geo.cin_logical
 
 BN_EPS = 2e-5          # chainer.links.BatchNormalization default (sheep/resnet.py:44)
 BN_DECAY = 0.9
@@ -343,6 +351,7 @@ def conv_fprop(x, w, geo, out=None, bias=None, stats=None, relu_in=False, addend
         tile = _tuned_tile(geo, COMPUTE + 'fprop' + ('_stats' if stats is not None else '') + ('_sk' if sk else ''), run,
                            _FPROP_TILES + sk)   # fp32 scratch output: the tile choice carries over
     d = _with_flags(geo.fwd, flags, tile)
+    _count_flops('fprop', geo)
     log = EVENT_LOG
     if log is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -389,6 +398,8 @@ def conv_fprop_pair(x, w_a, w_b, geo_a, geo_b, stats_a=None, stats_b=None, tile=
             check(lib.loans_igemm_pair_f32(_ptr(x), _ptr(w_a), _ptr(ta), _ptr(sa), _ptr(w_b), _ptr(tb), _ptr(sb), geo_b.Cout,
                                            C.byref(_with_flags(geo_a.fwd, flags, t)), _stream()), 'loans_igemm_pair_f32[tune]')
         tile = _tuned_tile(geo_a, 'f32fprop_pair%d%s' % (geo_b.Cout, '_stats' if flags else ''), run, _PAIR_TILES)
+    _count_flops('fprop', geo_a)
+    _count_flops('fprop', geo_b)
     log = EVENT_LOG
     if log is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -421,6 +432,7 @@ def _conv_fprop16(lib, x, w, geo, out, bias, stats, relu_in, addend, tile):
                                         C.byref(_with_flags(geo.fwd, tflags, t)), _stream()), 'loans_igemm_bf16s[tune]')
         tile = _tuned_tile(geo, 'bf16s_fprop' + ('_stats' if stats is not None else ''), run, _IGEMM16_TILES)
     d = _with_flags(geo.fwd, flags, tile)
+    _count_flops('fprop', geo)
     log = EVENT_LOG
     if log is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -474,6 +486,7 @@ def conv_dgrad(gy, w, geo, out=None, mask_ref=None, addend=None, addend_mask_ref
     Re-packs w per stride-parity class first (weights change every step)."""
     lib = _lib.load()
     assert gy.numel() == geo.B * geo.Ho * geo.Wo * geo.Cout
+    _count_flops('dgrad', geo)
     if _is16(gy) and geo.Cin != 4:
         return _conv_dgrad16(lib, gy, w, geo, out, mask_ref, addend, addend_mask_ref, tile)
     if out is None:
@@ -610,6 +623,7 @@ def _wgrad_candidates(geo, tiles, chunk_px, dims=None):
 
 def _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile):
     lib = _lib.load()
+    _count_flops('wgrad', geo)
     assert dw.numel() == geo.w_numel and x.numel() == geo.in_numel
     fl = (F_RELU_IN if relu_in else 0) | geo.base_flags
     s16 = _is16(x)
