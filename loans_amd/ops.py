@@ -554,6 +554,9 @@ def conv_dgrad(gy, w, geo, out=None, mask_ref=None, addend=None, addend_mask_ref
 # MFMA-bound wgrad kernels overlap the HBM-bound BN / ReLU passes of the data-gradient chain and
 # fill the tails of its dgrad launches.  `join_side_stream()` is the barrier the consumers call.
 ASYNC_WGRAD = os.environ.get('LOANS_ASYNC_WGRAD', '1') != '0'
+# while a step is being recorded into a hipGraph the side streams fork from / join the capturing stream, so the graph keeps
+# the eager step's concurrency (weight gradients beside the data-gradient chain, the assessor's chain beside the localizer's)
+CAPTURE_STREAMS = os.environ.get('LOANS_CAPTURE_STREAMS', '1') != '0'
 _side = {}
 _side_dirty = set()
 
@@ -583,7 +586,7 @@ def _wgrad_key(x, gy, relu_in):
 def conv_wgrad(x, gy, dw, geo, relu_in=False, splits=0, tile=0):
     """dw[Cout,k,k,Cin] += sum over pixels (atomic accumulate into the gradient arena)."""
     if ASYNC_WGRAD and geo.tuned.get(_wgrad_key(x, gy, relu_in)) is not None \
-            and not torch.cuda.is_current_stream_capturing():
+            and (CAPTURE_STREAMS or not torch.cuda.is_current_stream_capturing()):
         side = _side_stream(x.device)
         side.wait_stream(torch.cuda.current_stream(x.device))
         x.record_stream(side)

@@ -107,7 +107,8 @@ class SheepAssessor(training.StandardUpdater):
         localizer_optimizer = self.get_optimizer('opt_gen')
         discriminator_optimizer = self.get_optimizer('opt_dis')
         xp = self.localizer.xp
-        concurrent = CONCURRENT_CHAINS and not self.freeze_discriminator and not torch.cuda.is_current_stream_capturing()
+        concurrent = CONCURRENT_CHAINS and not self.freeze_discriminator and \
+            (ops.CAPTURE_STREAMS or not torch.cuda.is_current_stream_capturing())
 
         if not concurrent:
             y_real = self.discriminator(real_images)
