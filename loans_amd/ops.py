@@ -671,7 +671,7 @@ def prep_images(images_nchw, geo=None):
         assert (geo.B, geo.H, geo.W) == (B, H, W)
         # bf16 storage arm: the frames leave this kernel as bf16 (the same rounding the bf16 arm applies to fp32 frames
         # while it stages them) and conv1 / its weight gradient run on the bf16-storage kernels
-        s16 = STORAGE == 'bf16' and DENSE_BF16
+        s16 = STORAGE == 'bf16' and DENSE_BF16 and geo.stride % 2 == 0     # odd pixel steps would misalign the K units
         out = torch.empty((B, geo.Hp, geo.Wp, 3), device=images_nchw.device, dtype=BF16 if s16 else torch.float32)
         fn = _lib.load().loans_prep_images_dense_bf16 if s16 else _lib.load().loans_prep_images_dense_f32
         check(fn(_ptr(images_nchw), _ptr(out), B, H, W, geo.pad, geo.Hp, geo.Wp, _stream()), 'loans_prep_images_dense')
