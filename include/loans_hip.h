@@ -231,6 +231,31 @@ int loans_bn_bwd_apply_f32(const float* gy, const float* mask, const float* x,
                            const float* x2, const float* k1b, const float* k2b, const float* k3b, float* gx2,
                            int64_t rows, int32_t C, void* stream);
 
+/* ReLU mask as sign bits: loans_bn_apply_bits_* is loans_bn_apply_* that also writes signbits[rows * C / 4], one byte per four
+ * channels, bit e = (y[4i + e] > 0); loans_bn_bwd_{reduce,apply}_bits_* are the backward passes taking those bits where the
+ * plain ones take the mask tensor -- the final BN of a residual unit, whose mask is the unit's output relu(bn(x) + shortcut)
+ * (sheep/resnet.py:141,160): 1/16 (fp32) or 1/8 (bf16) of the activation's bytes in both passes. */
+int loans_bn_apply_bits_f32(const float* x, const float* scale, const float* shift,
+                            const float* x2, const float* scale2, const float* shift2,
+                            float* y, uint8_t* signbits, int64_t rows, int32_t C, int32_t mode, int32_t relu, void* stream);
+int loans_bn_apply_bits_bf16(const void* x, const float* scale, const float* shift,
+                             const void* x2, const float* scale2, const float* shift2,
+                             void* y, uint8_t* signbits, int64_t rows, int32_t C, int32_t mode, int32_t relu, void* stream);
+int loans_bn_bwd_reduce_bits_f32(const float* gy, const uint8_t* signbits, const float* x, const float* mean,
+                                 const float* rstd, const float* x2, const float* mean2, const float* rstd2,
+                                 double* sums, int64_t rows, int32_t C, void* stream);
+int loans_bn_bwd_reduce_bits_bf16(const void* gy, const uint8_t* signbits, const void* x, const float* mean,
+                                  const float* rstd, const void* x2, const float* mean2, const float* rstd2,
+                                  double* sums, int64_t rows, int32_t C, void* stream);
+int loans_bn_bwd_apply_bits_f32(const float* gy, const uint8_t* signbits, const float* x,
+                                const float* k1, const float* k2, const float* k3, float* gx,
+                                const float* x2, const float* k1b, const float* k2b, const float* k3b, float* gx2,
+                                int64_t rows, int32_t C, void* stream);
+int loans_bn_bwd_apply_bits_bf16(const void* gy, const uint8_t* signbits, const void* x,
+                                 const float* k1, const float* k2, const float* k3, void* gx,
+                                 const void* x2, const float* k1b, const float* k2b, const float* k3b, void* gx2,
+                                 int64_t rows, int32_t C, void* stream);
+
 /* The same two passes for a BN whose own ReLU supplies the mask (relu(bn(x)), the inner BNs of a residual unit,
  * sheep/resnet.py:137,157): g = gy * (x*scale+shift > 0) with the pre-activation recomputed from x -- no mask tensor. */
 int loans_bn_bwd_reduce_xmask_f32(const float* gy, const float* x, const float* scale, const float* shift,

@@ -52,6 +52,12 @@ SIGNATURES = {
     'loans_bn_bwd_reduce_bf16': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p],
     'loans_bn_bwd_apply_bf16': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p],
     'loans_colsum_bf16': [_p, _p, _i64, _i32, _p],
+    'loans_bn_apply_bits_f32': [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p],
+    'loans_bn_apply_bits_bf16': [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p],
+    'loans_bn_bwd_reduce_bits_f32': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p],
+    'loans_bn_bwd_reduce_bits_bf16': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p],
+    'loans_bn_bwd_apply_bits_f32': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p],
+    'loans_bn_bwd_apply_bits_bf16': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p],
     'loans_bn_bwd_reduce_xmask_f32': [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p],
     'loans_bn_bwd_reduce_xmask_bf16': [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p],
     'loans_bn_bwd_apply_xmask_f32': [_p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p],

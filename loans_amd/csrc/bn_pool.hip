@@ -56,10 +56,21 @@ __global__ void bn_eval_coeffs_kernel(int C, float eps, const float* gamma, cons
     shift[c] = beta[c] - rmean[c] * sc;
 }
 
+// signbits (optional): one byte per four channels, bit e = (y[4i + e] > 0) -- the ReLU mask the backward passes of this BN
+// need, at 1/16 (fp32) or 1/8 (bf16) of the bytes of y
+__device__ __forceinline__ uint8_t posbits4(f32x4 v) {
+    return (uint8_t)((v.x > 0.f ? 1 : 0) | (v.y > 0.f ? 2 : 0) | (v.z > 0.f ? 4 : 0) | (v.w > 0.f ? 8 : 0));
+}
+__device__ __forceinline__ f32x4 maskbits4(f32x4 g, uint8_t m) {
+    g.x = (m & 1) ? g.x : 0.f; g.y = (m & 2) ? g.y : 0.f;
+    g.z = (m & 4) ? g.z : 0.f; g.w = (m & 8) ? g.w : 0.f;
+    return g;
+}
+
 template <int MODE, typename T>
 __global__ __launch_bounds__(256) void bn_apply_kernel(const T* x, const float* scale, const float* shift,
                                                        const T* x2, const float* scale2, const float* shift2,
-                                                       T* y, int64_t n4, int C4, int relu) {
+                                                       T* y, int64_t n4, int C4, int relu, uint8_t* signbits) {
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
         const int c = (int)(i % C4) * 4;
         f32x4 v = io4<T>::ld(x + i * 4);
@@ -69,6 +80,7 @@ __global__ __launch_bounds__(256) void bn_apply_kernel(const T* x, const float* 
         if (MODE == 2) v += io4<T>::ld(x2 + i * 4) * ld4(scale2 + c) + ld4(shift2 + c);
         if (relu) v = relu4(v);
         io4<T>::st(y + i * 4, v);
+        if (signbits) signbits[i] = posbits4(v);
     }
 }
 
@@ -142,7 +154,8 @@ __global__ __launch_bounds__(256) void maxpool_relu_bwd_kernel(const TG* gy, con
 // Per-channel reductions over rows.  Thread (cg = tid % C4, rl = tid / C4) walks rows rl, rl+RL, ...
 // of the block's slab; NS = number of sums per channel.
 // MASK: 0 = g = gy; 1 = g = gy * (mask > 0); 2 = g = gy * (x*scale+shift > 0): the ReLU behind THIS BN, its output
-// recomputed from the x being read anyway instead of fetched (the inner BNs of a residual unit: one tensor less per pass)
+// recomputed from the x being read anyway instead of fetched (the inner BNs of a residual unit: one tensor less per pass);
+// 3 = `mask` points at the sign bits bn_apply wrote (one byte per four channels) instead of at the activation tensor
 template <bool DUAL, int MASK, typename T>
 __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* gy, const T* mask, const T* x,
                                                             const float* mean, const float* rstd, const T* x2,
@@ -171,6 +184,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_kernel(const T* gy, const T
             const f32x4 xv = io4<T>::ld(x + o);
             if (MASK == 1) g = maskpos4(g, io4<T>::ld(mask + o));
             if (MASK == 2) g = maskpos4(g, xv * sc + sh);
+            if (MASK == 3) g = maskbits4(g, reinterpret_cast<const uint8_t*>(mask)[o >> 2]);
             sg += g;
             sgx += g * ((xv - mu) * rs);
             if (DUAL) sgx2 += g * ((io4<T>::ld(x2 + o) - mu2) * rs2);
@@ -224,6 +238,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* gy, const T*
         const f32x4 xv = io4<T>::ld(x + i * 4);
         if (MASK == 1) g = maskpos4(g, io4<T>::ld(mask + i * 4));
         if (MASK == 2) g = maskpos4(g, xv * ld4(scale + c) + ld4(shift + c));
+        if (MASK == 3) g = maskbits4(g, reinterpret_cast<const uint8_t*>(mask)[i]);
         io4<T>::st(gx + i * 4, ld4(k1 + c) * g + ld4(k2 + c) * xv + ld4(k3 + c));
         if (DUAL) io4<T>::st(gx2 + i * 4, ld4(k1b + c) * g + ld4(k2b + c) * io4<T>::ld(x2 + i * 4) + ld4(k3b + c));
     }
@@ -492,15 +507,15 @@ extern "C" int loans_bn_eval_coeffs_f32(int32_t C, float eps, const float* gamma
 template <typename T>
 static int bn_apply_impl(const T* x, const float* scale, const float* shift, const T* x2,
                          const float* scale2, const float* shift2, T* y, int64_t rows, int32_t C,
-                         int32_t mode, int32_t relu, void* stream) {
+                         int32_t mode, int32_t relu, void* stream, uint8_t* signbits = nullptr) {
     if (!x || !scale || !shift || !y || rows <= 0 || C <= 0 || (C & 3)) return LOANS_EINVAL;
     if (mode < 0 || mode > 2 || (mode >= 1 && !x2) || (mode == 2 && (!scale2 || !shift2))) return LOANS_EINVAL;
     const int64_t n4 = rows * (C / 4);
     const int grid = grid_for(n4, 256);
     hipStream_t st = as_stream(stream);
-    if (mode == 0) hipLaunchKernelGGL((bn_apply_kernel<0, T>), dim3(grid), dim3(256), 0, st, x, scale, shift, x2, scale2, shift2, y, n4, C / 4, relu);
-    if (mode == 1) hipLaunchKernelGGL((bn_apply_kernel<1, T>), dim3(grid), dim3(256), 0, st, x, scale, shift, x2, scale2, shift2, y, n4, C / 4, relu);
-    if (mode == 2) hipLaunchKernelGGL((bn_apply_kernel<2, T>), dim3(grid), dim3(256), 0, st, x, scale, shift, x2, scale2, shift2, y, n4, C / 4, relu);
+    if (mode == 0) hipLaunchKernelGGL((bn_apply_kernel<0, T>), dim3(grid), dim3(256), 0, st, x, scale, shift, x2, scale2, shift2, y, n4, C / 4, relu, signbits);
+    if (mode == 1) hipLaunchKernelGGL((bn_apply_kernel<1, T>), dim3(grid), dim3(256), 0, st, x, scale, shift, x2, scale2, shift2, y, n4, C / 4, relu, signbits);
+    if (mode == 2) hipLaunchKernelGGL((bn_apply_kernel<2, T>), dim3(grid), dim3(256), 0, st, x, scale, shift, x2, scale2, shift2, y, n4, C / 4, relu, signbits);
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;
 }
@@ -509,6 +524,21 @@ extern "C" int loans_bn_apply_f32(const float* x, const float* scale, const floa
                                   const float* scale2, const float* shift2, float* y, int64_t rows, int32_t C,
                                   int32_t mode, int32_t relu, void* stream) {
     return bn_apply_impl<float>(x, scale, shift, x2, scale2, shift2, y, rows, C, mode, relu, stream);
+}
+
+extern "C" int loans_bn_apply_bits_f32(const float* x, const float* scale, const float* shift, const float* x2,
+                                       const float* scale2, const float* shift2, float* y, uint8_t* signbits, int64_t rows,
+                                       int32_t C, int32_t mode, int32_t relu, void* stream) {
+    if (!signbits) return LOANS_EINVAL;
+    return bn_apply_impl<float>(x, scale, shift, x2, scale2, shift2, y, rows, C, mode, relu, stream, signbits);
+}
+
+extern "C" int loans_bn_apply_bits_bf16(const void* x, const float* scale, const float* shift, const void* x2,
+                                        const float* scale2, const float* shift2, void* y, uint8_t* signbits, int64_t rows,
+                                        int32_t C, int32_t mode, int32_t relu, void* stream) {
+    if (!signbits) return LOANS_EINVAL;
+    return bn_apply_impl<__bf16>(static_cast<const __bf16*>(x), scale, shift, static_cast<const __bf16*>(x2), scale2, shift2,
+                                 static_cast<__bf16*>(y), rows, C, mode, relu, stream, signbits);
 }
 
 extern "C" int loans_bn_apply_bf16(const void* x, const float* scale, const float* shift, const void* x2,
@@ -637,7 +667,7 @@ template <typename T>
 static int bn_bwd_reduce_impl(const T* gy, const T* mask, const T* x, const float* mean,
                               const float* rstd, const T* x2, const float* mean2, const float* rstd2,
                               double* sums, int64_t rows, int32_t C, void* stream,
-                              const float* scale = nullptr, const float* shift = nullptr) {
+                              const float* scale = nullptr, const float* shift = nullptr, bool bits = false) {
     if (!gy || !x || !mean || !rstd || !sums || rows <= 0) return LOANS_EINVAL;
     if (!reduce_channels_ok(C)) return LOANS_EINVAL;
     if (x2 && (!mean2 || !rstd2)) return LOANS_EINVAL;
@@ -647,9 +677,10 @@ static int bn_bwd_reduce_impl(const T* gy, const T* mask, const T* x, const floa
     hipStream_t st = as_stream(stream);
 #define LAUNCH_RED(D, M) \
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<D, M, T>), dim3(grid, slabs), dim3(256), 0, st, gy, mask, x, mean, rstd, x2, mean2, rstd2, sums, rows, c4b, C / 4, rpb, scale, shift)
-    if (x2) { if (mask) LAUNCH_RED(true, 1); else LAUNCH_RED(true, 0); }
+    if (bits && !mask) return LOANS_EINVAL;
+    if (x2) { if (bits) LAUNCH_RED(true, 3); else if (mask) LAUNCH_RED(true, 1); else LAUNCH_RED(true, 0); }
     else if (scale) LAUNCH_RED(false, 2);
-    else { if (mask) LAUNCH_RED(false, 1); else LAUNCH_RED(false, 0); }
+    else { if (bits) LAUNCH_RED(false, 3); else if (mask) LAUNCH_RED(false, 1); else LAUNCH_RED(false, 0); }
 #undef LAUNCH_RED
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;
@@ -699,8 +730,9 @@ template <typename T>
 static int bn_bwd_apply_impl(const T* gy, const T* mask, const T* x, const float* k1,
                              const float* k2, const float* k3, T* gx, const T* x2, const float* k1b,
                              const float* k2b, const float* k3b, T* gx2, int64_t rows, int32_t C,
-                             void* stream, const float* scale = nullptr, const float* shift = nullptr) {
+                             void* stream, const float* scale = nullptr, const float* shift = nullptr, bool bits = false) {
     if (!gy || !x || !k1 || !k2 || !k3 || !gx || rows <= 0 || C <= 0 || (C & 3)) return LOANS_EINVAL;
+    if (bits && !mask) return LOANS_EINVAL;
     if (x2 && (!k1b || !k2b || !k3b || !gx2)) return LOANS_EINVAL;
     if (scale && (!shift || mask || x2)) return LOANS_EINVAL;
     const int64_t n4 = rows * (C / 4);
@@ -708,9 +740,9 @@ static int bn_bwd_apply_impl(const T* gy, const T* mask, const T* x, const float
     hipStream_t st = as_stream(stream);
 #define LAUNCH_APP(D, M) \
     hipLaunchKernelGGL((bn_bwd_apply_kernel<D, M, T>), dim3(grid), dim3(256), 0, st, gy, mask, x, k1, k2, k3, gx, x2, k1b, k2b, k3b, gx2, n4, C / 4, scale, shift)
-    if (x2) { if (mask) LAUNCH_APP(true, 1); else LAUNCH_APP(true, 0); }
+    if (x2) { if (bits) LAUNCH_APP(true, 3); else if (mask) LAUNCH_APP(true, 1); else LAUNCH_APP(true, 0); }
     else if (scale) LAUNCH_APP(false, 2);
-    else { if (mask) LAUNCH_APP(false, 1); else LAUNCH_APP(false, 0); }
+    else { if (bits) LAUNCH_APP(false, 3); else if (mask) LAUNCH_APP(false, 1); else LAUNCH_APP(false, 0); }
 #undef LAUNCH_APP
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;
@@ -730,6 +762,40 @@ extern "C" int loans_bn_bwd_apply_bf16(const void* gy, const void* mask, const v
     return bn_bwd_apply_impl<__bf16>(static_cast<const __bf16*>(gy), static_cast<const __bf16*>(mask), static_cast<const __bf16*>(x),
                                      k1, k2, k3, static_cast<__bf16*>(gx), static_cast<const __bf16*>(x2), k1b, k2b, k3b,
                                      static_cast<__bf16*>(gx2), rows, C, stream);
+}
+
+// g = gy * bit: the mask comes from the sign bits loans_bn_apply_bits_* wrote (one byte per four channels)
+extern "C" int loans_bn_bwd_reduce_bits_f32(const float* gy, const uint8_t* signbits, const float* x, const float* mean,
+                                            const float* rstd, const float* x2, const float* mean2, const float* rstd2,
+                                            double* sums, int64_t rows, int32_t C, void* stream) {
+    return bn_bwd_reduce_impl<float>(gy, reinterpret_cast<const float*>(signbits), x, mean, rstd, x2, mean2, rstd2, sums, rows, C,
+                                     stream, nullptr, nullptr, true);
+}
+
+extern "C" int loans_bn_bwd_reduce_bits_bf16(const void* gy, const uint8_t* signbits, const void* x, const float* mean,
+                                             const float* rstd, const void* x2, const float* mean2, const float* rstd2,
+                                             double* sums, int64_t rows, int32_t C, void* stream) {
+    return bn_bwd_reduce_impl<__bf16>(static_cast<const __bf16*>(gy), reinterpret_cast<const __bf16*>(signbits),
+                                      static_cast<const __bf16*>(x), mean, rstd, static_cast<const __bf16*>(x2), mean2, rstd2,
+                                      sums, rows, C, stream, nullptr, nullptr, true);
+}
+
+extern "C" int loans_bn_bwd_apply_bits_f32(const float* gy, const uint8_t* signbits, const float* x, const float* k1,
+                                           const float* k2, const float* k3, float* gx, const float* x2, const float* k1b,
+                                           const float* k2b, const float* k3b, float* gx2, int64_t rows, int32_t C,
+                                           void* stream) {
+    return bn_bwd_apply_impl<float>(gy, reinterpret_cast<const float*>(signbits), x, k1, k2, k3, gx, x2, k1b, k2b, k3b, gx2, rows,
+                                    C, stream, nullptr, nullptr, true);
+}
+
+extern "C" int loans_bn_bwd_apply_bits_bf16(const void* gy, const uint8_t* signbits, const void* x, const float* k1,
+                                            const float* k2, const float* k3, void* gx, const void* x2, const float* k1b,
+                                            const float* k2b, const float* k3b, void* gx2, int64_t rows, int32_t C,
+                                            void* stream) {
+    return bn_bwd_apply_impl<__bf16>(static_cast<const __bf16*>(gy), reinterpret_cast<const __bf16*>(signbits),
+                                     static_cast<const __bf16*>(x), k1, k2, k3, static_cast<__bf16*>(gx),
+                                     static_cast<const __bf16*>(x2), k1b, k2b, k3b, static_cast<__bf16*>(gx2), rows, C, stream,
+                                     nullptr, nullptr, true);
 }
 
 // g = gy * (x*scale+shift > 0): the ReLU mask of the BN being differentiated, recomputed from x (no mask tensor)

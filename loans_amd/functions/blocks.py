@@ -105,13 +105,14 @@ class ResidualUnitFunction(Function):
                 self.c[i], self.st[i], self.geo[i] = _ConvBN.forward(h, conv, bn, W, None, g, b)
             if i < n - 1:
                 h = self.h[i] = ops.bn_apply(self.c[i], self.st[i], relu=True)
+        bits = config.train and config.enable_backprop     # the backward's ReLU mask as sign bits (ops.bn_apply)
         if self.shortcut is not None:
             W, g, b = inputs[1 + 3 * n:4 + 3 * n]
             if not paired:
                 self.cs, self.sts, self.geos = _ConvBN.forward(x, self.shortcut[0], self.shortcut[1], W, None, g, b)
-            self.out = ops.bn_apply(self.c[-1], self.st[-1], relu=True, x2=self.cs, st2=self.sts)
+            self.out = ops.bn_apply(self.c[-1], self.st[-1], relu=True, x2=self.cs, st2=self.sts, want_bits=bits)
         else:
-            self.out = ops.bn_apply(self.c[-1], self.st[-1], relu=True, residual=x)
+            self.out = ops.bn_apply(self.c[-1], self.st[-1], relu=True, residual=x, want_bits=bits)
         return self.out
 
     def _forward_pair(self, x, inputs):

@@ -786,7 +786,13 @@ def bn_eval_coeffs(gamma, beta, running_mean, running_var):
     return st
 
 
-def bn_apply(x, st, relu=True, residual=None, x2=None, st2=None):
+# LOANS_BN_BITS=0: the final BN of a residual unit reads its ReLU mask from the unit's output tensor
+BN_BITS = os.environ.get('LOANS_BN_BITS', '1') != '0'
+
+
+def bn_apply(x, st, relu=True, residual=None, x2=None, st2=None, want_bits=False):
+    """y = act(bn(x) [+ residual | + bn2(x2)]).  want_bits: also write the sign bits of y (one byte per four channels) and
+    hang them on the result as ``y.relu_bits`` -- bn_backward then takes the ReLU mask from them instead of from y."""
     C_ = x.shape[-1]
     rows = x.numel() // C_
     y = torch.empty_like(x)
@@ -798,6 +804,14 @@ def bn_apply(x, st, relu=True, residual=None, x2=None, st2=None):
         mode, second = 2, x2
     lib = _lib.load()
     assert second is None or second.dtype == x.dtype
+    if want_bits and relu and BN_BITS:
+        bits = torch.empty(rows * (C_ // 4), device=x.device, dtype=torch.uint8)
+        fn = lib.loans_bn_apply_bits_bf16 if _is16(x) else lib.loans_bn_apply_bits_f32
+        check(fn(_ptr(x), _ptr(st.scale), _ptr(st.shift), _ptr(second),
+                 _ptr(st2.scale if st2 else None), _ptr(st2.shift if st2 else None),
+                 _ptr(y), _ptr(bits), rows, C_, mode, 1, _stream()), 'loans_bn_apply_bits')
+        y.relu_bits = bits
+        return y
     fn = lib.loans_bn_apply_bf16 if _is16(x) else lib.loans_bn_apply_f32
     check(fn(_ptr(x), _ptr(st.scale), _ptr(st.shift), _ptr(second),
              _ptr(st2.scale if st2 else None), _ptr(st2.shift if st2 else None),
@@ -866,6 +880,12 @@ def bn_backward(gy, mask, x, st, gamma, ggamma, gbeta, x2=None, st2=None, gamma2
     assert _is16(gy) == s16 and (mask is None or _is16(mask) == s16) and (x2 is None or _is16(x2) == s16)
     red_fn = lib.loans_bn_bwd_reduce_bf16 if s16 else lib.loans_bn_bwd_reduce_f32
     app_fn = lib.loans_bn_bwd_apply_bf16 if s16 else lib.loans_bn_bwd_apply_f32
+    bits = getattr(mask, 'relu_bits', None) if (mask is not None and BN_BITS) else None
+    if bits is not None:            # the mask as sign bits (ops.bn_apply(..., want_bits=True)) instead of the tensor
+        assert bits.numel() == rows * (C_ // 4)
+        mask = bits
+        red_fn = lib.loans_bn_bwd_reduce_bits_bf16 if s16 else lib.loans_bn_bwd_reduce_bits_f32
+        app_fn = lib.loans_bn_bwd_apply_bits_bf16 if s16 else lib.loans_bn_bwd_apply_bits_f32
     check(red_fn(_ptr(gy), _ptr(mask), _ptr(x), _ptr(st.mean), _ptr(st.rstd), _ptr(x2),
                                       _ptr(st2.mean if dual else None), _ptr(st2.rstd if dual else None),
                                       _ptr(sums), rows, C_, s), 'loans_bn_bwd_reduce_f32')

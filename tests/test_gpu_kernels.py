@@ -308,9 +308,31 @@ def test_bn_forward_backward(C_):
         for own in (False, True):
             gga, gba = torch.zeros(C_, device='cuda'), torch.zeros(C_, device='cuda')
             outs.append((ops.bn_backward(gys, h, xs, st, dev(gamma), gga, gba, mask_is_own_relu=own), gga, gba))
-        assert torch.equal(outs[0][0], outs[1][0])
+        assert rel_err(outs[1][0].float().cpu().numpy(), outs[0][0].float().cpu().numpy()) < (1e-5 if tdt == torch.float32 else 2 ** -7)
         assert rel_err(outs[1][1].cpu().numpy(), outs[0][1].cpu().numpy()) < 1e-6
         assert rel_err(outs[1][2].cpu().numpy(), outs[0][2].cpu().numpy()) < 1e-6
+    # the unit's output as the mask, handed over as sign bits (ops.bn_apply(want_bits=True) -> loans_bn_bwd_*_bits_*):
+    # same results as reading the mask tensor, single and dual form
+    for tdt in (torch.float32, torch.bfloat16):
+        xs, gys, rs = xd.to(tdt), dev(_nhwc(gy)).to(tdt), dev(_nhwc(res)).to(tdt)
+        y_plain = ops.bn_apply(xs, st, relu=True, residual=rs)
+        y_bits = ops.bn_apply(xs, st, relu=True, residual=rs, want_bits=True)
+        assert torch.equal(y_plain, y_bits) and not hasattr(y_plain, 'relu_bits')
+        assert y_bits.relu_bits.dtype == torch.uint8 and y_bits.relu_bits.numel() == xs.numel() // 4
+        ref_bits = ((y_plain.float().reshape(-1, 4) > 0).to(torch.int32) * torch.tensor([1, 2, 4, 8], dtype=torch.int32, device='cuda')).sum(1).to(torch.uint8)
+        assert torch.equal(y_bits.relu_bits, ref_bits)
+        for dual in (False, True):
+            outs = []
+            for m in (y_plain, y_bits):
+                g1, b1, g2, b2 = (torch.zeros(C_, device='cuda') for _ in range(4))
+                kw = dict(x2=xs, st2=st, gamma2=dev(gamma), ggamma2=g2, gbeta2=b2) if dual else {}
+                r = ops.bn_backward(gys, m, xs, st, dev(gamma), g1, b1, **kw)
+                outs.append((r if dual else (r,)) + (g1, b1, g2, b2))
+            # (the fp64 atomics of the reduction land in a different order from run to run: equal up to the last bit of
+            # the fp32 coefficients, one bf16 ulp on rounded outputs)
+            tol = 1e-5 if tdt == torch.float32 else 2 ** -7
+            for a, b in zip(*outs):
+                assert rel_err(a.float().cpu().numpy(), b.float().cpu().numpy()) < tol
     # dual form (BasicA's output feeds bn2 and bn3)
     gg2, gb2 = torch.zeros(C_, device='cuda'), torch.zeros(C_, device='cuda')
     gg.zero_(); gb.zero_()
