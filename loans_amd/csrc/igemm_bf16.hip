@@ -110,8 +110,10 @@ __global__ __launch_bounds__(256) void igemm16_kernel(const Igemm16Args a) {
     }
 
     // per row: byte offset of its base pixel and the bitmask of taps that must read zero (see igemm.hip)
+    // (32 bits here: the launcher admits at most 32 taps without LOANS_F_DENSE, and a dense launch has no bad tap --
+    // one v_bfe_i32 per piece instead of a 64-bit shift + extract)
     unsigned rowoff[RA];
-    unsigned long long badmask[RA];
+    unsigned badmask[RA];
     {
         const int gHW = d.gridH * d.gridW;
         const float inv_gw = 1.f / (float)d.gridW, inv_gh = 1.f / (float)d.gridH;
@@ -153,7 +155,7 @@ __global__ __launch_bounds__(256) void igemm16_kernel(const Igemm16Args a) {
                     }
                 }
             }
-            badmask[i] = ~mask;
+            badmask[i] = ~(unsigned)mask;
 #ifdef LOANS_EXPERIMENT
             if (a.dbg & 4) { rowoff[i] = (unsigned)((d.inW + 1) * pbytes) + (rowoff[i] & 0x3FFu); badmask[i] = 0; }   // cache-hot gathers
 #endif
@@ -188,29 +190,43 @@ __global__ __launch_bounds__(256) void igemm16_kernel(const Igemm16Args a) {
 #endif
     }
     unsigned toff = (unsigned)taps[min(tap, LOANS_MAX_TAPS - 1)] + (unsigned)c8 * 16u;
+    // per-chunk values every piece shares: the tap's bit position, and all-ones once this thread's K unit lies beyond K
+    unsigned tcs = (unsigned)min(tap, 31);
+    unsigned kb = (unsigned)((kunits - 1 - u) >> 31);
+    // the tap-table entry of the chunk AFTER the next one is fetched a whole chunk before it is needed: read at the point
+    // of use it sat behind an lgkmcnt(0) in the middle of the MFMA stream (LDS returns in order, and the fragment reads
+    // of the next step were already queued in front of it)
+    auto step_tap = [&](int& t, int& c) {
+        t += q8;
+        c += r8;
+        const int wrap = c >= cpt;
+        c -= wrap ? cpt : 0;
+        t += wrap;
+    };
+    int tap_n = tap, c8_n = c8;
+    step_tap(tap_n, c8_n);
+    int traw_n = taps[min(tap_n, LOANS_MAX_TAPS - 1)];
 
     const int wave_u = __builtin_amdgcn_readfirstlane(tid >> 6);
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     auto dma_a = [&](int buf, int i) {      // one 1 KiB LDS-DMA piece: 8 rows x 128 B of the A tile
-        const int tc = min(tap, LOANS_MAX_TAPS - 1);
-        const unsigned kbad = (unsigned)(u < kunits) - 1u;
-        const unsigned bad = 0u - ((unsigned)(badmask[i] >> tc) & 1u);
-        const unsigned off = (rowoff[i] + toff) | bad | kbad;
+        const unsigned bad = (unsigned)__builtin_amdgcn_sbfe((int)badmask[i], tcs, 1u);     // 0 / ~0: this row's bit of the tap
+        const unsigned off = (rowoff[i] + toff) | bad | kb;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(As + (buf * BM + 32 * i + 8 * wave_u) * BKH), 16, (int)off, 0, 0, 0);
     };
     auto dma_b = [&](int buf, int i) {
-        const unsigned kbad = (unsigned)(u < kunits) - 1u;
-        const unsigned off = (woff[i] + (unsigned)u * 16u) | wbad[i] | kbad;
+        const unsigned off = (woff[i] + (unsigned)u * 16u) | wbad[i] | kb;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(Bs + (buf * BN + 32 * i + 8 * wave_u) * BKH), 16, (int)off, 0, 0, 0);
     };
     auto advance = [&]() {      // to the following chunk (8 units further along K)
         u += 8;
-        tap += q8;
-        c8 += r8;
-        const int wrap = c8 >= cpt;
-        c8 -= wrap ? cpt : 0;
-        tap += wrap;
-        toff = (unsigned)taps[min(tap, LOANS_MAX_TAPS - 1)] + (unsigned)c8 * 16u;
+        tap = tap_n;
+        c8 = c8_n;
+        toff = (unsigned)traw_n + (unsigned)c8 * 16u;
+        tcs = (unsigned)min(tap, 31);
+        kb = (unsigned)((kunits - 1 - u) >> 31);
+        step_tap(tap_n, c8_n);
+        traw_n = taps[min(tap_n, LOANS_MAX_TAPS - 1)];
     };
     constexpr int NPIECE = RA + RB + 1;
     auto dma_piece = [&](int buf, int p) {
@@ -744,6 +760,7 @@ extern "C" int loans_igemm_bf16s(const void* in, const void* w, void* out, const
     if ((d->gridW - 1) * d->osx + d->ox0 >= d->outW) return LOANS_EINVAL;
     if (d->ntaps < 1 || d->ntaps > LOANS_MAX_TAPS) return LOANS_EINVAL;
     const bool dense = d->flags & LOANS_F_DENSE;
+    if (!dense && d->ntaps > 32) return LOANS_EINVAL;       // the kernel keeps one 32-bit tap mask per tile row
     if (dense) {
         // no bounds masks in this mode: every K-row of every grid pixel has to lie inside its input row; rows and row
         // steps must keep the 16-byte loads 4-byte aligned (even element counts)
