@@ -590,7 +590,14 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const Wgrad16Args a) {
     const int total_chunks = (a.M + WPC - 1) / WPC;
     if (c_end > total_chunks) c_end = total_chunks;
 
+    // Per staged row: its pixel (b, y, x) for the bounds checks, and the two BYTE offsets the loads use, kept incrementally.
+    // The gradient is read at grid pixel m itself (the launcher admits only the forward geometry: out row = grid pixel),
+    // so its offset just advances by WPC pixels; the input offset advances by WPC pixel steps plus a row / image
+    // correction per wrap.  (Recomputing both from (b, y, x) cost twelve 32-bit multiplies per row and chunk -- quarter
+    // rate -- and made the loop VALU-bound: 294 vector instructions beside 32 MFMAs.)
     int pb[NP], py[NP], px[NP];
+    unsigned glin[NP], xlin[NP];
+    const int xconst = ((dy * d.inW + dx) * ucin + xc8 * 8) * 2;        // this thread's tap / channel offset (may be < 0)
     {
         const int gHW = d.gridH * d.gridW;
 #pragma unroll
@@ -600,9 +607,15 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const Wgrad16Args a) {
             const int rem = m - pb[p] * gHW;
             py[p] = rem / d.gridW;
             px[p] = rem - py[p] * d.gridW;
+            glin[p] = (unsigned)(m * d.Cout + yco) * 2u;
+            xlin[p] = (unsigned)(((pb[p] * d.inH + py[p] * d.isy) * d.inW + px[p] * d.isx) * ucin) * 2u + (unsigned)xconst;
         }
     }
     const float inv_gw = 1.f / (float)d.gridW, inv_gh = 1.f / (float)d.gridH;
+    const unsigned g_step = (unsigned)(WPC * d.Cout) * 2u;
+    const int x_step = WPC * d.isx * ucin * 2;
+    const int x_row = (d.isy * d.inW - d.isx * d.gridW) * ucin * 2;          // per wrapped grid row   (|.| < 2^23: checked)
+    const int x_img = (d.inH - d.isy * d.gridH) * d.inW * ucin * 2;          // per wrapped image
 
     // A chunk's compute (a few hundred MFMA cycles) is far shorter than a global load's latency, so the loads run
     // WDEPTH - 1 chunks ahead through a ring of register sets (chunk c in set c % WDEPTH); the wait in front of a
@@ -614,21 +627,22 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const Wgrad16Args a) {
     auto load_row = [&](int k, int p) {
         const int b = pb[p], y = py[p], x = px[p];
         const bool rv = (b < d.B) & (lc < c_end);
-        const int pix = (b * d.outH + y * d.osy + d.oy0) * d.outW + x * d.osx + d.ox0;
-        const unsigned goff = ((unsigned)(pix * d.Cout + yco) * 2u) | ((unsigned)(rv & yv) - 1u);
+        const unsigned goff = glin[p] | ((unsigned)(rv & yv) - 1u);
         ry[k][p] = __builtin_amdgcn_raw_buffer_load_b128(rs_g, (int)goff, 0, 0);
-        const int iy = y * d.isy + dy, ix = x * d.isx + dx;
+        const int iy = __mul24(y, d.isy) + dy, ix = __mul24(x, d.isx) + dx;
         const unsigned ok = (unsigned)(rv & xtv) & (unsigned)((unsigned)iy < (unsigned)d.inH) &
                             (unsigned)((unsigned)ix < (unsigned)d.inW);
-        const unsigned xoff = ((unsigned)(((b * d.inH + iy) * d.inW + ix) * ucin + xc8 * 8) * 2u) | (ok - 1u);
+        const unsigned xoff = xlin[p] | (ok - 1u);
         rx[k][p] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)xoff, 0, 0);
         int nx = x + WPC;                       // advance one chunk: exact floor((v + .5) / n) for these small integers
         const int qx = (int)(((float)nx + 0.5f) * inv_gw);
-        nx -= qx * d.gridW;
+        nx -= __mul24(qx, d.gridW);
         int ny = y + qx;
         const int qy = (int)(((float)ny + 0.5f) * inv_gh);
-        ny -= qy * d.gridH;
+        ny -= __mul24(qy, d.gridH);
         px[p] = nx; py[p] = ny; pb[p] = b + qy;
+        glin[p] += g_step;
+        xlin[p] += (unsigned)(x_step + __mul24(qx, x_row) + __mul24(qy, x_img));
     };
     auto load_chunk = [&](int k) {
 #pragma unroll
@@ -848,6 +862,16 @@ extern "C" int loans_wgrad_bf16s(const void* x, const void* gy, float* dw, const
     if ((d->gridH - 1) * d->osy + d->oy0 >= d->outH) return LOANS_EINVAL;
     if ((d->gridW - 1) * d->osx + d->ox0 >= d->outW) return LOANS_EINVAL;
     if (d->ntaps < 1 || d->ntaps > LOANS_MAX_TAPS) return LOANS_EINVAL;
+    // the kernel reads the gradient at grid pixel m itself and keeps the input offset incrementally with 24-bit multiplies
+    if (d->osy != 1 || d->osx != 1 || d->oy0 || d->ox0 || d->outH != d->gridH || d->outW != d->gridW) return LOANS_EINVAL;
+    {
+        const int64_t uc = (d->flags & LOANS_F_DENSE) ? 1 : d->Cin;
+        const int64_t xr = ((int64_t)d->isy * d->inW - (int64_t)d->isx * d->gridW) * uc * 2;
+        const int64_t xi = ((int64_t)d->inH - (int64_t)d->isy * d->gridH) * d->inW * uc * 2;
+        const int64_t lim24 = (int64_t)1 << 23;
+        if (xr <= -lim24 || xr >= lim24 || xi <= -lim24 || xi >= lim24) return LOANS_ERANGE;
+        if (d->gridW >= lim24 || d->gridH >= lim24) return LOANS_ERANGE;
+    }
     const bool dense = d->flags & LOANS_F_DENSE;
     if (dense) {            // as in loans_igemm_bf16s
         if ((d->inW & 1) || (d->isx & 1)) return LOANS_EINVAL;
