@@ -83,6 +83,10 @@ typedef struct loans_igemm_desc {
 #define LOANS_TILE_64x128  5   /* wgrad only: 64 output channels x 128 tap-channel columns */
 #define LOANS_TILE_SPLIT   6   /* igemm only: 128x128 tiles over the rows that fill whole machine rounds, 64x64 over the rest (two launches) */
 #define LOANS_TILE_256x128 7   /* loans_igemm_bf16s only */
+#define LOANS_TILE_FINETAIL 8  /* loans_igemm_f32, forward geometry (out row = grid pixel), flags BIAS / STATS / RELU_IN / DENSE only:
+                                  64x64 tiles; the tiles that share out evenly over the CUs at full K, the remaining ones (fewer than
+                                  one per CU) as K-slices behind them in the same launch (raw partial tiles added with atomics to rows
+                                  zeroed here, then loans_igemm_finalize_f32 over those rows).  Plain 64x64 when nothing is left over. */
 #define LOANS_TILE_SPLITK(s) ((s) << 8) /* loans_igemm_f32, OR-ed onto a tile shape, s = 2..255: split-K for small grids (few tiles, long K:
                                   the deep layers at small batch, single-image inference).  Block (tile, i) contracts every s-th
                                   part of K and ADDS its raw partial tile to `out` with fp32 atomics: the caller zero-fills `out`

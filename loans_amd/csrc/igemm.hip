@@ -65,6 +65,8 @@ struct IgemmArgs {
     int Cout2, tiles_n2;
     unsigned w2_bytes, out2_bytes;
     int splits, chunks_per_split;   // split-K (LOANS_TILE_SPLITK): block (tile, s) contracts chunks [s * cps, (s + 1) * cps) and ADDS its tile
+    int n_full, tail_splits;        // LOANS_TILE_FINETAIL (n_full > 0): the first n_full tiles at full K with the normal epilogue, the
+                                    // tiles behind them in tail_splits K-slices each (raw partial tiles, like split-K)
     int m_begin;        // first GEMM row of this launch (LOANS_TILE_SPLIT runs a row range per tile shape); rows end at M
     int tail_groups;    // 8-deep k groups of the last chunk that hold any real K (1..4)
     int bf16;           // 1: round the operands to bf16 and use the bf16 MFMA (fp32 accumulate)
@@ -132,7 +134,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     // prologue and epilogue run at raised wave priority: their scalar / vector bookkeeping then is not queued behind the
     // MFMA streams of the co-resident blocks (+1.5 % on the short-K stem / res2 tiles, neutral elsewhere)
     __builtin_amdgcn_s_setprio(3);
-    const int logical = xcd_remap(blockIdx.x, gridDim.x);
+    // mixed grid (LOANS_TILE_FINETAIL): blocks [0, n_full) are whole tiles in XCD order, the blocks behind them K-slices of
+    // the remaining tiles, again in XCD order among themselves -- dispatched last, they even out the CUs' finish times
+    const bool fine = a.n_full > 0;
+    const bool fine_tail = fine && (int)blockIdx.x >= a.n_full;
+    const int logical = !fine ? xcd_remap(blockIdx.x, gridDim.x)
+                              : (fine_tail ? xcd_remap(blockIdx.x - a.n_full, gridDim.x - a.n_full) : xcd_remap(blockIdx.x, a.n_full));
+    const int my_splits = fine ? (fine_tail ? a.tail_splits : 1) : a.splits;
     // pair launch: the blocks behind the first convolution's tiles belong to the second one (block-uniform selection)
     const bool second = a.w2 != nullptr && logical >= a.tiles_m * a.tiles_n;
     const int Cout = second ? a.Cout2 : d.Cout;
@@ -143,12 +151,18 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     const unsigned w_bytes = second ? a.w2_bytes : a.w_bytes, out_bytes = second ? a.out2_bytes : a.out_bytes;
     const int lfirst = second ? logical - a.tiles_m * a.tiles_n : logical;
     const int ntile = a.tiles_m * tiles_n;
-    const int split = a.w2 ? 0 : lfirst / ntile;        // 0 unless split-K
-    const int ltile = lfirst - split * ntile;
+    int split = a.w2 ? 0 : lfirst / ntile;              // 0 unless split-K
+    int ltile = lfirst - split * ntile;
+    if (fine) {
+        const int n_tail = ntile - a.n_full;
+        split = fine_tail ? logical / n_tail : 0;
+        ltile = fine_tail ? a.n_full + (logical - split * n_tail) : logical;
+    }
     const int tn = ltile % tiles_n;
     const int tm = ltile / tiles_n;
-    const int c_begin = split * a.chunks_per_split;     // this block's K chunks
-    const int c_end = min(c_begin + a.chunks_per_split, a.nchunks);
+    const int cps = (fine && !fine_tail) ? a.nchunks : a.chunks_per_split;
+    const int c_begin = split * cps;                    // this block's K chunks
+    const int c_end = min(c_begin + cps, a.nchunks);
     const int nch = c_end - c_begin;
     const int tail_groups = c_end == a.nchunks ? a.tail_groups : 4;
     const int lrow = tid >> 3;
@@ -580,7 +594,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     float* Cs = reinterpret_cast<float*>(smem);          // [BM][LDC]
     __builtin_amdgcn_s_setprio(3);
     __syncthreads();                                     // every wave is done with the fragment buffers
-    if (f_stats && a.splits == 1) {
+    if (f_stats && my_splits == 1) {
         int nvalid = 0;
 #pragma unroll
         for (int i = 0; i < TM; ++i)
@@ -637,7 +651,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     const unsigned coff = (unsigned)col0 * (f_out16 ? 2u : 4u);
     f32x4 bv4 = {0.f, 0.f, 0.f, 0.f};
     if (f_bias && !cbad) bv4 = *reinterpret_cast<const f32x4*>(a.bias + col0);
-    if (a.splits > 1) {
+    if (my_splits > 1) {
         // split-K: the raw partial tile is added to `out` (zeroed, or holding the addend, by the caller); bias, statistics,
         // mask and addend are applied to the finished sums by loans_igemm_finalize_f32
 #pragma unroll
@@ -724,7 +738,13 @@ int launch_igemm_r(IgemmArgs& a, hipStream_t st) {
     if (a.splits > a.nchunks) a.splits = a.nchunks;
     a.chunks_per_split = (a.nchunks + a.splits - 1) / a.splits;
     a.splits = (a.nchunks + a.chunks_per_split - 1) / a.chunks_per_split;
-    const int nblk = a.w2 ? a.tiles_m * (a.tiles_n + a.tiles_n2) : a.tiles_m * a.tiles_n * a.splits;
+    int nblk = a.w2 ? a.tiles_m * (a.tiles_n + a.tiles_n2) : a.tiles_m * a.tiles_n * a.splits;
+    if (a.n_full > 0) {         // LOANS_TILE_FINETAIL: whole tiles, then K-slices of the rest (set up by igemm_impl)
+        if (a.w2 || a.splits != 1 || a.n_full >= a.tiles_m * a.tiles_n || a.tail_splits < 2) return LOANS_EINVAL;
+        a.chunks_per_split = (a.nchunks + a.tail_splits - 1) / a.tail_splits;
+        a.tail_splits = (a.nchunks + a.chunks_per_split - 1) / a.chunks_per_split;
+        nblk = a.n_full + (a.tiles_m * a.tiles_n - a.n_full) * a.tail_splits;
+    }
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, st, a);
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;
@@ -811,6 +831,7 @@ static int igemm_impl(const float* in, const float* w, float* out, const float* 
 #endif
     a.M = d->B * d->gridH * d->gridW;
     a.m_begin = 0;
+    a.n_full = 0; a.tail_splits = 1;
     a.Ktot = d->ntaps * d->Cin;
     a.nchunks = (a.Ktot + BK - 1) / BK;
     a.tail_groups = (a.Ktot - (a.nchunks - 1) * BK + 7) / 8;
@@ -874,6 +895,43 @@ static int igemm_impl(const float* in, const float* w, float* out, const float* 
         if (rows_big == a.M) return LOANS_OK;
         a.m_begin = rows_big;
         return launch_igemm<64, 64, 2, 2>(a, st);
+    }
+    if (tile == LOANS_TILE_FINETAIL) {
+        // 64x64 tiles; as many whole tiles as share out evenly over the CUs run at full K, the remaining ones (< one per CU)
+        // are cut into K-slices behind them in the SAME launch, so that every CU ends with a small unit instead of some CUs
+        // with a whole extra tile (res5 at B = 256: 1568 tiles on 256 CUs = 6.125 each -> 6 + 32 tiles x 8 slices).  The
+        // sliced tiles' rows are zeroed here, receive raw partial sums and get bias / statistics from the finalize pass.
+        if (pair || bf16 || a.splits > 1) return LOANS_EINVAL;
+        if (d->flags & (LOANS_F_MASK | LOANS_F_ADDEND | LOANS_F_ADDEND_MASK | LOANS_F_OUT_BF16)) return LOANS_EINVAL;
+        if (d->osy != 1 || d->osx != 1 || d->oy0 || d->ox0 || d->outH != d->gridH || d->outW != d->gridW) return LOANS_EINVAL;
+        const int c4 = d->Cout / 4;
+        if ((d->Cout & 3) || !(c4 <= 256 ? (256 % c4 == 0) : (c4 % 256 == 0))) return LOANS_EINVAL;   // finalize's thread map
+        static int cus = 0;
+        if (!cus) {
+            int dev = 0;
+            hipDeviceProp_t prop;
+            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return LOANS_EINVAL;
+            cus = prop.multiProcessorCount;
+        }
+        const int tiles_n = (d->Cout + 63) / 64, tiles_m = (a.M + 63) / 64;
+        const int ntile = tiles_m * tiles_n;
+        int n_full = ntile / cus * cus;
+        n_full -= n_full % tiles_n;                         // the sliced tiles are whole tile rows: contiguous output rows
+        const int n_tail = ntile - n_full;
+        int sl = n_tail > 0 ? cus / n_tail : 0;
+        if (sl > 16) sl = 16;
+        while (sl > 1 && a.nchunks / sl < 4) --sl;
+        if (n_full <= 0 || n_tail <= 0 || sl < 2) return launch_igemm<64, 64, 2, 2>(a, st);      // nothing to even out
+        const int rows_head = n_full / tiles_n * 64;
+        const int tail_rows = a.M - rows_head;
+        float* tail_out = out + (int64_t)rows_head * d->Cout;
+        if (hipMemsetAsync(tail_out, 0, (size_t)tail_rows * d->Cout * sizeof(float), st) != hipSuccess) return LOANS_EINVAL;
+        a.n_full = n_full;
+        a.tail_splits = sl;
+        rc = launch_igemm<64, 64, 2, 2>(a, st);
+        if (rc) return rc;
+        const int fin = d->flags & (LOANS_F_BIAS | LOANS_F_STATS);
+        return fin ? loans_igemm_finalize_f32(tail_out, bias, stats, nullptr, nullptr, fin, tail_rows, d->Cout, stream) : LOANS_OK;
     }
     switch (tile) {
         case LOANS_TILE_128x128: return launch_igemm<128, 128, 2, 2>(a, st);

@@ -308,9 +308,32 @@ def _igemm_splitk(lib, fn_in, w, out, d_list, flags, tile, bias, stats, ref, add
                                            fin, rows, Cout, st), 'loans_igemm_finalize_f32')
 
 
-def _igemm_launches(M, Cout, tile, device):
-    """Kernel launches behind one loans_igemm call: LOANS_TILE_SPLIT is two when both row ranges are non-empty
+TILE_FINETAIL = 8       # LOANS_TILE_FINETAIL (+16 = LDS-DMA): whole 64x64 tiles, then K-slices of the uneven rest in the same launch
+FINETAIL = os.environ.get('LOANS_FINETAIL', '1') != '0'
+
+
+def _finetail_plan(M, Cout, nchunks, device):
+    """(rows computed at full K, K slices of the remaining tiles) of LOANS_TILE_FINETAIL -- the arithmetic of igemm_impl"""
+    cus = torch.cuda.get_device_properties(device).multi_processor_count
+    tiles_n = (Cout + 63) // 64
+    ntile = ((M + 63) // 64) * tiles_n
+    n_full = ntile // cus * cus
+    n_full -= n_full % tiles_n
+    n_tail = ntile - n_full
+    sl = min(16, cus // n_tail) if n_tail > 0 else 0
+    while sl > 1 and nchunks // sl < 4:
+        sl -= 1
+    if n_full <= 0 or n_tail <= 0 or sl < 2:
+        return M, 1
+    return n_full // tiles_n * 64, sl
+
+
+def _igemm_launches(M, Cout, tile, device, nchunks=0):
+    """Kernel launches behind one loans_igemm call: LOANS_TILE_SPLIT is two when both row ranges are non-empty,
+    LOANS_TILE_FINETAIL two (the convolution and the finalize pass over the sliced rows) when it slices
     (same arithmetic as igemm_impl)."""
+    if (tile & 15) == TILE_FINETAIL:
+        return 2 if _finetail_plan(M, Cout, nchunks, device)[1] > 1 else 1
     if (tile & 15) != 6:
         return 1
     slots = 2 * torch.cuda.get_device_properties(device).multi_processor_count
@@ -346,10 +369,15 @@ def conv_fprop(x, w, geo, out=None, bias=None, stats=None, relu_in=False, addend
             check(_igemm_fn(lib)(_ptr(x), _ptr(w), _ptr(scratch), 0, _ptr(sstats), 0, 0,
                                       C.byref(_with_flags(geo.fwd, tflags, t)), _stream()), 'loans_igemm_f32[tune]')
         M_ = geo.B * geo.Ho * geo.Wo
-        sk = () if (out_bf16 or not reduce_channels_ok(geo.Cout)) else \
-            _splitk_candidates(M_, geo.Cout, (geo.w_numel // geo.Cout + 31) // 32)
-        tile = _tuned_tile(geo, COMPUTE + 'fprop' + ('_stats' if stats is not None else '') + ('_sk' if sk else ''), run,
-                           _FPROP_TILES + sk)   # fp32 scratch output: the tile choice carries over
+        nch = (geo.w_numel // geo.Cout + 31) // 32
+        sk = () if (out_bf16 or not reduce_channels_ok(geo.Cout)) else _splitk_candidates(M_, geo.Cout, nch)
+        # LOANS_TILE_FINETAIL slices its last tiles along K (atomics): offered under the same switch as split-K
+        ft = ()
+        if SPLITK and FINETAIL and COMPUTE == 'f32' and not out_bf16 and addend is None and reduce_channels_ok(geo.Cout) \
+                and _finetail_plan(M_, geo.Cout, nch, x.device)[1] > 1:
+            ft = (TILE_FINETAIL, TILE_FINETAIL | 16)
+        tile = _tuned_tile(geo, COMPUTE + 'fprop' + ('_stats' if stats is not None else '') + ('_sk' if sk else '') +
+                           ('_ft' if ft else ''), run, _FPROP_TILES + sk + ft)   # fp32 scratch output: the tile choice carries over
     d = _with_flags(geo.fwd, flags, tile)
     _count_flops('fprop', geo)
     log = EVENT_LOG
@@ -367,7 +395,8 @@ def conv_fprop(x, w, geo, out=None, bias=None, stats=None, relu_in=False, addend
         # algorithmic FLOPs: logical input channels (3 for the RGB stem), no padding, no im2col redundancy
         log.append(('fprop_bn' if stats is not None else 'fprop',
                     2 * geo.B * geo.Ho * geo.Wo * geo.Cout * geo.k * geo.k * geo.cin_logical, ev0, ev1,
-                    _igemm_launches(geo.B * geo.Ho * geo.Wo, geo.Cout, tile, x.device)))
+                    _igemm_launches(geo.B * geo.Ho * geo.Wo, geo.Cout, tile, x.device,
+                                    (geo.w_numel // geo.Cout + 31) // 32)))
     return out
 
 
@@ -378,7 +407,7 @@ def fprop_pair_ok(x, geo_a, geo_b):
             (geo_b.B, geo_b.H, geo_b.W, geo_b.Cin, geo_b.k, geo_b.stride, geo_b.pad))
 
 
-_PAIR_TILES = tuple(t for t in _FPROP_TILES if (t & 15) != 6)
+_PAIR_TILES = tuple(t for t in _FPROP_TILES if (t & 15) not in (6, 8))
 
 
 def conv_fprop_pair(x, w_a, w_b, geo_a, geo_b, stats_a=None, stats_b=None, tile=0):

@@ -147,6 +147,38 @@ def test_conv_split_tile():
     assert rel_err(_nchw(gx), gx_ref * (ref_t > 0)) < 2e-6
 
 
+@pytest.mark.parametrize("case", [(40, 32, 29, 29, 128, 3, 1, 1, 0), (37, 256, 31, 31, 128, 1, 1, 0, 1), (66, 64, 56, 56, 128, 3, 2, 1, 0)])
+def test_conv_fine_tail_tile(case):
+    """LOANS_TILE_FINETAIL: the 64x64 tiles that share out evenly over the CUs at full K, the rest as K-slices behind them in
+    the same launch (atomics into rows zeroed by the launcher) + loans_igemm_finalize_f32 over those rows; against the
+    oracle convolution and the plain 64x64 tile, with bias / BN statistics / relu(in)"""
+    from loans_amd import ops
+    B, Cin, H, W, Cout, k, s, p, relu_in = case
+    rng = np.random.RandomState(13)
+    x = rng.standard_normal((B, Cin, H, W)).astype(np.float32)
+    w = (rng.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
+    bias = rng.standard_normal(Cout).astype(np.float32)
+    geo = ops.ConvGeometry(B, H, W, Cin, Cout, k, s, p)
+    M_, nch = B * geo.Ho * geo.Wo, (k * k * Cin + 31) // 32
+    rows_head, slices = ops._finetail_plan(M_, Cout, nch, torch.device('cuda', 0))
+    assert 0 < rows_head < M_ and slices >= 2, 'the case must take the sliced path on this machine'
+    xin = np.maximum(x, 0) if relu_in else x
+    y_ref, _ = C.conv2d_fwd(xin.astype(np.float64), w.astype(np.float64), bias.astype(np.float64), s, p)
+    xd, wd, bd = dev(_nhwc(x)), dev(_ohwi(w)), dev(bias)
+    y3 = ops.conv_fprop(xd, wd, geo, bias=bd, relu_in=bool(relu_in), tile=3)
+    nimg = rows_head // (geo.Ho * geo.Wo)
+    for tile in (ops.TILE_FINETAIL, ops.TILE_FINETAIL | 16):
+        st = ops.stats_buffer(Cout, 'cuda')
+        y = ops.conv_fprop(xd, wd, geo, bias=bd, stats=st, relu_in=bool(relu_in), tile=tile)
+        assert rel_err(_nchw(y), y_ref) < 2e-6, tile
+        assert torch.equal(y[:nimg], y3[:nimg])               # full-K tiles: the plain kernel's arithmetic
+        assert torch.allclose(y, y3, rtol=1e-5, atol=1e-5)
+        stats = st.sum(dim=0)
+        np.testing.assert_allclose(stats[0].cpu().numpy(), y_ref.sum(axis=(0, 2, 3)), rtol=1e-5, atol=1e-2)
+        np.testing.assert_allclose(stats[1].cpu().numpy(), (y_ref ** 2).sum(axis=(0, 2, 3)), rtol=1e-5)
+    assert ops._igemm_launches(M_, Cout, ops.TILE_FINETAIL, torch.device('cuda', 0), nch) == 2
+
+
 @pytest.mark.parametrize("case", [(2, 64, 14, 14, 64, 3, 1, 1), (2, 64, 15, 13, 128, 3, 2, 1), (3, 256, 7, 7, 64, 1, 1, 0),
                                   (1, 128, 9, 9, 128, 4, 2, 1)])
 @pytest.mark.parametrize("splits", [2, 4, 16])
