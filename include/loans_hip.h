@@ -87,6 +87,10 @@ typedef struct loans_igemm_desc {
                                   64x64 tiles; the tiles that share out evenly over the CUs at full K, the remaining ones (fewer than
                                   one per CU) as K-slices behind them in the same launch (raw partial tiles added with atomics to rows
                                   zeroed here, then loans_igemm_finalize_f32 over those rows).  Plain 64x64 when nothing is left over. */
+#define LOANS_TILE_STEM    10   /* loans_igemm_f32 with LOANS_F_DENSE, the 7x7 / 2, Cout = 64 forward geometry, flags BIAS / STATS: direct
+                                  convolution -- a block stages the input rows of R output rows and the whole weight matrix in LDS
+                                  once and feeds the fp32 MFMA from that image (stem.hip); LOANS_EINVAL for frame sizes it does not
+                                  cover (R * Wo must be a multiple of 64 for an R in {4, 2, 1} dividing Ho, <= 448 pixels, <= 80 KB) */
 #define LOANS_TILE_SPLITK(s) ((s) << 8) /* loans_igemm_f32, OR-ed onto a tile shape, s = 2..255: split-K for small grids (few tiles, long K:
                                   the deep layers at small batch, single-image inference).  Block (tile, i) contracts every s-th
                                   part of K and ADDS its raw partial tile to `out` with fp32 atomics: the caller zero-fills `out`

@@ -54,3 +54,8 @@ static inline int grid_for(int64_t work_items, int block, int max_blocks = 256 *
     if (g > max_blocks) g = max_blocks;
     return (int)g;
 }
+
+// stem.hip: the direct 7x7 / 2 RGB stem convolution behind LOANS_TILE_STEM (internal; reached through loans_igemm_f32)
+int loans_stem7_rows(int Ho, int Wo, int Wp3, size_t* lds_bytes);
+int loans_stem7_launch(const float* in, const float* w, float* out, const float* bias, double* stats,
+                       const loans_igemm_desc* d, hipStream_t st);

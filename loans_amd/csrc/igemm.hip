@@ -896,6 +896,10 @@ static int igemm_impl(const float* in, const float* w, float* out, const float* 
         a.m_begin = rows_big;
         return launch_igemm<64, 64, 2, 2>(a, st);
     }
+    if (tile == LOANS_TILE_STEM) {          // the dense RGB stem as a direct convolution (stem.hip)
+        if (pair || bf16 || a.splits > 1 || a.dma) return LOANS_EINVAL;
+        return loans_stem7_launch(in, w, out, bias, stats, d, st);
+    }
     if (tile == LOANS_TILE_FINETAIL) {
         // 64x64 tiles; as many whole tiles as share out evenly over the CUs run at full K, the remaining ones (< one per CU)
         // are cut into K-slices behind them in the SAME launch, so that every CU ends with a small unit instead of some CUs

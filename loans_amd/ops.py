@@ -308,8 +308,28 @@ def _igemm_splitk(lib, fn_in, w, out, d_list, flags, tile, bias, stats, ref, add
                                            fin, rows, Cout, st), 'loans_igemm_finalize_f32')
 
 
+TILE_STEM = 10          # LOANS_TILE_STEM: the dense RGB stem as a direct convolution (csrc/stem.hip)
+
+
+def stem_tile_rows(geo):
+    """output rows per block of LOANS_TILE_STEM for this geometry, 0 = not covered (loans_stem7_rows of csrc/stem.hip)"""
+    if not (geo.dense and geo.k == 7 and geo.stride == 2 and geo.pad == 3 and geo.Cout == 64):
+        return 0
+    wp3 = geo.Wp * 3
+    if 2 * geo.Ho + 5 > geo.Hp or geo.Hp % 2:
+        return 0
+    for R in (4, 2, 1):
+        if geo.Ho % R or (R * geo.Wo) % 64 or R * geo.Wo // 32 > 14:
+            continue
+        if ((2 * R + 5) * wp3 + 154 * 65) * 4 > 80 * 1024:
+            continue
+        return R
+    return 0
+
+
 TILE_FINETAIL = 8       # LOANS_TILE_FINETAIL (+16 = LDS-DMA): whole 64x64 tiles, then K-slices of the uneven rest in the same launch
 FINETAIL = os.environ.get('LOANS_FINETAIL', '1') != '0'
+STEM_DIRECT = os.environ.get('LOANS_STEM_DIRECT', '1') != '0'
 
 
 def _finetail_plan(M, Cout, nchunks, device):
@@ -376,8 +396,11 @@ def conv_fprop(x, w, geo, out=None, bias=None, stats=None, relu_in=False, addend
         if SPLITK and FINETAIL and COMPUTE == 'f32' and not out_bf16 and addend is None and reduce_channels_ok(geo.Cout) \
                 and _finetail_plan(M_, geo.Cout, nch, x.device)[1] > 1:
             ft = (TILE_FINETAIL, TILE_FINETAIL | 16)
+        stem = (TILE_STEM,) if (STEM_DIRECT and COMPUTE == 'f32' and not out_bf16 and not relu_in and addend is None
+                                and stem_tile_rows(geo)) else ()
         tile = _tuned_tile(geo, COMPUTE + 'fprop' + ('_stats' if stats is not None else '') + ('_sk' if sk else '') +
-                           ('_ft' if ft else ''), run, _FPROP_TILES + sk + ft)   # fp32 scratch output: the tile choice carries over
+                           ('_ft' if ft else '') + ('_st' if stem else ''), run,
+                           _FPROP_TILES + sk + ft + stem)   # fp32 scratch output: the tile choice carries over
     d = _with_flags(geo.fwd, flags, tile)
     _count_flops('fprop', geo)
     log = EVENT_LOG
@@ -407,7 +430,7 @@ def fprop_pair_ok(x, geo_a, geo_b):
             (geo_b.B, geo_b.H, geo_b.W, geo_b.Cin, geo_b.k, geo_b.stride, geo_b.pad))
 
 
-_PAIR_TILES = tuple(t for t in _FPROP_TILES if (t & 15) not in (6, 8))
+_PAIR_TILES = tuple(t for t in _FPROP_TILES if (t & 15) not in (6, 8, 10))
 
 
 def conv_fprop_pair(x, w_a, w_b, geo_a, geo_b, stats_a=None, stats_b=None, tile=0):

@@ -299,6 +299,42 @@ def test_conv_dense_rows(case, tile):
         assert not got[:, :, k:].any()          # window-padding columns carry no gradient
 
 
+@pytest.mark.parametrize("case", [(2, 224, 224), (3, 64, 64), (2, 32, 32), (1, 128, 128), (2, 64, 96), (1, 256, 64)])
+def test_conv_stem_direct(case):
+    """LOANS_TILE_STEM (csrc/stem.hip): conv1 7x7 / 2, 3 -> 64 with bias and BN statistics as a direct convolution from an
+    LDS-staged image, against the oracle convolution and the implicit-GEMM dense-row kernel; frame sizes with 1 ... 7
+    pixel tiles per wave"""
+    from loans_amd import ops
+    B, H, W = case
+    rng = np.random.RandomState(H + W)
+    x = rng.standard_normal((B, 3, H, W)).astype(np.float32)
+    w = (rng.standard_normal((64, 3, 7, 7)) / np.sqrt(147)).astype(np.float32)
+    b = rng.standard_normal(64).astype(np.float32)
+    geo = ops.ConvGeometry(B, H, W, 3, 64, 7, 2, 3, dense=True)
+    assert ops.stem_tile_rows(geo) > 0
+    xp = np.zeros((B, geo.Hp, geo.Wp, 3), np.float32)
+    xp[:, 3:3 + H, 3:3 + W] = x.transpose(0, 2, 3, 1)
+    wp = np.zeros((64, 7, geo.kwp, 3), np.float32)
+    wp[:, :, :7] = w.transpose(0, 2, 3, 1)
+    xd, wd, bd = dev(xp), dev(wp), dev(b)
+    y_ref, _ = C.conv2d_fwd(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64), 2, 3)
+    st, st3 = ops.stats_buffer(64, 'cuda'), ops.stats_buffer(64, 'cuda')
+    y = ops.conv_fprop(xd, wd, geo, bias=bd, stats=st, tile=ops.TILE_STEM)
+    y3 = ops.conv_fprop(xd, wd, geo, bias=bd, stats=st3, tile=3)
+    assert rel_err(_nchw(y), y_ref) < 2e-6
+    assert torch.allclose(y, y3, rtol=1e-5, atol=1e-5)
+    stats = st.sum(dim=0)
+    np.testing.assert_allclose(stats[0].cpu().numpy(), y_ref.sum(axis=(0, 2, 3)), rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(stats[1].cpu().numpy(), (y_ref ** 2).sum(axis=(0, 2, 3)), rtol=1e-5)
+    y_nb = ops.conv_fprop(xd, wd, geo, tile=ops.TILE_STEM)                    # no bias, no statistics
+    assert torch.allclose(y_nb, y - bd, rtol=1e-5, atol=1e-5)
+    # sizes the kernel does not cover are refused (the autotuner never offers it there)
+    odd = ops.ConvGeometry(1, 17, 23, 3, 64, 7, 2, 3, dense=True)
+    assert ops.stem_tile_rows(odd) == 0
+    with pytest.raises(RuntimeError):
+        ops.conv_fprop(torch.zeros((1, odd.Hp, odd.Wp, 3), device='cuda'), wd, odd, tile=ops.TILE_STEM)
+
+
 @pytest.mark.parametrize("C_", [64, 128, 512, 2048])
 def test_bn_forward_backward(C_):
     from loans_amd import ops
