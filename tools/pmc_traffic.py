@@ -18,7 +18,7 @@ def conv_fwd_sum(path, counter):
     prep = [i for i, r in enumerate(rows) if 'prep_' in r['Kernel_Name']]
     seg = rows[prep[-2]:prep[-1]]
     gap = next(i for i, r in enumerate(seg) if 'gap_fwd_kernel' in r['Kernel_Name'])      # end of the backbone forward
-    fwd = [r for r in seg[:gap] if 'igemm' in r['Kernel_Name']]      # 21 convs; a LOANS_TILE_SPLIT conv is two launches
+    fwd = [r for r in seg[:gap] if 'igemm' in r['Kernel_Name'] or 'stem7' in r['Kernel_Name']]      # 21 convs; a LOANS_TILE_SPLIT conv is two launches
     assert len(fwd) >= 17          # 21 convs; BasicA pairs are one launch, a LOANS_TILE_SPLIT conv is two
     return sum(float(r['Counter_Value']) for r in fwd) * 1024.0, len(fwd)
 
