@@ -24,11 +24,27 @@ import os
 import sys
 import time
 
-import numpy as np
-import torch
-
 ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
+
+
+def _load_launcher():
+    """loans_amd/launch.py by path: importing the package would pull in torch, and the parent of an N-GPU run must stay a
+    plain process that never touches the GPU."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('_loans_launch', os.path.join(ROOT, 'loans_amd', 'launch.py'))
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    return mod
+
+
+if __name__ == '__main__':
+    # `python bench.py --gpus N` (N > 1) outside a launcher: fork the N ranks (python -m torch.distributed.run ... bench.py
+    # <same args>) as a child, relay its output -- rank 0's single JSON line -- and exit with its code.  Does not return then.
+    _load_launcher().launch_if_parent(os.path.abspath(__file__))
+
+import numpy as np          # noqa: E402
+import torch                # noqa: E402
 
 CONV_FWD_FLOP_PER_IMAGE_224 = 4166615040        # SURVEY §8d: 21 conv contractions, 2 FLOP per MAC
 FP32_MFMA_PEAK_TFLOPS = 157.3                   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
@@ -50,6 +66,12 @@ def parse():
                     help="storage of the localizer's stage activations / gradients (default: bf16 with --dtype bf16, else f32)")
     ap.add_argument('--graph', action='store_true', help='capture the step into a hipGraph after warm-up (small, launch-bound batches)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--tune-file', default=None,
+                    help="kernel-tile table: read if the file exists (the run then launches exactly those tiles -- use for the "
+                         "rocprofv3 passes of a command), else written by rank 0 after the run")
+    ap.add_argument('--traffic-file', default=None,
+                    help="PMC traffic summary (tools/pmc_traffic.py) of THIS command for roofline.traffic; default: "
+                         "profiles/r2_conv_fwd_hbm_traffic.json for the default workload, r2_cfg3_... for configs[2]")
     ap.add_argument('--cpu-batch', type=int, default=8)
     ap.add_argument('--cpu-iters', type=int, default=2)
     return ap.parse_args()
@@ -83,20 +105,66 @@ def cpu_baseline(args, hw, crop):
             "s_per_step": round(t, 3)}
 
 
+def dry_run(args):
+    """LOANS_BENCH_DRY=1: the launcher / rendezvous / collective plumbing of an N-rank run WITHOUT the kernels, for hosts
+    with no GPU (tests/test_launch_cpu.py: `python bench.py --gpus 2` end to end over gloo).  A "step" all-reduces a
+    gradient-arena-sized buffer through the same Communicator the real step uses; the line it prints carries
+    value = null and says so in `data` -- it is never a measurement."""
+    from loans_amd import parallel
+    comm = parallel.init_from_env()
+    if comm.size != args.gpus:
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, comm.size))
+    if os.environ.get('LOANS_BENCH_DRY_FAIL_RANK') == str(comm.rank):
+        raise SystemExit(7)                                # the launcher must propagate a rank's failure
+
+    class Arena:
+        numel = 1 << 18
+        grad = torch.full((1 << 18,), float(comm.rank + 1))
+    arena = Arena()
+    for _ in range(args.warmup):
+        comm.allreduce_grad(arena)
+    comm.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        comm.allreduce_grad(arena)
+    comm.barrier()
+    elapsed = comm.allreduce_max(time.perf_counter() - t0)
+    expect = float(sum(range(1, comm.size + 1))) if comm.size > 1 else 1.0
+    total = expect
+    for _ in range(args.warmup + args.steps - 1):
+        total *= comm.size if comm.size > 1 else 1
+    assert comm.size == 1 or abs(float(arena.grad[0]) - total) <= 1e-6 * total, (float(arena.grad[0]), total)
+    if comm.rank == 0:
+        print(json.dumps({"metric": "localizer+assessor train images/sec", "value": None, "unit": "images/s",
+                          "n_gpus": comm.size, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(elapsed / args.steps * 1e3, 3), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": args.dtype,
+                          "data": "dry-run: launcher / rendezvous / gradient all-reduce plumbing only, no kernels, not a measurement",
+                          "config": {"workload": "dry-run", "world_size": comm.size, "dist_backend": comm.backend,
+                                     "parallelism": "dp%d" % comm.size}}), flush=True)
+    parallel.shutdown()
+
+
 def main():
     args = parse()
+    if os.environ.get('LOANS_BENCH_DRY') == '1':
+        return dry_run(args)
     import loans_amd
     from loans_amd import ops, parallel
     from loans_amd.datasets import synthetic
     from loans_amd.runtime import training
 
+    tune_loaded = 0
+    if args.tune_file and os.path.exists(args.tune_file):
+        tune_loaded = ops.load_tune_table(args.tune_file)
     ops.set_compute_dtype(args.dtype)
     storage = args.storage or ('bf16' if args.dtype == 'bf16' else 'f32')
     ops.set_storage_dtype(storage)
     comm = parallel.init_from_env()
     world, rank = comm.size, comm.rank
     if world != args.gpus:
-        raise SystemExit('--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run' % (args.gpus, world))
+        # `python bench.py --gpus N` forks its own ranks (top of this file); this is a rank started with a mismatching count
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
     local_rank = int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count()
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
@@ -170,6 +238,8 @@ def main():
     if rank != 0:
         parallel.shutdown()
         return
+    if args.tune_file and not tune_loaded:
+        ops.save_tune_table(args.tune_file)
     ms_per_step = elapsed / args.steps * 1e3
     value = B * world * args.steps / elapsed
 
@@ -193,12 +263,27 @@ def main():
                     "conv_fwd_ms_per_step_raw_brackets": round(raw_ms / args.steps, 3),
                     "event_pair_overhead_us": round(ev_overhead_ms * 1e3, 2),
                     "algorithmic_flop_per_step": tot_flop // args.steps}
+        roofline["launches_per_step"] = n_launch // args.steps
         # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE, separate
-        # rocprofv3 runs of this same command); only valid for the configuration they were taken on
-        tpath = os.path.join(ROOT, 'profiles', 'r1_conv_fwd_hbm_traffic.json')
-        if hw == 224 and B == 256 and world == 1 and not args.resnet50 and args.dtype == 'f32' and os.path.exists(tpath):
-            roofline["traffic"] = round(json.load(open(tpath))["total_bytes_per_step"] / (n_launch // args.steps))
-            roofline["traffic_unit"] = "bytes/launch (PMC: 2*FETCH_SIZE + WRITE_SIZE, profiles/r1_conv_fwd_hbm_traffic.json)"
+        # rocprofv3 runs of this same command on the SAME tile table, see --tune-file / tools/profile_round.sh).  The file
+        # carries the launch count of its own pass: bytes are divided by THAT, and a file whose pass launched other
+        # kernels than this run does not describe it -- traffic stays null then.
+        tpath = args.traffic_file
+        if tpath is None and world == 1 and not args.resnet50 and crop == 75:
+            if hw == 224 and B == 256 and args.dtype == 'f32':
+                tpath = os.path.join(ROOT, 'profiles', 'r2_conv_fwd_hbm_traffic.json')
+            elif hw == 512 and B == 128 and args.dtype == 'bf16' and storage == 'bf16':
+                tpath = os.path.join(ROOT, 'profiles', 'r2_cfg3_conv_fwd_hbm_traffic.json')
+        if tpath and os.path.exists(tpath):
+            tf = json.load(open(tpath))
+            if int(tf["launches"]) == n_launch // args.steps:
+                roofline["traffic"] = round(tf["total_bytes_per_step"] / tf["launches"])
+                roofline["traffic_unit"] = "HBM bytes/launch (PMC: 2*FETCH_SIZE + WRITE_SIZE over the %d conv-forward launches of " \
+                                           "one step, %s)" % (tf["launches"], os.path.relpath(tpath, ROOT))
+                roofline["traffic_bytes_per_step"] = round(tf["total_bytes_per_step"])
+            else:
+                roofline["traffic_note"] = "%s was taken on %d launches per step, this run has %d: not comparable" % (
+                    os.path.relpath(tpath, ROOT), tf["launches"], n_launch // args.steps)
         if hw == 224 and not args.resnet50:
             assert tot_flop // args.steps == B * CONV_FWD_FLOP_PER_IMAGE_224, (tot_flop // args.steps, B)
         # the whole step against the same peak: algorithmic FLOP of EVERY convolution launch (localizer and assessor;
@@ -227,9 +312,10 @@ def main():
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": "LoANs joint step: %s localizer + STN crop + assessor, fwd+bwd+2xAdam-AMSGrad" % backbone,
                    "per_gpu_batch": B, "global_batch": B * world, "frame": "3x%dx%d" % (hw, hw),
-                   "crop": "3x%dx%d" % (crop, crop), "parallelism": "dp%d" % world,
+                   "crop": "3x%dx%d" % (crop, crop), "parallelism": "dp%d" % world, "world_size": world, "dist_backend": comm.backend,
                    "baseline_config": cfg_label, "hip_graph": bool(args.graph), "init_steps": init_steps,
-                   "activation_storage": storage},
+                   "activation_storage": storage,
+                   "tune_table": ("read %d shapes from %s" % (tune_loaded, args.tune_file)) if tune_loaded else "autotuned in this run"},
         "roofline": roofline,
     }
     if world == 1 and not args.no_cpu_baseline and not args.resnet50 and args.dtype == 'f32':

@@ -17,7 +17,15 @@
  *   - never allocates, frees or synchronises; work is enqueued on `stream`
  *     (a hipStream_t passed as void*; NULL = the default stream);
  *   - caller owns every buffer (workspaces included) until the stream passes;
- *   - device = current HIP device of the calling thread; re-entrant.
+ *   - device = current HIP device of the calling thread; re-entrant and
+ *     thread-safe given distinct streams, for any number of devices per
+ *     process: the only state the launchers keep is per kernel AND per device
+ *     ordinal (the raised dynamic-LDS limit of a kernel, the device's CU
+ *     count), held in lock-free tables (csrc/common.h).  The only runtime
+ *     calls besides the launch are hipGetDevice (thread-local read) and, once
+ *     per (kernel, device), hipFuncSetAttribute / hipDeviceGetAttribute --
+ *     none is a stream operation and none blocks, so the first call of an
+ *     entry point may sit inside a hipGraph stream capture.
  *
  * Layouts: activations NHWC float32 with C a multiple of 4 (3-channel images
  * are carried as 4 channels, the 4th zero); conv weights "OHWI"

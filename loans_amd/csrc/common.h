@@ -32,6 +32,42 @@ template <> struct io4<__bf16> {
 
 static inline hipStream_t as_stream(void* s) { return reinterpret_cast<hipStream_t>(s); }
 
+// ---- per-device launcher state ---------------------------------------------------------------------------------------------
+// "device = the calling thread's current HIP device" (include/loans_hip.h): whatever a launcher caches about the device is
+// keyed by its ordinal, and the caches are lock-free, so that one process may drive several devices from several threads.
+// hipGetDevice is a thread-local read; hipDeviceGetAttribute and hipFuncSetAttribute are not stream operations (neither
+// blocks, both are legal while a stream is being captured), so a first call inside a hipGraph capture is safe.
+#include <atomic>
+constexpr int LOANS_MAX_DEVICES = 64;
+
+// one bit per device: "this kernel's MaxDynamicSharedMemorySize attribute has been raised there" (the attribute is per
+// device; a launch asking for > 64 KB of dynamic LDS fails on a device where it was never set)
+struct loans_device_once {
+    std::atomic<uint64_t> bits{0};
+};
+
+static inline int loans_raise_lds_limit(loans_device_once& once, const void* kern, size_t lds) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= LOANS_MAX_DEVICES) return LOANS_EINVAL;
+    if ((once.bits.load(std::memory_order_acquire) >> dev) & 1) return LOANS_OK;
+    hipError_t e = hipFuncSetAttribute(kern, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);     // idempotent: a race sets it twice
+    if (e != hipSuccess) return (int)e;
+    once.bits.fetch_or(1ull << dev, std::memory_order_release);
+    return LOANS_OK;
+}
+
+// compute units of the CURRENT device (0 on error), cached per ordinal
+static inline int loans_device_cus() {
+    static std::atomic<int> table[LOANS_MAX_DEVICES];
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= LOANS_MAX_DEVICES) return 0;
+    int cus = table[dev].load(std::memory_order_relaxed);
+    if (cus > 0) return cus;
+    if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || cus <= 0) return 0;
+    table[dev].store(cus, std::memory_order_relaxed);
+    return cus;
+}
+
 // 64-lane wave reductions (wavefront = 64 on gfx950)
 __device__ __forceinline__ float wave_sum(float v) {
 #pragma unroll

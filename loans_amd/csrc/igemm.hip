@@ -717,7 +717,7 @@ constexpr size_t igemm_lds_bytes() {
 
 template <int BM, int BN, int WM, int WN, bool RELU, bool BF16, bool DMA>
 int launch_igemm_r(IgemmArgs& a, hipStream_t st) {
-    static bool attr_set = false;
+    static loans_device_once lds_limit_set;       // per template instance = per kernel, one bit per device
 #ifdef LOANS_STAMPS
     // diagnostic: LOANS_DBG_LDS=<bytes> pads the LDS request to force fewer blocks per CU
     const char* dbg_lds = getenv("LOANS_DBG_LDS");
@@ -726,12 +726,7 @@ int launch_igemm_r(IgemmArgs& a, hipStream_t st) {
     constexpr size_t lds = igemm_lds_bytes<BM, BN, DMA>();
 #endif
     auto kern = igemm_kernel<BM, BN, WM, WN, RELU, BF16, DMA>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    if (int rc_ = loans_raise_lds_limit(lds_limit_set, reinterpret_cast<const void*>(kern), lds)) return rc_;
     a.tiles_m = (a.M - a.m_begin + BM - 1) / BM;
     a.tiles_n = (a.d.Cout + BN - 1) / BN;
     a.tiles_n2 = a.w2 ? (a.Cout2 + BN - 1) / BN : 0;
@@ -876,13 +871,8 @@ static int igemm_impl(const float* in, const float* w, float* out, const float* 
     if (tile == LOANS_TILE_SPLIT) {
         // 128x128 tiles for as many rows as fill the machine in whole rounds (2 blocks per CU), 64x64 tiles for the
         // remaining rows: the big tile's better MFMA rate without its last, mostly empty round
-        static int slots = 0;
-        if (!slots) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return LOANS_EINVAL;
-            slots = 2 * prop.multiProcessorCount;
-        }
+        const int slots = 2 * loans_device_cus();           // of the current device
+        if (slots <= 0) return LOANS_EINVAL;
         const int tiles_n = (d->Cout + 127) / 128;
         const int64_t full = ((int64_t)(a.M / 128) * tiles_n / slots) * slots;      // big tiles in whole rounds
         const int rows_big = (int)(full / tiles_n) * 128;
@@ -910,13 +900,8 @@ static int igemm_impl(const float* in, const float* w, float* out, const float* 
         if (d->osy != 1 || d->osx != 1 || d->oy0 || d->ox0 || d->outH != d->gridH || d->outW != d->gridW) return LOANS_EINVAL;
         const int c4 = d->Cout / 4;
         if ((d->Cout & 3) || !(c4 <= 256 ? (256 % c4 == 0) : (c4 % 256 == 0))) return LOANS_EINVAL;   // finalize's thread map
-        static int cus = 0;
-        if (!cus) {
-            int dev = 0;
-            hipDeviceProp_t prop;
-            if (hipGetDevice(&dev) != hipSuccess || hipGetDeviceProperties(&prop, dev) != hipSuccess) return LOANS_EINVAL;
-            cus = prop.multiProcessorCount;
-        }
+        const int cus = loans_device_cus();                 // of the current device
+        if (cus <= 0) return LOANS_EINVAL;
         const int tiles_n = (d->Cout + 63) / 64, tiles_m = (a.M + 63) / 64;
         const int ntile = tiles_m * tiles_n;
         int n_full = ntile / cus * cus;
@@ -1213,15 +1198,10 @@ __global__ __launch_bounds__(256) void wgrad_kernel(const WgradArgs a) {
 
 template <int BCO, int BJ, bool RELU, bool BF16, bool GY16 = false>
 int launch_wgrad_r(WgradArgs& a, int splits_req, hipStream_t st) {
-    static bool attr_set = false;
+    static loans_device_once lds_limit_set;       // per template instance = per kernel, one bit per device
     constexpr size_t lds = (size_t)2 * 32 * (BCO + BJ) * 4;
     auto kern = wgrad_kernel<BCO, BJ, RELU, BF16, GY16>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    if (int rc_ = loans_raise_lds_limit(lds_limit_set, reinterpret_cast<const void*>(kern), lds)) return rc_;
     a.tiles_co = (a.d.Cout + BCO - 1) / BCO;
     a.tiles_j = (a.Ktot + BJ - 1) / BJ;
     const int total_chunks = (a.M + 31) / 32;

@@ -455,16 +455,11 @@ __global__ __launch_bounds__(256) void igemm16_kernel(const Igemm16Args a) {
 
 template <int BM, int BN, int WM, int WN, bool RELU>
 int launch_igemm16_r(Igemm16Args& a, hipStream_t st) {
-    static bool attr_set = false;
+    static loans_device_once lds_limit_set;       // per template instance = per kernel, one bit per device
     constexpr size_t lds = igemm16_lds_bytes<BM, BN>();
     static_assert(lds <= 160 * 1024, "tile does not fit the LDS");
     auto kern = igemm16_kernel<BM, BN, WM, WN, RELU>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    if (int rc_ = loans_raise_lds_limit(lds_limit_set, reinterpret_cast<const void*>(kern), lds)) return rc_;
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.d.Cout + BN - 1) / BN;
     hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(256), lds, st, a);
@@ -728,15 +723,10 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const Wgrad16Args a) {
 
 template <int BCO, int BJ, bool RELU>
 int launch_wgrad16_r(Wgrad16Args& a, int splits_req, hipStream_t st) {
-    static bool attr_set = false;
+    static loans_device_once lds_limit_set;       // per template instance = per kernel, one bit per device
     constexpr size_t lds = (size_t)2 * WPC * ((BCO + 32) + (BJ + 32)) * 2;
     auto kern = wgrad16_kernel<BCO, BJ, RELU>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern),
-                                           hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    if (int rc_ = loans_raise_lds_limit(lds_limit_set, reinterpret_cast<const void*>(kern), lds)) return rc_;
     a.tiles_co = (a.d.Cout + BCO - 1) / BCO;
     a.tiles_j = (a.Ktot + BJ - 1) / BJ;
     const int total_chunks = (a.M + WPC - 1) / WPC;

@@ -147,14 +147,9 @@ __global__ __launch_bounds__(256) void stem7_kernel(const float* in, const float
 template <int TMW>
 int launch_stem7(const float* in, const float* w, float* out, const float* bias, double* stats, int B, int Hp, int Wp3,
                  int Ho, int Wo, int R, int flags, size_t lds, hipStream_t st) {
-    static bool attr_set = false;
+    static loans_device_once lds_limit_set;       // per template instance = per kernel, one bit per device
     auto kern = stem7_kernel<TMW>;
-    if (!attr_set) {
-        hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize,
-                                           (int)STEM_LDS_MAX);       // the cap of loans_stem7_rows, whatever this call needs
-        if (e != hipSuccess) return (int)e;
-        attr_set = true;
-    }
+    if (int rc_ = loans_raise_lds_limit(lds_limit_set, reinterpret_cast<const void*>(kern), STEM_LDS_MAX)) return rc_;
     hipLaunchKernelGGL(kern, dim3(B * (Ho / R)), dim3(256), lds, st, in, w, out, bias, stats, Hp, Wp3, Ho, Wo, R, flags);
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;

@@ -105,6 +105,43 @@ def conv_outsize(size, k, s, p, cover_all=False):
 _TUNE_CACHE = {}
 
 
+# ---- persisted tile table ---------------------------------------------------------------------------------------------------
+# The autotuner decides by timing, so a run under a profiler (rocprofv3 --pmc serialises and slows every dispatch) would
+# pick other tiles than the run whose numbers are being explained.  A normal run therefore WRITES its table
+# (`save_tune_table`; bench.py --tune-file F when F does not exist yet) and the profiled runs of the same command READ it
+# (`load_tune_table`; LOANS_TUNE_FILE=F or bench.py --tune-file F with F present): every shape found in the table skips
+# the timing and launches exactly the kernels of the timed run; shapes that are not in it are tuned as usual.
+def _tune_key_str(key):
+    return ','.join(str(int(v)) for v in key)
+
+
+def save_tune_table(path):
+    import json
+    table = {_tune_key_str(k): dict(v) for k, v in sorted(_TUNE_CACHE.items()) if v}
+    with open(path, 'w') as f:
+        json.dump({"what": "loans_amd tile table: (B,H,W,Cin,Cout,k,stride,pad,dense) -> {mode: tile id | splits << 8}",
+                   "entries": table}, f, indent=1, sort_keys=True)
+    return len(table)
+
+
+def load_tune_table(path):
+    """Merge a saved table into the cache (entries tuned in this process win).  Returns the number of shapes read."""
+    import json
+    with open(path) as f:
+        table = json.load(f)["entries"]
+    for ks, modes in table.items():
+        key = tuple(int(v) for v in ks.split(','))
+        key = key[:-1] + (bool(key[-1]),)
+        cur = _TUNE_CACHE.setdefault(key, {})
+        for mode, tile in modes.items():
+            cur.setdefault(mode, int(tile))
+    return len(table)
+
+
+if os.environ.get('LOANS_TUNE_FILE') and os.path.exists(os.environ['LOANS_TUNE_FILE']):
+    load_tune_table(os.environ['LOANS_TUNE_FILE'])
+
+
 class ConvGeometry:
     """Descriptors for one Convolution2D at a fixed input shape (cached by the
     caller): forward, weight-gradient and the per-stride-parity-class data

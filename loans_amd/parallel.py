@@ -29,6 +29,8 @@ class Communicator:
         self.size = dist.get_world_size(group) if dist.is_initialized() else 1
         self.rank = dist.get_rank(group) if dist.is_initialized() else 0
         self.active = dist.is_initialized() and (self.size > 1 or _SELFTEST)
+        # what actually carries the collectives: 'nccl' (= RCCL over xGMI on ROCm), 'gloo' (tests), None (single process)
+        self.backend = dist.get_backend(group) if dist.is_initialized() else None
 
     def bcast_data(self, link):
         """Rank 0's parameters and persistents to everyone (once, after construction)."""

@@ -1,0 +1,50 @@
+"""-m gpu: `python bench.py --gpus 2` through its own launcher with the REAL step (two ranks of the HIP joint step on
+GPU 0, gradients exchanged through gloo: RCCL wants one device per rank, everything else is what the driver's 8-GPU run
+executes), and `--gpus 1` as a single process.  The parent process never touches the GPU."""
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+TINY = ['--batch', '4', '--image-size', '64', '--target-size', '16', '--steps', '2', '--warmup', '1', '--no-cpu-baseline']
+
+
+def _run(script, args, **env):
+    e = dict(os.environ, **env)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT', 'LOANS_SPLITK'):
+        e.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, script)] + args, cwd=ROOT, env=e, timeout=900,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+
+
+def _one_line(r):
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [json.loads(l) for l in r.stdout.splitlines() if l.startswith('{')]
+    assert len(lines) == 1, r.stdout
+    return lines[0]
+
+
+def test_bench_two_ranks_through_the_launcher():
+    out = _one_line(_run('bench.py', ['--gpus', '2'] + TINY, LOANS_DIST_BACKEND='gloo'))
+    assert out['n_gpus'] == 2 and out['config']['world_size'] == 2 and out['config']['dist_backend'] == 'gloo'
+    assert out['config']['global_batch'] == 8 and out['scaling'] == 'weak'
+    assert out['value'] > 0 and abs(out['value'] - 8 * 1e3 / out['ms_per_step']) < 1e-2 * out['value']
+    assert out['roofline']['achieved'] > 0
+
+
+def test_bench_single_process():
+    out = _one_line(_run('bench.py', ['--gpus', '1'] + TINY))
+    assert out['n_gpus'] == 1 and out['config']['dist_backend'] is None and out['value'] > 0
+
+
+def test_trainer_two_ranks_through_the_launcher(tmp_path):
+    r = _run('train_sheep_localizer.py', ['--gpus', '2', '--use-resnet-18', '-b', '2', '--image-size', '64', '64',
+                                          '--target-size', '16', '16', '--iterations', '3', '--dataset-size', '8',
+                                          '--log-interval', '1', '-l', str(tmp_path)], LOANS_DIST_BACKEND='gloo')
+    assert r.returncode == 0, r.stderr[-3000:]
+    assert r.stdout.count('iteration') == 3, r.stdout                    # rank 0 alone reports
+    assert os.path.exists(os.path.join(str(tmp_path), 'SheepLocalizer_3.npz'))

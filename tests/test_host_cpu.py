@@ -161,3 +161,46 @@ def test_tile_selection_host_logic():
     assert len(keys) == 5
     with __import__('pytest').raises(ValueError):
         ops.set_storage_dtype('bf16')            # bf16 storage needs the bf16 compute arm first
+
+
+def test_launcher_state_is_per_device_and_capture_safe():
+    """include/loans_hip.h promises: re-entrant, thread-safe given distinct streams, device = the caller's current device,
+    no blocking runtime call.  So the launchers may keep no process-wide mutable state: what they cache (a kernel's raised
+    dynamic-LDS limit, the CU count) is keyed by the device ordinal in lock-free tables (csrc/common.h)."""
+    header = open(os.path.join(ROOT, 'include', 'loans_hip.h')).read()
+    assert 'per kernel AND per device' in header and 'hipGraph stream capture' in header
+    csrc = os.path.join(ROOT, 'loans_amd', 'csrc')
+    common = open(os.path.join(csrc, 'common.h')).read()
+    assert 'std::atomic<uint64_t> bits' in common and 'hipDeviceGetAttribute' in common
+    for name in sorted(os.listdir(csrc)):
+        if not name.endswith('.hip'):
+            continue
+        src = open(os.path.join(csrc, name)).read()
+        # function-local mutable statics other than the per-device tables; `static const` / `static constexpr` / functions are fine
+        bad = re.findall(r'^\s+static\s+(?!const\b|constexpr\b|loans_device_once\b|__device__|inline\b|std::atomic)[\w:<>]+\s+\w+\s*(?:=[^;]*)?;',
+                         src, flags=re.M)
+        assert not bad, (name, bad)
+        assert 'hipGetDeviceProperties' not in src, name            # blocking, not capture-safe
+        assert src.count('hipFuncSetAttribute') == 0, name          # only through loans_raise_lds_limit (per device)
+
+
+def test_tune_table_round_trip(tmp_path):
+    """A normal run writes its tile table, the profiled runs of the same command read it: same kernels in both
+    (ops.save_tune_table / load_tune_table, bench.py --tune-file)."""
+    from loans_amd import ops
+    g = ops.ConvGeometry(3, 20, 24, 8, 16, 3, 1, 1)
+    gd = ops.ConvGeometry(3, 32, 32, 3, 64, 7, 2, 3, dense=True)
+    g.tuned.update({'f32fprop_stats': 19, 'f32wgrad': 3 | (7 << 8)})
+    gd.tuned['f32fprop_stats_st'] = 10
+    path = str(tmp_path / 'tune.json')
+    assert ops.save_tune_table(path) >= 2
+    g.tuned.clear(); gd.tuned.clear()
+    assert ops.load_tune_table(path) >= 2
+    assert g.tuned == {'f32fprop_stats': 19, 'f32wgrad': 3 | (7 << 8)} and gd.tuned == {'f32fprop_stats_st': 10}
+    g2 = ops.ConvGeometry(3, 20, 24, 8, 16, 3, 1, 1)                  # a geometry made later shares the entry
+    assert g2.tuned is g.tuned
+    g.tuned['f32dgrad'] = 2                                           # entries tuned in this process win over the file
+    g.tuned['f32fprop_stats'] = 1
+    ops.load_tune_table(path)
+    assert g.tuned['f32fprop_stats'] == 1 and g.tuned['f32dgrad'] == 2
+    g.tuned.clear(); gd.tuned.clear()

@@ -1,0 +1,82 @@
+"""`python bench.py --gpus N` is self-launching (the reference's DP site forks its own workers,
+schaaaafrichter/train.py:159-191): the parent forks N ranks through torch.distributed.run BEFORE anything touches the GPU,
+relays rank 0's single JSON line and propagates a failing rank's exit code.
+
+No GPU here, so the ranks run bench.py's dry mode (LOANS_BENCH_DRY=1: same launcher, rendezvous, Communicator and
+gradient-arena all-reduce over gloo, no kernels, value = null).  The real step through the same launcher runs in
+tests/test_gpu_launch.py."""
+import json
+import os
+import subprocess
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _run(args, **env):
+    e = dict(os.environ, LOANS_BENCH_DRY='1', LOANS_DIST_BACKEND='gloo', **env)
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        e.pop(k, None)
+    return subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, cwd=ROOT, env=e, timeout=300,
+                          stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+
+
+def _json_lines(out):
+    return [json.loads(l) for l in out.splitlines() if l.startswith('{')]
+
+
+def test_bench_gpus2_forks_its_own_ranks_and_prints_one_line():
+    r = _run(['--gpus', '2', '--steps', '3', '--warmup', '1'])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1, r.stdout
+    out = lines[0]
+    assert out['n_gpus'] == 2 and out['steps'] == 3 and out['warmup'] == 1
+    assert out['config']['world_size'] == 2 and out['config']['dist_backend'] == 'gloo'
+    assert out['value'] is None and 'dry-run' in out['data']          # never mistaken for a measurement
+
+
+def test_bench_gpus1_stays_a_single_process():
+    r = _run(['--gpus', '1', '--steps', '2', '--warmup', '0'])
+    assert r.returncode == 0, r.stderr[-2000:]
+    lines = _json_lines(r.stdout)
+    assert len(lines) == 1 and lines[0]['n_gpus'] == 1 and lines[0]['config']['dist_backend'] is None
+
+
+def test_failing_rank_fails_the_launch():
+    r = _run(['--gpus', '2', '--steps', '1', '--warmup', '0'], LOANS_BENCH_DRY_FAIL_RANK='1')
+    assert r.returncode != 0
+    assert not _json_lines(r.stdout)
+
+
+def test_launcher_parent_decision_needs_no_torch():
+    """the fork decision is taken from argv / env alone (loans_amd/launch.py imports neither torch nor the HIP library)"""
+    code = ("import sys, importlib.util; "
+            "spec = importlib.util.spec_from_file_location('l', %r); m = importlib.util.module_from_spec(spec); "
+            "spec.loader.exec_module(m); "
+            "assert m.requested_gpus(['--steps', '3', '--gpus', '4']) == 4; "
+            "assert m.requested_gpus(['--gpus=8']) == 8; assert m.requested_gpus([]) == 1; "
+            "cmd = m.command('bench.py', ['--gpus', '2'], 2, 29500); "
+            "assert cmd[1:3] == ['-m', 'torch.distributed.run'] and '--master-addr' in cmd and '127.0.0.1' in cmd; "
+            "assert 'torch' not in sys.modules and 'loans_amd' not in sys.modules"
+            % os.path.join(ROOT, 'loans_amd', 'launch.py'))
+    r = subprocess.run([sys.executable, '-c', code], cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert r.returncode == 0, r.stderr
+
+
+def test_rank_env_means_no_second_fork():
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('l', os.path.join(ROOT, 'loans_amd', 'launch.py'))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    old = {k: os.environ.get(k) for k in ('RANK', 'WORLD_SIZE')}
+    os.environ.update(RANK='0', WORLD_SIZE='2')
+    try:
+        assert m.is_rank()
+        assert m.launch_if_parent('bench.py', ['--gpus', '2']) is None        # returns: this process is a rank
+    finally:
+        for k, v in old.items():
+            if v is None:
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v

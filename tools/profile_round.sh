@@ -1,29 +1,42 @@
 #!/bin/bash
 # The measurement set of a round, on the GPU box (run through gpurun from the repo root):
-#   tools/profile_round.sh <tag>       -> gpurun_out/<tag>_*  (copy what is to be judged into profiles/)
-# 1 bench line (default command) | 2 rocprofv3 kernel trace + stats of the same command | 3 PMC passes (HBM traffic of the
-# conv-forward launches: FETCH_SIZE and WRITE_SIZE in separate runs) | 4 config 3 (bf16 storage) bench line + trace
+#   tools/profile_round.sh <tag> [fp32|cfg3|all]   -> gpurun_out/<tag>_*  (copy what is to be judged into profiles/)
+# Per workload: 1 the bench line (default command; it WRITES the kernel-tile table) | 2 rocprofv3 kernel trace + stats of the
+# same command READING that table | 3 two PMC passes (FETCH_SIZE, WRITE_SIZE) reading it too -> HBM traffic of the
+# conv-forward launches, asserted to be the launches of the timed run | 4 one SQ pass (MFMA busy) on the same kernels
 set -eo pipefail
-tag=${1:-r1x}
+tag=${1:-r2x}
+what=${2:-all}
 out=gpurun_out
 cd /tmp && export TMPDIR=/tmp && cd "$GRAFT_REPO_ROOT"
-python3 bench.py > $out/${tag}_bench.log 2>&1
-grep '^{' $out/${tag}_bench.log | tail -1 > $out/${tag}_bench_b256.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_tr -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline > $out/${tag}_trace.log 2>&1
-python3 tools/trace_summary.py $out/${tag}_tr > $out/${tag}_bench_b256_trace_summary.txt
-cp $out/${tag}_tr/*/*kernel_stats.csv $out/${tag}_bench_b256_kernel_stats.csv
-rm -rf $out/${tag}_tr
-rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/${tag}_f -- python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline > $out/${tag}_fetch.log 2>&1
-rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/${tag}_w -- python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline > $out/${tag}_write.log 2>&1
-python3 tools/pmc_traffic.py $out/${tag}_f $out/${tag}_w $out/${tag}_conv_fwd_hbm_traffic.json
-rm -rf $out/${tag}_f $out/${tag}_w
-python3 bench.py --dtype bf16 --batch 128 --image-size 512 --steps 20 > $out/${tag}_cfg3_bench.log 2>&1
-grep '^{' $out/${tag}_cfg3_bench.log | tail -1 > $out/${tag}_cfg3_bench.json
-rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_tr3 -- python3 bench.py --steps 3 --warmup 2 --no-cpu-baseline --dtype bf16 --batch 128 --image-size 512 > $out/${tag}_cfg3_trace.log 2>&1
-python3 tools/trace_summary.py $out/${tag}_tr3 128 2500 23655874560 > $out/${tag}_cfg3_trace_summary.txt
-cp $out/${tag}_tr3/*/*kernel_stats.csv $out/${tag}_cfg3_kernel_stats.csv
-rm -rf $out/${tag}_tr3
-cat $out/${tag}_bench_b256.json
-cat $out/${tag}_cfg3_bench.json
-grep "^localizer conv\|^algorithmic\|^timeline" $out/${tag}_bench_b256_trace_summary.txt $out/${tag}_cfg3_trace_summary.txt
-cat $out/${tag}_conv_fwd_hbm_traffic.json
+mkdir -p $out
+
+one () {   # one <name> <B> <peak TFLOP/s> <flop per image> <bench args...>
+  local name=$1 B=$2 peak=$3 fpi=$4; shift 4
+  local tune=$out/${tag}_${name}_tune.json
+  rm -f $tune
+  python3 bench.py --tune-file $tune "$@" > $out/${tag}_${name}_bench.log 2>&1
+  grep '^{' $out/${tag}_${name}_bench.log | tail -1 > $out/${tag}_${name}_bench.json
+  echo "[$name] bench done"; cat $out/${tag}_${name}_bench.json
+  rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_${name}_tr -- python3 bench.py --tune-file $tune --steps 3 --warmup 2 --no-cpu-baseline "$@" > $out/${tag}_${name}_trace.log 2>&1
+  python3 tools/trace_summary.py $out/${tag}_${name}_tr $B $peak $fpi > $out/${tag}_${name}_trace_summary.txt
+  cp $out/${tag}_${name}_tr/*/*kernel_stats.csv $out/${tag}_${name}_kernel_stats.csv
+  rm -rf $out/${tag}_${name}_tr
+  echo "[$name] trace done"
+  rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/${tag}_${name}_f -- python3 bench.py --tune-file $tune --steps 2 --warmup 2 --no-cpu-baseline "$@" > $out/${tag}_${name}_fetch.log 2>&1
+  rocprofv3 --pmc WRITE_SIZE --output-format csv -d $out/${tag}_${name}_w -- python3 bench.py --tune-file $tune --steps 2 --warmup 2 --no-cpu-baseline "$@" > $out/${tag}_${name}_write.log 2>&1
+  python3 tools/pmc_traffic.py $out/${tag}_${name}_f $out/${tag}_${name}_w $out/${tag}_${name}_conv_fwd_hbm_traffic.json $out/${tag}_${name}_bench.json "localizer conv-forward launches of one step of: bench.py $*"
+  rm -rf $out/${tag}_${name}_f $out/${tag}_${name}_w
+  echo "[$name] traffic done"
+  rocprofv3 --pmc SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES GRBM_GUI_ACTIVE --output-format csv -d $out/${tag}_${name}_sq -- python3 bench.py --tune-file $tune --steps 2 --warmup 2 --no-cpu-baseline "$@" > $out/${tag}_${name}_sq.log 2>&1
+  python3 tools/pmc_sq.py $out/${tag}_${name}_sq > $out/${tag}_${name}_conv_fwd_sq_pmc_summary.txt || echo "[$name] SQ summary failed"
+  rm -rf $out/${tag}_${name}_sq
+  grep "^localizer conv\|^algorithmic\|^timeline" $out/${tag}_${name}_trace_summary.txt
+}
+
+if [ "$what" = fp32 ] || [ "$what" = all ]; then
+  one b256 256 157.3 4166615040
+fi
+if [ "$what" = cfg3 ] || [ "$what" = all ]; then
+  one cfg3 128 2500 23655874560 --dtype bf16 --batch 128 --image-size 512
+fi

@@ -6,19 +6,30 @@ generator (the PIL / imgaug datasets are SURVEY §8f.2); the Trainer extensions 
 (BBOXPlotter, Logger, interactive prompt, dump_graph) are intentionally absent.
 
     python train_sheep_localizer.py --use-resnet-18 -b 64 --iterations 20
-    python -m torch.distributed.run --nproc-per-node 8 train_sheep_localizer.py --use-resnet-18 -b 128
+    python train_sheep_localizer.py --gpus 8 --use-resnet-18 -b 128        (forks its own 8 ranks)
 """
 import argparse
 import os
+import sys
 import time
 
-import numpy as np
-import torch
+if __name__ == "__main__":
+    # `--gpus N` (N > 1) outside a launcher: fork the N ranks as a child process group before anything touches the GPU,
+    # the way the reference's data-parallel trainer forks its workers (schaaaafrichter/train.py:159-191); does not return
+    import importlib.util
+    _spec = importlib.util.spec_from_file_location(
+        '_loans_launch', os.path.join(os.path.dirname(os.path.abspath(__file__)), 'loans_amd', 'launch.py'))
+    _launch = importlib.util.module_from_spec(_spec)
+    _spec.loader.exec_module(_launch)
+    _launch.launch_if_parent(os.path.abspath(__file__))
 
-import loans_amd
-from loans_amd import parallel
-from loans_amd.datasets import synthetic
-from loans_amd.runtime import training
+import numpy as np          # noqa: E402
+import torch                # noqa: E402
+
+import loans_amd            # noqa: E402
+from loans_amd import parallel                  # noqa: E402
+from loans_amd.datasets import synthetic        # noqa: E402
+from loans_amd.runtime import training          # noqa: E402
 
 
 class SyntheticFrames:
@@ -57,6 +68,8 @@ def main():
     parser.add_argument("--target-size", type=int, nargs=2, default=(75, 75), help="crop size for each image")
     parser.add_argument("-b", "--batch-size", type=int, default=16, help="batch size for training (per GPU)")
     parser.add_argument("-g", "--gpu", type=int, default=0, help="gpu id to use")
+    parser.add_argument("--gpus", type=int, default=1,
+                        help="data-parallel ranks on this node, one process per GPU, forked by this script itself")
     parser.add_argument("--lr", "--learning-rate", dest="learning_rate", type=float, default=0.001)
     parser.add_argument("-l", "--log-dir", default='sheep_logs')
     parser.add_argument("--iterations", type=int, default=20)
@@ -79,7 +92,7 @@ def main():
 
     comm = parallel.init_from_env()
     if comm.size > 1:
-        args.gpu = int(os.environ.get('LOCAL_RANK', '0'))
+        args.gpu = int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count()
     torch.cuda.set_device(args.gpu)
 
     train_dataset = SyntheticFrames(args.dataset_size, args.image_size, seed=10 + comm.rank)
