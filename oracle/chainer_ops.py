@@ -115,15 +115,28 @@ def conv2d_bwd(x_shape, col, W, gy, stride, pad, has_bias, need_gx=True):
 # --------------------------------------------------------------------------- #
 # batch normalisation: L.BatchNormalization (sheep/resnet.py:44,129-134,152-154)
 # --------------------------------------------------------------------------- #
-def bn_fwd_train(x, gamma, beta, running_mean, running_var, eps=BN_EPS, decay=BN_DECAY):
-    """Training-mode forward; updates running stats in place.  Returns (y, ctx)."""
+def round_bf16(a):
+    """Round to the nearest bfloat16 (ties to even), returned in a's own dtype: what one store of the HIP bf16-storage arm
+    does to a tensor.  Only used by oracle.model.emulate_bf16_storage (the oracle itself is fp32 / fp64)."""
+    a = np.asarray(a)
+    f = np.ascontiguousarray(a, dtype=np.float32)
+    u = f.view(np.uint32)
+    r = ((u + np.uint32(0x7FFF) + ((u >> np.uint32(16)) & np.uint32(1))) & np.uint32(0xFFFF0000)).view(np.float32)
+    r = np.where(np.isfinite(f), r, f)
+    return r.astype(a.dtype, copy=False)
+
+
+def bn_fwd_train(x, gamma, beta, running_mean, running_var, eps=BN_EPS, decay=BN_DECAY, x_apply=None):
+    """Training-mode forward; updates running stats in place.  Returns (y, ctx).
+    ``x_apply`` (bf16-storage emulation only): the statistics come from ``x`` (the conv's fp32 accumulators), the
+    normalisation is applied to ``x_apply`` (the tensor as it was stored)."""
     axis = (0, 2, 3)
     ex = (None, slice(None), None, None)
     mean = x.mean(axis=axis)
     var = x.var(axis=axis)                       # biased
     var_eps = var + eps
     inv_std = var_eps ** (-0.5)
-    x_hat = (x - mean[ex]) * inv_std[ex]
+    x_hat = ((x if x_apply is None else x_apply) - mean[ex]) * inv_std[ex]
     y = gamma[ex] * x_hat
     y += beta[ex]
     m = x.size // gamma.size

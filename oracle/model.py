@@ -96,6 +96,33 @@ def cast_params(p, dtype):
 
 
 # --------------------------------------------------------------------------- #
+# bf16-storage emulation (BASELINE configs 3 / 5): the HIP bf16 arm keeps every activation / gradient tensor of the
+# residual stages and of the assessor in bf16.  Inside `emulate_bf16_storage()` the oracle rounds its
+# tensors to bf16 at exactly the places where that arm STORES one -- conv outputs (statistics still from the unrounded
+# accumulators), the fused BN-apply / ReLU / residual-sum outputs, the fused dgrad (+ mask / addend) outputs, BN-backward
+# outputs, the bf16 operand copies of the weights and of the preprocessed frames -- while every reduction, coefficient,
+# parameter gradient and the optimiser stay in the oracle's own precision.  `_q` is the identity otherwise.
+# --------------------------------------------------------------------------- #
+import contextlib
+
+_Q = None
+
+
+def _q(a):
+    return a if _Q is None else _Q(a)
+
+
+@contextlib.contextmanager
+def emulate_bf16_storage():
+    global _Q
+    old, _Q = _Q, C.round_bf16
+    try:
+        yield
+    finally:
+        _Q = old
+
+
+# --------------------------------------------------------------------------- #
 # building blocks with explicit forward / backward
 # --------------------------------------------------------------------------- #
 class _ConvBN:
@@ -108,12 +135,13 @@ class _ConvBN:
         p = self.p
         self.x_shape = x.shape
         self.has_bias = (self.conv + '/b') in p
-        c, self.col = C.conv2d_fwd(x, p[self.conv + '/W'], p.get(self.conv + '/b'), self.stride, self.pad)
+        c, self.col = C.conv2d_fwd(x, _q(p[self.conv + '/W']), p.get(self.conv + '/b'), self.stride, self.pad)
         if self.train:
             y, self.ctx = C.bn_fwd_train(c, p[self.bn + '/gamma'], p[self.bn + '/beta'],
-                                         p[self.bn + '/avg_mean'], p[self.bn + '/avg_var'])
+                                         p[self.bn + '/avg_mean'], p[self.bn + '/avg_var'],
+                                         x_apply=None if _Q is None else _q(c))
         else:
-            y = C.bn_fwd_test(c, p[self.bn + '/gamma'], p[self.bn + '/beta'],
+            y = C.bn_fwd_test(_q(c), p[self.bn + '/gamma'], p[self.bn + '/beta'],
                               p[self.bn + '/avg_mean'], p[self.bn + '/avg_var'])
         return y
 
@@ -125,7 +153,8 @@ class _ConvBN:
             _acc(grads, self.bn + '/beta', gb)
         else:
             gc = C.bn_bwd_test(p[self.bn + '/gamma'], p[self.bn + '/avg_var'], gy)
-        gx, gW, gbias = C.conv2d_bwd(self.x_shape, self.col, p[self.conv + '/W'], gc,
+        gc = _q(gc)
+        gx, gW, gbias = C.conv2d_bwd(self.x_shape, self.col, _q(p[self.conv + '/W']), gc,
                                      self.stride, self.pad, self.has_bias, need_gx)
         _acc(grads, self.conv + '/W', gW)
         if self.has_bias:
@@ -149,17 +178,17 @@ class _BasicA:  # sheep/resnet.py:121-141
         self.c3 = _ConvBN(p, prefix + '/conv3', prefix + '/bn3', stride, 1, train)
 
     def fwd(self, x):
-        self.h1 = C.relu(self.c1.fwd(x))
+        self.h1 = _q(C.relu(self.c1.fwd(x)))
         a = self.c2.fwd(self.h1)
         b = self.c3.fwd(x)
-        self.out = C.relu(a + b)
+        self.out = _q(C.relu(a + b))
         return self.out
 
     def bwd(self, gy, grads):
         gz = gy * (self.out > 0)
-        gx = self.c3.bwd(gz, grads)
-        gh1 = self.c2.bwd(gz, grads)
-        gx = gx + self.c1.bwd(gh1 * (self.h1 > 0), grads)
+        gx = _q(self.c3.bwd(gz, grads))
+        gh1 = _q(self.c2.bwd(gz, grads))
+        gx = _q(gx + self.c1.bwd(gh1 * (self.h1 > 0), grads))
         return gx
 
 
@@ -169,14 +198,14 @@ class _BasicB:  # sheep/resnet.py:144-160
         self.c2 = _ConvBN(p, prefix + '/conv2', prefix + '/bn2', 1, 1, train)
 
     def fwd(self, x):
-        self.h1 = C.relu(self.c1.fwd(x))
-        self.out = C.relu(self.c2.fwd(self.h1) + x)
+        self.h1 = _q(C.relu(self.c1.fwd(x)))
+        self.out = _q(C.relu(self.c2.fwd(self.h1) + x))
         return self.out
 
     def bwd(self, gy, grads):
         gz = gy * (self.out > 0)
-        gh1 = self.c2.bwd(gz, grads)
-        return gz + self.c1.bwd(gh1 * (self.h1 > 0), grads)
+        gh1 = _q(self.c2.bwd(gz, grads))
+        return _q(gz + self.c1.bwd(gh1 * (self.h1 > 0), grads))
 
 
 class _ResUnit:
@@ -193,19 +222,19 @@ class _ResUnit:
         for i, st in enumerate(self.stages):
             h = st.fwd(h)
             if i < len(self.stages) - 1:
-                h = C.relu(h)
+                h = _q(C.relu(h))
                 self.hs.append(h)
         sc = self.shortcut.fwd(x) if self.shortcut is not None else x
-        self.out = C.relu(h + sc)
+        self.out = _q(C.relu(h + sc))
         return self.out
 
     def bwd(self, gy, grads):
         gz = gy * (self.out > 0)
-        gx = self.shortcut.bwd(gz, grads) if self.shortcut is not None else gz
+        gx = _q(self.shortcut.bwd(gz, grads)) if self.shortcut is not None else gz
         g = gz
         for i in range(len(self.stages) - 1, 0, -1):
-            g = self.stages[i].bwd(g, grads) * (self.hs[i - 1] > 0)
-        return gx + self.stages[0].bwd(g, grads)
+            g = _q(self.stages[i].bwd(g, grads)) * (self.hs[i - 1] > 0)
+        return _q(gx + self.stages[0].bwd(g, grads))
 
 
 RESNET50_STAGES = (('res2', 3, 64, 64, 256, 1), ('res3', 4, 256, 128, 512, 2),
@@ -261,11 +290,11 @@ class Localizer:
         p, train = self.p, self.train
         self.images = images
         H = images.shape[-2]
-        x = C.prepare_images(images)
+        x = _q(C.prepare_images(images))
         self.blocks = []
         fe = 'feature_extractor'
         self.stem = _ConvBN(p, fe + '/conv1', fe + '/bn1', 2, 3, train)
-        self.stem_relu = C.relu(self.stem.fwd(x))
+        self.stem_relu = _q(C.relu(self.stem.fwd(x)))
         h, self.pool_idx = C.max_pool_fwd(self.stem_relu, 3, 2, 0)
         for blk in self._make_blocks(H):
             h = blk.fwd(h)
@@ -302,7 +331,7 @@ class Localizer:
         gpooled, gW, gb = C.linear_bwd(self.pooled, p['param_predictor/W'], gtheta.reshape(-1, 6), True)
         _acc(grads, 'param_predictor/W', gW)
         _acc(grads, 'param_predictor/b', gb)
-        g = C.gap_bwd(self.feat.shape, gpooled)
+        g = _q(C.gap_bwd(self.feat.shape, gpooled))
         for blk in reversed(self.blocks):
             g = blk.bwd(g, grads)
         g = C.max_pool_bwd(self.stem_relu.shape, self.pool_idx, g, 3, 2, 0)
@@ -353,33 +382,35 @@ class Assessor:
         self.p = params
 
     def _conv(self, key, x, stride, pad):
-        y, col = C.conv2d_fwd(x, self.p[key + '/W'], None, stride, pad)
+        y, col = C.conv2d_fwd(x, _q(self.p[key + '/W']), None, stride, pad)
         self._ctx[key] = (x.shape, col, stride, pad)
         return y
 
-    def _conv_bwd(self, key, gy, grads, need_gx=True):
+    def _conv_bwd(self, key, gy, grads, need_gx=True, round_w=True):
         shape, col, stride, pad = self._ctx[key]
-        gx, gW, _ = C.conv2d_bwd(shape, col, self.p[key + '/W'], gy, stride, pad, False, need_gx)
+        W = self.p[key + '/W']
+        gx, gW, _ = C.conv2d_bwd(shape, col, _q(W) if round_w else W, gy, stride, pad, False, need_gx)
         _acc(grads, key + '/W', gW)
         return gx
 
     def forward(self, x):
         self._ctx = {}
+        x = _q(x)            # bf16 emulation: the crops stay fp32 in HBM, the first block rounds them while it stages them
         self.x = x
         # r0 = DownResBlock1 (net.py:19-25)
-        self.r0_h1 = self._conv('r0/c0', x, 1, 1)
-        h = self._conv('r0/c1', C.relu(self.r0_h1), 2, 1) + self._conv('r0/cs', x, 2, 1)
+        self.r0_h1 = _q(self._conv('r0/c0', x, 1, 1))
+        h = _q(self._conv('r0/c1', C.relu(self.r0_h1), 2, 1) + _q(self._conv('r0/cs', x, 2, 1)))
         self.h1 = h
         # r1 = DownResBlock2 (net.py:41-47)
-        self.r1_h1 = self._conv('r1/c0', C.relu(h), 1, 1)
-        h = self._conv('r1/c1', C.relu(self.r1_h1), 2, 1) + self._conv('r1/cs', h, 2, 1)
+        self.r1_h1 = _q(self._conv('r1/c0', C.relu(h), 1, 1))
+        h = _q(self._conv('r1/c1', C.relu(self.r1_h1), 2, 1) + _q(self._conv('r1/cs', h, 2, 1)))
         self.h2 = h
         # r2, r3 = DownResBlock3 (net.py:62-67)
-        self.r2_h1 = self._conv('r2/c0', C.relu(h), 1, 1)
-        h = self._conv('r2/c1', C.relu(self.r2_h1), 1, 1) + h
+        self.r2_h1 = _q(self._conv('r2/c0', C.relu(h), 1, 1))
+        h = _q(self._conv('r2/c1', C.relu(self.r2_h1), 1, 1) + h)
         self.h3 = h
-        self.r3_h1 = self._conv('r3/c0', C.relu(h), 1, 1)
-        h = self._conv('r3/c1', C.relu(self.r3_h1), 1, 1) + h
+        self.r3_h1 = _q(self._conv('r3/c0', C.relu(h), 1, 1))
+        h = _q(self._conv('r3/c1', C.relu(self.r3_h1), 1, 1) + h)
         self.h4 = h
         self.hr = C.relu(h)
         self.y = C.sigmoid(C.linear_fwd(self.hr, self.p['l4/W'], None))
@@ -392,23 +423,24 @@ class Assessor:
         gz = C.sigmoid_bwd(self.y, gy)
         ghr, gW, _ = C.linear_bwd(self.hr, self.p['l4/W'], gz, False)
         _acc(grads, 'l4/W', gW)
-        g = ghr * (self.h4 > 0)
+        g = _q(ghr * (self.h4 > 0))
         # r3
-        g1 = self._conv_bwd('r3/c1', g, grads) * (self.r3_h1 > 0)
-        g = g + self._conv_bwd('r3/c0', g1, grads) * (self.h3 > 0)
+        g1 = _q(self._conv_bwd('r3/c1', g, grads) * (self.r3_h1 > 0))
+        g = _q(g + self._conv_bwd('r3/c0', g1, grads) * (self.h3 > 0))
         # r2
-        g1 = self._conv_bwd('r2/c1', g, grads) * (self.r2_h1 > 0)
-        g = g + self._conv_bwd('r2/c0', g1, grads) * (self.h2 > 0)
+        g1 = _q(self._conv_bwd('r2/c1', g, grads) * (self.r2_h1 > 0))
+        g = _q(g + self._conv_bwd('r2/c0', g1, grads) * (self.h2 > 0))
         # r1
-        g1 = self._conv_bwd('r1/c1', g, grads) * (self.r1_h1 > 0)
-        g = self._conv_bwd('r1/cs', g, grads) + self._conv_bwd('r1/c0', g1, grads) * (self.h1 > 0)
+        g1 = _q(self._conv_bwd('r1/c1', g, grads) * (self.r1_h1 > 0))
+        g = _q(_q(self._conv_bwd('r1/cs', g, grads)) + self._conv_bwd('r1/c0', g1, grads) * (self.h1 > 0))
         # r0
-        g1 = self._conv_bwd('r0/c1', g, grads) * (self.r0_h1 > 0)
+        g1 = _q(self._conv_bwd('r0/c1', g, grads) * (self.r0_h1 > 0))
         if not need_gx:
             self._conv_bwd('r0/cs', g, grads, need_gx=False)
             self._conv_bwd('r0/c0', g1, grads, need_gx=False)
             return None
-        return self._conv_bwd('r0/cs', g, grads) + self._conv_bwd('r0/c0', g1, grads)
+        # the gradient w.r.t. the 4-channel crops: fp32 out, fp32 master weights (loans_dgrad_c4_bf16_f32)
+        return self._conv_bwd('r0/cs', g, grads, round_w=False) + self._conv_bwd('r0/c0', g1, grads, round_w=False)
 
 
 # --------------------------------------------------------------------------- #
