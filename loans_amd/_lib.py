@@ -31,11 +31,20 @@ class IgemmDesc(C.Structure):
         ('dy', C.c_int8 * MAX_TAPS), ('dx', C.c_int8 * MAX_TAPS)]
 
 
+class SmallConv(C.Structure):
+    """Mirror of ``loans_small_conv``."""
+    _fields_ = [(n, C.c_int32) for n in ('k', 'stride', 'pad', 'outH', 'outW')]
+
+
 _p = C.c_void_p
 _i32, _i64, _f32, _f64 = C.c_int32, C.c_int64, C.c_float, C.c_double
 
 # name -> argtypes, exactly the prototypes of include/loans_hip.h
 SIGNATURES = {
+    'loans_crop_dgrad_f32': [C.c_void_p, C.c_void_p, C.POINTER(SmallConv), C.c_void_p, C.c_void_p, C.POINTER(SmallConv),
+                             C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p],
+    'loans_crop_dgrad_bf16_f32': [C.c_void_p, C.c_void_p, C.POINTER(SmallConv), C.c_void_p, C.c_void_p, C.POINTER(SmallConv),
+                                  C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p],
     'loans_igemm_f32': [_p, _p, _p, _p, _p, _p, _p, C.POINTER(IgemmDesc), _p],
     'loans_igemm_pair_f32': [_p, _p, _p, _p, _p, _p, _p, _i32, C.POINTER(IgemmDesc), _p],
     'loans_igemm_finalize_f32': [_p, _p, _p, _p, _p, _i32, _i64, _i32, _p],

@@ -219,8 +219,12 @@ class DownResBlock1Function(Function):
             ops.conv_wgrad(self.x, gh1, W0.grad_view, self.g0)
         gx = None
         if need_gx:
-            gx = ops.conv_dgrad(g, Ws.data, self.gs)
-            ops.conv_dgrad(gh1, W0.data, self.g0, out=gx, addend=gx)
+            if ops.crop_dgrad_ok(self.g0, self.gs):
+                # the 4-channel crops: both data gradients in ONE launch that reads g and gh1 once (csrc/cropgrad.hip)
+                gx = ops.crop_dgrad(gh1, W0.data, self.g0, g, Ws.data, self.gs)
+            else:
+                gx = ops.conv_dgrad(g, Ws.data, self.gs)
+                ops.conv_dgrad(gh1, W0.data, self.g0, out=gx, addend=gx)
         return gx, None, None, None
 
     def release(self):

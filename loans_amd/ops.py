@@ -639,6 +639,41 @@ def conv_dgrad(gy, w, geo, out=None, mask_ref=None, addend=None, addend_mask_ref
     return out
 
 
+# LOANS_CROP_DGRAD=0: the gradient w.r.t. the 4-channel crops goes back to one loans_dgrad_c4 launch per stride-parity class
+CROP_DGRAD = os.environ.get('LOANS_CROP_DGRAD', '1') != '0'
+
+
+def crop_dgrad_ok(geo_a, geo_b=None):
+    """loans_crop_dgrad covers these convolutions of a 4-channel input (csrc/cropgrad.hip)"""
+    ok = CROP_DGRAD
+    for g in (geo_a, geo_b):
+        if g is None:
+            continue
+        ok = ok and g.Cin == 4 and not g.dense and g.k <= 4 and g.stride <= 2 and g.pad < g.k and g.Cout % 8 == 0
+    if geo_b is not None:
+        ok = ok and (geo_a.B, geo_a.H, geo_a.W, geo_a.Cout) == (geo_b.B, geo_b.H, geo_b.W, geo_b.Cout)
+    return ok
+
+
+def crop_dgrad(gy_a, w_a, geo_a, gy_b=None, w_b=None, geo_b=None, addend=None):
+    """gx[B,H,W,4] = dgrad(gy_a, w_a) (+ dgrad(gy_b, w_b)) (+ addend) for convolutions of the SAME 4-channel input, in one
+    launch that reads each gradient tensor once; weights are the forward OHWI tensors.  fp32 or bf16 gradients, fp32 gx."""
+    lib = _lib.load()
+    assert crop_dgrad_ok(geo_a, geo_b) and (gy_b is None) == (geo_b is None)
+    assert gy_b is None or gy_b.dtype == gy_a.dtype
+    for gy, g in ((gy_a, geo_a), (gy_b, geo_b)):
+        if gy is not None:
+            assert gy.is_contiguous() and gy.numel() == g.B * g.Ho * g.Wo * g.Cout
+            _count_flops('dgrad', g)
+    out = torch.empty((geo_a.B, geo_a.H, geo_a.W, 4), device=gy_a.device, dtype=torch.float32)
+    mk = lambda g: _lib.SmallConv(g.k, g.stride, g.pad, g.Ho, g.Wo)      # noqa: E731
+    ca, cb = mk(geo_a), (mk(geo_b) if geo_b is not None else None)
+    fn = lib.loans_crop_dgrad_bf16_f32 if _is16(gy_a) else lib.loans_crop_dgrad_f32
+    check(fn(_ptr(gy_a), _ptr(w_a), C.byref(ca), _ptr(gy_b), _ptr(w_b), C.byref(cb) if cb is not None else None,
+             _ptr(out), _ptr(addend), geo_a.B, geo_a.H, geo_a.W, geo_a.Cout, _stream()), 'loans_crop_dgrad')
+    return out
+
+
 # Weight gradients are consumed only by the optimiser, so they run on a second HIP stream: the
 # MFMA-bound wgrad kernels overlap the HBM-bound BN / ReLU passes of the data-gradient chain and
 # fill the tails of its dgrad launches.  `join_side_stream()` is the barrier the consumers call.
@@ -793,11 +828,17 @@ class _ZeroPool:
     (`begin_step` not called: tests, inference) and when the pool is exhausted, callers get a plain `torch.zeros`."""
 
     def __init__(self):
-        self.buf, self.off, self.need, self.live = None, 0, 0, False
+        self.buf, self.off, self.need, self.live, self.pinned = None, 0, 0, False, False
 
     def begin(self, device):
         capturing = torch.cuda.is_current_stream_capturing()
-        if not capturing and (self.buf is None or self.need > self.buf.numel()):
+        if capturing:
+            # a hipGraph recorded from here on has this buffer's addresses baked into its memset, its conv-statistics atomics
+            # and its BN kernels: the buffer must outlive the graph and never move.  A later eager step that needs more
+            # (taller frames enabling res6 / res7 after a shape change) gets plain torch.zeros for what does not fit
+            # (`take` returns None) instead of a reallocation that would hand the old memory back to the allocator.
+            self.pinned = True
+        elif not self.pinned and (self.buf is None or self.need > self.buf.numel()):
             self.buf = torch.empty(max(int(self.need * 1.25), 1 << 16), device=device, dtype=torch.float64)
         self.off, self.need, self.live = 0, 0, self.buf is not None
         if self.live:
@@ -1086,8 +1127,10 @@ def mul(x, m):
 
 
 def axpby(a, x, b, y):
-    """y = a*x + b*y in place."""
+    """y = a*x + b*y in place (fp32, contiguous)."""
     assert x.numel() == y.numel()
+    _chk(x, 'x')
+    _chk(y, 'y')
     check(_lib.load().loans_axpby_f32(a, _ptr(x), b, _ptr(y), x.numel(), _stream()), 'loans_axpby_f32')
     return y
 

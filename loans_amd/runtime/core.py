@@ -119,6 +119,7 @@ class Variable:
             self.grad = torch.ones_like(self.data)
         grads = {id(self): self.grad}
         keep = {id(self): self}
+        owned = set()       # ids whose gradient buffer was made by this sweep (safe to accumulate into in place)
         heap, seen = [], set()
 
         def push(f):
@@ -148,7 +149,16 @@ class Variable:
                 if not x.requires_grad:
                     continue
                 if id(x) in grads:
-                    ops.axpby(1.0, gx, 1.0, grads[id(x)])
+                    # the tensor that arrived first may be shared: Add.backward hands the SAME gy to both inputs, Reshape /
+                    # layout functions return views of theirs.  Accumulating into it in place would also change the other
+                    # branch's gradient, so the first accumulation goes into a buffer of this sweep's own.
+                    if id(x) not in owned:
+                        first = grads[id(x)]
+                        buf = torch.empty(first.shape, device=first.device, dtype=first.dtype)
+                        buf.copy_(first)
+                        grads[id(x)] = buf
+                        owned.add(id(x))
+                    ops.axpby(1.0, gx.contiguous(), 1.0, grads[id(x)])
                 else:
                     grads[id(x)] = gx
                     keep[id(x)] = x

@@ -3,7 +3,11 @@ as ONE fused kernel launch over the model's flat parameter arena.
 
 Chainer 4.1.0 semantics (oracle/chainer_ops.py:adam_amsgrad_update): eps sits outside
 the bias correction, ``lr_t = alpha * sqrt(1 - beta2^t) / (1 - beta1^t)``, parameters
-without a gradient are updated with zeros.  With a communicator attached
+without a gradient are updated with zeros (``reallocate_cleared_grads``): for a parameter
+that never had one (m = v = 0) that is a no-op, so the arena's never-used tail -- res6 / res7
+below 225 / 301 px -- is skipped; once a parameter HAS been stepped with a gradient its moments
+keep decaying and it keeps moving on zero gradients, so the step covers the largest prefix any
+update of this optimiser has seen, with the gradients beyond the current graph zeroed.  With a communicator attached
 (``parallel.create_multi_node_optimizer``) gradients are all-reduced over RCCL first."""
 import math
 from types import SimpleNamespace
@@ -24,10 +28,29 @@ class Adam:
         self.target = None
         self.comm = None
         self._state = None
+        self._hooks = {}
 
     def setup(self, link):
         self.target = link
         return self
+
+    # chainer.Optimizer.add_hook / remove_hook / call_hooks: a hook is called with the optimiser once per update(), after
+    # the gradients are complete (data parallel: after the all-reduce) and before the parameters move -- where Chainer's
+    # GradientMethod.update calls them.  The parity tests read every step's gradients through one.
+    def add_hook(self, hook, name=None):
+        if not callable(hook):
+            raise TypeError('hook function is not callable')
+        name = name or getattr(hook, 'name', None) or getattr(hook, '__name__', None) or 'hook%d' % len(self._hooks)
+        if name in self._hooks:
+            raise KeyError('hook %s already exists' % name)
+        self._hooks[name] = hook
+
+    def remove_hook(self, name):
+        del self._hooks[name]
+
+    def call_hooks(self):
+        for hook in list(self._hooks.values()):
+            hook(self)
 
     @property
     def alpha(self):
@@ -72,9 +95,24 @@ class Adam:
             if self.comm is not None and getattr(self.comm, 'active', self.comm.size > 1):
                 self.comm.allreduce_grad(arena)
                 grad_scale = 1.0 / self.comm.size
+        self.grad_scale = grad_scale        # data parallel: the arena holds the SUM over ranks, the kernel applies 1 / world size
+        if self._hooks:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('optimizer hooks run on the host: not inside a captured step')
+            self.call_hooks()
         hp = self.hyperparam
         m, v, vhat = self._state
-        n = arena.active_numel       # parameters outside the active prefix have no gradient: Chainer skips them too
+        # parameters beyond the prefix the current graph touches have no gradient.  Those that never had one are skipped
+        # (m = v = 0: Chainer's zero-gradient step is a no-op); those that were trained before -- the frame height crossed
+        # 224 / 300 px between steps -- are stepped with a zero gradient like Chainer does (their m decays, they keep moving)
+        n = arena.active_numel
+        seen = max(getattr(self, '_stepped_numel', 0), n)
+        if seen > n:
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('the active parameter prefix shrank inside a captured step')
+            arena.grad[n:seen].zero_()
+            n = seen
+        self._stepped_numel = seen
         if torch.cuda.is_current_stream_capturing():
             # being recorded into a hipGraph (SheepAssessor(use_graph=True)): nothing executes now, and the replays
             # must not bake in this step's rate -- the kernel reads it from device memory, `begin_replay()` advances it

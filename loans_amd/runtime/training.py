@@ -39,27 +39,36 @@ class SerialIterator:
         n = len(self.dataset)
         return self._rng.permutation(n) if self.shuffle else np.arange(n)
 
+    def reset(self):
+        """Back to the start of the first epoch (chainer iterators' ``reset``; the Evaluator runs a fresh pass each time)."""
+        self.epoch, self.is_new_epoch, self._pos = 0, False, 0
+        self._order = self._new_order()
+
     def __iter__(self):
         return self
 
     def __next__(self):
+        """chainer.iterators.SerialIterator: ``is_new_epoch`` is True for the batch that CONSUMES the last example of an epoch
+        (the reference's log / validation trigger reads it, train_sheep_localizer.py:188-190); with ``repeat`` a batch that
+        straddles the boundary is completed from the next epoch's order, without it the last batch is the short remainder."""
         n = len(self.dataset)
-        if not self.repeat and self.epoch > 0:
+        if not self.repeat and self._pos >= n:
             raise StopIteration
-        idx = []
-        self.is_new_epoch = False
-        while len(idx) < self.batch_size:
-            if self._pos >= n:
-                self.epoch += 1
-                self.is_new_epoch = True
-                self._pos = 0
+        i_end = self._pos + self.batch_size
+        idx = list(self._order[self._pos:i_end])
+        if i_end >= n:
+            if self.repeat:
+                rest = i_end - n
                 self._order = self._new_order()
-                if not self.repeat:
-                    break
-            idx.append(self._order[self._pos])
-            self._pos += 1
-        if not idx:
-            raise StopIteration
+                idx += list(self._order[:rest])
+                self._pos = rest
+            else:
+                self._pos = n
+            self.epoch += 1
+            self.is_new_epoch = True
+        else:
+            self.is_new_epoch = False
+            self._pos = i_end
         return [self.dataset[int(i)] for i in idx]
 
     next = __next__
@@ -95,6 +104,40 @@ class DeviceBatchIterator:
 
 def identity_converter(batch, device=None):
     return batch
+
+
+class Evaluator:
+    """``chainer.training.extensions.Evaluator(iterator, target, device=..., eval_func=...)`` as the reference uses it
+    (train_sheep_localizer.py:192-197): one pass over a ``repeat=False`` iterator, ``eval_func(*converter(batch, device))`` per
+    batch, every value the function reports (or returns) averaged over the batches (Chainer's ``DictSummary.compute_mean``)
+    and reported once.  Returns the averaged dict."""
+
+    def __init__(self, iterator, target, converter=concat_examples, device=None, eval_func=None):
+        self.iterator, self.target, self.converter, self.device = iterator, target, converter, device
+        self.eval_func = eval_func or target
+
+    def evaluate(self):
+        from .core import reporter
+        it = self.iterator
+        it.reset()
+        sums, n = {}, 0
+        for batch in it:
+            in_arrays = self.converter(batch, self.device)
+            before = dict(reporter.observation)
+            out = self.eval_func(*in_arrays) if isinstance(in_arrays, tuple) else self.eval_func(in_arrays)
+            seen = {k: v for k, v in reporter.observation.items() if before.get(k) is not v}
+            if isinstance(out, dict):
+                seen.update(out)
+            for k, v in seen.items():
+                sums[k] = sums.get(k, 0.0) + float(v)
+            n += 1
+        return {k: v / max(n, 1) for k, v in sums.items()}
+
+    def __call__(self, trainer=None):
+        from .core import report
+        result = self.evaluate()
+        report(result)
+        return result
 
 
 class StandardUpdater:

@@ -606,3 +606,49 @@ def test_conv_bf16_compute_fprop_dgrad(case, tile):
             assert rel_err(dw.cpu().numpy().transpose(0, 3, 1, 2)[:, :Cin], gw_ref) < 5e-6
     finally:
         ops.set_compute_dtype('f32')
+
+
+@pytest.mark.parametrize("shape", [(2, 75, 75), (3, 16, 16), (2, 19, 23), (1, 33, 17), (2, 28, 24)])
+@pytest.mark.parametrize("g16", [False, True])
+def test_crop_dgrad_one_launch(shape, g16):
+    """loans_crop_dgrad (csrc/cropgrad.hip): the gradient w.r.t. the 4-channel crops through r0.c0 (3x3 / 1) AND r0.cs
+    (4x4 / 2) of the assessor (common/net.py:15,17,22-25) in one launch, against the oracle's two conv2d_bwd calls; the single
+    convolution form; agreement with the per-class VALU kernel it replaces; fp32 and bf16 gradient tensors."""
+    from loans_amd import ops
+    B, H, W = shape
+    Cc = 128
+    rng = np.random.RandomState(H * 100 + W)
+    ga, gb = ops.ConvGeometry(B, H, W, 4, Cc, 3, 1, 1), ops.ConvGeometry(B, H, W, 4, Cc, 4, 2, 1)
+    wa = (rng.standard_normal((Cc, 3, 3, 3)) * 0.05).astype(np.float32)
+    wb = (rng.standard_normal((Cc, 3, 4, 4)) * 0.05).astype(np.float32)
+    gya = rng.standard_normal((B, Cc, ga.Ho, ga.Wo)).astype(np.float32)
+    gyb = rng.standard_normal((B, Cc, gb.Ho, gb.Wo)).astype(np.float32)
+    if g16:
+        gya, gyb = _bf16_round(gya), _bf16_round(gyb)
+    cast = (lambda t: t.to(torch.bfloat16)) if g16 else (lambda t: t)
+    x_shape = (B, 3, H, W)
+    _, col_a = C.conv2d_fwd(np.zeros(x_shape), wa.astype(np.float64), None, 1, 1)
+    _, col_b = C.conv2d_fwd(np.zeros(x_shape), wb.astype(np.float64), None, 2, 1)
+    ra = C.conv2d_bwd(x_shape, col_a, wa.astype(np.float64), gya.astype(np.float64), 1, 1, False)[0]
+    rb = C.conv2d_bwd(x_shape, col_b, wb.astype(np.float64), gyb.astype(np.float64), 2, 1, False)[0]
+    wad, wbd = dev(_ohwi(wa, 4)), dev(_ohwi(wb, 4))
+    gad, gbd = cast(dev(_nhwc(gya))), cast(dev(_nhwc(gyb)))
+    assert ops.crop_dgrad_ok(ga, gb)
+    out = ops.crop_dgrad(gad, wad, ga, gbd, wbd, gb)
+    assert out.dtype == torch.float32 and tuple(out.shape) == (B, H, W, 4)
+    assert rel_err(_nchw(out, 3), ra + rb) < 5e-6
+    assert not out[..., 3].any()                                   # the padding channel is written as zero
+    # one convolution, with an addend that aliases nothing
+    add = rng.standard_normal((B, H, W, 4)).astype(np.float32)
+    add[..., 3] = 0
+    one = ops.crop_dgrad(gbd, wbd, gb, addend=dev(add))
+    assert rel_err(_nchw(one, 3), rb + add.transpose(0, 3, 1, 2)[:, :3]) < 5e-6
+    # the kernel it replaces (one VALU launch per stride-parity class): same sums in another order
+    old = ops.CROP_DGRAD
+    try:
+        ops.CROP_DGRAD = False
+        ref = ops.conv_dgrad(gbd, wbd, gb)
+        ops.conv_dgrad(gad, wad, ga, out=ref, addend=ref)
+    finally:
+        ops.CROP_DGRAD = old
+    assert rel_err(out.cpu().numpy(), ref.cpu().numpy()) < 5e-6

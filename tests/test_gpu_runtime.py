@@ -1,0 +1,97 @@
+"""-m gpu: host-runtime behaviour that only shows with device tensors -- gradient accumulation into shared buffers, the step
+accumulator pool next to a captured hipGraph, Adam on parameters whose gradient disappears (frames no longer tall enough for
+res6 / res7): Chainer steps them with zeros, their moments keep decaying (GradientMethod.reallocate_cleared_grads)."""
+import numpy as np
+import pytest
+import torch
+
+import loans_amd
+from loans_amd import ops
+from loans_amd.functions import reshape
+from loans_amd.functions.basic import add
+from loans_amd.runtime.core import Variable
+from oracle import model as M
+from tests.gpu_util import build_pair, dev, inputs, oracle_params
+from tests.test_gpu_model import _updater
+
+pytestmark = pytest.mark.gpu
+
+
+def test_backward_fan_out_below_an_add_does_not_alias():
+    """Add.backward hands the SAME tensor to both inputs and Reshape.backward returns a view of its own: a variable with a
+    second consumer must not accumulate into that shared tensor in place."""
+    g0 = torch.arange(12, dtype=torch.float32, device='cuda').reshape(3, 4) + 1
+    p = Variable(torch.ones(12, device='cuda'), requires_grad=True)
+    q = Variable(torch.full((12,), 2.0, device='cuda'), requires_grad=True)
+    a, c = reshape(p, (3, 4)), reshape(q, (3, 4))
+    z = add(a, c)
+    w = add(a, z)                      # a feeds z and w
+    w.grad = g0.clone()
+    w.backward()
+    torch.cuda.synchronize()
+    assert torch.equal(w.grad, g0)                                    # the seed gradient was not written to
+    assert torch.equal(q.grad.reshape(3, 4), g0)                      # c's branch sees g, not 2 g
+    assert torch.equal(p.grad.reshape(3, 4), 2 * g0)                  # a = both paths
+    np.testing.assert_array_equal(w.data.cpu().numpy(), np.full((3, 4), 1 + 1 + 2.0))
+
+
+def test_zero_pool_never_moves_under_a_captured_graph():
+    pool = ops._ZeroPool()
+    dev_ = torch.device('cuda', 0)
+    pool.begin(dev_)
+    a = pool.take(100)
+    assert a is not None and not pool.pinned
+    ptr = pool.buf.data_ptr()
+    g = torch.cuda.CUDAGraph()
+    with torch.cuda.graph(g):
+        pool.begin(dev_)                                              # a captured step's memset
+        b = pool.take(64)
+        b.add_(1.0)
+    assert pool.pinned and pool.buf.data_ptr() == ptr
+    # an eager step that needs far more than the buffer holds (taller frames): what does not fit comes from torch.zeros
+    pool.begin(dev_)
+    assert pool.take(pool.buf.numel() * 4) is None
+    pool.begin(dev_)                                                  # ... and the next begin() must NOT reallocate
+    assert pool.buf.data_ptr() == ptr and pool.take(10) is not None
+    g.replay()
+    torch.cuda.synchronize()
+    assert float(b.sum()) == 64.0                                     # the graph still owns live memory
+
+
+def test_adam_keeps_stepping_parameters_that_lost_their_gradient(deterministic_forward):
+    """One step on 232 px frames (res6 trains), one on 64 px frames (res6 has no gradient any more): Chainer updates res6 with
+    a zero gradient in the second step -- its first moment decays, it keeps moving.  The oracle's AdamAMSGrad does exactly
+    that; the HIP optimiser must too (and res7, never trained, must stay bit-identical)."""
+    crop = (16, 16)
+    loc, dis = build_pair(81, crop)
+    tall, real, labels = inputs(82, 3, 232, 226, crop)
+    small = inputs(83, 3, 64, 64, crop)[0]
+    with loans_amd.using_config('enable_backprop', False):
+        dis(dev(real))
+    loc.finalize(torch.device('cuda', 0))
+    lp, dp = oracle_params(loc, np.float64), oracle_params(dis, np.float64)
+    init = {k: v.copy() for k, v in lp.items()}
+    og, od = M.AdamAMSGrad(lp), M.AdamAMSGrad(dp)
+    f64 = lambda a: a.astype(np.float64)            # noqa: E731
+    M.update_core(lp, dp, og, od, f64(tall), f64(real), f64(labels), crop, rng=np.random.RandomState(0))
+    after1 = {k: v.copy() for k, v in lp.items()}
+    M.update_core(lp, dp, og, od, f64(small), f64(real), f64(labels), crop, rng=np.random.RandomState(0))
+
+    upd = _updater(loc, dis, tall, real, labels)
+    upd.get_iterator('main').batches = [dev(tall), dev(small)]
+    upd.update()
+    s1 = loc.state_dict_chainer()
+    upd.update()
+    s2 = loc.state_dict_chainer()
+    k6, k7 = 'res6/0/conv1/W', 'res7/0/conv1/W'
+    np.testing.assert_array_equal(s2[k7], init[k7].astype(np.float32))                    # never had a gradient: untouched
+    assert np.abs(after1[k6] - init[k6]).max() > 5e-4                                     # step 1 trained res6
+    d_ref = lp[k6] - after1[k6]                                                           # step 2: zero gradient, m decays
+    assert np.abs(d_ref).max() > 1e-4
+    d_hip = s2[k6].astype(np.float64) - s1[k6].astype(np.float64)
+    assert np.abs(d_hip).max() > 1e-4, 'res6 froze when its gradient disappeared'
+    # the second move is m / (sqrt(vhat) + eps) of step 1's gradient: sign-like again; same criterion as the update tests
+    off = np.abs(d_hip - d_ref)
+    assert off.max() < 1.5e-3 and np.mean(off > 5e-5) < 5e-3, (off.max(), np.mean(off > 5e-5))
+    for key in ('res6/1/bn2/gamma', 'res6/0/bn3/beta'):
+        assert np.abs(s2[key] - s1[key]).max() > 0

@@ -125,6 +125,8 @@ def test_every_entry_point_rejects_null_pointers(lib):
                 args.append(ctypes.byref(desc))
             elif t is ctypes.POINTER(ctypes.c_int32):
                 args.append(tapsel)
+            elif t is ctypes.POINTER(_lib.SmallConv):
+                args.append(ctypes.byref(_lib.SmallConv(3, 1, 1, 4, 4)))
             elif t in (ctypes.c_float, ctypes.c_double):
                 args.append(1.0)
             else:
