@@ -180,18 +180,21 @@ int loans_dgrad_c4_bf16_f32(const void* gy, const float* w_ohwi, float* out, con
  * the two convolutions of DownResBlock1 that read the 4-channel crops (common/net.py:15,17: c0 3x3 / 1, cs 4x4 / 2; the
  * reference's backward runs cuDNN's dgrad twice and adds).  Each gradient tensor [B][outH][outW][C] is read once (taps in
  * the GEMM's N, col2im inside the block); w_* are the FORWARD weights, OHWI [C][k][k][4]; channel 3 of gx is written 0.
- * gy_b / w_b / cb may be NULL (one convolution).  k <= 4, stride <= 2, pad < k, C % 8 == 0; outH / outW must be the forward
- * output size of an H x W input.  `addend` may alias `out`. */
+ * gy_b / w_b / cb may be NULL (one convolution).  k <= 4, stride <= 2, pad < k, C == 128 (the assessor's width); outH / outW
+ * must be the forward output size of an H x W input; each gradient tensor below 2 GiB.  `addend` may alias `out`.
+ * `wpack`: caller-owned workspace of LOANS_CROP_WPACK_FLOATS floats (the weights in MFMA fragment order, written by a
+ * pre-pass of the same call on the same stream). */
+#define LOANS_CROP_WPACK_FLOATS 16384
 typedef struct loans_small_conv {
     int32_t k, stride, pad, outH, outW;
 } loans_small_conv;
 int loans_crop_dgrad_f32(const float* gy_a, const float* w_a, const loans_small_conv* ca, const float* gy_b, const float* w_b,
-                         const loans_small_conv* cb, float* out, const float* addend, int32_t B, int32_t H, int32_t W,
-                         int32_t C, void* stream);
+                         const loans_small_conv* cb, float* out, const float* addend, float* wpack, int32_t B, int32_t H,
+                         int32_t W, int32_t C, void* stream);
 /* same with bf16 gradient tensors (bf16-storage arm); weights, addend and gx fp32 */
 int loans_crop_dgrad_bf16_f32(const void* gy_a, const float* w_a, const loans_small_conv* ca, const void* gy_b, const float* w_b,
-                              const loans_small_conv* cb, float* out, const float* addend, int32_t B, int32_t H, int32_t W,
-                              int32_t C, void* stream);
+                              const loans_small_conv* cb, float* out, const float* addend, float* wpack, int32_t B, int32_t H,
+                              int32_t W, int32_t C, void* stream);
 
 /* weight repack for dgrad: dst[ci][t][co] = src[co][tapsel[t]][ci]  (src is OHWI with `src_taps` taps) */
 int loans_repack_dgrad_f32(const float* src, float* dst, int32_t Cout, int32_t Cin, int32_t src_taps,

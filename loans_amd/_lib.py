@@ -42,9 +42,9 @@ _i32, _i64, _f32, _f64 = C.c_int32, C.c_int64, C.c_float, C.c_double
 # name -> argtypes, exactly the prototypes of include/loans_hip.h
 SIGNATURES = {
     'loans_crop_dgrad_f32': [C.c_void_p, C.c_void_p, C.POINTER(SmallConv), C.c_void_p, C.c_void_p, C.POINTER(SmallConv),
-                             C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p],
+                             C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p],
     'loans_crop_dgrad_bf16_f32': [C.c_void_p, C.c_void_p, C.POINTER(SmallConv), C.c_void_p, C.c_void_p, C.POINTER(SmallConv),
-                                  C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p],
+                                  C.c_void_p, C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_int32, C.c_void_p],
     'loans_igemm_f32': [_p, _p, _p, _p, _p, _p, _p, C.POINTER(IgemmDesc), _p],
     'loans_igemm_pair_f32': [_p, _p, _p, _p, _p, _p, _p, _i32, C.POINTER(IgemmDesc), _p],
     'loans_igemm_finalize_f32': [_p, _p, _p, _p, _p, _i32, _i64, _i32, _p],

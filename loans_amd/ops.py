@@ -649,7 +649,8 @@ def crop_dgrad_ok(geo_a, geo_b=None):
     for g in (geo_a, geo_b):
         if g is None:
             continue
-        ok = ok and g.Cin == 4 and not g.dense and g.k <= 4 and g.stride <= 2 and g.pad < g.k and g.Cout % 8 == 0
+        ok = ok and g.Cin == 4 and not g.dense and g.k <= 4 and g.stride <= 2 and g.pad < g.k and g.Cout == 128 \
+            and g.B * g.Ho * g.Wo * g.Cout * 4 < (1 << 31)
     if geo_b is not None:
         ok = ok and (geo_a.B, geo_a.H, geo_a.W, geo_a.Cout) == (geo_b.B, geo_b.H, geo_b.W, geo_b.Cout)
     return ok
@@ -669,8 +670,9 @@ def crop_dgrad(gy_a, w_a, geo_a, gy_b=None, w_b=None, geo_b=None, addend=None):
     mk = lambda g: _lib.SmallConv(g.k, g.stride, g.pad, g.Ho, g.Wo)      # noqa: E731
     ca, cb = mk(geo_a), (mk(geo_b) if geo_b is not None else None)
     fn = lib.loans_crop_dgrad_bf16_f32 if _is16(gy_a) else lib.loans_crop_dgrad_f32
+    wpack = torch.empty(16384, device=gy_a.device, dtype=torch.float32)          # LOANS_CROP_WPACK_FLOATS
     check(fn(_ptr(gy_a), _ptr(w_a), C.byref(ca), _ptr(gy_b), _ptr(w_b), C.byref(cb) if cb is not None else None,
-             _ptr(out), _ptr(addend), geo_a.B, geo_a.H, geo_a.W, geo_a.Cout, _stream()), 'loans_crop_dgrad')
+             _ptr(out), _ptr(addend), _ptr(wpack), geo_a.B, geo_a.H, geo_a.W, geo_a.Cout, _stream()), 'loans_crop_dgrad')
     return out
 
 
