@@ -99,6 +99,12 @@ typedef struct loans_igemm_desc {
                                   convolution -- a block stages the input rows of R output rows and the whole weight matrix in LDS
                                   once and feeds the fp32 MFMA from that image (stem.hip); LOANS_EINVAL for frame sizes it does not
                                   cover (R * Wo must be a multiple of 64 for an R in {4, 2, 1} dividing Ho, <= 448 pixels, <= 80 KB) */
+#define LOANS_TILE_HALO_128    11  /* loans_igemm_bf16s, stride-1 geometries (forward k x k / 1 and its data gradient, k <= 3, Cin % 64 == 0):
+                                      a block owns an 8 x 16 pixel tile x 128 output channels and stages the input halo image once
+                                      per 64-channel chunk -- a tap is an LDS window shift, not a gather (csrc/halo_bf16.hip) */
+#define LOANS_TILE_HALO_128x64 13  /* the same with 64 output channels per block */
+#define LOANS_TILE_HALO_128x64S 14 /* 8 x 16 pixels x 64 output channels, Cin = 64, single-buffered image: four blocks per CU */
+#define LOANS_TILE_HALO_256x64 12  /* 16 x 16 pixels x 64 output channels, Cin = 64 (one chunk): the res2 convolutions */
 #define LOANS_TILE_SPLITK(s) ((s) << 8) /* loans_igemm_f32, OR-ed onto a tile shape, s = 2..255: split-K for small grids (few tiles, long K:
                                   the deep layers at small batch, single-image inference).  Block (tile, i) contracts every s-th
                                   part of K and ADDS its raw partial tile to `out` with fp32 atomics: the caller zero-fills `out`

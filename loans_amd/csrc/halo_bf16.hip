@@ -1,0 +1,454 @@
+// Stride-1 convolutions on bf16 STORAGE with the input tile staged ONCE per channel chunk (LOANS_TILE_HALO_*, reached
+// through loans_igemm_bf16s): the forward 3x3 / 1 convolutions of the residual stages and of the assessor
+// (sheep/resnet.py:128-132,151-153, common/net.py:15,37,58-59) and their data gradients (the same geometry with the
+// transposed weights).
+//
+// Why: as an implicit GEMM (igemm_bf16.hip) every one of the nine taps gathers its own BM x 64 A tile from L2 -- nine times
+// the input through the L2 -> LDS path (2.4 GB per res2 convolution of BASELINE configs[2], 8.8 TB/s of a path that tops
+// out near 17 TB/s) and, per 1 KiB DMA piece, the tap-mask / address arithmetic that the stamps of DESIGN 7 found to bound
+// the loop.  Here a block owns a TH x TW tile of output pixels of ONE image and BN output channels; per 64-channel chunk it
+// stages the (TH + 2) x (TW + 2) halo image once (out-of-image pixels: out-of-range offsets, zeros), and the taps read
+// SHIFTED WINDOWS of that image: a tap is an LDS address offset, not a gather.  Per (chunk, tap) step only the BN x 64
+// weight tile streams in.  Same LDS-DMA + XOR-swizzle idiom, fragment reads, pipelined step loop, epilogue and flags as
+// igemm16_kernel; K is walked chunk-major (64 channels x all taps), so sums agree with that kernel to fp32 rounding,
+// bit for bit when Cin = 64.
+//   tile 8 x 16 x BN 128 (LOANS_TILE_HALO_128): A 2 x 23 KiB + B 2 x 16 KiB = 78 KiB, two blocks per CU
+//   tile 16 x 16 x BN 64 (LOANS_TILE_HALO_256x64, Cin = 64 only -- one chunk, one A buffer): A 41 KiB + B 2 x 8 KiB
+//   tile 8 x 16 x BN 64, one chunk (LOANS_TILE_HALO_128x64S, Cin = 64): 39 KiB, FOUR blocks per CU -- a Cin = 64 tile lives for
+//     nine steps only, so what hides its image load and its epilogue is other blocks, not its own pipeline
+#include "common.h"
+
+namespace {
+
+constexpr int BKH = 64;
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+
+struct Halo16Args {
+    const __bf16* in;
+    const __bf16* w;
+    __bf16* out;
+    const float* bias;
+    double* stats;
+    const __bf16* ref;
+    const __bf16* addend;
+    loans_igemm_desc d;
+    int Ktot, cchunks, tiles_y, tiles_x, tiles_n;
+    int nx, ny, dymin, dxmin, sdy, sdx;     // the taps are an ny x nx grid: dy = dy0 + row * sdy, dx = dx0 + col * sdx, sd = +-1
+    int HH, HW;                             // halo image of a tile: (TH + ny - 1) x (TW + nx - 1) pixels
+    unsigned in_bytes, w_bytes, out_bytes;
+};
+
+__device__ __forceinline__ int xcd_remap_h(int id, int nblk) {
+    const int q = nblk >> 3, r = nblk & 7, xcd = id & 7;
+    return (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (id >> 3);
+}
+__device__ __forceinline__ bf16x8_t relu8(bf16x8_t v) {
+    const s16x8_t z = {0, 0, 0, 0, 0, 0, 0, 0};
+    return __builtin_bit_cast(bf16x8_t, __builtin_elementwise_max(__builtin_bit_cast(s16x8_t, v), z));
+}
+__device__ __forceinline__ f32x4 lo4(bf16x8_t v) { return f32x4{(float)v[0], (float)v[1], (float)v[2], (float)v[3]}; }
+__device__ __forceinline__ f32x4 hi4(bf16x8_t v) { return f32x4{(float)v[4], (float)v[5], (float)v[6], (float)v[7]}; }
+
+template <int TH, int TW, int BN, bool ADB>
+constexpr size_t halo_stage_bytes() {
+    constexpr int apieces = ((TH + 2) * (TW + 2) + 7) / 8;
+    return (size_t)(ADB ? 2 : 1) * apieces * 1024 + (size_t)2 * BN * BKH * 2;
+}
+template <int TH, int TW, int BN, bool ADB>
+constexpr size_t halo_aux_bytes() {
+    constexpr size_t cs = (size_t)TH * TW * (BN + 4) * 4;
+    return halo_stage_bytes<TH, TW, BN, ADB>() > cs ? halo_stage_bytes<TH, TW, BN, ADB>() : cs;
+}
+template <int TH, int TW, int BN, bool ADB>
+constexpr size_t halo_lds_bytes() { return halo_aux_bytes<TH, TW, BN, ADB>() + (size_t)TH * TW * 4; }
+
+// ADB: the A image is double-buffered across channel chunks (false: a single chunk, Cin = 64)
+template <int TH, int TW, int BN, int WM, int WN, bool ADB, bool RELU>
+__global__ __launch_bounds__(256) void halo16_kernel(const Halo16Args a) {
+    constexpr int BM = TH * TW;
+    constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
+    constexpr int RB = BN / 32;
+    constexpr int NMMA = TM * TN;
+    constexpr int APIECES = ((TH + 2) * (TW + 2) + 7) / 8;     // 1 KiB pieces (8 halo pixels x 128 B) of one A image
+    constexpr int APW = (APIECES + 3) / 4;                     // per wave
+    constexpr int ABUF = APIECES * 8 * BKH;                    // elements per A buffer
+    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && TW == 16, "tile shape");
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __bf16* As = reinterpret_cast<__bf16*>(smem);              // [ADB ? 2 : 1][APIECES * 8][64]
+    __bf16* Bs = As + (ADB ? 2 : 1) * ABUF;                    // [2][BN][64]
+    unsigned* opix = reinterpret_cast<unsigned*>(smem + halo_aux_bytes<TH, TW, BN, ADB>());     // [BM] output byte offset, ~0u = none
+
+    const loans_igemm_desc& d = a.d;
+    const int tid = threadIdx.x;
+    int logical = xcd_remap_h(blockIdx.x, gridDim.x);
+    const int tn = logical % a.tiles_n; logical /= a.tiles_n;
+    const int tx = logical % a.tiles_x; logical /= a.tiles_x;
+    const int ty = logical % a.tiles_y;
+    const int b = logical / a.tiles_y;
+    const int y0 = ty * TH, x0 = tx * TW;
+    const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+
+    for (int m = tid; m < BM; m += 256) {
+        const int y = y0 + m / TW, x = x0 + m % TW;
+        opix[m] = (y < d.outH && x < d.outW) ? (unsigned)((b * d.outH + y) * d.outW + x) * (unsigned)d.Cout * 2u : 0xFFFFFFFFu;
+    }
+
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.in), 0, (int)a.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.w), 0, (int)a.w_bytes, 0x00020000);
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+    // ---- A image: piece pi = wave + 4 j holds halo pixels 8 pi .. 8 pi + 7; lane (pixel l >> 3, slot l & 7) fetches unit
+    // slot ^ key(pixel) of its pixel.  The source offsets are fixed for the block (only the channel chunk moves).
+    unsigned aoff[APW];
+#pragma unroll
+    for (int j = 0; j < APW; ++j) {
+        const int pi = wave + 4 * j;
+        const int q = pi * 8 + (lane >> 3);
+        const int qy = q / a.HW, qx = q - qy * a.HW;
+        const int iy = y0 + a.dymin + qy, ix = x0 + a.dxmin + qx;
+        const bool ok = pi < APIECES && qy < a.HH && (unsigned)iy < (unsigned)d.inH && (unsigned)ix < (unsigned)d.inW;
+        const int unit = (lane & 7) ^ ((q >> 1) & 7);
+        aoff[j] = ok ? (unsigned)((b * d.inH + iy) * d.inW + ix) * (unsigned)d.Cin * 2u + (unsigned)unit * 16u : 0x80000000u;
+    }
+    auto dma_a = [&](int buf, int j, int cc) {
+        if (wave_u + 4 * j < APIECES)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(As + buf * ABUF + (wave_u + 4 * j) * 8 * BKH), 16,
+                                                     (int)(aoff[j] + (unsigned)cc * 128u), 0, 0, 0);
+    };
+    // ---- B tile of a step: rows n = tn BN + 32 i + 8 wave + (lane >> 3), unit (lane & 7) ^ key(row); k = tap Cin + 64 cc
+    const int lrow = tid >> 3;
+    const int lu = (tid & 7) ^ ((tid >> 4) & 7);
+    unsigned woff[RB];
+#pragma unroll
+    for (int i = 0; i < RB; ++i) {
+        const int n = tn * BN + lrow + 32 * i;
+        woff[i] = n < d.Cout ? (unsigned)n * (unsigned)a.Ktot * 2u + (unsigned)lu * 16u : 0x80000000u;
+    }
+    auto dma_b = [&](int buf, int i, unsigned kbytes) {
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(Bs + (buf * BN + 32 * i + 8 * wave_u) * BKH), 16,
+                                                 (int)(woff[i] + kbytes), 0, 0, 0);
+    };
+
+    // ---- fragments: A row = tile pixel m = (wm TM + i) 32 + r at halo position (m / TW, m % TW) + the tap's shift
+    const int wm = wave / WN, wn = wave % WN;
+    int q0[TM];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+        const int m = (wm * TM + i) * 32 + r;
+        q0[i] = (m / TW) * a.HW + (m % TW);
+    }
+    const int fkey = (r >> 1) & 7;
+    const int fragB = (wn * TN * 32 + r) * BKH + ((h ^ fkey) & 7) * 8;
+    auto read_frag = [&](int abuf, int bbuf, int tq, int s, bf16x8_t (&af)[TM], bf16x8_t (&bf)[TN]) {
+        const __bf16* Ab = As + abuf * ABUF;
+        const __bf16* Bb = Bs + bbuf * BN * BKH + (fragB ^ (s * 16));
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int q = q0[i] + tq;
+            af[i] = *reinterpret_cast<const bf16x8_t*>(Ab + ((q * BKH + ((h ^ (q >> 1)) & 7) * 8) ^ (s * 16)));
+        }
+#pragma unroll
+        for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const bf16x8_t*>(Bb + j * 32 * BKH);
+    };
+    auto relu_frag = [&](bf16x8_t (&af)[TM]) {
+        if constexpr (RELU) {
+#pragma unroll
+            for (int i = 0; i < TM; ++i) af[i] = relu8(af[i]);
+        }
+    };
+
+    f32x16 acc[TM][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+    auto mma_one = [&](int q, const bf16x8_t (&af)[TM], const bf16x8_t (&bf)[TN]) {
+        const int i = q / TN, j = q % TN;
+        acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    };
+    auto mma = [&](const bf16x8_t (&af)[TM], const bf16x8_t (&bf)[TN]) {
+#pragma unroll
+        for (int q = 0; q < NMMA; ++q) mma_one(q, af, bf);
+    };
+
+    // ---- step state (wave-uniform): tap (row tr, column tc of the tap grid), channel chunk cc
+    const int ntaps = d.ntaps;
+    auto tap_shift = [&](int tr, int tc) {      // halo shift of tap (tr, tc) in pixels
+        const int ry = a.sdy > 0 ? tr : a.ny - 1 - tr, rx = a.sdx > 0 ? tc : a.nx - 1 - tc;
+        return ry * a.HW + rx;
+    };
+    int t = 0, tr = 0, tc = 0, cc = 0;            // current step
+    int tn_ = 0, trn = 0, tcn = 0, ccn = 0;       // next step
+    auto next_of = [&](int& tt, int& r_, int& c_, int& ch) {
+        ++tt; ++c_;
+        if (c_ == a.nx) { c_ = 0; ++r_; }
+        if (tt == ntaps) { tt = 0; r_ = 0; c_ = 0; ++ch; }
+    };
+    next_of(tn_, trn, tcn, ccn);
+    const int nsteps = a.cchunks * ntaps;
+
+    // the DMA pieces of a step: the RB weight pieces of the NEXT step, and (double-buffered A) this step's share of the
+    // APW pieces of the next chunk's image
+    constexpr int APS = ADB ? (APW + 8) / 9 : 0;            // A pieces per step so that 9 steps cover APW (fewer taps: see below)
+    constexpr int NPIECE = RB + APS;
+    constexpr int PPG = (NPIECE + 2 * NMMA - 1) / (2 * NMMA);
+    auto dma_piece = [&](int p, int step) {
+        if (p < RB) {
+            dma_b((step + 1) & 1, p, (unsigned)((tn_ * d.Cin + ccn * BKH) * 2));
+        } else if (ADB && p < NPIECE) {
+            if (cc + 1 < a.cchunks) {
+                // piece j of the next image at tap t: j = t * APS + (p - RB); with fewer than 9 taps the rest goes out at the
+                // last tap
+                const int j0 = t * APS + (p - RB);
+                if (j0 < APW) dma_a((cc + 1) & 1, j0, cc + 1);
+                if (t == ntaps - 1 && (p - RB) == APS - 1)
+                    for (int j = ntaps * APS; j < APW; ++j) dma_a((cc + 1) & 1, j, cc + 1);
+            }
+        }
+    };
+
+    // ---- prologue: image of chunk 0 and weights of step 0
+#pragma unroll
+    for (int j = 0; j < APW; ++j) dma_a(0, j, 0);
+#pragma unroll
+    for (int i = 0; i < RB; ++i) dma_b(0, i, 0u);
+    __syncthreads();
+    bf16x8_t fa0[TM], fb0[TN], fa1[TM], fb1[TN];
+    int tq = tap_shift(0, 0);
+    read_frag(0, 0, tq, 0, fa0, fb0);
+    int step = 0;
+    for (; step + 1 < nsteps; ++step) {
+        const int abuf = ADB ? (cc & 1) : 0, bbuf = step & 1;
+        read_frag(abuf, bbuf, tq, 1, fa1, fb1);
+        relu_frag(fa0);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < NMMA; ++q) {
+            mma_one(q, fa0, fb0);
+#pragma unroll
+            for (int p = q * PPG; p < (q + 1) * PPG; ++p) dma_piece(p, step);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        read_frag(abuf, bbuf, tq, 2, fa0, fb0);
+        relu_frag(fa1);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int q = 0; q < NMMA; ++q) {
+            mma_one(q, fa1, fb1);
+#pragma unroll
+            for (int p = (NMMA + q) * PPG; p < (NMMA + q + 1) * PPG; ++p) dma_piece(p, step);
+            __builtin_amdgcn_sched_barrier(0);
+        }
+        read_frag(abuf, bbuf, tq, 3, fa1, fb1);
+        relu_frag(fa0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        relu_frag(fa1);
+        __syncthreads();                        // the next step's weights (and, at a chunk's end, the next image) have landed
+        t = tn_; tr = trn; tc = tcn; cc = ccn;
+        next_of(tn_, trn, tcn, ccn);
+        tq = tap_shift(tr, tc);
+        read_frag(ADB ? (cc & 1) : 0, (step + 1) & 1, tq, 0, fa0, fb0);
+        __builtin_amdgcn_sched_barrier(0);
+        mma(fa1, fb1);
+        __builtin_amdgcn_sched_barrier(0);
+    }
+    {   // last step
+        const int abuf = ADB ? (cc & 1) : 0, bbuf = step & 1;
+        read_frag(abuf, bbuf, tq, 1, fa1, fb1);
+        relu_frag(fa0);
+        mma(fa0, fb0);
+        read_frag(abuf, bbuf, tq, 2, fa0, fb0);
+        relu_frag(fa1);
+        mma(fa1, fb1);
+        read_frag(abuf, bbuf, tq, 3, fa1, fb1);
+        relu_frag(fa0);
+        mma(fa0, fb0);
+        relu_frag(fa1);
+        mma(fa1, fb1);
+    }
+
+    // ---- epilogue (as igemm16_kernel): BN statistics from the fp32 accumulators, tile staged through LDS in fp32, every lane
+    // converts and stores 8 contiguous channels
+    const bool f_bias = d.flags & LOANS_F_BIAS, f_stats = d.flags & LOANS_F_STATS;
+    const bool f_mask = d.flags & LOANS_F_MASK, f_add = d.flags & LOANS_F_ADDEND;
+    const bool f_addmask = d.flags & LOANS_F_ADDEND_MASK;
+    constexpr int LDC = BN + 4;
+    float* Cs = reinterpret_cast<float*>(smem);
+    __syncthreads();
+    if (f_stats) {
+        int nvalid = 0;
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                nvalid += opix[wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h] != 0xFFFFFFFFu;
+        const float cnt = (float)nvalid;
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+            const int col = tn * BN + wn * TN * 32 + j * 32 + r;
+            const bool cok = col < d.Cout;
+            const float bvv = (f_bias && cok) ? a.bias[col] : 0.f;
+            float s = 0.f, q2 = 0.f;
+#pragma unroll
+            for (int i = 0; i < TM; ++i)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    // rows beyond the image hold sums of zeros only if their A rows were zero: they are (out-of-range pixels
+                    // of the halo image), but a ragged tile's rows are real pixels of the NEXT tile -- mask them here
+                    const bool live = opix[wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h] != 0xFFFFFFFFu;
+                    const float v = live ? acc[i][j][e] : 0.f;
+                    s += v;
+                    q2 += v * v;
+                }
+            q2 = q2 + 2.f * bvv * s + cnt * bvv * bvv;
+            s = s + cnt * bvv;
+            s += __shfl_xor(s, 32, 64);
+            q2 += __shfl_xor(q2, 32, 64);
+            if (h == 0 && cok) {
+                double* st = a.stats + (size_t)(blockIdx.x % LOANS_STATS_REPLICAS) * 2 * d.Cout;
+                atomic_add_f64(st + col, (double)s);
+                atomic_add_f64(st + d.Cout + col, (double)q2);
+            }
+        }
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                Cs[(wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * LDC + wn * TN * 32 + j * 32 + r] = acc[i][j][e];
+    __syncthreads();
+
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)a.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_ref = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<__bf16*>(a.ref ? a.ref : a.out), 0, (int)a.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_add = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<__bf16*>(a.addend ? a.addend : a.out), 0, (int)a.out_bytes, 0x00020000);
+    constexpr int CPR = BN / 8;
+    constexpr int RSTEP = 256 / CPR;
+    const int oc8 = tid % CPR, r0 = tid / CPR;
+    const int col0 = tn * BN + oc8 * 8;
+    const unsigned cbad = (col0 + 7 < d.Cout) ? 0u : 0xFFFFFFFFu;
+    const unsigned coff = (unsigned)col0 * 2u;
+    f32x4 b_lo = {0.f, 0.f, 0.f, 0.f}, b_hi = b_lo;
+    if (f_bias && !cbad) {
+        b_lo = *reinterpret_cast<const f32x4*>(a.bias + col0);
+        b_hi = *reinterpret_cast<const f32x4*>(a.bias + col0 + 4);
+    }
+    auto keep_pos = [](f32x4 v, f32x4 m) {
+        v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
+        v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+        return v;
+    };
+#pragma unroll
+    for (int p = 0; p < BM / RSTEP; ++p) {
+        const int row = r0 + p * RSTEP;
+        const unsigned po = opix[row];
+        const unsigned off = (po + coff) | (po == 0xFFFFFFFFu ? 0xFFFFFFFFu : 0u) | cbad;
+        f32x4 lo = *reinterpret_cast<const f32x4*>(Cs + row * LDC + oc8 * 8) + b_lo;
+        f32x4 hi = *reinterpret_cast<const f32x4*>(Cs + row * LDC + oc8 * 8 + 4) + b_hi;
+        if (f_mask || f_addmask) {
+            const bf16x8_t rf = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_ref, (int)off, 0, 0));
+            const f32x4 rl = lo4(rf), rh = hi4(rf);
+            if (f_mask) { lo = keep_pos(lo, rl); hi = keep_pos(hi, rh); }
+            if (f_add) {
+                const bf16x8_t ad = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_add, (int)off, 0, 0));
+                f32x4 al = lo4(ad), ah = hi4(ad);
+                if (f_addmask) { al = keep_pos(al, rl); ah = keep_pos(ah, rh); }
+                lo += al; hi += ah;
+            }
+        } else if (f_add) {
+            const bf16x8_t ad = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_add, (int)off, 0, 0));
+            lo += lo4(ad); hi += hi4(ad);
+        }
+        bf16x8_t o;
+        const bf16x4_t ol = __builtin_convertvector(lo, bf16x4_t), oh = __builtin_convertvector(hi, bf16x4_t);
+        o[0] = ol[0]; o[1] = ol[1]; o[2] = ol[2]; o[3] = ol[3];
+        o[4] = oh[0]; o[5] = oh[1]; o[6] = oh[2]; o[7] = oh[3];
+        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_out, (int)off, 0, 0);
+    }
+}
+
+template <int TH, int TW, int BN, int WM, int WN, bool ADB, bool RELU>
+int launch_halo_r(Halo16Args& a, hipStream_t st) {
+    static loans_device_once lds_limit_set;
+    constexpr size_t lds = halo_lds_bytes<TH, TW, BN, ADB>();
+    static_assert(lds <= 80 * 1024, "two blocks per CU");
+    auto kern = halo16_kernel<TH, TW, BN, WM, WN, ADB, RELU>;
+    if (int rc_ = loans_raise_lds_limit(lds_limit_set, reinterpret_cast<const void*>(kern), lds)) return rc_;
+    a.tiles_y = (a.d.outH + TH - 1) / TH;
+    a.tiles_x = (a.d.outW + TW - 1) / TW;
+    a.tiles_n = (a.d.Cout + BN - 1) / BN;
+    a.HH = TH + a.ny - 1;
+    a.HW = TW + a.nx - 1;
+    const int64_t nblk = (int64_t)a.d.B * a.tiles_y * a.tiles_x * a.tiles_n;
+    if (nblk >= ((int64_t)1 << 31)) return LOANS_ERANGE;
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, a);
+    LOANS_LAUNCH_CHECK();
+    return LOANS_OK;
+}
+
+template <int TH, int TW, int BN, int WM, int WN, bool ADB>
+int launch_halo(Halo16Args& a, hipStream_t st) {
+    return (a.d.flags & LOANS_F_RELU_IN) ? launch_halo_r<TH, TW, BN, WM, WN, ADB, true>(a, st)
+                                         : launch_halo_r<TH, TW, BN, WM, WN, ADB, false>(a, st);
+}
+
+}  // namespace
+
+// 1 if the descriptor is a geometry the halo kernels cover (the caller -- loans_igemm_bf16s -- has validated everything else)
+int loans_halo16_covers(const loans_igemm_desc* d, int tile) {
+    if (d->flags & LOANS_F_DENSE) return 0;
+    if (d->isy != 1 || d->isx != 1 || d->osy != 1 || d->osx != 1 || d->oy0 || d->ox0) return 0;
+    if (d->gridH != d->outH || d->gridW != d->outW) return 0;
+    if (d->Cin % 64 || d->ntaps > 9) return 0;
+    if ((tile == LOANS_TILE_HALO_256x64 || tile == LOANS_TILE_HALO_128x64S) && d->Cin != 64) return 0;
+    int nx = 1;
+    while (nx < d->ntaps && d->dy[nx] == d->dy[0]) ++nx;
+    if (d->ntaps % nx) return 0;
+    const int ny = d->ntaps / nx;
+    if (nx > 3 || ny > 3) return 0;
+    const int sdx = nx > 1 ? d->dx[1] - d->dx[0] : 1, sdy = ny > 1 ? d->dy[nx] - d->dy[0] : 1;
+    if ((sdx != 1 && sdx != -1) || (sdy != 1 && sdy != -1)) return 0;
+    for (int t = 0; t < d->ntaps; ++t)
+        if (d->dy[t] != d->dy[0] + (t / nx) * sdy || d->dx[t] != d->dx[0] + (t % nx) * sdx) return 0;
+    return 1;
+}
+
+int loans_halo16_launch(const void* in, const void* w, void* out, const float* bias, double* stats, const void* ref,
+                        const void* addend, const loans_igemm_desc* d, int tile, unsigned in_bytes, unsigned w_bytes,
+                        unsigned out_bytes, hipStream_t st) {
+    if (!loans_halo16_covers(d, tile)) return LOANS_EINVAL;
+    Halo16Args a;
+    a.in = static_cast<const __bf16*>(in); a.w = static_cast<const __bf16*>(w); a.out = static_cast<__bf16*>(out);
+    a.bias = bias; a.stats = stats;
+    a.ref = static_cast<const __bf16*>(ref); a.addend = static_cast<const __bf16*>(addend);
+    a.d = *d;
+    a.Ktot = d->ntaps * d->Cin;
+    a.cchunks = d->Cin / BKH;
+    a.in_bytes = in_bytes; a.w_bytes = w_bytes; a.out_bytes = out_bytes;
+    if (in_bytes >= 0x80000000u || w_bytes >= 0x80000000u) return LOANS_ERANGE;       // offsets >= 2^31 mean "no load" here
+    int nx = 1;
+    while (nx < d->ntaps && d->dy[nx] == d->dy[0]) ++nx;
+    a.nx = nx; a.ny = d->ntaps / nx;
+    a.sdx = nx > 1 ? d->dx[1] - d->dx[0] : 1;
+    a.sdy = a.ny > 1 ? d->dy[nx] - d->dy[0] : 1;
+    a.dymin = a.sdy > 0 ? d->dy[0] : d->dy[0] - (a.ny - 1);
+    a.dxmin = a.sdx > 0 ? d->dx[0] : d->dx[0] - (a.nx - 1);
+    switch (tile) {
+        case LOANS_TILE_HALO_128: return launch_halo<8, 16, 128, 2, 2, true>(a, st);
+        case LOANS_TILE_HALO_128x64: return launch_halo<8, 16, 64, 4, 1, true>(a, st);
+        case LOANS_TILE_HALO_256x64: return launch_halo<16, 16, 64, 4, 1, false>(a, st);
+        case LOANS_TILE_HALO_128x64S: return launch_halo<8, 16, 64, 4, 1, false>(a, st);
+        default: return LOANS_EINVAL;
+    }
+}

@@ -814,6 +814,11 @@ extern "C" int loans_igemm_bf16s(const void* in, const void* w, void* out, const
         case LOANS_TILE_64x64: return launch_igemm16<64, 64, 2, 2>(a, st);
         case LOANS_TILE_256x64: return launch_igemm16<256, 64, 4, 1>(a, st);
         case LOANS_TILE_256x128: return launch_igemm16<256, 128, 2, 2>(a, st);
+        case LOANS_TILE_HALO_128:
+        case LOANS_TILE_HALO_128x64:
+        case LOANS_TILE_HALO_256x64:
+        case LOANS_TILE_HALO_128x64S:
+            return loans_halo16_launch(in, w, out, bias, stats, ref, addend, d, tile, a.in_bytes, a.w_bytes, a.out_bytes, st);
         default: return LOANS_EINVAL;
     }
 }

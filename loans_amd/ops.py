@@ -272,6 +272,20 @@ _IGEMM_TILES = tuple(int(t) for t in os.environ.get('LOANS_DGRAD_TILES', '1,2,3,
 _WGRAD_TILES = (1, 3, 5)
 _WGRAD16_TILES = (1, 3, 5)
 _IGEMM16_TILES = tuple(int(t) for t in os.environ.get('LOANS_BF16S_TILES', '1,2,3,4,7').split(','))
+# LOANS_TILE_HALO_* (csrc/halo_bf16.hip): stride-1 convolutions with the input tile staged once per 64-channel chunk
+TILE_HALO_128, TILE_HALO_256x64, TILE_HALO_128x64, TILE_HALO_128x64S = 11, 12, 13, 14
+HALO = os.environ.get('LOANS_HALO', '1') != '0'
+
+
+def _halo_tiles(geo, gathered_channels, out_channels, out_hw):
+    """halo-tile candidates of a bf16-storage convolution / data gradient (the conditions of loans_halo16_covers), offered
+    where a 8 x 16 pixel tile is not mostly empty"""
+    if not HALO or geo.dense or geo.stride != 1 or geo.k > 3 or gathered_channels % 64 or min(out_hw) < 6 or out_hw[1] < 12:
+        return ()
+    tiles = (TILE_HALO_128, TILE_HALO_128x64) if out_channels > 64 else (TILE_HALO_128x64,)
+    if gathered_channels == 64 and out_channels <= 64:
+        tiles += (TILE_HALO_128x64S,) + ((TILE_HALO_256x64,) if min(out_hw) >= 12 else ())
+    return tiles
 
 
 def _time_call(fn, reps=5):
@@ -519,7 +533,9 @@ def _conv_fprop16(lib, x, w, geo, out, bias, stats, relu_in, addend, tile):
             scratch = torch.empty((geo.B, geo.Ho, geo.Wo, geo.Cout), device=x.device, dtype=BF16)
             check(lib.loans_igemm_bf16s(_ptr(x), _ptr(w16), _ptr(scratch), 0, _ptr(sstats), 0, 0,
                                         C.byref(_with_flags(geo.fwd, tflags, t)), _stream()), 'loans_igemm_bf16s[tune]')
-        tile = _tuned_tile(geo, 'bf16s_fprop' + ('_stats' if stats is not None else ''), run, _IGEMM16_TILES)
+        halo = _halo_tiles(geo, geo.Cin, geo.Cout, (geo.Ho, geo.Wo))
+        tile = _tuned_tile(geo, 'bf16s_fprop' + ('_stats' if stats is not None else '') + ('_h' if halo else ''), run,
+                           _IGEMM16_TILES + halo)
     d = _with_flags(geo.fwd, flags, tile)
     _count_flops('fprop', geo)
     log = EVENT_LOG
@@ -562,7 +578,8 @@ def _conv_dgrad16(lib, gy, w, geo, out, mask_ref, addend, addend_mask_ref, tile)
             for d, _, off in geo.dgrad:
                 check(lib.loans_igemm_bf16s(_ptr(gy), _ptr(wp[off:]), _ptr(scratch), 0, 0, 0, 0,
                                             C.byref(_with_flags(d, 0, t)), st), 'loans_igemm_bf16s[tune]')
-        tile = _tuned_tile(geo, 'bf16s_dgrad', run, _IGEMM16_TILES)
+        halo = _halo_tiles(geo, geo.Cout, geo.Cin, (geo.H, geo.W))
+        tile = _tuned_tile(geo, 'bf16s_dgrad' + ('_h' if halo else ''), run, _IGEMM16_TILES + halo)
     for d, tapsel, off in geo.dgrad:
         _with_flags(d, flags, tile)
         check(lib.loans_igemm_bf16s(_ptr(gy), _ptr(wp[off:]), _ptr(out), 0, 0, _ptr(ref), _ptr(addend),

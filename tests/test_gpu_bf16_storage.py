@@ -249,3 +249,72 @@ def test_assessor_edges_bf16_storage():
     gx16 = ops.linear_bwd(d16(x), dev(Wl), y16, dev(gyl), gW=gW16, act_in=True, act_out=True)
     assert gx16.dtype == torch.bfloat16 and torch.equal(gx16, gx32.to(torch.bfloat16))
     assert torch.allclose(gW16, gW32, rtol=1e-5, atol=1e-6)
+
+
+HALO_CASES = [
+    # B, Cin, H, W, Cout, k, pad
+    (3, 64, 14, 14, 64, 3, 1),       # res2-like, one tile row ragged
+    (2, 64, 33, 21, 64, 3, 1),       # several tiles per image, ragged both ways
+    (2, 128, 16, 16, 128, 3, 1),     # two channel chunks, exact tiles
+    (2, 256, 9, 19, 192, 3, 1),      # four chunks, Cout not a multiple of the tile
+    (2, 128, 18, 18, 128, 3, 1),     # the assessor's r2 / r3 geometry
+    (2, 64, 12, 17, 128, 1, 0),      # 1x1: no halo
+    (1, 64, 40, 48, 64, 3, 1),       # 16 x 16 tiles, three per row
+]
+
+
+@pytest.mark.parametrize("case", HALO_CASES)
+@pytest.mark.parametrize("tile", [11, 12, 13, 14])
+def test_conv_halo_tiles_bf16_storage(case, tile):
+    """LOANS_TILE_HALO_* (csrc/halo_bf16.hip): stride-1 convolutions and their data gradients with the input tile staged once
+    per 64-channel chunk -- against the oracle on the bf16-rounded operands and against the implicit-GEMM tile (bit for bit
+    where K is one chunk per tap, Cin = 64; to the position of rare roundings otherwise), with every epilogue flag."""
+    from loans_amd import ops
+    B, Cin, H, W, Cout, k, p = case
+    if tile in (12, 14) and Cin != 64:
+        pytest.skip('one-chunk (Cin = 64) forms')
+    rng = np.random.RandomState(11)
+    x = _r(rng.standard_normal((B, Cin, H, W)))
+    w = (rng.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
+    wr = _r(w)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    geo = ops.ConvGeometry(B, H, W, Cin, Cout, k, 1, p)
+    xd, wd = d16(_nhwc(x)), dev(_nhwc(w))
+    y_ref, col = C.conv2d_fwd(x.astype(np.float64), wr.astype(np.float64), b.astype(np.float64), 1, p)
+
+    def same(a, b_, exact):
+        if exact:
+            assert torch.equal(a, b_)
+        else:       # another fp32 summation order under one bf16 rounding: a few results land on the neighbouring bf16 value
+            assert float((a != b_).float().mean()) < 0.02
+            assert rel_err(a.float().cpu().numpy(), b_.float().cpu().numpy()) < BF16_EPS
+    exact_f = Cin == 64
+    s_h, s_g = ops.stats_buffer(Cout, 'cuda'), ops.stats_buffer(Cout, 'cuda')
+    y = ops.conv_fprop(xd, wd, geo, bias=dev(b), stats=s_h, tile=tile)
+    y_g = ops.conv_fprop(xd, wd, geo, bias=dev(b), stats=s_g, tile=1)
+    assert y.dtype == torch.bfloat16 and rel_err(_nchw(y), y_ref) < BF16_EPS
+    same(y, y_g, exact_f)
+    np.testing.assert_allclose(s_h.sum(0).cpu().numpy(), s_g.sum(0).cpu().numpy(), rtol=1e-6, atol=1e-4)
+    np.testing.assert_allclose(s_h.sum(0).cpu().numpy()[0], y_ref.sum(axis=(0, 2, 3)), rtol=1e-4, atol=1e-3)
+    add = _r(rng.standard_normal(y_ref.shape))
+    y3 = ops.conv_fprop(xd, wd, geo, relu_in=True, addend=d16(_nhwc(add)), tile=tile)
+    y3_ref = C.conv2d_fwd(np.maximum(x, 0).astype(np.float64), wr.astype(np.float64), None, 1, p)[0] + add
+    assert rel_err(_nchw(y3), y3_ref) < BF16_EPS
+    same(y3, ops.conv_fprop(xd, wd, geo, relu_in=True, addend=d16(_nhwc(add)), tile=1), exact_f)
+
+    # data gradient: the gathered tensor is gy (Cout channels), the "output channels" are Cin
+    if Cout % 64 or (tile in (12, 14) and Cout != 64):
+        return
+    gy = _r(rng.standard_normal(y_ref.shape))
+    gx_ref = C.conv2d_bwd(x.shape, col, wr.astype(np.float64), gy.astype(np.float64), 1, p, False)[0]
+    gyd = d16(_nhwc(gy))
+    exact_d = Cout == 64
+    gx = ops.conv_dgrad(gyd, wd, geo, tile=tile)
+    assert rel_err(_nchw(gx), gx_ref) < BF16_EPS
+    same(gx, ops.conv_dgrad(gyd, wd, geo, tile=1), exact_d)
+    ref_t, addx = _r(rng.standard_normal(x.shape)), _r(rng.standard_normal(x.shape))
+    gx2 = ops.conv_dgrad(gyd, wd, geo, mask_ref=d16(_nhwc(ref_t)), addend=d16(_nhwc(addx)), tile=tile)
+    assert rel_err(_nchw(gx2), gx_ref * (ref_t > 0) + addx) < BF16_EPS
+    gx3 = ops.conv_dgrad(gyd, wd, geo, addend=d16(_nhwc(addx)), addend_mask_ref=d16(_nhwc(ref_t)), tile=tile)
+    assert rel_err(_nchw(gx3), gx_ref + addx * (ref_t > 0)) < BF16_EPS
+    same(gx3, ops.conv_dgrad(gyd, wd, geo, addend=d16(_nhwc(addx)), addend_mask_ref=d16(_nhwc(ref_t)), tile=1), exact_d)
