@@ -49,6 +49,7 @@ import torch                # noqa: E402
 CONV_FWD_FLOP_PER_IMAGE_224 = 4166615040        # 21 conv contractions, 2 FLOP per MAC
 FP32_MFMA_PEAK_TFLOPS = 157.3                   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 BF16_MFMA_PEAK_TFLOPS = 2500.0                  # MI355X_MICROARCH.md: dense bf16 MFMA (not the 2:1-sparsity figure)
+HBM_ACHIEVABLE_TBS = 6.3                        # MI355X_MICROARCH.md: what a streaming kernel reaches of the 8 TB/s spec
 
 
 def parse():
@@ -246,9 +247,9 @@ def main():
     # ---- conv-forward roofline from the events of the timed steps ----
     roofline = None
     if log:
-        log = [tuple(x) + (1,) * (6 - len(x)) for x in log]          # (tag, flops, ev0, ev1, launches, convolutions)
-        loc = [(tag, flops, max(s.elapsed_time(e) - ev_overhead_ms, 0.0), nl, nc) for tag, flops, s, e, nl, nc in log if tag == 'fprop_bn']
-        raw_ms = sum(s.elapsed_time(e) for tag, flops, s, e, nl, nc in log if tag == 'fprop_bn')
+        log = [(tuple(x) + (1, 1, 0))[:7] if len(x) < 7 else tuple(x) for x in log]   # (tag, flops, ev0, ev1, launches, convolutions, bytes)
+        loc = [(tag, flops, max(s.elapsed_time(e) - ev_overhead_ms, 0.0), nl, nc, nb) for tag, flops, s, e, nl, nc, nb in log if tag == 'fprop_bn']
+        raw_ms = sum(s.elapsed_time(e) for tag, flops, s, e, nl, nc, nb in log if tag == 'fprop_bn')
         tot_ms = sum(x[2] for x in loc)
         tot_flop = sum(x[1] for x in loc)
         n_launch = sum(x[3] for x in loc)          # a LOANS_TILE_SPLIT conv is two launches
@@ -264,6 +265,33 @@ def main():
                     "event_pair_overhead_us": round(ev_overhead_ms * 1e3, 2),
                     "algorithmic_flop_per_step": tot_flop // args.steps}
         roofline["launches_per_step"] = n_launch // args.steps
+        # The same launches against the roofline that BINDS each of them: a layer cannot run faster than its algorithmic
+        # bytes at the achievable HBM rate, nor than its algorithmic FLOP at the MFMA peak.  In fp32 every layer is MFMA-bound
+        # (205 FLOP/B against a balance of 25); in bf16 the stem and res2 are HBM-bound, so grading them against
+        # the MFMA peak alone would ask the impossible of them.
+        per = {}
+        for tag, flops, ms, nl, nc, nb in loc:
+            key = (flops, nb)
+            e = per.setdefault(key, [0, 0.0])
+            e[0] += 1
+            e[1] += ms
+        t_bound = t_meas = 0.0
+        n_hbm = 0
+        layers = []
+        for (flops, nb), (cnt, ms) in sorted(per.items(), key=lambda kv: -kv[1][1]):
+            t_f, t_b = flops / (peak * 1e12) * 1e3, nb / (HBM_ACHIEVABLE_TBS * 1e12) * 1e3
+            bound_ms = max(t_f, t_b)
+            calls = cnt
+            t_bound += bound_ms * calls
+            t_meas += ms
+            n_hbm += calls if t_b > t_f else 0
+            layers.append({"gflop": round(flops / 1e9, 2), "mbytes": round(nb / 1e6, 1), "calls_per_step": calls // args.steps,
+                           "ms": round(ms / calls, 4), "bound": "hbm" if t_b > t_f else "mfma", "bound_ms": round(bound_ms, 4),
+                           "frac": round(bound_ms * calls / ms, 3)})
+        roofline["binding"] = {
+            "rule": "per launch max(algorithmic bytes / %.1f TB/s, algorithmic FLOP / %.0f TFLOP/s)" % (HBM_ACHIEVABLE_TBS, peak),
+            "frac": round(t_bound / max(t_meas, 1e-9), 4), "bound_ms_per_step": round(t_bound / args.steps, 3),
+            "hbm_bound_launches_per_step": n_hbm // args.steps, "layers": layers}
         # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE, separate
         # rocprofv3 runs of this same command on the SAME tile table, see --tune-file / tools/profile_round.sh).  The file
         # carries the launch count of its own pass: bytes are divided by THAT, and a file whose pass launched other

@@ -21,6 +21,7 @@ from ...ops import _ptr, _stream, check
 
 PRECISION_BITS = 32 - 8 - 2
 LANCZOS_SUPPORT = 3.0
+BILINEAR_SUPPORT = 1.0
 
 
 def _sinc(x):
@@ -36,14 +37,32 @@ def _lanczos(x):
     return 0.0
 
 
-@functools.lru_cache(maxsize=256)
+def _bilinear(x):
+    """libImaging/Resample.c bilinear_filter: the triangle on [-1, 1] (``Image.BILINEAR``, the reference's ``Image.LINEAR`` of
+    datasets/sheep/paste_and_crop_sheep.py:218 -- the old name of the same filter)"""
+    if x < 0.0:
+        x = -x
+    if x < 1.0:
+        return 1.0 - x
+    return 0.0
+
+
+_FILTERS = {'lanczos': (_lanczos, LANCZOS_SUPPORT), 'bilinear': (_bilinear, BILINEAR_SUPPORT)}
+
+
 def lanczos_coeffs(in_size, out_size):
+    return resample_coeffs(in_size, out_size, 'lanczos')
+
+
+@functools.lru_cache(maxsize=512)
+def resample_coeffs(in_size, out_size, filt='lanczos'):
     """(bounds int32 [out_size][2] = (first input index, taps), coefficients int32 [out_size][ksize], ksize) of one axis."""
+    filter_fn, filter_support = _FILTERS[filt]
     in0, in1 = 0.0, float(in_size)
     scale = filterscale = (in1 - in0) / out_size
     if filterscale < 1.0:
         filterscale = 1.0
-    support = LANCZOS_SUPPORT * filterscale
+    support = filter_support * filterscale
     ksize = int(math.ceil(support)) * 2 + 1
     bounds = np.zeros((out_size, 2), np.int32)
     kk = np.zeros((out_size, ksize), np.int32)
@@ -61,7 +80,7 @@ def lanczos_coeffs(in_size, out_size):
         xmax -= xmin
         k = [0.0] * xmax
         for x in range(xmax):
-            w = _lanczos((x + xmin - center + 0.5) * ss)
+            w = filter_fn((x + xmin - center + 0.5) * ss)
             k[x] = w
             ww += w
         for x in range(xmax):
@@ -74,18 +93,24 @@ def lanczos_coeffs(in_size, out_size):
 _tables = {}
 
 
-def _device_tables(in_size, out_size, device):
-    key = (in_size, out_size, device)
+def _device_tables(in_size, out_size, device, filt='lanczos'):
+    key = (in_size, out_size, device, filt)
     t = _tables.get(key)
     if t is None:
-        b, k, ks = lanczos_coeffs(in_size, out_size)
+        b, k, ks = resample_coeffs(in_size, out_size, filt)
         t = _tables[key] = (torch.from_numpy(b).to(device), torch.from_numpy(k).to(device), ks)
     return t
 
 
-def resize_lanczos(frames_u8, out_hw, as_float=True):
+def resize_bilinear(frames_u8, out_hw, as_float=True):
+    """Pillow's ``Image.resize(size, Image.BILINEAR)`` (the generator's final resize, paste_and_crop_sheep.py:218)"""
+    return resize_lanczos(frames_u8, out_hw, as_float, filt='bilinear')
+
+
+def resize_lanczos(frames_u8, out_hw, as_float=True, filt='lanczos'):
     """frames_u8: device uint8 tensor [B][H][W][3] (RGB).  Returns [B][3][oh][ow] float32 in [0,1] (= Pillow's LANCZOS
-    resize, then ``/ 255``) or, with ``as_float=False``, the resized uint8 [B][oh][ow][3]."""
+    resize, then ``/ 255``) or, with ``as_float=False``, the resized uint8 [B][oh][ow][3].  ``filt``: 'lanczos' | 'bilinear'
+    (the two passes are filter-agnostic: they apply the coefficient tables)."""
     if not (frames_u8.is_cuda and frames_u8.dtype == torch.uint8 and frames_u8.is_contiguous() and frames_u8.dim() == 4
             and frames_u8.shape[3] == 3):
         raise ValueError('frames must be a contiguous device uint8 tensor [B][H][W][3]')
@@ -99,8 +124,8 @@ def resize_lanczos(frames_u8, out_hw, as_float=True):
         out = torch.empty((B, 3, oh, ow), device=dev, dtype=torch.float32)
         check(lib.loans_u8hwc3_to_f32chw(_ptr(frames_u8), _ptr(out), B, H, W, _stream()), 'loans_u8hwc3_to_f32chw')
         return out
-    hb, hk, hks = _device_tables(W, ow, dev)
-    vb, vk, vks = _device_tables(H, oh, dev)
+    hb, hk, hks = _device_tables(W, ow, dev, filt)
+    vb, vk, vks = _device_tables(H, oh, dev, filt)
     tmp = torch.empty((B, H, ow, 3), device=dev, dtype=torch.uint8)
     if as_float:
         out = torch.empty((B, 3, oh, ow), device=dev, dtype=torch.float32)

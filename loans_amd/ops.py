@@ -70,6 +70,13 @@ EVENT_LOG = None
 FLOP_COUNT = None
 
 
+def _conv_bytes(geo, x, w, out):
+    """ALGORITHMIC HBM bytes of one forward convolution: its input, its weights and its output once each, in the types they
+    are stored in (x = None: the input is shared with a convolution already counted)"""
+    n = 0 if x is None else x.numel() * x.element_size()
+    return n + w.numel() * w.element_size() + out.numel() * out.element_size()
+
+
 def _count_flops(kind, geo):
     if FLOP_COUNT is not None:
         FLOP_COUNT[kind] = FLOP_COUNT.get(kind, 0) + 2 * geo.B * geo.Ho * geo.Wo * geo.Cout * geo.k * geo.k * geo.cin_logical
@@ -470,7 +477,7 @@ def conv_fprop(x, w, geo, out=None, bias=None, stats=None, relu_in=False, addend
         log.append(('fprop_bn' if stats is not None else 'fprop',
                     2 * geo.B * geo.Ho * geo.Wo * geo.Cout * geo.k * geo.k * geo.cin_logical, ev0, ev1,
                     _igemm_launches(geo.B * geo.Ho * geo.Wo, geo.Cout, tile, x.device,
-                                    (geo.w_numel // geo.Cout + 31) // 32)))
+                                    (geo.w_numel // geo.Cout + 31) // 32), 1, _conv_bytes(geo, x, w, out)))
     return out
 
 
@@ -512,7 +519,8 @@ def conv_fprop_pair(x, w_a, w_b, geo_a, geo_b, stats_a=None, stats_b=None, tile=
     if log is not None:
         ev1.record()
         fl = 2 * geo_a.B * geo_a.Ho * geo_a.Wo * (geo_a.Cout + geo_b.Cout) * geo_a.k * geo_a.k * geo_a.cin_logical
-        log.append(('fprop_bn' if flags else 'fprop', fl, ev0, ev1, 1, 2))        # one launch, two convolutions
+        log.append(('fprop_bn' if flags else 'fprop', fl, ev0, ev1, 1, 2,         # one launch, two convolutions
+                    _conv_bytes(geo_a, x, w_a, out_a) + _conv_bytes(geo_b, None, w_b, out_b)))
     return out_a, out_b
 
 
@@ -547,7 +555,8 @@ def _conv_fprop16(lib, x, w, geo, out, bias, stats, relu_in, addend, tile):
     if log is not None:
         ev1.record()
         log.append(('fprop_bn' if stats is not None else 'fprop',
-                    2 * geo.B * geo.Ho * geo.Wo * geo.Cout * geo.k * geo.k * geo.cin_logical, ev0, ev1, 1))
+                    2 * geo.B * geo.Ho * geo.Wo * geo.Cout * geo.k * geo.k * geo.cin_logical, ev0, ev1, 1, 1,
+                    _conv_bytes(geo, x, w16, out)))
     return out
 
 

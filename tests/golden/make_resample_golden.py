@@ -22,6 +22,8 @@ def main():
             a = np.asarray(Image.fromarray(a).resize((W, H), Image.BILINEAR).resize((W // 2 + 1, H // 2 + 1)).resize((W, H)))
         out['src_%d' % n] = a
         out['dst_%d' % n] = np.asarray(Image.fromarray(a).resize((ow, oh), Image.LANCZOS))
+        # the generator's final resize (datasets/sheep/paste_and_crop_sheep.py:218: Image.LINEAR = today's Image.BILINEAR)
+        out['bil_%d' % n] = np.asarray(Image.fromarray(a).resize((ow, oh), Image.BILINEAR))
     path = os.path.join(os.path.dirname(os.path.abspath(__file__)), 'resample_lanczos.npz')
     np.savez_compressed(path, **out)
     print('Pillow', PIL.__version__, '->', path, os.path.getsize(path), 'bytes')

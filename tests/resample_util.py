@@ -3,11 +3,11 @@ be checked on a machine without a GPU)."""
 import numpy as np
 
 
-def two_pass_u8(a, oh, ow):
-    from loans_amd.common.datasets.resample import PRECISION_BITS, lanczos_coeffs
+def two_pass_u8(a, oh, ow, filt='lanczos'):
+    from loans_amd.common.datasets.resample import PRECISION_BITS, resample_coeffs
     H, W, _ = a.shape
-    hb, hk, _ = lanczos_coeffs(W, ow)
-    vb, vk, _ = lanczos_coeffs(H, oh)
+    hb, hk, _ = resample_coeffs(W, ow, filt)
+    vb, vk, _ = resample_coeffs(H, oh, filt)
     half = 1 << (PRECISION_BITS - 1)
     tmp = np.zeros((H, ow, 3), np.uint8)
     for xx in range(ow):

@@ -22,6 +22,8 @@ def test_kernels_reproduce_the_golden_vectors():
         np.testing.assert_array_equal(got, dst)
         gotf = resize_lanczos(x, dst.shape[:2])[0].cpu().numpy()
         np.testing.assert_array_equal(gotf, (dst.transpose(2, 0, 1).astype(np.float32) / 255))
+        from loans_amd.common.datasets.resample import resize_bilinear
+        np.testing.assert_array_equal(resize_bilinear(x, dst.shape[:2], as_float=False)[0].cpu().numpy(), g['bil_%d' % n])
         n += 1
     assert n >= 7
 
@@ -37,6 +39,9 @@ def test_kernels_against_installed_pillow(shape):
     x = torch.from_numpy(a).cuda()
     np.testing.assert_array_equal(resize_lanczos(x, (oh, ow), as_float=False).cpu().numpy(), ref)
     np.testing.assert_array_equal(resize_lanczos(x, (oh, ow)).cpu().numpy(), ref.transpose(0, 3, 1, 2).astype(np.float32) / 255)
+    from loans_amd.common.datasets.resample import resize_bilinear
+    ref = np.stack([np.asarray(Image.fromarray(a[b]).resize((ow, oh), Image.BILINEAR)) for b in range(B)])
+    np.testing.assert_array_equal(resize_bilinear(x, (oh, ow), as_float=False).cpu().numpy(), ref)
 
 
 def test_device_batch_equals_get_example(tmp_path):
@@ -53,3 +58,23 @@ def test_device_batch_equals_get_example(tmp_path):
     dev = ds.device_batch(range(len(ds)), 'cuda:0')
     assert dev.shape == (5, 3, 224, 224) and dev.dtype == torch.float32
     np.testing.assert_array_equal(dev.cpu().numpy(), host)
+
+
+def test_generator_final_resize_on_gpu_gives_pillows_bytes(tmp_path):
+    """datasets/sheep/paste_and_crop_sheep.py:218 (`sample.resize(output_size, Image.LINEAR)`): `--device cuda` does that resize
+    on the GPU for all samples of a run; every written PNG is byte-identical to the host run's"""
+    from PIL import Image
+    from loans_amd.datasets.sheep import paste_and_crop_sheep as G
+    runs = []
+    for name, extra in (('host', []), ('gpu', ['--device', 'cuda'])):
+        dest = str(tmp_path / name)
+        args = G.build_parser().parse_args(['-', dest, '--synthetic', '5', '--num-samples', '24', '--seed', '11', '--zoom-mode',
+                                            '--output-size', '75', '75'] + extra)
+        rows, _ = G.generate(args)
+        runs.append((dest, rows))
+    (d0, r0), (d1, r1) = runs
+    assert r0 == r1 and len(r0) >= 16
+    for name, _ in r0:
+        with Image.open(os.path.join(d0, name)) as a, Image.open(os.path.join(d1, name)) as b:
+            assert a.size == b.size == (75, 75)
+            np.testing.assert_array_equal(np.asarray(a.convert('RGBA')), np.asarray(b.convert('RGBA')))

@@ -16,15 +16,16 @@ def _cases():
     g = np.load(GOLDEN)
     n = 0
     while 'src_%d' % n in g.files:
-        yield g['src_%d' % n], g['dst_%d' % n]
+        yield g['src_%d' % n], g['dst_%d' % n], g['bil_%d' % n]
         n += 1
 
 
 def test_tables_reproduce_the_golden_vectors():
     cases = list(_cases())
     assert len(cases) >= 7
-    for src, dst in cases:
+    for src, dst, bil in cases:
         np.testing.assert_array_equal(two_pass_u8(src, dst.shape[0], dst.shape[1]), dst)
+        np.testing.assert_array_equal(two_pass_u8(src, bil.shape[0], bil.shape[1], 'bilinear'), bil)
 
 
 @pytest.mark.parametrize("shape", [(37, 53, 20, 24), (64, 64, 224, 224), (480, 640, 224, 224), (100, 30, 30, 100),
@@ -35,6 +36,8 @@ def test_tables_against_installed_pillow(shape):
     a = np.random.RandomState(H * 1000 + W).randint(0, 256, (H, W, 3)).astype(np.uint8)
     ref = np.asarray(Image.fromarray(a).resize((ow, oh), Image.LANCZOS))
     np.testing.assert_array_equal(two_pass_u8(a, oh, ow), ref)
+    ref = np.asarray(Image.fromarray(a).resize((ow, oh), Image.BILINEAR))
+    np.testing.assert_array_equal(two_pass_u8(a, oh, ow, 'bilinear'), ref)
 
 
 def test_table_properties():
