@@ -394,6 +394,23 @@ int loans_grid_loss_bwd_f32(const float* grid, const float* gloss, float* ggrid,
                             float imgH, float imgW, float oob_scale,
                             int32_t B, int32_t th, int32_t tw, void* stream);
 
+/* ---- VisualBackprop and grayscale rois (insights/visual_backprop.py:16-53; sheep/sheep_localizer.py:65-68,105-108) ---- */
+/* out[row] = (1 / cdiv) * sum_c a(x[row][c]); a = identity, or relu(x * scale[c] + shift[c]) when scale / shift are given
+ * (F.average(input, axis=1) of a convolution / pooling node's input, visual_backprop.py:39); C % 4 == 0; cdiv = the logical
+ * channel count (3 for the 4-channel padded frames) */
+int loans_channel_mean_f32(const float* x, const float* scale, const float* shift, float* out, int64_t rows, int32_t C,
+                           int32_t cdiv, void* stream);
+int loans_channel_mean_bf16(const void* x, const float* scale, const float* shift, float* out, int64_t rows, int32_t C,
+                            int32_t cdiv, void* stream);
+/* out = deconvolution_2d(feat [B][fh][fw], ones(kh, kw), stride, pad, outsize (H, W)) * avg [B][H][W]   (visual_backprop.py:31-40) */
+int loans_vbp_scale_f32(const float* feat, const float* avg, float* out, int32_t B, int32_t fh, int32_t fw, int32_t H, int32_t W,
+                        int32_t kh, int32_t kw, int32_t sy, int32_t sx, int32_t ph, int32_t pw, void* stream);
+/* per image of n values, in place: (x - min) / (max - min)   (visual_backprop.py:48-52) */
+int loans_minmax_normalize_f32(float* x, int32_t B, int32_t n, void* stream);
+/* rois NHWC4 -> 0.299 * ch2 + 0.587 * ch1 + 0.114 * ch0 per pixel, and its gradient (sheep_localizer.py:65-68) */
+int loans_gray_fwd_f32(const float* rois_nhwc4, float* out, int64_t npix, void* stream);
+int loans_gray_bwd_f32(const float* g, float* grois_nhwc4, int64_t npix, void* stream);
+
 /* ---- optimiser: chainer.optimizers.Adam(alpha, amsgrad=True) over one flat buffer
  *      (train_sheep_localizer.py:130-134; sheep_updater.py:52,66). lr_t = alpha*sqrt(1-b2^t)/(1-b1^t)
  *      is computed by the caller; eps sits outside the bias correction. grad_scale multiplies g first

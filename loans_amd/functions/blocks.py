@@ -64,6 +64,9 @@ class StemFunction(Function):
         x, W, b, gamma, beta = inputs
         self.x = x
         self.c, self.st, self.geo = _ConvBN.forward(x, self.conv, self.bn, W, b, gamma, beta)
+        # VisualBackprop: the pooling node's input relu(bn1(conv1)) is never materialised -- its channel mean is taken from
+        # the conv output and the BN coefficients (conv1's own tap needs the unpadded frames: SheepLocalizer records it)
+        ops.vbp_tap(self.c, 3, 2, 0, st=self.st)
         y, self.idx = ops.bn_relu_maxpool(self.c, self.st)
         return y
 
@@ -101,6 +104,7 @@ class ResidualUnitFunction(Function):
         paired = self._forward_pair(x, inputs) if self.shortcut is not None else False
         for i, (conv, bn) in enumerate(self.stages):
             W, g, b = inputs[1 + 3 * i:4 + 3 * i]
+            ops.vbp_tap(h, conv.ksize, conv.stride, conv.pad)           # main-branch convolution i and its input
             if not (paired and i == 0):
                 self.c[i], self.st[i], self.geo[i] = _ConvBN.forward(h, conv, bn, W, None, g, b)
             if i < n - 1:

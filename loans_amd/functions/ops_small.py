@@ -166,3 +166,28 @@ class ExposeNCHW(Function):
         out = torch.zeros((B, h, w, 4), device=g.device, dtype=g.dtype)
         out[..., :3] = g.permute(0, 2, 3, 1)
         return out
+
+
+class RoisToGrayscale(Function):
+    """``0.299 * r + 0.587 * g + 0.114 * b`` with ``b, g, r = split_axis(rois, 3, axis=1)`` (reference
+    sheep/sheep_localizer.py:65-68, ``transform_rois_to_grayscale=True``): (B,3,h,w) -> (B,1,h,w).  The rois are the NCHW
+    view of the sampler's NHWC4 buffer; forward and backward are one streaming kernel each."""
+
+    def forward(self, inputs):
+        x = inputs[0]
+        B, c, h, w = x.shape
+        assert c == 3, "rois are not in RGB, can not convert them to grayscale"
+        if x.stride() == (h * w * 4, 1, w * 4, 4):
+            nhwc4 = torch.as_strided(x, (B, h, w, 4), (h * w * 4, w * 4, 4, 1))
+        else:
+            nhwc4 = ops.nchw3_to_nhwc4(x.contiguous())
+        return ops.gray_fwd(nhwc4).view(B, 1, h, w)
+
+    def backward(self, inputs, gys):
+        g = gys[0].contiguous()
+        B, _, h, w = g.shape
+        return nchw_view(ops.gray_bwd(g.view(B, h, w)))
+
+
+def rois_to_grayscale(rois):
+    return RoisToGrayscale()(rois)

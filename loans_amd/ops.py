@@ -1164,6 +1164,65 @@ def axpby(a, x, b, y):
 
 
 # --------------------------------------------------------------------------- #
+# VisualBackprop / grayscale rois (insights/visual_backprop.py; sheep_localizer.py:65-68)
+# --------------------------------------------------------------------------- #
+# When a list, the fused block functions append one record per Convolution2D / max-pooling node of the MAIN branch they run,
+# in forward order: {'avg': channel mean of the node's input [B][H][W] fp32, 'k', 's', 'p'} -- what VisualBackprop's walk
+# over Chainer's graph reads off each such node (visual_backprop.py:18-20,29-40)
+VBP_TAPS = None
+
+
+def channel_mean(x, cdiv=None, st=None):
+    """mean over the channels of an NHWC tensor -> [B][H][W] fp32; st: apply relu(x * scale + shift) first"""
+    C_ = x.shape[-1]
+    rows = x.numel() // C_
+    out = torch.empty(x.shape[:-1], device=x.device, dtype=torch.float32)
+    fn = _lib.load().loans_channel_mean_bf16 if _is16(x) else _lib.load().loans_channel_mean_f32
+    check(fn(_ptr(x), _ptr(st.scale if st is not None else None), _ptr(st.shift if st is not None else None), _ptr(out), rows, C_,
+             cdiv or C_, _stream()), 'loans_channel_mean')
+    return out
+
+
+def vbp_tap(x, k, s, p, cdiv=None, st=None):
+    if VBP_TAPS is not None:
+        VBP_TAPS.append({'avg': channel_mean(x, cdiv, st), 'k': k, 's': s, 'p': p})
+
+
+def vbp_scale(feat, avg, k, s, p):
+    """deconvolution_2d(feat, ones, stride s, pad p, outsize = avg's size) * avg; the all-ones kernel's size follows from the
+    sizes (visual_backprop.py:29-30)"""
+    B, fh, fw = feat.shape
+    _, H, W = avg.shape
+    kh, kw = H + 2 * p - s * (fh - 1), W + 2 * p - s * (fw - 1)
+    out = torch.empty_like(avg)
+    check(_lib.load().loans_vbp_scale_f32(_ptr(feat), _ptr(avg), _ptr(out), B, fh, fw, H, W, kh, kw, s, s, p, p, _stream()),
+          'loans_vbp_scale_f32')
+    return out
+
+
+def minmax_normalize_(x):
+    B = x.shape[0]
+    check(_lib.load().loans_minmax_normalize_f32(_ptr(x), B, x.numel() // B, _stream()), 'loans_minmax_normalize_f32')
+    return x
+
+
+def gray_fwd(rois_nhwc4):
+    B, h, w, c = rois_nhwc4.shape
+    assert c == 4
+    _chk(rois_nhwc4, 'rois')
+    out = torch.empty((B, h, w), device=rois_nhwc4.device, dtype=torch.float32)
+    check(_lib.load().loans_gray_fwd_f32(_ptr(rois_nhwc4), _ptr(out), B * h * w, _stream()), 'loans_gray_fwd_f32')
+    return out
+
+
+def gray_bwd(g):
+    _chk(g, 'gradient')
+    out = torch.empty(tuple(g.shape) + (4,), device=g.device, dtype=torch.float32)
+    check(_lib.load().loans_gray_bwd_f32(_ptr(g), _ptr(out), g.numel(), _stream()), 'loans_gray_bwd_f32')
+    return out
+
+
+# --------------------------------------------------------------------------- #
 # spatial transformer
 # --------------------------------------------------------------------------- #
 def st_grid_fwd(theta, out_size):

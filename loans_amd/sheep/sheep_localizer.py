@@ -16,7 +16,7 @@ from .. import ops
 from ..common.utils import Size
 from ..functions import (global_average_pooling_2d, linear, reshape, rotation_dropout,
                          spatial_transformer_grid, spatial_transformer_sampler)
-from ..functions.ops_small import ExposeNCHW
+from ..functions.ops_small import ExposeNCHW, rois_to_grayscale
 from ..runtime.core import Chain, Variable, as_variable, config, using_config
 from ..chainercv_resnet import ResBlock
 from ..iou.iou_regressor import MyResNet50Layers
@@ -64,6 +64,7 @@ class SheepLocalizer(Chain):
         self.arena.set_active('res6' if height <= 224 else ('res7' if height <= 300 else None))
 
         input_images = self.prepare_images(images)
+        self._record_stem_tap(images)
         h = self.feature_extractor(input_images)
 
         if images.shape[-2] > 224:
@@ -72,7 +73,7 @@ class SheepLocalizer(Chain):
             if images.shape[-2] > 300:
                 h = self.res7(h)
 
-        self.visual_backprop_anchors.append(h)
+        self._anchor(h)
         h = global_average_pooling_2d(h)
 
         transform_params = linear(h, self.param_predictor.W, self.param_predictor.b)
@@ -82,9 +83,21 @@ class SheepLocalizer(Chain):
         self.last_transform_params = transform_params
 
         if self.transform_rois_to_grayscale:
-            raise NotImplementedError("grayscale rois are off on the training path (train_sheep_localizer.py:118-119)")
+            rois = rois_to_grayscale(rois)
 
         return rois, points
+
+    def _record_stem_tap(self, images):
+        """VisualBackprop: conv1's node -- the channel mean of the PREPROCESSED frames (the array conv1 reads in the reference,
+        sheep_localizer.py:45-46) at the frame's own size; the stem's fused function only sees the zero-padded buffer"""
+        if ops.VBP_TAPS is not None:
+            conv1 = self.feature_extractor.conv1
+            ops.vbp_tap(ops.prep_images(images), conv1.ksize, conv1.stride, conv1.pad, cdiv=3)
+
+    def _anchor(self, h):
+        if ops.VBP_TAPS is not None:
+            h.vbp_taps = list(ops.VBP_TAPS)
+        self.visual_backprop_anchors.append(h)
 
     def prepare_images(self, images):
         """``images * 255`` -> uint8 truncation -> BGR -> minus mean, cutting the graph
@@ -109,10 +122,18 @@ class SheepLocalizer(Chain):
     def predict(self, images, return_visual_backprop=False):
         images = np.stack([np.asarray(image, dtype=np.float32) for image in images], axis=0)
         with using_config('train', False), using_config('enable_backprop', False):
-            rois, bboxes = self(images)
+            old_taps, ops.VBP_TAPS = ops.VBP_TAPS, ([] if return_visual_backprop else None)
+            try:
+                rois, bboxes = self(images)
+            finally:
+                ops.VBP_TAPS = old_taps
             if return_visual_backprop:
-                raise NotImplementedError("VisualBackprop is a visualisation tool outside the hot path (SURVEY §2.1 #13)")
-            visual_backprop = None
+                if not hasattr(self, 'visual_backprop'):
+                    from ..insights.visual_backprop import VisualBackprop
+                    self.visual_backprop = VisualBackprop()
+                visual_backprop = self.visual_backprop.perform_visual_backprop(self.visual_backprop_anchors[0]).cpu().numpy()
+            else:
+                visual_backprop = None
             bboxes = self.extract_corners(bboxes)
             bboxes = self.scale_bboxes(bboxes, Size._make(images.shape[-2:]))
 
@@ -160,9 +181,10 @@ class Resnet50SheepLocalizer(SheepLocalizer):
         self.arena.set_active('res6' if height <= 224 else ('res7' if height <= 300 else 'feature_extractor/fc6'))
 
         input_images = self.prepare_images(images)
+        self._record_stem_tap(images)
         h = self.feature_extractor(input_images, layers=['res5', 'pool5'])
 
-        self.visual_backprop_anchors.append(h['res5'])
+        self._anchor(h['res5'])
         if images.shape[-2] > 224:
             h = h['res5']
             h = self.res6(h)
@@ -181,6 +203,6 @@ class Resnet50SheepLocalizer(SheepLocalizer):
         self.last_transform_params = transform_params
 
         if self.transform_rois_to_grayscale:
-            raise NotImplementedError("grayscale rois are off on the training path (train_sheep_localizer.py:118-119)")
+            rois = rois_to_grayscale(rois)
 
         return rois, points
