@@ -411,6 +411,13 @@ int loans_minmax_normalize_f32(float* x, int32_t B, int32_t n, void* stream);
 int loans_gray_fwd_f32(const float* rois_nhwc4, float* out, int64_t npix, void* stream);
 int loans_gray_bwd_f32(const float* g, float* grois_nhwc4, int64_t npix, void* stream);
 
+/* ---- the imgaug branch of the input pipeline (common/datasets/image_dataset.py:57-70,80-83), one position of the sampled
+ * operation order per launch: params_dev [B][8] int32, [0] = op (0 copy, 1 Fliplr, 2 AddToHueAndSaturation: [1] dh [2] ds,
+ * 3 CropAndPad: [1..4] top, right, bottom, left pixels (< 0 crop, > 0 pad), [5] fill 0 constant / 1 edge, resized back to H x W);
+ * uint8 HWC RGB frames of one size, in != out.  Integer arithmetic throughout (loans_amd/common/datasets/augment.py is the
+ * NumPy form of the same operations). */
+int loans_augment_stage_u8(const void* in, void* out, int32_t B, int32_t H, int32_t W, const int32_t* params_dev, void* stream);
+
 /* ---- optimiser: chainer.optimizers.Adam(alpha, amsgrad=True) over one flat buffer
  *      (train_sheep_localizer.py:130-134; sheep_updater.py:52,66). lr_t = alpha*sqrt(1-b2^t)/(1-b1^t)
  *      is computed by the caller; eps sits outside the bias correction. grad_scale multiplies g first

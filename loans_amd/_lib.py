@@ -41,6 +41,7 @@ _i32, _i64, _f32, _f64 = C.c_int32, C.c_int64, C.c_float, C.c_double
 
 # name -> argtypes, exactly the prototypes of include/loans_hip.h
 SIGNATURES = {
+    'loans_augment_stage_u8': [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p],
     'loans_channel_mean_f32': [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p],
     'loans_channel_mean_bf16': [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p],
     'loans_vbp_scale_f32': [C.c_void_p] * 3 + [C.c_int32] * 11 + [C.c_void_p],

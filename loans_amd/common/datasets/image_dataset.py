@@ -2,15 +2,15 @@
 contract of the hot path -- float32 CHW RGB in [0,1] (exactly ``uint8 / 255``), PIL load, LANCZOS resize,
 labelled variant returning ``(image, label, zeros(1))`` with bounding boxes rescaled to the resized image.
 
-Same constructor keywords and ``get_example`` behaviour.  ``imgaug`` is not available here: with
-``use_imgaug=True`` (the reference default) the naive crop / flip augmentation of the reference's own fallback
-branch (:86-90) is used instead and a note is printed once; the hue / contrast jitter of the imgaug branch is
-not reproduced.  Decode and the crop / flip stay on host threads; ``ImageDataset.device_batch`` moves the LANCZOS resize,
+Same constructor keywords and ``get_example`` behaviour.  ``imgaug`` is not installable here: with ``use_imgaug=True`` (the
+reference default) and ``transform_probability > 0`` the three operations of the reference's imgaug pipeline (:57-70) run in
+the restated form of ``augment.py`` (mirror, hue / saturation jitter, crop-and-pad; host NumPy in ``get_example``, HIP kernels
+in ``device_batch``, same bytes); ``use_imgaug=False`` is the reference's own naive crop / flip branch (:86-90).  Decode and
+the naive crop / flip stay on host threads; ``ImageDataset.device_batch`` moves the LANCZOS resize,
 ``/ 255`` and the layout change to the GPU (resample.py, bit-identical to Pillow)."""
 import csv
 import os
 import random
-import warnings
 
 import numpy
 from PIL import Image
@@ -61,15 +61,6 @@ def resize_bbox(bbox, in_size, out_size):
     return bbox
 
 
-_warned = []
-
-
-def _no_imgaug():
-    if not _warned:
-        warnings.warn("imgaug is not installed: using the reference's naive crop/flip augmentation branch")
-        _warned.append(1)
-
-
 class ImageDataset:
 
     def __init__(self, paths, root='.', dtype=numpy.float32, **kwargs):
@@ -80,8 +71,9 @@ class ImageDataset:
         self.min_crop_ratio = kwargs.pop('min_crop_ratio', 0.6)
         self.max_crop_ratio = kwargs.pop('max_crop_ratio', 0.9)
         self.crop_always = kwargs.pop('crop_always', False)
-        if self.transform_probability > 0 and self.use_imgaug:
-            _no_imgaug()
+        # the imgaug branch draws from a stream of its own (reseed() restarts it): get_example and device_batch consume one
+        # set of draws per example, in call order
+        self._aug_rng = random.Random(kwargs.pop('augment_seed', None))
         if isinstance(paths, str):
             with open(paths) as paths_file:
                 paths = [path.strip() for path in paths_file]
@@ -93,18 +85,39 @@ class ImageDataset:
     def __getitem__(self, i):
         return self.get_example(i)
 
-    def _decoded(self, i):
-        """Decode + the naive crop / flip augmentation (reference :76-90): CHW in the dataset's dtype, values 0..255."""
+    def reseed(self, seed):
+        self._aug_rng = random.Random(seed)
+
+    def _imgaug_rows(self, image_chw):
+        """the imgaug branch's draws for one example (None: branch off)"""
+        if not (self.use_imgaug and self.transform_probability > 0):
+            return None
+        from .augment import sample_params
+        return sample_params(self._aug_rng, image_chw.shape[-2], image_chw.shape[-1], self.transform_probability)
+
+    def _decoded(self, i, imgaug_rows=False):
+        """Decode + augmentation (reference :76-90): CHW in the dataset's dtype, values 0..255.  ``imgaug_rows``: return the
+        imgaug branch's parameter rows beside the un-augmented frame instead of applying them (device_batch applies them on
+        the GPU)."""
         image = _read_image_as_array(os.path.join(self._root, self._paths[i]), self._dtype)
         if image.shape[0] == 1:
             image = numpy.tile(image, (3, 1, 1))
         image = image[:3]
-        if random.random() < self.transform_probability:
+        rows = self._imgaug_rows(image)
+        if rows is not None:
+            if imgaug_rows:
+                return image, rows
+            from .augment import apply_host
+            u8 = numpy.ascontiguousarray(image.transpose(1, 2, 0).astype(numpy.uint8))        # reference :80-83
+            return apply_host(u8, rows).astype(self._dtype).transpose(2, 0, 1)
+        if imgaug_rows:
+            rows = [[0] * 8] * 3
+        if not self.use_imgaug and random.random() < self.transform_probability:
             if self.crop_always or random.random() <= 0.5:
                 crop_ratio = random.uniform(self.min_crop_ratio, self.max_crop_ratio)
                 image = random_crop(image, tuple([int(size * crop_ratio) for size in image.shape[-2:]]))
             image = random_flip(image, x_random=True)
-        return image
+        return (image, rows) if imgaug_rows else image
 
     def get_example(self, i):
         image = self._decoded(i)
@@ -125,6 +138,10 @@ class ImageDataset:
         from .resample import frames_to_device
         if self.image_mode != 'RGB' or self.image_size is None:
             raise ValueError('device_batch covers the training configuration: RGB frames resized to image_size')
+        if self.use_imgaug and self.transform_probability > 0:
+            pairs = [self._decoded(i, imgaug_rows=True) for i in indices]
+            frames = [numpy.ascontiguousarray(im.transpose(1, 2, 0).astype(numpy.uint8)) for im, _ in pairs]
+            return frames_to_device(frames, self.image_size, device, augment_rows=[r for _, r in pairs])
         return frames_to_device([self.get_raw_example(i) for i in indices], self.image_size, device)
 
 
@@ -136,8 +153,6 @@ class LabeledImageDataset:
             with open(pairs) as pairs_file:
                 reader = csv.reader(pairs_file, delimiter='\t')
                 pairs = [(pair[0], list(map(label_dtype, pair[1:]))) for pair in reader]
-        if transform_probability > 0:
-            _no_imgaug()
         self.transform_probability = transform_probability
         self._pairs, self._root, self._dtype, self._label_dtype = pairs, root, dtype, label_dtype
         self.image_size, self.image_mode, self.return_dummy_scores = image_size, image_mode, return_dummy_scores

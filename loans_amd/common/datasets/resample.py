@@ -138,7 +138,7 @@ def resize_lanczos(frames_u8, out_hw, as_float=True, filt='lanczos'):
     return out
 
 
-def frames_to_device(images, out_hw, device):
+def frames_to_device(images, out_hw, device, augment_rows=None):
     """``[ImageDataset.get_example(i) for i in batch]`` for decoded frames: a list of uint8 HWC RGB arrays of any sizes
     -> one device batch [N][3][oh][ow] float32 in [0,1], in input order.  Frames of equal size are uploaded (pinned,
     asynchronous) and resized together."""
@@ -154,6 +154,10 @@ def frames_to_device(images, out_hw, device):
         host = torch.empty((len(idx), H, W, 3), dtype=torch.uint8).pin_memory()
         for j, i in enumerate(idx):
             host[j] = torch.from_numpy(np.ascontiguousarray(images[i]))
-        batch = resize_lanczos(host.to(device, non_blocking=True), out_hw)
+        frames = host.to(device, non_blocking=True)
+        if augment_rows is not None:            # the imgaug branch (augment.py), per image, before the resize (reference :80-93)
+            from .augment import apply_device
+            frames = apply_device(frames, [augment_rows[i] for i in idx])
+        batch = resize_lanczos(frames, out_hw)
         out[torch.as_tensor(idx, device=device)] = batch
     return out

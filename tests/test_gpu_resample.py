@@ -78,3 +78,35 @@ def test_generator_final_resize_on_gpu_gives_pillows_bytes(tmp_path):
         with Image.open(os.path.join(d0, name)) as a, Image.open(os.path.join(d1, name)) as b:
             assert a.size == b.size == (75, 75)
             np.testing.assert_array_equal(np.asarray(a.convert('RGBA')), np.asarray(b.convert('RGBA')))
+
+
+def test_imgaug_branch_gpu_equals_host(tmp_path):
+    """the restated imgaug branch (common/datasets/image_dataset.py:57-70,80-83; loans_amd/common/datasets/augment.py): the HIP
+    stages give the bytes of the NumPy form for every operation, order and fill mode, and `device_batch` equals
+    `stack(get_example)` with augmentation on (same draws, augment -> LANCZOS resize -> / 255)."""
+    import random
+    from PIL import Image
+    from loans_amd.common.datasets import augment as A
+    from loans_amd.common.datasets.image_dataset import ImageDataset
+    rng = np.random.RandomState(3)
+    frames = rng.randint(0, 256, (12, 45, 70, 3)).astype(np.uint8)
+    frames[3] = 128                                       # a grey frame: hue undefined
+    frames[4, :, :, 1:] = 0                               # pure red
+    r = random.Random(9)
+    rows = [A.sample_params(r, 45, 70, 1.0) for _ in range(12)]
+    rows[0] = [[3, -4, 7, 4, -7, 0, 0, 0], [2, 20, -20, 0, 0, 0, 0, 0], [1] + [0] * 7]
+    rows[1] = [[3, 4, -7, -4, 7, 1, 0, 0], [1] + [0] * 7, [2, -20, 20, 0, 0, 0, 0, 0]]
+    want = np.stack([A.apply_host(f, rw) for f, rw in zip(frames, rows)])
+    got = A.apply_device(torch.from_numpy(frames).cuda(), rows).cpu().numpy()
+    np.testing.assert_array_equal(got, want)
+    assert sum(1 for rw in rows for row in rw if row[0]) >= 15
+
+    names = []
+    for i, (H, W) in enumerate([(60, 80), (50, 50), (60, 80), (33, 47)]):
+        Image.fromarray(rng.randint(0, 256, (H, W, 3)).astype(np.uint8)).save(str(tmp_path / ('g%d.png' % i)))
+        names.append('g%d.png' % i)
+    ds = ImageDataset(names, root=str(tmp_path), image_size=(48, 64), transform_probability=0.8, augment_seed=21)
+    host = np.stack([ds.get_example(i) for i in range(4)])
+    ds.reseed(21)
+    dev_ = ds.device_batch(range(4), 'cuda:0')
+    np.testing.assert_array_equal(dev_.cpu().numpy(), host)
