@@ -167,6 +167,14 @@ int loans_igemm_bf16s(const void* in, const void* w, void* out, const float* bia
 /* wgrad with bf16 x and gy, fp32 atomic accumulation into dw ("fp32 grad accumulate"); the pixel-major tiles are staged as
  * they lie and transposed by the fragment reads (ds_read_b64_tr_b16).  Tiles 128x128, 64x64, 64x128. */
 int loans_wgrad_bf16s(const void* x, const void* gy, float* dw, const loans_igemm_desc* d, int32_t splits, void* stream);
+/* Split-K on bf16 storage for grids that cannot fill the machine (res6 / res7 at 512 px: 2048 - 8192 rows, K = 4608): block
+ * (tile, s) contracts every `splits`-th slice of K and ADDS its raw fp32 tile to `partial` [B * outH * outW][Cout] (zeroed by the
+ * caller; the descriptor's flags may only carry RELU_IN / DENSE; the implicit-GEMM tiles only); the parity classes of a strided
+ * data gradient add into the same buffer.  loans_igemm_finalize_bf16 then writes the bf16 tensor of the finished sums with the
+ * epilogue flags BIAS / STATS / MASK / ADDEND / ADDEND_MASK of loans_igemm_bf16s (Cout / 8 must divide 256). */
+int loans_igemm_bf16s_splitk(const void* in, const void* w, float* partial, const loans_igemm_desc* d, int32_t splits, void* stream);
+int loans_igemm_finalize_bf16(const float* partial, void* out, const float* bias, double* stats, const void* ref,
+                              const void* addend, int32_t flags, int64_t rows, int32_t Cout, void* stream);
 /* fp32 master weights -> bf16 operand copies: plain cast (n % 4 == 0), and the dgrad re-pack with the cast folded in */
 int loans_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
 int loans_repack_dgrad_bf16(const float* src, void* dst, int32_t Cout, int32_t Cin, int32_t src_taps,

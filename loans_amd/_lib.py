@@ -41,6 +41,8 @@ _i32, _i64, _f32, _f64 = C.c_int32, C.c_int64, C.c_float, C.c_double
 
 # name -> argtypes, exactly the prototypes of include/loans_hip.h
 SIGNATURES = {
+    'loans_igemm_bf16s_splitk': [C.c_void_p, C.c_void_p, C.c_void_p, C.POINTER(IgemmDesc), C.c_int32, C.c_void_p],
+    'loans_igemm_finalize_bf16': [C.c_void_p] * 6 + [C.c_int32, C.c_int64, C.c_int32, C.c_void_p],
     'loans_augment_stage_u8': [C.c_void_p, C.c_void_p, C.c_int32, C.c_int32, C.c_int32, C.c_void_p, C.c_void_p],
     'loans_channel_mean_f32': [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p],
     'loans_channel_mean_bf16': [C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int64, C.c_int32, C.c_int32, C.c_void_p],

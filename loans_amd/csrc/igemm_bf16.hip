@@ -51,6 +51,10 @@ struct Igemm16Args {
         int nx, ny, dy0, sdy, dx0, sdx;
         unsigned long long rowpat;
     } ap;
+    // split-K (loans_igemm_bf16s_splitk): block (tile, s) contracts chunks [s * cps, (s + 1) * cps) and ADDS its raw fp32 tile
+    // to `partial` [pixels][Cout] (zeroed by the caller); loans_igemm_finalize_bf16 makes the bf16 tensor of the finished sums
+    int splits, chunks_per_split;
+    float* partial;
 };
 
 __device__ __forceinline__ int xcd_remap16(int id, int nblk) {
@@ -96,8 +100,14 @@ __global__ __launch_bounds__(256) void igemm16_kernel(const Igemm16Args a) {
     const loans_igemm_desc& d = a.d;
     const int tid = threadIdx.x;
     const int logical = xcd_remap16(blockIdx.x, gridDim.x);
-    const int tn = logical % a.tiles_n;
-    const int tm = logical / a.tiles_n;
+    const int ntile = a.tiles_m * a.tiles_n;
+    const int split = logical / ntile;                  // 0 unless split-K
+    const int ltile = logical - split * ntile;
+    const int tn = ltile % a.tiles_n;
+    const int tm = ltile / a.tiles_n;
+    const int c_begin = split * a.chunks_per_split;     // this block's K chunks
+    const int c_end = min(c_begin + a.chunks_per_split, a.nchunks);
+    const int nch = c_end - c_begin;
     const int lrow = tid >> 3;
     const int lu = (tid & 7) ^ ((tid >> 4) & 7);       // K unit this thread stages: slot ^ key(row)
     // LOANS_F_DENSE (the RGB stem, see igemm.hip): inW / isx / dx count ELEMENTS of packed 3-channel rows inside a zero
@@ -177,8 +187,8 @@ __global__ __launch_bounds__(256) void igemm16_kernel(const Igemm16Args a) {
     const int cpt = d.Cin >> 3;   // 16-byte units per tap
     const int q8 = 8 / cpt, r8 = 8 - q8 * cpt;
     const int kunits = a.Ktot >> 3;
-    int u = lu;                   // this thread's K unit in the chunk being loaded
-    int tap = lu / cpt, c8 = lu - tap * cpt;
+    int u = lu + 8 * c_begin;     // this thread's K unit in the chunk being loaded
+    int tap = u / cpt, c8 = u - tap * cpt;
     unsigned woff[RB], wbad[RB];
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
@@ -286,7 +296,7 @@ __global__ __launch_bounds__(256) void igemm16_kernel(const Igemm16Args a) {
     unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0, p_s0 = 0, p_s1 = 0, p_s2 = 0, p_bar = 0, p_s3 = 0, q_begin = 0;
     STAMP16(q_begin);
 #endif
-    for (; c + 1 < a.nchunks; ++c) {
+    for (; c + 1 < nch; ++c) {
         const int buf = c & 1;
         STAMP16(q0);
         read_frag(buf, 1, fa1, fb1);
@@ -332,12 +342,12 @@ __global__ __launch_bounds__(256) void igemm16_kernel(const Igemm16Args a) {
 #ifdef LOANS_STAMPS
     if (logical < 64 && (tid & 63) == 0) {
         unsigned long long* o = g_stamps16 + (logical * 4 + (tid >> 6)) * 8;
-        o[0] = p_s0; o[1] = p_s1; o[2] = p_s2; o[3] = p_bar; o[4] = p_s3; o[5] = q5 - q_begin; o[6] = a.nchunks - 1; o[7] = 0;
+        o[0] = p_s0; o[1] = p_s1; o[2] = p_s2; o[3] = p_bar; o[4] = p_s3; o[5] = q5 - q_begin; o[6] = nch - 1; o[7] = 0;
     }
 #endif
     {   // last chunk: steps that lie wholly beyond Ktot hold zeros on both sides and are skipped
         const int buf = c & 1;
-        const int ts = (a.Ktot - (a.nchunks - 1) * BKH + 15) / 16;      // 1..4
+        const int ts = c_end == a.nchunks ? (a.Ktot - (a.nchunks - 1) * BKH + 15) / 16 : 4;      // 1..4
         if (ts > 1) read_frag(buf, 1, fa1, fb1);
         relu_frag(fa0);
         mma(fa0, fb0);
@@ -403,16 +413,31 @@ __global__ __launch_bounds__(256) void igemm16_kernel(const Igemm16Args a) {
                 Cs[(wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * LDC + wn * TN * 32 + j * 32 + r] = acc[i][j][e];
     __syncthreads();
 
-    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)a.out_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_ref = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<__bf16*>(a.ref ? a.ref : a.out), 0, (int)a.out_bytes, 0x00020000);
-    const __amdgpu_buffer_rsrc_t rs_add = __builtin_amdgcn_make_buffer_rsrc(
-        const_cast<__bf16*>(a.addend ? a.addend : a.out), 0, (int)a.out_bytes, 0x00020000);
     constexpr int CPR = BN / 8;                 // 8-channel units per row
     constexpr int RSTEP = 256 / CPR;            // rows covered by the block per pass
     const int oc8 = tid % CPR, r0 = tid / CPR;
     const int col0 = tn * BN + oc8 * 8;
     const unsigned cbad = (col0 + 7 < d.Cout) ? 0u : 0xFFFFFFFFu;     // Cout % 8 == 0 (checked)
+    if (a.partial) {
+        // raw partial tile: fp32 atomic adds into the zeroed workspace, one wave-instruction = 256 CONTIGUOUS bytes of one row
+        // (64 lanes x 4 B: the full-rate shape; lanes 32 B apart run an order of magnitude slower); bias / statistics / mask /
+        // addend / the rounding to bf16 belong to loans_igemm_finalize_bf16
+        constexpr int WPR = BN / 64;                        // wave-instructions per row
+        const int wv = tid >> 6, ln = tid & 63;
+#pragma unroll 4
+        for (int q = wv; q < BM * WPR; q += 4) {
+            const int row = q / WPR, cc = (q - row * WPR) * 64 + ln;
+            const unsigned po = opix[row];                  // byte offset of the row in a bf16 tensor = 2 * element offset
+            const int col = tn * BN + cc;
+            if (po != 0xFFFFFFFFu && col < d.Cout) atomic_add_f32(a.partial + (size_t)(po >> 1) + col, Cs[row * LDC + cc]);
+        }
+        return;
+    }
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)a.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_ref = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<__bf16*>(a.ref ? a.ref : a.out), 0, (int)a.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_add = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<__bf16*>(a.addend ? a.addend : a.out), 0, (int)a.out_bytes, 0x00020000);
     const unsigned coff = (unsigned)col0 * 2u;
     f32x4 b_lo = {0.f, 0.f, 0.f, 0.f}, b_hi = b_lo;
     if (f_bias && !cbad) {
@@ -462,7 +487,11 @@ int launch_igemm16_r(Igemm16Args& a, hipStream_t st) {
     if (int rc_ = loans_raise_lds_limit(lds_limit_set, reinterpret_cast<const void*>(kern), lds)) return rc_;
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.d.Cout + BN - 1) / BN;
-    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n), dim3(256), lds, st, a);
+    if (a.splits < 1) a.splits = 1;
+    if (a.splits > a.nchunks) a.splits = a.nchunks;
+    a.chunks_per_split = (a.nchunks + a.splits - 1) / a.splits;
+    a.splits = (a.nchunks + a.chunks_per_split - 1) / a.chunks_per_split;       // no empty slice
+    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n * a.splits), dim3(256), lds, st, a);
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;
 }
@@ -753,9 +782,10 @@ int launch_wgrad16(Wgrad16Args& a, int splits_req, hipStream_t st) {
 
 }  // namespace
 
-extern "C" int loans_igemm_bf16s(const void* in, const void* w, void* out, const float* bias, double* stats,
-                                 const void* ref, const void* addend, const loans_igemm_desc* d, void* stream) {
-    if (!d || !in || !w || !out) return LOANS_EINVAL;
+static int igemm_bf16s_impl(const void* in, const void* w, void* out, const float* bias, double* stats, const void* ref,
+                           const void* addend, const loans_igemm_desc* d, float* partial, int splits, void* stream) {
+    if (!d || !in || !w || (!out && !partial)) return LOANS_EINVAL;
+    if (partial && (d->flags & ~(LOANS_F_RELU_IN | LOANS_F_DENSE))) return LOANS_EINVAL;      // raw partial sums only
     if (d->B <= 0 || d->inH <= 0 || d->inW <= 0 || d->Cin <= 0 || (d->Cin & 7)) return LOANS_EINVAL;
     if (d->outH <= 0 || d->outW <= 0 || d->Cout <= 0 || (d->Cout & 7)) return LOANS_EINVAL;
     if (d->gridH <= 0 || d->gridW <= 0 || d->osy <= 0 || d->osx <= 0 || d->isy <= 0 || d->isx <= 0) return LOANS_EINVAL;
@@ -793,6 +823,8 @@ extern "C" int loans_igemm_bf16s(const void* in, const void* w, void* out, const
 #ifdef LOANS_EXPERIMENT
     if (const char* e = getenv("LOANS_DBG")) a.dbg = atoi(e);
 #endif
+    a.partial = partial;
+    a.splits = partial ? splits : 1;
     a.nchunks = (a.Ktot + BKH - 1) / BKH;
     {
         const int64_t ib = (int64_t)d->B * d->inH * d->inW * (dense ? 1 : d->Cin) * 2;
@@ -808,6 +840,7 @@ extern "C" int loans_igemm_bf16s(const void* in, const void* w, void* out, const
         const int64_t big = (int64_t)((a.M + 127) / 128) * ((d->Cout + 127) / 128);
         tile = d->Cout <= 64 ? LOANS_TILE_128x64 : (big >= 512 ? LOANS_TILE_128x128 : LOANS_TILE_64x64);
     }
+    if (partial && tile >= LOANS_TILE_HALO_128) return LOANS_EINVAL;      // the halo tiles have no split-K form
     switch (tile) {
         case LOANS_TILE_128x128: return launch_igemm16<128, 128, 2, 2>(a, st);
         case LOANS_TILE_128x64: return launch_igemm16<128, 64, 2, 2>(a, st);
@@ -821,6 +854,114 @@ extern "C" int loans_igemm_bf16s(const void* in, const void* w, void* out, const
             return loans_halo16_launch(in, w, out, bias, stats, ref, addend, d, tile, a.in_bytes, a.w_bytes, a.out_bytes, st);
         default: return LOANS_EINVAL;
     }
+}
+
+extern "C" int loans_igemm_bf16s(const void* in, const void* w, void* out, const float* bias, double* stats,
+                                 const void* ref, const void* addend, const loans_igemm_desc* d, void* stream) {
+    if (!out) return LOANS_EINVAL;
+    return igemm_bf16s_impl(in, w, out, bias, stats, ref, addend, d, nullptr, 1, stream);
+}
+
+extern "C" int loans_igemm_bf16s_splitk(const void* in, const void* w, float* partial, const loans_igemm_desc* d, int32_t splits,
+                                        void* stream) {
+    if (!partial || splits < 1 || splits > 64) return LOANS_EINVAL;
+    return igemm_bf16s_impl(in, w, nullptr, nullptr, nullptr, nullptr, nullptr, d, partial, splits, stream);
+}
+
+namespace {
+// the epilogue of a split-K convolution on bf16 storage: out = bf16(act(partial + bias)), statistics of (partial + bias) in fp64.
+// 8 channels per thread, C8 = Cout / 8 divides 256; one pass over the finished sums.
+__global__ __launch_bounds__(256) void igemm16_finalize_kernel(const float* partial, __bf16* out, const float* bias, double* stats,
+                                                               const __bf16* ref, const __bf16* addend, int flags, int64_t rows,
+                                                               int C8, int rows_per_block) {
+    __shared__ float red[2][256][8];
+    const int tid = threadIdx.x;
+    const int cl = tid % C8, rl = tid / C8, RL = 256 / C8;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    const bool f_bias = flags & LOANS_F_BIAS, f_stats = flags & LOANS_F_STATS, f_mask = flags & LOANS_F_MASK;
+    const bool f_add = flags & LOANS_F_ADDEND, f_addmask = flags & LOANS_F_ADDEND_MASK;
+    f32x4 b_lo = {0.f, 0.f, 0.f, 0.f}, b_hi = b_lo;
+    if (f_bias) {
+        b_lo = *reinterpret_cast<const f32x4*>(bias + cl * 8);
+        b_hi = *reinterpret_cast<const f32x4*>(bias + cl * 8 + 4);
+    }
+    auto keep_pos = [](f32x4 v, f32x4 m) {
+        v.x = m.x > 0.f ? v.x : 0.f; v.y = m.y > 0.f ? v.y : 0.f;
+        v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
+        return v;
+    };
+    f32x4 s1l = {0.f, 0.f, 0.f, 0.f}, s1h = s1l, s2l = s1l, s2h = s1l;
+    for (int64_t r = r0 + rl; r < r1; r += RL) {
+        const int64_t o = (r * C8 + cl) * 8;
+        f32x4 lo = *reinterpret_cast<const f32x4*>(partial + o) + b_lo;
+        f32x4 hi = *reinterpret_cast<const f32x4*>(partial + o + 4) + b_hi;
+        s1l += lo; s1h += hi;
+        s2l += lo * lo; s2h += hi * hi;
+        if (f_mask || f_addmask) {
+            const bf16x8_t rf = *reinterpret_cast<const bf16x8_t*>(ref + o);
+            const f32x4 ml = cvt_lo(rf), mh = cvt_hi(rf);
+            if (f_mask) { lo = keep_pos(lo, ml); hi = keep_pos(hi, mh); }
+            if (f_add) {
+                const bf16x8_t ad = *reinterpret_cast<const bf16x8_t*>(addend + o);
+                f32x4 al = cvt_lo(ad), ah = cvt_hi(ad);
+                if (f_addmask) { al = keep_pos(al, ml); ah = keep_pos(ah, mh); }
+                lo += al; hi += ah;
+            }
+        } else if (f_add) {
+            const bf16x8_t ad = *reinterpret_cast<const bf16x8_t*>(addend + o);
+            lo += cvt_lo(ad); hi += cvt_hi(ad);
+        }
+        bf16x8_t v;
+        const bf16x4_t ol = __builtin_convertvector(lo, bf16x4_t), oh = __builtin_convertvector(hi, bf16x4_t);
+        v[0] = ol[0]; v[1] = ol[1]; v[2] = ol[2]; v[3] = ol[3];
+        v[4] = oh[0]; v[5] = oh[1]; v[6] = oh[2]; v[7] = oh[3];
+        *reinterpret_cast<bf16x8_t*>(out + o) = v;
+    }
+    if (!f_stats) return;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        red[0][tid][e] = s1l[e]; red[0][tid][4 + e] = s1h[e];
+        red[1][tid][e] = s2l[e]; red[1][tid][4 + e] = s2h[e];
+    }
+    __syncthreads();
+    for (int c = tid; c < C8 * 8; c += 256) {
+        float t1 = 0.f, t2 = 0.f;
+        for (int k = 0; k < RL; ++k) {
+            t1 += red[0][(c >> 3) + k * C8][c & 7];
+            t2 += red[1][(c >> 3) + k * C8][c & 7];
+        }
+        const int C = C8 * 8;
+        double* st = stats + (size_t)(blockIdx.x % LOANS_STATS_REPLICAS) * 2 * C;
+        atomic_add_f64(st + c, (double)t1);
+        atomic_add_f64(st + C + c, (double)t2);
+    }
+}
+}  // namespace
+
+// Statistics are those of (sum + bias) BEFORE mask / addend -- what the fused epilogue of loans_igemm_bf16s takes from its
+// accumulators (the BN that follows a convolution sees the convolution's output; mask / addend belong to data gradients, which
+// carry no statistics).
+extern "C" int loans_igemm_finalize_bf16(const float* partial, void* out, const float* bias, double* stats, const void* ref,
+                                         const void* addend, int32_t flags, int64_t rows, int32_t Cout, void* stream) {
+    if (!partial || !out || rows <= 0 || Cout <= 0 || (Cout & 7)) return LOANS_EINVAL;
+    const int C8 = Cout / 8;
+    if (C8 > 256 || 256 % C8) return LOANS_EINVAL;          // the thread map: Cout / 8 divides 256
+    if ((flags & LOANS_F_BIAS) && !bias) return LOANS_EINVAL;
+    if ((flags & LOANS_F_STATS) && !stats) return LOANS_EINVAL;
+    if ((flags & (LOANS_F_MASK | LOANS_F_ADDEND_MASK)) && !ref) return LOANS_EINVAL;
+    if ((flags & LOANS_F_ADDEND) && !addend) return LOANS_EINVAL;
+    if (flags & ~(LOANS_F_BIAS | LOANS_F_STATS | LOANS_F_MASK | LOANS_F_ADDEND | LOANS_F_ADDEND_MASK)) return LOANS_EINVAL;
+    const int RL = 256 / C8;
+    int rows_per_block = RL * 8;
+    const int64_t nblk = (rows + rows_per_block - 1) / rows_per_block;
+    if (nblk >= ((int64_t)1 << 31)) return LOANS_ERANGE;
+    hipLaunchKernelGGL(igemm16_finalize_kernel, dim3((unsigned)nblk), dim3(256), 0, as_stream(stream), partial,
+                       static_cast<__bf16*>(out), bias, stats, static_cast<const __bf16*>(ref),
+                       static_cast<const __bf16*>(addend), flags, rows, C8, rows_per_block);
+    LOANS_LAUNCH_CHECK();
+    return LOANS_OK;
 }
 
 extern "C" int loans_cast_bf16(const float* src, void* dst, int64_t n, void* stream) {

@@ -284,6 +284,37 @@ TILE_HALO_128, TILE_HALO_256x64, TILE_HALO_128x64, TILE_HALO_128x64S = 11, 12, 1
 HALO = os.environ.get('LOANS_HALO', '1') != '0'
 
 
+def _splitk16_candidates(rows, out_channels, ktot):
+    """split-K forms of the bf16 implicit GEMM (loans_igemm_bf16s_splitk) for grids that cannot fill the machine: few tiles,
+    long K (res6 / res7 at 512 px, everything at small batch).  tile id = base tile | (splits << 8)."""
+    nchunks = (ktot + 63) // 64
+    out = []
+    c8 = out_channels // 8
+    if not SPLITK or out_channels % 8 or c8 > 256 or 256 % c8 or nchunks < 16:
+        return ()
+    for base, bm, bn in ((3, 64, 64), (2, 128, 64)):
+        tiles = ((rows + bm - 1) // bm) * ((out_channels + bn - 1) // bn)
+        # below one tile per CU only: at 256 tiles (res7 of configs[2]) the memset, the atomics and the finalize pass cost what
+        # the second resident block gains (measured: 0.036 - 0.039 against 0.041 ms per conv, nothing on the step)
+        if tiles >= 256:
+            continue
+        out += [base | (sp << 8) for sp in (2, 4, 8) if tiles * sp <= 2048 and nchunks // sp >= 4]
+    return tuple(out)
+
+
+def _igemm16_splitk(lib, src, d_list, out, flags, tile, bias, stats, ref, addend, rows, Cout, st):
+    """split-K convolution on bf16 storage: zeroed fp32 workspace, raw partial launches (one per descriptor: the parity classes
+    of a strided data gradient share the workspace), one finalize pass with the epilogue flags.  d_list = [(desc, weights)]."""
+    partial = torch.zeros((rows, Cout), device=out.device, dtype=torch.float32)
+    for d, wt in d_list:
+        check(lib.loans_igemm_bf16s_splitk(_ptr(src), _ptr(wt), _ptr(partial),
+                                           C.byref(_with_flags(d, flags & (F_RELU_IN | F_DENSE), tile & 0xFF)), tile >> 8, st),
+              'loans_igemm_bf16s_splitk')
+    check(lib.loans_igemm_finalize_bf16(_ptr(partial), _ptr(out), _ptr(bias), _ptr(stats), _ptr(ref), _ptr(addend),
+                                        flags & (F_BIAS | F_STATS | F_MASK | F_ADDEND | F_ADDEND_MASK), rows, Cout, st),
+          'loans_igemm_finalize_bf16')
+
+
 def _halo_tiles(geo, gathered_channels, out_channels, out_hw):
     """halo-tile candidates of a bf16-storage convolution / data gradient (the conditions of loans_halo16_covers), offered
     where a 8 x 16 pixel tile is not mostly empty"""
@@ -539,24 +570,33 @@ def _conv_fprop16(lib, x, w, geo, out, bias, stats, relu_in, addend, tile):
 
         def run(t):
             scratch = torch.empty((geo.B, geo.Ho, geo.Wo, geo.Cout), device=x.device, dtype=BF16)
+            if t >> 8:
+                _igemm16_splitk(lib, x, [(geo.fwd, w16)], scratch, tflags, t, None, sstats, None, None,
+                                geo.B * geo.Ho * geo.Wo, geo.Cout, _stream())
+                return
             check(lib.loans_igemm_bf16s(_ptr(x), _ptr(w16), _ptr(scratch), 0, _ptr(sstats), 0, 0,
                                         C.byref(_with_flags(geo.fwd, tflags, t)), _stream()), 'loans_igemm_bf16s[tune]')
         halo = _halo_tiles(geo, geo.Cin, geo.Cout, (geo.Ho, geo.Wo))
-        tile = _tuned_tile(geo, 'bf16s_fprop' + ('_stats' if stats is not None else '') + ('_h' if halo else ''), run,
-                           _IGEMM16_TILES + halo)
+        sk = () if geo.dense else _splitk16_candidates(geo.B * geo.Ho * geo.Wo, geo.Cout, geo.w_numel // geo.Cout)
+        tile = _tuned_tile(geo, 'bf16s_fprop' + ('_stats' if stats is not None else '') + ('_h' if halo else '') +
+                           ('_sk' if sk else ''), run, _IGEMM16_TILES + halo + sk)
     d = _with_flags(geo.fwd, flags, tile)
     _count_flops('fprop', geo)
     log = EVENT_LOG
     if log is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
-    check(lib.loans_igemm_bf16s(_ptr(x), _ptr(w16), _ptr(out), _ptr(bias), _ptr(stats), 0, _ptr(addend),
-                                C.byref(d), _stream()), 'loans_igemm_bf16s[fprop]')
+    if tile >> 8:
+        _igemm16_splitk(lib, x, [(geo.fwd, w16)], out, flags, tile, bias, stats, None, addend,
+                        geo.B * geo.Ho * geo.Wo, geo.Cout, _stream())
+    else:
+        check(lib.loans_igemm_bf16s(_ptr(x), _ptr(w16), _ptr(out), _ptr(bias), _ptr(stats), 0, _ptr(addend),
+                                    C.byref(d), _stream()), 'loans_igemm_bf16s[fprop]')
     if log is not None:
         ev1.record()
         log.append(('fprop_bn' if stats is not None else 'fprop',
-                    2 * geo.B * geo.Ho * geo.Wo * geo.Cout * geo.k * geo.k * geo.cin_logical, ev0, ev1, 1, 1,
-                    _conv_bytes(geo, x, w16, out)))
+                    2 * geo.B * geo.Ho * geo.Wo * geo.Cout * geo.k * geo.k * geo.cin_logical, ev0, ev1, 2 if tile >> 8 else 1, 1,
+                    _conv_bytes(geo, x, w16, out)))          # split-K: the partial launch and the finalize pass (the memset is torch's)
     return out
 
 
@@ -581,14 +621,30 @@ def _conv_dgrad16(lib, gy, w, geo, out, mask_ref, addend, addend_mask_ref, tile)
     for d, tapsel, off in geo.dgrad:
         check(lib.loans_repack_dgrad_bf16(_ptr(w), _ptr(wp[off:]), geo.Cout, geo.Cin, geo.k * geo.k, tapsel,
                                           d.ntaps, st), 'loans_repack_dgrad_bf16')
+    dl = [(d, wp[off:]) for d, _, off in geo.dgrad]
+    rows_in = geo.B * geo.H * geo.W
+    # a split-K data gradient finishes in ONE pass over the whole tensor: the tap-less classes of a strided 1x1 (which only
+    # take the addend, handled above by a copy) and an addend aliasing `out` do not go through it
+    sk_ok = not geo.dgrad_has_empty_class and not (addend is not None and addend.data_ptr() == out.data_ptr())
     if tile == 0:
         def run(t):
             scratch = torch.empty((geo.B, geo.H, geo.W, geo.Cin), device=gy.device, dtype=BF16)
+            if t >> 8:
+                _igemm16_splitk(lib, gy, dl, scratch, 0, t, None, None, None, None, rows_in, geo.Cin, st)
+                return
             for d, _, off in geo.dgrad:
                 check(lib.loans_igemm_bf16s(_ptr(gy), _ptr(wp[off:]), _ptr(scratch), 0, 0, 0, 0,
                                             C.byref(_with_flags(d, 0, t)), st), 'loans_igemm_bf16s[tune]')
         halo = _halo_tiles(geo, geo.Cout, geo.Cin, (geo.H, geo.W))
-        tile = _tuned_tile(geo, 'bf16s_dgrad' + ('_h' if halo else ''), run, _IGEMM16_TILES + halo)
+        sk = ()
+        if sk_ok:
+            cls_rows = geo.B * min(d.gridH * d.gridW for d, _, _ in geo.dgrad)
+            sk = _splitk16_candidates(cls_rows, geo.Cin, min(d.ntaps for d, _, _ in geo.dgrad) * geo.Cout)
+        tile = _tuned_tile(geo, 'bf16s_dgrad' + ('_h' if halo else '') + ('_sk' if sk else ''), run, _IGEMM16_TILES + halo + sk)
+    if tile >> 8:
+        assert sk_ok
+        _igemm16_splitk(lib, gy, dl, out, flags, tile, None, None, ref, addend, rows_in, geo.Cin, st)
+        return out
     for d, tapsel, off in geo.dgrad:
         _with_flags(d, flags, tile)
         check(lib.loans_igemm_bf16s(_ptr(gy), _ptr(wp[off:]), _ptr(out), 0, 0, _ptr(ref), _ptr(addend),

@@ -318,3 +318,43 @@ def test_conv_halo_tiles_bf16_storage(case, tile):
     gx3 = ops.conv_dgrad(gyd, wd, geo, addend=d16(_nhwc(addx)), addend_mask_ref=d16(_nhwc(ref_t)), tile=tile)
     assert rel_err(_nchw(gx3), gx_ref + addx * (ref_t > 0)) < BF16_EPS
     same(gx3, ops.conv_dgrad(gyd, wd, geo, addend=d16(_nhwc(addx)), addend_mask_ref=d16(_nhwc(ref_t)), tile=1), exact_d)
+
+
+@pytest.mark.parametrize("case", [(2, 256, 7, 7, 512, 3, 2, 1), (3, 512, 4, 4, 512, 3, 1, 1), (2, 128, 9, 9, 128, 4, 2, 1),
+                                  (2, 512, 8, 8, 64, 3, 1, 1)])
+@pytest.mark.parametrize("tile", [3 | (2 << 8), 3 | (4 << 8), 2 | (8 << 8)])
+def test_conv_split_k_bf16_storage(case, tile):
+    """split-K on bf16 storage (loans_igemm_bf16s_splitk + loans_igemm_finalize_bf16): raw fp32 partial tiles added into a
+    workspace, one finalize pass with bias / statistics / mask / addend and the single rounding to bf16 -- forward and data
+    gradient (all stride-parity classes into one workspace) against the oracle on the rounded operands and against the
+    unsplit kernel (another summation order under one rounding)."""
+    from loans_amd import ops
+    B, Cin, H, W, Cout, k, s, p = case
+    rng = np.random.RandomState(17)
+    x = _r(rng.standard_normal((B, Cin, H, W)))
+    w = (rng.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
+    wr = _r(w)
+    b = rng.standard_normal(Cout).astype(np.float32)
+    geo = ops.ConvGeometry(B, H, W, Cin, Cout, k, s, p)
+    xd, wd = d16(_nhwc(x)), dev(_nhwc(w))
+    y_ref, col = C.conv2d_fwd(x.astype(np.float64), wr.astype(np.float64), b.astype(np.float64), s, p)
+    s_k, s_1 = ops.stats_buffer(Cout, 'cuda'), ops.stats_buffer(Cout, 'cuda')
+    y = ops.conv_fprop(xd, wd, geo, bias=dev(b), stats=s_k, tile=tile)
+    y1 = ops.conv_fprop(xd, wd, geo, bias=dev(b), stats=s_1, tile=3)
+    assert y.dtype == torch.bfloat16 and rel_err(_nchw(y), y_ref) < BF16_EPS
+    assert float((y != y1).float().mean()) < 0.02
+    np.testing.assert_allclose(s_k.sum(0).cpu().numpy(), s_1.sum(0).cpu().numpy(), rtol=1e-5, atol=1e-3)
+    add = _r(rng.standard_normal(y_ref.shape))
+    y2 = ops.conv_fprop(xd, wd, geo, relu_in=True, addend=d16(_nhwc(add)), tile=tile)
+    y2_ref = C.conv2d_fwd(np.maximum(x, 0).astype(np.float64), wr.astype(np.float64), None, s, p)[0] + add
+    assert rel_err(_nchw(y2), y2_ref) < BF16_EPS
+    gy = _r(rng.standard_normal(y_ref.shape))
+    gx_ref = C.conv2d_bwd(x.shape, col, wr.astype(np.float64), gy.astype(np.float64), s, p, False)[0]
+    gyd = d16(_nhwc(gy))
+    gx = ops.conv_dgrad(gyd, wd, geo, tile=tile)
+    assert gx.dtype == torch.bfloat16 and rel_err(_nchw(gx), gx_ref) < BF16_EPS
+    ref_t, addx = _r(rng.standard_normal(x.shape)), _r(rng.standard_normal(x.shape))
+    gx2 = ops.conv_dgrad(gyd, wd, geo, mask_ref=d16(_nhwc(ref_t)), addend=d16(_nhwc(addx)), tile=tile)
+    assert rel_err(_nchw(gx2), gx_ref * (ref_t > 0) + addx) < BF16_EPS
+    gx3 = ops.conv_dgrad(gyd, wd, geo, addend=d16(_nhwc(addx)), addend_mask_ref=d16(_nhwc(ref_t)), tile=tile)
+    assert rel_err(_nchw(gx3), gx_ref + addx * (ref_t > 0)) < BF16_EPS
