@@ -17,6 +17,7 @@
 //   tile 8 x 16 x BN 64, one chunk (LOANS_TILE_HALO_128x64S, Cin = 64): 39 KiB, FOUR blocks per CU -- a Cin = 64 tile lives for
 //     nine steps only, so what hides its image load and its epilogue is other blocks, not its own pipeline
 #include "common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -39,7 +40,14 @@ struct Halo16Args {
     int nx, ny, dymin, dxmin, sdy, sdx;     // the taps are an ny x nx grid: dy = dy0 + row * sdy, dx = dx0 + col * sdx, sd = +-1
     int HH, HW;                             // halo image of a tile: (TH + ny - 1) x (TW + nx - 1) pixels
     unsigned in_bytes, w_bytes, out_bytes;
+    int dbg;                                // experiment bits (LOANS_EXPERIMENT builds only; 0 in the product library)
 };
+
+#ifdef LOANS_EXPERIMENT
+#define HDBG(bit) (a.dbg & (bit))
+#else
+#define HDBG(bit) false
+#endif
 
 __device__ __forceinline__ int xcd_remap_h(int id, int nblk) {
     const int q = nblk >> 3, r = nblk & 7, xcd = id & 7;
@@ -378,6 +386,220 @@ __global__ __launch_bounds__(256) void halo16_kernel(const Halo16Args a) {
     }
 }
 
+// ---- weights stationary in LDS: 3x3 / 1, Cin = 64, Cout <= 64 (the res2 convolutions and their data gradients) ----------
+// A Cin = 64 tile of the kernel above lives for nine steps of 8 MFMAs per wave, each behind a barrier and the L2 latency of its
+// weight tile: latency-bound at 0.2 ms per res2 convolution of configs[2] against an HBM bound of 0.085.  Here ONE 512-thread
+// block per CU keeps the whole weight matrix (9 taps x 64 x 64 bf16 = 72 KiB) in LDS for its lifetime and walks 16 x 16 pixel
+// tiles: per tile the only traffic is the halo image (double-buffered: tile k + 1 streams in under tile k's MFMAs) and the
+// output; no per-tap barrier, no weight re-read.  Wave w owns row block w (32 pixels) x all 64 output channels: 72 MFMAs per
+// tile, 3 fragment reads per 2 MFMAs.  (The same idea with the weights in REGISTERS -- 144 VGPRs per wave -- spills at two waves
+// per SIMD and its scratch reloads serialise the LDS-DMA: 0.46 ms.  Eight waves on one block need no weight registers.)
+// The output tile is staged through the tile's own, by then idle, image buffer in two passes of 128 rows; BN statistics stay in
+// registers (fp64) across the block's tiles and leave as one atomic pair per wave and column.
+constexpr int W8_T = 16, W8_BM = 256;
+constexpr int W8_APIECES = ((W8_T + 2) * (W8_T + 2) + 7) / 8, W8_APW = (W8_APIECES + 7) / 8, W8_ABUF = W8_APIECES * 8 * BKH;
+constexpr int W8_BELEMS = 9 * 64 * BKH;
+constexpr size_t ws8_lds_bytes() { return (size_t)2 * W8_ABUF * 2 + (size_t)W8_BELEMS * 2 + W8_BM * 4; }
+
+__global__ __launch_bounds__(512, 1) void ws8_kernel(const Halo16Args a, int ntiles) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __bf16* As = reinterpret_cast<__bf16*>(smem);                       // [2][APIECES * 8][64]
+    __bf16* Bl = As + 2 * W8_ABUF;                                      // [9][64 n][64 k], rows swizzled like a B tile
+    unsigned* opix = reinterpret_cast<unsigned*>(smem + (size_t)2 * W8_ABUF * 2 + (size_t)W8_BELEMS * 2);
+    const loans_igemm_desc& d = a.d;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.in), 0, (int)a.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.w), 0, (int)a.w_bytes, 0x00020000);
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+    // ---- all weights into LDS, once: 72 pieces of 1 KiB = 8 rows (n) x 128 B of one tap; lane (row l >> 3, slot l & 7) fetches
+    // unit slot ^ key(row), so that the fragment reads are conflict-free (the B-tile idiom of igemm16_kernel)
+    for (int pc = wave_u; pc < 72; pc += 8) {
+        const int t = pc >> 3, n = (pc & 7) * 8 + (lane >> 3);
+        const int unit = (lane & 7) ^ ((n >> 1) & 7);
+        const unsigned off = n < d.Cout ? (unsigned)n * (unsigned)a.Ktot * 2u + (unsigned)(t * 64) * 2u + (unsigned)unit * 16u : 0x80000000u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(Bl + pc * 8 * BKH), 16, (int)off, 0, 0, 0);
+    }
+    // per piece of the image this lane stages: its halo pixel (qy, qx) and its swizzled 16-byte unit -- fixed for the block
+    int pqy[W8_APW], pqx[W8_APW];
+#pragma unroll
+    for (int j = 0; j < W8_APW; ++j) {
+        const int q = (wave + 8 * j) * 8 + (lane >> 3);
+        pqy[j] = q / a.HW;
+        pqx[j] = (q - pqy[j] * a.HW) | ((((lane & 7) ^ ((q >> 1) & 7)) * 16) << 16);          // qx | unit bytes << 16
+        if (wave + 8 * j >= W8_APIECES || pqy[j] >= a.HH) pqy[j] = 1 << 20;                     // never inside an image
+    }
+    const int tiles_per_img = a.tiles_y * a.tiles_x;
+    auto issue_image = [&](int tile, int buf) {                         // the halo image of `tile` into A[buf] (this wave's pieces)
+        const int b = tile / tiles_per_img, tt = tile - b * tiles_per_img;
+        const int ty = tt / a.tiles_x, tx = tt - ty * a.tiles_x;
+        const int iy0 = ty * W8_T + a.dymin, ix0 = tx * W8_T + a.dxmin;
+        const int base = b * d.inH;
+        const bool tile_ok = tile < ntiles && !HDBG(1);                 // beyond the last tile: out-of-range offsets, no traffic
+#pragma unroll
+        for (int j = 0; j < W8_APW; ++j) {
+            if (wave_u + 8 * j < W8_APIECES) {
+                const int iy = iy0 + pqy[j], ix = ix0 + (pqx[j] & 0xFFFF);
+                const bool ok = tile_ok && (unsigned)iy < (unsigned)d.inH && (unsigned)ix < (unsigned)d.inW;
+                const unsigned off = ok ? (unsigned)((base + iy) * d.inW + ix) * 128u + ((unsigned)pqx[j] >> 16) : 0x80000000u;
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(As + buf * W8_ABUF + (wave_u + 8 * j) * 8 * BKH), 16, (int)off, 0, 0, 0);
+            }
+        }
+    };
+    const int m0 = wave * 32 + r;                                       // this lane's row of the tile
+    const int q0 = (m0 / W8_T) * a.HW + (m0 % W8_T);
+    const int fragB = r * BKH + ((h ^ ((r >> 1) & 7)) & 7) * 8;         // column r (and r + 32) of a tap's [64][64] block
+    const bool f_bias = d.flags & LOANS_F_BIAS, f_stats = d.flags & LOANS_F_STATS;
+    const bool f_mask = d.flags & LOANS_F_MASK, f_add = d.flags & LOANS_F_ADDEND, f_addmask = d.flags & LOANS_F_ADDEND_MASK;
+    const float bv0 = (f_bias && r < d.Cout) ? a.bias[r] : 0.f, bv1 = (f_bias && r + 32 < d.Cout) ? a.bias[r + 32] : 0.f;
+    double st_s0 = 0.0, st_q0 = 0.0, st_s1 = 0.0, st_q1 = 0.0;
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)a.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_ref = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<__bf16*>(a.ref ? a.ref : a.out), 0, (int)a.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_add = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<__bf16*>(a.addend ? a.addend : a.out), 0, (int)a.out_bytes, 0x00020000);
+    constexpr int LDC = 64 + 4;
+    const int oc8 = tid & 7, er0 = tid >> 3;                            // epilogue: 8-channel unit, row within a 64-row sweep
+    const unsigned cbad = (oc8 * 8 + 7 < d.Cout) ? 0u : 0xFFFFFFFFu;
+    f32x4 b_lo = {0.f, 0.f, 0.f, 0.f}, b_hi = b_lo;
+    if (f_bias && !cbad) {
+        b_lo = *reinterpret_cast<const f32x4*>(a.bias + oc8 * 8);
+        b_hi = *reinterpret_cast<const f32x4*>(a.bias + oc8 * 8 + 4);
+    }
+    auto keep_pos = [](f32x4 v, f32x4 m_) {
+        v.x = m_.x > 0.f ? v.x : 0.f; v.y = m_.y > 0.f ? v.y : 0.f;
+        v.z = m_.z > 0.f ? v.z : 0.f; v.w = m_.w > 0.f ? v.w : 0.f;
+        return v;
+    };
+
+    issue_image(blockIdx.x, 0);
+    int it = 0;
+    for (int tile = blockIdx.x; tile < ntiles; tile += gridDim.x, ++it) {
+        const int buf = it & 1;
+        __syncthreads();            // this tile's image (first tile: the weights too) has landed; the previous tile's stage is read out
+        issue_image(tile + gridDim.x, buf ^ 1);
+        if (tid < W8_BM) {
+            const int b = tile / tiles_per_img, tt = tile - b * tiles_per_img;
+            const int ty = tt / a.tiles_x, tx = tt - ty * a.tiles_x;
+            const int y = ty * W8_T + tid / W8_T, x = tx * W8_T + tid % W8_T;
+            opix[tid] = (y < d.outH && x < d.outW) ? (unsigned)((b * d.outH + y) * d.outW + x) * (unsigned)d.Cout * 2u : 0xFFFFFFFFu;
+        }
+        // ---- 9 taps x 4 k-steps x 2 column blocks = 72 MFMAs; fragments of step s + 1 are read while step s multiplies
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+        const __bf16* Ab = As + buf * W8_ABUF;
+        auto frags = [&](int t, int s_, bf16x8_t& fa, bf16x8_t& f0, bf16x8_t& f1) {
+            const int tr = t / 3, tc = t - tr * 3;
+            const int q = q0 + (a.sdy > 0 ? tr : 2 - tr) * a.HW + (a.sdx > 0 ? tc : 2 - tc);
+            fa = *reinterpret_cast<const bf16x8_t*>(Ab + ((q * BKH + ((h ^ (q >> 1)) & 7) * 8) ^ (s_ * 16)));
+            const __bf16* bt = Bl + t * 64 * BKH + (fragB ^ (s_ * 16));
+            f0 = *reinterpret_cast<const bf16x8_t*>(bt);
+            f1 = *reinterpret_cast<const bf16x8_t*>(bt + 32 * BKH);
+        };
+        bf16x8_t fa, f0, f1, ga, g0, g1;
+        frags(0, 0, fa, f0, f1);
+        if (!HDBG(2))
+#pragma unroll
+        for (int st = 0; st < 36; st += 2) {
+            frags((st + 1) >> 2, (st + 1) & 3, ga, g0, g1);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, f0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, f1, acc1, 0, 0, 0);
+            if (st + 2 < 36) frags((st + 2) >> 2, (st + 2) & 3, fa, f0, f1);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, g0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, g1, acc1, 0, 0, 0);
+        }
+        __syncthreads();            // all fragment reads of this image are done (and opix is visible): the buffer becomes the stage
+        if (f_stats) {
+            float s0 = 0.f, q20 = 0.f, s1 = 0.f, q21 = 0.f;
+            int nvalid = 0;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const bool live = opix[wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h] != 0xFFFFFFFFu;
+                const float v0 = live ? acc0[e] : 0.f, v1 = live ? acc1[e] : 0.f;
+                s0 += v0; q20 += v0 * v0;
+                s1 += v1; q21 += v1 * v1;
+                nvalid += (int)live;
+            }
+            const float cnt = (float)nvalid;
+            st_q0 += (double)(q20 + 2.f * bv0 * s0 + cnt * bv0 * bv0); st_s0 += (double)(s0 + cnt * bv0);
+            st_q1 += (double)(q21 + 2.f * bv1 * s1 + cnt * bv1 * bv1); st_s1 += (double)(s1 + cnt * bv1);
+        }
+        float* Cs = reinterpret_cast<float*>(As + buf * W8_ABUF);      // [128][LDC]: the row blocks of waves 4 pass .. 4 pass + 3
+        if (!HDBG(4))
+#pragma unroll
+        for (int pass = 0; pass < 2; ++pass) {
+            if (pass) __syncthreads();                                   // the first pass's readers are done
+            if ((wave >> 2) == pass) {
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    float* cp = Cs + ((wave & 3) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * LDC + r;
+                    cp[0] = acc0[e];
+                    cp[32] = acc1[e];
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int sw = 0; sw < 2; ++sw) {
+                const int lr = er0 + 64 * sw;                            // staged row = tile row 128 pass + lr
+                const unsigned po = opix[pass * 128 + lr];
+                const unsigned off = (po + (unsigned)oc8 * 16u) | (po == 0xFFFFFFFFu ? 0xFFFFFFFFu : 0u) | cbad;
+                f32x4 lo = *reinterpret_cast<const f32x4*>(Cs + lr * LDC + oc8 * 8) + b_lo;
+                f32x4 hi = *reinterpret_cast<const f32x4*>(Cs + lr * LDC + oc8 * 8 + 4) + b_hi;
+                if (f_mask || f_addmask) {
+                    const bf16x8_t rf = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_ref, (int)off, 0, 0));
+                    const f32x4 rl = lo4(rf), rh = hi4(rf);
+                    if (f_mask) { lo = keep_pos(lo, rl); hi = keep_pos(hi, rh); }
+                    if (f_add) {
+                        const bf16x8_t ad = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_add, (int)off, 0, 0));
+                        f32x4 al = lo4(ad), ah = hi4(ad);
+                        if (f_addmask) { al = keep_pos(al, rl); ah = keep_pos(ah, rh); }
+                        lo += al; hi += ah;
+                    }
+                } else if (f_add) {
+                    const bf16x8_t ad = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_add, (int)off, 0, 0));
+                    lo += lo4(ad); hi += hi4(ad);
+                }
+                bf16x8_t o;
+                const bf16x4_t ol = __builtin_convertvector(lo, bf16x4_t), oh = __builtin_convertvector(hi, bf16x4_t);
+                o[0] = ol[0]; o[1] = ol[1]; o[2] = ol[2]; o[3] = ol[3];
+                o[4] = oh[0]; o[5] = oh[1]; o[6] = oh[2]; o[7] = oh[3];
+                if (!HDBG(8)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_out, (int)off, 0, 0);
+            }
+        }
+    }
+    if (f_stats) {
+        st_s0 += __shfl_xor(st_s0, 32, 64); st_q0 += __shfl_xor(st_q0, 32, 64);
+        st_s1 += __shfl_xor(st_s1, 32, 64); st_q1 += __shfl_xor(st_q1, 32, 64);
+        if (h == 0) {
+            double* st = a.stats + (size_t)((blockIdx.x * 8 + wave) % LOANS_STATS_REPLICAS) * 2 * d.Cout;
+            if (r < d.Cout) { atomic_add_f64(st + r, st_s0); atomic_add_f64(st + d.Cout + r, st_q0); }
+            if (r + 32 < d.Cout) { atomic_add_f64(st + r + 32, st_s1); atomic_add_f64(st + d.Cout + r + 32, st_q1); }
+        }
+    }
+}
+
+int launch_ws8(Halo16Args& a, hipStream_t st) {
+    static loans_device_once lds_limit_set;
+    constexpr size_t lds = ws8_lds_bytes();
+    static_assert(lds <= 160 * 1024, "one block per CU");
+    if (int rc_ = loans_raise_lds_limit(lds_limit_set, reinterpret_cast<const void*>(ws8_kernel), lds)) return rc_;
+    a.tiles_y = (a.d.outH + W8_T - 1) / W8_T;
+    a.tiles_x = (a.d.outW + W8_T - 1) / W8_T;
+    a.tiles_n = 1;
+    a.HH = W8_T + 2;
+    a.HW = W8_T + 2;
+    const int64_t ntiles = (int64_t)a.d.B * a.tiles_y * a.tiles_x;
+    if (ntiles >= ((int64_t)1 << 31)) return LOANS_ERANGE;
+    const int cus = loans_device_cus();
+    if (cus <= 0) return LOANS_EINVAL;
+    const int64_t grid = ntiles < cus ? ntiles : cus;
+    hipLaunchKernelGGL(ws8_kernel, dim3((unsigned)grid), dim3(512), lds, st, a, (int)ntiles);
+    LOANS_LAUNCH_CHECK();
+    return LOANS_OK;
+}
+
 template <int TH, int TW, int BN, int WM, int WN, bool ADB, bool RELU>
 int launch_halo_r(Halo16Args& a, hipStream_t st) {
     static loans_device_once lds_limit_set;
@@ -412,6 +634,7 @@ int loans_halo16_covers(const loans_igemm_desc* d, int tile) {
     if (d->gridH != d->outH || d->gridW != d->outW) return 0;
     if (d->Cin % 64 || d->ntaps > 9) return 0;
     if ((tile == LOANS_TILE_HALO_256x64 || tile == LOANS_TILE_HALO_128x64S) && d->Cin != 64) return 0;
+    if (tile == LOANS_TILE_WS64 && (d->Cin != 64 || d->Cout > 64 || d->ntaps != 9 || (d->flags & LOANS_F_RELU_IN))) return 0;
     int nx = 1;
     while (nx < d->ntaps && d->dy[nx] == d->dy[0]) ++nx;
     if (d->ntaps % nx) return 0;
@@ -436,6 +659,10 @@ int loans_halo16_launch(const void* in, const void* w, void* out, const float* b
     a.Ktot = d->ntaps * d->Cin;
     a.cchunks = d->Cin / BKH;
     a.in_bytes = in_bytes; a.w_bytes = w_bytes; a.out_bytes = out_bytes;
+    a.dbg = 0;
+#ifdef LOANS_EXPERIMENT
+    if (const char* e = getenv("LOANS_HALO_DBG")) a.dbg = atoi(e);
+#endif
     if (in_bytes >= 0x80000000u || w_bytes >= 0x80000000u) return LOANS_ERANGE;       // offsets >= 2^31 mean "no load" here
     int nx = 1;
     while (nx < d->ntaps && d->dy[nx] == d->dy[0]) ++nx;
@@ -449,6 +676,7 @@ int loans_halo16_launch(const void* in, const void* w, void* out, const float* b
         case LOANS_TILE_HALO_128x64: return launch_halo<8, 16, 64, 4, 1, true>(a, st);
         case LOANS_TILE_HALO_256x64: return launch_halo<16, 16, 64, 4, 1, false>(a, st);
         case LOANS_TILE_HALO_128x64S: return launch_halo<8, 16, 64, 4, 1, false>(a, st);
+        case LOANS_TILE_WS64: return a.nx == 3 && a.ny == 3 ? launch_ws8(a, st) : LOANS_EINVAL;
         default: return LOANS_EINVAL;
     }
 }

@@ -851,6 +851,7 @@ static int igemm_bf16s_impl(const void* in, const void* w, void* out, const floa
         case LOANS_TILE_HALO_128x64:
         case LOANS_TILE_HALO_256x64:
         case LOANS_TILE_HALO_128x64S:
+        case LOANS_TILE_WS64:
             return loans_halo16_launch(in, w, out, bias, stats, ref, addend, d, tile, a.in_bytes, a.w_bytes, a.out_bytes, st);
         default: return LOANS_EINVAL;
     }

@@ -280,7 +280,7 @@ _WGRAD_TILES = (1, 3, 5)
 _WGRAD16_TILES = (1, 3, 5)
 _IGEMM16_TILES = tuple(int(t) for t in os.environ.get('LOANS_BF16S_TILES', '1,2,3,4,7').split(','))
 # LOANS_TILE_HALO_* (csrc/halo_bf16.hip): stride-1 convolutions with the input tile staged once per 64-channel chunk
-TILE_HALO_128, TILE_HALO_256x64, TILE_HALO_128x64, TILE_HALO_128x64S = 11, 12, 13, 14
+TILE_HALO_128, TILE_HALO_256x64, TILE_HALO_128x64, TILE_HALO_128x64S, TILE_WS64 = 11, 12, 13, 14, 15
 HALO = os.environ.get('LOANS_HALO', '1') != '0'
 
 
@@ -315,7 +315,7 @@ def _igemm16_splitk(lib, src, d_list, out, flags, tile, bias, stats, ref, addend
           'loans_igemm_finalize_bf16')
 
 
-def _halo_tiles(geo, gathered_channels, out_channels, out_hw):
+def _halo_tiles(geo, gathered_channels, out_channels, out_hw, relu_in=False):
     """halo-tile candidates of a bf16-storage convolution / data gradient (the conditions of loans_halo16_covers), offered
     where a 8 x 16 pixel tile is not mostly empty"""
     if not HALO or geo.dense or geo.stride != 1 or geo.k > 3 or gathered_channels % 64 or min(out_hw) < 6 or out_hw[1] < 12:
@@ -323,6 +323,8 @@ def _halo_tiles(geo, gathered_channels, out_channels, out_hw):
     tiles = (TILE_HALO_128, TILE_HALO_128x64) if out_channels > 64 else (TILE_HALO_128x64,)
     if gathered_channels == 64 and out_channels <= 64:
         tiles += (TILE_HALO_128x64S,) + ((TILE_HALO_256x64,) if min(out_hw) >= 12 else ())
+        if geo.k == 3 and geo.pad == 1 and not relu_in and min(out_hw) >= 12:
+            tiles += (TILE_WS64,)
     return tiles
 
 
@@ -576,7 +578,7 @@ def _conv_fprop16(lib, x, w, geo, out, bias, stats, relu_in, addend, tile):
                 return
             check(lib.loans_igemm_bf16s(_ptr(x), _ptr(w16), _ptr(scratch), 0, _ptr(sstats), 0, 0,
                                         C.byref(_with_flags(geo.fwd, tflags, t)), _stream()), 'loans_igemm_bf16s[tune]')
-        halo = _halo_tiles(geo, geo.Cin, geo.Cout, (geo.Ho, geo.Wo))
+        halo = _halo_tiles(geo, geo.Cin, geo.Cout, (geo.Ho, geo.Wo), relu_in)
         sk = () if geo.dense else _splitk16_candidates(geo.B * geo.Ho * geo.Wo, geo.Cout, geo.w_numel // geo.Cout)
         tile = _tuned_tile(geo, 'bf16s_fprop' + ('_stats' if stats is not None else '') + ('_h' if halo else '') +
                            ('_sk' if sk else ''), run, _IGEMM16_TILES + halo + sk)
