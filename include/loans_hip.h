@@ -124,6 +124,19 @@ int loans_igemm_f32(const float* in, const float* w, float* out,
                     const float* bias, double* stats, const float* ref, const float* addend,
                     const loans_igemm_desc* d, void* stream);
 
+/* The stride-parity classes of ONE strided data gradient in ONE launch (conv_transpose of a k x k / s convolution is s * s
+ * stride-1 correlations over interleaved output pixels -- in the reference a single F.deconvolution_2d inside
+ * Convolution2DFunction.backward, reached from every strided convolution of sheep/resnet.py:115-141).  descs[0..n) are the
+ * per-class descriptors loans_igemm_f32 would get one launch each; they may differ in gridH / gridW, oy0 / ox0 and the taps
+ * (<= LOANS_MAX_CLS_TAPS each) and must agree in everything else; w[c] is class c's [Cout][ntaps_c][Cin] matrix (host array of
+ * n device pointers, read before the call returns).  The classes' tiles share one grid -- the longest-K class should come
+ * first -- and so one tail.  Flags MASK / ADDEND / ADDEND_MASK / RELU_IN; fp32 arm; descs[0].tile one of 128x128, 128x64,
+ * 64x64, 256x64 (| LOANS_TILE_DMA), used for every class. */
+#define LOANS_MAX_CLASSES 4
+#define LOANS_MAX_CLS_TAPS 16
+int loans_igemm_classes_f32(const float* in, const float* const* w, float* out, const float* ref, const float* addend,
+                            const loans_igemm_desc* descs, int32_t n, void* stream);
+
 /* Two forward convolutions of the SAME input with the same geometry (kernel, stride, padding, Cin) in ONE launch: BasicA's
  * conv1 and its strided conv shortcut (sheep/resnet.py:128-133), a bottleneck's conv1 and conv4.  `d` describes
  * convolution a (Cout = Cout_a); b differs in weights, Cout_b, output and statistics.  The second one's tiles take the

@@ -77,6 +77,19 @@ struct IgemmArgs {
         int nx, ny, dy0, sdy, dx0, sdx;
         unsigned long long rowpat;      // bit (row * nx) set for every row
     } ap;
+    // class launch (loans_igemm_classes_f32): the stride-parity classes of ONE strided data gradient share a grid and a tail.
+    // Everything that differs between classes lives here and the kernel reads it through `k` -- an ordinary launch is a class
+    // launch with ncls = 1 (cls[0] mirrors d / ap / M / Ktot).
+    int ncls;
+    struct Cls {
+        const float* w;
+        unsigned w_bytes;
+        int gridH, gridW, oy0, ox0, ntaps;
+        int M, Ktot, nchunks, tail_groups, tiles_m, blk0, per_xcd;
+        int nx, ny, dy0, sdy, dx0, sdx;
+        unsigned long long rowpat;
+        signed char dy[LOANS_MAX_CLS_TAPS], dx[LOANS_MAX_CLS_TAPS];
+    } cls[LOANS_MAX_CLASSES];
 };
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -141,16 +154,30 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     const int logical = !fine ? xcd_remap(blockIdx.x, gridDim.x)
                               : (fine_tail ? xcd_remap(blockIdx.x - a.n_full, gridDim.x - a.n_full) : xcd_remap(blockIdx.x, a.n_full));
     const int my_splits = fine ? (fine_tail ? a.tail_splits : 1) : a.splits;
+    // class launch: block-uniform choice of the stride-parity class this block works for (class 0 in every other launch)
+    // Each XCD (blockIdx % 8) gets a contiguous eighth of EVERY class, longest K first: classes differ in K (1, 2, 2 and 4 taps
+    // for 3x3 / 2), so whole classes per XCD would leave some XCDs with 4x the work of others.  blk0 / per_xcd count blocks
+    // per XCD; a class's tile count is padded to a multiple of 8 and the (< 8) surplus blocks leave here.
+    int ci = 0, lcls = logical;
+    if (a.ncls > 1) {
+        const int x = blockIdx.x & 7, j = blockIdx.x >> 3;
+        for (int c = 1; c < a.ncls; ++c) ci += j >= a.cls[c].blk0;
+        lcls = x * a.cls[ci].per_xcd + (j - a.cls[ci].blk0);
+        if (lcls >= a.cls[ci].tiles_m * a.tiles_n) return;
+    }
+    const IgemmArgs::Cls& k = a.cls[ci];
+    const signed char* const tap_dy = a.ncls > 1 ? k.dy : reinterpret_cast<const signed char*>(d.dy);
+    const signed char* const tap_dx = a.ncls > 1 ? k.dx : reinterpret_cast<const signed char*>(d.dx);
     // pair launch: the blocks behind the first convolution's tiles belong to the second one (block-uniform selection)
-    const bool second = a.w2 != nullptr && logical >= a.tiles_m * a.tiles_n;
+    const bool second = a.w2 != nullptr && logical >= k.tiles_m * a.tiles_n;
     const int Cout = second ? a.Cout2 : d.Cout;
     const int tiles_n = second ? a.tiles_n2 : a.tiles_n;
-    const float* const w_sel = second ? a.w2 : a.w;
+    const float* const w_sel = second ? a.w2 : k.w;
     float* const out_sel = second ? a.out2 : a.out;
     double* const stats_sel = second ? a.stats2 : a.stats;
-    const unsigned w_bytes = second ? a.w2_bytes : a.w_bytes, out_bytes = second ? a.out2_bytes : a.out_bytes;
-    const int lfirst = second ? logical - a.tiles_m * a.tiles_n : logical;
-    const int ntile = a.tiles_m * tiles_n;
+    const unsigned w_bytes = second ? a.w2_bytes : k.w_bytes, out_bytes = second ? a.out2_bytes : a.out_bytes;
+    const int lfirst = second ? logical - k.tiles_m * a.tiles_n : lcls;
+    const int ntile = k.tiles_m * tiles_n;
     int split = a.w2 ? 0 : lfirst / ntile;              // 0 unless split-K
     int ltile = lfirst - split * ntile;
     if (fine) {
@@ -160,11 +187,11 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     }
     const int tn = ltile % tiles_n;
     const int tm = ltile / tiles_n;
-    const int cps = (fine && !fine_tail) ? a.nchunks : a.chunks_per_split;
+    const int cps = (fine && !fine_tail) ? k.nchunks : (a.ncls > 1 ? k.nchunks : a.chunks_per_split);
     const int c_begin = split * cps;                    // this block's K chunks
-    const int c_end = min(c_begin + cps, a.nchunks);
+    const int c_end = min(c_begin + cps, k.nchunks);
     const int nch = c_end - c_begin;
-    const int tail_groups = c_end == a.nchunks ? a.tail_groups : 4;
+    const int tail_groups = c_end == k.nchunks ? k.tail_groups : 4;
     const int lrow = tid >> 3;
     const int lu = DMA ? ((tid & 7) ^ ((tid >> 4) & 7)) : (tid & 7);   // K unit this thread stages (DMA: slot ^ row key)
     // tap table in LDS: byte offset of tap t relative to the row's base pixel
@@ -173,8 +200,8 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     const bool dense = d.flags & LOANS_F_DENSE;
     const int ubytes = dense ? 4 : d.Cin * 4;          // bytes per unit of inW / ix
     if (tid < LOANS_MAX_TAPS) {
-        const int t = tid < d.ntaps ? tid : 0;
-        taps[tid] = (int(d.dy[t]) * d.inW + int(d.dx[t])) * ubytes;
+        const int t = tid < k.ntaps ? tid : 0;
+        taps[tid] = (int(tap_dy[t]) * d.inW + int(tap_dx[t])) * ubytes;
     }
 
     // per row (fixed for the whole K loop): byte offset of its base pixel and a bitmask with bit t SET
@@ -185,44 +212,45 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     unsigned rowoff[RA];
     unsigned long long badmask[RA];
     {
-        const int gHW = d.gridH * d.gridW;
-        const float inv_gw = 1.f / (float)d.gridW, inv_gh = 1.f / (float)d.gridH;
+        const int gridH = k.gridH, gridW = k.gridW;
+        const int gHW = gridH * gridW;
+        const float inv_gw = 1.f / (float)gridW, inv_gh = 1.f / (float)gridH;
         const int m0 = a.m_begin + tm * BM + lrow;
         int b = m0 / gHW;
         int rem = m0 - b * gHW;
-        int y = rem / d.gridW;
-        int x = rem - y * d.gridW;
+        int y = rem / gridW;
+        int x = rem - y * gridW;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
             const int m = m0 + 32 * i;
             unsigned pixoff = 0xFFFFFFFFu;
             unsigned long long mask = 0;
             rowoff[i] = 0;
-            if (m < a.M) {
+            if (m < k.M) {
                 const int iy0 = y * d.isy, ix0 = x * d.isx;
                 rowoff[i] = (unsigned)((b * d.inH + iy0) * d.inW + ix0) * (unsigned)ubytes;
-                pixoff = (unsigned)((b * d.outH + y * d.osy + d.oy0) * d.outW + x * d.osx + d.ox0) * (unsigned)Cout *
+                pixoff = (unsigned)((b * d.outH + y * d.osy + k.oy0) * d.outW + x * d.osx + k.ox0) * (unsigned)Cout *
                          ((d.flags & LOANS_F_OUT_BF16) ? 2u : 4u);
                 if (dense) {
                     mask = ~0ull;
-                } else if (a.ap.nx > 0) {
+                } else if (k.nx > 0) {
                     // column j valid <=> 0 <= ix0 + dx0 + j*sdx < inW  (sdx = +-1): a contiguous j range
-                    const int cx = ix0 + a.ap.dx0, cy = iy0 + a.ap.dy0;
+                    const int cx = ix0 + k.dx0, cy = iy0 + k.dy0;
                     int jlo, jhi, rlo, rhi;
-                    if (a.ap.sdx > 0) { jlo = max(0, -cx); jhi = min(a.ap.nx, d.inW - cx); }
-                    else { jlo = max(0, cx - d.inW + 1); jhi = min(a.ap.nx, cx + 1); }
-                    if (a.ap.sdy > 0) { rlo = max(0, -cy); rhi = min(a.ap.ny, d.inH - cy); }
-                    else { rlo = max(0, cy - d.inH + 1); rhi = min(a.ap.ny, cy + 1); }
+                    if (k.sdx > 0) { jlo = max(0, -cx); jhi = min(k.nx, d.inW - cx); }
+                    else { jlo = max(0, cx - d.inW + 1); jhi = min(k.nx, cx + 1); }
+                    if (k.sdy > 0) { rlo = max(0, -cy); rhi = min(k.ny, d.inH - cy); }
+                    else { rlo = max(0, cy - d.inH + 1); rhi = min(k.ny, cy + 1); }
                     if (jhi > jlo && rhi > rlo) {
                         const unsigned long long colbits = ((1ull << jhi) - 1ull) & ~((1ull << jlo) - 1ull);
-                        const int blo = rlo * a.ap.nx, bhi = rhi * a.ap.nx;     // bhi <= 64
+                        const int blo = rlo * k.nx, bhi = rhi * k.nx;     // bhi <= 64
                         const unsigned long long below_hi = bhi >= 64 ? ~0ull : ((1ull << bhi) - 1ull);
-                        const unsigned long long rowsel = a.ap.rowpat & below_hi & ~((1ull << blo) - 1ull);
+                        const unsigned long long rowsel = k.rowpat & below_hi & ~((1ull << blo) - 1ull);
                         mask = colbits * rowsel;       // colbits < 2^nx, rowsel bits nx apart: no carries
                     }
                 } else {
-                    for (int t = 0; t < d.ntaps; ++t) {
-                        const int iy = iy0 + d.dy[t], ix = ix0 + d.dx[t];
+                    for (int t = 0; t < k.ntaps; ++t) {
+                        const int iy = iy0 + tap_dy[t], ix = ix0 + tap_dx[t];
                         if ((unsigned)iy < (unsigned)d.inH && (unsigned)ix < (unsigned)d.inW) mask |= 1ull << t;
                     }
                 }
@@ -235,10 +263,10 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
             // advance 32 pixels: exact floor((v + .5) / n) for the small integers involved
             x += 32;
             const int qx = (int)(((float)x + 0.5f) * inv_gw);
-            x -= qx * d.gridW;
+            x -= qx * gridW;
             y += qx;
             const int qy = (int)(((float)y + 0.5f) * inv_gh);
-            y -= qy * d.gridH;
+            y -= qy * gridH;
             b += qy;
         }
     }
@@ -252,6 +280,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
         const_cast<float*>(w_sel), 0, (int)w_bytes, 0x00020000);
 
     const int cpt = d.Cin >> 2;   // float4 units per tap
+    const int Ktot = k.Ktot;
     const int q8 = 8 / cpt, r8 = 8 - q8 * cpt;
     int u = lu + 8 * c_begin;     // this thread's K unit in the chunk being loaded
     int tap = u / cpt, c4 = u - tap * cpt;
@@ -260,7 +289,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     for (int i = 0; i < RB; ++i) {
         const int n = tn * BN + lrow + 32 * i;
         wbad[i] = n < Cout ? 0u : 0xFFFFFFFFu;
-        woff[i] = n < Cout ? (unsigned)n * (unsigned)a.Ktot * 4u : 0u;
+        woff[i] = n < Cout ? (unsigned)n * (unsigned)Ktot * 4u : 0u;
     }
     unsigned toff = (unsigned)taps[min(tap, LOANS_MAX_TAPS - 1)] + (unsigned)c4 * 16u;   // prefetched one chunk ahead
 
@@ -269,13 +298,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     // that the K loop can drop one piece behind each MFMA of group 0: no waits, no branches.
     auto load_a = [&](int i) {
         const int tc = min(tap, LOANS_MAX_TAPS - 1);
-        const unsigned kbad = (unsigned)(u * 4 < a.Ktot) - 1u;
+        const unsigned kbad = (unsigned)(u * 4 < Ktot) - 1u;
         const unsigned bad = 0u - ((unsigned)(badmask[i] >> tc) & 1u);
         const unsigned off = (rowoff[i] + toff) | bad | kbad;
         ra[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)off, 0, 0));
     };
     auto load_b = [&](int i) {
-        const unsigned kbad = (unsigned)(u * 4 < a.Ktot) - 1u;
+        const unsigned kbad = (unsigned)(u * 4 < Ktot) - 1u;
         const unsigned off = (woff[i] + (unsigned)u * 16u) | wbad[i] | kbad;
         rb[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_w, (int)off, 0, 0));
     };
@@ -283,13 +312,13 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
     auto dma_a = [&](int buf, int i) {      // one 1 KiB LDS-DMA piece: 8 rows x 128 B of the A tile
         const int tc = min(tap, LOANS_MAX_TAPS - 1);
-        const unsigned kbad = (unsigned)(u * 4 < a.Ktot) - 1u;
+        const unsigned kbad = (unsigned)(u * 4 < Ktot) - 1u;
         const unsigned bad = 0u - ((unsigned)(badmask[i] >> tc) & 1u);
         const unsigned off = (rowoff[i] + toff) | bad | kbad;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(As + (buf * BM + 32 * i + 8 * wave_u) * BK), 16, (int)off, 0, 0, 0);
     };
     auto dma_b = [&](int buf, int i) {
-        const unsigned kbad = (unsigned)(u * 4 < a.Ktot) - 1u;
+        const unsigned kbad = (unsigned)(u * 4 < Ktot) - 1u;
         const unsigned off = (woff[i] + (unsigned)u * 16u) | wbad[i] | kbad;
         __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(Bs + (buf * BN + 32 * i + 8 * wave_u) * BK), 16, (int)off, 0, 0, 0);
     };
@@ -715,6 +744,17 @@ constexpr size_t igemm_lds_bytes() {
     return igemm_aux_floats<BM, BN, DMA>() * 4 + LOANS_MAX_TAPS * 4 + BM * 4;
 }
 
+// an ordinary launch is a class launch with one class: the kernel reads the per-class view only
+void fill_class0(IgemmArgs& a) {
+    IgemmArgs::Cls& k = a.cls[0];
+    a.ncls = 1;
+    k.w = a.w; k.w_bytes = a.w_bytes;
+    k.gridH = a.d.gridH; k.gridW = a.d.gridW; k.oy0 = a.d.oy0; k.ox0 = a.d.ox0; k.ntaps = a.d.ntaps;
+    k.M = a.M; k.Ktot = a.Ktot; k.nchunks = a.nchunks; k.tail_groups = a.tail_groups; k.tiles_m = a.tiles_m; k.blk0 = 0; k.per_xcd = 0;
+    k.nx = a.ap.nx; k.ny = a.ap.ny; k.dy0 = a.ap.dy0; k.sdy = a.ap.sdy; k.dx0 = a.ap.dx0; k.sdx = a.ap.sdx;
+    k.rowpat = a.ap.rowpat;
+}
+
 template <int BM, int BN, int WM, int WN, bool RELU, bool BF16, bool DMA>
 int launch_igemm_r(IgemmArgs& a, hipStream_t st) {
     static loans_device_once lds_limit_set;       // per template instance = per kernel, one bit per device
@@ -730,6 +770,21 @@ int launch_igemm_r(IgemmArgs& a, hipStream_t st) {
     a.tiles_m = (a.M - a.m_begin + BM - 1) / BM;
     a.tiles_n = (a.d.Cout + BN - 1) / BN;
     a.tiles_n2 = a.w2 ? (a.Cout2 + BN - 1) / BN : 0;
+    if (a.ncls > 1) {           // class launch: every class at full K, its tiles behind the previous class's
+        if (a.w2 || a.splits != 1 || a.n_full > 0 || a.m_begin) return LOANS_EINVAL;
+        int per_xcd = 0;
+        for (int c = 0; c < a.ncls; ++c) {
+            a.cls[c].tiles_m = (a.cls[c].M + BM - 1) / BM;
+            a.cls[c].per_xcd = (a.cls[c].tiles_m * a.tiles_n + 7) / 8;
+            a.cls[c].blk0 = per_xcd;
+            per_xcd += a.cls[c].per_xcd;
+        }
+        a.chunks_per_split = a.cls[0].nchunks;
+        hipLaunchKernelGGL(kern, dim3(8 * per_xcd), dim3(256), lds, st, a);
+        LOANS_LAUNCH_CHECK();
+        return LOANS_OK;
+    }
+    fill_class0(a);
     if (a.splits > a.nchunks) a.splits = a.nchunks;
     a.chunks_per_split = (a.nchunks + a.splits - 1) / a.splits;
     a.splits = (a.nchunks + a.chunks_per_split - 1) / a.chunks_per_split;
@@ -803,9 +858,15 @@ struct IgemmPair {       // second convolution of a pair launch
     int Cout;
 };
 
+struct IgemmClasses {    // class launch: descs[0] is `d`, the weights of class c at w[c]
+    int n;
+    const loans_igemm_desc* descs;
+    const float* const* w;
+};
+
 static int igemm_impl(const float* in, const float* w, float* out, const float* bias, double* stats,
                       const float* ref, const float* addend, const loans_igemm_desc* d, void* stream, int bf16,
-                      const IgemmPair* pair = nullptr) {
+                      const IgemmPair* pair = nullptr, const IgemmClasses* mc = nullptr) {
     int rc = check_desc(d);
     if (rc) return rc;
     if (!in || !w || !out || (d->Cout & 3)) return LOANS_EINVAL;
@@ -847,8 +908,42 @@ static int igemm_impl(const float* in, const float* w, float* out, const float* 
         a.w2 = pair->w; a.out2 = pair->out; a.stats2 = pair->stats; a.Cout2 = pair->Cout;
         a.w2_bytes = (unsigned)wb2; a.out2_bytes = (unsigned)ob2;
     }
+    a.ncls = 1;
+    if (mc) {
+        // the classes differ in their grid, their output phase and their taps; image, strides, channels and flags are shared
+        if (pair || bf16 || mc->n < 2 || mc->n > LOANS_MAX_CLASSES) return LOANS_EINVAL;
+        if (d->flags & (LOANS_F_DENSE | LOANS_F_STATS | LOANS_F_BIAS)) return LOANS_EINVAL;
+        a.ncls = mc->n;
+        for (int c = 0; c < mc->n; ++c) {
+            const loans_igemm_desc* e = mc->descs + c;
+            if ((rc = check_desc(e))) return rc;
+            if (!mc->w[c] || e->ntaps > LOANS_MAX_CLS_TAPS) return LOANS_EINVAL;
+            if (e->B != d->B || e->inH != d->inH || e->inW != d->inW || e->Cin != d->Cin || e->outH != d->outH ||
+                e->outW != d->outW || e->Cout != d->Cout || e->osy != d->osy || e->osx != d->osx || e->isy != d->isy ||
+                e->isx != d->isx || e->flags != d->flags)
+                return LOANS_EINVAL;
+            IgemmArgs t;                    // tap grid of this class
+            detect_tap_grid(e, t);
+            IgemmArgs::Cls& k = a.cls[c];
+            k.w = mc->w[c];
+            k.gridH = e->gridH; k.gridW = e->gridW; k.oy0 = e->oy0; k.ox0 = e->ox0; k.ntaps = e->ntaps;
+            k.M = e->B * e->gridH * e->gridW;
+            k.Ktot = e->ntaps * e->Cin;
+            k.w_bytes = (unsigned)((int64_t)e->Cout * k.Ktot * 4);
+            k.nchunks = (k.Ktot + BK - 1) / BK;
+            k.tail_groups = (k.Ktot - (k.nchunks - 1) * BK + 7) / 8;
+            k.tiles_m = 0; k.blk0 = 0; k.per_xcd = 0;      // per tile shape: launch_igemm_r
+            k.nx = t.ap.nx; k.ny = t.ap.ny; k.dy0 = t.ap.dy0; k.sdy = t.ap.sdy; k.dx0 = t.ap.dx0; k.sdx = t.ap.sdx;
+            k.rowpat = t.ap.rowpat;
+            for (int i = 0; i < LOANS_MAX_CLS_TAPS; ++i) { k.dy[i] = e->dy[i < e->ntaps ? i : 0]; k.dx[i] = e->dx[i < e->ntaps ? i : 0]; }
+        }
+    }
     hipStream_t st = as_stream(stream);
     int tile = d->tile;
+    if (mc) {
+        const int t = tile & ~LOANS_TILE_DMA;
+        if (t != LOANS_TILE_128x128 && t != LOANS_TILE_128x64 && t != LOANS_TILE_64x64 && t != LOANS_TILE_256x64) return LOANS_EINVAL;
+    }
     if (pair && ((tile >> 8) || (tile & 0xFF) == LOANS_TILE_SPLIT)) return LOANS_EINVAL;
     a.splits = (tile >> 8) & 0xFF;          // LOANS_TILE_SPLITK(s)
     if (a.splits < 1) a.splits = 1;
@@ -934,6 +1029,14 @@ static int igemm_impl(const float* in, const float* w, float* out, const float* 
 extern "C" int loans_igemm_f32(const float* in, const float* w, float* out, const float* bias, double* stats,
                                const float* ref, const float* addend, const loans_igemm_desc* d, void* stream) {
     return igemm_impl(in, w, out, bias, stats, ref, addend, d, stream, 0);
+}
+
+extern "C" int loans_igemm_classes_f32(const float* in, const float* const* w, float* out, const float* ref, const float* addend,
+                                       const loans_igemm_desc* descs, int32_t n, void* stream) {
+    if (!descs || !w || n < 1) return LOANS_EINVAL;
+    if (n == 1) return igemm_impl(in, w[0], out, nullptr, nullptr, ref, addend, descs, stream, 0);
+    const IgemmClasses mc = {n, descs, w};
+    return igemm_impl(in, w[0], out, nullptr, nullptr, ref, addend, descs, stream, 0, nullptr, &mc);
 }
 
 extern "C" int loans_igemm_pair_f32(const float* in, const float* w_a, float* out_a, double* stats_a, const float* w_b,

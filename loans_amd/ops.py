@@ -126,7 +126,7 @@ def save_tune_table(path):
     import json
     table = {_tune_key_str(k): dict(v) for k, v in sorted(_TUNE_CACHE.items()) if v}
     with open(path, 'w') as f:
-        json.dump({"what": "loans_amd tile table: (B,H,W,Cin,Cout,k,stride,pad,dense) -> {mode: tile id | splits << 8}",
+        json.dump({"what": "loans_amd tile table: (B,H,W,Cin,Cout,k,stride,pad,dense) -> {mode: tile id | splits << 8 | class launch << 16}",
                    "entries": table}, f, indent=1, sort_keys=True)
     return len(table)
 
@@ -700,19 +700,25 @@ def conv_dgrad(gy, w, geo, out=None, mask_ref=None, addend=None, addend_mask_ref
     if tile == 0:
         def run(t):
             scratch = torch.empty((geo.B, geo.H, geo.W, geo.Cin), device=gy.device, dtype=torch.float32)
+            if t & TILE_CLASSES:
+                _igemm_classes(lib, gy, wp, scratch, geo, 0, t & 0xFF, None, None, st)
+                return
             if t >> 8:
                 _igemm_splitk(lib, gy, None, scratch, dl, 0, t, None, None, None, None, rows_in, geo.Cin, st)
                 return
             for d, _, off in geo.dgrad:
                 check(_igemm_fn(lib)(_ptr(gy), _ptr(wp[off:]), _ptr(scratch), 0, 0, 0, 0,
                                      C.byref(_with_flags(d, 0, t)), st), 'loans_igemm[tune]')
-        cands, key = _IGEMM_TILES, COMPUTE + 'dgrad'
+        cands, key = _IGEMM_TILES + _class_candidates(geo), COMPUTE + 'dgrad'
         if not inplace_masked and reduce_channels_ok(geo.Cin):
             # the smallest class grid decides: (Ho x Wo pixels of one parity class) x Cin columns, K = its taps x Cout
             cls_rows = geo.B * geo.dgrad[0][0].gridH * geo.dgrad[0][0].gridW
             sk = _splitk_candidates(cls_rows, geo.Cin, (min(d.ntaps for d, _, _ in geo.dgrad) * geo.Cout + 31) // 32)
             cands, key = cands + sk, key + ('_sk' if sk else '')
         tile = _tuned_tile(geo, key, run, cands)
+    if tile & TILE_CLASSES:
+        _igemm_classes(lib, gy, wp, out, geo, flags, tile & 0xFF, ref, addend, st)
+        return out
     if tile >> 8:
         _igemm_splitk(lib, gy, None, out, dl, flags, tile, None, None, ref, addend, rows_in, geo.Cin, st)
         return out
@@ -721,6 +727,30 @@ def conv_dgrad(gy, w, geo, out=None, mask_ref=None, addend=None, addend_mask_ref
         check(_igemm_fn(lib)(_ptr(gy), _ptr(wp[off:]), _ptr(out), 0, 0, _ptr(ref), _ptr(addend),
                              C.byref(d), st), 'loans_igemm[dgrad]')
     return out
+
+
+# tile id bit (host side only): every stride-parity class of a strided data gradient in ONE launch (loans_igemm_classes_f32)
+TILE_CLASSES = 1 << 16
+CLASS_LAUNCH = os.environ.get('LOANS_CLASS_LAUNCH', '1') != '0'
+
+
+def _class_candidates(geo):
+    if not CLASS_LAUNCH or COMPUTE != 'f32' or not 2 <= len(geo.dgrad) <= 4 or max(d.ntaps for d, _, _ in geo.dgrad) > 16:
+        return ()
+    return tuple(t | TILE_CLASSES for t in _IGEMM_TILES if (t & 15) in (1, 2, 3, 4))
+
+
+def _igemm_classes(lib, gy, wp, out, geo, flags, tile, ref, addend, st):
+    """classes in descending K: the long blocks start first, the 1-tap class fills the tail"""
+    order = sorted(geo.dgrad, key=lambda e: -e[0].ntaps)
+    n = len(order)
+    descs = (_lib.IgemmDesc * n)()
+    ws = (C.c_void_p * n)()
+    for i, (d, _, off) in enumerate(order):
+        C.memmove(C.byref(descs[i]), C.byref(_with_flags(d, flags, tile)), C.sizeof(_lib.IgemmDesc))
+        ws[i] = _ptr(wp[off:])
+    check(lib.loans_igemm_classes_f32(_ptr(gy), ws, _ptr(out), _ptr(ref), _ptr(addend), descs, n, st),
+          'loans_igemm_classes_f32')
 
 
 # LOANS_CROP_DGRAD=0: the gradient w.r.t. the 4-channel crops goes back to one loans_dgrad_c4 launch per stride-parity class

@@ -105,6 +105,82 @@ def test_conv_fprop_dgrad_wgrad(case, tile):
         assert rel_err(got, 2 * gw_ref) < 5e-6
 
 
+@pytest.mark.parametrize("case", [(2, 64, 15, 13, 128, 3, 2, 1), (3, 128, 9, 9, 128, 4, 2, 1), (1, 256, 7, 7, 512, 3, 2, 1),
+                                  (2, 64, 56, 56, 128, 3, 2, 1), (2, 64, 9, 10, 128, 1, 2, 0), (2, 32, 11, 11, 64, 3, 3, 1)])
+@pytest.mark.parametrize("tile", [1, 2, 3, 4, 17, 18, 19, 20])
+def test_conv_dgrad_class_launch(case, tile):
+    """loans_igemm_classes_f32: the stride-parity classes of a strided data gradient in one grid.  Every block contracts its
+    class's K in the order of the per-class launch, so the two are bit-identical -- plain, masked and with addends; the
+    per-class path itself is checked against the oracle above."""
+    from loans_amd import ops
+    B, Cin, H, W, Cout, k, s, p = case
+    rng = np.random.RandomState(7)
+    geo = ops.ConvGeometry(B, H, W, Cin, Cout, k, s, p)
+    w = dev((rng.standard_normal((Cout, k, k, Cin)) / np.sqrt(Cin * k * k)).astype(np.float32))
+    gy = dev(rng.standard_normal((B, geo.Ho, geo.Wo, Cout)).astype(np.float32))
+    ref_t = dev(rng.standard_normal((B, H, W, Cin)).astype(np.float32))
+    add = dev(rng.standard_normal((B, H, W, Cin)).astype(np.float32))
+    if len(geo.dgrad) > 4:          # LOANS_MAX_CLASSES: stride 3 has nine classes, no convolution of this path has
+        from loans_amd._lib import HipKernelError
+        with pytest.raises(HipKernelError):
+            ops.conv_dgrad(gy, w, geo, tile=tile | ops.TILE_CLASSES)
+        return
+    kinds = [dict(), dict(addend=add)]
+    if not geo.dgrad_has_empty_class:
+        kinds += [dict(mask_ref=ref_t), dict(mask_ref=ref_t, addend=add), dict(addend=add, addend_mask_ref=ref_t)]
+    for kw in kinds:
+        one = ops.conv_dgrad(gy, w, geo, tile=tile | ops.TILE_CLASSES, **kw)
+        per = ops.conv_dgrad(gy, w, geo, tile=tile, **kw)
+        assert torch.equal(one, per), (case, tile, sorted(kw))
+    acc_a, acc_b = add.clone(), add.clone()
+    ops.conv_dgrad(gy, w, geo, out=acc_a, addend=acc_a, tile=tile | ops.TILE_CLASSES)         # in-place accumulate
+    ops.conv_dgrad(gy, w, geo, out=acc_b, addend=acc_b, tile=tile)
+    assert torch.equal(acc_a, acc_b)
+
+
+def test_conv_dgrad_class_launch_rejects():
+    """classes that disagree in a shared field, too many taps, a tile shape without a class form: LOANS_EINVAL, no launch"""
+    import ctypes as Ct
+    from loans_amd import _lib, ops
+    lib = _lib.load()
+    geo = ops.ConvGeometry(2, 16, 16, 64, 64, 3, 2, 1)
+    gy = torch.zeros((2, 8, 8, 64), device='cuda')
+    wp = torch.zeros(geo.dgrad_weight_floats, device='cuda')
+    out = torch.zeros((2, 16, 16, 64), device='cuda')
+    n = len(geo.dgrad)
+
+    def call(mut=None, tile=3):
+        descs = (_lib.IgemmDesc * n)()
+        ws = (Ct.c_void_p * n)()
+        for i, (d, _, off) in enumerate(geo.dgrad):
+            Ct.memmove(Ct.byref(descs[i]), Ct.byref(d), Ct.sizeof(_lib.IgemmDesc))
+            descs[i].flags, descs[i].tile = 0, tile
+            ws[i] = wp[off:].data_ptr()
+        if mut:
+            mut(descs, ws)
+        return lib.loans_igemm_classes_f32(gy.data_ptr(), ws, out.data_ptr(), None, None, descs, n, None)
+
+    assert call() == 0
+    assert call(tile=6) == -1 and call(tile=8) == -1 and call(tile=3 | (2 << 8)) == -1
+
+    def other_cout(descs, ws):
+        descs[1].Cout = 32
+    assert call(other_cout) == -1
+
+    def other_flags(descs, ws):
+        descs[2].flags = _lib.F_RELU_IN
+    assert call(other_flags) == -1
+
+    def null_weight(descs, ws):
+        ws[1] = None
+    assert call(null_weight) == -1
+
+    def stats_flag(descs, ws):
+        for i in range(n):
+            descs[i].flags = _lib.F_STATS
+    assert call(stats_flag) == -1
+
+
 def test_prep_images_exact():
     from loans_amd import ops
     rng = np.random.RandomState(0)

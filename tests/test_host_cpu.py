@@ -110,19 +110,25 @@ def test_every_entry_point_rejects_null_pointers(lib):
     """each launcher validates before it launches: with every pointer NULL (and otherwise sane scalars) it returns
     LOANS_EINVAL / LOANS_ERANGE, never a hipError and never a crash -- on a machine without a GPU"""
     from loans_amd import _lib
-    desc = _lib.IgemmDesc()
+    descs = (_lib.IgemmDesc * 4)()        # loans_igemm_classes_f32 reads up to n = 4 of them
+    desc = descs[0]
     desc.B = desc.inH = desc.inW = desc.outH = desc.outW = desc.gridH = desc.gridW = 4
     desc.Cin = desc.Cout = 8
     desc.osy = desc.osx = desc.isy = desc.isx = 1
     desc.ntaps = 1
+    for i in range(1, 4):
+        ctypes.memmove(ctypes.byref(descs[i]), ctypes.byref(desc), ctypes.sizeof(_lib.IgemmDesc))
     tapsel = (ctypes.c_int32 * 1)(0)
+    null_table = (ctypes.c_void_p * 4)()
     for name, argtypes in sorted(_lib.SIGNATURES.items()):
         args = []
         for t in argtypes:
             if t is ctypes.c_void_p:
                 args.append(0)
             elif t is ctypes.POINTER(_lib.IgemmDesc):
-                args.append(ctypes.byref(desc))
+                args.append(descs)
+            elif t is ctypes.POINTER(ctypes.c_void_p):
+                args.append(null_table)
             elif t is ctypes.POINTER(ctypes.c_int32):
                 args.append(tapsel)
             elif t is ctypes.POINTER(_lib.SmallConv):
