@@ -98,7 +98,10 @@ typedef struct loans_igemm_desc {
 #define LOANS_TILE_STEM    10   /* loans_igemm_f32 with LOANS_F_DENSE, the 7x7 / 2, Cout = 64 forward geometry, flags BIAS / STATS: direct
                                   convolution -- a block stages the input rows of R output rows and the whole weight matrix in LDS
                                   once and feeds the fp32 MFMA from that image (stem.hip); LOANS_EINVAL for frame sizes it does not
-                                  cover (R * Wo must be a multiple of 64 for an R in {4, 2, 1} dividing Ho, <= 448 pixels, <= 80 KB) */
+                                  cover (R * Wo must be a multiple of 64 for an R in {4, 2, 1} dividing Ho, <= 448 pixels, <= 80 KB).
+                                  loans_igemm_bf16_f32 with LOANS_F_OUT_BF16 (the stem of the bf16 arm): the same direct scheme on the
+                                  bf16 MFMA in a persistent kernel -- weights rounded once per block into registers, the image staged
+                                  as bf16, any frame size whose 2R + 5 rows fit 78 KB next to the output slabs */
 #define LOANS_TILE_HALO_128    11  /* loans_igemm_bf16s, stride-1 geometries (forward k x k / 1 and its data gradient, k <= 3, Cin % 64 == 0):
                                       a block owns an 8 x 16 pixel tile x 128 output channels and stages the input halo image once
                                       per 64-channel chunk -- a tap is an LDS window shift, not a gather (csrc/halo_bf16.hip) */

@@ -95,6 +95,11 @@ static inline int grid_for(int64_t work_items, int block, int max_blocks = 256 *
 int loans_stem7_rows(int Ho, int Wo, int Wp3, size_t* lds_bytes);
 int loans_stem7_launch(const float* in, const float* w, float* out, const float* bias, double* stats,
                        const loans_igemm_desc* d, hipStream_t st);
+int loans_stem7_bf16_rows(int Ho, int Wo, int Wp3, size_t* lds_bytes);
+int loans_stem7_bf16_launch(const float* in, const float* w, void* out, const float* bias, double* stats,
+                            const loans_igemm_desc* d, hipStream_t st);
+int loans_stem7_bf16s_launch(const void* in, const void* w, void* out, const float* bias, double* stats,
+                             const loans_igemm_desc* d, hipStream_t st);
 
 // halo_bf16.hip: stride-1 convolutions on bf16 storage with the input tile staged once per channel chunk (LOANS_TILE_HALO_*;
 // internal, reached through loans_igemm_bf16s)

@@ -982,7 +982,8 @@ static int igemm_impl(const float* in, const float* w, float* out, const float* 
         return launch_igemm<64, 64, 2, 2>(a, st);
     }
     if (tile == LOANS_TILE_STEM) {          // the dense RGB stem as a direct convolution (stem.hip)
-        if (pair || bf16 || a.splits > 1 || a.dma) return LOANS_EINVAL;
+        if (pair || a.splits > 1 || a.dma || mc) return LOANS_EINVAL;
+        if (bf16) return loans_stem7_bf16_launch(in, w, out, bias, stats, d, st);       // needs LOANS_F_OUT_BF16 (checked there)
         return loans_stem7_launch(in, w, out, bias, stats, d, st);
     }
     if (tile == LOANS_TILE_FINETAIL) {

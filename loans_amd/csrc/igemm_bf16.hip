@@ -841,6 +841,10 @@ static int igemm_bf16s_impl(const void* in, const void* w, void* out, const floa
         tile = d->Cout <= 64 ? LOANS_TILE_128x64 : (big >= 512 ? LOANS_TILE_128x128 : LOANS_TILE_64x64);
     }
     if (partial && tile >= LOANS_TILE_HALO_128) return LOANS_EINVAL;      // the halo tiles have no split-K form
+    if (tile == LOANS_TILE_STEM) {          // the dense RGB stem as a direct convolution (stem.hip)
+        if (partial || splits > 1) return LOANS_EINVAL;
+        return loans_stem7_bf16s_launch(in, w, out, bias, stats, d, st);
+    }
     switch (tile) {
         case LOANS_TILE_128x128: return launch_igemm16<128, 128, 2, 2>(a, st);
         case LOANS_TILE_128x64: return launch_igemm16<128, 64, 2, 2>(a, st);

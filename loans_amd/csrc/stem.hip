@@ -155,6 +155,181 @@ int launch_stem7(const float* in, const float* w, float* out, const float* bias,
     return LOANS_OK;
 }
 
+
+// ---- the same layer on the bf16 MFMA (bf16 compute arm: fp32 frame and weights rounded to bf16 RNE, fp32 accumulate, bias and
+// statistics in fp32, bf16 NHWC output -- the arithmetic of igemm_kernel<BF16> with LOANS_F_OUT_BF16) ----------------------------
+// As an implicit GEMM this layer is the slowest forward launch of the bf16 joint step (0.62 ms at 128 x 3 x 512^2 for 0.20 ms of
+// HBM traffic: every tile gathers its own 7 x 24 window per pixel and converts it while staging).  Here a block is PERSISTENT:
+//   * it rounds the whole weight matrix to bf16 ONCE into registers -- 21 (+1 zero) groups of 8 K-values x 64 channels are the
+//     B fragments of v_mfma_f32_32x32x16_bf16 as they lie in the dense [64][7][24] layout, 88 VGPRs;
+//   * per unit (R output rows of one image) it stages the 2R + 5 input rows once, as bf16 (one contiguous run of the padded
+//     frame buffer, converted on the way), and every wave builds its A fragments from that image: lane (pixel r, half h) of
+//     step s reads the 8 consecutive bf16 of group G = 2 s + h at  patch[2 oy + G / 3][6 ox + 8 (G % 3)]  (4-byte aligned:
+//     two ds_read2_b32).  K = 176 computed per 147 real;
+//   * a wave owns whole 32-pixel tiles with all 64 channels (one A fragment feeds two MFMAs: half the LDS reads of a 2 x 2
+//     wave grid), transposes each finished tile through its own LDS slab and writes the pixels' 128 contiguous bytes;
+//   * units are handed out in contiguous runs, so the 5 input rows two neighbouring units share are re-read by the same CU
+//     while they are still in L2; BN statistics are summed per unit in fp32, across units in fp64, one atomic per channel
+//     and block at the end.
+typedef __bf16 sbf16x8 __attribute__((ext_vector_type(8)));
+typedef __bf16 sbf16x4 __attribute__((ext_vector_type(4)));
+struct __attribute__((packed, aligned(4))) sbf16x8_a4 { sbf16x8 v; };      // an A fragment in the image: dword-aligned only
+constexpr int S16_STEPS = 11;       // 22 groups of 8 K-values (21 real: 7 rows x 24), two per MFMA
+constexpr int S16_LDC = 68;         // fp32 transposing slab of a wave: [32 pixels][64 channels + 4]
+constexpr size_t STEM16_LDS_MAX = 78 * 1024;     // two blocks per CU
+
+// eight consecutive K-values of an operand as bf16 (fp32 operands: rounded to nearest even here)
+__device__ __forceinline__ sbf16x8 s16_load8(const float* p) {
+    const f32x4 lo = *reinterpret_cast<const f32x4*>(p), hi = *reinterpret_cast<const f32x4*>(p + 4);
+    const sbf16x4 l4 = __builtin_convertvector(lo, sbf16x4), h4 = __builtin_convertvector(hi, sbf16x4);
+    return __builtin_shufflevector(l4, h4, 0, 1, 2, 3, 4, 5, 6, 7);
+}
+__device__ __forceinline__ sbf16x8 s16_load8(const __bf16* p) { return *reinterpret_cast<const sbf16x8*>(p); }
+
+// TIN = float: fp32 frame buffer and weights (loans_igemm_bf16_f32); TIN = __bf16: the bf16 frame buffer of
+// loans_prep_images_dense_bf16 and bf16 weights (loans_igemm_bf16s) -- the same operands, already rounded
+template <typename TIN>
+__global__ __launch_bounds__(256, 2) void stem7_bf16_kernel(const TIN* in, const TIN* w, __bf16* out, const float* bias,
+                                                            double* stats, int Hp, int Wp3, int Ho, int Wo, int R, int units,
+                                                            int flags) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    const int rows_in = 2 * R + 5;
+    const int nfl = rows_in * Wp3;                              // even (Wp3 is)
+    __bf16* patch0 = reinterpret_cast<__bf16*>(smem);           // [<= 7 elements of lead-in][2R + 5][Wp3]
+    float* slab = reinterpret_cast<float*>(smem + (((size_t)(nfl + 8) * 2 + 15) & ~(size_t)15));
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    float* Cs = slab + wave * 32 * S16_LDC;
+    const int per_img = Ho / R, npx = R * Wo, ntile = (npx + 31) >> 5;
+
+    // weights -> bf16 B fragments, once per block
+    sbf16x8 bf[S16_STEPS][2];
+#pragma unroll
+    for (int s = 0; s < S16_STEPS; ++s)
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            const int G = 2 * s + h;
+            sbf16x8 z;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) z[e] = (__bf16)0.f;
+            bf[s][j] = G < 21 ? s16_load8(w + (size_t)(32 * j + r) * 168 + G * 8) : z;
+        }
+    float bv[2] = {0.f, 0.f};
+    if (flags & LOANS_F_BIAS) { bv[0] = bias[r]; bv[1] = bias[32 + r]; }
+    double ssum[2] = {0., 0.}, ssq[2] = {0., 0.};
+
+    // this block's run of units
+    const int nb = gridDim.x;
+    const int u_begin = (int)((long long)units * blockIdx.x / nb), u_end = (int)((long long)units * (blockIdx.x + 1) / nb);
+    for (int u = u_begin; u < u_end; ++u) {
+        const int b = u / per_img, oy0 = (u - b * per_img) * R;
+        __syncthreads();            // the previous unit's readers are done with the image
+        // stage the unit's 2R + 5 input rows (one contiguous run) in 16-byte pieces: the loads of a batch first, the LDS writes
+        // behind them.  The run starts 16-byte aligned in an fp32 buffer (Hp, Wp3 even: checked) but only 4-byte aligned in
+        // a bf16 one: there the copy starts at the aligned address below it and the image sits `lead` elements into the LDS
+        // buffer (the elements before it belong to the previous row of the same buffer: readable)
+        const TIN* src = in + ((size_t)b * Hp + 2 * oy0) * Wp3;
+        constexpr int EPV = 16 / (int)sizeof(TIN);                  // elements per 16 bytes: 4 (fp32) / 8 (bf16)
+        const int lead = (int)((reinterpret_cast<uintptr_t>(src) & 15) / sizeof(TIN));
+        {
+            const TIN* src_al = src - lead;
+            const int nel = nfl + lead, nv = nel / EPV;
+            constexpr int PU = 8;
+            typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+            for (int base = 0; base < nv; base += 256 * PU) {
+                u32x4 pv[PU];
+#pragma unroll
+                for (int q = 0; q < PU; ++q) {
+                    const int i = base + tid + 256 * q;
+                    pv[q] = i < nv ? *reinterpret_cast<const u32x4*>(src_al + (size_t)EPV * i) : u32x4{0u, 0u, 0u, 0u};
+                }
+#pragma unroll
+                for (int q = 0; q < PU; ++q) {
+                    const int i = base + tid + 256 * q;
+                    if (i < nv) {
+                        if constexpr (sizeof(TIN) == 4)
+                            *reinterpret_cast<sbf16x4*>(patch0 + 4 * i) = __builtin_convertvector(__builtin_bit_cast(f32x4, pv[q]), sbf16x4);
+                        else
+                            *reinterpret_cast<u32x4*>(patch0 + 8 * i) = pv[q];
+                    }
+                }
+            }
+            if (tid < nel - nv * EPV) patch0[nv * EPV + tid] = (__bf16)src_al[nv * EPV + tid];
+        }
+        const __bf16* patch = patch0 + lead;
+        __syncthreads();
+
+        float us[2] = {0.f, 0.f}, uq[2] = {0.f, 0.f};
+        for (int mt = wave; mt < ntile; mt += 4) {
+            const int p = mt * 32 + r;
+            const int pc = p < npx ? p : 0;                     // ragged last tile: rows beyond the unit read pixel 0
+            const int oyl = pc / Wo, ox = pc - oyl * Wo;
+            const __bf16* abase = patch + 2 * oyl * Wp3 + 6 * ox;
+            f32x16 acc[2];
+#pragma unroll
+            for (int j = 0; j < 2; ++j)
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[j][e] = 0.f;
+#pragma unroll
+            for (int s = 0; s < S16_STEPS; ++s) {
+                // group of this half; the zero-weight group 21 re-reads group 20 (finite pixels x 0)
+                const int G0 = 2 * s, G1 = 2 * s + 1 < 21 ? 2 * s + 1 : 20;
+                const int o0 = (G0 / 3) * Wp3 + 8 * (G0 % 3), o1 = (G1 / 3) * Wp3 + 8 * (G1 % 3);
+                const sbf16x8 av = reinterpret_cast<const sbf16x8_a4*>(abase + (h ? o1 : o0))->v;
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bf[s][0], acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bf[s][1], acc[1], 0, 0, 0);
+            }
+            // + bias, statistics of the fp32 result, transpose through the wave's slab
+#pragma unroll
+            for (int j = 0; j < 2; ++j) {
+                float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+                    const float v = acc[j][e] + bv[j];
+                    const bool ok = mt * 32 + row < npx;
+                    s1 += ok ? v : 0.f;
+                    s2 += ok ? v * v : 0.f;
+                    Cs[row * S16_LDC + 32 * j + r] = v;
+                }
+                us[j] += s1; uq[j] += s2;
+            }
+            // a wave's slab is private and its LDS operations execute in program order: no block barrier (the waves run
+            // different tile counts), only the compiler must not move the reads above the other lanes' writes
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __bf16* otile = out + (((size_t)b * Ho + oy0) * Wo + (size_t)mt * 32) * 64;
+#pragma unroll
+            for (int it = 0; it < 4; ++it) {
+                const int px = it * 8 + (lane >> 3), g8 = lane & 7;
+                const f32x4 lo = *reinterpret_cast<const f32x4*>(Cs + px * S16_LDC + 8 * g8);
+                const f32x4 hi = *reinterpret_cast<const f32x4*>(Cs + px * S16_LDC + 8 * g8 + 4);
+                const sbf16x4 l4 = __builtin_convertvector(lo, sbf16x4), h4 = __builtin_convertvector(hi, sbf16x4);
+                if (mt * 32 + px < npx)
+                    *reinterpret_cast<sbf16x8*>(otile + (size_t)px * 64 + 8 * g8) = __builtin_shufflevector(l4, h4, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the slab is rewritten by the next tile
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        }
+#pragma unroll
+        for (int j = 0; j < 2; ++j) { ssum[j] += (double)us[j]; ssq[j] += (double)uq[j]; }
+    }
+    if (flags & LOANS_F_STATS) {
+#pragma unroll
+        for (int j = 0; j < 2; ++j) {
+            double s1 = ssum[j], s2 = ssq[j];
+            s1 += __shfl_xor(s1, 32, 64);
+            s2 += __shfl_xor(s2, 32, 64);
+            if (h == 0) {
+                double* st = stats + (size_t)(blockIdx.x % LOANS_STATS_REPLICAS) * 2 * 64;
+                atomic_add_f64(st + 32 * j + r, s1);
+                atomic_add_f64(st + 64 + 32 * j + r, s2);
+            }
+        }
+    }
+}
+
 }  // namespace
 
 // rows per block for a frame geometry, 0 = not covered (the caller falls back to the implicit GEMM)
@@ -169,6 +344,65 @@ int loans_stem7_rows(int Ho, int Wo, int Wp3, size_t* lds_bytes) {
         return R;
     }
     return 0;
+}
+
+// rows per unit of the bf16 direct stem for a frame geometry, 0 = not covered
+int loans_stem7_bf16_rows(int Ho, int Wo, int Wp3, size_t* lds_bytes) {
+    for (int R = 4; R >= 1; R >>= 1) {
+        if (Ho % R) continue;
+        const size_t lds = ((((size_t)(2 * R + 5) * Wp3 + 8) * 2 + 15) & ~(size_t)15) + (size_t)4 * 32 * S16_LDC * sizeof(float);
+        if (lds > STEM16_LDS_MAX) continue;
+        if (lds_bytes) *lds_bytes = lds;
+        return R;
+    }
+    return 0;
+}
+
+namespace {
+template <typename TIN>
+int stem7_bf16_launch(const TIN* in, const TIN* w, void* out, const float* bias, double* stats, const loans_igemm_desc* d,
+                      hipStream_t st) {
+    if (!(d->flags & LOANS_F_DENSE) || (d->flags & ~(LOANS_F_DENSE | LOANS_F_OUT_BF16 | LOANS_F_BIAS | LOANS_F_STATS))) return LOANS_EINVAL;
+    if (d->ntaps != 7 || d->Cin != 24 || d->Cout != 64 || d->isy != 2 || d->isx != 6) return LOANS_EINVAL;
+    if ((d->inW & 1) || (d->inH & 1) || (reinterpret_cast<uintptr_t>(in) & 15) || (reinterpret_cast<uintptr_t>(w) & 15) ||
+        (reinterpret_cast<uintptr_t>(out) & 15))
+        return LOANS_EINVAL;
+    for (int t = 0; t < 7; ++t)
+        if (d->dy[t] != t || d->dx[t] != 0) return LOANS_EINVAL;
+    if (d->osy != 1 || d->osx != 1 || d->oy0 || d->ox0 || d->outH != d->gridH || d->outW != d->gridW) return LOANS_EINVAL;
+    if (2 * (d->gridH - 1) + 7 > d->inH || 6 * (d->gridW - 1) + 24 > d->inW) return LOANS_EINVAL;
+    if ((int64_t)d->B * d->inH * d->inW >= ((int64_t)1 << 31) || (int64_t)d->B * d->gridH * d->gridW * 64 >= ((int64_t)1 << 31))
+        return LOANS_ERANGE;
+    size_t lds = 0;
+    const int R = loans_stem7_bf16_rows(d->gridH, d->gridW, d->inW, &lds);
+    if (!R) return LOANS_EINVAL;
+    if (2 * (d->gridH - R) + 2 * R + 5 > d->inH) return LOANS_EINVAL;       // the last unit's 2R + 5 input rows exist
+    static loans_device_once lds_limit_set[2];
+    auto kern = stem7_bf16_kernel<TIN>;
+    if (int rc_ = loans_raise_lds_limit(lds_limit_set[sizeof(TIN) == 2], reinterpret_cast<const void*>(kern), STEM16_LDS_MAX)) return rc_;
+    const int cus = loans_device_cus();
+    if (cus <= 0) return LOANS_EINVAL;
+    const int units = d->B * (d->gridH / R);
+    const int nblk = units < 2 * cus ? units : 2 * cus;
+    hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, st, in, w, reinterpret_cast<__bf16*>(out), bias, stats,
+                       d->inH, d->inW, d->gridH, d->gridW, R, units, d->flags);
+    LOANS_LAUNCH_CHECK();
+    return LOANS_OK;
+}
+}  // namespace
+
+// LOANS_TILE_STEM of loans_igemm_bf16_f32 (fp32 frame buffer and weights; LOANS_F_OUT_BF16 required: the output is bf16)
+int loans_stem7_bf16_launch(const float* in, const float* w, void* out, const float* bias, double* stats,
+                            const loans_igemm_desc* d, hipStream_t st) {
+    if (!(d->flags & LOANS_F_OUT_BF16)) return LOANS_EINVAL;
+    return stem7_bf16_launch<float>(in, w, out, bias, stats, d, st);
+}
+
+// LOANS_TILE_STEM of loans_igemm_bf16s (bf16 frame buffer and weights)
+int loans_stem7_bf16s_launch(const void* in, const void* w, void* out, const float* bias, double* stats,
+                             const loans_igemm_desc* d, hipStream_t st) {
+    if (d->flags & LOANS_F_OUT_BF16) return LOANS_EINVAL;       // implied there
+    return stem7_bf16_launch<__bf16>(reinterpret_cast<const __bf16*>(in), reinterpret_cast<const __bf16*>(w), out, bias, stats, d, st);
 }
 
 // LOANS_TILE_STEM of loans_igemm_f32: `d` must be the dense 7x7 / 2, Cout = 64 forward geometry

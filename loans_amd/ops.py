@@ -418,6 +418,21 @@ def stem_tile_rows(geo):
     return 0
 
 
+def stem16_tile_rows(geo):
+    """output rows per unit of LOANS_TILE_STEM on the bf16 MFMA (loans_stem7_bf16_rows of csrc/stem.hip), 0 = not covered"""
+    if not (geo.dense and geo.k == 7 and geo.stride == 2 and geo.pad == 3 and geo.Cout == 64):
+        return 0
+    if 2 * geo.Ho + 5 > geo.Hp or geo.Hp % 2:
+        return 0
+    for R in (4, 2, 1):
+        if geo.Ho % R:
+            continue
+        if ((((2 * R + 5) * geo.Wp * 3 + 8) * 2 + 15) & ~15) + 4 * 32 * 68 * 4 > 78 * 1024:
+            continue
+        return R
+    return 0
+
+
 TILE_FINETAIL = 8       # LOANS_TILE_FINETAIL (+16 = LDS-DMA): whole 64x64 tiles, then K-slices of the uneven rest in the same launch
 FINETAIL = os.environ.get('LOANS_FINETAIL', '1') != '0'
 STEM_DIRECT = os.environ.get('LOANS_STEM_DIRECT', '1') != '0'
@@ -468,11 +483,11 @@ def conv_fprop(x, w, geo, out=None, bias=None, stats=None, relu_in=False, addend
             (F_STATS if stats is not None else 0) | (F_ADDEND if addend is not None else 0) | geo.base_flags
     assert x.numel() == geo.in_numel and w.numel() == geo.w_numel
     if tile == 0:
-        tflags = flags & (F_RELU_IN | F_STATS | F_DENSE)
+        tflags = flags & (F_RELU_IN | F_STATS | F_DENSE | F_OUT_BF16)
         sstats = stats_buffer(geo.Cout, x.device) if stats is not None else None
 
         def run(t):
-            scratch = torch.empty((geo.B, geo.Ho, geo.Wo, geo.Cout), device=x.device, dtype=torch.float32)
+            scratch = torch.empty((geo.B, geo.Ho, geo.Wo, geo.Cout), device=x.device, dtype=BF16 if out_bf16 else torch.float32)
             if t >> 8:
                 _igemm_splitk(lib, x, w, scratch, [(geo.fwd, w)], tflags, t, None, sstats, None, None,
                               geo.B * geo.Ho * geo.Wo, geo.Cout, _stream())
@@ -487,8 +502,10 @@ def conv_fprop(x, w, geo, out=None, bias=None, stats=None, relu_in=False, addend
         if SPLITK and FINETAIL and COMPUTE == 'f32' and not out_bf16 and addend is None and reduce_channels_ok(geo.Cout) \
                 and _finetail_plan(M_, geo.Cout, nch, x.device)[1] > 1:
             ft = (TILE_FINETAIL, TILE_FINETAIL | 16)
-        stem = (TILE_STEM,) if (STEM_DIRECT and COMPUTE == 'f32' and not out_bf16 and not relu_in and addend is None
-                                and stem_tile_rows(geo)) else ()
+        stem = ()
+        if STEM_DIRECT and not relu_in and addend is None:
+            if (stem_tile_rows(geo) if not out_bf16 else stem16_tile_rows(geo)) and (COMPUTE == 'f32') != out_bf16:
+                stem = (TILE_STEM,)
         tile = _tuned_tile(geo, COMPUTE + 'fprop' + ('_stats' if stats is not None else '') + ('_sk' if sk else '') +
                            ('_ft' if ft else '') + ('_st' if stem else ''), run,
                            _FPROP_TILES + sk + ft + stem)   # fp32 scratch output: the tile choice carries over
@@ -580,8 +597,9 @@ def _conv_fprop16(lib, x, w, geo, out, bias, stats, relu_in, addend, tile):
                                         C.byref(_with_flags(geo.fwd, tflags, t)), _stream()), 'loans_igemm_bf16s[tune]')
         halo = _halo_tiles(geo, geo.Cin, geo.Cout, (geo.Ho, geo.Wo), relu_in)
         sk = () if geo.dense else _splitk16_candidates(geo.B * geo.Ho * geo.Wo, geo.Cout, geo.w_numel // geo.Cout)
+        stem = (TILE_STEM,) if (STEM_DIRECT and geo.dense and not relu_in and addend is None and stem16_tile_rows(geo)) else ()
         tile = _tuned_tile(geo, 'bf16s_fprop' + ('_stats' if stats is not None else '') + ('_h' if halo else '') +
-                           ('_sk' if sk else ''), run, _IGEMM16_TILES + halo + sk)
+                           ('_sk' if sk else '') + ('_st' if stem else ''), run, _IGEMM16_TILES + halo + sk + stem)
     d = _with_flags(geo.fwd, flags, tile)
     _count_flops('fprop', geo)
     log = EVENT_LOG

@@ -386,3 +386,52 @@ def test_ws64_persistent_blocks_walk_many_tiles():
     assert torch.equal(ops.conv_dgrad(gy, w, geo, addend=add, addend_mask_ref=ref, tile=15),
                        ops.conv_dgrad(gy, w, geo, addend=add, addend_mask_ref=ref, tile=1))
     assert torch.equal(ops.conv_dgrad(gy, w, geo, mask_ref=ref, tile=15), ops.conv_dgrad(gy, w, geo, mask_ref=ref, tile=1))
+
+
+@pytest.mark.parametrize("case", [(2, 32, 32), (3, 64, 64), (2, 96, 80), (1, 130, 66), (2, 224, 224), (1, 512, 512), (2, 50, 34), (1, 22, 30)])
+def test_stem_direct_bf16(case):
+    """LOANS_TILE_STEM on the bf16 MFMA (csrc/stem.hip, stem7_bf16_kernel): conv1 with bias and BN statistics as a persistent
+    direct convolution, from the fp32 frame buffer (loans_igemm_bf16_f32, operands rounded while staged) and from the bf16 one
+    (loans_igemm_bf16s) -- against the oracle convolution of the bf16-rounded operands (fp64 sums; the kernel differs by its
+    fp32 accumulation and the final rounding to bf16) and against the implicit-GEMM arm.  Frame sizes with R = 4, 2, 1 rows
+    per unit, ragged last pixel tiles, units that start 4-byte aligned only, more units than blocks (512 x 512 is config 3)."""
+    from loans_amd import ops
+    B, H, W = case
+    rng = np.random.RandomState(H * 7 + W)
+    x = _r(rng.uniform(-1, 1, (B, 3, H, W)))
+    w = _r(rng.standard_normal((64, 3, 7, 7)) / np.sqrt(147))
+    b = rng.standard_normal(64).astype(np.float32)
+    geo = ops.ConvGeometry(B, H, W, 3, 64, 7, 2, 3, dense=True)
+    assert ops.stem16_tile_rows(geo) > 0
+    xp = np.zeros((B, geo.Hp, geo.Wp, 3), np.float32)
+    xp[:, 3:3 + H, 3:3 + W] = x.transpose(0, 2, 3, 1)
+    wp = np.zeros((64, 7, geo.kwp, 3), np.float32)
+    wp[:, :, :7] = w.transpose(0, 2, 3, 1)
+    y_ref, _ = C.conv2d_fwd(x.astype(np.float64), w.astype(np.float64), b.astype(np.float64), 2, 3)
+    y_ref = y_ref.transpose(0, 2, 3, 1)
+    xd, wd, bd = dev(xp), dev(wp), dev(b)
+    ops.set_compute_dtype('bf16')
+    try:
+        outs = []
+        for src, wt in ((xd, wd), (d16(xp), d16(wp))):
+            for tile in (ops.TILE_STEM, 3):
+                st = ops.stats_buffer(64, 'cuda')
+                y = ops.conv_fprop(src, wt, geo, bias=bd, stats=st, tile=tile, **({} if src.dtype == torch.bfloat16 else dict(out_bf16=True)))
+                assert y.dtype == torch.bfloat16
+                outs.append((y, st.sum(dim=0)))
+        for y, st in outs:
+            # bf16 output: half an ulp of the rounding (2^-9 relative) on top of the fp32 sums
+            err = np.abs(y.float().cpu().numpy() - y_ref)
+            assert (err <= 2.0 ** -8 * np.abs(y_ref) + 1e-5).all(), err.max()
+            np.testing.assert_allclose(st[0].cpu().numpy(), y_ref.sum(axis=(0, 1, 2)), rtol=1e-5, atol=2e-3)
+            np.testing.assert_allclose(st[1].cpu().numpy(), (y_ref ** 2).sum(axis=(0, 1, 2)), rtol=2e-5)
+        # same operands, same arithmetic, another summation order: the direct and the implicit-GEMM results differ in a few
+        # last-place roundings at most; the two input forms of the direct kernel are the SAME computation
+        assert torch.equal(outs[0][0], outs[2][0]) and torch.equal(outs[0][1], outs[2][1])
+        flips = (outs[0][0] != outs[1][0]).float().mean().item()
+        assert flips < 0.02, flips
+        y_nb = ops.conv_fprop(d16(xp), d16(wp), geo, tile=ops.TILE_STEM)            # no bias, no statistics
+        ref_nb = torch.from_numpy((y_ref - b).astype(np.float32)).cuda()
+        assert (y_nb.float() - ref_nb).abs().max().item() <= 2.0 ** -8 * ref_nb.abs().max().item() + 1e-5
+    finally:
+        ops.set_compute_dtype('f32')
