@@ -101,7 +101,12 @@ typedef struct loans_igemm_desc {
                                   cover (R * Wo must be a multiple of 64 for an R in {4, 2, 1} dividing Ho, <= 448 pixels, <= 80 KB).
                                   loans_igemm_bf16_f32 with LOANS_F_OUT_BF16 (the stem of the bf16 arm): the same direct scheme on the
                                   bf16 MFMA in a persistent kernel -- weights rounded once per block into registers, the image staged
-                                  as bf16, any frame size whose 2R + 5 rows fit 78 KB next to the output slabs */
+                                  as bf16, any frame size whose 2R + 5 rows fit 78 KB next to the output slabs.
+                                  loans_wgrad_f32 with LOANS_F_DENSE (flags DENSE only; `splits` ignored): conv1's weight gradient as a
+                                  persistent direct kernel -- per output row the 7 input rows and the row's gradient pixels arrive by
+                                  LDS-DMA (double-buffered), rows = 64 channels, columns = the 147 real window positions, every wave
+                                  keeps the whole 64 x 160 tile in registers over all its units; the three window-padding columns of
+                                  dw [64][7][24] are not written.  LOANS_EINVAL when two unit buffers exceed 156 KB */
 #define LOANS_TILE_HALO_128    11  /* loans_igemm_bf16s, stride-1 geometries (forward k x k / 1 and its data gradient, k <= 3, Cin % 64 == 0):
                                       a block owns an 8 x 16 pixel tile x 128 output channels and stages the input halo image once
                                       per 64-channel chunk -- a tap is an LDS window shift, not a gather (csrc/halo_bf16.hip) */

@@ -1382,6 +1382,7 @@ static int wgrad_impl(const float* x, const float* gy, float* dw, const loans_ig
     const bool small = (d->Cout <= 64) || (a.Ktot <= 64);
     int tile = d->tile;
     if (tile == 0) tile = small ? LOANS_TILE_64x64 : LOANS_TILE_128x128;
+    if (tile == LOANS_TILE_STEM) return bf16 ? LOANS_EINVAL : loans_stem7_wgrad_launch(x, gy, dw, d, st);     // direct (stem.hip)
     if (tile == LOANS_TILE_64x64) return launch_wgrad<64, 64>(a, splits, st);
     if (tile == LOANS_TILE_128x128) return launch_wgrad<128, 128>(a, splits, st);
     if (tile == LOANS_TILE_64x128) return launch_wgrad<64, 128>(a, splits, st);

@@ -330,6 +330,132 @@ __global__ __launch_bounds__(256, 2) void stem7_bf16_kernel(const TIN* in, const
     }
 }
 
+
+// ---- conv1's weight gradient as a direct kernel (fp32 MFMA): dw[co][ky][6 kx' + c] += sum_pixels gy[p][co] * x[2 oy + ky][6 ox + j]
+// As an implicit GEMM (wgrad_kernel) the layer runs at 65-69 TFLOP/s: K = 168 is short, every 32-pixel chunk gathers its own
+// 7 x 24 window per pixel, and the result tile is small against the reduction.  Here a block is persistent over units (one
+// output row of one image): it stages the 7 input rows (one contiguous run) and the row's gradient pixels [Wo][64] once, and
+// the GEMM is  rows = 64 channels, columns = 147 real (ky, j) window positions (5 MFMA tiles), reduction = pixels:
+//   A = gy[p + h][channel]           (lane = channel, h = the pixel of the MFMA's k pair)
+//   B = patch[ky][6 (ox + h) + j]    (lane = window position)
+// The eight waves split the row's pixel pairs, each accumulates the whole 64 x 160 tile in registers over ALL the block's units;
+// one reduction through LDS and one atomic add per element and block at the very end.  The next unit is brought in by LDS-DMA
+// while this one is contracted (two LDS buffers, one barrier per unit).
+constexpr int SWG_CT = 5;           // 32-column tiles: 147 real columns of 160
+
+// LDS: two unit buffers, each the 7 input rows and the row's gradient pixels in whole 1 KiB LDS-DMA pieces
+__host__ __device__ inline int swg_x_pieces(int Wp3) { return (7 * Wp3 * 4 + 1023) >> 10; }
+__host__ __device__ inline int swg_g_pieces(int Wo) { return (Wo + 3) >> 2; }            // a pixel's 64 channels = 256 bytes
+
+constexpr int SWG_NW = 8;           // waves per block: two per SIMD, one block per CU
+
+__global__ __launch_bounds__(64 * SWG_NW) void stem7_wgrad_kernel(const float* x, const float* gy, float* dw, int Hp, int Wp3, int Ho,
+                                                             int Wo, int units, unsigned x_bytes, unsigned gy_bytes) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+    const int xp = swg_x_pieces(Wp3), gp = swg_g_pieces(Wo);
+    const int buf_floats = (xp + gp) * 256;
+    float* const lds = reinterpret_cast<float*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(x), 0, (int)x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(gy), 0, (int)gy_bytes, 0x00020000);
+
+    // per lane: the window position of each column tile (columns >= 147 re-read column 146; their sums are dropped)
+    int coff[SWG_CT];
+#pragma unroll
+    for (int ct = 0; ct < SWG_CT; ++ct) {
+        const int c = min(ct * 32 + r, 146);
+        const int ky = c / 21, j = c - ky * 21;
+        coff[ct] = ky * Wp3 + j + 6 * h;
+    }
+    f32x16 acc[2][SWG_CT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int ct = 0; ct < SWG_CT; ++ct)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][ct][e] = 0.f;
+
+    // unit u = output row oy of image b: its 7 input rows are one contiguous run of the padded buffer, its gradient pixels
+    // another; both go to LDS by LDS-DMA (no staging registers: the accumulators own the register file), a piece past the
+    // end of a run brings the bytes behind it (finite pixels / the next row's gradient: never multiplied in, see below) or,
+    // past the end of the buffer, zeros
+    auto stage = [&](int u, int buf) {
+        const int b = u / Ho, oy = u - b * Ho;
+        const unsigned xoff = (unsigned)((b * Hp + 2 * oy) * Wp3) * 4u + (unsigned)lane * 16u;
+        const unsigned goff = (unsigned)((b * Ho + oy) * Wo) * 256u + (unsigned)lane * 16u;
+        float* dst = lds + buf * buf_floats;
+        for (int q = wave; q < xp; q += SWG_NW)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_x, (lds_ptr_t)(dst + q * 256), 16, (int)(xoff + (unsigned)q * 1024u), 0, 0, 0);
+        dst += xp * 256;
+        for (int q = wave; q < gp; q += SWG_NW)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_g, (lds_ptr_t)(dst + q * 256), 16, (int)(goff + (unsigned)q * 1024u), 0, 0, 0);
+    };
+
+    const int nb = gridDim.x;
+    const int u_begin = (int)((long long)units * blockIdx.x / nb), u_end = (int)((long long)units * (blockIdx.x + 1) / nb);
+    const int ksteps = (Wo + 1) >> 1;
+    int buf = 0;
+    if (u_begin < u_end) stage(u_begin, 0);
+    for (int u = u_begin; u < u_end; ++u) {
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();            // unit u has landed; every wave is done with the other buffer
+        if (u + 1 < u_end) stage(u + 1, buf ^ 1);
+        const float* patch = lds + buf * buf_floats;
+        const float* gyt = patch + xp * 256;                    // [Wo][64]
+        // software-pipelined over the wave's pixel pairs: the operands of pair n + 1 are read while pair n is contracted
+        float a0, a1, bv[SWG_CT];
+        auto fetch = [&](int ks) {
+            const int px = 2 * ks + h;
+            const float* ap = gyt + px * 64 + r;
+            a0 = ap[0]; a1 = ap[32];
+            if (px >= Wo) { a0 = 0.f; a1 = 0.f; }              // the missing pixel of an odd row
+            const float* bp = patch + 12 * ks;
+#pragma unroll
+            for (int ct = 0; ct < SWG_CT; ++ct) bv[ct] = bp[coff[ct]];
+        };
+        if (wave < ksteps) fetch(wave);
+        for (int ks = wave; ks < ksteps; ks += SWG_NW) {
+            const float c0 = a0, c1 = a1;
+            float cb[SWG_CT];
+#pragma unroll
+            for (int ct = 0; ct < SWG_CT; ++ct) cb[ct] = bv[ct];
+            if (ks + SWG_NW < ksteps) fetch(ks + SWG_NW);
+#pragma unroll
+            for (int ct = 0; ct < SWG_CT; ++ct) {
+                acc[0][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(c0, cb[ct], acc[0][ct], 0, 0, 0);
+                acc[1][ct] = __builtin_amdgcn_mfma_f32_32x32x2f32(c1, cb[ct], acc[1][ct], 0, 0, 0);
+            }
+        }
+        buf ^= 1;
+    }
+    // the waves' partial tiles -> one sum per element -> dw (+=)
+    float* red = lds;                                           // [SWG_NW][32][33]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int ct = 0; ct < SWG_CT; ++ct) {
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                red[(wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * 33 + r] = acc[i][ct][e];
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 1024 / (64 * SWG_NW); ++q) {
+                const int idx = tid + 64 * SWG_NW * q, row = idx >> 5, col = idx & 31;
+                float v = 0.f;
+#pragma unroll
+                for (int wv = 0; wv < SWG_NW; ++wv) v += red[(wv * 32 + row) * 33 + col];
+                const int c = ct * 32 + col;
+                if (c < 147) {
+                    const int ky = c / 21, j = c - ky * 21;
+                    atomic_add_f32(dw + (size_t)(i * 32 + row) * 168 + ky * 24 + j, v);
+                }
+            }
+        }
+}
+
 }  // namespace
 
 // rows per block for a frame geometry, 0 = not covered (the caller falls back to the implicit GEMM)
@@ -403,6 +529,36 @@ int loans_stem7_bf16s_launch(const void* in, const void* w, void* out, const flo
                              const loans_igemm_desc* d, hipStream_t st) {
     if (d->flags & LOANS_F_OUT_BF16) return LOANS_EINVAL;       // implied there
     return stem7_bf16_launch<__bf16>(reinterpret_cast<const __bf16*>(in), reinterpret_cast<const __bf16*>(w), out, bias, stats, d, st);
+}
+
+// LOANS_TILE_STEM of loans_wgrad_f32: `d` is the dense 7x7 / 2, Cout = 64 forward geometry; dw [64][7][24] (+=; the three
+// window-padding columns of every row are left alone)
+int loans_stem7_wgrad_launch(const float* x, const float* gy, float* dw, const loans_igemm_desc* d, hipStream_t st) {
+    if (d->flags != LOANS_F_DENSE) return LOANS_EINVAL;
+    if (d->ntaps != 7 || d->Cin != 24 || d->Cout != 64 || d->isy != 2 || d->isx != 6) return LOANS_EINVAL;
+    if ((d->inW & 1) || (d->inH & 1) || (reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(gy) & 15)) return LOANS_EINVAL;
+    for (int t = 0; t < 7; ++t)
+        if (d->dy[t] != t || d->dx[t] != 0) return LOANS_EINVAL;
+    if (d->osy != 1 || d->osx != 1 || d->oy0 || d->ox0 || d->outH != d->gridH || d->outW != d->gridW) return LOANS_EINVAL;
+    if (2 * (d->gridH - 1) + 7 > d->inH || 6 * (d->gridW - 1) + 24 > d->inW) return LOANS_EINVAL;
+    if ((int64_t)d->B * d->inH * d->inW >= ((int64_t)1 << 31) || (int64_t)d->B * d->gridH * d->gridW * 64 >= ((int64_t)1 << 31))
+        return LOANS_ERANGE;
+    size_t lds = (size_t)2 * (swg_x_pieces(d->inW) + swg_g_pieces(d->gridW)) * 1024;
+    if (lds < (size_t)SWG_NW * 32 * 33 * sizeof(float)) lds = (size_t)SWG_NW * 32 * 33 * sizeof(float);
+    if (lds > 156 * 1024) return LOANS_EINVAL;
+    const int64_t xb = (int64_t)d->B * d->inH * d->inW * 4, gb = (int64_t)d->B * d->gridH * d->gridW * 256;
+    if (xb >= 0xFFFFFFF0ll || gb >= 0xFFFFFFF0ll) return LOANS_ERANGE;
+    static loans_device_once lds_limit_set;
+    if (int rc_ = loans_raise_lds_limit(lds_limit_set, reinterpret_cast<const void*>(stem7_wgrad_kernel), 156 * 1024)) return rc_;
+    const int cus = loans_device_cus();
+    if (cus <= 0) return LOANS_EINVAL;
+    const int per_cu = 1;                   // eight waves with 160 accumulator registers each fill the register file
+    const int units = d->B * d->gridH;
+    const int nblk = units < per_cu * cus ? units : per_cu * cus;
+    hipLaunchKernelGGL(stem7_wgrad_kernel, dim3(nblk), dim3(64 * SWG_NW), lds, st, x, gy, dw, d->inH, d->inW, d->gridH, d->gridW, units,
+                       (unsigned)xb, (unsigned)gb);
+    LOANS_LAUNCH_CHECK();
+    return LOANS_OK;
 }
 
 // LOANS_TILE_STEM of loans_igemm_f32: `d` must be the dense 7x7 / 2, Cout = 64 forward geometry

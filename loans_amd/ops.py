@@ -418,6 +418,15 @@ def stem_tile_rows(geo):
     return 0
 
 
+def stem_wgrad_ok(geo):
+    """LOANS_TILE_STEM of loans_wgrad_f32 covers this geometry (loans_stem7_wgrad_launch of csrc/stem.hip)"""
+    if not (STEM_DIRECT and geo.dense and geo.k == 7 and geo.stride == 2 and geo.pad == 3 and geo.Cout == 64):
+        return False
+    if 2 * geo.Ho + 5 > geo.Hp or geo.Hp % 2:
+        return False
+    return 2 * ((7 * geo.Wp * 3 * 4 + 1023) // 1024 + (geo.Wo + 3) // 4) * 1024 <= 156 * 1024
+
+
 def stem16_tile_rows(geo):
     """output rows per unit of LOANS_TILE_STEM on the bf16 MFMA (loans_stem7_bf16_rows of csrc/stem.hip), 0 = not covered"""
     if not (geo.dense and geo.k == 7 and geo.stride == 2 and geo.pad == 3 and geo.Cout == 64):
@@ -902,12 +911,16 @@ def _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile):
         cands = _WGRAD16_TILES if s16 else _WGRAD_TILES
         if splits == 0:
             cands = _wgrad_candidates(geo, cands, 32, _WGRAD16_TILE_DIMS if s16 else None)
-        tile = _tuned_tile(geo, _wgrad_key(x, gy, relu_in) + ('' if splits == 0 else '_s%d' % splits), run, cands)
+        stem = stem_wgrad_ok(geo) and wfn is lib.loans_wgrad_f32 and fl == F_DENSE
+        if stem:
+            cands = tuple(cands) + (TILE_STEM,)
+        tile = _tuned_tile(geo, _wgrad_key(x, gy, relu_in) + ('' if splits == 0 else '_s%d' % splits) + ('_st' if stem else ''),
+                           run, cands)
     if tile >> 8:
         tile, splits = tile & 0xFF, tile >> 8
     d = _with_flags(geo.fwd, fl, tile)
     check(wfn(_ptr(x), _ptr(gy), _ptr(dw), C.byref(d), splits, _stream()), 'loans_wgrad')
-    if geo.dense:
+    if geo.dense and tile != TILE_STEM:         # the direct kernel never writes those columns
         # the window-padding columns of the dense layout saw real pixels: their "gradient" is not one
         check(lib.loans_mul_f32(_ptr(dw), _ptr(geo.wmask(x.device)), _ptr(dw), dw.numel(), _stream()), 'loans_mul_f32')
 

@@ -181,6 +181,36 @@ def test_conv_dgrad_class_launch_rejects():
     assert call(stats_flag) == -1
 
 
+@pytest.mark.parametrize("case", [(2, 224, 224), (3, 64, 64), (2, 34, 50), (1, 130, 66), (5, 32, 96), (1, 320, 304)])
+def test_stem_wgrad_direct(case):
+    """LOANS_TILE_STEM of loans_wgrad_f32 (csrc/stem.hip, stem7_wgrad_kernel): conv1's weight gradient as a persistent direct
+    kernel, against the oracle and the implicit-GEMM kernel; even and odd output widths, more units than blocks and fewer,
+    accumulation into a non-zero dw, the window-padding columns of the dense layout untouched"""
+    from loans_amd import ops
+    B, H, W = case
+    rng = np.random.RandomState(H + 3 * W)
+    x = rng.standard_normal((B, 3, H, W)).astype(np.float32)
+    geo = ops.ConvGeometry(B, H, W, 3, 64, 7, 2, 3, dense=True)
+    assert ops.stem_wgrad_ok(geo)
+    gy = rng.standard_normal((B, 64, geo.Ho, geo.Wo)).astype(np.float32)
+    xp = np.zeros((B, geo.Hp, geo.Wp, 3), np.float32)
+    xp[:, 3:3 + H, 3:3 + W] = x.transpose(0, 2, 3, 1)
+    w0 = np.zeros((64, 3, 7, 7))
+    _, col = C.conv2d_fwd(x.astype(np.float64), w0, None, 2, 3)
+    _, gw_ref, _ = C.conv2d_bwd(x.shape, col, w0, gy.astype(np.float64), 2, 3, False)
+    xd, gyd = dev(xp), dev(_nhwc(gy))
+    dw = torch.zeros((64, 7, geo.kwp, 3), device='cuda')
+    ops._conv_wgrad(xd, gyd, dw, geo, False, 0, ops.TILE_STEM)
+    got = dw.cpu().numpy()
+    assert not got[:, :, 7:].any()
+    assert rel_err(got[:, :, :7].transpose(0, 3, 1, 2), gw_ref) < 5e-6
+    dw3 = torch.zeros_like(dw)
+    ops._conv_wgrad(xd, gyd, dw3, geo, False, 0, 3)
+    assert torch.allclose(dw, dw3, rtol=1e-4, atol=1e-3 * float(np.abs(gw_ref).max()))
+    ops._conv_wgrad(xd, gyd, dw, geo, False, 0, ops.TILE_STEM)           # accumulates
+    assert rel_err(dw.cpu().numpy()[:, :, :7].transpose(0, 3, 1, 2), 2 * gw_ref) < 5e-6
+
+
 def test_prep_images_exact():
     from loans_amd import ops
     rng = np.random.RandomState(0)
