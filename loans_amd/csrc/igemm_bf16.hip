@@ -17,6 +17,7 @@
 #ifdef LOANS_STAMPS
 // Diagnostic build only (tools/stamp_run16.py): per-wave cycle sums of the K-loop phases of the first 64 blocks.
 __device__ unsigned long long g_stamps16[64 * 4 * 8];
+__device__ unsigned long long g_stamps16b[64 * 4 * 4];     // per wave: kernel entry, K loop begin, K loop end, kernel exit
 #define STAMP16(t)                                                                       \
     do {                                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                               \
@@ -99,6 +100,10 @@ __global__ __launch_bounds__(256) void igemm16_kernel(const Igemm16Args a) {
 
     const loans_igemm_desc& d = a.d;
     const int tid = threadIdx.x;
+#ifdef LOANS_STAMPS
+    unsigned long long t_entry = 0;
+    STAMP16(t_entry);
+#endif
     const int logical = xcd_remap16(blockIdx.x, gridDim.x);
     const int ntile = a.tiles_m * a.tiles_n;
     const int split = logical / ntile;                  // 0 unless split-K
@@ -343,6 +348,8 @@ __global__ __launch_bounds__(256) void igemm16_kernel(const Igemm16Args a) {
     if (logical < 64 && (tid & 63) == 0) {
         unsigned long long* o = g_stamps16 + (logical * 4 + (tid >> 6)) * 8;
         o[0] = p_s0; o[1] = p_s1; o[2] = p_s2; o[3] = p_bar; o[4] = p_s3; o[5] = q5 - q_begin; o[6] = nch - 1; o[7] = 0;
+        unsigned long long* ob = g_stamps16b + (logical * 4 + (tid >> 6)) * 4;
+        ob[0] = t_entry; ob[1] = q_begin; ob[2] = q5;
     }
 #endif
     {   // last chunk: steps that lie wholly beyond Ktot hold zeros on both sides and are skipped
@@ -476,6 +483,11 @@ __global__ __launch_bounds__(256) void igemm16_kernel(const Igemm16Args a) {
         o[4] = oh[0]; o[5] = oh[1]; o[6] = oh[2]; o[7] = oh[3];
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_out, (int)off, 0, 0);
     }
+#ifdef LOANS_STAMPS
+    unsigned long long t_exit = 0;
+    STAMP16(t_exit);
+    if (logical < 64 && (tid & 63) == 0) g_stamps16b[(logical * 4 + (tid >> 6)) * 4 + 3] = t_exit;
+#endif
 }
 
 template <int BM, int BN, int WM, int WN, bool RELU>
@@ -1041,6 +1053,12 @@ extern "C" int loans_wgrad_bf16s(const void* x, const void* gy, float* dw, const
     if (tile == LOANS_TILE_64x128) return launch_wgrad16<64, 128>(a, splits, st);
     return LOANS_EINVAL;
 }
+
+#ifdef LOANS_STAMPS
+extern "C" int loans_debug_read_stamps16b(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps16b), sizeof(unsigned long long) * n);
+}
+#endif
 
 #ifdef LOANS_STAMPS
 extern "C" int loans_debug_read_stamps16(unsigned long long* host, int n) {

@@ -12,7 +12,8 @@ dbg = os.path.join(csrc, 'libloans_hip_stamps.so')
 if not os.path.exists(dbg):
     subprocess.check_call('/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -DLOANS_STAMPS '
                           '-I%s/include -shared -o %s %s' % (ROOT, dbg, ' '.join('%s/%s' % (csrc, f) for f in (
-                              'igemm.hip', 'igemm_bf16.hip', 'smalln.hip', 'bn_pool.hip', 'misc.hip', 'resample.hip'))), shell=True)
+                              'igemm.hip', 'igemm_bf16.hip', 'halo_bf16.hip', 'stem.hip', 'smalln.hip', 'cropgrad.hip', 'bn_pool.hip', 'misc.hip', 'insight.hip',
+                              'resample.hip', 'augment.hip'))), shell=True)
 if len(sys.argv) < 11:
     sys.exit(0)         # build only (the GPU box has no reason to compile)
 from loans_amd import _lib
@@ -37,3 +38,16 @@ med = np.median(per.reshape(-1, 5), axis=0)
 print('%s tile=%d chunks=%d | per-chunk wave cycles (median of 256 waves): step0+dma %.0f  step1+dma %.0f  step2 %.0f  '
       'wait+barrier %.0f  step3 %.0f  | total %.0f  (4 steps x %d MFMAs x 32 cycles = %d pipe cycles per wave)' % (
           name, tile, int(n[0, 0]) + 1, *med, med.sum(), 4, 16 * 32))
+bufb = np.zeros(64 * 4 * 4, np.uint64)
+lib.loans_debug_read_stamps16b.argtypes = [ctypes.c_void_p, ctypes.c_int]
+assert lib.loans_debug_read_stamps16b(bufb.ctypes.data, bufb.size) == 0
+sb = bufb.reshape(64, 4, 4).astype(np.float64)
+pro, loop, epi = sb[..., 1] - sb[..., 0], sb[..., 2] - sb[..., 1], sb[..., 3] - sb[..., 2]
+print('   per block (median of the first 64 tiles): prologue %.0f  K loop %.0f  last chunk + epilogue %.0f cycles; first-wave entries span %.0f cycles' % (
+    np.median(pro), np.median(loop), np.median(epi), sb[..., 0].max() - sb[..., 0].min()))
+e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+e0.record()
+for _ in range(10):
+    ops.conv_fprop(x, w, geo, tile=tile)
+e1.record(); torch.cuda.synchronize()
+print('   launch %.1f us' % (e0.elapsed_time(e1) * 100))
