@@ -77,25 +77,35 @@ __device__ __forceinline__ f32x4 cvt_hi(bf16x8_t v) {
     return f32x4{(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
 }
 
+// LDS stages of the operand ring: two (the DMA of chunk c + 1 rides behind the MFMAs of chunk c) for the 256-thread tiles, of
+// which two or more blocks share a CU; THREE for the 512-thread tiles, which own their CU: chunk c + 2 is in flight while
+// chunk c is contracted, and the barrier waits with a counted vmcnt for chunk c + 1 only
+template <int BM, int BN, int WM, int WN>
+constexpr int igemm16_stages() { return (WM * WN == 8 && (size_t)3 * (BM + BN) * BKH * 2 <= 150 * 1024) ? 3 : 2; }
 template <int BM, int BN>
+constexpr int igemm16_epilogue_passes() { return (size_t)BM * (BN + 4) * 4 > 140 * 1024 ? 2 : 1; }
+template <int BM, int BN, int ST>
 constexpr size_t igemm16_aux_bytes() {      // offset of the tap table / row table behind the tiles
-    constexpr size_t stage = (size_t)2 * (BM + BN) * BKH * 2;
-    constexpr size_t cs = (size_t)BM * (BN + 4) * 4;          // fp32 epilogue staging tile
+    constexpr size_t stage = (size_t)ST * (BM + BN) * BKH * 2;
+    constexpr size_t cs = (size_t)BM / igemm16_epilogue_passes<BM, BN>() * (BN + 4) * 4;      // fp32 epilogue staging tile
     return stage > cs ? stage : cs;
 }
-template <int BM, int BN>
-constexpr size_t igemm16_lds_bytes() { return igemm16_aux_bytes<BM, BN>() + LOANS_MAX_TAPS * 4 + BM * 4; }
+template <int BM, int BN, int ST>
+constexpr size_t igemm16_lds_bytes() { return igemm16_aux_bytes<BM, BN, ST>() + LOANS_MAX_TAPS * 4 + BM * 4; }
 
 // RELU: gather relu(in) (LOANS_F_RELU_IN, the assessor's pre-activation convs): applied to the A fragments
 template <int BM, int BN, int WM, int WN, bool RELU>
-__global__ __launch_bounds__(256) void igemm16_kernel(const Igemm16Args a) {
+__global__ __launch_bounds__(64 * WM * WN) void igemm16_kernel(const Igemm16Args a) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int RA = BM / 32, RB = BN / 32;
+    constexpr int NT = 64 * WM * WN;           // 256 threads, or 512 for the 256-row tiles (two waves per SIMD from ONE block)
+    constexpr int RPP = NT / 8;                // tile rows staged per pass: a thread owns one 16-byte K unit of one row
+    constexpr int RA = BM / RPP, RB = BN / RPP;
     constexpr int NMMA = TM * TN;              // MFMAs per 16-deep k step
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    __bf16* As = reinterpret_cast<__bf16*>(smem);      // [2][BM][64]
-    __bf16* Bs = As + 2 * BM * BKH;                    // [2][BN][64]
-    int* taps = reinterpret_cast<int*>(smem + igemm16_aux_bytes<BM, BN>());
+    constexpr int ST = igemm16_stages<BM, BN, WM, WN>();
+    __bf16* As = reinterpret_cast<__bf16*>(smem);      // [ST][BM][64]
+    __bf16* Bs = As + ST * BM * BKH;                   // [ST][BN][64]
+    int* taps = reinterpret_cast<int*>(smem + igemm16_aux_bytes<BM, BN, ST>());
     unsigned* opix = reinterpret_cast<unsigned*>(taps + LOANS_MAX_TAPS);   // [BM] output row byte offset, ~0u = no row
 
     const loans_igemm_desc& d = a.d;
@@ -139,7 +149,7 @@ __global__ __launch_bounds__(256) void igemm16_kernel(const Igemm16Args a) {
         int x = rem - y * d.gridW;
 #pragma unroll
         for (int i = 0; i < RA; ++i) {
-            const int m = m0 + 32 * i;
+            const int m = m0 + RPP * i;
             unsigned pixoff = 0xFFFFFFFFu;
             unsigned long long mask = 0;
             rowoff[i] = 0;
@@ -174,8 +184,8 @@ __global__ __launch_bounds__(256) void igemm16_kernel(const Igemm16Args a) {
 #ifdef LOANS_EXPERIMENT
             if (a.dbg & 4) { rowoff[i] = (unsigned)((d.inW + 1) * pbytes) + (rowoff[i] & 0x3FFu); badmask[i] = 0; }   // cache-hot gathers
 #endif
-            if (lu == 0) opix[lrow + 32 * i] = pixoff;
-            x += 32;
+            if (lu == 0) opix[lrow + RPP * i] = pixoff;
+            x += RPP;
             const int qx = (int)(((float)x + 0.5f) * inv_gw);
             x -= qx * d.gridW;
             y += qx;
@@ -197,7 +207,7 @@ __global__ __launch_bounds__(256) void igemm16_kernel(const Igemm16Args a) {
     unsigned woff[RB], wbad[RB];
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
-        const int n = tn * BN + lrow + 32 * i;
+        const int n = tn * BN + lrow + RPP * i;
         wbad[i] = n < d.Cout ? 0u : 0xFFFFFFFFu;
         woff[i] = n < d.Cout ? (unsigned)n * (unsigned)a.Ktot * 2u : 0u;
 #ifdef LOANS_EXPERIMENT
@@ -227,11 +237,11 @@ __global__ __launch_bounds__(256) void igemm16_kernel(const Igemm16Args a) {
     auto dma_a = [&](int buf, int i) {      // one 1 KiB LDS-DMA piece: 8 rows x 128 B of the A tile
         const unsigned bad = (unsigned)__builtin_amdgcn_sbfe((int)badmask[i], tcs, 1u);     // 0 / ~0: this row's bit of the tap
         const unsigned off = (rowoff[i] + toff) | bad | kb;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(As + (buf * BM + 32 * i + 8 * wave_u) * BKH), 16, (int)off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(As + (buf * BM + RPP * i + 8 * wave_u) * BKH), 16, (int)off, 0, 0, 0);
     };
     auto dma_b = [&](int buf, int i) {
         const unsigned off = (woff[i] + (unsigned)u * 16u) | wbad[i] | kb;
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(Bs + (buf * BN + 32 * i + 8 * wave_u) * BKH), 16, (int)off, 0, 0, 0);
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(Bs + (buf * BN + RPP * i + 8 * wave_u) * BKH), 16, (int)off, 0, 0, 0);
     };
     auto advance = [&]() {      // to the following chunk (8 units further along K)
         u += 8;
@@ -294,15 +304,32 @@ __global__ __launch_bounds__(256) void igemm16_kernel(const Igemm16Args a) {
     bf16x8_t fa0[TM], fb0[TN], fa1[TM], fb1[TN];
 #pragma unroll
     for (int p = 0; p < NPIECE; ++p) dma_piece(0, p);
-    __syncthreads();
+    // end of a chunk: the next one has landed and every wave is done reading the stage the coming DMA overwrites.  Three
+    // stages: the RA + RB pieces of chunk c + 2, issued last, may stay in flight (loads retire in order); the LDS reads of
+    // this wave must have returned (lgkmcnt) because another wave's DMA may write that stage right behind the barrier.
+    auto chunk_barrier = [&]() {
+        if constexpr (ST == 2) {
+            __syncthreads();
+        } else {
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(RA + RB) : "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
+        }
+    };
+    if constexpr (ST == 3) {
+#pragma unroll
+        for (int p = 0; p < NPIECE; ++p) dma_piece(1, p);
+    }
+    chunk_barrier();
     read_frag(0, 0, fa0, fb0);
     int c = 0;
+    int s_cur = 0, s_nxt = 1, s_pre = ST == 3 ? 2 : 1;     // stages of chunk c, c + 1 and of the chunk being fetched
 #ifdef LOANS_STAMPS
     unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0, p_s0 = 0, p_s1 = 0, p_s2 = 0, p_bar = 0, p_s3 = 0, q_begin = 0;
     STAMP16(q_begin);
 #endif
     for (; c + 1 < nch; ++c) {
-        const int buf = c & 1;
+        const int buf = s_cur;
         STAMP16(q0);
         read_frag(buf, 1, fa1, fb1);
         relu_frag(fa0);
@@ -311,7 +338,7 @@ __global__ __launch_bounds__(256) void igemm16_kernel(const Igemm16Args a) {
         for (int q = 0; q < NMMA; ++q) {
             mma_one(q, fa0, fb0);
 #pragma unroll
-            for (int p = q * PPG; p < (q + 1) * PPG; ++p) dma_piece(buf ^ 1, p);
+            for (int p = q * PPG; p < (q + 1) * PPG; ++p) dma_piece(s_pre, p);
             __builtin_amdgcn_sched_barrier(0);
         }
         STAMP16(q1);
@@ -322,7 +349,7 @@ __global__ __launch_bounds__(256) void igemm16_kernel(const Igemm16Args a) {
         for (int q = 0; q < NMMA; ++q) {
             mma_one(q, fa1, fb1);
 #pragma unroll
-            for (int p = (NMMA + q) * PPG; p < (NMMA + q + 1) * PPG; ++p) dma_piece(buf ^ 1, p);
+            for (int p = (NMMA + q) * PPG; p < (NMMA + q + 1) * PPG; ++p) dma_piece(s_pre, p);
             __builtin_amdgcn_sched_barrier(0);
         }
         STAMP16(q2);
@@ -333,9 +360,9 @@ __global__ __launch_bounds__(256) void igemm16_kernel(const Igemm16Args a) {
         __builtin_amdgcn_sched_barrier(0);
         relu_frag(fa1);
         STAMP16(q3);
-        __syncthreads();
+        chunk_barrier();
         STAMP16(q4);
-        read_frag(buf ^ 1, 0, fa0, fb0);
+        read_frag(s_nxt, 0, fa0, fb0);
         __builtin_amdgcn_sched_barrier(0);
         mma(fa1, fb1);
         __builtin_amdgcn_sched_barrier(0);
@@ -343,9 +370,11 @@ __global__ __launch_bounds__(256) void igemm16_kernel(const Igemm16Args a) {
 #ifdef LOANS_STAMPS
         p_s0 += q1 - q0; p_s1 += q2 - q1; p_s2 += q3 - q2; p_bar += q4 - q3; p_s3 += q5 - q4;
 #endif
+        if constexpr (ST == 3) { const int t = s_cur; s_cur = s_nxt; s_nxt = s_pre; s_pre = t; }
+        else { s_cur ^= 1; s_nxt ^= 1; s_pre ^= 1; }
     }
 #ifdef LOANS_STAMPS
-    if (logical < 64 && (tid & 63) == 0) {
+    if (logical < 64 && (tid & 63) == 0 && tid < 256) {
         unsigned long long* o = g_stamps16 + (logical * 4 + (tid >> 6)) * 8;
         o[0] = p_s0; o[1] = p_s1; o[2] = p_s2; o[3] = p_bar; o[4] = p_s3; o[5] = q5 - q_begin; o[6] = nch - 1; o[7] = 0;
         unsigned long long* ob = g_stamps16b + (logical * 4 + (tid >> 6)) * 4;
@@ -353,7 +382,7 @@ __global__ __launch_bounds__(256) void igemm16_kernel(const Igemm16Args a) {
     }
 #endif
     {   // last chunk: steps that lie wholly beyond Ktot hold zeros on both sides and are skipped
-        const int buf = c & 1;
+        const int buf = s_cur;
         const int ts = c_end == a.nchunks ? (a.Ktot - (a.nchunks - 1) * BKH + 15) / 16 : 4;      // 1..4
         if (ts > 1) read_frag(buf, 1, fa1, fb1);
         relu_frag(fa0);
@@ -377,7 +406,7 @@ __global__ __launch_bounds__(256) void igemm16_kernel(const Igemm16Args a) {
     const bool f_mask = d.flags & LOANS_F_MASK, f_add = d.flags & LOANS_F_ADDEND;
     const bool f_addmask = d.flags & LOANS_F_ADDEND_MASK;
     constexpr int LDC = BN + 4;
-    float* Cs = reinterpret_cast<float*>(smem);          // [BM][LDC]
+    float* Cs = reinterpret_cast<float*>(smem);          // [BM / passes][LDC]
     __syncthreads();
     if (f_stats) {
         int nvalid = 0;
@@ -411,35 +440,12 @@ __global__ __launch_bounds__(256) void igemm16_kernel(const Igemm16Args a) {
             }
         }
     }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-                Cs[(wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * LDC + wn * TN * 32 + j * 32 + r] = acc[i][j][e];
-    __syncthreads();
-
     constexpr int CPR = BN / 8;                 // 8-channel units per row
-    constexpr int RSTEP = 256 / CPR;            // rows covered by the block per pass
+    constexpr int RSTEP = NT / CPR;            // rows covered by the block per pass
     const int oc8 = tid % CPR, r0 = tid / CPR;
     const int col0 = tn * BN + oc8 * 8;
     const unsigned cbad = (col0 + 7 < d.Cout) ? 0u : 0xFFFFFFFFu;     // Cout % 8 == 0 (checked)
-    if (a.partial) {
-        // raw partial tile: fp32 atomic adds into the zeroed workspace, one wave-instruction = 256 CONTIGUOUS bytes of one row
-        // (64 lanes x 4 B: the full-rate shape; lanes 32 B apart run an order of magnitude slower); bias / statistics / mask /
-        // addend / the rounding to bf16 belong to loans_igemm_finalize_bf16
-        constexpr int WPR = BN / 64;                        // wave-instructions per row
-        const int wv = tid >> 6, ln = tid & 63;
-#pragma unroll 4
-        for (int q = wv; q < BM * WPR; q += 4) {
-            const int row = q / WPR, cc = (q - row * WPR) * 64 + ln;
-            const unsigned po = opix[row];                  // byte offset of the row in a bf16 tensor = 2 * element offset
-            const int col = tn * BN + cc;
-            if (po != 0xFFFFFFFFu && col < d.Cout) atomic_add_f32(a.partial + (size_t)(po >> 1) + col, Cs[row * LDC + cc]);
-        }
-        return;
-    }
+    // (descriptors, bias: once; unused by a partial launch)
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)a.out_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_ref = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<__bf16*>(a.ref ? a.ref : a.out), 0, (int)a.out_bytes, 0x00020000);
@@ -456,44 +462,80 @@ __global__ __launch_bounds__(256) void igemm16_kernel(const Igemm16Args a) {
         v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
         return v;
     };
+    // the tile goes through the fp32 staging area in EP passes of PR rows (one pass for every tile whose [BM][BN + 4] floats
+    // fit the operand stages; the 256 x 256 tile takes two): the waves that own the pass's rows write, everybody stores
+    constexpr int EP = igemm16_epilogue_passes<BM, BN>();
+    constexpr int PR = BM / EP;
+    static_assert(PR % (TM * 32) == 0 || (TM * 32) % PR == 0, "a wave's rows fall into whole passes");
+#pragma unroll 1
+    for (int ep = 0; ep < EP; ++ep) {
+        if (ep) __syncthreads();            // the previous pass has been read
 #pragma unroll
-    for (int p = 0; p < BM / RSTEP; ++p) {
-        const int row = r0 + p * RSTEP;
-        const unsigned po = opix[row];
-        const unsigned off = (po + coff) | (po == 0xFFFFFFFFu ? 0xFFFFFFFFu : 0u) | cbad;
-        f32x4 lo = *reinterpret_cast<const f32x4*>(Cs + row * LDC + oc8 * 8) + b_lo;
-        f32x4 hi = *reinterpret_cast<const f32x4*>(Cs + row * LDC + oc8 * 8 + 4) + b_hi;
-        if (f_mask || f_addmask) {
-            const bf16x8_t rf = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_ref, (int)off, 0, 0));
-            const f32x4 rl = cvt_lo(rf), rh = cvt_hi(rf);
-            if (f_mask) { lo = keep_pos(lo, rl); hi = keep_pos(hi, rh); }
-            if (f_add) {
-                const bf16x8_t ad = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_add, (int)off, 0, 0));
-                f32x4 al = cvt_lo(ad), ah = cvt_hi(ad);
-                if (f_addmask) { al = keep_pos(al, rl); ah = keep_pos(ah, rh); }
-                lo += al; hi += ah;
+        for (int i = 0; i < TM; ++i) {
+            const int trow = wm * TM * 32 + i * 32;         // first row of this 32-row MFMA tile
+            if (trow / PR == ep) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        Cs[(trow % PR + (e & 3) + 8 * (e >> 2) + 4 * h) * LDC + wn * TN * 32 + j * 32 + r] = acc[i][j][e];
             }
-        } else if (f_add) {
-            const bf16x8_t ad = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_add, (int)off, 0, 0));
-            lo += cvt_lo(ad); hi += cvt_hi(ad);
         }
-        bf16x8_t o;
-        const bf16x4_t ol = __builtin_convertvector(lo, bf16x4_t), oh = __builtin_convertvector(hi, bf16x4_t);
-        o[0] = ol[0]; o[1] = ol[1]; o[2] = ol[2]; o[3] = ol[3];
-        o[4] = oh[0]; o[5] = oh[1]; o[6] = oh[2]; o[7] = oh[3];
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_out, (int)off, 0, 0);
+        __syncthreads();
+        if (a.partial) {
+            // raw partial tile: fp32 atomic adds into the zeroed workspace, one wave-instruction = 256 CONTIGUOUS bytes of one row
+            // (64 lanes x 4 B: the full-rate shape; lanes 32 B apart run an order of magnitude slower); bias / statistics / mask /
+            // addend / the rounding to bf16 belong to loans_igemm_finalize_bf16
+            constexpr int WPR = BN / 64;                        // wave-instructions per row
+            const int wv = tid >> 6, ln = tid & 63;
+#pragma unroll 4
+            for (int q = wv; q < PR * WPR; q += NT / 64) {
+                const int row = q / WPR, cc = (q - row * WPR) * 64 + ln;
+                const unsigned po = opix[ep * PR + row];        // byte offset of the row in a bf16 tensor = 2 * element offset
+                const int col = tn * BN + cc;
+                if (po != 0xFFFFFFFFu && col < d.Cout) atomic_add_f32(a.partial + (size_t)(po >> 1) + col, Cs[row * LDC + cc]);
+            }
+            continue;
+        }
+#pragma unroll
+        for (int p = 0; p < PR / RSTEP; ++p) {
+            const int row = r0 + p * RSTEP;
+            const unsigned po = opix[ep * PR + row];
+            const unsigned off = (po + coff) | (po == 0xFFFFFFFFu ? 0xFFFFFFFFu : 0u) | cbad;
+            f32x4 lo = *reinterpret_cast<const f32x4*>(Cs + row * LDC + oc8 * 8) + b_lo;
+            f32x4 hi = *reinterpret_cast<const f32x4*>(Cs + row * LDC + oc8 * 8 + 4) + b_hi;
+            if (f_mask || f_addmask) {
+                const bf16x8_t rf = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_ref, (int)off, 0, 0));
+                const f32x4 rl = cvt_lo(rf), rh = cvt_hi(rf);
+                if (f_mask) { lo = keep_pos(lo, rl); hi = keep_pos(hi, rh); }
+                if (f_add) {
+                    const bf16x8_t ad = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_add, (int)off, 0, 0));
+                    f32x4 al = cvt_lo(ad), ah = cvt_hi(ad);
+                    if (f_addmask) { al = keep_pos(al, rl); ah = keep_pos(ah, rh); }
+                    lo += al; hi += ah;
+                }
+            } else if (f_add) {
+                const bf16x8_t ad = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_add, (int)off, 0, 0));
+                lo += cvt_lo(ad); hi += cvt_hi(ad);
+            }
+            bf16x8_t o;
+            const bf16x4_t ol = __builtin_convertvector(lo, bf16x4_t), oh = __builtin_convertvector(hi, bf16x4_t);
+            o[0] = ol[0]; o[1] = ol[1]; o[2] = ol[2]; o[3] = ol[3];
+            o[4] = oh[0]; o[5] = oh[1]; o[6] = oh[2]; o[7] = oh[3];
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_out, (int)off, 0, 0);
+        }
     }
 #ifdef LOANS_STAMPS
     unsigned long long t_exit = 0;
     STAMP16(t_exit);
-    if (logical < 64 && (tid & 63) == 0) g_stamps16b[(logical * 4 + (tid >> 6)) * 4 + 3] = t_exit;
+    if (logical < 64 && (tid & 63) == 0 && tid < 256) g_stamps16b[(logical * 4 + (tid >> 6)) * 4 + 3] = t_exit;
 #endif
 }
 
 template <int BM, int BN, int WM, int WN, bool RELU>
 int launch_igemm16_r(Igemm16Args& a, hipStream_t st) {
     static loans_device_once lds_limit_set;       // per template instance = per kernel, one bit per device
-    constexpr size_t lds = igemm16_lds_bytes<BM, BN>();
+    constexpr size_t lds = igemm16_lds_bytes<BM, BN, igemm16_stages<BM, BN, WM, WN>()>();
     static_assert(lds <= 160 * 1024, "tile does not fit the LDS");
     auto kern = igemm16_kernel<BM, BN, WM, WN, RELU>;
     if (int rc_ = loans_raise_lds_limit(lds_limit_set, reinterpret_cast<const void*>(kern), lds)) return rc_;
@@ -503,7 +545,7 @@ int launch_igemm16_r(Igemm16Args& a, hipStream_t st) {
     if (a.splits > a.nchunks) a.splits = a.nchunks;
     a.chunks_per_split = (a.nchunks + a.splits - 1) / a.splits;
     a.splits = (a.nchunks + a.chunks_per_split - 1) / a.chunks_per_split;       // no empty slice
-    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n * a.splits), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(a.tiles_m * a.tiles_n * a.splits), dim3(64 * WM * WN), lds, st, a);
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;
 }
@@ -862,7 +904,8 @@ static int igemm_bf16s_impl(const void* in, const void* w, void* out, const floa
         case LOANS_TILE_128x64: return launch_igemm16<128, 64, 2, 2>(a, st);
         case LOANS_TILE_64x64: return launch_igemm16<64, 64, 2, 2>(a, st);
         case LOANS_TILE_256x64: return launch_igemm16<256, 64, 4, 1>(a, st);
-        case LOANS_TILE_256x128: return launch_igemm16<256, 128, 2, 2>(a, st);
+        case LOANS_TILE_256x128: return launch_igemm16<256, 128, 4, 2>(a, st);      // 512 threads: eight 64 x 64 wave tiles
+        case LOANS_TILE_256x256: return launch_igemm16<256, 256, 2, 4>(a, st);      // 512 threads: eight 128 x 64 wave tiles
         case LOANS_TILE_HALO_128:
         case LOANS_TILE_HALO_128x64:
         case LOANS_TILE_HALO_256x64:

@@ -284,6 +284,13 @@ TILE_HALO_128, TILE_HALO_256x64, TILE_HALO_128x64, TILE_HALO_128x64S, TILE_WS64 
 HALO = os.environ.get('LOANS_HALO', '1') != '0'
 
 
+TILE_256x256 = 9        # LOANS_TILE_256x256 (loans_igemm_bf16s): eight 128 x 64 wave tiles, for GEMMs with >= 256 columns
+
+
+def _wide16_tiles(columns):
+    return (TILE_256x256,) if columns % 256 == 0 else ()
+
+
 def _splitk16_candidates(rows, out_channels, ktot):
     """split-K forms of the bf16 implicit GEMM (loans_igemm_bf16s_splitk) for grids that cannot fill the machine: few tiles,
     long K (res6 / res7 at 512 px, everything at small batch).  tile id = base tile | (splits << 8)."""
@@ -604,7 +611,7 @@ def _conv_fprop16(lib, x, w, geo, out, bias, stats, relu_in, addend, tile):
                 return
             check(lib.loans_igemm_bf16s(_ptr(x), _ptr(w16), _ptr(scratch), 0, _ptr(sstats), 0, 0,
                                         C.byref(_with_flags(geo.fwd, tflags, t)), _stream()), 'loans_igemm_bf16s[tune]')
-        halo = _halo_tiles(geo, geo.Cin, geo.Cout, (geo.Ho, geo.Wo), relu_in)
+        halo = _halo_tiles(geo, geo.Cin, geo.Cout, (geo.Ho, geo.Wo), relu_in) + _wide16_tiles(geo.Cout)
         sk = () if geo.dense else _splitk16_candidates(geo.B * geo.Ho * geo.Wo, geo.Cout, geo.w_numel // geo.Cout)
         stem = (TILE_STEM,) if (STEM_DIRECT and geo.dense and not relu_in and addend is None and stem16_tile_rows(geo)) else ()
         tile = _tuned_tile(geo, 'bf16s_fprop' + ('_stats' if stats is not None else '') + ('_h' if halo else '') +
@@ -664,7 +671,7 @@ def _conv_dgrad16(lib, gy, w, geo, out, mask_ref, addend, addend_mask_ref, tile)
             for d, _, off in geo.dgrad:
                 check(lib.loans_igemm_bf16s(_ptr(gy), _ptr(wp[off:]), _ptr(scratch), 0, 0, 0, 0,
                                             C.byref(_with_flags(d, 0, t)), st), 'loans_igemm_bf16s[tune]')
-        halo = _halo_tiles(geo, geo.Cout, geo.Cin, (geo.H, geo.W))
+        halo = _halo_tiles(geo, geo.Cout, geo.Cin, (geo.H, geo.W)) + _wide16_tiles(geo.Cin)
         sk = ()
         if sk_ok:
             cls_rows = geo.B * min(d.gridH * d.gridW for d, _, _ in geo.dgrad)

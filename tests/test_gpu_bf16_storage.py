@@ -40,11 +40,12 @@ CASES = [
     (3, 256, 7, 7, 64, 1, 1, 0),       # 1x1 bottleneck reduce
     (2, 64, 9, 9, 256, 1, 2, 0),       # 1x1 strided (ResNet-50 shortcut)
     (2, 8, 11, 11, 16, 3, 1, 1),       # a single 16-byte unit per tap, K tail
+    (3, 128, 20, 20, 512, 3, 1, 1),    # more than one 256-row tile, two 256-column tiles
 ]
 
 
 @pytest.mark.parametrize("case", CASES)
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 7, 5])     # 5: a weight-gradient tile
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 7, 9, 5])     # 5: a weight-gradient tile; 7, 9: the 512-thread tiles
 def test_conv_bf16_storage(case, tile):
     from loans_amd import ops
     B, Cin, H, W, Cout, k, s, p = case
@@ -57,7 +58,7 @@ def test_conv_bf16_storage(case, tile):
     xd, wd = d16(_nhwc(x)), dev(_nhwc(w))
     y_ref, col = C.conv2d_fwd(x.astype(np.float64), wr.astype(np.float64), b.astype(np.float64), s, p)
     stats_r = ops.stats_buffer(Cout, 'cuda')
-    wtile, tile = tile, (tile if tile in (0, 1, 2, 3, 4, 7) else 0)
+    wtile, tile = tile, (tile if tile in (0, 1, 2, 3, 4, 7, 9) else 0)
     y = ops.conv_fprop(xd, wd, geo, bias=dev(b), stats=stats_r, tile=tile)
     assert y.dtype == torch.bfloat16
     assert np.abs(_nchw(y) - y_ref).max() <= BF16_EPS * np.abs(y_ref).max()
@@ -209,7 +210,7 @@ def test_region_boundaries_bf16_storage():
         ops.set_storage_dtype('bf16')
         xp16 = ops.prep_images(dev(frames), geo)
         assert xp16.dtype == torch.bfloat16 and xp16.frame_hw == (Hs, Hs) and torch.equal(xp16, xp.to(torch.bfloat16))
-        for t in (1, 2, 3, 4, 7):
+        for t in (1, 2, 3, 4, 7, 9):
             sb = ops.stats_buffer(64, 'cuda')
             cb = ops.conv_fprop(xp16, wd, geo, bias=bias, stats=sb, tile=t)
             assert cb.dtype == torch.bfloat16
