@@ -77,11 +77,17 @@ __device__ __forceinline__ f32x4 cvt_hi(bf16x8_t v) {
     return f32x4{(float)v[4], (float)v[5], (float)v[6], (float)v[7]};
 }
 
-// LDS stages of the operand ring: two (the DMA of chunk c + 1 rides behind the MFMAs of chunk c) for the 256-thread tiles, of
-// which two or more blocks share a CU; THREE for the 512-thread tiles, which own their CU: chunk c + 2 is in flight while
-// chunk c is contracted, and the barrier waits with a counted vmcnt for chunk c + 1 only
+// LDS stages of the operand ring (ST): with two, the DMA of chunk c + 1 rides behind the MFMAs of chunk c -- enough where two
+// or more blocks share a CU and cover each other's waits.  A block that owns its CU gets a longer ring: chunk c + ST - 1 is
+// issued while chunk c is contracted and the chunk barrier waits with a COUNTED vmcnt for chunk c + 1 only (loads retire in
+// order: the ST - 2 younger chunks stay in flight).  Three stages for the 512-thread 256 x 128 tile; the LOANS_TILE_DEEP forms
+// of the small tiles (few blocks, long K: res6 / res7 at 512 px, where one block per CU waited a full memory latency per
+// chunk) take as many stages as fit half the LDS.
 template <int BM, int BN, int WM, int WN>
-constexpr int igemm16_stages() { return (WM * WN == 8 && (size_t)3 * (BM + BN) * BKH * 2 <= 150 * 1024) ? 3 : 2; }
+constexpr int igemm16_stages(bool deep) {
+    if (deep) return BM * BN <= 64 * 64 ? 8 : (BM * BN <= 128 * 64 ? 5 : 4);
+    return (WM * WN == 8 && (size_t)3 * (BM + BN) * BKH * 2 <= 150 * 1024) ? 3 : 2;
+}
 template <int BM, int BN>
 constexpr int igemm16_epilogue_passes() { return (size_t)BM * (BN + 4) * 4 > 140 * 1024 ? 2 : 1; }
 template <int BM, int BN, int ST>
@@ -94,7 +100,7 @@ template <int BM, int BN, int ST>
 constexpr size_t igemm16_lds_bytes() { return igemm16_aux_bytes<BM, BN, ST>() + LOANS_MAX_TAPS * 4 + BM * 4; }
 
 // RELU: gather relu(in) (LOANS_F_RELU_IN, the assessor's pre-activation convs): applied to the A fragments
-template <int BM, int BN, int WM, int WN, bool RELU>
+template <int BM, int BN, int WM, int WN, int ST, bool RELU>
 __global__ __launch_bounds__(64 * WM * WN) void igemm16_kernel(const Igemm16Args a) {
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
     constexpr int NT = 64 * WM * WN;           // 256 threads, or 512 for the 256-row tiles (two waves per SIMD from ONE block)
@@ -102,7 +108,6 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm16_kernel(const Igemm16Args
     constexpr int RA = BM / RPP, RB = BN / RPP;
     constexpr int NMMA = TM * TN;              // MFMAs per 16-deep k step
     extern __shared__ __attribute__((aligned(16))) char smem[];
-    constexpr int ST = igemm16_stages<BM, BN, WM, WN>();
     __bf16* As = reinterpret_cast<__bf16*>(smem);      // [ST][BM][64]
     __bf16* Bs = As + ST * BM * BKH;                   // [ST][BN][64]
     int* taps = reinterpret_cast<int*>(smem + igemm16_aux_bytes<BM, BN, ST>());
@@ -304,26 +309,27 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm16_kernel(const Igemm16Args
     bf16x8_t fa0[TM], fb0[TN], fa1[TM], fb1[TN];
 #pragma unroll
     for (int p = 0; p < NPIECE; ++p) dma_piece(0, p);
-    // end of a chunk: the next one has landed and every wave is done reading the stage the coming DMA overwrites.  Three
-    // stages: the RA + RB pieces of chunk c + 2, issued last, may stay in flight (loads retire in order); the LDS reads of
+    // end of a chunk: the next one has landed and every wave is done reading the stage the coming DMA overwrites.  More than
+    // two stages: the pieces of the ST - 2 chunks issued after it may stay in flight (loads retire in order); the LDS reads of
     // this wave must have returned (lgkmcnt) because another wave's DMA may write that stage right behind the barrier.
     auto chunk_barrier = [&]() {
         if constexpr (ST == 2) {
             __syncthreads();
         } else {
-            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"(RA + RB) : "memory");
+            static_assert((ST - 2) * (RA + RB) <= 63, "vmcnt is a 6-bit counter");
+            asm volatile("s_waitcnt vmcnt(%0) lgkmcnt(0)" ::"n"((ST - 2) * (RA + RB)) : "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         }
     };
-    if constexpr (ST == 3) {
 #pragma unroll
-        for (int p = 0; p < NPIECE; ++p) dma_piece(1, p);
-    }
+    for (int k = 1; k < ST - 1; ++k)
+#pragma unroll
+        for (int p = 0; p < NPIECE; ++p) dma_piece(k, p);
     chunk_barrier();
     read_frag(0, 0, fa0, fb0);
     int c = 0;
-    int s_cur = 0, s_nxt = 1, s_pre = ST == 3 ? 2 : 1;     // stages of chunk c, c + 1 and of the chunk being fetched
+    int s_cur = 0, s_nxt = 1, s_pre = ST - 1;     // stages of chunk c, c + 1 and of the chunk being fetched (c + ST - 1)
 #ifdef LOANS_STAMPS
     unsigned long long q0 = 0, q1 = 0, q2 = 0, q3 = 0, q4 = 0, q5 = 0, p_s0 = 0, p_s1 = 0, p_s2 = 0, p_bar = 0, p_s3 = 0, q_begin = 0;
     STAMP16(q_begin);
@@ -370,8 +376,9 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm16_kernel(const Igemm16Args
 #ifdef LOANS_STAMPS
         p_s0 += q1 - q0; p_s1 += q2 - q1; p_s2 += q3 - q2; p_bar += q4 - q3; p_s3 += q5 - q4;
 #endif
-        if constexpr (ST == 3) { const int t = s_cur; s_cur = s_nxt; s_nxt = s_pre; s_pre = t; }
-        else { s_cur ^= 1; s_nxt ^= 1; s_pre ^= 1; }
+        s_cur = s_nxt;
+        s_nxt = s_nxt + 1 == ST ? 0 : s_nxt + 1;
+        s_pre = s_pre + 1 == ST ? 0 : s_pre + 1;
     }
 #ifdef LOANS_STAMPS
     if (logical < 64 && (tid & 63) == 0 && tid < 256) {
@@ -532,12 +539,12 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm16_kernel(const Igemm16Args
 #endif
 }
 
-template <int BM, int BN, int WM, int WN, bool RELU>
+template <int BM, int BN, int WM, int WN, int ST, bool RELU>
 int launch_igemm16_r(Igemm16Args& a, hipStream_t st) {
     static loans_device_once lds_limit_set;       // per template instance = per kernel, one bit per device
-    constexpr size_t lds = igemm16_lds_bytes<BM, BN, igemm16_stages<BM, BN, WM, WN>()>();
+    constexpr size_t lds = igemm16_lds_bytes<BM, BN, ST>();
     static_assert(lds <= 160 * 1024, "tile does not fit the LDS");
-    auto kern = igemm16_kernel<BM, BN, WM, WN, RELU>;
+    auto kern = igemm16_kernel<BM, BN, WM, WN, ST, RELU>;
     if (int rc_ = loans_raise_lds_limit(lds_limit_set, reinterpret_cast<const void*>(kern), lds)) return rc_;
     a.tiles_m = (a.M + BM - 1) / BM;
     a.tiles_n = (a.d.Cout + BN - 1) / BN;
@@ -550,9 +557,10 @@ int launch_igemm16_r(Igemm16Args& a, hipStream_t st) {
     return LOANS_OK;
 }
 
-template <int BM, int BN, int WM, int WN>
+template <int BM, int BN, int WM, int WN, bool DEEP = false>
 int launch_igemm16(Igemm16Args& a, hipStream_t st) {
-    return (a.d.flags & LOANS_F_RELU_IN) ? launch_igemm16_r<BM, BN, WM, WN, true>(a, st) : launch_igemm16_r<BM, BN, WM, WN, false>(a, st);
+    constexpr int ST = igemm16_stages<BM, BN, WM, WN>(DEEP);
+    return (a.d.flags & LOANS_F_RELU_IN) ? launch_igemm16_r<BM, BN, WM, WN, ST, true>(a, st) : launch_igemm16_r<BM, BN, WM, WN, ST, false>(a, st);
 }
 
 void detect_tap_grid16(const loans_igemm_desc* d, Igemm16Args& a) {
@@ -894,7 +902,7 @@ static int igemm_bf16s_impl(const void* in, const void* w, void* out, const floa
         const int64_t big = (int64_t)((a.M + 127) / 128) * ((d->Cout + 127) / 128);
         tile = d->Cout <= 64 ? LOANS_TILE_128x64 : (big >= 512 ? LOANS_TILE_128x128 : LOANS_TILE_64x64);
     }
-    if (partial && tile >= LOANS_TILE_HALO_128) return LOANS_EINVAL;      // the halo tiles have no split-K form
+    if (partial && tile >= LOANS_TILE_HALO_128 && tile <= LOANS_TILE_WS64) return LOANS_EINVAL;      // the halo tiles have no split-K form
     if (tile == LOANS_TILE_STEM) {          // the dense RGB stem as a direct convolution (stem.hip)
         if (partial || splits > 1) return LOANS_EINVAL;
         return loans_stem7_bf16s_launch(in, w, out, bias, stats, d, st);
@@ -904,6 +912,9 @@ static int igemm_bf16s_impl(const void* in, const void* w, void* out, const floa
         case LOANS_TILE_128x64: return launch_igemm16<128, 64, 2, 2>(a, st);
         case LOANS_TILE_64x64: return launch_igemm16<64, 64, 2, 2>(a, st);
         case LOANS_TILE_256x64: return launch_igemm16<256, 64, 4, 1>(a, st);
+        case LOANS_TILE_128x128 | LOANS_TILE_DEEP: return launch_igemm16<128, 128, 2, 2, true>(a, st);
+        case LOANS_TILE_128x64 | LOANS_TILE_DEEP: return launch_igemm16<128, 64, 2, 2, true>(a, st);
+        case LOANS_TILE_64x64 | LOANS_TILE_DEEP: return launch_igemm16<64, 64, 2, 2, true>(a, st);
         case LOANS_TILE_256x128: return launch_igemm16<256, 128, 4, 2>(a, st);      // 512 threads: eight 64 x 64 wave tiles
         case LOANS_TILE_256x256: return launch_igemm16<256, 256, 2, 4>(a, st);      // 512 threads: eight 128 x 64 wave tiles
         case LOANS_TILE_HALO_128:

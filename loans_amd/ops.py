@@ -287,8 +287,16 @@ HALO = os.environ.get('LOANS_HALO', '1') != '0'
 TILE_256x256 = 9        # LOANS_TILE_256x256 (loans_igemm_bf16s): eight 128 x 64 wave tiles, for GEMMs with >= 256 columns
 
 
-def _wide16_tiles(columns):
-    return (TILE_256x256,) if columns % 256 == 0 else ()
+TILE_DEEP = 32          # LOANS_TILE_DEEP: a longer LDS ring for grids of about one block per CU
+
+
+def _wide16_tiles(columns, rows=None):
+    """further tile forms of loans_igemm_bf16s by GEMM shape: 256 x 256 where the columns fill it, the deep-ring forms of the
+    small tiles where the grid is small (at most four 64 x 64 blocks per CU of an MI355X)"""
+    t = (TILE_256x256,) if columns % 256 == 0 else ()
+    if rows is not None and ((rows + 63) // 64) * ((columns + 63) // 64) <= 1024:
+        t += (1 | TILE_DEEP, 2 | TILE_DEEP, 3 | TILE_DEEP)
+    return t
 
 
 def _splitk16_candidates(rows, out_channels, ktot):
@@ -611,7 +619,7 @@ def _conv_fprop16(lib, x, w, geo, out, bias, stats, relu_in, addend, tile):
                 return
             check(lib.loans_igemm_bf16s(_ptr(x), _ptr(w16), _ptr(scratch), 0, _ptr(sstats), 0, 0,
                                         C.byref(_with_flags(geo.fwd, tflags, t)), _stream()), 'loans_igemm_bf16s[tune]')
-        halo = _halo_tiles(geo, geo.Cin, geo.Cout, (geo.Ho, geo.Wo), relu_in) + _wide16_tiles(geo.Cout)
+        halo = _halo_tiles(geo, geo.Cin, geo.Cout, (geo.Ho, geo.Wo), relu_in) + _wide16_tiles(geo.Cout, geo.B * geo.Ho * geo.Wo)
         sk = () if geo.dense else _splitk16_candidates(geo.B * geo.Ho * geo.Wo, geo.Cout, geo.w_numel // geo.Cout)
         stem = (TILE_STEM,) if (STEM_DIRECT and geo.dense and not relu_in and addend is None and stem16_tile_rows(geo)) else ()
         tile = _tuned_tile(geo, 'bf16s_fprop' + ('_stats' if stats is not None else '') + ('_h' if halo else '') +
@@ -671,7 +679,7 @@ def _conv_dgrad16(lib, gy, w, geo, out, mask_ref, addend, addend_mask_ref, tile)
             for d, _, off in geo.dgrad:
                 check(lib.loans_igemm_bf16s(_ptr(gy), _ptr(wp[off:]), _ptr(scratch), 0, 0, 0, 0,
                                             C.byref(_with_flags(d, 0, t)), st), 'loans_igemm_bf16s[tune]')
-        halo = _halo_tiles(geo, geo.Cout, geo.Cin, (geo.H, geo.W)) + _wide16_tiles(geo.Cin)
+        halo = _halo_tiles(geo, geo.Cout, geo.Cin, (geo.H, geo.W)) + _wide16_tiles(geo.Cin, geo.B * min(d.gridH * d.gridW for d, _, _ in geo.dgrad))
         sk = ()
         if sk_ok:
             cls_rows = geo.B * min(d.gridH * d.gridW for d, _, _ in geo.dgrad)
