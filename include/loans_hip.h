@@ -190,6 +190,13 @@ int loans_wgrad_bf16_f32(const float* x, const float* gy, float* dw,
  * dx[] count bf16 ELEMENTS and must be even (the 16-byte K units are then 4-byte aligned), Cin % 8 == 0. */
 int loans_igemm_bf16s(const void* in, const void* w, void* out, const float* bias, double* stats,
                       const void* ref, const void* addend, const loans_igemm_desc* d, void* stream);
+/* Two forward convolutions of the SAME bf16 input with the same geometry AND the same channel count (BasicA's conv1 and its
+ * strided conv shortcut, sheep/resnet.py:128-133) as ONE GEMM with 2 x Cout columns: w_ab = [2][Cout][ntaps][Cin] (a's
+ * matrix, then b's), out_ab = [2][B][outH][outW][Cout] (two ordinary tensors back to back).  Unlike loans_igemm_pair_f32
+ * the two share the staged input tile, not just the grid: at N = 2 x 128 the 256-column tiles apply.  `d` describes
+ * convolution a; flags STATS / RELU_IN; Cout % 32 == 0; the implicit-GEMM tiles only. */
+int loans_igemm_pair_bf16s(const void* in, const void* w_ab, void* out_ab, double* stats_a, double* stats_b,
+                           const loans_igemm_desc* d, void* stream);
 /* wgrad with bf16 x and gy, fp32 atomic accumulation into dw ("fp32 grad accumulate"); the pixel-major tiles are staged as
  * they lie and transposed by the fragment reads (ds_read_b64_tr_b16).  Tiles 128x128, 64x64, 64x128. */
 int loans_wgrad_bf16s(const void* x, const void* gy, float* dw, const loans_igemm_desc* d, int32_t splits, void* stream);

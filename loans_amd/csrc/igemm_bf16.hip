@@ -56,6 +56,12 @@ struct Igemm16Args {
     // to `partial` [pixels][Cout] (zeroed by the caller); loans_igemm_finalize_bf16 makes the bf16 tensor of the finished sums
     int splits, chunks_per_split;
     float* partial;
+    // pair launch (loans_igemm_pair_bf16s): the GEMM has 2 x out_c columns -- two convolutions of the same input, weights
+    // stacked along N -- and columns >= csplit belong to the second output tensor (right behind the first one) and to stats2:
+    // the input tile is staged ONCE for both.  csplit = 0, out_c = d.Cout otherwise.
+    int csplit, out_c;
+    unsigned tensor_bytes;
+    double* stats2;
 };
 
 __device__ __forceinline__ int xcd_remap16(int id, int nblk) {
@@ -161,7 +167,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm16_kernel(const Igemm16Args
             if (m < a.M) {
                 const int iy0 = y * d.isy, ix0 = x * d.isx;
                 rowoff[i] = (unsigned)((b * d.inH + iy0) * d.inW + ix0) * (unsigned)pbytes;
-                pixoff = (unsigned)((b * d.outH + y * d.osy + d.oy0) * d.outW + x * d.osx + d.ox0) * (unsigned)d.Cout * 2u;
+                pixoff = (unsigned)((b * d.outH + y * d.osy + d.oy0) * d.outW + x * d.osx + d.ox0) * (unsigned)a.out_c * 2u;
                 if (dense) {
                     mask = ~0ull;
                 } else if (a.ap.nx > 0) {
@@ -441,9 +447,11 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm16_kernel(const Igemm16Args
             s += __shfl_xor(s, 32, 64);
             q2 += __shfl_xor(q2, 32, 64);
             if (h == 0 && cok) {
-                double* st = a.stats + (size_t)(blockIdx.x % LOANS_STATS_REPLICAS) * 2 * d.Cout;
-                atomic_add_f64(st + col, (double)s);
-                atomic_add_f64(st + d.Cout + col, (double)q2);
+                const bool sec = a.csplit && col >= a.csplit;           // the second convolution of a pair launch
+                double* st = (sec ? a.stats2 : a.stats) + (size_t)(blockIdx.x % LOANS_STATS_REPLICAS) * 2 * a.out_c;
+                const int scol = sec ? col - a.csplit : col;
+                atomic_add_f64(st + scol, (double)s);
+                atomic_add_f64(st + a.out_c + scol, (double)q2);
             }
         }
     }
@@ -458,7 +466,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm16_kernel(const Igemm16Args
         const_cast<__bf16*>(a.ref ? a.ref : a.out), 0, (int)a.out_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_add = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<__bf16*>(a.addend ? a.addend : a.out), 0, (int)a.out_bytes, 0x00020000);
-    const unsigned coff = (unsigned)col0 * 2u;
+    const unsigned coff = (a.csplit && col0 >= a.csplit) ? (unsigned)(col0 - a.csplit) * 2u + a.tensor_bytes : (unsigned)col0 * 2u;
     f32x4 b_lo = {0.f, 0.f, 0.f, 0.f}, b_hi = b_lo;
     if (f_bias && !cbad) {
         b_lo = *reinterpret_cast<const f32x4*>(a.bias + col0);
@@ -845,7 +853,8 @@ int launch_wgrad16(Wgrad16Args& a, int splits_req, hipStream_t st) {
 }  // namespace
 
 static int igemm_bf16s_impl(const void* in, const void* w, void* out, const float* bias, double* stats, const void* ref,
-                           const void* addend, const loans_igemm_desc* d, float* partial, int splits, void* stream) {
+                           const void* addend, const loans_igemm_desc* d, float* partial, int splits, void* stream,
+                           double* pair_stats = nullptr, bool pair = false) {
     if (!d || !in || !w || (!out && !partial)) return LOANS_EINVAL;
     if (partial && (d->flags & ~(LOANS_F_RELU_IN | LOANS_F_DENSE))) return LOANS_EINVAL;      // raw partial sums only
     if (d->B <= 0 || d->inH <= 0 || d->inW <= 0 || d->Cin <= 0 || (d->Cin & 7)) return LOANS_EINVAL;
@@ -886,6 +895,13 @@ static int igemm_bf16s_impl(const void* in, const void* w, void* out, const floa
     if (const char* e = getenv("LOANS_DBG")) a.dbg = atoi(e);
 #endif
     a.partial = partial;
+    a.csplit = 0; a.out_c = d->Cout; a.tensor_bytes = 0; a.stats2 = nullptr;
+    if (pair) {                 // `d` describes the stacked GEMM: Cout = 2 x the channels of either convolution
+        if (partial || (d->Cout & 63) || (d->flags & ~(LOANS_F_STATS | LOANS_F_RELU_IN))) return LOANS_EINVAL;
+        if ((d->flags & LOANS_F_STATS) && !pair_stats) return LOANS_EINVAL;
+        a.csplit = a.out_c = d->Cout / 2;
+        a.stats2 = pair_stats;
+    }
     a.splits = partial ? splits : 1;
     a.nchunks = (a.Ktot + BKH - 1) / BKH;
     {
@@ -894,6 +910,7 @@ static int igemm_bf16s_impl(const void* in, const void* w, void* out, const floa
         const int64_t ob = (int64_t)d->B * d->outH * d->outW * d->Cout * 2;
         if (ib >= 0xFFFFFFF0ll || wb >= 0xFFFFFFF0ll || ob >= 0xFFFFFFF0ll) return LOANS_ERANGE;   // 32-bit buffer offsets
         a.in_bytes = (unsigned)ib; a.w_bytes = (unsigned)wb; a.out_bytes = (unsigned)ob;
+        if (pair) a.tensor_bytes = (unsigned)(ob / 2);
     }
     detect_tap_grid16(d, a);
     hipStream_t st = as_stream(stream);
@@ -903,6 +920,7 @@ static int igemm_bf16s_impl(const void* in, const void* w, void* out, const floa
         tile = d->Cout <= 64 ? LOANS_TILE_128x64 : (big >= 512 ? LOANS_TILE_128x128 : LOANS_TILE_64x64);
     }
     if (partial && tile >= LOANS_TILE_HALO_128 && tile <= LOANS_TILE_WS64) return LOANS_EINVAL;      // the halo tiles have no split-K form
+    if (pair && (tile == LOANS_TILE_STEM || (tile >= LOANS_TILE_HALO_128 && tile <= LOANS_TILE_WS64))) return LOANS_EINVAL;
     if (tile == LOANS_TILE_STEM) {          // the dense RGB stem as a direct convolution (stem.hip)
         if (partial || splits > 1) return LOANS_EINVAL;
         return loans_stem7_bf16s_launch(in, w, out, bias, stats, d, st);
@@ -931,6 +949,14 @@ extern "C" int loans_igemm_bf16s(const void* in, const void* w, void* out, const
                                  const void* ref, const void* addend, const loans_igemm_desc* d, void* stream) {
     if (!out) return LOANS_EINVAL;
     return igemm_bf16s_impl(in, w, out, bias, stats, ref, addend, d, nullptr, 1, stream);
+}
+
+extern "C" int loans_igemm_pair_bf16s(const void* in, const void* w_ab, void* out_ab, double* stats_a, double* stats_b,
+                                      const loans_igemm_desc* d, void* stream) {
+    if (!d || !out_ab || d->Cout <= 0 || (d->Cout & 31)) return LOANS_EINVAL;
+    loans_igemm_desc d2 = *d;
+    d2.Cout = 2 * d->Cout;
+    return igemm_bf16s_impl(in, w_ab, out_ab, nullptr, stats_a, nullptr, nullptr, &d2, nullptr, 1, stream, stats_b, true);
 }
 
 extern "C" int loans_igemm_bf16s_splitk(const void* in, const void* w, float* partial, const loans_igemm_desc* d, int32_t splits,

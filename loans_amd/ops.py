@@ -555,11 +555,23 @@ def conv_fprop(x, w, geo, out=None, bias=None, stats=None, relu_in=False, addend
     return out
 
 
+# LOANS_PAIR16=0: the bf16-storage arm launches a unit's first conv and its conv shortcut separately again
+PAIR16 = os.environ.get('LOANS_PAIR16', '1') != '0'
+
+
 def fprop_pair_ok(x, geo_a, geo_b):
-    """conv_fprop_pair applies: fp32 tensors and arithmetic, same input / kernel / stride / padding, no dense rows"""
-    return (COMPUTE == 'f32' and not _is16(x) and not geo_a.dense and not geo_b.dense and
+    """conv_fprop_pair applies: same input / kernel / stride / padding, no dense rows; fp32 tensors and arithmetic
+    (loans_igemm_pair_f32: one grid, one tail) or bf16 storage with equal channel counts (loans_igemm_pair_bf16s: one GEMM
+    with the weights stacked along N, the input tile staged once for both)"""
+    same = (not geo_a.dense and not geo_b.dense and
             (geo_a.B, geo_a.H, geo_a.W, geo_a.Cin, geo_a.k, geo_a.stride, geo_a.pad) ==
             (geo_b.B, geo_b.H, geo_b.W, geo_b.Cin, geo_b.k, geo_b.stride, geo_b.pad))
+    if _is16(x):
+        # strided units only: at stride 1 each convolution runs faster alone on the halo-staged tiles (res2: 2 x 0.205 ms
+        # against 0.455 ms for the pair at 128 x 3 x 512^2)
+        return same and PAIR16 and geo_a.stride > 1 and geo_a.Cout == geo_b.Cout and geo_a.Cout % 32 == 0 and geo_a.Cin % 8 == 0 and \
+            2 * geo_a.B * geo_a.Ho * geo_a.Wo * geo_a.Cout * 2 < 0xFFFFFFF0
+    return same and COMPUTE == 'f32'
 
 
 _PAIR_TILES = tuple(t for t in _FPROP_TILES if (t & 15) not in (6, 8, 10))
@@ -570,6 +582,8 @@ def conv_fprop_pair(x, w_a, w_b, geo_a, geo_b, stats_a=None, stats_b=None, tile=
     a bottleneck's conv1 and conv4.  Returns (out_a, out_b); statistics for both or for neither."""
     lib = _lib.load()
     assert fprop_pair_ok(x, geo_a, geo_b) and (stats_a is None) == (stats_b is None)
+    if _is16(x):
+        return _conv_fprop_pair16(lib, x, w_a, w_b, geo_a, geo_b, stats_a, stats_b, tile)
     mk = lambda g: torch.empty((g.B, g.Ho, g.Wo, g.Cout), device=x.device, dtype=torch.float32)      # noqa: E731
     out_a, out_b = mk(geo_a), mk(geo_b)
     flags = F_STATS if stats_a is not None else 0
@@ -596,6 +610,45 @@ def conv_fprop_pair(x, w_a, w_b, geo_a, geo_b, stats_a=None, stats_b=None, tile=
         log.append(('fprop_bn' if flags else 'fprop', fl, ev0, ev1, 1, 2,         # one launch, two convolutions
                     _conv_bytes(geo_a, x, w_a, out_a) + _conv_bytes(geo_b, None, w_b, out_b)))
     return out_a, out_b
+
+
+_PAIR16_TILES = (1, 2, 3, 7)
+
+
+def _conv_fprop_pair16(lib, x, w_a, w_b, geo_a, geo_b, stats_a, stats_b, tile):
+    """the bf16-storage pair: weights cast into the two halves of one [2][Cout][K] matrix, outputs two views of one allocation"""
+    n = geo_a.w_numel
+    w_ab = torch.empty(2 * n, device=x.device, dtype=BF16)
+    for i, w in enumerate((w_a, w_b)):
+        assert w.numel() == n and not _is16(w)
+        check(lib.loans_cast_bf16(_ptr(w), _ptr(w_ab[i * n:]), n, _stream()), 'loans_cast_bf16')
+    flags = F_STATS if stats_a is not None else 0
+    mk = lambda: torch.empty((2, geo_a.B, geo_a.Ho, geo_a.Wo, geo_a.Cout), device=x.device, dtype=BF16)      # noqa: E731
+    if tile == 0:
+        sa = stats_buffer(geo_a.Cout, x.device) if flags else None
+        sb = stats_buffer(geo_a.Cout, x.device) if flags else None
+        scratch = mk()
+
+        def run(t):
+            check(lib.loans_igemm_pair_bf16s(_ptr(x), _ptr(w_ab), _ptr(scratch), _ptr(sa), _ptr(sb),
+                                             C.byref(_with_flags(geo_a.fwd, flags, t)), _stream()), 'loans_igemm_pair_bf16s[tune]')
+        tile = _tuned_tile(geo_a, 'bf16s_fprop_pair' + ('_stats' if flags else ''), run,
+                           _PAIR16_TILES + _wide16_tiles(2 * geo_a.Cout, geo_a.B * geo_a.Ho * geo_a.Wo))
+    out = mk()
+    _count_flops('fprop', geo_a)
+    _count_flops('fprop', geo_b)
+    log = EVENT_LOG
+    if log is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    check(lib.loans_igemm_pair_bf16s(_ptr(x), _ptr(w_ab), _ptr(out), _ptr(stats_a), _ptr(stats_b),
+                                     C.byref(_with_flags(geo_a.fwd, flags, tile)), _stream()), 'loans_igemm_pair_bf16s')
+    if log is not None:
+        ev1.record()
+        fl = 2 * geo_a.B * geo_a.Ho * geo_a.Wo * 2 * geo_a.Cout * geo_a.k * geo_a.k * geo_a.cin_logical
+        log.append(('fprop_bn' if flags else 'fprop', fl, ev0, ev1, 1, 2,         # one launch, two convolutions
+                    _conv_bytes(geo_a, x, w_ab[:n], out[0]) + _conv_bytes(geo_b, None, w_ab[n:], out[1])))
+    return out[0], out[1]
 
 
 def _conv_fprop16(lib, x, w, geo, out, bias, stats, relu_in, addend, tile):

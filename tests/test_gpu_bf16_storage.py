@@ -436,3 +436,40 @@ def test_stem_direct_bf16(case):
         assert (y_nb.float() - ref_nb).abs().max().item() <= 2.0 ** -8 * ref_nb.abs().max().item() + 1e-5
     finally:
         ops.set_compute_dtype('f32')
+
+
+@pytest.mark.parametrize("case", [(2, 64, 15, 13, 128, 3, 2, 1), (3, 128, 12, 12, 256, 3, 2, 1), (2, 64, 9, 9, 64, 1, 2, 0), (5, 32, 8, 8, 96, 3, 2, 1)])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 7, 9, 33, 35])
+def test_conv_pair_bf16_storage(case, tile):
+    """loans_igemm_pair_bf16s: a unit's first convolution and its conv shortcut as ONE GEMM with the weights stacked along N.
+    Every output element is contracted in the order of the single launch with the same tile, so the two tensors are
+    bit-identical to two loans_igemm_bf16s calls; the BN statistics agree to the fp64 atomics' summation order."""
+    from loans_amd import ops
+    B, Cin, H, W, Cout, k, s, p = case
+    rng = np.random.RandomState(11)
+    geo_a = ops.ConvGeometry(B, H, W, Cin, Cout, k, s, p)
+    geo_b = ops.ConvGeometry(B, H, W, Cin, Cout, k, s, p)
+    x = d16(rng.standard_normal((B, H, W, Cin)))
+    wa = dev((rng.standard_normal((Cout, k, k, Cin)) / np.sqrt(Cin * k * k)).astype(np.float32))
+    wb = dev((rng.standard_normal((Cout, k, k, Cin)) / np.sqrt(Cin * k * k)).astype(np.float32))
+    assert ops.fprop_pair_ok(x, geo_a, geo_b)
+    sa, sb = ops.stats_buffer(Cout, 'cuda'), ops.stats_buffer(Cout, 'cuda')
+    ya, yb = ops.conv_fprop_pair(x, wa, wb, geo_a, geo_b, sa, sb, tile=tile)
+    assert ya.dtype == torch.bfloat16 and ya.is_contiguous() and yb.is_contiguous()
+    if tile:
+        ra, rb = ops.stats_buffer(Cout, 'cuda'), ops.stats_buffer(Cout, 'cuda')
+        ea = ops.conv_fprop(x, wa, geo_a, stats=ra, tile=tile)
+        eb = ops.conv_fprop(x, wb, geo_b, stats=rb, tile=tile)
+        assert torch.equal(ya, ea) and torch.equal(yb, eb)
+        assert torch.allclose(sa.sum(0), ra.sum(0), rtol=1e-12, atol=1e-9) and torch.allclose(sb.sum(0), rb.sum(0), rtol=1e-12, atol=1e-9)
+    # against the oracle on the bf16-rounded operands
+    xr = x.float().cpu().numpy().transpose(0, 3, 1, 2).astype(np.float64)
+    for y, w, st in ((ya, wa, sa), (yb, wb, sb)):
+        wr = w.to(torch.bfloat16).float().cpu().numpy().transpose(0, 3, 1, 2).astype(np.float64)
+        y_ref, _ = C.conv2d_fwd(xr, wr, None, s, p)
+        y_ref = y_ref.transpose(0, 2, 3, 1)
+        err = np.abs(y.float().cpu().numpy() - y_ref)
+        assert (err <= 2.0 ** -8 * np.abs(y_ref) + 1e-5).all(), err.max()
+        np.testing.assert_allclose(st.sum(0)[0].cpu().numpy(), y_ref.sum(axis=(0, 1, 2)), rtol=1e-5, atol=2e-3)
+    y2a, y2b = ops.conv_fprop_pair(x, wa, wb, geo_a, geo_b, tile=tile)           # without statistics
+    assert torch.equal(y2a, ya) and torch.equal(y2b, yb)
