@@ -264,8 +264,9 @@ def main():
         peak = BF16_MFMA_PEAK_TFLOPS if args.dtype == 'bf16' else FP32_MFMA_PEAK_TFLOPS
         roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
                     "frac": round(achieved / peak, 4), "traffic": None,
-                    "kernel": "igemm_kernel + stem7_kernel (localizer conv forward: %d convs = %d launches per step)"
-                              % (sum(x[4] for x in loc) // args.steps, n_launch // args.steps),
+                    "kernel": "%s (localizer conv forward: %d convs = %d launches per step)"
+                              % ("igemm16_kernel + halo16 / ws8 kernels + stem7_bf16_kernel" if args.dtype == 'bf16' else
+                                 "igemm_kernel + stem7_kernel", sum(x[4] for x in loc) // args.steps, n_launch // args.steps),
                     "avg_launch_ms": round(tot_ms / max(n_launch, 1), 4),
                     "conv_fwd_ms_per_step": round(tot_ms / args.steps, 3),
                     "conv_fwd_ms_per_step_raw_brackets": round(raw_ms / args.steps, 3),

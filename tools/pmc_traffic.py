@@ -40,7 +40,7 @@ def main():
     write = 1024.0 * sum(float(r['Counter_Value']) for r in wr)
     per_kernel = {}
     for a, b in zip(fr, wr):
-        k = a['Kernel_Name'].split('(')[0][-60:]
+        k = a['Kernel_Name'].replace('(anonymous namespace)::', '').replace('void ', '').split('(')[0][:80]
         e = per_kernel.setdefault(k, [0, 0.0])
         e[0] += 1
         e[1] += 2.0 * 1024.0 * float(a['Counter_Value']) + 1024.0 * float(b['Counter_Value'])
