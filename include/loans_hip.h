@@ -117,6 +117,8 @@ typedef struct loans_igemm_desc {
 #define LOANS_TILE_HALO_128x64S 14 /* 8 x 16 pixels x 64 output channels, Cin = 64, single-buffered image: four blocks per CU */
 #define LOANS_TILE_WS64       15  /* 3x3 / 1, Cin = 64, Cout <= 64 (res2 and its data gradient): one persistent 512-thread block per CU, all
                                       nine taps' weights stationary in LDS, halo images double-buffered across 16 x 16 pixel tiles */
+#define LOANS_TILE_HALO_256x128 36 /* 16 x 16 pixels x 128 output channels in one 512-thread block per CU (eight 64 x 64 wave tiles): twice the
+                                      MFMA work per staged byte of LOANS_TILE_HALO_128 -- the N = 128 layers, too narrow for a 256-column tile */
 #define LOANS_TILE_HALO_256x64 12  /* 16 x 16 pixels x 64 output channels, Cin = 64 (one chunk): the res2 convolutions */
 #define LOANS_TILE_SPLITK(s) ((s) << 8) /* loans_igemm_f32, OR-ed onto a tile shape, s = 2..255: split-K for small grids (few tiles, long K:
                                   the deep layers at small batch, single-image inference).  Block (tile, i) contracts every s-th

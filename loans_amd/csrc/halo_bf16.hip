@@ -75,15 +75,17 @@ constexpr size_t halo_lds_bytes() { return halo_aux_bytes<TH, TW, BN, ADB>() + (
 
 // ADB: the A image is double-buffered across channel chunks (false: a single chunk, Cin = 64)
 template <int TH, int TW, int BN, int WM, int WN, bool ADB, bool RELU>
-__global__ __launch_bounds__(256) void halo16_kernel(const Halo16Args a) {
+__global__ __launch_bounds__(64 * WM * WN) void halo16_kernel(const Halo16Args a) {
+    constexpr int NW = WM * WN, NT = 64 * NW;             // 4 waves, or 8 for the 16 x 16 x 128 tile (one block per CU)
+    constexpr int RPP = NT / 8;                             // weight-tile rows staged per pass
     constexpr int BM = TH * TW;
     constexpr int TM = BM / WM / 32, TN = BN / WN / 32;
-    constexpr int RB = BN / 32;
+    constexpr int RB = BN / RPP;
     constexpr int NMMA = TM * TN;
     constexpr int APIECES = ((TH + 2) * (TW + 2) + 7) / 8;     // 1 KiB pieces (8 halo pixels x 128 B) of one A image
-    constexpr int APW = (APIECES + 3) / 4;                     // per wave
+    constexpr int APW = (APIECES + NW - 1) / NW;               // per wave
     constexpr int ABUF = APIECES * 8 * BKH;                    // elements per A buffer
-    static_assert(WM * WN == 4 && TM >= 1 && TN >= 1 && TW == 16, "tile shape");
+    static_assert((NW == 4 || NW == 8) && TM >= 1 && TN >= 1 && TW == 16 && RB >= 1, "tile shape");
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __bf16* As = reinterpret_cast<__bf16*>(smem);              // [ADB ? 2 : 1][APIECES * 8][64]
     __bf16* Bs = As + (ADB ? 2 : 1) * ABUF;                    // [2][BN][64]
@@ -100,7 +102,7 @@ __global__ __launch_bounds__(256) void halo16_kernel(const Halo16Args a) {
     const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int wave_u = __builtin_amdgcn_readfirstlane(wave);
 
-    for (int m = tid; m < BM; m += 256) {
+    for (int m = tid; m < BM; m += NT) {
         const int y = y0 + m / TW, x = x0 + m % TW;
         opix[m] = (y < d.outH && x < d.outW) ? (unsigned)((b * d.outH + y) * d.outW + x) * (unsigned)d.Cout * 2u : 0xFFFFFFFFu;
     }
@@ -109,12 +111,12 @@ __global__ __launch_bounds__(256) void halo16_kernel(const Halo16Args a) {
     const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.w), 0, (int)a.w_bytes, 0x00020000);
     typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
-    // ---- A image: piece pi = wave + 4 j holds halo pixels 8 pi .. 8 pi + 7; lane (pixel l >> 3, slot l & 7) fetches unit
+    // ---- A image: piece pi = wave + NW j holds halo pixels 8 pi .. 8 pi + 7; lane (pixel l >> 3, slot l & 7) fetches unit
     // slot ^ key(pixel) of its pixel.  The source offsets are fixed for the block (only the channel chunk moves).
     unsigned aoff[APW];
 #pragma unroll
     for (int j = 0; j < APW; ++j) {
-        const int pi = wave + 4 * j;
+        const int pi = wave + NW * j;
         const int q = pi * 8 + (lane >> 3);
         const int qy = q / a.HW, qx = q - qy * a.HW;
         const int iy = y0 + a.dymin + qy, ix = x0 + a.dxmin + qx;
@@ -123,21 +125,21 @@ __global__ __launch_bounds__(256) void halo16_kernel(const Halo16Args a) {
         aoff[j] = ok ? (unsigned)((b * d.inH + iy) * d.inW + ix) * (unsigned)d.Cin * 2u + (unsigned)unit * 16u : 0x80000000u;
     }
     auto dma_a = [&](int buf, int j, int cc) {
-        if (wave_u + 4 * j < APIECES)
-            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(As + buf * ABUF + (wave_u + 4 * j) * 8 * BKH), 16,
+        if (wave_u + NW * j < APIECES)
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(As + buf * ABUF + (wave_u + NW * j) * 8 * BKH), 16,
                                                      (int)(aoff[j] + (unsigned)cc * 128u), 0, 0, 0);
     };
-    // ---- B tile of a step: rows n = tn BN + 32 i + 8 wave + (lane >> 3), unit (lane & 7) ^ key(row); k = tap Cin + 64 cc
+    // ---- B tile of a step: rows n = tn BN + RPP i + 8 wave + (lane >> 3), unit (lane & 7) ^ key(row); k = tap Cin + 64 cc
     const int lrow = tid >> 3;
     const int lu = (tid & 7) ^ ((tid >> 4) & 7);
     unsigned woff[RB];
 #pragma unroll
     for (int i = 0; i < RB; ++i) {
-        const int n = tn * BN + lrow + 32 * i;
+        const int n = tn * BN + lrow + RPP * i;
         woff[i] = n < d.Cout ? (unsigned)n * (unsigned)a.Ktot * 2u + (unsigned)lu * 16u : 0x80000000u;
     }
     auto dma_b = [&](int buf, int i, unsigned kbytes) {
-        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(Bs + (buf * BN + 32 * i + 8 * wave_u) * BKH), 16,
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(Bs + (buf * BN + RPP * i + 8 * wave_u) * BKH), 16,
                                                  (int)(woff[i] + kbytes), 0, 0, 0);
     };
 
@@ -342,7 +344,7 @@ __global__ __launch_bounds__(256) void halo16_kernel(const Halo16Args a) {
     const __amdgpu_buffer_rsrc_t rs_add = __builtin_amdgcn_make_buffer_rsrc(
         const_cast<__bf16*>(a.addend ? a.addend : a.out), 0, (int)a.out_bytes, 0x00020000);
     constexpr int CPR = BN / 8;
-    constexpr int RSTEP = 256 / CPR;
+    constexpr int RSTEP = NT / CPR;
     const int oc8 = tid % CPR, r0 = tid / CPR;
     const int col0 = tn * BN + oc8 * 8;
     const unsigned cbad = (col0 + 7 < d.Cout) ? 0u : 0xFFFFFFFFu;
@@ -604,7 +606,7 @@ template <int TH, int TW, int BN, int WM, int WN, bool ADB, bool RELU>
 int launch_halo_r(Halo16Args& a, hipStream_t st) {
     static loans_device_once lds_limit_set;
     constexpr size_t lds = halo_lds_bytes<TH, TW, BN, ADB>();
-    static_assert(lds <= 80 * 1024, "two blocks per CU");
+    static_assert(WM * WN == 8 ? lds <= 156 * 1024 : lds <= 80 * 1024, "one 512-thread block or two 256-thread blocks per CU");
     auto kern = halo16_kernel<TH, TW, BN, WM, WN, ADB, RELU>;
     if (int rc_ = loans_raise_lds_limit(lds_limit_set, reinterpret_cast<const void*>(kern), lds)) return rc_;
     a.tiles_y = (a.d.outH + TH - 1) / TH;
@@ -614,7 +616,7 @@ int launch_halo_r(Halo16Args& a, hipStream_t st) {
     a.HW = TW + a.nx - 1;
     const int64_t nblk = (int64_t)a.d.B * a.tiles_y * a.tiles_x * a.tiles_n;
     if (nblk >= ((int64_t)1 << 31)) return LOANS_ERANGE;
-    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3((unsigned)nblk), dim3(64 * WM * WN), lds, st, a);
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;
 }
@@ -676,6 +678,7 @@ int loans_halo16_launch(const void* in, const void* w, void* out, const float* b
         case LOANS_TILE_HALO_128x64: return launch_halo<8, 16, 64, 4, 1, true>(a, st);
         case LOANS_TILE_HALO_256x64: return launch_halo<16, 16, 64, 4, 1, false>(a, st);
         case LOANS_TILE_HALO_128x64S: return launch_halo<8, 16, 64, 4, 1, false>(a, st);
+        case LOANS_TILE_HALO_256x128: return launch_halo<16, 16, 128, 4, 2, true>(a, st);      // 512 threads, one block per CU
         case LOANS_TILE_WS64: return a.nx == 3 && a.ny == 3 ? launch_ws8(a, st) : LOANS_EINVAL;
         default: return LOANS_EINVAL;
     }

@@ -281,6 +281,7 @@ _WGRAD16_TILES = (1, 3, 5)
 _IGEMM16_TILES = tuple(int(t) for t in os.environ.get('LOANS_BF16S_TILES', '1,2,3,4,7').split(','))
 # LOANS_TILE_HALO_* (csrc/halo_bf16.hip): stride-1 convolutions with the input tile staged once per 64-channel chunk
 TILE_HALO_128, TILE_HALO_256x64, TILE_HALO_128x64, TILE_HALO_128x64S, TILE_WS64 = 11, 12, 13, 14, 15
+TILE_HALO_256x128 = 36       # one 512-thread block per CU: 16 x 16 pixels x 128 output channels
 HALO = os.environ.get('LOANS_HALO', '1') != '0'
 
 
@@ -336,6 +337,8 @@ def _halo_tiles(geo, gathered_channels, out_channels, out_hw, relu_in=False):
     if not HALO or geo.dense or geo.stride != 1 or geo.k > 3 or gathered_channels % 64 or min(out_hw) < 6 or out_hw[1] < 12:
         return ()
     tiles = (TILE_HALO_128, TILE_HALO_128x64) if out_channels > 64 else (TILE_HALO_128x64,)
+    if out_channels > 64 and min(out_hw) >= 12:
+        tiles += (TILE_HALO_256x128,)
     if gathered_channels == 64 and out_channels <= 64:
         tiles += (TILE_HALO_128x64S,) + ((TILE_HALO_256x64,) if min(out_hw) >= 12 else ())
         if geo.k == 3 and geo.pad == 1 and not relu_in and min(out_hw) >= 12:

@@ -266,7 +266,7 @@ HALO_CASES = [
 
 
 @pytest.mark.parametrize("case", HALO_CASES)
-@pytest.mark.parametrize("tile", [11, 12, 13, 14, 15])
+@pytest.mark.parametrize("tile", [11, 12, 13, 14, 15, 36])
 def test_conv_halo_tiles_bf16_storage(case, tile):
     """LOANS_TILE_HALO_* (csrc/halo_bf16.hip): stride-1 convolutions and their data gradients with the input tile staged once
     per 64-channel chunk -- against the oracle on the bf16-rounded operands and against the implicit-GEMM tile (bit for bit
