@@ -200,7 +200,8 @@ int loans_igemm_bf16s(const void* in, const void* w, void* out, const float* bia
 int loans_igemm_pair_bf16s(const void* in, const void* w_ab, void* out_ab, double* stats_a, double* stats_b,
                            const loans_igemm_desc* d, void* stream);
 /* wgrad with bf16 x and gy, fp32 atomic accumulation into dw ("fp32 grad accumulate"); the pixel-major tiles are staged as
- * they lie and transposed by the fragment reads (ds_read_b64_tr_b16).  Tiles 128x128, 64x64, 64x128. */
+ * they lie and transposed by the fragment reads (ds_read_b64_tr_b16).  Tiles 128x128, 64x64, 64x128, and 256x256 (512 threads, one
+ * block per CU) for layers with >= 256 output channels. */
 int loans_wgrad_bf16s(const void* x, const void* gy, float* dw, const loans_igemm_desc* d, int32_t splits, void* stream);
 /* Split-K on bf16 storage for grids that cannot fill the machine (res6 / res7 at 512 px: 2048 - 8192 rows, K = 4608): block
  * (tile, s) contracts every `splits`-th slice of K and ADDS its raw fp32 tile to `partial` [B * outH * outW][Cout] (zeroed by the

@@ -639,13 +639,16 @@ struct Wgrad16Args {
 constexpr int WPC = 32;     // pixels (reduction rows) per staged chunk
 constexpr int WDEPTH = 4;   // register sets: global loads run WDEPTH - 1 chunks ahead of the chunk being computed
 
-template <int BCO, int BJ, bool RELU>   // BCO (output channels) x BJ (tap-channel columns) block tile, 4 waves as 2 x 2; RELU: relu(x)
-__global__ __launch_bounds__(256) void wgrad16_kernel(const Wgrad16Args a) {
+// BCO (output channels) x BJ (tap-channel columns) block tile on NWV waves: 4 as 2 x 2, or 8 as 2 x 4 (the 256 x 256 tile: one
+// 512-thread block per CU, twice the MFMA work per staged byte of 128 x 128); RELU: relu(x)
+template <int BCO, int BJ, int NWV, bool RELU>
+__global__ __launch_bounds__(64 * NWV) void wgrad16_kernel(const Wgrad16Args a) {
+    constexpr int WGM = 2, WGN = NWV / 2;           // wave grid
     static_assert(BCO <= BJ, "the loader's thread map follows the wider (X) tile");
     static_assert(WDEPTH % 2 == 0, "LDS stage = chunk parity = register-set parity");
-    constexpr int TM = BCO / 2 / 32, TN = BJ / 2 / 32;   // MFMA tiles per wave
+    constexpr int TM = BCO / WGM / 32, TN = BJ / WGN / 32;   // MFMA tiles per wave
     constexpr int UPR = BJ / 8;             // 16-byte units per X row (thread map); Y rows use the first BCO/8
-    constexpr int RPP = 256 / UPR;          // rows per loader pass
+    constexpr int RPP = 64 * NWV / UPR;     // rows per loader pass
     constexpr int NP = WPC / RPP;           // passes (rows per thread) per chunk
     constexpr int SY = BCO + 32, SX = BJ + 32;      // padded LDS row strides (elements)
     extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -756,7 +759,7 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const Wgrad16Args a) {
     // g >> 1) and channels 16*(g&1) .. +15 of its 32-wide MFMA tile; lane 4q + p of the group addresses pixel row q,
     // channels 4p .. 4p+3, and receives channel (lane & 15) of the four pixels
     const int wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
-    const int wm = wave >> 1, wn = wave & 1;
+    const int wm = wave / WGN, wn = wave % WGN;
     const int li = lane & 15, fq = li >> 2, fp = li & 3, cg = (lane >> 4) & 1;
     const int trY = (8 * h + fq) * SY + wm * TM * 32 + 16 * cg + 4 * fp;
     const int trX = (8 * h + fq) * SX + wn * TN * 32 + 16 * cg + 4 * fp;
@@ -820,11 +823,11 @@ __global__ __launch_bounds__(256) void wgrad16_kernel(const Wgrad16Args a) {
         }
 }
 
-template <int BCO, int BJ, bool RELU>
+template <int BCO, int BJ, int NWV, bool RELU>
 int launch_wgrad16_r(Wgrad16Args& a, int splits_req, hipStream_t st) {
     static loans_device_once lds_limit_set;       // per template instance = per kernel, one bit per device
     constexpr size_t lds = (size_t)2 * WPC * ((BCO + 32) + (BJ + 32)) * 2;
-    auto kern = wgrad16_kernel<BCO, BJ, RELU>;
+    auto kern = wgrad16_kernel<BCO, BJ, NWV, RELU>;
     if (int rc_ = loans_raise_lds_limit(lds_limit_set, reinterpret_cast<const void*>(kern), lds)) return rc_;
     a.tiles_co = (a.d.Cout + BCO - 1) / BCO;
     a.tiles_j = (a.Ktot + BJ - 1) / BJ;
@@ -840,14 +843,15 @@ int launch_wgrad16_r(Wgrad16Args& a, int splits_req, hipStream_t st) {
     if (splits > total_chunks) splits = total_chunks;
     a.chunks_per_split = (total_chunks + splits - 1) / splits;
     a.splits = (total_chunks + a.chunks_per_split - 1) / a.chunks_per_split;
-    hipLaunchKernelGGL(kern, dim3(a.tiles_co * a.tiles_j * a.splits), dim3(256), lds, st, a);
+    hipLaunchKernelGGL(kern, dim3(a.tiles_co * a.tiles_j * a.splits), dim3(64 * NWV), lds, st, a);
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;
 }
 
-template <int BCO, int BJ>
+template <int BCO, int BJ, int NWV = 4>
 int launch_wgrad16(Wgrad16Args& a, int splits_req, hipStream_t st) {
-    return (a.d.flags & LOANS_F_RELU_IN) ? launch_wgrad16_r<BCO, BJ, true>(a, splits_req, st) : launch_wgrad16_r<BCO, BJ, false>(a, splits_req, st);
+    return (a.d.flags & LOANS_F_RELU_IN) ? launch_wgrad16_r<BCO, BJ, NWV, true>(a, splits_req, st)
+                                         : launch_wgrad16_r<BCO, BJ, NWV, false>(a, splits_req, st);
 }
 
 }  // namespace
@@ -1133,6 +1137,7 @@ extern "C" int loans_wgrad_bf16s(const void* x, const void* gy, float* dw, const
     if (tile == LOANS_TILE_64x64) return launch_wgrad16<64, 64>(a, splits, st);
     if (tile == LOANS_TILE_128x128) return launch_wgrad16<128, 128>(a, splits, st);
     if (tile == LOANS_TILE_64x128) return launch_wgrad16<64, 128>(a, splits, st);
+    if (tile == LOANS_TILE_256x256) return launch_wgrad16<256, 256, 8>(a, splits, st);
     return LOANS_EINVAL;
 }
 

@@ -937,7 +937,7 @@ def conv_wgrad(x, gy, dw, geo, relu_in=False, splits=0, tile=0):
 
 
 _WGRAD_TILE_DIMS = {1: (128, 128, 2), 3: (64, 64, 4), 5: (64, 128, 3)}      # tile id -> (BCO, BJ, blocks per CU by LDS)
-_WGRAD16_TILE_DIMS = {1: (128, 128, 3), 3: (64, 64, 5), 5: (64, 128, 4)}    # bf16 tiles: smaller LDS images, register-bound
+_WGRAD16_TILE_DIMS = {1: (128, 128, 3), 3: (64, 64, 5), 5: (64, 128, 4), 9: (256, 256, 1)}    # bf16 tiles: smaller LDS images, register-bound
 
 
 def _wgrad_candidates(geo, tiles, chunk_px, dims=None):
@@ -980,6 +980,8 @@ def _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile):
             check(wfn(_ptr(x), _ptr(gy), _ptr(scratch), C.byref(_with_flags(geo.fwd, fl, t & 0xFF)), (t >> 8) or splits,
                       _stream()), 'loans_wgrad[tune]')
         cands = _WGRAD16_TILES if s16 else _WGRAD_TILES
+        if s16 and geo.Cout % 256 == 0:
+            cands = cands + (TILE_256x256,)         # one 512-thread block per CU (csrc/igemm_bf16.hip, wgrad16_kernel<256, 256, 8>)
         if splits == 0:
             cands = _wgrad_candidates(geo, cands, 32, _WGRAD16_TILE_DIMS if s16 else None)
         stem = stem_wgrad_ok(geo) and wfn is lib.loans_wgrad_f32 and fl == F_DENSE
