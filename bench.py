@@ -335,10 +335,14 @@ def main():
     if world > 1:
         std = hw == 224 and not args.resnet50 and args.dtype == 'f32'
         cfg_label = "configs[3]" if (std and B == 128) else ("configs[1] per GPU, data parallel" if (std and B == 256) else "custom")
+        if hw == 512 and B == 64 and args.resnet50 and args.dtype == 'bf16':
+            cfg_label = "configs[4]" if world == 8 else "configs[4] per GPU, data parallel"
     elif hw == 224 and B == 256 and not args.resnet50 and args.dtype == 'f32':
         cfg_label = "configs[1]"
     elif hw == 512 and B == 128 and not args.resnet50 and args.dtype == 'bf16':
         cfg_label = "configs[2]"
+    elif hw == 512 and B == 64 and args.resnet50 and args.dtype == 'bf16':
+        cfg_label = "configs[4] per GPU (64 of the global 512)"
     else:
         cfg_label = "custom"
     backbone = "ResNet-50" if args.resnet50 else "ResNet-18"
