@@ -36,4 +36,4 @@ if tot.get('GRBM_GUI_ACTIVE') and tot.get('SQ_VALU_MFMA_BUSY_CYCLES'):
     cycles = tot['GRBM_GUI_ACTIVE'] / xcds          # the counter is summed over the 8 XCDs
     print('GPU-active cycles of these launches: %.4g (GRBM_GUI_ACTIVE / %d XCDs)' % (cycles, xcds))
     print('MFMA pipe busy: %.1f %% of SIMD-cycles (SQ_VALU_MFMA_BUSY_CYCLES / (cycles x %d SIMDs); 64 busy cycles per '
-          'v_mfma_f32_32x32x2_f32)' % (100 * tot['SQ_VALU_MFMA_BUSY_CYCLES'] / (cycles * simds), simds))
+          'v_mfma_f32_32x32x2_f32, 32 per v_mfma_f32_32x32x16_bf16)' % (100 * tot['SQ_VALU_MFMA_BUSY_CYCLES'] / (cycles * simds), simds))
