@@ -119,6 +119,8 @@ typedef struct loans_igemm_desc {
                                       nine taps' weights stationary in LDS, halo images double-buffered across 16 x 16 pixel tiles */
 #define LOANS_TILE_HALO_256x128 36 /* 16 x 16 pixels x 128 output channels in one 512-thread block per CU (eight 64 x 64 wave tiles): twice the
                                       MFMA work per staged byte of LOANS_TILE_HALO_128 -- the N = 128 layers, too narrow for a 256-column tile */
+#define LOANS_TILE_WSW64      37  /* the same layers with the weights stationary and every WAVE on its own unit (2 rows x 16 pixels x 64 channels:
+                                      own halo image, own vmcnt, own staging slab): no block barrier after the weights have landed */
 #define LOANS_TILE_HALO_256x64 12  /* 16 x 16 pixels x 64 output channels, Cin = 64 (one chunk): the res2 convolutions */
 #define LOANS_TILE_SPLITK(s) ((s) << 8) /* loans_igemm_f32, OR-ed onto a tile shape, s = 2..255: split-K for small grids (few tiles, long K:
                                   the deep layers at small batch, single-image inference).  Block (tile, i) contracts every s-th

@@ -602,6 +602,220 @@ int launch_ws8(Halo16Args& a, hipStream_t st) {
     return LOANS_OK;
 }
 
+// ---- weights stationary, waves autonomous: LOANS_TILE_WSW64 ------------------------------------------------------------------
+// ws8_kernel's phases (image DMA, 72 MFMAs, statistics, staged epilogue) ADD: its eight waves work on one 16 x 16 tile and meet
+// at five barriers per tile, so nothing runs under the epilogue or under the wait for the next image (0.061 ms of skeleton +
+// 0.092 MFMA + 0.038 DMA + 0.042 epilogue per res2 convolution of configs[2]).  Here a WAVE owns its unit of work end to end --
+// 2 rows x 16 pixels of one image x all 64 output channels: it stages its own 4 x 18 pixel halo image (nine 1 KiB LDS-DMA
+// pieces into its own 9 KiB of LDS), waits on its own vmcnt, runs the same 72 MFMAs against the block's stationary weights,
+// transposes the result through its own image buffer (idle by then) and stores it.  No block barrier after the weights have
+// landed: the eight waves of a CU drift apart and one wave's DMA wait and epilogue lie under the other waves' MFMAs.  The
+// price is halo: 72 staged pixels per 32 outputs instead of 324 per 256 (served by L2: the waves of a block take eight
+// neighbouring units of a row pair, the blocks of an XCD neighbouring row pairs).  LDS: 72 KiB of weights + 8 x 9 KiB.
+constexpr int WSW_HW = 18, WSW_PIECES = 9, WSW_ABUF = WSW_PIECES * 8 * BKH;          // 4 x 18 = 72 halo pixels
+constexpr size_t wsw_lds_bytes() { return (size_t)W8_BELEMS * 2 + (size_t)8 * WSW_ABUF * 2; }
+
+__global__ __launch_bounds__(512, 1) void wsw_kernel(const Halo16Args a, int nunits, int units_y, int units_x) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    __bf16* Bl = reinterpret_cast<__bf16*>(smem);                       // [9][64 n][64 k], rows swizzled like a B tile
+    const loans_igemm_desc& d = a.d;
+    const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wave_u = __builtin_amdgcn_readfirstlane(wave);
+    __bf16* Aw = Bl + W8_BELEMS + wave_u * WSW_ABUF;                    // this wave's image / staging slab
+    const __amdgpu_buffer_rsrc_t rs_in = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.in), 0, (int)a.in_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_w = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(a.w), 0, (int)a.w_bytes, 0x00020000);
+    typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+    for (int pc = wave_u; pc < 72; pc += 8) {                           // all weights, once (as ws8_kernel)
+        const int t = pc >> 3, n = (pc & 7) * 8 + (lane >> 3);
+        const int unit = (lane & 7) ^ ((n >> 1) & 7);
+        const unsigned off = n < d.Cout ? (unsigned)n * (unsigned)a.Ktot * 2u + (unsigned)(t * 64) * 2u + (unsigned)unit * 16u : 0x80000000u;
+        __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_w, (lds_ptr_t)(Bl + pc * 8 * BKH), 16, (int)off, 0, 0, 0);
+    }
+    // the nine pieces of an image: piece j holds halo pixels 8 j .. 8 j + 7, lane (pixel l >> 3, slot l & 7) fetches unit
+    // slot ^ key(pixel) of its pixel
+    int pqy[WSW_PIECES], pqx[WSW_PIECES];
+#pragma unroll
+    for (int j = 0; j < WSW_PIECES; ++j) {
+        const int q = j * 8 + (lane >> 3);
+        pqy[j] = q / WSW_HW;
+        pqx[j] = (q - pqy[j] * WSW_HW) | ((((lane & 7) ^ ((q >> 1) & 7)) * 16) << 16);            // qx | unit bytes << 16
+    }
+    const int q0 = (r >> 4) * WSW_HW + (r & 15);                        // this lane's output pixel inside the halo image
+    const int fragB = r * BKH + ((h ^ ((r >> 1) & 7)) & 7) * 8;
+    const bool f_bias = d.flags & LOANS_F_BIAS, f_stats = d.flags & LOANS_F_STATS;
+    const bool f_mask = d.flags & LOANS_F_MASK, f_add = d.flags & LOANS_F_ADDEND, f_addmask = d.flags & LOANS_F_ADDEND_MASK;
+    const float bv0 = (f_bias && r < d.Cout) ? a.bias[r] : 0.f, bv1 = (f_bias && r + 32 < d.Cout) ? a.bias[r + 32] : 0.f;
+    double st_s0 = 0.0, st_q0 = 0.0, st_s1 = 0.0, st_q1 = 0.0;
+    const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)a.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_ref = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<__bf16*>(a.ref ? a.ref : a.out), 0, (int)a.out_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_add = __builtin_amdgcn_make_buffer_rsrc(
+        const_cast<__bf16*>(a.addend ? a.addend : a.out), 0, (int)a.out_bytes, 0x00020000);
+    constexpr int LDC = 64 + 4;
+    const int oc8 = lane & 7;                                           // epilogue: this lane's 8-channel unit
+    const unsigned cbad = (oc8 * 8 + 7 < d.Cout) ? 0u : 0xFFFFFFFFu;
+    f32x4 b_lo = {0.f, 0.f, 0.f, 0.f}, b_hi = b_lo;
+    if (f_bias && !cbad) {
+        b_lo = *reinterpret_cast<const f32x4*>(a.bias + oc8 * 8);
+        b_hi = *reinterpret_cast<const f32x4*>(a.bias + oc8 * 8 + 4);
+    }
+    auto keep_pos = [](f32x4 v, f32x4 m_) {
+        v.x = m_.x > 0.f ? v.x : 0.f; v.y = m_.y > 0.f ? v.y : 0.f;
+        v.z = m_.z > 0.f ? v.z : 0.f; v.w = m_.w > 0.f ? v.w : 0.f;
+        return v;
+    };
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                    // the weights are in LDS: the only block barrier of the kernel
+
+    // units in row-pair strips: the eight waves of a block take eight neighbouring units, the blocks of an XCD the strips next
+    // to each other (their halo rows overlap: L2 hits)
+    const int gw = xcd_remap_h(blockIdx.x, gridDim.x) * 8 + wave_u, nw = gridDim.x * 8;
+    const int per_img = units_y * units_x;
+    auto issue_image = [&](int u) {     // unit u's halo image into this wave's buffer
+        const int b = u / per_img, uu = u - b * per_img;
+        const int uy = uu / units_x, ux = uu - uy * units_x;
+        const int iy0 = 2 * uy + a.dymin, ix0 = 16 * ux + a.dxmin, base = b * d.inH;
+#pragma unroll
+        for (int j = 0; j < WSW_PIECES; ++j) {
+            const int iy = iy0 + pqy[j], ix = ix0 + (pqx[j] & 0xFFFF);
+            const bool ok = (unsigned)iy < (unsigned)d.inH && (unsigned)ix < (unsigned)d.inW;
+            const unsigned off = ok ? (unsigned)((base + iy) * d.inW + ix) * 128u + ((unsigned)pqx[j] >> 16) : 0x80000000u;
+            __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(Aw + j * 8 * BKH), 16, (int)off, 0, 0, 0);
+        }
+    };
+    // The next unit's image is requested as soon as this unit's staging slab (the same LDS) has been read out -- BEFORE this
+    // unit's output stores: at the top of the loop the wave then waits for its nine DMA pieces only, with a counted vmcnt that
+    // leaves the four younger stores in flight (vector memory operations retire in order).
+    if (gw < nunits) issue_image(gw);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    for (int u = gw; u < nunits; u += nw) {
+        const int b = u / per_img, uu = u - b * per_img;
+        const int uy = uu / units_x, ux = uu - uy * units_x;
+        const int y0 = 2 * uy, x0 = 16 * ux;
+        if (u != gw) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        f32x16 acc0, acc1;
+#pragma unroll
+        for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
+        auto frags = [&](int t, int s_, bf16x8_t& fa, bf16x8_t& f0, bf16x8_t& f1) {
+            const int tr = t / 3, tc = t - tr * 3;
+            const int q = q0 + (a.sdy > 0 ? tr : 2 - tr) * WSW_HW + (a.sdx > 0 ? tc : 2 - tc);
+            fa = *reinterpret_cast<const bf16x8_t*>(Aw + ((q * BKH + ((h ^ (q >> 1)) & 7) * 8) ^ (s_ * 16)));
+            const __bf16* bt = Bl + t * 64 * BKH + (fragB ^ (s_ * 16));
+            f0 = *reinterpret_cast<const bf16x8_t*>(bt);
+            f1 = *reinterpret_cast<const bf16x8_t*>(bt + 32 * BKH);
+        };
+        bf16x8_t fa, f0, f1, ga, g0, g1;
+        frags(0, 0, fa, f0, f1);
+#pragma unroll
+        for (int st = 0; st < 36; st += 2) {
+            frags((st + 1) >> 2, (st + 1) & 3, ga, g0, g1);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, f0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, f1, acc1, 0, 0, 0);
+            if (st + 2 < 36) frags((st + 2) >> 2, (st + 2) & 3, fa, f0, f1);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, g0, acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, g1, acc1, 0, 0, 0);
+        }
+        if (f_stats) {
+            float s0 = 0.f, q20 = 0.f, s1 = 0.f, q21 = 0.f;
+            int nvalid = 0;
+#pragma unroll
+            for (int e = 0; e < 16; ++e) {
+                const int m = (e & 3) + 8 * (e >> 2) + 4 * h;           // tile row of this accumulator element
+                const bool live = (y0 + (m >> 4) < d.outH) && (x0 + (m & 15) < d.outW);
+                const float v0 = live ? acc0[e] : 0.f, v1 = live ? acc1[e] : 0.f;
+                s0 += v0; q20 += v0 * v0;
+                s1 += v1; q21 += v1 * v1;
+                nvalid += (int)live;
+            }
+            const float cnt = (float)nvalid;
+            st_q0 += (double)(q20 + 2.f * bv0 * s0 + cnt * bv0 * bv0); st_s0 += (double)(s0 + cnt * bv0);
+            st_q1 += (double)(q21 + 2.f * bv1 * s1 + cnt * bv1 * bv1); st_s1 += (double)(s1 + cnt * bv1);
+        }
+        // the image has been read (this wave's LDS operations execute in order): it becomes the fp32 staging slab [32][LDC]
+        float* Cs = reinterpret_cast<float*>(Aw);
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+            float* cp = Cs + ((e & 3) + 8 * (e >> 2) + 4 * h) * LDC + r;
+            cp[0] = acc0[e];
+            cp[32] = acc1[e];
+        }
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+        __builtin_amdgcn_wave_barrier();
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        f32x4 lo[4], hi[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int px = it * 8 + (lane >> 3);
+            lo[it] = *reinterpret_cast<const f32x4*>(Cs + px * LDC + oc8 * 8) + b_lo;
+            hi[it] = *reinterpret_cast<const f32x4*>(Cs + px * LDC + oc8 * 8 + 4) + b_hi;
+        }
+        // the slab has been read out: the next unit's image may land in it
+        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+        __builtin_amdgcn_wave_barrier();
+        if (u + nw < nunits) issue_image(u + nw);
+        asm volatile("" ::: "memory");          // the stores below stay behind the DMA: the counted wait relies on it
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int px = it * 8 + (lane >> 3);
+            const int y = y0 + (px >> 4), x = x0 + (px & 15);
+            const bool pok = y < d.outH && x < d.outW;
+            const unsigned off = pok ? ((unsigned)((b * d.outH + y) * d.outW + x) * (unsigned)d.Cout * 2u + (unsigned)oc8 * 16u) | cbad : 0xFFFFFFFFu;
+            if (f_mask || f_addmask) {
+                const bf16x8_t rf = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_ref, (int)off, 0, 0));
+                const f32x4 rl = lo4(rf), rh = hi4(rf);
+                if (f_mask) { lo[it] = keep_pos(lo[it], rl); hi[it] = keep_pos(hi[it], rh); }
+                if (f_add) {
+                    const bf16x8_t ad = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_add, (int)off, 0, 0));
+                    f32x4 al = lo4(ad), ah = hi4(ad);
+                    if (f_addmask) { al = keep_pos(al, rl); ah = keep_pos(ah, rh); }
+                    lo[it] += al; hi[it] += ah;
+                }
+            } else if (f_add) {
+                const bf16x8_t ad = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_add, (int)off, 0, 0));
+                lo[it] += lo4(ad); hi[it] += hi4(ad);
+            }
+            bf16x8_t o;
+            const bf16x4_t ol = __builtin_convertvector(lo[it], bf16x4_t), oh = __builtin_convertvector(hi[it], bf16x4_t);
+            o[0] = ol[0]; o[1] = ol[1]; o[2] = ol[2]; o[3] = ol[3];
+            o[4] = oh[0]; o[5] = oh[1]; o[6] = oh[2]; o[7] = oh[3];
+            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_out, (int)off, 0, 0);
+        }
+    }
+    if (f_stats) {
+        st_s0 += __shfl_xor(st_s0, 32, 64); st_q0 += __shfl_xor(st_q0, 32, 64);
+        st_s1 += __shfl_xor(st_s1, 32, 64); st_q1 += __shfl_xor(st_q1, 32, 64);
+        if (h == 0) {
+            double* st = a.stats + (size_t)((blockIdx.x * 8 + wave) % LOANS_STATS_REPLICAS) * 2 * d.Cout;
+            if (r < d.Cout) { atomic_add_f64(st + r, st_s0); atomic_add_f64(st + d.Cout + r, st_q0); }
+            if (r + 32 < d.Cout) { atomic_add_f64(st + r + 32, st_s1); atomic_add_f64(st + d.Cout + r + 32, st_q1); }
+        }
+    }
+}
+
+int launch_wsw(Halo16Args& a, hipStream_t st) {
+    static loans_device_once lds_limit_set;
+    constexpr size_t lds = wsw_lds_bytes();
+    static_assert(lds <= 160 * 1024, "one block per CU");
+    static_assert((size_t)32 * (64 + 4) * 4 <= (size_t)WSW_ABUF * 2, "the staging slab fits the wave's image buffer");
+    if (int rc_ = loans_raise_lds_limit(lds_limit_set, reinterpret_cast<const void*>(wsw_kernel), lds)) return rc_;
+    const int units_y = (a.d.outH + 1) / 2, units_x = (a.d.outW + 15) / 16;
+    const int64_t nunits = (int64_t)a.d.B * units_y * units_x;
+    if (nunits >= ((int64_t)1 << 31)) return LOANS_ERANGE;
+    const int cus = loans_device_cus();
+    if (cus <= 0) return LOANS_EINVAL;
+    const int64_t blocks_needed = (nunits + 7) / 8;
+    const int64_t grid = blocks_needed < cus ? blocks_needed : cus;
+    hipLaunchKernelGGL(wsw_kernel, dim3((unsigned)grid), dim3(512), lds, st, a, (int)nunits, units_y, units_x);
+    LOANS_LAUNCH_CHECK();
+    return LOANS_OK;
+}
+
 template <int TH, int TW, int BN, int WM, int WN, bool ADB, bool RELU>
 int launch_halo_r(Halo16Args& a, hipStream_t st) {
     static loans_device_once lds_limit_set;
@@ -636,7 +850,7 @@ int loans_halo16_covers(const loans_igemm_desc* d, int tile) {
     if (d->gridH != d->outH || d->gridW != d->outW) return 0;
     if (d->Cin % 64 || d->ntaps > 9) return 0;
     if ((tile == LOANS_TILE_HALO_256x64 || tile == LOANS_TILE_HALO_128x64S) && d->Cin != 64) return 0;
-    if (tile == LOANS_TILE_WS64 && (d->Cin != 64 || d->Cout > 64 || d->ntaps != 9 || (d->flags & LOANS_F_RELU_IN))) return 0;
+    if ((tile == LOANS_TILE_WS64 || tile == LOANS_TILE_WSW64) && (d->Cin != 64 || d->Cout > 64 || d->ntaps != 9 || (d->flags & LOANS_F_RELU_IN))) return 0;
     int nx = 1;
     while (nx < d->ntaps && d->dy[nx] == d->dy[0]) ++nx;
     if (d->ntaps % nx) return 0;
@@ -680,6 +894,7 @@ int loans_halo16_launch(const void* in, const void* w, void* out, const float* b
         case LOANS_TILE_HALO_128x64S: return launch_halo<8, 16, 64, 4, 1, false>(a, st);
         case LOANS_TILE_HALO_256x128: return launch_halo<16, 16, 128, 4, 2, true>(a, st);      // 512 threads, one block per CU
         case LOANS_TILE_WS64: return a.nx == 3 && a.ny == 3 ? launch_ws8(a, st) : LOANS_EINVAL;
+        case LOANS_TILE_WSW64: return a.nx == 3 && a.ny == 3 ? launch_wsw(a, st) : LOANS_EINVAL;
         default: return LOANS_EINVAL;
     }
 }

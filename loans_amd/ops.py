@@ -282,6 +282,7 @@ _IGEMM16_TILES = tuple(int(t) for t in os.environ.get('LOANS_BF16S_TILES', '1,2,
 # LOANS_TILE_HALO_* (csrc/halo_bf16.hip): stride-1 convolutions with the input tile staged once per 64-channel chunk
 TILE_HALO_128, TILE_HALO_256x64, TILE_HALO_128x64, TILE_HALO_128x64S, TILE_WS64 = 11, 12, 13, 14, 15
 TILE_HALO_256x128 = 36       # one 512-thread block per CU: 16 x 16 pixels x 128 output channels
+TILE_WSW64 = 37              # weights stationary, every wave on its own 2 x 16 pixel unit (no block barriers)
 HALO = os.environ.get('LOANS_HALO', '1') != '0'
 
 
@@ -342,7 +343,7 @@ def _halo_tiles(geo, gathered_channels, out_channels, out_hw, relu_in=False):
     if gathered_channels == 64 and out_channels <= 64:
         tiles += (TILE_HALO_128x64S,) + ((TILE_HALO_256x64,) if min(out_hw) >= 12 else ())
         if geo.k == 3 and geo.pad == 1 and not relu_in and min(out_hw) >= 12:
-            tiles += (TILE_WS64,)
+            tiles += (TILE_WS64, TILE_WSW64)
     return tiles
 
 

@@ -266,17 +266,17 @@ HALO_CASES = [
 
 
 @pytest.mark.parametrize("case", HALO_CASES)
-@pytest.mark.parametrize("tile", [11, 12, 13, 14, 15, 36])
+@pytest.mark.parametrize("tile", [11, 12, 13, 14, 15, 36, 37])
 def test_conv_halo_tiles_bf16_storage(case, tile):
     """LOANS_TILE_HALO_* (csrc/halo_bf16.hip): stride-1 convolutions and their data gradients with the input tile staged once
     per 64-channel chunk -- against the oracle on the bf16-rounded operands and against the implicit-GEMM tile (bit for bit
     where K is one chunk per tap, Cin = 64; to the position of rare roundings otherwise), with every epilogue flag."""
     from loans_amd import ops
     B, Cin, H, W, Cout, k, p = case
-    if tile in (12, 14, 15) and Cin != 64:
+    if tile in (12, 14, 15, 37) and Cin != 64:
         pytest.skip('one-chunk (Cin = 64) forms')
-    if tile == 15 and (Cout > 64 or k != 3):
-        pytest.skip('LOANS_TILE_WS64: 3x3, Cin = 64, Cout <= 64')
+    if tile in (15, 37) and (Cout > 64 or k != 3):
+        pytest.skip('LOANS_TILE_WS64 / LOANS_TILE_WSW64: 3x3, Cin = 64, Cout <= 64')
     rng = np.random.RandomState(11)
     x = _r(rng.standard_normal((B, Cin, H, W)))
     w = (rng.standard_normal((Cout, Cin, k, k)) / np.sqrt(Cin * k * k)).astype(np.float32)
@@ -301,14 +301,14 @@ def test_conv_halo_tiles_bf16_storage(case, tile):
     np.testing.assert_allclose(s_h.sum(0).cpu().numpy(), s_g.sum(0).cpu().numpy(), rtol=1e-6, atol=1e-4)
     np.testing.assert_allclose(s_h.sum(0).cpu().numpy()[0], y_ref.sum(axis=(0, 2, 3)), rtol=1e-4, atol=1e-3)
     add = _r(rng.standard_normal(y_ref.shape))
-    relu_in = tile != 15                                  # the weight-stationary kernel has no pre-activation form
+    relu_in = tile not in (15, 37)                        # the weight-stationary kernels have no pre-activation form
     y3 = ops.conv_fprop(xd, wd, geo, relu_in=relu_in, addend=d16(_nhwc(add)), tile=tile)
     y3_ref = C.conv2d_fwd((np.maximum(x, 0) if relu_in else x).astype(np.float64), wr.astype(np.float64), None, 1, p)[0] + add
     assert rel_err(_nchw(y3), y3_ref) < BF16_EPS
     same(y3, ops.conv_fprop(xd, wd, geo, relu_in=relu_in, addend=d16(_nhwc(add)), tile=1), exact_f)
 
     # data gradient: the gathered tensor is gy (Cout channels), the "output channels" are Cin
-    if Cout % 64 or (tile in (12, 14, 15) and Cout != 64):
+    if Cout % 64 or (tile in (12, 14, 15, 37) and Cout != 64):
         return
     gy = _r(rng.standard_normal(y_ref.shape))
     gx_ref = C.conv2d_bwd(x.shape, col, wr.astype(np.float64), gy.astype(np.float64), 1, p, False)[0]
@@ -365,8 +365,9 @@ def test_conv_split_k_bf16_storage(case, tile):
     assert rel_err(_nchw(gx3), gx_ref + addx * (ref_t > 0)) < BF16_EPS
 
 
-def test_ws64_persistent_blocks_walk_many_tiles():
-    """LOANS_TILE_WS64 with more tiles than CUs: every block walks several tiles through its two image buffers; forward with
+@pytest.mark.parametrize("wtile", [15, 37])
+def test_ws64_persistent_blocks_walk_many_tiles(wtile):
+    """LOANS_TILE_WS64 / LOANS_TILE_WSW64 with more tiles than CUs (and, for the wave-autonomous form, more units than waves): every block walks several tiles through its two image buffers; forward with
     statistics and bias, data gradient with the masked-addend epilogue -- bit for bit the implicit GEMM's results (same K order
     at Cin = 64), statistics to fp64-summation accuracy."""
     from loans_amd import ops
@@ -377,16 +378,16 @@ def test_ws64_persistent_blocks_walk_many_tiles():
     w = torch.randn(64, 3, 3, 64, device='cuda', generator=g) * 0.05
     bias = torch.randn(64, device='cuda', generator=g)
     s1, s2 = ops.stats_buffer(64, 'cuda'), ops.stats_buffer(64, 'cuda')
-    y_ws = ops.conv_fprop(x, w, geo, bias=bias, stats=s1, tile=15)
+    y_ws = ops.conv_fprop(x, w, geo, bias=bias, stats=s1, tile=wtile)
     y_ig = ops.conv_fprop(x, w, geo, bias=bias, stats=s2, tile=1)
     assert torch.equal(y_ws, y_ig)
     np.testing.assert_allclose(s1.sum(0).cpu().numpy(), s2.sum(0).cpu().numpy(), rtol=1e-6, atol=1e-3)
     gy = torch.randn(B, H, W, 64, device='cuda', generator=g).to(torch.bfloat16)
     ref = torch.randn(B, H, W, 64, device='cuda', generator=g).to(torch.bfloat16)
     add = torch.randn(B, H, W, 64, device='cuda', generator=g).to(torch.bfloat16)
-    assert torch.equal(ops.conv_dgrad(gy, w, geo, addend=add, addend_mask_ref=ref, tile=15),
+    assert torch.equal(ops.conv_dgrad(gy, w, geo, addend=add, addend_mask_ref=ref, tile=wtile),
                        ops.conv_dgrad(gy, w, geo, addend=add, addend_mask_ref=ref, tile=1))
-    assert torch.equal(ops.conv_dgrad(gy, w, geo, mask_ref=ref, tile=15), ops.conv_dgrad(gy, w, geo, mask_ref=ref, tile=1))
+    assert torch.equal(ops.conv_dgrad(gy, w, geo, mask_ref=ref, tile=wtile), ops.conv_dgrad(gy, w, geo, mask_ref=ref, tile=1))
 
 
 @pytest.mark.parametrize("case", [(2, 32, 32), (3, 64, 64), (2, 96, 80), (1, 130, 66), (2, 224, 224), (1, 512, 512), (2, 50, 34), (1, 22, 30)])
