@@ -706,30 +706,39 @@ __global__ __launch_bounds__(512, 1) void wsw_kernel(const Halo16Args a, int nun
             f0 = *reinterpret_cast<const bf16x8_t*>(bt);
             f1 = *reinterpret_cast<const bf16x8_t*>(bt + 32 * BKH);
         };
-        bf16x8_t fa, f0, f1, ga, g0, g1;
-        frags(0, 0, fa, f0, f1);
+        // fragments run two steps ahead of the MFMAs (three register sets): with two waves per SIMD an LDS read issued one step
+        // (two MFMAs = 64 pipe cycles) ahead is not back in time
+        bf16x8_t fa[3], f0[3], f1[3];
+        frags(0, 0, fa[0], f0[0], f1[0]);
+        frags(0, 1, fa[1], f0[1], f1[1]);
 #pragma unroll
-        for (int st = 0; st < 36; st += 2) {
-            frags((st + 1) >> 2, (st + 1) & 3, ga, g0, g1);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, f0, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa, f1, acc1, 0, 0, 0);
-            if (st + 2 < 36) frags((st + 2) >> 2, (st + 2) & 3, fa, f0, f1);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, g0, acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ga, g1, acc1, 0, 0, 0);
+        for (int st = 0; st < 36; ++st) {
+            if (st + 2 < 36) frags((st + 2) >> 2, (st + 2) & 3, fa[(st + 2) % 3], f0[(st + 2) % 3], f1[(st + 2) % 3]);
+            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st % 3], f0[st % 3], acc0, 0, 0, 0);
+            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st % 3], f1[st % 3], acc1, 0, 0, 0);
         }
         if (f_stats) {
             float s0 = 0.f, q20 = 0.f, s1 = 0.f, q21 = 0.f;
-            int nvalid = 0;
+            float cnt = 16.f;
+            if (y0 + 2 <= d.outH && x0 + 16 <= d.outW) {                // a whole unit (wave-uniform): every element counts
 #pragma unroll
-            for (int e = 0; e < 16; ++e) {
-                const int m = (e & 3) + 8 * (e >> 2) + 4 * h;           // tile row of this accumulator element
-                const bool live = (y0 + (m >> 4) < d.outH) && (x0 + (m & 15) < d.outW);
-                const float v0 = live ? acc0[e] : 0.f, v1 = live ? acc1[e] : 0.f;
-                s0 += v0; q20 += v0 * v0;
-                s1 += v1; q21 += v1 * v1;
-                nvalid += (int)live;
+                for (int e = 0; e < 16; ++e) {
+                    s0 += acc0[e]; q20 += acc0[e] * acc0[e];
+                    s1 += acc1[e]; q21 += acc1[e] * acc1[e];
+                }
+            } else {
+                int nvalid = 0;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) {
+                    const int m = (e & 3) + 8 * (e >> 2) + 4 * h;       // tile row of this accumulator element
+                    const bool live = (y0 + (m >> 4) < d.outH) && (x0 + (m & 15) < d.outW);
+                    const float v0 = live ? acc0[e] : 0.f, v1 = live ? acc1[e] : 0.f;
+                    s0 += v0; q20 += v0 * v0;
+                    s1 += v1; q21 += v1 * v1;
+                    nvalid += (int)live;
+                }
+                cnt = (float)nvalid;
             }
-            const float cnt = (float)nvalid;
             st_q0 += (double)(q20 + 2.f * bv0 * s0 + cnt * bv0 * bv0); st_s0 += (double)(s0 + cnt * bv0);
             st_q1 += (double)(q21 + 2.f * bv1 * s1 + cnt * bv1 * bv1); st_s1 += (double)(s1 + cnt * bv1);
         }
