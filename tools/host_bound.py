@@ -1,10 +1,17 @@
+"""How far ahead of the GPU the host runs: time to ENQUEUE one joint step against the time the step takes.
+usage: host_bound.py B [frame size] [f32|bf16]"""
 import sys, os, time
 sys.path.insert(0, os.getcwd())
 import numpy as np, torch
 import loans_amd
 from loans_amd.datasets import synthetic
 from loans_amd.runtime import training
-B = int(sys.argv[1]); hw, crop = 224, 75
+B = int(sys.argv[1]); hw, crop = (int(sys.argv[2]) if len(sys.argv) > 2 else 224), 75
+dtype = sys.argv[3] if len(sys.argv) > 3 else 'f32'
+from loans_amd import ops
+if os.environ.get('LOANS_TUNE_FILE') is None and os.path.exists('profiles/r2_cfg3_tune.json') and dtype == 'bf16':
+    ops.load_tune_table('profiles/r2_cfg3_tune.json')
+ops.set_compute_dtype(dtype); ops.set_storage_dtype(dtype)
 dev = torch.device('cuda', 0)
 frames = torch.from_numpy(synthetic.make_frames(1, B, hw, hw)).to(dev)
 real, labels = synthetic.make_assessor_batch(2, B, crop, crop)
@@ -23,4 +30,4 @@ enq, tot = [], []
 for _ in range(10):
     t0 = time.perf_counter(); upd.update(); t1 = time.perf_counter(); torch.cuda.synchronize(); t2 = time.perf_counter()
     enq.append(t1 - t0); tot.append(t2 - t0)
-print('B=%d: host enqueue %.2f ms, step %.2f ms' % (B, np.median(enq) * 1e3, np.median(tot) * 1e3))
+print('B=%d %dpx %s: host enqueue %.2f ms, step %.2f ms' % (B, hw, dtype, np.median(enq) * 1e3, np.median(tot) * 1e3))
