@@ -171,6 +171,49 @@ def test_tile_selection_host_logic():
         ops.set_storage_dtype('bf16')            # bf16 storage needs the bf16 compute arm first
 
 
+def test_round2_tile_offers_host_logic():
+    """which of the round-2 kernel forms the autotuner is offered, from shapes alone (no GPU): the one-launch class form of a
+    strided fp32 data gradient, the 256-column / deep-ring / halo / weight-stationary tiles and the stacked pair of the bf16 arm,
+    the direct conv1 kernels -- each mirrors a launcher-side condition of csrc/*.hip that would answer LOANS_EINVAL"""
+    import torch
+    from loans_amd import ops
+    g32 = ops.ConvGeometry(4, 56, 56, 64, 128, 3, 2, 1)           # four parity classes, at most four taps each
+    g11 = ops.ConvGeometry(4, 56, 56, 64, 128, 1, 2, 0)           # 1x1 / 2: a single class with taps
+    g33 = ops.ConvGeometry(4, 57, 57, 64, 64, 3, 3, 1)            # stride 3: nine classes, more than the launcher takes
+    assert all(t & ops.TILE_CLASSES for t in ops._class_candidates(g32)) and len(ops._class_candidates(g32)) >= 4
+    assert ops._class_candidates(g11) == () and ops._class_candidates(g33) == ()
+    ops.set_compute_dtype('bf16')
+    try:
+        assert ops._class_candidates(g32) == ()                   # fp32 arm only
+    finally:
+        ops.set_compute_dtype('f32')
+    assert ops._wide16_tiles(512) == (ops.TILE_256x256,) and ops._wide16_tiles(128) == ()
+    deep = ops._wide16_tiles(512, rows=2048)                      # res7 at 512 px: 32 x 8 tiles of 64 x 64
+    assert set(deep) == {ops.TILE_256x256, 1 | ops.TILE_DEEP, 2 | ops.TILE_DEEP, 3 | ops.TILE_DEEP}
+    assert ops._wide16_tiles(512, rows=128 * 32 * 32) == (ops.TILE_256x256,)      # res4: a grid that fills the machine
+    res2 = ops.ConvGeometry(2, 128, 128, 64, 64, 3, 1, 1)
+    t = ops._halo_tiles(res2, 64, 64, (128, 128))
+    assert ops.TILE_WS64 in t and ops.TILE_WSW64 in t and ops.TILE_HALO_256x128 not in t
+    assert ops.TILE_WSW64 not in ops._halo_tiles(res2, 64, 64, (128, 128), relu_in=True)     # no pre-activation form
+    res3 = ops.ConvGeometry(2, 64, 64, 128, 128, 3, 1, 1)
+    assert ops.TILE_HALO_256x128 in ops._halo_tiles(res3, 128, 128, (64, 64)) and ops.TILE_WSW64 not in ops._halo_tiles(res3, 128, 128, (64, 64))
+    assert ops._halo_tiles(g32, 64, 128, (28, 28)) == ()          # strided: no halo form
+    x16, x32 = torch.zeros(1, dtype=torch.bfloat16), torch.zeros(1)
+    a, b = ops.ConvGeometry(2, 32, 32, 64, 128, 3, 2, 1), ops.ConvGeometry(2, 32, 32, 64, 128, 3, 2, 1)
+    assert ops.fprop_pair_ok(x16, a, b) and ops.fprop_pair_ok(x32, a, b)
+    s1a, s1b = ops.ConvGeometry(2, 32, 32, 64, 64, 3, 1, 1), ops.ConvGeometry(2, 32, 32, 64, 64, 3, 1, 1)
+    assert not ops.fprop_pair_ok(x16, s1a, s1b) and ops.fprop_pair_ok(x32, s1a, s1b)       # bf16: strided units only
+    assert not ops.fprop_pair_ok(x16, a, ops.ConvGeometry(2, 32, 32, 64, 256, 3, 2, 1))    # bf16: equal channel counts
+    stem224 = ops.ConvGeometry(2, 224, 224, 3, 64, 7, 2, 3, dense=True)
+    stem512 = ops.ConvGeometry(2, 512, 512, 3, 64, 7, 2, 3, dense=True)
+    assert ops.stem_tile_rows(stem224) == 4 and ops.stem16_tile_rows(stem224) == 4 and ops.stem16_tile_rows(stem512) == 4
+    assert ops.stem_wgrad_ok(stem224) and not ops.stem_wgrad_ok(stem512)          # two unit buffers of a 512 px row: 215 KB
+    odd = ops.ConvGeometry(1, 18, 23, 3, 64, 7, 2, 3, dense=True)            # 9 x 12 output pixels: no whole 64-pixel tile
+    assert ops.stem_tile_rows(odd) == 0 and ops.stem16_tile_rows(odd) == 1 and ops.stem_wgrad_ok(odd)
+    odd_rows = ops.ConvGeometry(1, 17, 23, 3, 64, 7, 2, 3, dense=True)       # an odd padded height: runs are not 16-byte aligned
+    assert ops.stem16_tile_rows(odd_rows) == 0 and not ops.stem_wgrad_ok(odd_rows)
+
+
 def test_launcher_state_is_per_device_and_capture_safe():
     """include/loans_hip.h promises: re-entrant, thread-safe given distinct streams, device = the caller's current device,
     no blocking runtime call.  So the launchers may keep no process-wide mutable state: what they cache (a kernel's raised
