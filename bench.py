@@ -11,6 +11,11 @@ per-GPU work is identical at every N so the driver's efficiency compares like wi
 all-reduced over RCCL; `--batch 128` gives configs[3] exactly (global 1024 at N=8).  Synthetic
 paste-and-crop frames, random-init weights; inputs are resident in HBM before timing.
 
+At N = 1 with the default workload the same process then measures the other single-GPU configurations of BASELINE.json as
+short SECONDARY legs -- configs[2] (bf16 storage arm, 128 x 3 x 512 x 512) and one GPU's share of configs[4] (ResNet-50
+localizer, bf16, 64 x 3 x 512 x 512) -- and reports them under "secondary" in the same line, each with its own roofline; the
+primary keys describe the fp32 leg alone (its timed region is closed before a secondary leg starts).
+
 Prints ONE JSON line (rank 0) with the contract keys plus
   roofline     : the ResNet-18 conv-forward MFMA roofline, measured live with HIP events
                  around the forward implicit-GEMM launches (21 convs) of every timed step
@@ -50,6 +55,7 @@ CONV_FWD_FLOP_PER_IMAGE_224 = 4166615040        # 21 conv contracti
 FP32_MFMA_PEAK_TFLOPS = 157.3                   # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32
 BF16_MFMA_PEAK_TFLOPS = 2500.0                  # MI355X_MICROARCH.md: dense bf16 MFMA (not the 2:1-sparsity figure)
 HBM_ACHIEVABLE_TBS = 6.3                        # MI355X_MICROARCH.md: what a streaming kernel reaches of the 8 TB/s spec
+HBM_READ_TBS, HBM_WRITE_TBS = 6.5, 4.6          # measured on this chip by tools/chip_peaks (profiles/r2_chip_peaks.txt): plain read / fill kernels
 
 
 def parse():
@@ -72,7 +78,16 @@ def parse():
                          "rocprofv3 passes of a command), else written by rank 0 after the run")
     ap.add_argument('--traffic-file', default=None,
                     help="PMC traffic summary (tools/pmc_traffic.py) of THIS command for roofline.traffic; default: "
-                         "profiles/r2_conv_fwd_hbm_traffic.json for the default workload, r2_cfg3_... for configs[2]")
+                         "profiles/<tag>_<b256|cfg3|r50>_conv_fwd_hbm_traffic.json of the newest committed round for those workloads")
+    ap.add_argument('--no-secondary', action='store_true',
+                    help="only the primary leg (the rocprofv3 passes of tools/profile_round.sh profile one workload per command)")
+    ap.add_argument('--secondary', default='cfg3,r50',
+                    help="secondary legs run after the default primary workload at N = 1: cfg3 = configs[2] (bf16, 128 x 3 x 512 x 512), "
+                         "r50 = one GPU's share of configs[4] (ResNet-50 localizer, bf16, 64 x 3 x 512 x 512)")
+    ap.add_argument('--secondary-steps', type=int, default=10)
+    ap.add_argument('--secondary-warmup', type=int, default=3)
+    ap.add_argument('--secondary-shape', default=None,
+                    help="B,HW: shrink the secondary legs and run them behind any primary workload (schema tests on tiny shapes)")
     ap.add_argument('--cpu-batch', type=int, default=8)
     ap.add_argument('--cpu-iters', type=int, default=2)
     return ap.parse_args()
@@ -146,39 +161,183 @@ def dry_run(args):
     parallel.shutdown()
 
 
-def main():
-    args = parse()
-    if os.environ.get('LOANS_BENCH_DRY') == '1':
-        return dry_run(args)
+PROFILE_TAGS = ('r3', 'r2')          # newest first: the committed rocprofv3 evidence a default workload is tied to
+
+# The workloads with committed evidence under profiles/ (<tag>_<name>_tune.json = the tile table the timed run, the kernel trace
+# and the PMC passes of tools/profile_round.sh all ran on; <tag>_<name>_conv_fwd_hbm_traffic.json = the PMC bytes)
+STD_WORKLOADS = {(224, 256, 'f32', 'f32', 75, False): 'b256',        # BASELINE configs[1] shape, the primary leg
+                 (512, 128, 'bf16', 'bf16', 75, False): 'cfg3',     # BASELINE configs[2]
+                 (512, 64, 'bf16', 'bf16', 75, True): 'r50'}        # BASELINE configs[4], one GPU's share (64 of 512)
+
+
+def _profile_file(name, kind):
+    for tag in PROFILE_TAGS:
+        tune = os.path.join(ROOT, 'profiles', '%s_%s_tune.json' % (tag, name))
+        if os.path.exists(tune):
+            path = os.path.join(ROOT, 'profiles', '%s_%s_%s.json' % (tag, name, kind))
+            return path if os.path.exists(path) else None
+    return None
+
+
+def workload_of(args, **over):
+    """the knobs of one leg: the command line's, or a secondary leg's overrides of them"""
+    from types import SimpleNamespace
+    w = SimpleNamespace(image_size=args.image_size, batch=args.batch or 256, dtype=args.dtype, storage=args.storage,
+                        resnet50=args.resnet50, target_size=args.target_size, steps=args.steps, warmup=args.warmup,
+                        graph=args.graph, tune_file=args.tune_file, traffic_file=args.traffic_file)
+    for k, v in over.items():
+        setattr(w, k, v)
+    w.storage = w.storage or ('bf16' if w.dtype == 'bf16' else 'f32')
+    return w
+
+
+def config_label(w, world):
+    hw, B = w.image_size, w.batch
+    std18 = hw == 224 and not w.resnet50 and w.dtype == 'f32'
+    r50 = hw == 512 and B == 64 and w.resnet50 and w.dtype == 'bf16'
+    if world > 1:
+        if r50:
+            return "configs[4]" if world == 8 else "configs[4] per GPU, data parallel"
+        return "configs[3]" if (std18 and B == 128) else ("configs[1] per GPU, data parallel" if (std18 and B == 256) else "custom")
+    if std18 and B == 256:
+        return "configs[1]"
+    if hw == 512 and B == 128 and not w.resnet50 and w.dtype == 'bf16':
+        return "configs[2]"
+    if r50:
+        return "configs[4] per GPU (64 of the global 512)"
+    return "custom"
+
+
+def conv_forward_roofline(w, log, flop_count, ev_overhead_ms, ms_per_step, world):
+    """`roofline` of one leg from the HIP events of its timed steps (ops.EVENT_LOG): the localizer's conv-forward launches
+    against the MFMA peak (`frac`), against the roofline that binds each launch (`binding`), the PMC bytes of the same
+    launches (`traffic`) and every convolution of the step against the same peak over the step's wall time (`whole_step`)."""
+    B, hw, steps = w.batch, w.image_size, w.steps
+    rows = []
+    for x in log:
+        x = tuple(x)
+        x = (x + (1, 1, (0, 0)))[:7] if len(x) < 7 else x          # (tag, flops, ev0, ev1, launches, convolutions, (read, written) bytes)
+        rows.append(x)
+    loc = [(tag, flops, max(s.elapsed_time(e) - ev_overhead_ms, 0.0), nl, nc, nb) for tag, flops, s, e, nl, nc, nb in rows if tag == 'fprop_bn']
+    raw_ms = sum(s.elapsed_time(e) for tag, flops, s, e, nl, nc, nb in rows if tag == 'fprop_bn')
+    tot_ms = sum(x[2] for x in loc)
+    tot_flop = sum(x[1] for x in loc)
+    n_launch = sum(x[3] for x in loc)          # a LOANS_TILE_SPLIT conv is two launches
+    achieved = tot_flop / (tot_ms * 1e-3) / 1e12
+    peak = BF16_MFMA_PEAK_TFLOPS if w.dtype == 'bf16' else FP32_MFMA_PEAK_TFLOPS
+    if w.dtype != 'bf16':
+        kernels = "igemm_kernel + stem7_kernel"
+    elif w.resnet50:
+        kernels = "igemm16_kernel (1x1 and 3x3) + halo16 kernels + stem7_bf16_kernel"
+    else:
+        kernels = "igemm16_kernel + halo16 / ws8 / wsw kernels + stem7_bf16_kernel"
+    roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4), "traffic": None,
+                "kernel": "%s (localizer conv forward: %d convs = %d launches per step)"
+                          % (kernels, sum(x[4] for x in loc) // steps, n_launch // steps),
+                "avg_launch_ms": round(tot_ms / max(n_launch, 1), 4),
+                "conv_fwd_ms_per_step": round(tot_ms / steps, 3),
+                "conv_fwd_ms_per_step_raw_brackets": round(raw_ms / steps, 3),
+                "event_pair_overhead_us": round(ev_overhead_ms * 1e3, 2),
+                "event_brackets_inside_timed_region": "%d pairs per step (~%.2f ms of ms_per_step)"
+                                                      % (len(rows) // steps, len(rows) / steps * ev_overhead_ms),
+                "algorithmic_flop_per_step": tot_flop // steps}
+    roofline["launches_per_step"] = n_launch // steps
+    # The same launches against the roofline that BINDS each of them: a layer cannot run faster than its algorithmic
+    # bytes at the achievable HBM rate, nor than its algorithmic FLOP at the MFMA peak.  In fp32 every layer is MFMA-bound
+    # (205 FLOP/B against a balance of 25); in bf16 the stem and res2 are HBM-bound (SURVEY 8d), so grading them against
+    # the MFMA peak alone would ask the impossible of them.  Two prices for the bytes: everything at the 6.3 TB/s a streaming
+    # kernel reaches (`frac`, rounds 1-2), and reads at 6.5 / writes at 4.6 TB/s -- what tools/chip_peaks measured on this chip
+    # for plain read / fill kernels (`frac_write_priced`; a conv whose bytes are mostly output is bound by the write rate).
+    per = {}
+    for tag, flops, ms, nl, nc, nb in loc:
+        e = per.setdefault((flops, tuple(nb)), [0, 0.0])
+        e[0] += 1
+        e[1] += ms
+    t_bound = t_bound_rw = t_meas = 0.0
+    n_hbm = 0
+    layers = []
+    for (flops, (rd, wr)), (cnt, ms) in sorted(per.items(), key=lambda kv: -kv[1][1]):
+        t_f = flops / (peak * 1e12) * 1e3
+        t_b = (rd + wr) / (HBM_ACHIEVABLE_TBS * 1e12) * 1e3
+        t_rw = rd / (HBM_READ_TBS * 1e12) * 1e3 + wr / (HBM_WRITE_TBS * 1e12) * 1e3
+        bound_ms, bound_rw = max(t_f, t_b), max(t_f, t_rw)
+        t_bound += bound_ms * cnt
+        t_bound_rw += bound_rw * cnt
+        t_meas += ms
+        n_hbm += cnt if t_b > t_f else 0
+        layer = {"gflop": round(flops / 1e9, 2), "mbytes": round((rd + wr) / 1e6, 1), "mbytes_written": round(wr / 1e6, 1),
+                 "calls_per_step": cnt // steps, "ms": round(ms / cnt, 4), "bound": "hbm" if t_b > t_f else "mfma",
+                 "bound_ms": round(bound_ms, 4), "frac": round(bound_ms * cnt / max(ms, 1e-9), 3),
+                 "frac_write_priced": round(bound_rw * cnt / max(ms, 1e-9), 3)}
+        # a launch cannot beat its own bound: a fraction above 1 means the byte or FLOP count is wrong, not that the kernel is
+        # fast (launches of a few microseconds, where the bracket correction is the measurement, are exempt: tiny test shapes)
+        if ms / cnt > 10 * ev_overhead_ms:
+            assert layer["frac"] <= 1.0 and layer["frac_write_priced"] <= 1.0, ("conv-forward layer above its roofline", layer)
+        layers.append(layer)
+    roofline["binding"] = {
+        "rule": "per launch max(algorithmic bytes / %.1f TB/s, algorithmic FLOP / %.0f TFLOP/s); algorithmic bytes = the input "
+                "pixels the taps address + weights + output, once each" % (HBM_ACHIEVABLE_TBS, peak),
+        "frac": round(t_bound / max(t_meas, 1e-9), 4), "bound_ms_per_step": round(t_bound / steps, 3),
+        "rule_write_priced": "reads at %.1f TB/s, writes at %.1f TB/s (tools/chip_peaks, profiles/r2_chip_peaks.txt)" % (HBM_READ_TBS, HBM_WRITE_TBS),
+        "frac_write_priced": round(t_bound_rw / max(t_meas, 1e-9), 4),
+        "hbm_bound_launches_per_step": n_hbm // steps, "layers": layers}
+    # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE, separate
+    # rocprofv3 runs of this same command on the SAME tile table, see --tune-file / tools/profile_round.sh).  The file
+    # carries the launch count of its own pass: bytes are divided by THAT, and a file whose pass launched other
+    # kernels than this run does not describe it -- traffic stays null then.
+    tpath = w.traffic_file
+    name = STD_WORKLOADS.get((hw, B, w.dtype, w.storage, w.target_size, w.resnet50))
+    if tpath is None and world == 1 and name:
+        tpath = _profile_file(name, 'conv_fwd_hbm_traffic')
+    if tpath and os.path.exists(tpath):
+        tf = json.load(open(tpath))
+        if int(tf["launches"]) == n_launch // steps:
+            roofline["traffic"] = round(tf["total_bytes_per_step"] / tf["launches"])
+            roofline["traffic_unit"] = "HBM bytes/launch (PMC: 2*FETCH_SIZE + WRITE_SIZE over the %d conv-forward launches of " \
+                                       "one step, %s)" % (tf["launches"], os.path.relpath(tpath, ROOT))
+            roofline["traffic_bytes_per_step"] = round(tf["total_bytes_per_step"])
+            alg = sum((rd + wr) * cnt for (flops, (rd, wr)), (cnt, ms) in per.items()) // steps
+            roofline["algorithmic_bytes_per_step"] = alg
+            roofline["traffic_over_algorithmic"] = round(tf["total_bytes_per_step"] / max(alg, 1), 3)
+        else:
+            roofline["traffic_note"] = "%s was taken on %d launches per step, this run has %d: not comparable" % (
+                os.path.relpath(tpath, ROOT), tf["launches"], n_launch // steps)
+    if hw == 224 and not w.resnet50:
+        assert tot_flop // steps == B * CONV_FWD_FLOP_PER_IMAGE_224, (tot_flop // steps, B)
+    # the whole step against the same peak: algorithmic FLOP of EVERY convolution launch (localizer and assessor;
+    # forward, data gradient, weight gradient) over the step's wall time -- what the three streams together sustain
+    if flop_count:
+        step_flop = sum(flop_count.values()) // steps
+        roofline["whole_step"] = {
+            "algorithmic_flop_per_step": step_flop,
+            "by_kind": {k: v // steps for k, v in sorted(flop_count.items())},
+            "achieved": round(step_flop / (ms_per_step * 1e-3) / 1e12, 2),
+            "frac": round(step_flop / (ms_per_step * 1e-3) / 1e12 / peak, 4)}
+    return roofline
+
+
+def run_workload(w, comm, local_rank, retune):
+    """One leg: build the models of workload `w`, W warm-up steps, exactly K timed steps between barrier + synchronize on
+    both sides, max over ranks.  Returns (rank 0) the dict of that leg: value, ms_per_step, config, roofline."""
     import loans_amd
     from loans_amd import ops, parallel
     from loans_amd.datasets import synthetic
     from loans_amd.runtime import training
 
-    tune_loaded = 0
-    if args.tune_file is None and os.environ.get('LOANS_BENCH_RETUNE') != '1':
-        # the two workloads whose rocprofv3 evidence is committed under profiles/ run on the tile table those passes used, so
-        # that the timed run, the trace and the PMC counters describe the SAME launches (LOANS_BENCH_RETUNE=1: tune afresh)
-        std = args.image_size, args.batch or 256, args.dtype, args.target_size, args.resnet50
-        name = {(224, 256, 'f32', 75, False): 'r2_b256_tune.json', (512, 128, 'bf16', 75, False): 'r2_cfg3_tune.json'}.get(std)
-        if name and args.storage in (None, 'bf16' if args.dtype == 'bf16' else 'f32') and os.path.exists(os.path.join(ROOT, 'profiles', name)):
-            args.tune_file = os.path.join(ROOT, 'profiles', name)
-    if args.tune_file and os.path.exists(args.tune_file):
-        tune_loaded = ops.load_tune_table(args.tune_file)
-    ops.set_compute_dtype(args.dtype)
-    storage = args.storage or ('bf16' if args.dtype == 'bf16' else 'f32')
-    ops.set_storage_dtype(storage)
-    comm = parallel.init_from_env()
     world, rank = comm.size, comm.rank
-    if world != args.gpus:
-        # `python bench.py --gpus N` forks its own ranks (top of this file); this is a rank started with a mismatching count
-        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
-    local_rank = int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count()
-    torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
-
-    B = args.batch or 256
-    hw, crop = args.image_size, args.target_size
+    B, hw, crop = w.batch, w.image_size, w.target_size
+    name = STD_WORKLOADS.get((hw, B, w.dtype, w.storage, crop, w.resnet50))
+    tune_loaded, tune_file = 0, w.tune_file
+    if tune_file is None and not retune and name:
+        # a workload whose rocprofv3 evidence is committed under profiles/ runs on the tile table those passes used, so that
+        # the timed run, the trace and the PMC counters describe the SAME launches (LOANS_BENCH_RETUNE=1: tune afresh)
+        tune_file = _profile_file(name, 'tune')
+    if tune_file and os.path.exists(tune_file):
+        tune_loaded = ops.load_tune_table(tune_file)
+    ops.set_compute_dtype(w.dtype)
+    ops.set_storage_dtype(w.storage)
 
     # ---- synthetic inputs, resident in HBM ----
     pool = 32
@@ -191,7 +350,7 @@ def main():
 
     # ---- models (random init; param_predictor.W seeded non-zero so the backbone gets gradients) ----
     np.random.seed(1234)
-    localizer = (loans_amd.Resnet50SheepLocalizer if args.resnet50 else loans_amd.SheepLocalizer)((crop, crop))
+    localizer = (loans_amd.Resnet50SheepLocalizer if w.resnet50 else loans_amd.SheepLocalizer)((crop, crop))
     localizer.param_predictor.W.set_logical(
         (1e-3 * np.random.standard_normal(localizer.param_predictor.W.logical_shape)).astype(np.float32))
     discriminator = loans_amd.ResnetAssessor()
@@ -208,12 +367,12 @@ def main():
         iterator={'main': training.DeviceBatchIterator([frames_d]),
                   'real': training.DeviceBatchIterator([(real_d, labels_d)])},
         optimizer={'opt_gen': opt_gen, 'opt_dis': opt_dis},
-        converter=training.identity_converter, device=local_rank, comm=comm, use_graph=args.graph)
+        converter=training.identity_converter, device=local_rank, comm=comm, use_graph=w.graph)
 
     # kernel-tile autotuning and lazily created links happen on the first step a shape is seen; with --warmup 0 that
     # one-off initialisation would land in the timed region, so it gets a step of its own (reported as init_steps)
-    init_steps = 1 if args.warmup == 0 else 0
-    for _ in range(init_steps + args.warmup):
+    init_steps = 1 if w.warmup == 0 else 0
+    for _ in range(init_steps + w.warmup):
         updater.update()
 
     # ---- timed region: exactly K steps between barrier + synchronize ----
@@ -222,7 +381,7 @@ def main():
     comm.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    for _ in range(w.steps):
         updater.update()
     torch.cuda.synchronize()
     comm.barrier()
@@ -244,123 +403,84 @@ def main():
         ev_overhead_ms = float(np.median(nulls))
 
     if rank != 0:
-        parallel.shutdown()
-        return
-    if args.tune_file and not tune_loaded:
-        ops.save_tune_table(args.tune_file)
-    ms_per_step = elapsed / args.steps * 1e3
-    value = B * world * args.steps / elapsed
-
-    # ---- conv-forward roofline from the events of the timed steps ----
-    roofline = None
-    if log:
-        log = [(tuple(x) + (1, 1, 0))[:7] if len(x) < 7 else tuple(x) for x in log]   # (tag, flops, ev0, ev1, launches, convolutions, bytes)
-        loc = [(tag, flops, max(s.elapsed_time(e) - ev_overhead_ms, 0.0), nl, nc, nb) for tag, flops, s, e, nl, nc, nb in log if tag == 'fprop_bn']
-        raw_ms = sum(s.elapsed_time(e) for tag, flops, s, e, nl, nc, nb in log if tag == 'fprop_bn')
-        tot_ms = sum(x[2] for x in loc)
-        tot_flop = sum(x[1] for x in loc)
-        n_launch = sum(x[3] for x in loc)          # a LOANS_TILE_SPLIT conv is two launches
-        achieved = tot_flop / (tot_ms * 1e-3) / 1e12
-        peak = BF16_MFMA_PEAK_TFLOPS if args.dtype == 'bf16' else FP32_MFMA_PEAK_TFLOPS
-        roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                    "frac": round(achieved / peak, 4), "traffic": None,
-                    "kernel": "%s (localizer conv forward: %d convs = %d launches per step)"
-                              % ("igemm16_kernel + halo16 / ws8 kernels + stem7_bf16_kernel" if args.dtype == 'bf16' else
-                                 "igemm_kernel + stem7_kernel", sum(x[4] for x in loc) // args.steps, n_launch // args.steps),
-                    "avg_launch_ms": round(tot_ms / max(n_launch, 1), 4),
-                    "conv_fwd_ms_per_step": round(tot_ms / args.steps, 3),
-                    "conv_fwd_ms_per_step_raw_brackets": round(raw_ms / args.steps, 3),
-                    "event_pair_overhead_us": round(ev_overhead_ms * 1e3, 2),
-                    "algorithmic_flop_per_step": tot_flop // args.steps}
-        roofline["launches_per_step"] = n_launch // args.steps
-        # The same launches against the roofline that BINDS each of them: a layer cannot run faster than its algorithmic
-        # bytes at the achievable HBM rate, nor than its algorithmic FLOP at the MFMA peak.  In fp32 every layer is MFMA-bound
-        # (205 FLOP/B against a balance of 25); in bf16 the stem and res2 are HBM-bound, so grading them against
-        # the MFMA peak alone would ask the impossible of them.
-        per = {}
-        for tag, flops, ms, nl, nc, nb in loc:
-            key = (flops, nb)
-            e = per.setdefault(key, [0, 0.0])
-            e[0] += 1
-            e[1] += ms
-        t_bound = t_meas = 0.0
-        n_hbm = 0
-        layers = []
-        for (flops, nb), (cnt, ms) in sorted(per.items(), key=lambda kv: -kv[1][1]):
-            t_f, t_b = flops / (peak * 1e12) * 1e3, nb / (HBM_ACHIEVABLE_TBS * 1e12) * 1e3
-            bound_ms = max(t_f, t_b)
-            calls = cnt
-            t_bound += bound_ms * calls
-            t_meas += ms
-            n_hbm += calls if t_b > t_f else 0
-            layers.append({"gflop": round(flops / 1e9, 2), "mbytes": round(nb / 1e6, 1), "calls_per_step": calls // args.steps,
-                           "ms": round(ms / calls, 4), "bound": "hbm" if t_b > t_f else "mfma", "bound_ms": round(bound_ms, 4),
-                           "frac": round(bound_ms * calls / ms, 3)})
-        roofline["binding"] = {
-            "rule": "per launch max(algorithmic bytes / %.1f TB/s, algorithmic FLOP / %.0f TFLOP/s)" % (HBM_ACHIEVABLE_TBS, peak),
-            "frac": round(t_bound / max(t_meas, 1e-9), 4), "bound_ms_per_step": round(t_bound / args.steps, 3),
-            "hbm_bound_launches_per_step": n_hbm // args.steps, "layers": layers}
-        # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE, separate
-        # rocprofv3 runs of this same command on the SAME tile table, see --tune-file / tools/profile_round.sh).  The file
-        # carries the launch count of its own pass: bytes are divided by THAT, and a file whose pass launched other
-        # kernels than this run does not describe it -- traffic stays null then.
-        tpath = args.traffic_file
-        if tpath is None and world == 1 and not args.resnet50 and crop == 75:
-            if hw == 224 and B == 256 and args.dtype == 'f32':
-                tpath = os.path.join(ROOT, 'profiles', 'r2_conv_fwd_hbm_traffic.json')
-            elif hw == 512 and B == 128 and args.dtype == 'bf16' and storage == 'bf16':
-                tpath = os.path.join(ROOT, 'profiles', 'r2_cfg3_conv_fwd_hbm_traffic.json')
-        if tpath and os.path.exists(tpath):
-            tf = json.load(open(tpath))
-            if int(tf["launches"]) == n_launch // args.steps:
-                roofline["traffic"] = round(tf["total_bytes_per_step"] / tf["launches"])
-                roofline["traffic_unit"] = "HBM bytes/launch (PMC: 2*FETCH_SIZE + WRITE_SIZE over the %d conv-forward launches of " \
-                                           "one step, %s)" % (tf["launches"], os.path.relpath(tpath, ROOT))
-                roofline["traffic_bytes_per_step"] = round(tf["total_bytes_per_step"])
-            else:
-                roofline["traffic_note"] = "%s was taken on %d launches per step, this run has %d: not comparable" % (
-                    os.path.relpath(tpath, ROOT), tf["launches"], n_launch // args.steps)
-        if hw == 224 and not args.resnet50:
-            assert tot_flop // args.steps == B * CONV_FWD_FLOP_PER_IMAGE_224, (tot_flop // args.steps, B)
-        # the whole step against the same peak: algorithmic FLOP of EVERY convolution launch (localizer and assessor;
-        # forward, data gradient, weight gradient) over the step's wall time -- what the three streams together sustain
-        if flop_count:
-            step_flop = sum(flop_count.values()) // args.steps
-            roofline["whole_step"] = {
-                "algorithmic_flop_per_step": step_flop,
-                "by_kind": {k: v // args.steps for k, v in sorted(flop_count.items())},
-                "achieved": round(step_flop / (ms_per_step * 1e-3) / 1e12, 2),
-                "frac": round(step_flop / (ms_per_step * 1e-3) / 1e12 / peak, 4)}
-
-    if world > 1:
-        std = hw == 224 and not args.resnet50 and args.dtype == 'f32'
-        cfg_label = "configs[3]" if (std and B == 128) else ("configs[1] per GPU, data parallel" if (std and B == 256) else "custom")
-        if hw == 512 and B == 64 and args.resnet50 and args.dtype == 'bf16':
-            cfg_label = "configs[4]" if world == 8 else "configs[4] per GPU, data parallel"
-    elif hw == 224 and B == 256 and not args.resnet50 and args.dtype == 'f32':
-        cfg_label = "configs[1]"
-    elif hw == 512 and B == 128 and not args.resnet50 and args.dtype == 'bf16':
-        cfg_label = "configs[2]"
-    elif hw == 512 and B == 64 and args.resnet50 and args.dtype == 'bf16':
-        cfg_label = "configs[4] per GPU (64 of the global 512)"
-    else:
-        cfg_label = "custom"
-    backbone = "ResNet-50" if args.resnet50 else "ResNet-18"
-    out = {
-        "metric": "localizer+assessor train images/sec", "value": round(value, 2), "unit": "images/s",
-        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        return None
+    if w.tune_file and not tune_loaded:
+        ops.save_tune_table(w.tune_file)
+    ms_per_step = elapsed / w.steps * 1e3
+    value = B * world * w.steps / elapsed
+    roofline = conv_forward_roofline(w, log, flop_count, ev_overhead_ms, ms_per_step, world) if log else None
+    backbone = "ResNet-50" if w.resnet50 else "ResNet-18"
+    return {
+        "value": round(value, 2), "unit": "images/s", "steps": w.steps, "warmup": w.warmup, "ms_per_step": round(ms_per_step, 3),
+        "dtype": w.dtype,
         "config": {"workload": "LoANs joint step: %s localizer + STN crop + assessor, fwd+bwd+2xAdam-AMSGrad" % backbone,
                    "per_gpu_batch": B, "global_batch": B * world, "frame": "3x%dx%d" % (hw, hw),
                    "crop": "3x%dx%d" % (crop, crop), "parallelism": "dp%d" % world, "world_size": world, "dist_backend": comm.backend,
-                   "baseline_config": cfg_label, "hip_graph": bool(args.graph), "init_steps": init_steps,
-                   "activation_storage": storage,
-                   "tune_table": ("read %d shapes from %s" % (tune_loaded, os.path.relpath(args.tune_file, ROOT))) if tune_loaded
+                   "baseline_config": config_label(w, world), "hip_graph": bool(w.graph), "init_steps": init_steps,
+                   "activation_storage": w.storage,
+                   "tune_table": ("read %d shapes from %s" % (tune_loaded, os.path.relpath(tune_file, ROOT))) if tune_loaded
                    else "autotuned in this run"},
         "roofline": roofline,
     }
+
+
+def secondary_legs(args):
+    """The other single-GPU configurations of BASELINE.json, measured in the same process after the primary leg so that the
+    driver's one bench line carries them: configs[2] (bf16 joint step, 128 x 3 x 512 x 512) and one GPU's share of configs[4]
+    (ResNet-50 localizer, bf16, 64 x 3 x 512 x 512).  --secondary-shape B,HW shrinks both (schema tests on tiny shapes)."""
+    legs = [("configs[2]", dict(image_size=512, batch=128, dtype='bf16', storage='bf16', resnet50=False)),
+            ("configs[4] per GPU", dict(image_size=512, batch=64, dtype='bf16', storage='bf16', resnet50=True))]
+    want = [s for s in args.secondary.split(',') if s]
+    legs = [l for l, key in zip(legs, ('cfg3', 'r50')) if key in want]
+    for _, over in legs:
+        over.update(steps=args.secondary_steps, warmup=args.secondary_warmup, graph=False, tune_file=None, traffic_file=None)
+        if args.secondary_shape:
+            b, hw = (int(v) for v in args.secondary_shape.split(','))
+            over.update(batch=b, image_size=hw)
+    return legs
+
+
+def main():
+    args = parse()
+    if os.environ.get('LOANS_BENCH_DRY') == '1':
+        return dry_run(args)
+    import gc
+    from loans_amd import parallel
+
+    retune = os.environ.get('LOANS_BENCH_RETUNE') == '1'
+    comm = parallel.init_from_env()
+    world, rank = comm.size, comm.rank
+    if world != args.gpus:
+        # `python bench.py --gpus N` forks its own ranks (top of this file); this is a rank started with a mismatching count
+        raise SystemExit('--gpus %d but WORLD_SIZE=%d' % (args.gpus, world))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count()
+    torch.cuda.set_device(local_rank)
+
+    primary_w = workload_of(args)
+    primary = run_workload(primary_w, comm, local_rank, retune)
+    secondary = {}
+    is_default = STD_WORKLOADS.get((primary_w.image_size, primary_w.batch, primary_w.dtype, primary_w.storage,
+                                    primary_w.target_size, primary_w.resnet50)) == 'b256' and not primary_w.graph
+    if world == 1 and (is_default or args.secondary_shape) and not args.no_secondary:
+        for label, over in secondary_legs(args):
+            gc.collect()
+            torch.cuda.empty_cache()
+            leg = run_workload(workload_of(args, **over), comm, local_rank, retune)
+            leg["metric"] = "localizer+assessor train images/sec"
+            secondary[label] = leg
+    if rank != 0:
+        parallel.shutdown()
+        return
+    out = {
+        "metric": "localizer+assessor train images/sec", "value": primary["value"], "unit": "images/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": primary["ms_per_step"],
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": primary["config"], "roofline": primary["roofline"],
+    }
+    if secondary:
+        out["secondary"] = secondary
     if world == 1 and not args.no_cpu_baseline and not args.resnet50 and args.dtype == 'f32':
-        out["cpu_baseline"] = cpu_baseline(args, hw, crop)
+        out["cpu_baseline"] = cpu_baseline(args, args.image_size, args.target_size)
     print(json.dumps(out), flush=True)
     parallel.shutdown()
 

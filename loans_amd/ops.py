@@ -70,11 +70,29 @@ EVENT_LOG = None
 FLOP_COUNT = None
 
 
+def _addressed(size, out, k, stride, pad):
+    """input rows (columns) that at least one tap of one output position addresses: all of them once k >= stride, every
+    stride-th one for a strided 1x1"""
+    if k >= stride:
+        return size
+    return len({o * stride + r - pad for o in range(out) for r in range(k)} & set(range(size)))
+
+
 def _conv_bytes(geo, x, w, out):
-    """ALGORITHMIC HBM bytes of one forward convolution: its input, its weights and its output once each, in the types they
-    are stored in (x = None: the input is shared with a convolution already counted)"""
-    n = 0 if x is None else x.numel() * x.element_size()
-    return n + w.numel() * w.element_size() + out.numel() * out.element_size()
+    """ALGORITHMIC HBM bytes of one forward convolution as (read, written): the input pixels its taps address (a stride-2 1x1
+    reads a quarter of its input tensor), its weights and its output once each, in the types they are stored in (x = None:
+    the input is shared with a convolution already counted)"""
+    n = 0
+    if x is not None:
+        n = x.numel() * x.element_size()
+        if not geo.dense and geo.k < geo.stride:
+            n = n * _addressed(geo.H, geo.Ho, geo.k, geo.stride, geo.pad) * _addressed(geo.W, geo.Wo, geo.k, geo.stride, geo.pad) \
+                // (geo.H * geo.W)
+    return n + w.numel() * w.element_size(), out.numel() * out.element_size()
+
+
+def _sum_bytes(a, b):
+    return a[0] + b[0], a[1] + b[1]
 
 
 def _count_flops(kind, geo):
@@ -122,24 +140,46 @@ def _tune_key_str(key):
     return ','.join(str(int(v)) for v in key)
 
 
+# Tile ids are this library's: bump when an id changes meaning, so that tables written by an older build are not launched as-is
+TUNE_SCHEMA = 3
+_TUNE_LOADED = {}        # shape key -> {mode: tile} read from a file: a proposal, accepted per use if the tile is on offer (_tuned_tile)
+
+
+def _tune_stamp():
+    """what a table's timings were taken on: entries are only trusted on the same chip and tile-id schema"""
+    if not torch.cuda.is_available():
+        return {"device": None, "compute_units": 0, "schema": TUNE_SCHEMA}
+    p = torch.cuda.get_device_properties(torch.cuda.current_device())
+    return {"device": p.name, "compute_units": int(p.multi_processor_count), "schema": TUNE_SCHEMA}
+
+
 def save_tune_table(path):
     import json
     table = {_tune_key_str(k): dict(v) for k, v in sorted(_TUNE_CACHE.items()) if v}
     with open(path, 'w') as f:
         json.dump({"what": "loans_amd tile table: (B,H,W,Cin,Cout,k,stride,pad,dense) -> {mode: tile id | splits << 8 | class launch << 16}",
-                   "entries": table}, f, indent=1, sort_keys=True)
+                   "stamp": _tune_stamp(), "entries": table}, f, indent=1, sort_keys=True)
     return len(table)
 
 
 def load_tune_table(path):
-    """Merge a saved table into the cache (entries tuned in this process win).  Returns the number of shapes read."""
+    """Read a saved table as PROPOSALS (entries tuned in this process win; a proposed tile is launched only if the current
+    candidate list of its problem still offers it -- an ablation switch, another library revision or another chip retunes
+    instead of launching a stale id).  A table stamped for another device / CU count / tile-id schema is ignored.  Returns
+    the number of shapes read."""
     import json
     with open(path) as f:
-        table = json.load(f)["entries"]
+        doc = json.load(f)
+    stamp = doc.get("stamp")
+    if stamp is not None and stamp != _tune_stamp():
+        return 0
+    if stamp is None and doc.get("entries") and TUNE_SCHEMA > 2:
+        return 0                    # a table from before the stamps (rounds 1-2): mode keys and tile offers have changed since
+    table = doc["entries"]
     for ks, modes in table.items():
         key = tuple(int(v) for v in ks.split(','))
         key = key[:-1] + (bool(key[-1]),)
-        cur = _TUNE_CACHE.setdefault(key, {})
+        cur = _TUNE_LOADED.setdefault(key, {})
         for mode, tile in modes.items():
             cur.setdefault(mode, int(tile))
     return len(table)
@@ -162,7 +202,8 @@ class ConvGeometry:
         self.base_flags = 0
         self.cin_logical = 3 if Cin == 4 else Cin
         # tile choices are a property of the problem shape, not of the layer: equal convs share one table
-        self.tuned = _TUNE_CACHE.setdefault((B, H, W, Cin, Cout, k, stride, pad, dense), {})
+        self.key = (B, H, W, Cin, Cout, k, stride, pad, dense)
+        self.tuned = _TUNE_CACHE.setdefault(self.key, {})
         if dense:
             self._init_dense()
             return
@@ -370,6 +411,10 @@ def _tuned_tile(geo, mode, run, candidates):
         return 0
     if COMPUTE == 'bf16':
         candidates = [t for t in candidates if not (t & 16)]
+    tile = _TUNE_LOADED.get(geo.key, {}).get(mode)
+    if tile is not None and tile in candidates:         # a file's proposal, still on offer for this problem
+        geo.tuned[mode] = tile
+        return tile
     times = {t: _time_call(lambda: run(t)) for t in candidates}
     tile = min(times, key=times.get)
     geo.tuned[mode] = tile
@@ -612,7 +657,7 @@ def conv_fprop_pair(x, w_a, w_b, geo_a, geo_b, stats_a=None, stats_b=None, tile=
         ev1.record()
         fl = 2 * geo_a.B * geo_a.Ho * geo_a.Wo * (geo_a.Cout + geo_b.Cout) * geo_a.k * geo_a.k * geo_a.cin_logical
         log.append(('fprop_bn' if flags else 'fprop', fl, ev0, ev1, 1, 2,         # one launch, two convolutions
-                    _conv_bytes(geo_a, x, w_a, out_a) + _conv_bytes(geo_b, None, w_b, out_b)))
+                    _sum_bytes(_conv_bytes(geo_a, x, w_a, out_a), _conv_bytes(geo_b, None, w_b, out_b))))
     return out_a, out_b
 
 
@@ -651,7 +696,7 @@ def _conv_fprop_pair16(lib, x, w_a, w_b, geo_a, geo_b, stats_a, stats_b, tile):
         ev1.record()
         fl = 2 * geo_a.B * geo_a.Ho * geo_a.Wo * 2 * geo_a.Cout * geo_a.k * geo_a.k * geo_a.cin_logical
         log.append(('fprop_bn' if flags else 'fprop', fl, ev0, ev1, 1, 2,         # one launch, two convolutions
-                    _conv_bytes(geo_a, x, w_ab[:n], out[0]) + _conv_bytes(geo_b, None, w_ab[n:], out[1])))
+                    _sum_bytes(_conv_bytes(geo_a, x, w_ab[:n], out[0]), _conv_bytes(geo_b, None, w_ab[n:], out[1]))))
     return out[0], out[1]
 
 
@@ -808,7 +853,8 @@ def conv_dgrad(gy, w, geo, out=None, mask_ref=None, addend=None, addend_mask_ref
             for d, _, off in geo.dgrad:
                 check(_igemm_fn(lib)(_ptr(gy), _ptr(wp[off:]), _ptr(scratch), 0, 0, 0, 0,
                                      C.byref(_with_flags(d, 0, t)), st), 'loans_igemm[tune]')
-        cands, key = _IGEMM_TILES + _class_candidates(geo), COMPUTE + 'dgrad'
+        cl = _class_candidates(geo)
+        cands, key = _IGEMM_TILES + cl, COMPUTE + 'dgrad' + ('_cl' if cl else '')
         if not inplace_masked and reduce_channels_ok(geo.Cin):
             # the smallest class grid decides: (Ho x Wo pixels of one parity class) x Cin columns, K = its taps x Cout
             cls_rows = geo.B * geo.dgrad[0][0].gridH * geo.dgrad[0][0].gridW

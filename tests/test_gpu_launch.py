@@ -41,6 +41,28 @@ def test_bench_single_process():
     assert out['n_gpus'] == 1 and out['config']['dist_backend'] is None and out['value'] > 0
 
 
+def test_bench_secondary_legs_schema():
+    """The driver's one bench line carries the other single-GPU configurations as `secondary` legs (configs[2]: bf16 joint
+    step; configs[4] per GPU: ResNet-50 localizer, bf16), each with its own roofline -- here on tiny shapes (2 x 3 x 320 x 320:
+    res6 and res7 active) behind a tiny primary leg; the primary keys stay those of the fp32 leg."""
+    out = _one_line(_run('bench.py', ['--gpus', '1', '--secondary-shape', '2,320', '--secondary-steps', '2',
+                                      '--secondary-warmup', '1'] + TINY))
+    assert out['dtype'] == 'f32' and out['config']['activation_storage'] == 'f32' and out['config']['frame'] == '3x64x64'
+    sec = out['secondary']
+    assert sorted(sec) == ['configs[2]', 'configs[4] per GPU']
+    for name, leg in sec.items():
+        assert leg['dtype'] == 'bf16' and leg['config']['activation_storage'] == 'bf16' and leg['config']['frame'] == '3x320x320'
+        assert leg['config']['per_gpu_batch'] == 2 and leg['steps'] == 2 and leg['unit'] == 'images/s'
+        assert leg['value'] > 0 and abs(leg['value'] - 2 * 1e3 / leg['ms_per_step']) < 1e-2 * leg['value']
+        r = leg['roofline']
+        assert r['bound'] == 'mfma' and r['peak'] == 2500.0 and 0 < r['frac'] < 1 and 'traffic' in r
+        assert 0 < r['binding']['frac'] and 0 < r['binding']['frac_write_priced'] and r['binding']['layers']
+        assert 0 < r['whole_step']['frac'] < 1 and set(r['whole_step']['by_kind']) == {'dgrad', 'fprop', 'wgrad'}
+    assert 'ResNet-50' in sec['configs[4] per GPU']['config']['workload'] and 'ResNet-18' in sec['configs[2]']['config']['workload']
+    # 31 convolutions of the ResNet-18 variant at 320 px (res6 + res7), 53 + 10 of the ResNet-50 localizer
+    assert '31 convs' in sec['configs[2]']['roofline']['kernel']
+
+
 def test_trainer_two_ranks_through_the_launcher(tmp_path):
     r = _run('train_sheep_localizer.py', ['--gpus', '2', '--use-resnet-18', '-b', '2', '--image-size', '64', '64',
                                           '--target-size', '16', '16', '--iterations', '3', '--dataset-size', '8',

@@ -235,9 +235,12 @@ def test_launcher_state_is_per_device_and_capture_safe():
         assert src.count('hipFuncSetAttribute') == 0, name          # only through loans_raise_lds_limit (per device)
 
 
-def test_tune_table_round_trip(tmp_path):
+def test_tune_table_round_trip(tmp_path, monkeypatch):
     """A normal run writes its tile table, the profiled runs of the same command read it: same kernels in both
-    (ops.save_tune_table / load_tune_table, bench.py --tune-file)."""
+    (ops.save_tune_table / load_tune_table, bench.py --tune-file).  What a file holds is a PROPOSAL: it is launched only if
+    the problem's current candidate list still offers that tile (ablation switches, another library revision), and only on
+    the chip / tile-id schema the table was stamped with."""
+    import json
     from loans_amd import ops
     g = ops.ConvGeometry(3, 20, 24, 8, 16, 3, 1, 1)
     gd = ops.ConvGeometry(3, 32, 32, 3, 64, 7, 2, 3, dense=True)
@@ -245,13 +248,30 @@ def test_tune_table_round_trip(tmp_path):
     gd.tuned['f32fprop_stats_st'] = 10
     path = str(tmp_path / 'tune.json')
     assert ops.save_tune_table(path) >= 2
-    g.tuned.clear(); gd.tuned.clear()
+    assert json.load(open(path))['stamp']['schema'] == ops.TUNE_SCHEMA
+    g.tuned.clear(); gd.tuned.clear(); ops._TUNE_LOADED.clear()
     assert ops.load_tune_table(path) >= 2
-    assert g.tuned == {'f32fprop_stats': 19, 'f32wgrad': 3 | (7 << 8)} and gd.tuned == {'f32fprop_stats_st': 10}
+    assert g.tuned == {} and ops._TUNE_LOADED[g.key] == {'f32fprop_stats': 19, 'f32wgrad': 3 | (7 << 8)}
+    ran = []
+    monkeypatch.setattr(ops, '_time_call', lambda fn, reps=5: (fn(), float(len(ran)))[1])
+    run = ran.append
+    # on offer: taken without timing anything
+    assert ops._tuned_tile(g, 'f32fprop_stats', run, (1, 2, 19)) == 19 and not ran
+    assert ops._tuned_tile(gd, 'f32fprop_stats_st', run, (1, 10)) == 10 and not ran
+    # not on offer any more (an ablation switch removed the tile): tuned afresh among the candidates
+    assert ops._tuned_tile(g, 'f32wgrad', run, (1, 3)) == 1 and ran == [1, 3]
     g2 = ops.ConvGeometry(3, 20, 24, 8, 16, 3, 1, 1)                  # a geometry made later shares the entry
-    assert g2.tuned is g.tuned
-    g.tuned['f32dgrad'] = 2                                           # entries tuned in this process win over the file
-    g.tuned['f32fprop_stats'] = 1
+    assert g2.tuned is g.tuned and g2.tuned['f32fprop_stats'] == 19
+    g.tuned['f32fprop_stats'] = 1                                     # entries tuned in this process win over the file
     ops.load_tune_table(path)
-    assert g.tuned['f32fprop_stats'] == 1 and g.tuned['f32dgrad'] == 2
+    assert ops._tuned_tile(g, 'f32fprop_stats', run, (1, 2, 19)) == 1
+    # a table stamped for another chip, and one from before the stamps, are ignored
+    doc = json.load(open(path))
+    doc['stamp']['compute_units'] = 7
+    json.dump(doc, open(path, 'w'))
+    ops._TUNE_LOADED.clear()
+    assert ops.load_tune_table(path) == 0 and not ops._TUNE_LOADED
+    del doc['stamp']
+    json.dump(doc, open(path, 'w'))
+    assert ops.load_tune_table(path) == 0 and not ops._TUNE_LOADED
     g.tuned.clear(); gd.tuned.clear()
