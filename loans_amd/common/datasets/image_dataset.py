@@ -95,14 +95,17 @@ class ImageDataset:
         from .augment import sample_params
         return sample_params(self._aug_rng, image_chw.shape[-2], image_chw.shape[-1], self.transform_probability)
 
-    def _decoded(self, i, imgaug_rows=False):
-        """Decode + augmentation (reference :76-90): CHW in the dataset's dtype, values 0..255.  ``imgaug_rows``: return the
-        imgaug branch's parameter rows beside the un-augmented frame instead of applying them (device_batch applies them on
-        the GPU)."""
+    def _read(self, i):
+        """decode only (no random draws: safe to run on a pool thread): CHW in the dataset's dtype, values 0..255, 3 channels"""
         image = _read_image_as_array(os.path.join(self._root, self._paths[i]), self._dtype)
         if image.shape[0] == 1:
             image = numpy.tile(image, (3, 1, 1))
-        image = image[:3]
+        return image[:3]
+
+    def _augment(self, image, imgaug_rows=False):
+        """the augmentation of one decoded example (reference :76-90); every random draw of an example happens here, so the
+        order of the calls alone fixes the streams.  ``imgaug_rows``: return the imgaug branch's parameter rows beside the
+        un-augmented frame instead of applying them (finish_batch applies them on the GPU)."""
         rows = self._imgaug_rows(image)
         if rows is not None:
             if imgaug_rows:
@@ -119,30 +122,93 @@ class ImageDataset:
             image = random_flip(image, x_random=True)
         return (image, rows) if imgaug_rows else image
 
-    def get_example(self, i):
-        image = self._decoded(i)
+    def _decoded(self, i, imgaug_rows=False):
+        """Decode + augmentation (reference :76-90): CHW in the dataset's dtype, values 0..255."""
+        return self._augment(self._read(i), imgaug_rows)
+
+    def _finish(self, image):
+        """resize + ``/ 255`` of one augmented example (reference :92-98); no random draws"""
         if self.image_size is not None:
             image = resize_image(image, self.image_size, image_mode=self.image_mode)
         if len(image.shape) == 2:
             image = image[None, ...]
         return numpy.ascontiguousarray(image / 255, dtype=numpy.float32)
 
+    def get_example(self, i):
+        return self._finish(self._decoded(i))
+
+    def get_examples(self, indices, map_fn=map):
+        """``[get_example(i) for i in indices]`` with decode and resize spread over ``map_fn`` (a thread pool's ``map``) and the
+        random draws in between taken one example after the other in index order: the same bytes whatever the pool size"""
+        images = list(map_fn(self._read, list(indices)))
+        return list(map_fn(self._finish, [self._augment(image) for image in images]))
+
     def get_raw_example(self, i):
         """The frame as it stands before ``resize_image``: uint8 HWC RGB (what ``Image.fromarray(...astype('uint8'))``
         sees at reference :20).  ``device_batch`` finishes the example on the GPU."""
         return numpy.ascontiguousarray(self._decoded(i).transpose(1, 2, 0).astype(numpy.uint8))
 
-    def device_batch(self, indices, device):
-        """``concat_examples([self.get_example(i) for i in indices])`` with the LANCZOS resize, ``/ 255`` and the CHW
-        layout done on the GPU (bit-identical, see resample.py): uint8 frames cross PCIe, not float32 ones."""
-        from .resample import frames_to_device
+    def _read_u8(self, i):
+        """decode only, straight to what the GPU stages take: uint8 HWC RGB (no float round trip, no transposes -- the
+        values ``_read`` + ``astype('uint8')`` give for 8-bit files); None for anything else (16-bit, float files), which goes
+        through ``_read``"""
+        with Image.open(os.path.join(self._root, self._paths[i])) as f:
+            image = numpy.asarray(f)
+        if image.dtype != numpy.uint8:
+            return None
+        if image.ndim == 2:
+            return numpy.repeat(image[:, :, None], 3, axis=2)
+        if image.shape[2] == 1:
+            return numpy.repeat(image, 3, axis=2)
+        return image[:, :, :3] if image.shape[2] >= 3 else None
+
+    def _augment_u8(self, image):
+        """``_augment(..., imgaug_rows=True)`` on a uint8 HWC frame: the same draws in the same order"""
+        rows = self._imgaug_rows(image.transpose(2, 0, 1))
+        if rows is not None:
+            return image, rows
+        if not self.use_imgaug and random.random() < self.transform_probability:
+            if self.crop_always or random.random() <= 0.5:
+                crop_ratio = random.uniform(self.min_crop_ratio, self.max_crop_ratio)
+                image = random_crop(image.transpose(2, 0, 1), tuple([int(size * crop_ratio) for size in image.shape[:2]])).transpose(1, 2, 0)
+            image = random_flip(image.transpose(2, 0, 1), x_random=True).transpose(1, 2, 0)
+        return image, [[0] * 8] * 3
+
+    def decode_batch(self, indices, map_fn=map, farm=None):
+        """Host half of ``device_batch``: the frames of a batch as uint8 HWC RGB arrays (as ``Image.fromarray(...astype('uint8'))``
+        sees them at reference :20) with the imgaug branch's parameter rows beside them.  ``map_fn`` decodes (a thread pool's
+        ``map``: PIL releases the GIL while it inflates); the random draws are taken afterwards, one example after the other in
+        index order, so a pooled batch consumes the streams exactly like ``[get_example(i) for i in indices]``."""
         if self.image_mode != 'RGB' or self.image_size is None:
             raise ValueError('device_batch covers the training configuration: RGB frames resized to image_size')
-        if self.use_imgaug and self.transform_probability > 0:
-            pairs = [self._decoded(i, imgaug_rows=True) for i in indices]
-            frames = [numpy.ascontiguousarray(im.transpose(1, 2, 0).astype(numpy.uint8)) for im, _ in pairs]
-            return frames_to_device(frames, self.image_size, device, augment_rows=[r for _, r in pairs])
-        return frames_to_device([self.get_raw_example(i) for i in indices], self.image_size, device)
+        indices = list(indices)
+        if farm is not None:        # decode processes (decode_farm.py): Pillow's decoders hold the GIL, threads do not scale
+            images = farm.decode([os.path.join(self._root, self._paths[i]) for i in indices], map_fn)
+        else:
+            images = list(map_fn(self._read_u8, indices))
+        frames, rows = [], []
+        for i, image in zip(indices, images):
+            if image is None or isinstance(image, int):          # not an 8-bit file, or unreadable (the read raises here)
+                image, r = self._augment(self._read(i), imgaug_rows=True)
+                image = image.transpose(1, 2, 0).astype(numpy.uint8)
+            else:
+                image, r = self._augment_u8(image)
+            frames.append(image)                      # possibly a strided view (crop / flip): frames_to_device copies it once
+            rows.append(r)
+        return frames, (rows if self.use_imgaug and self.transform_probability > 0 else None)
+
+    def finish_batch(self, decoded, device, map_fn=map):
+        """Device half: upload the uint8 frames, run the imgaug stages, the LANCZOS resize, ``/ 255`` and the CHW layout on the
+        GPU (resample.py / augment.py, the bytes of the host path).  ``map_fn`` spreads the copies into the pinned staging
+        buffer over a pool."""
+        from .resample import frames_to_device
+        frames, rows = decoded
+        return frames_to_device(frames, self.image_size, device, augment_rows=rows, map_fn=map_fn)
+
+    def device_batch(self, indices, device, map_fn=map):
+        """``concat_examples([self.get_example(i) for i in indices])`` with the LANCZOS resize, ``/ 255`` and the CHW
+        layout done on the GPU (bit-identical, see resample.py): uint8 frames cross PCIe, not float32 ones."""
+        return self.finish_batch(self.decode_batch(indices, map_fn), device, map_fn)
 
 
 class LabeledImageDataset:

@@ -138,26 +138,71 @@ def resize_lanczos(frames_u8, out_hw, as_float=True, filt='lanczos'):
     return out
 
 
-def frames_to_device(images, out_hw, device, augment_rows=None):
+class _Staging:
+    """Pinned host buffers for the uint8 upload, re-used from batch to batch (``pin_memory()`` of a fresh 200 MB tensor per
+    batch cost more than the upload itself).  Two buffers per calling thread take turns; each carries the event of the last
+    copy that read it, and is only overwritten once that copy has finished."""
+
+    def __init__(self):
+        self.slots = {}
+
+    def get(self, nbytes):
+        import threading
+        key = threading.get_ident()
+        ring = self.slots.setdefault(key, {'i': 0, 'bufs': [None, None], 'events': [None, None]})
+        i = ring['i'] = (ring['i'] + 1) % 2
+        if ring['events'][i] is not None:
+            ring['events'][i].synchronize()
+        buf = ring['bufs'][i]
+        if buf is None or buf.numel() < nbytes:
+            buf = ring['bufs'][i] = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8).pin_memory()
+        return ring, i, buf
+
+
+_staging = _Staging()
+
+
+def frames_to_device(images, out_hw, device, augment_rows=None, map_fn=map):
     """``[ImageDataset.get_example(i) for i in batch]`` for decoded frames: a list of uint8 HWC RGB arrays of any sizes
     -> one device batch [N][3][oh][ow] float32 in [0,1], in input order.  Frames of equal size are uploaded (pinned,
-    asynchronous) and resized together."""
+    asynchronous, ONE copy for all groups) and resized together; ``map_fn`` (a thread pool's ``map``) spreads the copies into
+    the staging buffer."""
     device = torch.device(device)
-    out = torch.empty((len(images), 3, int(out_hw[0]), int(out_hw[1])), device=device, dtype=torch.float32)
     groups = {}
     for i, im in enumerate(images):
-        im = np.asarray(im)
         if im.dtype != np.uint8 or im.ndim != 3 or im.shape[2] != 3:
             raise ValueError('frames must be uint8 HWC RGB arrays')
         groups.setdefault(im.shape[:2], []).append(i)
+    jobs, off, spans = [], 0, []
     for (H, W), idx in groups.items():
-        host = torch.empty((len(idx), H, W, 3), dtype=torch.uint8).pin_memory()
-        for j, i in enumerate(idx):
-            host[j] = torch.from_numpy(np.ascontiguousarray(images[i]))
-        frames = host.to(device, non_blocking=True)
+        off = (off + 255) & ~255                # every size group starts on a 256-byte boundary
+        spans.append(((H, W), idx, off))
+        for i in idx:
+            jobs.append((i, off, H, W))
+            off += H * W * 3
+    total = off
+    ring, slot, host = _staging.get(total)
+    host_np = host.numpy()
+
+    def stage(job):
+        i, o, H, W = job
+        np.copyto(host_np[o:o + H * W * 3].reshape(H, W, 3), images[i])
+
+    list(map_fn(stage, jobs))
+    dev_all = host[:total].to(device, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(device))
+    ring['events'][slot] = ev
+    out = None
+    for (H, W), idx, o in spans:
+        frames = dev_all[o:o + len(idx) * H * W * 3].view(len(idx), H, W, 3)
         if augment_rows is not None:            # the imgaug branch (augment.py), per image, before the resize (reference :80-93)
             from .augment import apply_device
             frames = apply_device(frames, [augment_rows[i] for i in idx])
         batch = resize_lanczos(frames, out_hw)
+        if len(spans) == 1:
+            return batch                        # one size: already in input order
+        if out is None:
+            out = torch.empty((len(images), 3, int(out_hw[0]), int(out_hw[1])), device=device, dtype=torch.float32)
         out[torch.as_tensor(idx, device=device)] = batch
     return out

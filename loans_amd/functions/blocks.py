@@ -223,7 +223,7 @@ class DownResBlock1Function(Function):
             ops.conv_wgrad(self.x, gh1, W0.grad_view, self.g0)
         gx = None
         if need_gx:
-            if ops.crop_dgrad_ok(self.g0, self.gs):
+            if ops.crop_dgrad_ok(self.g0, self.gs, gh1, g):
                 # the 4-channel crops: both data gradients in ONE launch that reads g and gh1 once (csrc/cropgrad.hip)
                 gx = ops.crop_dgrad(gh1, W0.data, self.g0, g, Ws.data, self.gs)
             else:

@@ -14,6 +14,7 @@ output and exits with its code.  Two rules of the GPU pool shape this:
 A script that already runs under a launcher (``RANK`` / ``WORLD_SIZE`` in the environment) is a rank and returns at once.
 """
 import os
+import signal
 import socket
 import subprocess
 import sys
@@ -60,11 +61,34 @@ def launch_if_parent(script, argv=None, flag='--gpus'):
     env = dict(os.environ)
     env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')      # this pool's driver only supports dmabuf IPC (RCCL needs it)
     env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or n) // n)))
-    proc = subprocess.Popen(command(os.path.abspath(script), argv, n), env=env)
-    try:
-        rc = proc.wait()
-    except KeyboardInterrupt:
-        proc.terminate()
-        rc = proc.wait()
+    # the ranks live in a session of their own: a signal that ends the parent (Ctrl-C, a scheduler's SIGTERM, a closed
+    # terminal) is passed on to the WHOLE group -- torch.distributed.run and every rank -- so that no rank is left holding a GPU
+    proc = subprocess.Popen(command(os.path.abspath(script), argv, n), env=env, start_new_session=True)
+    got = []
+
+    def forward(signum, frame):
+        got.append(signum)
+        _signal_group(proc, signum)
+
+    for sig in (signal.SIGINT, signal.SIGTERM, signal.SIGHUP):
+        signal.signal(sig, forward)
+    while True:
+        try:
+            rc = proc.wait(timeout=GRACE_SECONDS if got else None)
+            break
+        except subprocess.TimeoutExpired:        # signalled, and the group did not wind down in time
+            _signal_group(proc, signal.SIGKILL)
     sys.stdout.flush()
+    if got:
+        sys.exit(128 + got[0])
     sys.exit(rc if rc >= 0 else 128 - rc)
+
+
+GRACE_SECONDS = 15.0
+
+
+def _signal_group(proc, signum):
+    try:
+        os.killpg(proc.pid, signum)             # start_new_session: the child's pid is its process-group id
+    except (ProcessLookupError, PermissionError):
+        pass

@@ -902,9 +902,16 @@ def _igemm_classes(lib, gy, wp, out, geo, flags, tile, ref, addend, st):
 CROP_DGRAD = os.environ.get('LOANS_CROP_DGRAD', '1') != '0'
 
 
-def crop_dgrad_ok(geo_a, geo_b=None):
-    """loans_crop_dgrad covers these convolutions of a 4-channel input (csrc/cropgrad.hip)"""
+def crop_dgrad_ok(geo_a, geo_b=None, gy_a=None, gy_b=None):
+    """loans_crop_dgrad covers these convolutions of a 4-channel input (csrc/cropgrad.hip) and -- when the gradient tensors
+    are given -- these operands: contiguous, one storage type for both (a caller falls back to conv_dgrad otherwise)"""
     ok = CROP_DGRAD
+    for gy, g in ((gy_a, geo_a), (gy_b, geo_b)):
+        if gy is not None:
+            ok = ok and g is not None and gy.is_contiguous() and gy.dtype in (torch.float32, BF16) \
+                and gy.numel() == g.B * g.Ho * g.Wo * g.Cout
+    if gy_a is not None and gy_b is not None:
+        ok = ok and gy_a.dtype == gy_b.dtype
     for g in (geo_a, geo_b):
         if g is None:
             continue
@@ -915,21 +922,32 @@ def crop_dgrad_ok(geo_a, geo_b=None):
     return ok
 
 
+_crop_wpacks = {}
+
+
+def _crop_wpack(device):
+    """the kernel's fragment-order weight workspace (LOANS_CROP_WPACK_FLOATS), one per (device, stream): re-packed by every
+    call's pre-pass and consumed by the same call on the same stream, so calls on one stream may share it"""
+    key = (device.index, torch.cuda.current_stream(device).cuda_stream)
+    w = _crop_wpacks.get(key)
+    if w is None:
+        w = _crop_wpacks[key] = torch.empty(16384, device=device, dtype=torch.float32)
+    return w
+
+
 def crop_dgrad(gy_a, w_a, geo_a, gy_b=None, w_b=None, geo_b=None, addend=None):
     """gx[B,H,W,4] = dgrad(gy_a, w_a) (+ dgrad(gy_b, w_b)) (+ addend) for convolutions of the SAME 4-channel input, in one
     launch that reads each gradient tensor once; weights are the forward OHWI tensors.  fp32 or bf16 gradients, fp32 gx."""
     lib = _lib.load()
-    assert crop_dgrad_ok(geo_a, geo_b) and (gy_b is None) == (geo_b is None)
-    assert gy_b is None or gy_b.dtype == gy_a.dtype
+    assert crop_dgrad_ok(geo_a, geo_b, gy_a, gy_b) and (gy_b is None) == (geo_b is None)
     for gy, g in ((gy_a, geo_a), (gy_b, geo_b)):
         if gy is not None:
-            assert gy.is_contiguous() and gy.numel() == g.B * g.Ho * g.Wo * g.Cout
             _count_flops('dgrad', g)
     out = torch.empty((geo_a.B, geo_a.H, geo_a.W, 4), device=gy_a.device, dtype=torch.float32)
     mk = lambda g: _lib.SmallConv(g.k, g.stride, g.pad, g.Ho, g.Wo)      # noqa: E731
     ca, cb = mk(geo_a), (mk(geo_b) if geo_b is not None else None)
     fn = lib.loans_crop_dgrad_bf16_f32 if _is16(gy_a) else lib.loans_crop_dgrad_f32
-    wpack = torch.empty(16384, device=gy_a.device, dtype=torch.float32)          # LOANS_CROP_WPACK_FLOATS
+    wpack = _crop_wpack(gy_a.device)
     check(fn(_ptr(gy_a), _ptr(w_a), C.byref(ca), _ptr(gy_b), _ptr(w_b), C.byref(cb) if cb is not None else None,
              _ptr(out), _ptr(addend), _ptr(wpack), geo_a.B, geo_a.H, geo_a.W, geo_a.Cout, _stream()), 'loans_crop_dgrad')
     return out

@@ -7,7 +7,10 @@ import torch
 
 
 def concat_examples(batch, device=None):
-    """Stack a list of examples (arrays or tuples of arrays) and move them to ``device``."""
+    """Stack a list of examples (arrays or tuples of arrays) and move them to ``device``.  A batch that an iterator already
+    finished on the device (``MultithreadIterator(device=...)``: a tensor, or a tuple of tensors) passes through."""
+    if torch.is_tensor(batch) or (isinstance(batch, tuple) and all(torch.is_tensor(b) for b in batch)):
+        return batch
     first = batch[0]
     if isinstance(first, tuple):
         cols = [np.stack([np.asarray(ex[i]) for ex in batch]) for i in range(len(first))]
@@ -78,7 +81,159 @@ class SerialIterator:
         return self.epoch + self._pos / max(len(self.dataset), 1)
 
 
-MultithreadIterator = SerialIterator      # the decode work of the real datasets is out of scope
+class MultithreadIterator(SerialIterator):
+    """``chainer.iterators.MultithreadIterator(dataset, batch_size, repeat, shuffle, n_threads)`` in the role the reference
+    gives it (train_sheep_localizer.py:113-116): the examples of the NEXT batches are decoded by a pool of host threads while
+    the current step runs.  Same order / epoch bookkeeping as ``SerialIterator`` (the values a batch is returned with are
+    those of that batch, not of the prefetched ones).
+
+    MI355X side: with ``device=`` and a dataset that offers ``decode_batch / finish_batch`` (``ImageDataset``) the producer
+    thread also uploads the uint8 frames and runs augmentation + LANCZOS resize + ``/ 255`` on the GPU on a stream of its own
+    (``loans_amd/common/datasets/resample.py``), so ``next()`` hands out a float32 NCHW batch that is already resident in HBM
+    and the step's stream only waits for an event; other datasets are decoded by the pool and uploaded by the converter.
+    ``device_stage='consumer'`` keeps every GPU call on the caller's thread (needed while a hipGraph is being captured: an
+    allocation from another thread would invalidate the capture).
+
+    Random draws of the datasets (augmentation) are taken on the producer thread in index order, so a run is reproducible
+    for a given seed whatever the pool size."""
+
+    def __init__(self, dataset, batch_size, repeat=True, shuffle=True, n_threads=4, seed=0, device=None, n_prefetch=2,
+                 device_stage='producer', n_processes=0):
+        super().__init__(dataset, batch_size, repeat=repeat, shuffle=shuffle, seed=seed)
+        # n_processes > 0: frames are decoded by that many worker PROCESSES (common/datasets/decode_farm.py; Pillow's decoders
+        # hold the GIL, a thread pool stays near one core's rate); the pool threads then only move pixels over pipes
+        self.n_processes, self._farm = int(n_processes), None
+        if self.n_processes > 0:
+            n_threads = max(n_threads, self.n_processes)
+        self.n_threads, self.n_prefetch, self.device_stage = max(1, int(n_threads)), max(1, int(n_prefetch)), device_stage
+        self.device = None if device is None or (isinstance(device, int) and device < 0) else \
+            (torch.device('cuda', device) if isinstance(device, int) else torch.device(device))
+        self._pool = self._thread = self._queue = self._stream = None
+        self._generation = 0
+        self._host_state = (self.epoch, self.is_new_epoch, self._pos)
+
+    # ---- producer side ----------------------------------------------------------------------------------------------
+    def _indices(self):
+        """the next batch's indices + the bookkeeping values that batch is handed out with (SerialIterator.__next__)"""
+        n = len(self.dataset)
+        if not self.repeat and self._pos >= n:
+            return None
+        i_end = self._pos + self.batch_size
+        idx = list(self._order[self._pos:i_end])
+        if i_end >= n:
+            if self.repeat:
+                rest = i_end - n
+                self._order = self._new_order()
+                idx += list(self._order[:rest])
+                self._pos = rest
+            else:
+                self._pos = n
+            epoch, new = self._p_epoch + 1, True
+        else:
+            epoch, new = self._p_epoch, False
+            self._pos = i_end
+        self._p_epoch = epoch
+        return [int(i) for i in idx], (epoch, new, self._pos)
+
+    def _make(self, idx):
+        ds = self.dataset
+        if self.device is not None and hasattr(ds, 'decode_batch'):
+            decoded = ds.decode_batch(idx, self._pool.map, self._farm) if self._farm is not None else \
+                ds.decode_batch(idx, self._pool.map)
+            if self.device_stage != 'producer':
+                return ('decoded', decoded)
+            with torch.cuda.device(self.device), torch.cuda.stream(self._stream):
+                batch = ds.finish_batch(decoded, self.device, self._pool.map)
+                ev = torch.cuda.Event()
+                ev.record(self._stream)
+            return ('device', batch, ev)
+        if hasattr(ds, 'get_examples'):        # decode / resize pooled, random draws in index order
+            return ('host', ds.get_examples(idx, self._pool.map))
+        return ('host', list(self._pool.map(ds.__getitem__, idx)))
+
+    def _produce(self, generation, q):
+        try:
+            while generation == self._generation:
+                nxt = self._indices()
+                if nxt is None:
+                    q.put((generation, StopIteration, None))
+                    return
+                idx, state = nxt
+                q.put((generation, self._make(idx), state))
+        except BaseException as e:          # handed to the consumer: a failing decode must fail the training loop
+            q.put((generation, e, None))
+
+    def _start(self):
+        import queue
+        import threading
+        from concurrent.futures import ThreadPoolExecutor
+        if self._pool is None:
+            self._pool = ThreadPoolExecutor(max_workers=self.n_threads, thread_name_prefix='loans-decode')
+        if self.device is not None and self._stream is None and self.device_stage == 'producer':
+            self._stream = torch.cuda.Stream(device=self.device)
+        if self.n_processes > 0 and self._farm is None and self.device is not None and hasattr(self.dataset, 'decode_batch'):
+            from ..common.datasets.decode_farm import DecodeFarm
+            self._farm = DecodeFarm(self.n_processes)
+        self._p_epoch = self.epoch
+        self._queue = queue.Queue(maxsize=self.n_prefetch)
+        self._thread = threading.Thread(target=self._produce, args=(self._generation, self._queue), daemon=True,
+                                        name='loans-feed')
+        self._thread.start()
+
+    def _stop(self):
+        self._generation += 1
+        q, t = self._queue, self._thread
+        self._queue = self._thread = None
+        if t is not None:
+            while t.is_alive():                 # unblock a producer waiting on a full queue
+                try:
+                    q.get(timeout=0.05)
+                except Exception:
+                    pass
+            t.join()
+
+    # ---- consumer side ----------------------------------------------------------------------------------------------
+    def reset(self):
+        self._stop()
+        super().reset()
+
+    def finalize(self):
+        self._stop()
+        if self._pool is not None:
+            self._pool.shutdown(wait=True)
+            self._pool = None
+        if self._farm is not None:
+            self._farm.close()
+            self._farm = None
+
+    def __next__(self):
+        if self._thread is None:
+            self._start()
+        generation, item, state = self._queue.get()
+        assert generation == self._generation
+        if item is StopIteration:
+            self._queue.put((generation, StopIteration, None))       # keeps raising until reset()
+            raise StopIteration
+        if isinstance(item, BaseException):
+            self._stop()
+            raise item
+        self.epoch, self.is_new_epoch, self._host_pos = state[0], state[1], state[2]
+        kind = item[0]
+        if kind == 'host':
+            return item[1]
+        if kind == 'decoded':
+            return self.dataset.finish_batch(item[1], self.device)
+        _, batch, ev = item
+        cur = torch.cuda.current_stream(self.device)
+        cur.wait_event(ev)
+        batch.record_stream(cur)
+        return batch
+
+    next = __next__
+
+    @property
+    def epoch_detail(self):
+        return self.epoch + getattr(self, '_host_pos', 0) / max(len(self.dataset), 1)
 
 
 class DeviceBatchIterator:

@@ -129,7 +129,10 @@ def run_full_steps(dtype=np.float64, iterations=3):
 # for the drift bound, in fp32 (tests/golden/config1_b8_224.npz).
 # --------------------------------------------------------------------------------------------------------------------------
 CONFIG1_ARGV = ['--use-resnet-18', '-b', '8', '--image-size', '224', '224', '--target-size', '75', '75', '--iterations', '10',
-                '--dataset-size', '8', '--seed', '1234', '--data-seed', '10', '--no-shuffle', '--log-interval', '100']
+                '--dataset-size', '8', '--seed', '1234', '--data-seed', '10', '--no-shuffle', '--log-interval', '100',
+                # loop controls only (no effect on the models, the batches or the oracle's trajectory): every iteration's
+                # losses / theta on the host, no validation pass, no snapshot per epoch (an epoch is ONE iteration here)
+                '--record-history', '--no-validation', '--no-snapshot-every-epoch', '--flat-log-dir']
 
 
 # the same run at a learning rate where ten Adam steps stay in the smooth regime: with the reference's default 1e-3 and 8

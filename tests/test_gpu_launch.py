@@ -66,7 +66,8 @@ def test_bench_secondary_legs_schema():
 def test_trainer_two_ranks_through_the_launcher(tmp_path):
     r = _run('train_sheep_localizer.py', ['--gpus', '2', '--use-resnet-18', '-b', '2', '--image-size', '64', '64',
                                           '--target-size', '16', '16', '--iterations', '3', '--dataset-size', '8',
-                                          '--log-interval', '1', '-l', str(tmp_path)], LOANS_DIST_BACKEND='gloo')
+                                          '--log-interval', '1', '--no-validation', '--flat-log-dir', '-l', str(tmp_path)],
+             LOANS_DIST_BACKEND='gloo')
     assert r.returncode == 0, r.stderr[-3000:]
     assert r.stdout.count('iteration') == 3, r.stdout                    # rank 0 alone reports
     assert os.path.exists(os.path.join(str(tmp_path), 'SheepLocalizer_3.npz'))

@@ -66,8 +66,8 @@ def test_trainer_validation_loop(tmp_path):
     import train_sheep_localizer as T
     from loans_amd.sheep.sheep_evaluator import bbox_iou
     argv = ['--use-resnet-18', '-b', '4', '--image-size', '64', '64', '--target-size', '16', '16', '--iterations', '4',
-            '--dataset-size', '8', '--seed', '5', '--no-shuffle', '--log-interval', '2', '--validation', '--validation-size', '10',
-            '--lr', '1e-5', '-l', str(tmp_path)]
+            '--dataset-size', '8', '--seed', '5', '--no-shuffle', '--log-interval', '2', '--validation-size', '10',
+            '--lr', '1e-5', '-l', str(tmp_path), '--no-snapshot-every-epoch']        # validation is the reference's default
     args = T.parse_args(argv)
     lines = []
     history, localizer, _ = T.run(args, log=lines.append)
@@ -111,8 +111,8 @@ def test_evaluate_sweep_against_oracle(tmp_path, capsys):
     logdir = str(tmp_path)
     size, crop, n_eval = (64, 64), (16, 16), 12
     T.run(T.parse_args(['--use-resnet-18', '-b', '4', '--image-size', '64', '64', '--target-size', '16', '16', '--iterations', '4',
-                        '--dataset-size', '8', '--seed', '9', '--no-shuffle', '--snapshot-interval', '2', '--lr', '2e-2',
-                        '-l', logdir]), log=lambda s: None)
+                        '--dataset-size', '8', '--seed', '9', '--no-shuffle', '--no-snapshot-every-epoch', '--snapshot-interval', '2',
+                        '--lr', '2e-2', '--no-validation', '--flat-log-dir', '-l', logdir]), log=lambda s: None)
     assert {'SheepLocalizer_2.npz', 'SheepLocalizer_4.npz'} <= set(os.listdir(logdir))
     argv = [logdir, 'SheepLocalizer_', '--synthetic', str(n_eval), '--use-resnet-18', '--image-size', '64', '64',
             '--target-size', '16', '16', '--batchsize', '1', '--iou-threshold', '0.3']

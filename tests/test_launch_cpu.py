@@ -80,3 +80,37 @@ def test_rank_env_means_no_second_fork():
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
+
+
+def test_sigterm_to_the_parent_ends_every_rank():
+    """ADVICE (round 2): a scheduler's SIGTERM (or a closed terminal) must not orphan torch.distributed.run and its ranks with
+    the GPUs in their hands -- the launcher passes the signal to the ranks' whole process group and exits 128 + signal"""
+    import signal
+    import time
+    import psutil
+    e = dict(os.environ, LOANS_BENCH_DRY='1', LOANS_DIST_BACKEND='gloo')
+    for k in ('RANK', 'WORLD_SIZE', 'LOCAL_RANK', 'MASTER_ADDR', 'MASTER_PORT'):
+        e.pop(k, None)
+    p = subprocess.Popen([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '2', '--steps', '100000000', '--warmup', '0'],
+                         cwd=ROOT, env=e, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    try:
+        deadline = time.time() + 120
+        kids = []
+        while time.time() < deadline:               # until both ranks exist (python -m torch.distributed.run -> 2 x bench.py)
+            kids = psutil.Process(p.pid).children(recursive=True)
+            if sum('bench.py' in ' '.join(k.cmdline()) and 'torch.distributed.run' not in ' '.join(k.cmdline()) for k in kids) >= 2:
+                break
+            time.sleep(0.5)
+        assert len(kids) >= 3, [k.cmdline() for k in kids]
+        time.sleep(2.0)
+        p.send_signal(signal.SIGTERM)
+        rc = p.wait(timeout=60)
+        assert rc == 128 + signal.SIGTERM, rc
+        gone, alive = psutil.wait_procs(kids, timeout=20)
+        assert not alive, [k.cmdline() for k in alive]
+    finally:
+        if p.poll() is None:
+            p.kill()
+        for k in psutil.Process().children(recursive=True):
+            if 'bench.py' in ' '.join(k.cmdline()):
+                k.kill()

@@ -1,0 +1,129 @@
+"""CPU: the trainer's command line and dataset wiring are the reference's (train_sheep_localizer.py:52-116): positional
+``train_file val_file reference_file``, ``--no-validation`` / ``--num-epoch`` / ``--no-imgaug`` / ``--ln`` /
+``--no-snapshot-every-epoch`` with its defaults, ``.json`` path lists, the training ``ImageDataset`` built with
+``use_imgaug=args.use_imgaug, transform_probability=0.5``, the validation set with the default (int32) label type; and the
+``MultithreadIterator`` that feeds the loop: pooled decode, SerialIterator's order and epoch bookkeeping."""
+import random
+
+import numpy as np
+
+from tests._input_files import write_files
+
+
+def test_command_line_is_the_references():
+    import train_sheep_localizer as T
+    a = T.parse_args(['train.txt', 'val.csv', 'ref/images.csv'])
+    assert (a.train_file, a.val_file, a.reference_file) == ('train.txt', 'val.csv', 'ref/images.csv')
+    # the reference's defaults (:52-74)
+    assert a.validation is True and tuple(a.image_size) == (224, 224) and tuple(a.target_size) == (75, 75)
+    assert a.batch_size == 16 and a.gpu == -1 and a.learning_rate == 0.001 and a.log_dir == 'sheep_logs' and a.ln == 'test'
+    assert a.num_epoch == 100 and a.snapshot_interval == 1000 and a.snapshot_every_epoch is True and a.log_interval == 100
+    assert a.use_imgaug is True and a.use_resnet_18 is False and a.localizer_target == 1.0 and a.port == 1337
+    assert a.resume_localizer is None and a.resume_discriminator is None
+    b = T.parse_args(['t', 'gibberish', 'r', '--no-validation', '--no-imgaug', '--no-snapshot-every-epoch', '--ln', 'run7',
+                      '--log-name', 'run8', '--num-epoch', '3', '--lr', '0.01', '--learning-rate', '0.02', '-b', '64', '-g', '2',
+                      '--rl', 'a.npz', '--rd', 'b.npz', '--use-resnet-18', '--localizer-target', '0.9', '--test-image', 'x.png',
+                      '--anchor-image', 'y.png', '--port', '9'])
+    assert b.validation is False and b.use_imgaug is False and b.snapshot_every_epoch is False and b.ln == 'run8'
+    assert b.num_epoch == 3 and b.learning_rate == 0.02 and b.batch_size == 64 and b.gpu == 2
+    assert (b.resume_localizer, b.resume_discriminator) == ('a.npz', 'b.npz') and b.use_resnet_18 and b.localizer_target == 0.9
+    # positionals omitted (an extension): the seeded synthetic generator
+    c = T.parse_args(['--use-resnet-18', '--iterations', '5'])
+    assert (c.train_file, c.val_file, c.reference_file) == ('synthetic',) * 3 and c.iterations == 5
+
+
+def test_file_datasets_are_built_like_the_references(tmp_path):
+    import train_sheep_localizer as T
+    from loans_amd.common.datasets.image_dataset import ImageDataset, LabeledImageDataset
+    for as_json in (False, True):
+        train, val, ref = write_files(tmp_path / ('j' if as_json else 't'), as_json=as_json)
+        args = T.parse_args([train, val, ref, '--image-size', '64', '64', '--target-size', '16', '16', '--seed', '1'])
+        tr, rf, va = T.build_datasets(args)
+        assert isinstance(tr, ImageDataset) and tr.transform_probability == 0.5 and tr.use_imgaug is True     # reference :84-91
+        assert tr.image_size == (64, 64) and len(tr) == 10
+        assert isinstance(rf, LabeledImageDataset) and rf._label_dtype is np.float32 and rf.image_size == (16, 16)
+        assert isinstance(va, LabeledImageDataset) and va._label_dtype is np.int32 and len(va) == 6               # reference :111
+        frame = tr.get_example(0)
+        assert frame.shape == (3, 64, 64) and frame.dtype == np.float32 and 0 <= frame.min() and frame.max() <= 1
+        crop, label, dummy = rf.get_example(0)
+        assert crop.shape == (3, 16, 16) and label.dtype == np.float32 and 0 < float(label[0]) <= 1
+        vframe, vbox, _ = va.get_example(0)
+        assert vframe.shape == (3, 64, 64) and vbox.shape == (1, 4) and vbox.dtype == np.int32
+        no_aug = T.build_datasets(T.parse_args([train, 'gibberish', ref, '--no-validation', '--no-imgaug']))
+        assert no_aug[0].use_imgaug is False and no_aug[0].transform_probability == 0.5 and no_aug[2] is None
+
+
+def test_multithread_iterator_is_serial_iterator_with_a_pool(tmp_path):
+    """same batches, same epoch / is_new_epoch / epoch_detail per batch as SerialIterator although batches are prepared ahead
+    on other threads; augmentation draws are consumed in index order, so a pooled, prefetching pass over a seeded dataset gives
+    the bytes of a plain loop over ``get_example``; ``reset()`` restarts a ``repeat=False`` pass; a failing example fails
+    ``next()``"""
+    from loans_amd.common.datasets.image_dataset import ImageDataset
+    from loans_amd.runtime import training
+    train, _, _ = write_files(tmp_path)
+    for use_imgaug in (True, False):
+        mk = lambda: ImageDataset(train, str(tmp_path), image_size=(48, 40), use_imgaug=use_imgaug,      # noqa: E731
+                                  transform_probability=0.5, augment_seed=11)
+        a, b = mk(), mk()
+        random.seed(3)
+        it = training.SerialIterator(a, 4, shuffle=True, seed=9)
+        want = [(np.stack(next(it)), it.epoch, it.is_new_epoch, it.epoch_detail) for _ in range(6)]
+        random.seed(3)          # the naive branch draws from the global stream (reference :86-90)
+        mt = training.MultithreadIterator(b, 4, shuffle=True, seed=9, n_threads=3, n_prefetch=1)
+        for ref_batch, epoch, new, detail in want:
+            got = np.stack(next(mt))
+            np.testing.assert_array_equal(got, ref_batch)
+            assert (mt.epoch, mt.is_new_epoch) == (epoch, new) and abs(mt.epoch_detail - detail) < 1e-12
+        mt.finalize()
+        assert any(new for _, _, new, _ in want)
+    ds = ImageDataset(train, str(tmp_path), image_size=(32, 32))
+    once = training.MultithreadIterator(ds, 4, repeat=False, shuffle=False, n_threads=2)
+    for _ in range(2):
+        sizes = [len(b) for b in once]
+        assert sizes == [4, 4, 2] and once.epoch == 1
+        once.reset()
+    once.finalize()
+    ds._paths = list(ds._paths) + ['frames/missing.png']
+    bad = training.MultithreadIterator(ds, 4, repeat=False, shuffle=False, n_threads=2)
+    next(bad), next(bad)
+    try:
+        next(bad)
+        raise AssertionError('a failing decode must fail the loop')
+    except FileNotFoundError:
+        pass
+    bad.finalize()
+
+
+def test_decode_farm_gives_the_bytes_of_the_in_process_decode(tmp_path):
+    """decode processes (common/datasets/decode_farm.py) return what ``ImageDataset._read_u8`` returns -- RGB, grey and RGBA
+    8-bit files --, decline 16-bit files (decoded in-process then) and an unreadable file raises in the parent"""
+    from concurrent.futures import ThreadPoolExecutor
+    from PIL import Image
+    from loans_amd.common.datasets.decode_farm import DecodeFarm
+    from loans_amd.common.datasets.image_dataset import ImageDataset
+    rng = np.random.RandomState(0)
+    names = []
+    for i, (shape, mode) in enumerate([((40, 56, 3), 'RGB'), ((33, 21), 'L'), ((24, 24, 4), 'RGBA'), ((50, 30, 3), 'RGB')]):
+        Image.fromarray(rng.randint(0, 256, shape).astype(np.uint8), mode).save(str(tmp_path / ('a%d.png' % i)))
+        names.append('a%d.png' % i)
+    Image.fromarray(rng.randint(0, 65536, (20, 20)).astype(np.uint16)).save(str(tmp_path / 'deep.png'))
+    names.append('deep.png')
+    mk = lambda: ImageDataset(names, str(tmp_path), image_size=(32, 32), use_imgaug=True, transform_probability=0.5,  # noqa: E731
+                              augment_seed=4)
+    farm = DecodeFarm(2)
+    try:
+        with ThreadPoolExecutor(2) as pool:
+            for _ in range(2):
+                a, b = mk().decode_batch(range(5), pool.map, farm), mk().decode_batch(range(5))
+                assert a[1] == b[1] and len(a[0]) == 5
+                for x, y in zip(a[0], b[0]):
+                    assert x.dtype == np.uint8 and x.shape == y.shape and (x == y).all()
+            ds = mk()
+            ds._paths = names + ['missing.png']
+            try:
+                ds.decode_batch([5], pool.map, farm)
+                raise AssertionError('an unreadable file must raise')
+            except FileNotFoundError:
+                pass
+    finally:
+        farm.close()

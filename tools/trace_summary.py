@@ -24,7 +24,7 @@ span = (int(seg[-1]['End_Timestamp']) - int(seg[0]['Start_Timestamp'])) / 1e3
 print('one step (prep_kernel to prep_kernel): span %.1f us, sum of kernel durations %.1f us (two streams overlap)' % (span, sum(tot.values())))
 for k, v in tot.most_common(30):
     print('%10.1f us %5d launches  avg %9.1f us  %s' % (v, cnt[k], v / cnt[k], k))
-gap = next(i for i, r in enumerate(seg) if 'gap_fwd_kernel' in r['Kernel_Name'])      # end of the backbone forward
+gap = max(i for i, r in enumerate(seg) if 'gap_fwd_kernel' in r['Kernel_Name'])       # end of the localizer's conv forward (ResNet-50: pool5, then the one behind res6 / res7)
 fwd = [r for r in seg[:gap] if 'igemm' in r['Kernel_Name'] or 'stem7' in r['Kernel_Name'] or 'halo16' in r['Kernel_Name'] or 'ws8_kernel' in r['Kernel_Name'] or 'wsw_kernel' in r['Kernel_Name']]     # the backbone's convs; a LOANS_TILE_SPLIT conv is two launches
 t = sum(dur(r) for r in fwd)
 # optional: batch, MFMA peak (TFLOP/s) and algorithmic conv-forward FLOP per image of the run (defaults: configs[1], fp32)

@@ -1,18 +1,31 @@
 #!/usr/bin/env python
-"""The reference's training driver (train_sheep_localizer.py:50-255) for the MI355X build: same wiring
-(datasets -> iterators -> SheepLocalizer / ResnetAssessor -> two Adam(amsgrad=True) -> SheepAssessor ->
-loop -> snapshots), same flags where they touch the hot path, and the validation loop of :106-113,192-197
-(``--validation``: a validation iterator run through ``SheepMAPEvaluator`` at every log interval).
+"""The reference's training driver (train_sheep_localizer.py:50-255) for the MI355X build: the same command line --
+positional ``train_file val_file reference_file``, ``--no-validation``, ``--num-epoch``, ``--no-imgaug``, ``--ln``,
+``--no-snapshot-every-epoch`` ... (:52-74) --, the same wiring (datasets -> MultithreadIterator -> SheepLocalizer /
+ResnetAssessor -> two Adam(amsgrad=True) -> SheepAssessor -> loop until ``num_epoch`` -> snapshots), the validation loop of
+:106-113,192-197 (a validation iterator run through ``SheepMAPEvaluator`` at every log interval / new epoch) and the
+timestamped ``<log-dir>/<iso time>_<log name>/`` directory with a JSON ``log`` whose first entry carries the configuration
+(:158-180).
 
-Datasets: the seeded synthetic paste-and-crop generator by default; ``--train-file`` / ``--reference-file`` /
-``--val-file`` read the reference's file formats (``ImageDataset`` path list, ``LabeledImageDataset`` tab-separated
-csv: common/datasets/image_dataset.py).  The Trainer extensions that are not on the path (BBOXPlotter, Logger,
-interactive prompt, dump_graph) are intentionally absent.
+    python train_sheep_localizer.py train.txt val.csv reference/images.csv --use-resnet-18 -b 64 -g 0
 
-    python train_sheep_localizer.py --use-resnet-18 -b 64 --iterations 20 --validation
+Input path (MI355X side): frames are decoded by a pool of host threads one or two batches ahead and finished on the GPU --
+uint8 upload, the augmentation branch (``ImageDataset(use_imgaug=..., transform_probability=0.5)``, :84-91), LANCZOS resize,
+``/ 255``, NCHW -- on a stream of their own (``loans_amd.runtime.training.MultithreadIterator(device=...)``), so a step
+starts with its batch resident in HBM.
+
+Extensions (not in the reference, all optional): the literal ``synthetic`` for any of the three files = the seeded synthetic
+paste-and-crop generator (like the reference's own ``mnist`` literal for the reference file, :94-96) -- omitted positionals
+default to it --, ``--iterations N`` (stop early), ``--gpus N`` (data parallel, forks its own ranks), ``--dtype bf16``,
+``--use-graph``, seeds.  The Trainer extensions that are not on the path (BBOXPlotter and its ``--port`` / ``--test-image``,
+``--anchor-image``, Logger's source copies, the interactive prompt, dump_graph) are accepted on the command line and absent.
+
+    python train_sheep_localizer.py --use-resnet-18 -b 64 --iterations 20
     python train_sheep_localizer.py --gpus 8 --use-resnet-18 -b 128        (forks its own 8 ranks)
 """
 import argparse
+import datetime
+import json
 import os
 import sys
 import time
@@ -35,6 +48,8 @@ from loans_amd import parallel                  # noqa: E402
 from loans_amd.datasets import synthetic        # noqa: E402
 from loans_amd.runtime import training          # noqa: E402
 
+SYNTHETIC = 'synthetic'
+
 
 class SyntheticFrames:
     """`ImageDataset` stand-in: float32 CHW RGB frames in [0,1] (common/datasets/image_dataset.py:47-98)."""
@@ -48,6 +63,8 @@ class SyntheticFrames:
     def __getitem__(self, i):
         return self.frames[i]
 
+    get_example = __getitem__
+
 
 class SyntheticAssessorSamples:
     """`LabeledImageDataset` stand-in: (crop, IoU label, zeros(1)) triples (image_dataset.py:180-181)."""
@@ -60,6 +77,8 @@ class SyntheticAssessorSamples:
 
     def __getitem__(self, i):
         return self.x[i], self.y[i], np.zeros(1, np.float32)
+
+    get_example = __getitem__
 
 
 class SyntheticValidationFrames:
@@ -80,6 +99,19 @@ class SyntheticValidationFrames:
     def __getitem__(self, i):
         return self.frames[i], self.boxes[i], np.zeros(1, np.float32)
 
+    get_example = __getitem__
+
+
+def load_train_paths(train_file, with_label=False):
+    """``.json`` file lists (reference :24-32): ``[{"image": path, "bounding_boxes": [[...]]}, ...]``"""
+    with open(train_file) as handle:
+        train_data = json.load(handle)
+    paths = [item["image"] for item in train_data]
+    if with_label:
+        labels = [item['bounding_boxes'][0] for item in train_data]
+        return list(zip(paths, labels))
+    return paths
+
 
 def load_pretrained_model(model_file, model):
     loans_amd.load_npz(model_file, model, strict=False)       # NpzDeserializer(strict=False), reference :45-47
@@ -87,34 +119,55 @@ def load_pretrained_model(model_file, model):
 
 def parse_args(argv=None):
     parser = argparse.ArgumentParser(description="Train a sheep localizer (MI355X-native LoANs hot path)")
-    parser.add_argument("--train-file", help="path list of training frames (ImageDataset); default: synthetic frames")
-    parser.add_argument("--reference-file", help="tab-separated <crop>\\t<iou> csv (LabeledImageDataset, the output of "
-                                                 "datasets/sheep/paste_and_crop_sheep.py); default: synthetic crops")
-    parser.add_argument("--val-file", help="tab-separated <frame>\\t<top>\\t<left>\\t<bottom>\\t<right> csv for --validation")
+    # ---- the reference's command line (:52-74), same names, defaults and meaning ----
+    parser.add_argument("train_file", nargs='?', default=SYNTHETIC, help="path to train csv ('synthetic': seeded synthetic frames)")
+    parser.add_argument("val_file", nargs='?', default=SYNTHETIC,
+                        help="path to validation file (if you do not want to do validation just enter gibberish here)")
+    parser.add_argument("reference_file", nargs='?', default=SYNTHETIC, help="path to reference images with different zoom levels")
+    parser.add_argument("--no-validation", dest='validation', action='store_false', default=True, help="don't do validation")
     parser.add_argument("--image-size", type=int, nargs=2, default=(224, 224), help="input size for localizer")
     parser.add_argument("--target-size", type=int, nargs=2, default=(75, 75), help="crop size for each image")
     parser.add_argument("-b", "--batch-size", type=int, default=16, help="batch size for training (per GPU)")
-    parser.add_argument("-g", "--gpu", type=int, default=0, help="gpu id to use")
+    parser.add_argument("-g", "--gpu", type=int, default=-1,
+                        help="gpu id to use (the reference's -1 = cpu does not exist here: -1 takes the current device)")
+    parser.add_argument("--lr", "--learning-rate", dest="learning_rate", type=float, default=0.001, help="learning rate")
+    parser.add_argument("-l", "--log-dir", default='sheep_logs', help="path to log dir")
+    parser.add_argument("--ln", "--log-name", dest="ln", default="test", help="name of log")
+    parser.add_argument("--num-epoch", type=int, default=100, help="number of epochs to train")
+    parser.add_argument("--snapshot-interval", type=int, default=1000, help="number of iterations after which a snapshot will be taken")
+    parser.add_argument("--no-snapshot-every-epoch", dest="snapshot_every_epoch", action='store_false', default=True,
+                        help="Do not take a snapshot on every epoch")
+    parser.add_argument("--log-interval", type=int, default=100, help="log interval")
+    parser.add_argument("--port", type=int, default=1337, help="(BBOXPlotter: accepted, not used)")
+    parser.add_argument("--test-image", help="(BBOXPlotter: accepted, not used)")
+    parser.add_argument("--anchor-image", help="(accepted, not used)")
+    parser.add_argument("--rl", dest="resume_localizer", help="path to snapshot that is to be used to resume training of localizer")
+    parser.add_argument("--rd", dest="resume_discriminator", help="path to snapshot that is to be used to pre-initialize discriminator")
+    parser.add_argument("--use-resnet-18", action='store_true', default=False, help="Use Resnet-18 for localization")
+    parser.add_argument("--localizer-target", type=float, default=1.0, help="target iou for localizer to reach in the interval [0,1]")
+    parser.add_argument("--no-imgaug", action='store_false', dest='use_imgaug', default=True,
+                        help="disable image augmentation with `imgaug`, but use naive image augmentation instead")
+    # ---- extensions ----
+    parser.add_argument("--validation", dest='validation', action='store_true', help="(default; kept for older command lines)")
+    parser.add_argument("--iterations", type=int, default=None, help="stop after this many iterations (before --num-epoch epochs)")
     parser.add_argument("--gpus", type=int, default=1,
                         help="data-parallel ranks on this node, one process per GPU, forked by this script itself")
-    parser.add_argument("--lr", "--learning-rate", dest="learning_rate", type=float, default=0.001)
-    parser.add_argument("-l", "--log-dir", default='sheep_logs')
-    parser.add_argument("--iterations", type=int, default=20)
-    parser.add_argument("--dataset-size", type=int, default=256)
-    parser.add_argument("--snapshot-interval", type=int, default=0, help="0 = only at the end")
-    parser.add_argument("--log-interval", type=int, default=5)
-    parser.add_argument("--rl", dest="resume_localizer")
-    parser.add_argument("--rd", dest="resume_discriminator")
-    parser.add_argument("--use-resnet-18", action='store_true', default=False)
-    parser.add_argument("--localizer-target", type=float, default=1.0)
-    parser.add_argument("--no-validation", dest='validation', action='store_false', default=False)
-    parser.add_argument("--validation", dest='validation', action='store_true',
-                        help="run SheepMAPEvaluator over a validation set at every log interval (reference :106-113,192-197)")
-    parser.add_argument("--validation-size", type=int, default=32, help="synthetic validation frames (without --val-file)")
+    parser.add_argument("--dataset-size", type=int, default=256, help="synthetic training / reference examples")
+    parser.add_argument("--validation-size", type=int, default=32, help="synthetic validation frames")
     parser.add_argument("--seed", type=int, default=None,
-                        help="seed NumPy's global RNG before the models are built (initialisers draw from it, like Chainer's)")
+                        help="seed NumPy's global RNG before the models are built (initialisers draw from it, like Chainer's) "
+                             "and the augmentation streams of the datasets")
     parser.add_argument("--data-seed", type=int, default=10, help="seed of the synthetic datasets")
     parser.add_argument("--no-shuffle", action='store_true', help="iterate the datasets in order (reproducible trajectories)")
+    parser.add_argument("--loader-threads", type=int, default=0, help="decode threads per iterator (0: host cores / ranks, at most 8)")
+    parser.add_argument("--loader-processes", type=int, default=-1,
+                        help="decode PROCESSES of the training-frame iterator (Pillow's decoders hold the GIL: threads do not "
+                             "scale); -1: as many as --loader-threads resolves to, 0: decode on the threads")
+    parser.add_argument("--host-input", action='store_true',
+                        help="finish the frames on the host (Pillow resize in get_example) instead of on the GPU")
+    parser.add_argument("--flat-log-dir", action='store_true', help="write into --log-dir itself (no <time>_<name> sub-directory)")
+    parser.add_argument("--record-history", action='store_true',
+                        help="keep losses and theta of EVERY iteration (a host sync per iteration: parity tests only)")
     parser.add_argument("--use-graph", action='store_true', default=False,
                         help="capture the step into a hipGraph after two eager iterations (launch-bound small batches)")
     parser.add_argument("--dtype", default='f32', choices=['f32', 'bf16'],
@@ -124,7 +177,7 @@ def parse_args(argv=None):
 
 
 def build_models(args):
-    """localizer + assessor exactly as the loop uses them (reference :115-127).  Host-side only (no GPU needed): the
+    """localizer + assessor exactly as the loop uses them (reference :118-127).  Host-side only (no GPU needed): the
     fixture generator builds the very same initial weights from the same seed.  ``Linear(None, 1)`` of the assessor is
     resolved here from the target size, which is what its first Chainer call would do."""
     if args.seed is not None:
@@ -144,30 +197,51 @@ def build_models(args):
 
 
 def build_datasets(args, rank=0):
-    """(train, reference, validation or None) -- reference :77-111."""
+    """(train, reference, validation or None) -- reference :77-111, keyword for keyword."""
     from loans_amd.common.datasets.image_dataset import ImageDataset, LabeledImageDataset
-    if args.train_file:
-        train = ImageDataset(args.train_file, os.path.dirname(args.train_file), image_size=tuple(args.image_size))
-    else:
+    if args.train_file == SYNTHETIC:
         train = SyntheticFrames(args.dataset_size, args.image_size, seed=args.data_seed + rank)
-    if args.reference_file:
-        reference = LabeledImageDataset(args.reference_file, os.path.dirname(args.reference_file),
-                                        image_size=tuple(args.target_size), dtype=np.float32, label_dtype=np.float32)
     else:
+        train_image_paths = load_train_paths(args.train_file) if args.train_file.endswith('.json') else args.train_file
+        train = ImageDataset(
+            train_image_paths,
+            os.path.dirname(args.train_file),
+            image_size=tuple(args.image_size),
+            dtype=np.float32,
+            use_imgaug=args.use_imgaug,
+            transform_probability=0.5,
+            augment_seed=None if args.seed is None else args.seed + 7919 * rank,
+        )
+    if args.reference_file == SYNTHETIC:
         reference = SyntheticAssessorSamples(args.dataset_size, args.target_size, seed=args.data_seed + 990 + rank)
+    else:
+        reference = LabeledImageDataset(
+            args.reference_file,
+            os.path.dirname(args.reference_file),
+            image_size=tuple(args.target_size),
+            dtype=np.float32,
+            label_dtype=np.float32,
+        )
     validation = None
     if args.validation:
-        if args.val_file:
-            validation = LabeledImageDataset(args.val_file, os.path.dirname(args.val_file), image_size=tuple(args.image_size),
-                                             dtype=np.float32, label_dtype=np.float32)
-        else:
+        if args.val_file == SYNTHETIC:
             validation = SyntheticValidationFrames(args.validation_size, args.image_size, seed=args.data_seed + 5000)
+        else:
+            validation_data = load_train_paths(args.val_file, with_label=True) if args.val_file.endswith('.json') else args.val_file
+            # reference :111 -- default label dtype (int32), default dtype
+            validation = LabeledImageDataset(validation_data, os.path.dirname(args.val_file), image_size=tuple(args.image_size))
     return train, reference, validation
 
 
+def loader_threads(args, world):
+    if args.loader_threads > 0:
+        return args.loader_threads
+    return max(1, min(8, (os.cpu_count() or 1) // max(world, 1)))
+
+
 def run(args, log=print):
-    """The training loop.  Returns the per-iteration history (losses, theta of the batch; validation metrics at the log
-    intervals) -- what tests/test_gpu_trainer.py compares with the oracle's trajectory."""
+    """The training loop.  Returns (history, localizer, discriminator): the entries of the log intervals (every iteration with
+    ``--record-history``: losses, theta of the batch -- what tests/test_gpu_trainer.py compares with the oracle's trajectory)."""
     if args.dtype == 'bf16':
         loans_amd.set_compute_dtype('bf16')
         loans_amd.set_storage_dtype('bf16')
@@ -175,12 +249,20 @@ def run(args, log=print):
     comm = parallel.init_from_env()
     if comm.size > 1:
         args.gpu = int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count()
+    elif args.gpu < 0:
+        args.gpu = torch.cuda.current_device()
     torch.cuda.set_device(args.gpu)
 
     train_dataset, reference_dataset, validation_dataset = build_datasets(args, comm.rank)
     shuffle = not args.no_shuffle
-    data_iter = training.MultithreadIterator(train_dataset, args.batch_size, shuffle=shuffle)
-    reference_iter = training.MultithreadIterator(reference_dataset, args.batch_size, shuffle=shuffle)
+    threads = loader_threads(args, comm.size)
+    # while a hipGraph is being captured no other thread may allocate device memory: the GPU stages of the feed then run on
+    # the training thread (decode still runs ahead on the pool)
+    feed = dict(n_threads=threads, device=None if args.host_input else args.gpu,
+                device_stage='consumer' if args.use_graph else 'producer')
+    procs = threads if args.loader_processes < 0 else args.loader_processes
+    data_iter = training.MultithreadIterator(train_dataset, args.batch_size, shuffle=shuffle, n_processes=procs, **feed)
+    reference_iter = training.MultithreadIterator(reference_dataset, args.batch_size, shuffle=shuffle, **feed)
 
     localizer, discriminator = build_models(args)
     localizer.to_gpu(args.gpu)
@@ -205,37 +287,82 @@ def run(args, log=print):
 
     evaluator = None
     if validation_dataset is not None:
-        validation_iter = training.MultithreadIterator(validation_dataset, args.batch_size, repeat=False, shuffle=False)
+        validation_iter = training.MultithreadIterator(validation_dataset, args.batch_size, repeat=False, shuffle=False,
+                                                       n_threads=threads)
         sheep_evaluator = loans_amd.SheepMAPEvaluator(localizer, args.gpu)
         evaluator = training.Evaluator(validation_iter, localizer, device=args.gpu, eval_func=sheep_evaluator)
 
+    # reference :158-162: <log-dir>/<iso time>_<log name>
+    if not args.flat_log_dir:
+        stamp = datetime.datetime.now().isoformat() if comm.size == 1 else os.environ.get('TORCHELASTIC_RUN_ID', 'dp') + \
+            '_' + datetime.datetime.now().strftime('%Y-%m-%dT%H')
+        args.log_dir = os.path.join(args.log_dir, "{}_{}".format(stamp, args.ln))
     os.makedirs(args.log_dir, exist_ok=True)
+    # reference :166-180: the first log entry carries the configuration (evaluate.py and the inference tools read it back)
+    data_to_log = {'log_dir': args.log_dir, 'image_size': list(args.image_size),
+                   'updater': [updater.__class__.__name__, 'updater.py'],
+                   'discriminator': [discriminator.__class__.__name__, 'discriminator.py'], 'discriminator_output_dim': 1,
+                   'localizer': [localizer.__class__.__name__, 'localizer.py']}
+    for argument in filter(lambda x: not x.startswith('_'), dir(args)):
+        data_to_log[argument] = getattr(args, argument)
+    log_entries = []
+
+    def snapshot(it):
+        for model in (localizer, discriminator):
+            loans_amd.save_npz(os.path.join(args.log_dir, '%s_%d.npz' % (model.__class__.__name__, it)), model)
+
+    def theta_of_batch():
+        return localizer.last_transform_params.data.reshape(-1, 6).cpu().numpy().copy()
+
     history = []
     t0 = time.time()
-    for _ in range(args.iterations):
+    it = 0
+    while updater.epoch < args.num_epoch and (args.iterations is None or it < args.iterations):
         updater.update()
         it = updater.iteration
-        obs = loans_amd.reporter.observation
-        entry = {'iteration': it, 'loss_localizer': float(obs['loss_localizer']), 'loss_dis': float(obs['loss_dis']),
-                 'theta': localizer.last_transform_params.data.reshape(-1, 6).cpu().numpy().copy()}
+        last = (args.iterations is not None and it == args.iterations) or updater.epoch >= args.num_epoch
         # log train information every time a new epoch starts or log_interval iterations have been done (reference :188-190)
-        if updater.is_new_epoch or it % args.log_interval == 0 or it == args.iterations:
+        log_now = updater.is_new_epoch or it % args.log_interval == 0 or last
+        entry = None
+        if log_now or args.record_history:
+            # the only host synchronisation of an iteration; between log intervals the launch queue runs ahead freely
+            obs = loans_amd.reporter.observation
+            entry = {'iteration': it, 'epoch': updater.epoch, 'loss_localizer': float(obs['loss_localizer']),
+                     'loss_dis': float(obs['loss_dis'])}
+            if args.record_history:
+                entry['theta'] = theta_of_batch()
+        if log_now:
             if evaluator is not None:
+                # the evaluator's test-mode forward rebinds the localizer's last_transform_params (and, under a captured
+                # graph, the training step's own tensor must stay the one the replays write): restored afterwards
+                keep = localizer.last_transform_params
                 entry['validation'] = evaluator()
+                localizer.last_transform_params = keep
             if comm.rank == 0:
                 val = ''
                 if 'validation' in entry:
                     val = '  mean_iou %.4f  map %.4f' % (entry['validation']['mean_iou'], entry['validation']['map'])
                 log('iteration %4d  epoch %d  loss_localizer %.5f  loss_dis %.5f%s  (%.1f s)' % (
                     it, updater.epoch, entry['loss_localizer'], entry['loss_dis'], val, time.time() - t0))
-        history.append(entry)
-        if comm.rank == 0 and args.snapshot_interval and it % args.snapshot_interval == 0:
-            for model in (localizer, discriminator):
-                loans_amd.save_npz(os.path.join(args.log_dir, '%s_%d.npz' % (model.__class__.__name__, it)), model)
+                stats = {k: v for k, v in entry.items() if k not in ('theta', 'validation')}
+                stats.update(entry.get('validation', {}))
+                stats['elapsed_time'] = time.time() - t0
+                if it == args.log_interval or not log_entries:
+                    stats.update(data_to_log)
+                log_entries.append(stats)
+                with open(os.path.join(args.log_dir, 'log'), 'w') as f:
+                    json.dump(log_entries, f, indent=4, default=str)
+        if entry is not None:
+            history.append(entry)
+        # reference :182-186: a snapshot on every new epoch, or every snapshot_interval iterations
+        if comm.rank == 0 and (updater.is_new_epoch if args.snapshot_every_epoch else it % args.snapshot_interval == 0):
+            snapshot(it)
+    for iterator in (data_iter, reference_iter):
+        iterator.finalize()
     if comm.rank == 0:
-        for model in (localizer, discriminator):
-            loans_amd.save_npz(os.path.join(args.log_dir, '%s_%d.npz' % (model.__class__.__name__, updater.iteration)), model)
-        frame0 = train_dataset[0]
+        if not os.path.exists(os.path.join(args.log_dir, '%s_%d.npz' % (localizer.__class__.__name__, updater.iteration))):
+            snapshot(updater.iteration)
+        frame0 = train_dataset.get_example(0)
         bboxes, rois, scores, _ = localizer.predict([frame0[0] if isinstance(frame0, tuple) else frame0])
         log('predict() on frame 0: bbox (top,left,bottom,right) = %s' % np.round(bboxes[0], 2).tolist())
     return history, localizer, discriminator
