@@ -52,6 +52,32 @@ def _require_train():
         raise RuntimeError('backward through test-mode BatchNormalization is not on the training path')
 
 
+class StageBoundary(Function):
+    """Identity between two stages of a backbone that tells a data-parallel optimiser when a stage's parameter gradients are
+    complete: its backward runs once every function ABOVE it has run its own, i.e. when the weight gradients of the stages
+    behind it are enqueued -- the optimiser then starts the all-reduce of that part of the gradient arena while the backward of
+    the stages in front of it is still being issued (loans_amd/parallel.py, SURVEY 8e: "bucket + overlap with backward").
+    Only inserted while a gradient exchange is active; the values that flow through are untouched."""
+
+    def __init__(self, hook, name):
+        self.hook, self.name = hook, name
+
+    def forward(self, inputs):
+        return inputs[0]
+
+    def backward(self, inputs, grad_outputs):
+        self.hook(self.name)
+        return grad_outputs[0]
+
+
+def stage_boundary(link, name, h):
+    """``h`` unchanged, with a StageBoundary in front of stage ``name`` when ``link`` has an exchange hook attached"""
+    hook = link.__dict__.get('_stage_hook')
+    if hook is None or not config.enable_backprop or not config.train:
+        return h
+    return StageBoundary(hook, name)(h)
+
+
 class StemFunction(Function):
     """conv1(7x7/2, bias) -> bn1 -> relu -> max_pool(3, 2, cover_all)   (sheep/resnet.py:72-73).
     inputs: x (preprocessed frames: the zero-padded packed-RGB buffer of ops.prep_images(images, geometry) for a

@@ -80,6 +80,8 @@ class ResNet50Layers(Chain):
             self.fc6 = L.Linear(2048, 1000)
         self.pretrained_model = pretrained_model
 
+    exchange_stages = ('res4', 'res5')        # see sheep/resnet.py
+
     def _stem(self, x):
         return blocks.StemFunction(self.conv1, self.bn1)(x, self.conv1.W, self.conv1.b, self.bn1.gamma, self.bn1.beta)
 
@@ -113,6 +115,8 @@ class ResNet50Layers(Chain):
         for key, funcs in self.functions.items():
             if len(target_layers) == 0:
                 break
+            if key in self.exchange_stages:
+                h = blocks.stage_boundary(self, key, h)
             for func in funcs:
                 h = func(h)
             if key in target_layers:

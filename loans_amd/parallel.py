@@ -46,13 +46,16 @@ class Communicator:
     def allreduce_grad(self, arena, async_op=False):
         """Sum the gradient arena over all ranks, in place, in large buckets.  ``async_op``: return the work handles
         instead of making the current stream wait (the collectives then overlap what is launched next)."""
-        if not self.active:
+        return self.allreduce_range(arena, 0, getattr(arena, 'active_numel', arena.numel), async_op)
+
+    def allreduce_range(self, arena, lo, hi, async_op=False):
+        """The same for the floats [lo, hi) of the gradient arena (one stage's share, see ``exchange_plan``)."""
+        if not self.active or hi <= lo:
             return []
-        g = arena.grad[:getattr(arena, 'active_numel', arena.numel)]
-        n = g.numel()
+        g = arena.grad
         works = []
-        for lo in range(0, n, BUCKET_FLOATS):
-            w = dist.all_reduce(g[lo:min(lo + BUCKET_FLOATS, n)], op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
+        for a in range(lo, hi, BUCKET_FLOATS):
+            w = dist.all_reduce(g[a:min(a + BUCKET_FLOATS, hi)], op=dist.ReduceOp.SUM, group=self.group, async_op=async_op)
             if async_op:
                 works.append(w)
         return works
@@ -89,9 +92,37 @@ def init_from_env(backend=None):
     return Communicator()
 
 
+# LOANS_STAGED_EXCHANGE=0: one exchange of the whole arena after the backward (rounds 1-2)
+STAGED_EXCHANGE = os.environ.get('LOANS_STAGED_EXCHANGE', '1') != '0'
+
+
+def exchange_plan(link):
+    """Where the gradient arena of ``link`` is cut for the staged exchange: ``{stage name: first float of that stage}`` for the
+    stages a backbone names in ``exchange_stages`` (sheep/resnet.py: res4, res5).  The arena is laid out in forward order
+    (the head and the cold res6 / res7 behind the backbone), so when the backward has left stage S every gradient from S's
+    first float to the end of the active prefix is complete: [res5 .. end) goes first -- 9.4 M of the 12.6 M floats at 224 px
+    --, [res4, res5) second, [0, res4) when the backward ends."""
+    arena = link.arena or link.finalize()
+    offset = {id(p): o for p, o in zip(arena.params, arena.offsets)}
+    plan = {}
+    for path, l in link.namedlinks():
+        for name in getattr(l, 'exchange_stages', ()):
+            prefix = (path if path != '/' else '') + '/' + name + '/'
+            inside = [offset[id(p)] for k, p in link.namedparams() if k.startswith(prefix)]
+            if inside:
+                plan[name] = min(inside)
+    return plan
+
+
 def create_multi_node_optimizer(optimizer, comm):
-    """Attach a communicator to an optimiser (ChainerMN's name for the same thing)."""
+    """Attach a communicator to an optimiser (ChainerMN's name for the same thing).  With an active communicator the backbone's
+    stage boundaries report to the optimiser (``Adam.stage_done``), which exchanges each part of the gradient arena as soon as
+    it is complete, beside the backward of the stages in front of it."""
     optimizer.comm = comm
+    if STAGED_EXCHANGE and comm is not None and comm.active and optimizer.target is not None:
+        for l in optimizer.target.links():
+            if getattr(l, 'exchange_stages', None):
+                l.__dict__['_stage_hook'] = optimizer.stage_done
     return optimizer
 
 

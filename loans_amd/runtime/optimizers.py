@@ -29,6 +29,7 @@ class Adam:
         self.comm = None
         self._state = None
         self._hooks = {}
+        self._pending, self._exchanged_from, self._plan = [], None, None      # staged gradient exchange (data parallel)
 
     def setup(self, link):
         self.target = link
@@ -84,11 +85,14 @@ class Adam:
         if not any(p.update_rule.enabled for p in self.target.params()):
             return
         arena = self._ensure_state()
-        pending, self._pending = getattr(self, '_pending', None), None
         grad_scale = 1.0
-        if pending is not None:                 # update_begin() already started the exchange of this step
-            for work in pending:
+        if self._exchanged_from is not None:    # stage_done() / update_begin() already started the exchange of this step
+            if self._exchanged_from > 0:
+                self._exchange(arena, 0)        # what the stage boundaries left (stem .. res3, or everything below the last one)
+            for work in self._pending:
                 work.wait()                     # the current stream waits for RCCL's
+            self._pending, self._exchanged_from = [], None
+            ops.join_side_stream(arena.device)
             grad_scale = 1.0 / self.comm.size
         else:
             ops.join_side_stream(arena.device)  # all weight gradients of this step have landed
@@ -126,17 +130,51 @@ class Adam:
         ops.adam_amsgrad(arena.data[:n], arena.grad[:n], m[:n], v[:n], vhat[:n], lr, hp.beta1, hp.beta2,
                          hp.eps, hp.eta, hp.weight_decay_rate, grad_scale)
 
-    def update_begin(self):
-        """Data parallel only: start the gradient all-reduce now and return, so that it runs beside whatever the
-        caller issues next; the following ``update()`` waits for it and applies the step.  The gradients must not be
-        touched (no ``cleargrads``) in between.  Without an active communicator this is a no-op."""
-        if self.comm is None or not getattr(self.comm, 'active', self.comm.size > 1):
-            return
-        if not any(p.update_rule.enabled for p in self.target.params()):
+    def _exchange_active(self):
+        return self.comm is not None and getattr(self.comm, 'active', self.comm.size > 1) and \
+            any(p.update_rule.enabled for p in self.target.params())
+
+    def _exchange(self, arena, lo):
+        """Start the all-reduce of the gradient floats [lo, what has been started already) and return.  It is issued from the
+        weight-gradient stream after that stream has caught up with the current one: RCCL's stream then waits for every
+        gradient kernel enqueued so far -- weight gradients (side stream) and the BN gamma / beta sums (current stream) --
+        and for nothing that is enqueued afterwards; neither stream waits for the collective."""
+        hi = arena.active_numel if self._exchanged_from is None else self._exchanged_from
+        if lo < hi:
+            if arena.grad.is_cuda:
+                main = torch.cuda.current_stream(arena.device)
+                side = ops._side_stream(arena.device)
+                side.wait_stream(main)
+                with torch.cuda.stream(side):
+                    self._pending += self.comm.allreduce_range(arena, lo, hi, async_op=True)
+            else:
+                self._pending += self.comm.allreduce_range(arena, lo, hi, async_op=True)
+        self._exchanged_from = min(lo, hi)
+
+    def stage_done(self, name):
+        """A backbone's StageBoundary reports that the backward has left stage ``name``: every gradient from that stage's
+        first float to the end of the arena's active prefix is complete (parallel.exchange_plan) and its exchange starts now,
+        beside the backward of the stages in front of it (attached by parallel.create_multi_node_optimizer)."""
+        if not self._exchange_active():
             return
         arena = self._ensure_state()
-        ops.join_side_stream(arena.device)
-        self._pending = self.comm.allreduce_grad(arena, async_op=True)
+        if arena.grad.is_cuda and torch.cuda.is_current_stream_capturing():
+            return
+        if self._plan is None:
+            from .. import parallel
+            self._plan = parallel.exchange_plan(self.target)
+        lo = self._plan.get(name)
+        if lo is not None and lo < arena.active_numel:
+            self._exchange(arena, lo)
+
+    def update_begin(self):
+        """Data parallel only: start the all-reduce of whatever part of the gradient arena the stage boundaries have not
+        started yet and return, so that it runs beside whatever the caller issues next; the following ``update()`` waits for
+        all parts and applies the step.  The gradients must not be touched (no ``cleargrads``) in between.  Without an active
+        communicator this is a no-op."""
+        if not self._exchange_active():
+            return
+        self._exchange(self._ensure_state(), 0)
 
     def prepare_capture(self):
         """Allocate what a captured update reads at replay time -- outside the capture, so that neither the buffer nor

@@ -108,7 +108,7 @@ class MultithreadIterator(SerialIterator):
         self.n_threads, self.n_prefetch, self.device_stage = max(1, int(n_threads)), max(1, int(n_prefetch)), device_stage
         self.device = None if device is None or (isinstance(device, int) and device < 0) else \
             (torch.device('cuda', device) if isinstance(device, int) else torch.device(device))
-        self._pool = self._thread = self._queue = self._stream = None
+        self._pool = self._pool2 = self._thread = self._thread2 = self._queue = self._mid = self._stream = None
         self._generation = 0
         self._host_state = (self.epoch, self.is_new_epoch, self._pos)
 
@@ -135,33 +135,67 @@ class MultithreadIterator(SerialIterator):
         self._p_epoch = epoch
         return [int(i) for i in idx], (epoch, new, self._pos)
 
-    def _make(self, idx):
+    def _decode(self, idx):
+        """host half of a batch (runs on the decode thread): pooled / farmed decode, random draws in index order"""
         ds = self.dataset
         if self.device is not None and hasattr(ds, 'decode_batch'):
-            decoded = ds.decode_batch(idx, self._pool.map, self._farm) if self._farm is not None else \
-                ds.decode_batch(idx, self._pool.map)
-            if self.device_stage != 'producer':
-                return ('decoded', decoded)
-            with torch.cuda.device(self.device), torch.cuda.stream(self._stream):
-                batch = ds.finish_batch(decoded, self.device, self._pool.map)
-                ev = torch.cuda.Event()
-                ev.record(self._stream)
-            return ('device', batch, ev)
+            if self._farm is not None:
+                return ('decoded', ds.decode_batch(idx, self._pool.map, self._farm))
+            return ('decoded', ds.decode_batch(idx, self._pool.map))
         if hasattr(ds, 'get_examples'):        # decode / resize pooled, random draws in index order
             return ('host', ds.get_examples(idx, self._pool.map))
         return ('host', list(self._pool.map(ds.__getitem__, idx)))
 
-    def _produce(self, generation, q):
+    def _finish(self, item):
+        """device half (runs on the finish thread, so that batch k is uploaded and resampled while batch k + 1 is decoded)"""
+        if item[0] != 'decoded' or self.device_stage != 'producer':
+            return item
+        with torch.cuda.device(self.device), torch.cuda.stream(self._stream):
+            batch = self.dataset.finish_batch(item[1], self.device, self._pool2.map)
+            ev = torch.cuda.Event()
+            ev.record(self._stream)
+        return ('device', batch, ev)
+
+    def _put(self, generation, q, item):
+        """blocking put that gives up when the iterator has been reset / finalised meanwhile"""
+        import queue
+        while generation == self._generation:
+            try:
+                q.put(item, timeout=0.1)
+                return True
+            except queue.Full:
+                continue
+        return False
+
+    def _produce(self, generation, q, q_mid):
         try:
             while generation == self._generation:
                 nxt = self._indices()
                 if nxt is None:
-                    q.put((generation, StopIteration, None))
+                    self._put(generation, q_mid, (generation, StopIteration, None))
                     return
                 idx, state = nxt
-                q.put((generation, self._make(idx), state))
+                if not self._put(generation, q_mid, (generation, self._decode(idx), state)):
+                    return
         except BaseException as e:          # handed to the consumer: a failing decode must fail the training loop
-            q.put((generation, e, None))
+            self._put(generation, q_mid, (generation, e, None))
+
+    def _produce_finish(self, generation, q, q_mid):
+        import queue
+        while generation == self._generation:
+            try:
+                g, item, state = q_mid.get(timeout=0.1)
+            except queue.Empty:
+                continue
+            if item is StopIteration or isinstance(item, BaseException):
+                self._put(generation, q, (g, item, state))
+                return
+            try:
+                out = (g, self._finish(item), state)
+            except BaseException as e:
+                out = (g, e, None)
+            if not self._put(generation, q, out) or out[2] is None:
+                return
 
     def _start(self):
         import queue
@@ -174,22 +208,21 @@ class MultithreadIterator(SerialIterator):
         if self.n_processes > 0 and self._farm is None and self.device is not None and hasattr(self.dataset, 'decode_batch'):
             from ..common.datasets.decode_farm import DecodeFarm
             self._farm = DecodeFarm(self.n_processes)
+        if self._pool2 is None:
+            self._pool2 = ThreadPoolExecutor(max_workers=min(self.n_threads, 8), thread_name_prefix='loans-stage')
         self._p_epoch = self.epoch
-        self._queue = queue.Queue(maxsize=self.n_prefetch)
-        self._thread = threading.Thread(target=self._produce, args=(self._generation, self._queue), daemon=True,
-                                        name='loans-feed')
+        self._queue, self._mid = queue.Queue(maxsize=self.n_prefetch), queue.Queue(maxsize=1)
+        args = (self._generation, self._queue, self._mid)
+        self._thread = threading.Thread(target=self._produce, args=args, daemon=True, name='loans-feed-decode')
+        self._thread2 = threading.Thread(target=self._produce_finish, args=args, daemon=True, name='loans-feed-finish')
         self._thread.start()
+        self._thread2.start()
 
     def _stop(self):
-        self._generation += 1
-        q, t = self._queue, self._thread
-        self._queue = self._thread = None
-        if t is not None:
-            while t.is_alive():                 # unblock a producer waiting on a full queue
-                try:
-                    q.get(timeout=0.05)
-                except Exception:
-                    pass
+        self._generation += 1              # both threads poll it (their queue operations time out every 0.1 s)
+        threads = [t for t in (self._thread, self._thread2) if t is not None]
+        self._queue = self._mid = self._thread = self._thread2 = None
+        for t in threads:
             t.join()
 
     # ---- consumer side ----------------------------------------------------------------------------------------------
@@ -199,9 +232,10 @@ class MultithreadIterator(SerialIterator):
 
     def finalize(self):
         self._stop()
-        if self._pool is not None:
-            self._pool.shutdown(wait=True)
-            self._pool = None
+        for name in ('_pool', '_pool2'):
+            if getattr(self, name) is not None:
+                getattr(self, name).shutdown(wait=True)
+                setattr(self, name, None)
         if self._farm is not None:
             self._farm.close()
             self._farm = None

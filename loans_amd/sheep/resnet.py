@@ -43,14 +43,19 @@ class ResNet(Chain):
         self.n_layers = n_layers
         self.class_labels = class_labels
 
+    # data parallel: the gradient arena is exchanged in three parts, cut in front of these stages -- everything from res5 up
+    # (res5 + the head + res6 / res7: 75 % of the bytes at 224 px) as soon as the backward has left res5, res4 (19 %) next,
+    # the rest when the backward ends (loans_amd/parallel.py)
+    exchange_stages = ('res4', 'res5')
+
     def __call__(self, x):
         """x: preprocessed frames (``prepare_images``: the padded packed-RGB buffer conv1 reads).  Returns the NHWC feature map."""
         h = blocks.StemFunction(self.conv1, self.bn1)(x, self.conv1.W, self.conv1.b, self.bn1.gamma, self.bn1.beta)
         h = self.res2(h)
         h = self.res3(h)
-        h = self.res4(h)
+        h = self.res4(blocks.stage_boundary(self, 'res4', h))
         if hasattr(self, 'res5'):
-            h = self.res5(h)
+            h = self.res5(blocks.stage_boundary(self, 'res5', h))
         if hasattr(self, 'res6'):
             h = self.res6(h)
         if hasattr(self, 'res7'):

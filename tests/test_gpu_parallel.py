@@ -1,7 +1,8 @@
 """-m gpu: two data-parallel ranks running the HIP joint step (both on GPU 0, gradients exchanged through gloo --
 RCCL wants one device per rank, the rest of the flow is what `bench.py --gpus N` runs) against the CPU oracle's
 data-parallel step: per-shard gradients with local BN statistics, OutOfImageLoss scaled by the world size, averaged,
-one Adam-AMSGrad update; every rank must end with the same parameters."""
+one Adam-AMSGrad update; every rank must end with the same parameters.  The localizer's gradients are exchanged in stages
+during the backward (loans_amd/parallel.py:exchange_plan; UNMEASURED on RCCL / xGMI: this box has one GPU)."""
 import os
 import socket
 
@@ -47,8 +48,17 @@ def _worker(rank, world, port, outdir):
         models=[loc, dis], iterator={'main': training.DeviceBatchIterator([dev(frames)]),
                                      'real': training.DeviceBatchIterator([(dev(real), dev(labels))])},
         optimizer={'opt_gen': og, 'opt_dis': od}, converter=training.identity_converter, device=0, comm=comm)
+    calls, plain = [], comm.allreduce_range
+    comm.allreduce_range = lambda arena, lo, hi, async_op=False: (calls.append((arena is loc.arena, lo, hi, async_op)),
+                                                                    plain(arena, lo, hi, async_op))[1]
     upd.update()
     torch.cuda.synchronize()
+    # the localizer's gradients travelled in three parts started DURING its backward (res5 + head first, then res4, the rest
+    # when the backward ended), together exactly the active prefix; the assessor's in one piece at its update
+    plan = parallel.exchange_plan(loc)
+    mine = [(lo, hi) for is_loc, lo, hi, a in calls if is_loc and a]
+    assert mine == [(plan['res5'], loc.arena.active_numel), (plan['res4'], plan['res5']), (0, plan['res4'])], (mine, plan)
+    assert [c for c in calls if not c[0]] == [(False, 0, dis.arena.active_numel, False)], calls
     np.savez(os.path.join(outdir, 'loc_%d.npz' % rank), **loc.state_dict_chainer())
     np.savez(os.path.join(outdir, 'dis_%d.npz' % rank), **dis.state_dict_chainer())
     comm.barrier()

@@ -77,6 +77,42 @@ def _worker(rank, world, port, out):
         total = v if total is None else total + v
     np.testing.assert_allclose(averaged, total, rtol=1e-9, atol=1e-12)
 
+    # 2b. the STAGED exchange (SURVEY 8e "bucket + overlap with backward"): the stage boundaries of the backbone report to the
+    #     optimiser during the backward (res5 first, then res4), which starts the all-reduce of that part of the arena at once;
+    #     update_begin() adds the rest.  Bit-identical to ONE exchange of the whole active prefix, and nothing beyond it moves.
+    import loans_amd
+    np.random.seed(3)
+    loc = loans_amd.SheepLocalizer((16, 16))
+    arena = loc.finalize(torch.device('cpu'))
+    arena.set_active('res6')                                   # 224 px frames: res6 / res7 are outside the active prefix
+    g = torch.Generator().manual_seed(100 + rank)
+    arena.grad.copy_(torch.randn(arena.numel, generator=g))
+    mine = arena.grad.clone()
+    opt = parallel.create_multi_node_optimizer(loans_amd.Adam(alpha=1e-3, amsgrad=True).setup(loc), comm)
+    fe = loc.feature_extractor
+    assert fe.__dict__['_stage_hook'] == opt.stage_done and fe.exchange_stages == ('res4', 'res5')
+    plan = parallel.exchange_plan(loc)
+    assert 0 < plan['res4'] < plan['res5'] < arena.active_numel < arena.numel
+    parallel.BUCKET_FLOATS = 1 << 20                           # several collectives per part
+    fe.__dict__['_stage_hook']('res5')                         # what StageBoundary.backward calls
+    assert opt._exchanged_from == plan['res5'] and len(opt._pending) == -(-(arena.active_numel - plan['res5']) // (1 << 20))
+    fe.__dict__['_stage_hook']('res4')
+    assert opt._exchanged_from == plan['res4']
+    opt.update_begin()
+    assert opt._exchanged_from == 0
+    for w in opt._pending:
+        w.wait()
+    staged = arena.grad.clone()
+    arena.grad.copy_(mine)
+    comm.allreduce_grad(arena)
+    assert torch.equal(staged, arena.grad)
+    assert torch.equal(staged[arena.active_numel:], mine[arena.active_numel:])
+    other = torch.randn(arena.numel, generator=torch.Generator().manual_seed(100 + (1 - rank)))
+    assert torch.equal(staged[:arena.active_numel], (mine + other)[:arena.active_numel])
+    # the share of the bytes that travels while the backward of res4 .. stem is still being issued
+    assert (arena.active_numel - plan['res5']) / arena.active_numel > 0.7
+    opt._pending, opt._exchanged_from = [], None
+
     # 3. max-reduce used by bench.py's timing, and the barrier
     assert comm.allreduce_max(float(rank)) == float(world - 1)
     comm.barrier()
@@ -127,3 +163,28 @@ def test_adam_lr_schedule_matches_chainer():
     for t in (1, 2, 10, 1000):
         opt.t = t
         assert abs(opt.lr - C.adam_lr(1e-3, .9, .999, t)) < 1e-18
+
+
+def test_exchange_plan_of_both_localizers():
+    """the cut points of the staged gradient exchange: res4 / res5 of either backbone, in arena (= forward) order, the head and
+    the cold res6 / res7 behind res5; without an active communicator no hook is attached and the graph is untouched"""
+    import loans_amd
+    from loans_amd import parallel
+    np.random.seed(0)
+    for cls in (loans_amd.SheepLocalizer, loans_amd.Resnet50SheepLocalizer):
+        loc = cls((16, 16))
+        arena = loc.finalize(torch.device('cpu'))
+        plan = parallel.exchange_plan(loc)
+        assert sorted(plan) == ['res4', 'res5'] and 0 < plan['res4'] < plan['res5'] < arena.numel
+        off = {k: o for (k, p), o in zip([(k, p) for k, p in loc.namedparams() if not k.startswith(('/res6/', '/res7/'))], arena.offsets)}
+        for k, o in off.items():
+            stage = k.split('/')[2] if k.startswith('/feature_extractor/') else 'head'
+            if stage in ('res5', 'fc6', 'head'):
+                assert o >= plan['res5'], k
+            elif stage == 'res4':
+                assert plan['res4'] <= o < plan['res5'], k
+            else:
+                assert o < plan['res4'], k
+        assert min(arena.cold_offsets.values()) > plan['res5']
+        opt = parallel.create_multi_node_optimizer(loans_amd.Adam(amsgrad=True).setup(loc), parallel.Communicator())
+        assert '_stage_hook' not in loc.feature_extractor.__dict__ and opt._exchanged_from is None
