@@ -121,6 +121,10 @@ typedef struct loans_igemm_desc {
                                       MFMA work per staged byte of LOANS_TILE_HALO_128 -- the N = 128 layers, too narrow for a 256-column tile */
 #define LOANS_TILE_WSW64      37  /* the same layers with the weights stationary and every WAVE on its own unit (2 rows x 16 pixels x 64 channels:
                                       own halo image, own vmcnt, own staging slab): no block barrier after the weights have landed */
+#define LOANS_TILE_WGHALO_64   38  /* loans_wgrad_bf16s, stride-1 3 x 3 forward geometries with Cin % 64 == 0, Cout % 64 == 0: a block owns 64 output x 64
+                                      input channels x ALL nine taps and walks 8 x 16 pixel tiles; gradient tile and input halo tile staged once per
+                                      tile, a tap is a window shift in LDS (csrc/wgrad_halo_bf16.hip).  splits = blocks per channel-tile pair */
+#define LOANS_TILE_WGHALO_128  39  /* the same with 128 output channels per block on eight waves (Cout % 128 == 0) */
 #define LOANS_TILE_HALO_256x64 12  /* 16 x 16 pixels x 64 output channels, Cin = 64 (one chunk): the res2 convolutions */
 #define LOANS_TILE_SPLITK(s) ((s) << 8) /* loans_igemm_f32, OR-ed onto a tile shape, s = 2..255: split-K for small grids (few tiles, long K:
                                   the deep layers at small batch, single-image inference).  Block (tile, i) contracts every s-th

@@ -108,3 +108,9 @@ int loans_halo16_covers(const loans_igemm_desc* d, int tile);
 int loans_halo16_launch(const void* in, const void* w, void* out, const float* bias, double* stats, const void* ref,
                         const void* addend, const loans_igemm_desc* d, int tile, unsigned in_bytes, unsigned w_bytes,
                         unsigned out_bytes, hipStream_t st);
+
+// wgrad_halo_bf16.hip: weight gradient of stride-1 3 x 3 convolutions on bf16 storage with all taps in one block
+// (LOANS_TILE_WGHALO_*; internal, reached through loans_wgrad_bf16s)
+int loans_wgrad_halo16_covers(const loans_igemm_desc* d, int tile);
+int loans_wgrad_halo16_launch(const void* x, const void* gy, float* dw, const loans_igemm_desc* d, int tile, int splits,
+                              unsigned x_bytes, unsigned gy_bytes, hipStream_t st);

@@ -1135,6 +1135,8 @@ extern "C" int loans_wgrad_bf16s(const void* x, const void* gy, float* dw, const
     hipStream_t st = as_stream(stream);
     int tile = d->tile;
     if (tile == 0) tile = (d->Cout <= 64) ? (a.Ktot <= 64 ? LOANS_TILE_64x64 : LOANS_TILE_64x128) : LOANS_TILE_128x128;
+    if (tile == LOANS_TILE_WGHALO_64 || tile == LOANS_TILE_WGHALO_128)
+        return loans_wgrad_halo16_launch(x, gy, dw, d, tile, splits, a.x_bytes, a.gy_bytes, st);
     if (tile == LOANS_TILE_64x64) return launch_wgrad16<64, 64>(a, splits, st);
     if (tile == LOANS_TILE_128x128) return launch_wgrad16<128, 128>(a, splits, st);
     if (tile == LOANS_TILE_64x128) return launch_wgrad16<64, 128>(a, splits, st);

@@ -1027,6 +1027,39 @@ def _wgrad_candidates(geo, tiles, chunk_px, dims=None):
     return tuple(out)
 
 
+# LOANS_TILE_WGHALO_* (csrc/wgrad_halo_bf16.hip): all nine taps of a stride-1 3x3 weight gradient in one block
+TILE_WGHALO_64, TILE_WGHALO_128 = 38, 39
+WGHALO = os.environ.get('LOANS_WGHALO', '1') != '0'
+
+
+def wghalo_tiles(geo):
+    """the halo weight-gradient tiles that cover this geometry (loans_wgrad_halo16_covers), where an 8 x 16 pixel tile is not
+    mostly empty"""
+    if not WGHALO or geo.dense or geo.k != 3 or geo.stride != 1 or geo.Cin % 64 or geo.Cout % 64 or (geo.Ho, geo.Wo) != (geo.H, geo.W):
+        return ()
+    if geo.H < 6 or geo.W < 12:
+        return ()
+    return (TILE_WGHALO_64,) + ((TILE_WGHALO_128,) if geo.Cout % 128 == 0 else ())
+
+
+def _wghalo_candidates(geo):
+    """(tile | blocks per channel-tile pair << 8): whole rounds of the machine's block slots (two 4-wave blocks or one 8-wave
+    block per CU), 0 = the library's default"""
+    cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+    ntiles = geo.B * ((geo.H + 7) // 8) * ((geo.W + 15) // 16)
+    out = []
+    for t in wghalo_tiles(geo):
+        bco, per_cu = (64, 2) if t == TILE_WGHALO_64 else (128, 1)
+        npairs = (geo.Cout // bco) * (geo.Cin // 64)
+        cand = {0}
+        for rounds in (1, 2, 3, 4, 6):
+            sp = max(1, rounds * per_cu * cus // npairs)
+            if ntiles // sp >= 2:
+                cand.add(sp)
+        out += [t | (sp << 8) for sp in sorted(cand)]
+    return tuple(out)
+
+
 def _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile):
     lib = _lib.load()
     _count_flops('wgrad', geo)
@@ -1049,6 +1082,8 @@ def _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile):
             cands = cands + (TILE_256x256,)         # one 512-thread block per CU (csrc/igemm_bf16.hip, wgrad16_kernel<256, 256, 8>)
         if splits == 0:
             cands = _wgrad_candidates(geo, cands, 32, _WGRAD16_TILE_DIMS if s16 else None)
+            if s16:
+                cands = tuple(cands) + _wghalo_candidates(geo)
         stem = stem_wgrad_ok(geo) and wfn is lib.loans_wgrad_f32 and fl == F_DENSE
         if stem:
             cands = tuple(cands) + (TILE_STEM,)

@@ -110,6 +110,43 @@ def test_conv_bf16_storage(case, tile):
         assert rel_err(dw.cpu().numpy().transpose(0, 3, 1, 2), gwr_ref) < 1e-5
 
 
+@pytest.mark.parametrize("case", [(3, 64, 14, 14, 64), (2, 128, 20, 33, 128), (2, 64, 9, 50, 256), (1, 192, 8, 16, 64),
+                                  (5, 64, 17, 12, 128), (2, 256, 32, 32, 256)])
+@pytest.mark.parametrize("tile", [38, 39])
+def test_weight_gradient_halo_tiles(case, tile):
+    """LOANS_TILE_WGHALO_64 / _128 (csrc/wgrad_halo_bf16.hip): a block holds all nine taps of a stride-1 3x3 weight gradient
+    and walks 8 x 16 pixel tiles with a staged halo image -- against the oracle on the bf16-rounded operands (fp32
+    accumulation: 1e-5) and against the plain GEMM form; image sizes that are no multiples of the tile, several channel-tile
+    pairs, explicit block counts, accumulation into a non-zero gradient, the relu(x) form of the assessor's blocks"""
+    from loans_amd import ops
+    B, Cin, H, W, Cout = case
+    if tile == 39 and Cout % 128:
+        pytest.skip('128 output channels per block')
+    rng = np.random.RandomState(11)
+    x = _r(rng.standard_normal((B, Cin, H, W)))
+    gy = _r(rng.standard_normal((B, Cout, H, W)))
+    w = np.zeros((Cout, Cin, 3, 3))
+    geo = ops.ConvGeometry(B, H, W, Cin, Cout, 3, 1, 1)
+    assert tile in ops.wghalo_tiles(geo) or min(H, W) < 12
+    _, col = C.conv2d_fwd(x.astype(np.float64), w, None, 1, 1)
+    _, gw_ref, _ = C.conv2d_bwd(x.shape, col, w, gy.astype(np.float64), 1, 1, False, need_gx=False)
+    xd, gyd = d16(_nhwc(x)), d16(_nhwc(gy))
+    start = rng.standard_normal((Cout, 3, 3, Cin)).astype(np.float32)
+    for splits in (0, 1, 5):
+        dw = dev(start)
+        ops._conv_wgrad(xd, gyd, dw, geo, False, splits, tile)
+        got = (dw.cpu().numpy() - start).transpose(0, 3, 1, 2)
+        assert rel_err(got, gw_ref) < 1e-5, (splits, rel_err(got, gw_ref))
+    plain = torch.zeros((Cout, 3, 3, Cin), device='cuda')
+    ops._conv_wgrad(xd, gyd, plain, geo, False, 0, 1)
+    assert rel_err(got, plain.cpu().numpy().transpose(0, 3, 1, 2)) < 1e-5
+    _, col_relu = C.conv2d_fwd(np.maximum(x, 0).astype(np.float64), w, None, 1, 1)
+    _, gwr_ref, _ = C.conv2d_bwd(x.shape, col_relu, w, gy.astype(np.float64), 1, 1, False, need_gx=False)
+    dw = torch.zeros((Cout, 3, 3, Cin), device='cuda')
+    ops._conv_wgrad(xd, gyd, dw, geo, True, 0, tile)
+    assert rel_err(dw.cpu().numpy().transpose(0, 3, 1, 2), gwr_ref) < 1e-5
+
+
 def test_bn_passes_bf16_storage():
     """bn_apply (3 modes), bn_backward (single / dual, with and without the ReLU mask) on bf16 tensors against the
     fp32 kernels fed the same (already rounded) values"""
