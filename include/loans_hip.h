@@ -222,6 +222,23 @@ int loans_cast_bf16(const float* src, void* dst, int64_t n, void* stream);
 int loans_repack_dgrad_bf16(const float* src, void* dst, int32_t Cout, int32_t Cin, int32_t src_taps,
                             const int32_t* tapsel_host, int32_t ntaps, void* stream);
 
+/* All data-gradient weight re-packs of a step in ONE launch (csrc/weightprep.hip).  `jobs_dev`: a table of `njobs` jobs in DEVICE
+ * memory, caller-owned and kept alive while launches that read it are in flight (built once: sources are parameter views of a
+ * fixed arena, destinations persistent buffers).  Job i covers the blocks [first_tile, first_tile + tiles_co * tiles_ci * ntaps)
+ * with tiles_co = ceil(Cout / 32), tiles_ci = ceil(Cin / 32); first_tile ascending from 0, `total_tiles` = their sum.  Each job
+ * is one loans_repack_dgrad_f32 (dst_bf16 = 0) or loans_repack_dgrad_bf16 (dst_bf16 = 1) call with at most
+ * LOANS_REPACK_JOB_TAPS selected taps.  Replaces the per-class launches in front of every F.convolution_2d backward-data
+ * (sheep/resnet.py:121-160, common/net.py:15-65). */
+#define LOANS_REPACK_JOB_TAPS 16
+typedef struct loans_repack_job {
+    const void* src;            /* fp32 [Cout][src_taps][Cin] */
+    void* dst;                  /* [Cin][ntaps][Cout], fp32 or bf16 */
+    int32_t Cout, Cin, src_taps, ntaps;
+    int32_t tapsel[LOANS_REPACK_JOB_TAPS];
+    int32_t first_tile, tiles_co, tiles_ci, dst_bf16;
+} loans_repack_job;
+int loans_repack_dgrad_batch(const loans_repack_job* jobs_dev, int32_t njobs, int32_t total_tiles, void* stream);
+
 /* dgrad for convolutions whose input has 4 physical channels (the RGB crops, common/net.py:15,17):
  * out[opix(m)][0..3] = sum_t sum_co gy[pix(m,t)][co] * w_ohwi[co][tapsel[t]][0..3]; same descriptor as
  * loans_igemm_f32 (Cin = gy channels, Cout must be 4), flags MASK / ADDEND only. */

@@ -31,6 +31,15 @@ class IgemmDesc(C.Structure):
         ('dy', C.c_int8 * MAX_TAPS), ('dx', C.c_int8 * MAX_TAPS)]
 
 
+REPACK_JOB_TAPS = 16
+
+
+class RepackJob(C.Structure):
+    """Mirror of ``loans_repack_job``."""
+    _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p)] + [(n, C.c_int32) for n in ('Cout', 'Cin', 'src_taps', 'ntaps')] + \
+               [('tapsel', C.c_int32 * REPACK_JOB_TAPS)] + [(n, C.c_int32) for n in ('first_tile', 'tiles_co', 'tiles_ci', 'dst_bf16')]
+
+
 class SmallConv(C.Structure):
     """Mirror of ``loans_small_conv``."""
     _fields_ = [(n, C.c_int32) for n in ('k', 'stride', 'pad', 'outH', 'outW')]
@@ -93,6 +102,7 @@ SIGNATURES = {
     'loans_linear_bwd_bf16': [_p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p],
     'loans_dgrad_c4_f32': [_p, _p, _p, _p, _p, C.POINTER(IgemmDesc), C.POINTER(_i32), _i32, _p],
     'loans_repack_dgrad_f32': [_p, _p, _i32, _i32, _i32, C.POINTER(_i32), _i32, _p],
+    'loans_repack_dgrad_batch': [_p, _i32, _i32, _p],
     'loans_resize_lanczos_u8': [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _i32, _p, _p, _i32, _p],
     'loans_resize_lanczos_u8_f32': [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _i32, _p, _p, _i32, _p],
     'loans_u8hwc3_to_f32chw': [_p, _p, _i32, _i32, _i32, _p],

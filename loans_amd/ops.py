@@ -706,7 +706,9 @@ def _conv_fprop16(lib, x, w, geo, out, bias, stats, relu_in, addend, tile):
         out = torch.empty((geo.B, geo.Ho, geo.Wo, geo.Cout), device=x.device, dtype=BF16)
     assert out.dtype == BF16 and (addend is None or addend.dtype == BF16)
     assert x.numel() == geo.in_numel and w.numel() == geo.w_numel
-    w16 = w if _is16(w) else cast_bf16(w)
+    w16 = w if _is16(w) else _bf16_shadow(w)            # inside a step: the arena's bf16 shadow, cast whole at its start
+    if w16 is None:
+        w16 = cast_bf16(w)
     flags = (F_RELU_IN if relu_in else 0) | (F_BIAS if bias is not None else 0) | (F_STATS if stats is not None else 0) | \
             (F_ADDEND if addend is not None else 0) | geo.base_flags
     if tile == 0:
@@ -758,15 +760,17 @@ def _conv_dgrad16(lib, gy, w, geo, out, mask_ref, addend, addend_mask_ref, tile)
             out.copy_(addend)
         if addend is not None:
             addend = out
-    wp = torch.empty(geo.dgrad_weight_floats, device=gy.device, dtype=BF16)
     flags = (F_MASK if mask_ref is not None else 0) | (F_ADDEND if addend is not None else 0) | \
             (F_ADDEND_MASK if addend_mask_ref is not None else 0)
     ref = mask_ref if mask_ref is not None else addend_mask_ref
     assert not (mask_ref is not None and addend_mask_ref is not None)
     st = _stream()
-    for d, tapsel, off in geo.dgrad:
-        check(lib.loans_repack_dgrad_bf16(_ptr(w), _ptr(wp[off:]), geo.Cout, geo.Cin, geo.k * geo.k, tapsel,
-                                          d.ntaps, st), 'loans_repack_dgrad_bf16')
+    wp = _prepacked_dgrad_weights(w, geo, True)          # inside a step: made at its start, all layers in one launch
+    if wp is None:
+        wp = torch.empty(geo.dgrad_weight_floats, device=gy.device, dtype=BF16)
+        for d, tapsel, off in geo.dgrad:
+            check(lib.loans_repack_dgrad_bf16(_ptr(w), _ptr(wp[off:]), geo.Cout, geo.Cin, geo.k * geo.k, tapsel,
+                                              d.ntaps, st), 'loans_repack_dgrad_bf16')
     dl = [(d, wp[off:]) for d, _, off in geo.dgrad]
     rows_in = geo.B * geo.H * geo.W
     # a split-K data gradient finishes in ONE pass over the whole tensor: the tap-less classes of a strided 1x1 (which only
@@ -828,15 +832,17 @@ def conv_dgrad(gy, w, geo, out=None, mask_ref=None, addend=None, addend_mask_ref
             check(fn(_ptr(gy), _ptr(w), _ptr(out), _ptr(mask_ref), _ptr(addend),
                      C.byref(_with_flags(d, fl, 0)), tapsel, geo.k * geo.k, _stream()), 'loans_dgrad_c4')
         return out
-    wp = torch.empty(geo.dgrad_weight_floats, device=gy.device, dtype=torch.float32)
     flags = (F_MASK if mask_ref is not None else 0) | (F_ADDEND if addend is not None else 0) | \
             (F_ADDEND_MASK if addend_mask_ref is not None else 0)
     ref = mask_ref if mask_ref is not None else addend_mask_ref
     assert not (mask_ref is not None and addend_mask_ref is not None)
     st = _stream()
-    for d, tapsel, off in geo.dgrad:
-        check(lib.loans_repack_dgrad_f32(_ptr(w), _ptr(wp[off:]), geo.Cout, geo.Cin, geo.k * geo.k, tapsel,
-                                         d.ntaps, st), 'loans_repack_dgrad_f32')
+    wp = _prepacked_dgrad_weights(w, geo, False)         # inside a step: made at its start, all layers in one launch
+    if wp is None:
+        wp = torch.empty(geo.dgrad_weight_floats, device=gy.device, dtype=torch.float32)
+        for d, tapsel, off in geo.dgrad:
+            check(lib.loans_repack_dgrad_f32(_ptr(w), _ptr(wp[off:]), geo.Cout, geo.Cin, geo.k * geo.k, tapsel,
+                                             d.ntaps, st), 'loans_repack_dgrad_f32')
     # split-K adds raw partial sums: a masked conv term cannot land on an addend that already sits in `out`
     inplace_masked = addend is not None and addend.data_ptr() == out.data_ptr() and mask_ref is not None
     dl = [(d, wp[off:]) for d, _, off in geo.dgrad]
@@ -1177,17 +1183,163 @@ class _ZeroPool:
 _zero_pools = {}
 
 
+# --------------------------------------------------------------------------- #
+# per-step weight preparation: the operand forms of the weights that every step derives from the fp32 masters --
+# bf16 copies for the bf16 arm's forward convolutions, per-stride-parity-class re-packs for the data gradients -- made ONCE at
+# the start of a step (weights only change in the optimiser's update) by two launches instead of one cast per forward
+# convolution and one re-pack per class and layer (47 + 94 launches of 4 - 20 us per step at configs[2], 72 at configs[1],
+# all on the step's critical stream).  LOANS_WEIGHT_PREP=0 restores the per-call launches.
+# --------------------------------------------------------------------------- #
+WEIGHT_PREP = os.environ.get('LOANS_WEIGHT_PREP', '1') != '0'
+_MAX_PREP_JOBS = 2048
+
+
+class _WeightPrep:
+    """State of one device.  `arenas`: parameter arenas registered by ParamArena (their bf16 shadows are cast whole at
+    begin_step).  `repacks`: (weight pointer, geometry key, bf16) -> persistent re-packed buffer; an entry is created (and
+    filled by per-call launches) the first time a data gradient asks inside a step, every later step fills all entries with
+    one loans_repack_dgrad_batch launch."""
+
+    def __init__(self):
+        self.arenas, self.repacks, self.order = [], {}, []
+        self.table = None          # device copy of the job table (uint8 tensor), rebuilt when entries were added
+        self.table_host = None
+        self.total_tiles = 0
+        self.dirty = False
+        self.live = False          # inside a step whose begin_step prepared everything registered so far
+        self.prepared = set()      # keys filled by this step's batch launch
+        self.shadow_ok = set()     # ids of arenas whose bf16 shadow was cast by this step's begin_step
+        self.step = 0
+
+    def begin(self, device):
+        lib = _lib.load()
+        st = _stream()
+        self.prepared, self.shadow_ok = set(), set()
+        self.live = True
+        self.step += 1
+        # entries no step has asked for lately belong to a model or a batch shape that is gone: dropped with their buffers
+        stale = [k for k in self.order if self.repacks[k]['used'] < self.step - 2]
+        if stale and not torch.cuda.is_current_stream_capturing():
+            for k in stale:
+                del self.repacks[k]
+            self.order = [k for k in self.order if k in self.repacks]
+            self.dirty = True
+        if STORAGE == 'bf16':
+            for ref in list(self.arenas):
+                arena = ref()
+                if arena is None:
+                    self.arenas.remove(ref)
+                    continue
+                n = (arena.active_numel + 3) // 4 * 4
+                if getattr(arena, 'data16', None) is None:
+                    arena.data16 = torch.empty(arena.numel, device=arena.device, dtype=BF16)
+                check(lib.loans_cast_bf16(_ptr(arena.data), _ptr(arena.data16), min(n, arena.numel), st), 'loans_cast_bf16')
+                self.shadow_ok.add(id(arena))
+        if not self.order:
+            self.dirty = False
+            return
+        if self.dirty:
+            jobs = (_lib.RepackJob * sum(len(self.repacks[k]['jobs']) for k in self.order))()
+            i = tile = 0
+            for k in self.order:
+                for job in self.repacks[k]['jobs']:
+                    C.memmove(C.byref(jobs[i]), C.byref(job), C.sizeof(_lib.RepackJob))
+                    jobs[i].first_tile = tile
+                    tile += job.tiles_co * job.tiles_ci * job.ntaps
+                    i += 1
+            raw = np.frombuffer(bytes(jobs), dtype=np.uint8).copy()
+            if torch.cuda.is_current_stream_capturing():
+                raise RuntimeError('the weight-preparation table changed inside a captured step')
+            self.table_host = torch.from_numpy(raw)
+            self.table = self.table_host.to(device)
+            self.njobs, self.total_tiles, self.dirty = i, tile, False
+        check(lib.loans_repack_dgrad_batch(_ptr(self.table), self.njobs, self.total_tiles, st), 'loans_repack_dgrad_batch')
+        self.prepared = set(self.order)
+
+
+_weight_preps = {}
+
+
+def register_arena(arena):
+    """ParamArena calls this: the arena's bf16 shadow is refreshed at every begin_step of the bf16 arm"""
+    import weakref
+    idx = arena.device.index if arena.device.type == 'cuda' else None
+    if idx is not None:
+        _weight_preps.setdefault(idx, _WeightPrep()).arenas.append(weakref.ref(arena))
+
+
+def _bf16_shadow(w):
+    """the bf16 copy of a parameter tensor inside its arena's shadow, cast by this step's begin_step; None outside a step or
+    for a tensor that is no arena view"""
+    wp = _weight_preps.get(w.device.index)
+    if wp is None or not wp.live or not WEIGHT_PREP:
+        return None
+    ptr = w.data_ptr()
+    for ref in wp.arenas:
+        arena = ref()
+        if arena is None or id(arena) not in wp.shadow_ok:
+            continue
+        base = arena.data.data_ptr()
+        off = ptr - base
+        if 0 <= off and off + w.numel() * 4 <= arena.active_numel * 4 and off % 4 == 0 and w.is_contiguous():
+            return arena.data16[off // 4:off // 4 + w.numel()].view(w.shape)
+    return None
+
+
+def _prepacked_dgrad_weights(w, geo, bf16):
+    """the re-packed data-gradient weights of (w, geo) -- all stride-parity classes in one buffer, class c at geo.dgrad[c]'s
+    offset -- prepared by this step's begin_step, or prepared now by per-class launches and registered for the next steps;
+    None outside a step (tests, inference: the caller re-packs per call)"""
+    wp = _weight_preps.setdefault(w.device.index, _WeightPrep())
+    if not wp.live or not WEIGHT_PREP or not geo.dgrad or max(d.ntaps for d, _, _ in geo.dgrad) > _lib.REPACK_JOB_TAPS:
+        return None
+    key = (w.data_ptr(), geo.key, bool(bf16))
+    entry = wp.repacks.get(key)
+    if entry is not None:
+        entry['used'] = wp.step
+        if key in wp.prepared:
+            return entry['buf']
+    lib = _lib.load()
+    if entry is None:
+        if len(wp.order) >= _MAX_PREP_JOBS or torch.cuda.is_current_stream_capturing():
+            return None
+        buf = torch.empty(geo.dgrad_weight_floats, device=w.device, dtype=BF16 if bf16 else torch.float32)
+        jobs = []
+        for d, tapsel, off in geo.dgrad:
+            j = _lib.RepackJob()
+            j.src, j.dst = w.data_ptr(), buf.data_ptr() + off * buf.element_size()
+            j.Cout, j.Cin, j.src_taps, j.ntaps = geo.Cout, geo.Cin, geo.k * geo.k, d.ntaps
+            for t in range(d.ntaps):
+                j.tapsel[t] = tapsel[t]
+            j.tiles_co, j.tiles_ci, j.dst_bf16 = (geo.Cout + 31) // 32, (geo.Cin + 31) // 32, int(bool(bf16))
+            jobs.append(j)
+        entry = wp.repacks[key] = {'buf': buf, 'jobs': jobs, 'w': w, 'used': wp.step}      # `w` keeps the source (its arena) alive
+        wp.order.append(key)
+        wp.dirty = True
+    fn = lib.loans_repack_dgrad_bf16 if bf16 else lib.loans_repack_dgrad_f32
+    for d, tapsel, off in geo.dgrad:
+        check(fn(_ptr(w), _ptr(entry['buf'][off:]), geo.Cout, geo.Cin, geo.k * geo.k, tapsel, d.ntaps, _stream()),
+              'loans_repack_dgrad')
+    return entry['buf']
+
+
 def begin_step(device):
-    """Called by the updater at the start of a training step (see _ZeroPool)."""
+    """Called by the updater at the start of a training step: one memset for the step's accumulators (_ZeroPool), the step's
+    weight preparation (_WeightPrep)."""
     device = torch.device(device) if not isinstance(device, torch.device) else device
     idx = device.index if device.index is not None else torch.cuda.current_device()
     _zero_pools.setdefault(idx, _ZeroPool()).begin(torch.device('cuda', idx))
+    if WEIGHT_PREP:
+        _weight_preps.setdefault(idx, _WeightPrep()).begin(torch.device('cuda', idx))
 
 
 def end_step(device=None):
-    """Accumulators requested after this come from `torch.zeros` again (the pool is only valid inside a step)."""
+    """Accumulators requested after this come from `torch.zeros` again (the pool is only valid inside a step), weights are
+    cast / re-packed per call again (the optimisers have moved them)."""
     for p in _zero_pools.values():
         p.live = False
+    for wp in _weight_preps.values():
+        wp.live = False
 
 
 def _zeros_f64(shape, device):

@@ -491,6 +491,10 @@ class ParamArena:
             if isinstance(v, np.ndarray) and v.dtype.kind == 'f':
                 object.__setattr__(link, n, torch.from_numpy(v.astype(np.float32)).to(device))
         self.active_numel = total
+        self.data16 = None          # bf16 shadow of `data`, made and refreshed by ops._WeightPrep (bf16 arm)
+        if device.type == 'cuda':
+            from .. import ops
+            ops.register_arena(self)
 
     def set_active(self, first_unused_cold_link=None):
         """Everything from `first_unused_cold_link` on is not touched by the current graph."""

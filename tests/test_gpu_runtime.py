@@ -95,3 +95,44 @@ def test_adam_keeps_stepping_parameters_that_lost_their_gradient(deterministic_f
     assert off.max() < 1.5e-3 and np.mean(off > 5e-5) < 5e-3, (off.max(), np.mean(off > 5e-5))
     for key in ('res6/1/bn2/gamma', 'res6/0/bn3/beta'):
         assert np.abs(s2[key] - s1[key]).max() > 0
+
+
+def test_weight_preparation_once_per_step():
+    """ops._WeightPrep: inside a step the data gradients take their re-packed weights from ONE batched launch at the step's
+    start (loans_repack_dgrad_batch; bf16 arm: forward weights from the arena's bf16 shadow) instead of per-class launches --
+    same bytes as the per-call form, refreshed after the weights moved, per-call again outside a step"""
+    import numpy as np
+    import torch
+    from loans_amd import _lib, ops
+    from tests.gpu_util import dev
+    rng = np.random.RandomState(2)
+    dev0 = torch.device('cuda', 0)
+    for bf16 in (False, True):
+        geo = ops.ConvGeometry(2, 10, 12, 64, 128, 3, 2, 1)          # strided: four stride-parity classes
+        geo1 = ops.ConvGeometry(2, 10, 12, 64, 128, 3, 1, 1)
+        w = dev(rng.standard_normal((128, 3, 3, 64)).astype(np.float32))
+
+        def per_call(g):
+            out = torch.empty(g.dgrad_weight_floats, device='cuda', dtype=torch.bfloat16 if bf16 else torch.float32)
+            fn = _lib.load().loans_repack_dgrad_bf16 if bf16 else _lib.load().loans_repack_dgrad_f32
+            for d, tapsel, off in g.dgrad:
+                ops.check(fn(w.data_ptr(), out[off:].data_ptr(), g.Cout, g.Cin, 9, tapsel, d.ntaps, ops._stream()), 'repack')
+            return out
+        assert ops._prepacked_dgrad_weights(w, geo, bf16) is None                      # outside a step
+        ops.begin_step(dev0)
+        first = [ops._prepacked_dgrad_weights(w, g, bf16) for g in (geo, geo1)]          # registered, filled per call
+        assert all(torch.equal(a, per_call(g)) for a, g in zip(first, (geo, geo1)))
+        ops.end_step()
+        w.mul_(-0.5)                                                                     # "the optimiser's update"
+        ops.begin_step(dev0)                                                             # one launch fills both
+        wp = ops._weight_preps[0]
+        assert {(w.data_ptr(), geo.key, bf16), (w.data_ptr(), geo1.key, bf16)} <= wp.prepared
+        again = [ops._prepacked_dgrad_weights(w, g, bf16) for g in (geo, geo1)]
+        assert all(a.data_ptr() == b.data_ptr() for a, b in zip(first, again))          # persistent buffers
+        assert all(torch.equal(a, per_call(g)) for a, g in zip(again, (geo, geo1)))
+        ops.end_step()
+        assert ops._prepacked_dgrad_weights(w, geo, bf16) is None
+        for _ in range(4):                                                               # unused for some steps: dropped
+            ops.begin_step(dev0)
+            ops.end_step()
+        assert (w.data_ptr(), geo.key, bf16) not in ops._weight_preps[0].repacks
