@@ -46,12 +46,12 @@ def _whole_net_active(loc):
     return a.active_numel == a.cold_offsets.get('feature_extractor/fc6', a.numel) and a.active_numel > a.cold_offsets['res7']
 
 
-def _updater(loc, dis, frames_d, real_d, labels_d):
+def _updater(loc, dis, frames_d, real_d, labels_d, lr=1e-3):
     return loans_amd.SheepAssessor(
         models=[loc, dis], iterator={'main': training.DeviceBatchIterator([frames_d]),
                                      'real': training.DeviceBatchIterator([(real_d, labels_d)])},
-        optimizer={'opt_gen': loans_amd.Adam(alpha=1e-3, amsgrad=True).setup(loc),
-                   'opt_dis': loans_amd.Adam(alpha=1e-3, amsgrad=True).setup(dis)},
+        optimizer={'opt_gen': loans_amd.Adam(alpha=lr, amsgrad=True).setup(loc),
+                   'opt_dis': loans_amd.Adam(alpha=lr, amsgrad=True).setup(dis)},
         converter=training.identity_converter, device=0)
 
 
@@ -256,6 +256,49 @@ def test_cfg2_bf16_crop_path_and_assessor_against_bf16_rounded_oracle(bf16_arm, 
     de = {k: _l2(p.grad_logical(), emu['dis_grads'][k[1:]]) for k, p in dis.namedparams()}
     print('assessor gradients vs emulated oracle:', {k: '%.3f' % v for k, v in de.items()})
     assert max(de.values()) < 0.05, de
+
+
+def test_bf16_three_steps_teacher_forced_against_bf16_rounded_oracle(bf16_arm, deterministic_forward):
+    """A short TRAJECTORY check of the bf16 arm that does not decorrelate: three consecutive `update_core`s of the HIP step
+    (its own Adam states, BN running statistics, parameters), and before each of them the bf16-rounding oracle is re-seeded
+    from the HIP parameters and runs the same step once.  What one step adds -- losses, theta, the crops' scores -- is bounded
+    per step although a free run of two bf16 networks would drift apart; the frame is small (the backbone ends after
+    8 units at 128 px), theta comes out of a seeded non-zero param_predictor.W.  PARITY UNPINNED: the oracle is
+    this repository's restatement of Chainer's arithmetic."""
+    B, H, W, crop = 4, 128, 128, (16, 16)
+    frames, real, labels = inputs(81, B, H, W, crop)
+    f64 = [a.astype(np.float64) for a in (frames, real, labels)]
+    np.random.seed(82)
+    loc, dis = loans_amd.SheepLocalizer(crop), loans_amd.ResnetAssessor()
+    randomize_bn_and_predictor(loc, np.random.RandomState(83))
+    with loans_amd.using_config('enable_backprop', False):
+        dis(dev(real))
+    loc.finalize(torch.device('cuda', 0))
+    upd = _updater(loc, dis, dev(frames), dev(real), dev(labels), lr=1e-4)
+    worst = {'loss_localizer': 0.0, 'loss_dis': 0.0, 'theta': 0.0}
+    moved = 0.0
+    for step in range(3):
+        lp, dp = oracle_params(loc, np.float64), oracle_params(dis, np.float64)
+        with M.emulate_bf16_storage():
+            emu = M.update_core(lp, dp, M.AdamAMSGrad(lp, alpha=1e-4), M.AdamAMSGrad(dp, alpha=1e-4), f64[0], f64[1], f64[2], crop,
+                                rng=np.random.RandomState(0))
+        before = loc.param_predictor.b.get_logical().copy()
+        upd.update()
+        obs = loans_amd.reporter.observation
+        theta = loc.last_transform_params.data.cpu().numpy().reshape(B, 6)
+        errs = {'loss_localizer': abs(float(obs['loss_localizer']) - emu['loss_localizer']) / max(abs(emu['loss_localizer']), 1e-6),
+                'loss_dis': abs(float(obs['loss_dis']) - emu['loss_dis']) / max(abs(emu['loss_dis']), 1e-6),
+                'theta': float(np.abs(theta - emu['theta'].reshape(B, 6)).max())}
+        print('step %d: loss_localizer %.5f (oracle %.5f), loss_dis %.5f (oracle %.5f), max |theta - oracle| %.2e'
+              % (step + 1, float(obs['loss_localizer']), emu['loss_localizer'], float(obs['loss_dis']), emu['loss_dis'], errs['theta']))
+        for k in worst:
+            worst[k] = max(worst[k], errs[k])
+        moved = max(moved, float(np.abs(loc.param_predictor.b.get_logical() - before).max()))
+    assert moved > 5e-5                                       # the HIP trajectory is a trajectory: parameters move every step
+    # measured: loss_localizer within 5e-5 / 3.8e-3 / 3.3e-3 relative, loss_dis within 1e-5, theta within 3.4e-3 / 6.0e-3 / 3.4e-3
+    # over the three steps (losses move from 7.9 to 1.1 meanwhile) -- one step's bf16 rounding each time, not a drift that
+    # grows with the step number
+    assert worst['loss_localizer'] < 2e-2 and worst['loss_dis'] < 2e-2 and worst['theta'] < 1e-2, worst
 
 
 # --------------------------------------------------------------------------------------------------------------------------

@@ -12,7 +12,7 @@ from oracle import chainer_ops as C
 from oracle import model as M
 from tests.gpu_util import build_pair, dev, inputs, oracle_params, rel_err
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures('kernel_selection')]
 TOL = 1e-4      # BASELINE.json: outputs within 1e-4 fp32
 
 

@@ -13,7 +13,7 @@ from oracle import model as M
 from tests.gpu_util import build_pair, dev, inputs, oracle_params, rel_err
 from tests.test_gpu_model import _updater
 
-pytestmark = pytest.mark.gpu
+pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures('kernel_selection')]
 
 
 def test_res6_res7_gradients_and_update_parity(deterministic_forward):
