@@ -61,6 +61,14 @@ extern "C" {
 
 #define LOANS_F_OUT_BF16 128   /* loans_igemm_bf16_f32 only: `out` is a bf16 tensor (fp32 in, bf16 out: the stem conv of the bf16
                                   storage arm); not with MASK / ADDEND */
+#define LOANS_F_BNSUMS  512   /* data gradients only (loans_igemm_f32 / loans_igemm_bf16s; no other epilogue flag): the launch's output g is the
+                                  gradient that reaches a BatchNormalization whose own ReLU follows it (sheep/resnet.py:137,157).  `ref` is that
+                                  BN's INPUT y (same shape as out), `bias` its coefficient table float[4][C] = mean, rstd, scale, shift (C = out
+                                  channels) and `stats` fp64 accumulators [LOANS_STATS_REPLICAS][2][C]: the epilogue adds sum_m g m and
+                                  sum_m g m (y - mean) with m = (y scale + shift > 0) -- the two sums of that BN's backward, taken from the tile
+                                  while it is in registers instead of by a pass over the stored tensor (loans_bn_bwd_reduce_xmask_*); g is
+                                  stored unmasked, on bf16 tensors the sums use the ROUNDED g the later passes will read.  Not with split-K /
+                                  fine-tail tiles, LOANS_TILE_WS64, class launches. */
 #define LOANS_F_GY_BF16  256   /* loans_wgrad_bf16_f32 only: `gy` is a bf16 tensor, x stays fp32 (the stem's weight gradient) */
 
 /*
@@ -334,6 +342,10 @@ int loans_bn_bwd_reduce_f32(const float* gy, const float* mask, const float* x, 
 int loans_bn_bwd_coeffs_f32(const double* sums, int32_t C, int64_t count, const float* gamma,
                             const float* mean, const float* rstd, float* ggamma, float* gbeta,
                             float* k1, float* k2, float* k3, void* stream);
+/* the same from the sums a data gradient's epilogue took (LOANS_F_BNSUMS): `replicas` x [sum g m | sum g m (y - mean)][C] */
+int loans_bn_bwd_coeffs_rep_f32(const double* sums, int32_t replicas, int32_t C, int64_t count, const float* gamma,
+                                const float* mean, const float* rstd, float* ggamma, float* gbeta, float* k1,
+                                float* k2, float* k3, void* stream);
 /* gx = k1*g + k2*x + k3, g = gy*(mask>0); optional second output for (x2, k1b, k2b, k3b) */
 int loans_bn_bwd_apply_f32(const float* gy, const float* mask, const float* x,
                            const float* k1, const float* k2, const float* k3, float* gx,

@@ -15,6 +15,7 @@ MAX_TAPS = 64
 F_RELU_IN, F_BIAS, F_STATS, F_MASK, F_ADDEND, F_ADDEND_MASK = 1, 2, 4, 8, 16, 32
 F_DENSE = 64
 F_OUT_BF16, F_GY_BF16 = 128, 256
+F_BNSUMS = 512
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_256x64 = 0, 1, 2, 3, 4
 TILE_256x128, TILE_DMA = 7, 16
 
@@ -117,6 +118,7 @@ SIGNATURES = {
     'loans_maxpool_relu_bwd_f32': [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p],
     'loans_bn_bwd_reduce_f32': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p],
     'loans_bn_bwd_coeffs_f32': [_p, _i32, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    'loans_bn_bwd_coeffs_rep_f32': [_p, _i32, _i32, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     'loans_bn_bwd_apply_f32': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p],
     'loans_colsum_f32': [_p, _p, _i64, _i32, _p],
     'loans_gap_fwd_f32': [_p, _p, _i32, _i32, _i32, _p],

@@ -226,6 +226,25 @@ __global__ void bn_bwd_coeffs_kernel(const double* sums, int C, double inv_count
     k3[c] = (float)(a * ((double)mean[c] * (double)rstd[c] * dg - db) * inv_count);
 }
 
+// the same from the sums a data gradient's epilogue took (LOANS_F_BNSUMS): `reps` replicas of [sum g m | sum g m (y - mean)]
+__global__ void bn_bwd_coeffs_rep_kernel(const double* sums, int reps, int C, double inv_count, const float* gamma, const float* mean,
+                                         const float* rstd, float* ggamma, float* gbeta, float* k1, float* k2, float* k3) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    double db = 0.0, dc = 0.0;
+    for (int r = 0; r < reps; ++r) {
+        db += sums[(size_t)r * 2 * C + c];
+        dc += sums[(size_t)r * 2 * C + C + c];
+    }
+    const double dg = dc * (double)rstd[c];                 // sum g m xhat
+    ggamma[c] += (float)dg;
+    gbeta[c] += (float)db;
+    const double a = (double)gamma[c] * (double)rstd[c];
+    k1[c] = (float)a;
+    k2[c] = (float)(-a * (double)rstd[c] * dg * inv_count);
+    k3[c] = (float)(a * ((double)mean[c] * (double)rstd[c] * dg - db) * inv_count);
+}
+
 template <bool DUAL, int MASK, typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_kernel(const T* gy, const T* mask, const T* x,
                                                            const float* k1, const float* k2, const float* k3, T* gx,
@@ -721,6 +740,16 @@ extern "C" int loans_bn_bwd_coeffs_f32(const double* sums, int32_t C, int64_t co
                                        float* k2, float* k3, void* stream) {
     if (!sums || !gamma || !mean || !rstd || !ggamma || !gbeta || !k1 || !k2 || !k3 || C <= 0 || count <= 0) return LOANS_EINVAL;
     hipLaunchKernelGGL(bn_bwd_coeffs_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), sums, C,
+                       1.0 / (double)count, gamma, mean, rstd, ggamma, gbeta, k1, k2, k3);
+    LOANS_LAUNCH_CHECK();
+    return LOANS_OK;
+}
+
+extern "C" int loans_bn_bwd_coeffs_rep_f32(const double* sums, int32_t replicas, int32_t C, int64_t count, const float* gamma,
+                                           const float* mean, const float* rstd, float* ggamma, float* gbeta, float* k1,
+                                           float* k2, float* k3, void* stream) {
+    if (!sums || !gamma || !mean || !rstd || !ggamma || !gbeta || !k1 || !k2 || !k3 || C <= 0 || count <= 0 || replicas <= 0) return LOANS_EINVAL;
+    hipLaunchKernelGGL(bn_bwd_coeffs_rep_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), sums, replicas, C,
                        1.0 / (double)count, gamma, mean, rstd, ggamma, gbeta, k1, k2, k3);
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;

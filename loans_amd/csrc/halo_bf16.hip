@@ -290,6 +290,7 @@ __global__ __launch_bounds__(64 * WM * WN) void halo16_kernel(const Halo16Args a
     const bool f_bias = d.flags & LOANS_F_BIAS, f_stats = d.flags & LOANS_F_STATS;
     const bool f_mask = d.flags & LOANS_F_MASK, f_add = d.flags & LOANS_F_ADDEND;
     const bool f_addmask = d.flags & LOANS_F_ADDEND_MASK;
+    const bool f_bnsums = d.flags & LOANS_F_BNSUMS;            // see igemm16_kernel
     constexpr int LDC = BN + 4;
     float* Cs = reinterpret_cast<float*>(smem);
     __syncthreads();
@@ -359,6 +360,17 @@ __global__ __launch_bounds__(64 * WM * WN) void halo16_kernel(const Halo16Args a
         v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
         return v;
     };
+    f32x4 bn_mean[2], bn_scale[2], bn_shift[2], bn_s1[2], bn_s2[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) { bn_mean[q] = bn_scale[q] = bn_shift[q] = bn_s1[q] = bn_s2[q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    if (f_bnsums && !cbad) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            bn_mean[q] = *reinterpret_cast<const f32x4*>(a.bias + col0 + 4 * q);
+            bn_scale[q] = *reinterpret_cast<const f32x4*>(a.bias + 2 * d.Cout + col0 + 4 * q);
+            bn_shift[q] = *reinterpret_cast<const f32x4*>(a.bias + 3 * d.Cout + col0 + 4 * q);
+        }
+    }
 #pragma unroll
     for (int p = 0; p < BM / RSTEP; ++p) {
         const int row = r0 + p * RSTEP;
@@ -384,7 +396,41 @@ __global__ __launch_bounds__(64 * WM * WN) void halo16_kernel(const Halo16Args a
         const bf16x4_t ol = __builtin_convertvector(lo, bf16x4_t), oh = __builtin_convertvector(hi, bf16x4_t);
         o[0] = ol[0]; o[1] = ol[1]; o[2] = ol[2]; o[3] = ol[3];
         o[4] = oh[0]; o[5] = oh[1]; o[6] = oh[2]; o[7] = oh[3];
+        if (f_bnsums && off != 0xFFFFFFFFu) {
+            const bf16x8_t yv = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_ref, (int)off, 0, 0));
+            const f32x4 y2[2] = {lo4(yv), hi4(yv)};
+            const f32x4 g2[2] = {__builtin_convertvector(ol, f32x4), __builtin_convertvector(oh, f32x4)};
+#pragma unroll
+            for (int q = 0; q < 2; ++q) {
+                const f32x4 gm = keep_pos(g2[q], y2[q] * bn_scale[q] + bn_shift[q]);
+                bn_s1[q] += gm;
+                bn_s2[q] += gm * (y2[q] - bn_mean[q]);
+            }
+        }
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_out, (int)off, 0, 0);
+    }
+    if (f_bnsums) {
+        __syncthreads();
+        float* Red = reinterpret_cast<float*>(smem);            // [NT / CPR][CPR][16]
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                Red[(r0 * CPR + oc8) * 16 + q * 4 + e] = bn_s1[q][e];
+                Red[(r0 * CPR + oc8) * 16 + 8 + q * 4 + e] = bn_s2[q][e];
+            }
+        __syncthreads();
+        if (tid < CPR * 16) {
+            const int u8 = tid >> 4, j = tid & 15;
+            float acc_ = 0.f;
+#pragma unroll 4
+            for (int rr = 0; rr < NT / CPR; ++rr) acc_ += Red[(rr * CPR + u8) * 16 + j];
+            const int col = tn * BN + u8 * 8 + (j & 7);
+            if (col < d.Cout) {
+                double* st = a.stats + (size_t)(blockIdx.x % LOANS_STATS_REPLICAS) * 2 * d.Cout;
+                atomic_add_f64(st + (j >> 3) * d.Cout + col, (double)acc_);
+            }
+        }
     }
 }
 
@@ -645,6 +691,7 @@ __global__ __launch_bounds__(512, 1) void wsw_kernel(const Halo16Args a, int nun
     const int fragB = r * BKH + ((h ^ ((r >> 1) & 7)) & 7) * 8;
     const bool f_bias = d.flags & LOANS_F_BIAS, f_stats = d.flags & LOANS_F_STATS;
     const bool f_mask = d.flags & LOANS_F_MASK, f_add = d.flags & LOANS_F_ADDEND, f_addmask = d.flags & LOANS_F_ADDEND_MASK;
+    const bool f_bnsums = d.flags & LOANS_F_BNSUMS;            // see igemm16_kernel
     const float bv0 = (f_bias && r < d.Cout) ? a.bias[r] : 0.f, bv1 = (f_bias && r + 32 < d.Cout) ? a.bias[r + 32] : 0.f;
     double st_s0 = 0.0, st_q0 = 0.0, st_s1 = 0.0, st_q1 = 0.0;
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)a.out_bytes, 0x00020000);
@@ -665,6 +712,18 @@ __global__ __launch_bounds__(512, 1) void wsw_kernel(const Halo16Args a, int nun
         v.z = m_.z > 0.f ? v.z : 0.f; v.w = m_.w > 0.f ? v.w : 0.f;
         return v;
     };
+    // LOANS_F_BNSUMS: this lane's eight channels of the BN's coefficient table and its sums over all units of this wave
+    f32x4 bn_mean[2], bn_scale[2], bn_shift[2], bn_s1[2], bn_s2[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) { bn_mean[q] = bn_scale[q] = bn_shift[q] = bn_s1[q] = bn_s2[q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    if (f_bnsums && !cbad) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            bn_mean[q] = *reinterpret_cast<const f32x4*>(a.bias + oc8 * 8 + 4 * q);
+            bn_scale[q] = *reinterpret_cast<const f32x4*>(a.bias + 2 * d.Cout + oc8 * 8 + 4 * q);
+            bn_shift[q] = *reinterpret_cast<const f32x4*>(a.bias + 3 * d.Cout + oc8 * 8 + 4 * q);
+        }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                    // the weights are in LDS: the only block barrier of the kernel
 
@@ -793,8 +852,36 @@ __global__ __launch_bounds__(512, 1) void wsw_kernel(const Halo16Args a, int nun
             const bf16x4_t ol = __builtin_convertvector(lo[it], bf16x4_t), oh = __builtin_convertvector(hi[it], bf16x4_t);
             o[0] = ol[0]; o[1] = ol[1]; o[2] = ol[2]; o[3] = ol[3];
             o[4] = oh[0]; o[5] = oh[1]; o[6] = oh[2]; o[7] = oh[3];
+            if (f_bnsums && off != 0xFFFFFFFFu) {
+                const bf16x8_t yv = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_ref, (int)off, 0, 0));
+                const f32x4 y2[2] = {lo4(yv), hi4(yv)};
+                const f32x4 g2[2] = {__builtin_convertvector(ol, f32x4), __builtin_convertvector(oh, f32x4)};
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const f32x4 gm = keep_pos(g2[q], y2[q] * bn_scale[q] + bn_shift[q]);
+                    bn_s1[q] += gm;
+                    bn_s2[q] += gm * (y2[q] - bn_mean[q]);
+                }
+            }
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_out, (int)off, 0, 0);
         }
+    }
+    if (f_bnsums) {
+        // the eight lanes that share a channel unit (lane & 7) differ in lane >> 3: butterfly over those bits, then lanes 0..7
+        // hold the wave's sums of their eight channels
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                float v1 = bn_s1[q][e], v2 = bn_s2[q][e];
+#pragma unroll
+                for (int o_ = 8; o_ < 64; o_ <<= 1) { v1 += __shfl_xor(v1, o_, 64); v2 += __shfl_xor(v2, o_, 64); }
+                if (lane < 8 && !cbad) {
+                    double* st = a.stats + (size_t)((blockIdx.x * 8 + wave) % LOANS_STATS_REPLICAS) * 2 * d.Cout;
+                    atomic_add_f64(st + oc8 * 8 + q * 4 + e, (double)v1);
+                    atomic_add_f64(st + d.Cout + oc8 * 8 + q * 4 + e, (double)v2);
+                }
+            }
     }
     if (f_stats) {
         st_s0 += __shfl_xor(st_s0, 32, 64); st_q0 += __shfl_xor(st_q0, 32, 64);
@@ -855,6 +942,7 @@ int launch_halo(Halo16Args& a, hipStream_t st) {
 // 1 if the descriptor is a geometry the halo kernels cover (the caller -- loans_igemm_bf16s -- has validated everything else)
 int loans_halo16_covers(const loans_igemm_desc* d, int tile) {
     if (d->flags & LOANS_F_DENSE) return 0;
+    if ((d->flags & LOANS_F_BNSUMS) && tile == LOANS_TILE_WS64) return 0;        // ws8_kernel's epilogue does not take the BN sums
     if (d->isy != 1 || d->isx != 1 || d->osy != 1 || d->osx != 1 || d->oy0 || d->ox0) return 0;
     if (d->gridH != d->outH || d->gridW != d->outW) return 0;
     if (d->Cin % 64 || d->ntaps > 9) return 0;

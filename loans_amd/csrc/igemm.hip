@@ -619,6 +619,7 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     const bool f_bias = d.flags & LOANS_F_BIAS, f_stats = d.flags & LOANS_F_STATS;
     const bool f_mask = d.flags & LOANS_F_MASK, f_add = d.flags & LOANS_F_ADDEND;
     const bool f_addmask = d.flags & LOANS_F_ADDEND_MASK;
+    const bool f_bnsums = d.flags & LOANS_F_BNSUMS;      // the sums of the BN below a data gradient, from the tile (loans_hip.h)
     constexpr int LDC = BN + 4;
     float* Cs = reinterpret_cast<float*>(smem);          // [BM][LDC]
     __builtin_amdgcn_s_setprio(3);
@@ -680,6 +681,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
     const unsigned coff = (unsigned)col0 * (f_out16 ? 2u : 4u);
     f32x4 bv4 = {0.f, 0.f, 0.f, 0.f};
     if (f_bias && !cbad) bv4 = *reinterpret_cast<const f32x4*>(a.bias + col0);
+    // LOANS_F_BNSUMS: a.bias = the BN's coefficient table [mean | rstd | scale | shift][Cout]; this thread's four channels
+    f32x4 bn_mean = {0.f, 0.f, 0.f, 0.f}, bn_scale = bn_mean, bn_shift = bn_mean, bn_s1 = bn_mean, bn_s2 = bn_mean;
+    if (f_bnsums && !cbad) {
+        bn_mean = *reinterpret_cast<const f32x4*>(a.bias + col0);
+        bn_scale = *reinterpret_cast<const f32x4*>(a.bias + 2 * Cout + col0);
+        bn_shift = *reinterpret_cast<const f32x4*>(a.bias + 3 * Cout + col0);
+        bv4 = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
     if (my_splits > 1) {
         // split-K: the raw partial tile is added to `out` (zeroed, or holding the addend, by the caller); bias, statistics,
         // mask and addend are applied to the finished sums by loans_igemm_finalize_f32
@@ -718,6 +727,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
         } else if (f_add) {
             v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_add, (int)off, 0, 0));
         }
+        if (f_bnsums && off != 0xFFFFFFFFu) {
+            const f32x4 y = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_ref, (int)off, 0, 0));
+            const f32x4 z = y * bn_scale + bn_shift;
+            f32x4 gm;
+            gm.x = z.x > 0.f ? v.x : 0.f; gm.y = z.y > 0.f ? v.y : 0.f;
+            gm.z = z.z > 0.f ? v.z : 0.f; gm.w = z.w > 0.f ? v.w : 0.f;
+            bn_s1 += gm;
+            bn_s2 += gm * (y - bn_mean);
+        }
 #ifdef LOANS_EXPERIMENT
         if ((a.dbg & 8) && v.x != 12345.f) continue;      // no output stores
 #endif
@@ -727,6 +745,29 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
             continue;
         }
         __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_out, (int)off, 0, 0);
+    }
+    if (f_bnsums) {
+        // the threads that share a channel quad (same oc4, RSTEP rows apart) are summed through LDS, then one fp64 atomic per
+        // channel and sum into this block's replica
+        __syncthreads();
+        float* Red = reinterpret_cast<float*>(smem);            // [256 / CPR][CPR][8]
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            Red[(r0 * CPR + oc4) * 8 + e] = bn_s1[e];
+            Red[(r0 * CPR + oc4) * 8 + 4 + e] = bn_s2[e];
+        }
+        __syncthreads();
+        if (tid < CPR * 8) {
+            const int u4 = tid >> 3, j = tid & 7;               // channel quad, (sum, channel of the quad)
+            float acc_ = 0.f;
+#pragma unroll 4
+            for (int rr = 0; rr < 256 / CPR; ++rr) acc_ += Red[(rr * CPR + u4) * 8 + j];
+            const int col = tn * BN + u4 * 4 + (j & 3);
+            if (col < Cout) {
+                double* st = stats_sel + (size_t)(blockIdx.x % LOANS_STATS_REPLICAS) * 2 * Cout;
+                atomic_add_f64(st + (j >> 2) * Cout + col, (double)acc_);
+            }
+        }
     }
 #ifdef LOANS_STAMPS
     unsigned long long t_end = 0;
@@ -876,6 +917,12 @@ static int igemm_impl(const float* in, const float* w, float* out, const float* 
     if ((d->flags & LOANS_F_ADDEND_MASK) && !(d->flags & LOANS_F_ADDEND)) return LOANS_EINVAL;
     if ((d->flags & LOANS_F_ADDEND) && !addend) return LOANS_EINVAL;
     if ((d->flags & LOANS_F_OUT_BF16) && (d->flags & (LOANS_F_MASK | LOANS_F_ADDEND | LOANS_F_ADDEND_MASK))) return LOANS_EINVAL;
+    if (d->flags & LOANS_F_BNSUMS) {        // a data gradient's epilogue takes the sums of the BN below it: nothing else rides along
+        if (!ref || !bias || !stats || pair || mc) return LOANS_EINVAL;
+        if (d->flags & (LOANS_F_BIAS | LOANS_F_STATS | LOANS_F_MASK | LOANS_F_ADDEND | LOANS_F_ADDEND_MASK | LOANS_F_DENSE | LOANS_F_OUT_BF16))
+            return LOANS_EINVAL;
+        if ((d->tile & 0xEF) == LOANS_TILE_FINETAIL) return LOANS_EINVAL;
+    }
     IgemmArgs a;
     a.in = in; a.w = w; a.out = out; a.bias = bias; a.stats = stats; a.ref = ref; a.addend = addend;
     a.d = *d;

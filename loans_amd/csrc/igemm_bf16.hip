@@ -418,6 +418,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm16_kernel(const Igemm16Args
     const bool f_bias = d.flags & LOANS_F_BIAS, f_stats = d.flags & LOANS_F_STATS;
     const bool f_mask = d.flags & LOANS_F_MASK, f_add = d.flags & LOANS_F_ADDEND;
     const bool f_addmask = d.flags & LOANS_F_ADDEND_MASK;
+    const bool f_bnsums = d.flags & LOANS_F_BNSUMS;
     constexpr int LDC = BN + 4;
     float* Cs = reinterpret_cast<float*>(smem);          // [BM / passes][LDC]
     __syncthreads();
@@ -477,6 +478,19 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm16_kernel(const Igemm16Args
         v.z = m.z > 0.f ? v.z : 0.f; v.w = m.w > 0.f ? v.w : 0.f;
         return v;
     };
+    // LOANS_F_BNSUMS: this thread's eight channels of the BN's coefficient table (a.bias = [mean | rstd | scale | shift][C]) and
+    // its partial sums over the rows it stores
+    f32x4 bn_mean[2], bn_scale[2], bn_shift[2], bn_s1[2], bn_s2[2];
+#pragma unroll
+    for (int q = 0; q < 2; ++q) { bn_mean[q] = bn_scale[q] = bn_shift[q] = bn_s1[q] = bn_s2[q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+    if (f_bnsums && !cbad) {
+#pragma unroll
+        for (int q = 0; q < 2; ++q) {
+            bn_mean[q] = *reinterpret_cast<const f32x4*>(a.bias + col0 + 4 * q);
+            bn_scale[q] = *reinterpret_cast<const f32x4*>(a.bias + 2 * d.Cout + col0 + 4 * q);
+            bn_shift[q] = *reinterpret_cast<const f32x4*>(a.bias + 3 * d.Cout + col0 + 4 * q);
+        }
+    }
     // the tile goes through the fp32 staging area in EP passes of PR rows (one pass for every tile whose [BM][BN + 4] floats
     // fit the operand stages; the 256 x 256 tile takes two): the waves that own the pass's rows write, everybody stores
     constexpr int EP = igemm16_epilogue_passes<BM, BN>();
@@ -537,7 +551,44 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm16_kernel(const Igemm16Args
             const bf16x4_t ol = __builtin_convertvector(lo, bf16x4_t), oh = __builtin_convertvector(hi, bf16x4_t);
             o[0] = ol[0]; o[1] = ol[1]; o[2] = ol[2]; o[3] = ol[3];
             o[4] = oh[0]; o[5] = oh[1]; o[6] = oh[2]; o[7] = oh[3];
+            if (f_bnsums && off != 0xFFFFFFFFu) {
+                // the BN's input tile; the sums take the ROUNDED gradient (what the apply pass will read back)
+                const bf16x8_t yv = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_ref, (int)off, 0, 0));
+                const f32x4 y2[2] = {cvt_lo(yv), cvt_hi(yv)};
+                const f32x4 g2[2] = {__builtin_convertvector(ol, f32x4), __builtin_convertvector(oh, f32x4)};
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const f32x4 gm = keep_pos(g2[q], y2[q] * bn_scale[q] + bn_shift[q]);
+                    bn_s1[q] += gm;
+                    bn_s2[q] += gm * (y2[q] - bn_mean[q]);
+                }
+            }
             __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_out, (int)off, 0, 0);
+        }
+    }
+    if (f_bnsums) {
+        // per block: the threads that share a channel unit (same oc8, RSTEP rows apart) are summed through LDS, then one fp64
+        // atomic per channel and sum into this block's replica
+        __syncthreads();
+        float* Red = reinterpret_cast<float*>(smem);            // [NT / CPR][CPR][16]
+#pragma unroll
+        for (int q = 0; q < 2; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                Red[(r0 * CPR + oc8) * 16 + q * 4 + e] = bn_s1[q][e];
+                Red[(r0 * CPR + oc8) * 16 + 8 + q * 4 + e] = bn_s2[q][e];
+            }
+        __syncthreads();
+        if (tid < CPR * 16) {
+            const int u8 = tid >> 4, j = tid & 15;              // channel unit, (sum, channel of the unit)
+            float acc_ = 0.f;
+#pragma unroll 4
+            for (int rr = 0; rr < NT / CPR; ++rr) acc_ += Red[(rr * CPR + u8) * 16 + j];
+            const int col = tn * BN + u8 * 8 + (j & 7);
+            if (col < d.Cout) {
+                double* st = a.stats + (size_t)(blockIdx.x % LOANS_STATS_REPLICAS) * 2 * d.Cout;
+                atomic_add_f64(st + (j >> 3) * d.Cout + col, (double)acc_);
+            }
         }
     }
 #ifdef LOANS_STAMPS
@@ -882,6 +933,10 @@ static int igemm_bf16s_impl(const void* in, const void* w, void* out, const floa
     }
     if ((d->flags & LOANS_F_BIAS) && !bias) return LOANS_EINVAL;
     if ((d->flags & LOANS_F_STATS) && !stats) return LOANS_EINVAL;
+    if (d->flags & LOANS_F_BNSUMS) {        // a data gradient's epilogue takes the sums of the BN below it: nothing else rides along
+        if (!ref || !bias || !stats || partial || pair) return LOANS_EINVAL;
+        if (d->flags & (LOANS_F_BIAS | LOANS_F_STATS | LOANS_F_MASK | LOANS_F_ADDEND | LOANS_F_ADDEND_MASK | LOANS_F_DENSE)) return LOANS_EINVAL;
+    }
     if ((d->flags & (LOANS_F_MASK | LOANS_F_ADDEND_MASK)) && !ref) return LOANS_EINVAL;
     if ((d->flags & LOANS_F_ADDEND_MASK) && !(d->flags & LOANS_F_ADDEND)) return LOANS_EINVAL;
     if ((d->flags & LOANS_F_ADDEND) && !addend) return LOANS_EINVAL;

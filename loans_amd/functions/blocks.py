@@ -182,9 +182,16 @@ class ResidualUnitFunction(Function):
             # dgrad first: the weight gradient goes to the side stream and, enqueued after the dgrad, starts when
             # that finishes -- it then overlaps the HBM-bound BN passes that follow instead of fighting the dgrad
             # for the matrix pipes
+            _, gp, bp = P[1 + 3 * (i - 1):4 + 3 * (i - 1)]
+            if ops.bn_sums_ok(self.geo[i], self.c[i - 1]) and ops.BN_XMASK:
+                # the two sums of BN i-1's backward ride in this dgrad's epilogue (its output tile meets the BN's input tile
+                # there): the reduction pass over gh disappears, the BN backward is one pass
+                gh, sums = ops.conv_dgrad(g, W.data, self.geo[i], bn_sums=(self.c[i - 1], self.st[i - 1]))
+                ops.conv_wgrad(self.h[i - 1], g, W.grad_view, self.geo[i])
+                g = ops.bn_backward_from_sums(gh, self.c[i - 1], self.st[i - 1], sums, gp.data, gp.grad_view, bp.grad_view)
+                continue
             gh = ops.conv_dgrad(g, W.data, self.geo[i])
             ops.conv_wgrad(self.h[i - 1], g, W.grad_view, self.geo[i])
-            _, gp, bp = P[1 + 3 * (i - 1):4 + 3 * (i - 1)]
             g = ops.bn_backward(gh, self.h[i - 1], self.c[i - 1], self.st[i - 1], gp.data, gp.grad_view, bp.grad_view,
                                 mask_is_own_relu=True)         # h[i-1] = relu(bn(c[i-1]))
         W0 = P[1]

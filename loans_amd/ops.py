@@ -13,8 +13,8 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (F_ADDEND, F_ADDEND_MASK, F_BIAS, F_DENSE, F_GY_BF16, F_MASK, F_OUT_BF16, F_RELU_IN, F_STATS, IgemmDesc,
-                   check)
+from ._lib import (F_ADDEND, F_ADDEND_MASK, F_BIAS, F_BNSUMS, F_DENSE, F_GY_BF16, F_MASK, F_OUT_BF16, F_RELU_IN, F_STATS,
+                   IgemmDesc, check)
 
 # Arithmetic of the convolution contractions: 'f32' (exact fp32 MFMA, the parity path) or 'bf16' (operands rounded
 # to bf16 while staged into LDS, bf16 MFMA, fp32 accumulate; tensors stay fp32 in memory).  BASELINE configs 3 / 5.
@@ -748,7 +748,7 @@ def _conv_fprop16(lib, x, w, geo, out, bias, stats, relu_in, addend, tile):
     return out
 
 
-def _conv_dgrad16(lib, gy, w, geo, out, mask_ref, addend, addend_mask_ref, tile):
+def _conv_dgrad16(lib, gy, w, geo, out, mask_ref, addend, addend_mask_ref, tile, bn_sums=None):
     if out is None:
         out = torch.empty((geo.B, geo.H, geo.W, geo.Cin), device=gy.device, dtype=BF16)
     assert out.dtype == BF16 and not _is16(w)
@@ -764,6 +764,12 @@ def _conv_dgrad16(lib, gy, w, geo, out, mask_ref, addend, addend_mask_ref, tile)
             (F_ADDEND_MASK if addend_mask_ref is not None else 0)
     ref = mask_ref if mask_ref is not None else addend_mask_ref
     assert not (mask_ref is not None and addend_mask_ref is not None)
+    coef = sums = None
+    if bn_sums is not None:             # LOANS_F_BNSUMS: the epilogue takes the two sums of the BN below (see conv_dgrad)
+        assert flags == 0 and len(geo.dgrad) == 1 and not geo.dgrad_has_empty_class
+        y, bst = bn_sums
+        assert _is16(y) and y.is_contiguous() and y.numel() == out.numel()
+        flags, ref, coef, sums = F_BNSUMS, y, bst.mean, stats_buffer(geo.Cin, gy.device)
     st = _stream()
     wp = _prepacked_dgrad_weights(w, geo, True)          # inside a step: made at its start, all layers in one launch
     if wp is None:
@@ -787,29 +793,46 @@ def _conv_dgrad16(lib, gy, w, geo, out, mask_ref, addend, addend_mask_ref, tile)
                                             C.byref(_with_flags(d, 0, t)), st), 'loans_igemm_bf16s[tune]')
         halo = _halo_tiles(geo, geo.Cout, geo.Cin, (geo.H, geo.W)) + _wide16_tiles(geo.Cin, geo.B * min(d.gridH * d.gridW for d, _, _ in geo.dgrad))
         sk = ()
-        if sk_ok:
+        if sk_ok and bn_sums is None:
             cls_rows = geo.B * min(d.gridH * d.gridW for d, _, _ in geo.dgrad)
             sk = _splitk16_candidates(cls_rows, geo.Cin, min(d.ntaps for d, _, _ in geo.dgrad) * geo.Cout)
-        tile = _tuned_tile(geo, 'bf16s_dgrad' + ('_h' if halo else '') + ('_sk' if sk else ''), run, _IGEMM16_TILES + halo + sk)
+        if bn_sums is not None:         # ws8_kernel's epilogue does not take the sums
+            halo = tuple(t for t in halo if t != TILE_WS64)
+        tile = _tuned_tile(geo, 'bf16s_dgrad' + ('_h' if halo else '') + ('_sk' if sk else '') + ('_bn' if bn_sums is not None else ''),
+                           run, _IGEMM16_TILES + halo + sk)
     if tile >> 8:
-        assert sk_ok
+        assert sk_ok and bn_sums is None
         _igemm16_splitk(lib, gy, dl, out, flags, tile, None, None, ref, addend, rows_in, geo.Cin, st)
         return out
     for d, tapsel, off in geo.dgrad:
         _with_flags(d, flags, tile)
-        check(lib.loans_igemm_bf16s(_ptr(gy), _ptr(wp[off:]), _ptr(out), 0, 0, _ptr(ref), _ptr(addend),
+        check(lib.loans_igemm_bf16s(_ptr(gy), _ptr(wp[off:]), _ptr(out), _ptr(coef), _ptr(sums), _ptr(ref), _ptr(addend),
                                     C.byref(d), st), 'loans_igemm_bf16s[dgrad]')
-    return out
+    return out if bn_sums is None else (out, sums)
 
 
-def conv_dgrad(gy, w, geo, out=None, mask_ref=None, addend=None, addend_mask_ref=None, tile=0):
+# LOANS_BN_FUSED_SUMS=0: the inner BNs' backward sums come from their own reduction pass again
+BN_FUSED_SUMS = os.environ.get('LOANS_BN_FUSED_SUMS', '1') != '0'
+
+
+def bn_sums_ok(geo, y):
+    """conv_dgrad(..., bn_sums=) covers this data gradient: one stride-parity class (stride 1), a gradient tensor the
+    row-reduction layout tiles, operands in one storage type"""
+    return BN_FUSED_SUMS and len(geo.dgrad) == 1 and not geo.dgrad_has_empty_class and not geo.dense and geo.Cin != 4 and \
+        geo.Cin % 8 == 0 and y.is_contiguous()
+
+
+def conv_dgrad(gy, w, geo, out=None, mask_ref=None, addend=None, addend_mask_ref=None, tile=0, bn_sums=None):
     """gx[B,H,W,Cin] = conv_transpose(gy, w); epilogue: (* (mask_ref>0)), (+ addend [masked by addend_mask_ref>0]).
-    Re-packs w per stride-parity class first (weights change every step)."""
+    Re-packs w per stride-parity class first (weights change every step).
+    bn_sums=(y, BNState): gx is the gradient that reaches a BatchNormalization (input y, batch coefficients in the BNState)
+    followed by its own ReLU; the epilogue also takes that BN's two backward sums from the tile (LOANS_F_BNSUMS) and the call
+    returns (gx, sums) with sums = fp64 [replicas][2][C] for bn_backward_from_sums -- the reduction pass over gx disappears."""
     lib = _lib.load()
     assert gy.numel() == geo.B * geo.Ho * geo.Wo * geo.Cout
     _count_flops('dgrad', geo)
     if _is16(gy) and geo.Cin != 4:
-        return _conv_dgrad16(lib, gy, w, geo, out, mask_ref, addend, addend_mask_ref, tile)
+        return _conv_dgrad16(lib, gy, w, geo, out, mask_ref, addend, addend_mask_ref, tile, bn_sums)
     if out is None:
         out = torch.empty((geo.B, geo.H, geo.W, geo.Cin), device=gy.device, dtype=torch.float32)
     if geo.dgrad_has_empty_class:
@@ -836,6 +859,12 @@ def conv_dgrad(gy, w, geo, out=None, mask_ref=None, addend=None, addend_mask_ref
             (F_ADDEND_MASK if addend_mask_ref is not None else 0)
     ref = mask_ref if mask_ref is not None else addend_mask_ref
     assert not (mask_ref is not None and addend_mask_ref is not None)
+    coef = sums = None
+    if bn_sums is not None:
+        assert flags == 0 and len(geo.dgrad) == 1 and not geo.dgrad_has_empty_class
+        y, bst = bn_sums
+        assert not _is16(y) and y.is_contiguous() and y.numel() == out.numel()
+        flags, ref, coef, sums = F_BNSUMS, y, bst.mean, stats_buffer(geo.Cin, gy.device)
     st = _stream()
     wp = _prepacked_dgrad_weights(w, geo, False)         # inside a step: made at its start, all layers in one launch
     if wp is None:
@@ -861,7 +890,9 @@ def conv_dgrad(gy, w, geo, out=None, mask_ref=None, addend=None, addend_mask_ref
                                      C.byref(_with_flags(d, 0, t)), st), 'loans_igemm[tune]')
         cl = _class_candidates(geo)
         cands, key = _IGEMM_TILES + cl, COMPUTE + 'dgrad' + ('_cl' if cl else '')
-        if not inplace_masked and reduce_channels_ok(geo.Cin):
+        if bn_sums is not None:
+            key += '_bn'
+        elif not inplace_masked and reduce_channels_ok(geo.Cin):
             # the smallest class grid decides: (Ho x Wo pixels of one parity class) x Cin columns, K = its taps x Cout
             cls_rows = geo.B * geo.dgrad[0][0].gridH * geo.dgrad[0][0].gridW
             sk = _splitk_candidates(cls_rows, geo.Cin, (min(d.ntaps for d, _, _ in geo.dgrad) * geo.Cout + 31) // 32)
@@ -875,9 +906,9 @@ def conv_dgrad(gy, w, geo, out=None, mask_ref=None, addend=None, addend_mask_ref
         return out
     for d, tapsel, off in geo.dgrad:
         _with_flags(d, flags, tile)
-        check(_igemm_fn(lib)(_ptr(gy), _ptr(wp[off:]), _ptr(out), 0, 0, _ptr(ref), _ptr(addend),
+        check(_igemm_fn(lib)(_ptr(gy), _ptr(wp[off:]), _ptr(out), _ptr(coef), _ptr(sums), _ptr(ref), _ptr(addend),
                              C.byref(d), st), 'loans_igemm[dgrad]')
-    return out
+    return out if bn_sums is None else (out, sums)
 
 
 # tile id bit (host side only): every stride-parity class of a strided data gradient in ONE launch (loans_igemm_classes_f32)
@@ -1505,6 +1536,27 @@ def bn_backward(gy, mask, x, st, gamma, ggamma, gbeta, x2=None, st2=None, gamma2
                                      _ptr(x2), _ptr(k[3]) if dual else 0, _ptr(k[4]) if dual else 0,
                                      _ptr(k[5]) if dual else 0, _ptr(gx2), rows, C_, s), 'loans_bn_bwd_apply_f32')
     return (gx, gx2) if dual else gx
+
+
+def bn_backward_from_sums(gy, x, st, sums, gamma, ggamma, gbeta):
+    """bn_backward(gy, relu(bn(x)), x, st, ..., mask_is_own_relu=True) with the reduction already done: `sums` are the
+    [replicas][2][C] accumulators conv_dgrad(..., bn_sums=(x, st)) filled while gy was in registers.  One pass over the
+    tensors (gx = k1 g m + k2 x + k3) instead of two."""
+    lib = _lib.load()
+    C_ = x.shape[-1]
+    rows = x.numel() // C_
+    s = _stream()
+    s16 = _is16(x)
+    assert _is16(gy) == s16 and sums.numel() == STATS_REPLICAS * 2 * C_
+    k = torch.empty((3, C_), device=x.device, dtype=torch.float32)
+    check(lib.loans_bn_bwd_coeffs_rep_f32(_ptr(sums), STATS_REPLICAS, C_, rows, _ptr(gamma), _ptr(st.mean), _ptr(st.rstd),
+                                          _ptr(ggamma), _ptr(gbeta), _ptr(k[0]), _ptr(k[1]), _ptr(k[2]), s),
+          'loans_bn_bwd_coeffs_rep_f32')
+    gx = torch.empty_like(x)
+    app_fn = lib.loans_bn_bwd_apply_xmask_bf16 if s16 else lib.loans_bn_bwd_apply_xmask_f32
+    check(app_fn(_ptr(gy), _ptr(x), _ptr(st.scale), _ptr(st.shift), _ptr(k[0]), _ptr(k[1]), _ptr(k[2]), _ptr(gx), rows, C_, s),
+          'loans_bn_bwd_apply_xmask')
+    return gx
 
 
 # LOANS_FUSED_STEM_TAIL=0 restores the three-pass form (maxpool_relu_bwd -> bn_backward)

@@ -511,3 +511,73 @@ def test_conv_pair_bf16_storage(case, tile):
         np.testing.assert_allclose(st.sum(0)[0].cpu().numpy(), y_ref.sum(axis=(0, 1, 2)), rtol=1e-5, atol=2e-3)
     y2a, y2b = ops.conv_fprop_pair(x, wa, wb, geo_a, geo_b, tile=tile)           # without statistics
     assert torch.equal(y2a, ya) and torch.equal(y2b, yb)
+
+
+@pytest.mark.parametrize("storage,tiles", [('f32', [0, 1, 2, 3, 4, 6, 17, 18, 19, 20]),
+                                           ('bf16', [0, 1, 2, 3, 4, 7, 9, 33, 34, 35, 11, 12, 13, 14, 36, 37])])
+@pytest.mark.parametrize("case", [(3, 64, 14, 14, 64, 3), (2, 128, 20, 33, 128, 3), (2, 256, 9, 12, 64, 3), (5, 64, 17, 12, 256, 1),
+                                  (2, 512, 6, 7, 128, 1)])
+def test_data_gradient_takes_the_bn_backward_sums(storage, tiles, case):
+    """LOANS_F_BNSUMS (round 3): the data gradient that feeds a BatchNormalization followed by its own ReLU
+    (sheep/resnet.py:137,157) takes that BN's two backward sums -- sum g m, sum g m (y - mean), m = (y scale + shift > 0) --
+    in its epilogue, from the tile it is about to store, and the BN backward becomes ONE pass (`bn_backward_from_sums`).
+    Every tile form that carries the flag, both storage types: the gradient tensor is bit-identical to the plain launch, the
+    BN backward equals the two-pass form (`bn_backward(..., mask_is_own_relu=True)`) to the order of the sums, and both equal
+    the oracle's bn_bwd of the masked gradient."""
+    from loans_amd import ops
+    B, C_, H, W, Cout, k = case          # C_ = channels of the gradient / of the BN; the conv maps C_ -> Cout
+    s16 = storage == 'bf16'
+    rng = np.random.RandomState(17)
+    rnd = _r if s16 else (lambda a: a.astype(np.float32))
+    up = d16 if s16 else dev
+    gy = rnd(rng.standard_normal((B, H, W, Cout)))
+    y = rnd(1.5 * rng.standard_normal((B, H, W, C_)) + 0.3 * rng.standard_normal(C_))
+    w = (rng.standard_normal((Cout, k, k, C_)) / np.sqrt(C_ * k * k)).astype(np.float32)
+    gamma = (1 + 0.2 * rng.standard_normal(C_)).astype(np.float32)
+    beta = (0.3 * rng.standard_normal(C_)).astype(np.float32)
+    geo = ops.ConvGeometry(B, H, W, C_, Cout, k, 1, k // 2)
+    stats = torch.zeros((ops.STATS_REPLICAS, 2, C_), device='cuda', dtype=torch.float64)
+    flat = torch.from_numpy(y.reshape(-1, C_).astype(np.float64)).cuda()
+    stats[0, 0], stats[0, 1] = flat.sum(0), (flat * flat).sum(0)
+    st = ops.bn_finalize(stats, B * H * W, dev(gamma), dev(beta), dev(np.zeros(C_, np.float32)), dev(np.ones(C_, np.float32)))
+    gyd, yd, wd = up(gy), up(y), dev(w)
+    act = ops.bn_apply(yd, st, relu=True)
+    assert ops.bn_sums_ok(geo, yd)
+    old = (ops.COMPUTE, ops.STORAGE)
+    if s16:
+        ops.set_compute_dtype('bf16'); ops.set_storage_dtype('bf16')
+    try:
+        ran = 0
+        for tile in tiles:
+            if s16 and tile in (11, 12, 13, 14, 36, 37) and tile not in ops._halo_tiles(geo, geo.Cout, geo.Cin, (geo.H, geo.W)):
+                continue
+            if s16 and tile == 9 and C_ % 256:
+                continue
+            plain = ops.conv_dgrad(gyd, wd, geo, tile=tile)
+            z = lambda: torch.zeros(C_, device='cuda')      # noqa: E731
+            gg0, gb0, gg1, gb1 = z(), z(), z(), z()
+            two_pass = ops.bn_backward(plain, act, yd, st, dev(gamma), gg0, gb0, mask_is_own_relu=True)
+            fused, sums = ops.conv_dgrad(gyd, wd, geo, tile=tile, bn_sums=(yd, st))
+            assert torch.equal(fused, plain), tile
+            one_pass = ops.bn_backward_from_sums(fused, yd, st, sums, dev(gamma), gg1, gb1)
+            tol = 2 * BF16_EPS if s16 else 2e-5
+            assert rel_err(one_pass.float().cpu().numpy(), two_pass.float().cpu().numpy()) < tol, tile
+            np.testing.assert_allclose(gg1.cpu().numpy(), gg0.cpu().numpy(), rtol=2e-4, atol=2e-3 * float(gg0.abs().max()))
+            np.testing.assert_allclose(gb1.cpu().numpy(), gb0.cpu().numpy(), rtol=2e-4, atol=2e-3 * float(gb0.abs().max()))
+            ran += 1
+        assert ran >= 6
+        # ... and against the oracle: bn_bwd of the masked gradient
+        g = plain.float().cpu().numpy().astype(np.float64)
+        yy = yd.float().cpu().numpy().astype(np.float64)
+        mean, var = yy.reshape(-1, C_).mean(0), yy.reshape(-1, C_).var(0)
+        rstd = 1 / np.sqrt(var + ops.BN_EPS)
+        xhat = (yy - mean) * rstd
+        gm = g * ((xhat * gamma + beta) > 0)
+        n = B * H * W
+        ref = gamma * rstd * (gm - gm.reshape(-1, C_).sum(0) / n - xhat * (gm * xhat).reshape(-1, C_).sum(0) / n)
+        assert rel_err(one_pass.float().cpu().numpy(), ref) < (2 * BF16_EPS if s16 else 1e-4)
+        np.testing.assert_allclose(gg1.cpu().numpy(), (gm * xhat).reshape(-1, C_).sum(0), rtol=1e-3, atol=1e-3 * np.abs(gm).sum() / C_)
+    finally:
+        ops.set_compute_dtype(old[0])
+        if old[1] == 'bf16':
+            ops.set_storage_dtype('bf16')
