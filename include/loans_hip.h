@@ -342,9 +342,21 @@ int loans_bn_bwd_reduce_f32(const float* gy, const float* mask, const float* x, 
 int loans_bn_bwd_coeffs_f32(const double* sums, int32_t C, int64_t count, const float* gamma,
                             const float* mean, const float* rstd, float* ggamma, float* gbeta,
                             float* k1, float* k2, float* k3, void* stream);
-/* the same from the sums a data gradient's epilogue took (LOANS_F_BNSUMS): `replicas` x [sum g m | sum g m (y - mean)][C] */
-int loans_bn_bwd_coeffs_rep_f32(const double* sums, int32_t replicas, int32_t C, int64_t count, const float* gamma,
-                                const float* mean, const float* rstd, float* ggamma, float* gbeta, float* k1,
+/* BN-backward reduction into REPLICATED accumulators (round 3; replaces loans_bn_bwd_reduce_* / _bits_* / _xmask_* where the
+ * channel count allows it: C / V a divisor of 256, V = 4 fp32 / 8 bf16 channels = one 16-byte unit): one entry per storage type,
+ * mask_kind 0 = none, 1 = g (mask > 0), 2 = g (x scale + shift > 0), 3 = sign bits.  `sums` fp64 [replicas][2][C], dual (x2 given)
+ * [replicas][4][C] = [sum g | sum g xhat | sum g | sum g xhat2], zeroed by the caller; blocks add into replica block % replicas
+ * (thousands of blocks on 2 C addresses cost more than the pass).  F.batch_normalization's backward, sheep/resnet.py:129-134. */
+int loans_bn_bwd_reduce_rep_f32(const float* gy, const void* mask, int32_t mask_kind, const float* x, const float* mean,
+                                const float* rstd, const float* x2, const float* mean2, const float* rstd2, const float* scale,
+                                const float* shift, double* sums, int32_t replicas, int64_t rows, int32_t C, void* stream);
+int loans_bn_bwd_reduce_rep_bf16(const void* gy, const void* mask, int32_t mask_kind, const void* x, const float* mean,
+                                 const float* rstd, const void* x2, const float* mean2, const float* rstd2, const float* scale,
+                                 const float* shift, double* sums, int32_t replicas, int64_t rows, int32_t C, void* stream);
+/* loans_bn_bwd_coeffs_f32 from `replicas` (<= 32) accumulators `rep_stride` doubles apart, each [sum g | second sum][C]; centred = 1:
+ * the second sum is sum g (y - mean) as a data gradient's epilogue took it (LOANS_F_BNSUMS), centred = 0: it is sum g xhat */
+int loans_bn_bwd_coeffs_rep_f32(const double* sums, int32_t replicas, int32_t rep_stride, int32_t centred, int32_t C, int64_t count,
+                                const float* gamma, const float* mean, const float* rstd, float* ggamma, float* gbeta, float* k1,
                                 float* k2, float* k3, void* stream);
 /* gx = k1*g + k2*x + k3, g = gy*(mask>0); optional second output for (x2, k1b, k2b, k3b) */
 int loans_bn_bwd_apply_f32(const float* gy, const float* mask, const float* x,

@@ -158,8 +158,20 @@ class _Staging:
             buf = ring['bufs'][i] = torch.empty(max(int(nbytes * 1.25), 1 << 20), dtype=torch.uint8).pin_memory()
         return ring, i, buf
 
+    def drop(self, thread_ident):
+        """forget (and free) the buffers of a thread that is gone -- a feed iterator's finish thread"""
+        ring = self.slots.pop(thread_ident, None)
+        if ring is not None:
+            for ev in ring['events']:
+                if ev is not None:
+                    ev.synchronize()
+
 
 _staging = _Staging()
+
+
+def release_staging(thread_ident):
+    _staging.drop(thread_ident)
 
 
 def frames_to_device(images, out_hw, device, augment_rows=None, map_fn=map):

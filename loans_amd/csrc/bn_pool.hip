@@ -229,19 +229,20 @@ __global__ void bn_bwd_coeffs_kernel(const double* sums, int C, double inv_count
 // the same from the sums a data gradient's epilogue took (LOANS_F_BNSUMS): `reps` (<= 32) replicas of
 // [sum g m | sum g m (y - mean)]; 32 lanes per channel fold the replicas with shuffles (a serial loop over 32 replicas cost 18 us
 // per call on 2048 channels)
-__global__ __launch_bounds__(256) void bn_bwd_coeffs_rep_kernel(const double* sums, int reps, int C, double inv_count, const float* gamma,
-                                                                const float* mean, const float* rstd, float* ggamma, float* gbeta,
+__global__ __launch_bounds__(256) void bn_bwd_coeffs_rep_kernel(const double* sums, int reps, int rep_stride, int centred, int C,
+                                                                double inv_count, const float* gamma, const float* mean,
+                                                                const float* rstd, float* ggamma, float* gbeta,
                                                                 float* k1, float* k2, float* k3) {
     const int c = blockIdx.x * 8 + (threadIdx.x >> 5), r = threadIdx.x & 31;
     double db = 0.0, dc = 0.0;
     if (c < C && r < reps) {
-        db = sums[(size_t)r * 2 * C + c];
-        dc = sums[(size_t)r * 2 * C + C + c];
+        db = sums[(size_t)r * rep_stride + c];
+        dc = sums[(size_t)r * rep_stride + C + c];
     }
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) { db += __shfl_xor(db, o, 32); dc += __shfl_xor(dc, o, 32); }
     if (c >= C || r != 0) return;
-    const double dg = dc * (double)rstd[c];                 // sum g m xhat
+    const double dg = centred ? dc * (double)rstd[c] : dc;  // sum g m xhat (centred: the second sum is sum g m (y - mean))
     ggamma[c] += (float)dg;
     gbeta[c] += (float)db;
     const double a = (double)gamma[c] * (double)rstd[c];
@@ -482,6 +483,215 @@ __global__ __launch_bounds__(256) void igemm_finalize_kernel(float* out, const f
     }
 }
 
+
+// ---- the streaming passes on 16-byte units (round 3) ---------------------------------------------------------------------------
+// The kernels above walk float4 (fp32) / 8-byte (bf16) elements with a 64-bit modulo per element for the channel and re-read
+// their per-channel coefficients in every iteration: measured alone on a res2-sized bf16 tensor they reach 3.1 - 3.6 TB/s
+// where a plain copy does 4.7 and a plain read 6.5 (tools/bn_bench2.py) -- 60 % of what the same bytes cost a streaming
+// kernel.  Here a thread handles one 16-BYTE unit per tensor and iteration (4 fp32 or 8 bf16 channels) and, because the unit
+// count per row U = C / V divides the block size and the grid stride is a multiple of it, ALWAYS THE SAME channels: the
+// coefficients are loaded once into registers, the loop is loads, a few FMAs and stores, two units in flight.  Offered where
+// U <= 256 divides 256 (every BN of both localizers); other channel counts keep the kernels above.
+template <typename T> struct unit16;
+template <> struct unit16<float> {
+    static constexpr int V = 4, NV = 1;
+    static __device__ __forceinline__ void ld(const float* p, f32x4* v) { v[0] = *reinterpret_cast<const f32x4*>(p); }
+    static __device__ __forceinline__ void st(float* p, const f32x4* v) { *reinterpret_cast<f32x4*>(p) = v[0]; }
+};
+template <> struct unit16<__bf16> {
+    static constexpr int V = 8, NV = 2;
+    typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+    static __device__ __forceinline__ void ld(const __bf16* p, f32x4* v) {
+        const bf16x8 r = *reinterpret_cast<const bf16x8*>(p);
+        v[0] = __builtin_convertvector(__builtin_shufflevector(r, r, 0, 1, 2, 3), f32x4);
+        v[1] = __builtin_convertvector(__builtin_shufflevector(r, r, 4, 5, 6, 7), f32x4);
+    }
+    static __device__ __forceinline__ void st(__bf16* p, const f32x4* v) {
+        const loans_bf16x4 a = __builtin_convertvector(v[0], loans_bf16x4), b = __builtin_convertvector(v[1], loans_bf16x4);
+        *reinterpret_cast<bf16x8*>(p) = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+    }
+};
+
+// one byte of sign bits per four channels: a unit owns NV consecutive bytes
+template <int NV> __device__ __forceinline__ void st_bits(uint8_t* p, const f32x4* v) {
+    if (NV == 1) p[0] = posbits4(v[0]);
+    else *reinterpret_cast<uint16_t*>(p) = (uint16_t)(posbits4(v[0]) | (posbits4(v[1]) << 8));
+}
+template <int NV> __device__ __forceinline__ void ld_bits(const uint8_t* p, uint8_t* b) {
+    if (NV == 1) b[0] = p[0];
+    else { const uint16_t w = *reinterpret_cast<const uint16_t*>(p); b[0] = (uint8_t)(w & 255); b[1] = (uint8_t)(w >> 8); }
+}
+
+template <int MODE, bool BITS, typename T>
+__global__ __launch_bounds__(256) void bn_apply_u16_kernel(const T* x, const float* scale, const float* shift, const T* x2,
+                                                           const float* scale2, const float* shift2, T* y, int64_t nunits,
+                                                           int U, int relu, uint8_t* signbits) {
+    constexpr int V = unit16<T>::V, NV = unit16<T>::NV;
+    const int cu = threadIdx.x % U;             // this thread's channel unit, the same in every iteration
+    f32x4 s[NV], t[NV], s2[NV], t2[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        s[q] = ld4(scale + cu * V + 4 * q); t[q] = ld4(shift + cu * V + 4 * q);
+        if (MODE == 2) { s2[q] = ld4(scale2 + cu * V + 4 * q); t2[q] = ld4(shift2 + cu * V + 4 * q); }
+    }
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    auto one = [&](int64_t i, const f32x4* xv, const f32x4* rv) {
+        f32x4 v[NV];
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            v[q] = xv[q] * s[q] + t[q];
+            if (MODE == 1) v[q] += rv[q];
+            if (MODE == 2) v[q] += rv[q] * s2[q] + t2[q];
+            if (relu) v[q] = relu4(v[q]);
+        }
+        unit16<T>::st(y + i * V, v);
+        if (BITS) st_bits<NV>(signbits + i * NV, v);
+    };
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + stride < nunits; i += 2 * stride) {          // two units in flight
+        f32x4 a[NV], b[NV], ra[NV], rb[NV];
+        unit16<T>::ld(x + i * V, a);
+        unit16<T>::ld(x + (i + stride) * V, b);
+        if (MODE != 0) { unit16<T>::ld(x2 + i * V, ra); unit16<T>::ld(x2 + (i + stride) * V, rb); }
+        one(i, a, ra);
+        one(i + stride, b, rb);
+    }
+    if (i < nunits) {
+        f32x4 a[NV], ra[NV];
+        unit16<T>::ld(x + i * V, a);
+        if (MODE != 0) unit16<T>::ld(x2 + i * V, ra);
+        one(i, a, ra);
+    }
+}
+
+// gx = k1 g + k2 x + k3 (and gx2 for the second BN of a dual); MASK as in bn_bwd_apply_kernel
+template <bool DUAL, int MASK, typename T>
+__global__ __launch_bounds__(256) void bn_bwd_apply_u16_kernel(const T* gy, const T* mask, const T* x, const float* k1,
+                                                               const float* k2, const float* k3, T* gx, const T* x2,
+                                                               const float* k1b, const float* k2b, const float* k3b, T* gx2,
+                                                               int64_t nunits, int U, const float* scale, const float* shift) {
+    constexpr int V = unit16<T>::V, NV = unit16<T>::NV;
+    const int cu = threadIdx.x % U;
+    f32x4 a1[NV], a2[NV], a3[NV], b1[NV], b2[NV], b3[NV], sc[NV], sh[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        const int c = cu * V + 4 * q;
+        a1[q] = ld4(k1 + c); a2[q] = ld4(k2 + c); a3[q] = ld4(k3 + c);
+        if (DUAL) { b1[q] = ld4(k1b + c); b2[q] = ld4(k2b + c); b3[q] = ld4(k3b + c); }
+        if (MASK == 2) { sc[q] = ld4(scale + c); sh[q] = ld4(shift + c); }
+    }
+    const uint8_t* bits = reinterpret_cast<const uint8_t*>(mask);
+    const int64_t stride = (int64_t)gridDim.x * 256;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nunits; i += stride) {
+        f32x4 g[NV], xv[NV], mv[NV], xw[NV], o[NV];
+        uint8_t mb[NV];
+        unit16<T>::ld(gy + i * V, g);
+        unit16<T>::ld(x + i * V, xv);
+        if (MASK == 1) unit16<T>::ld(mask + i * V, mv);
+        if (MASK == 3) ld_bits<NV>(bits + i * NV, mb);
+        if (DUAL) unit16<T>::ld(x2 + i * V, xw);
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            if (MASK == 1) g[q] = maskpos4(g[q], mv[q]);
+            if (MASK == 2) g[q] = maskpos4(g[q], xv[q] * sc[q] + sh[q]);
+            if (MASK == 3) g[q] = maskbits4(g[q], mb[q]);
+            o[q] = a1[q] * g[q] + a2[q] * xv[q] + a3[q];
+        }
+        unit16<T>::st(gx + i * V, o);
+        if (DUAL) {
+#pragma unroll
+            for (int q = 0; q < NV; ++q) o[q] = b1[q] * g[q] + b2[q] * xw[q] + b3[q];
+            unit16<T>::st(gx2 + i * V, o);
+        }
+    }
+}
+
+// the two (dual: three) per-channel sums of a BN backward over 16-byte units: thread (cu = tid % U, rl = tid / U) walks the rows
+// rl, rl + RL, ... of its block's slab (no index arithmetic beyond an add), the block folds through LDS, one fp64 atomic per
+// channel and sum
+template <bool DUAL, int MASK, typename T>
+__global__ __launch_bounds__(256) void bn_bwd_reduce_u16_kernel(const T* gy, const T* mask, const T* x, const float* mean,
+                                                                const float* rstd, const T* x2, const float* mean2,
+                                                                const float* rstd2, double* sums, int64_t rows, int U,
+                                                                int rows_per_block, const float* scale, const float* shift,
+                                                                int replicas) {
+    constexpr int V = unit16<T>::V, NV = unit16<T>::NV, NS = DUAL ? 3 : 2;
+    __shared__ f32x4 red[NS * NV][256];
+    const int tid = threadIdx.x, cu = tid % U, rl = tid / U, RL = 256 / U;
+    const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+    int64_t r1 = r0 + rows_per_block;
+    if (r1 > rows) r1 = rows;
+    f32x4 mu[NV], rs[NV], mu2[NV], rs2[NV], sc[NV], sh[NV], sg[NV], sgx[NV], sgx2[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        const int c = cu * V + 4 * q;
+        mu[q] = ld4(mean + c); rs[q] = ld4(rstd + c);
+        if (DUAL) { mu2[q] = ld4(mean2 + c); rs2[q] = ld4(rstd2 + c); }
+        if (MASK == 2) { sc[q] = ld4(scale + c); sh[q] = ld4(shift + c); }
+        sg[q] = sgx[q] = sgx2[q] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    const uint8_t* bits = reinterpret_cast<const uint8_t*>(mask);
+    for (int64_t r = r0 + rl; r < r1; r += RL) {
+        const int64_t i = r * U + cu;
+        f32x4 g[NV], xv[NV], mv[NV], xw[NV];
+        uint8_t mb[NV];
+        unit16<T>::ld(gy + i * V, g);
+        unit16<T>::ld(x + i * V, xv);
+        if (MASK == 1) unit16<T>::ld(mask + i * V, mv);
+        if (MASK == 3) ld_bits<NV>(bits + i * NV, mb);
+        if (DUAL) unit16<T>::ld(x2 + i * V, xw);
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            if (MASK == 1) g[q] = maskpos4(g[q], mv[q]);
+            if (MASK == 2) g[q] = maskpos4(g[q], xv[q] * sc[q] + sh[q]);
+            if (MASK == 3) g[q] = maskbits4(g[q], mb[q]);
+            sg[q] += g[q];
+            sgx[q] += g[q] * ((xv[q] - mu[q]) * rs[q]);
+            if (DUAL) sgx2[q] += g[q] * ((xw[q] - mu2[q]) * rs2[q]);
+        }
+    }
+#pragma unroll
+    for (int q = 0; q < NV; ++q) {
+        red[q][tid] = sg[q];
+        red[NV + q][tid] = sgx[q];
+        if (DUAL) red[2 * NV + q][tid] = sgx2[q];
+    }
+    __syncthreads();
+    if (tid < U) {
+        const int C = U * V;
+        // `replicas` accumulators [replica][2 | 4][C], picked by block: thousands of blocks adding to the same 2 C addresses
+        // cost more than the pass itself (measured: +0.1 ms per 1024 blocks on 128 addresses)
+        sums += (size_t)(blockIdx.x % replicas) * (DUAL ? 4 : 2) * C;
+#pragma unroll
+        for (int q = 0; q < NV; ++q) {
+            f32x4 a = sg[q], b = sgx[q], c2 = sgx2[q];
+            for (int k = 1; k < RL; ++k) {
+                a += red[q][tid + k * U];
+                b += red[NV + q][tid + k * U];
+                if (DUAL) c2 += red[2 * NV + q][tid + k * U];
+            }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int ch = cu * V + 4 * q + e;
+                atomic_add_f64(sums + ch, (double)a[e]);
+                atomic_add_f64(sums + C + ch, (double)b[e]);
+                if (DUAL) {
+                    atomic_add_f64(sums + 2 * C + ch, (double)a[e]);
+                    atomic_add_f64(sums + 3 * C + ch, (double)c2[e]);
+                }
+            }
+        }
+    }
+}
+
+// a channel count the 16-byte-unit kernels tile: U = C / V units per row, U <= 256 and 256 % U == 0
+template <typename T> static inline int units_per_row(int C) {
+    constexpr int V = unit16<T>::V;
+    if (C % V) return 0;
+    const int U = C / V;
+    return (U <= 256 && 256 % U == 0) ? U : 0;
+}
+
 // channel slabs: C4 = float4 groups per block (<= 256, divides 256), *slabs = number of slabs
 int reduce_geometry(int64_t rows, int C, int* rows_per_block, int* c4_block, int* slabs) {
     const int C4T = C / 4;
@@ -534,9 +744,19 @@ static int bn_apply_impl(const T* x, const float* scale, const float* shift, con
                          int32_t mode, int32_t relu, void* stream, uint8_t* signbits = nullptr) {
     if (!x || !scale || !shift || !y || rows <= 0 || C <= 0 || (C & 3)) return LOANS_EINVAL;
     if (mode < 0 || mode > 2 || (mode >= 1 && !x2) || (mode == 2 && (!scale2 || !shift2))) return LOANS_EINVAL;
+    hipStream_t st = as_stream(stream);
+    if (const int U = units_per_row<T>(C)) {
+        const int64_t nunits = rows * U;
+        const int g16 = grid_for(nunits, 256, 256 * 16);
+#define LAUNCH_A16(M, B_) hipLaunchKernelGGL((bn_apply_u16_kernel<M, B_, T>), dim3(g16), dim3(256), 0, st, x, scale, shift, x2, scale2, shift2, y, nunits, U, relu, signbits)
+        if (signbits) { if (mode == 0) LAUNCH_A16(0, true); else if (mode == 1) LAUNCH_A16(1, true); else LAUNCH_A16(2, true); }
+        else { if (mode == 0) LAUNCH_A16(0, false); else if (mode == 1) LAUNCH_A16(1, false); else LAUNCH_A16(2, false); }
+#undef LAUNCH_A16
+        LOANS_LAUNCH_CHECK();
+        return LOANS_OK;
+    }
     const int64_t n4 = rows * (C / 4);
     const int grid = grid_for(n4, 256);
-    hipStream_t st = as_stream(stream);
     if (mode == 0) hipLaunchKernelGGL((bn_apply_kernel<0, T>), dim3(grid), dim3(256), 0, st, x, scale, shift, x2, scale2, shift2, y, n4, C / 4, relu, signbits);
     if (mode == 1) hipLaunchKernelGGL((bn_apply_kernel<1, T>), dim3(grid), dim3(256), 0, st, x, scale, shift, x2, scale2, shift2, y, n4, C / 4, relu, signbits);
     if (mode == 2) hipLaunchKernelGGL((bn_apply_kernel<2, T>), dim3(grid), dim3(256), 0, st, x, scale, shift, x2, scale2, shift2, y, n4, C / 4, relu, signbits);
@@ -691,14 +911,33 @@ template <typename T>
 static int bn_bwd_reduce_impl(const T* gy, const T* mask, const T* x, const float* mean,
                               const float* rstd, const T* x2, const float* mean2, const float* rstd2,
                               double* sums, int64_t rows, int32_t C, void* stream,
-                              const float* scale = nullptr, const float* shift = nullptr, bool bits = false) {
+                              const float* scale = nullptr, const float* shift = nullptr, bool bits = false, int replicas = 1) {
     if (!gy || !x || !mean || !rstd || !sums || rows <= 0) return LOANS_EINVAL;
     if (!reduce_channels_ok(C)) return LOANS_EINVAL;
     if (x2 && (!mean2 || !rstd2)) return LOANS_EINVAL;
     if (scale && (!shift || mask || x2)) return LOANS_EINVAL;
+    hipStream_t st = as_stream(stream);
+    if (bits && !mask) return LOANS_EINVAL;
+    if (replicas < 1 || replicas > 32) return LOANS_EINVAL;
+    const int U = units_per_row<T>(C);
+    if (replicas > 1 && !U) return LOANS_EINVAL;            // replicated accumulators: the 16-byte-unit kernel only
+    if (U) {
+        const int RL = 256 / U;
+        const int max_blocks = replicas > 1 ? 4096 : 1024;  // un-replicated sums: every block adds to the same 2 C addresses
+        int64_t rpb16 = ((rows + max_blocks - 1) / max_blocks + RL - 1) / RL * RL;
+        if (rpb16 < 8 * RL) rpb16 = 8 * RL;
+        const int g16 = (int)((rows + rpb16 - 1) / rpb16);
+#define LAUNCH_R16(D, M) \
+    hipLaunchKernelGGL((bn_bwd_reduce_u16_kernel<D, M, T>), dim3(g16), dim3(256), 0, st, gy, mask, x, mean, rstd, x2, mean2, rstd2, sums, rows, U, (int)rpb16, scale, shift, replicas)
+        if (x2) { if (bits) LAUNCH_R16(true, 3); else if (mask) LAUNCH_R16(true, 1); else LAUNCH_R16(true, 0); }
+        else if (scale) LAUNCH_R16(false, 2);
+        else { if (bits) LAUNCH_R16(false, 3); else if (mask) LAUNCH_R16(false, 1); else LAUNCH_R16(false, 0); }
+#undef LAUNCH_R16
+        LOANS_LAUNCH_CHECK();
+        return LOANS_OK;
+    }
     int rpb, c4b, slabs;
     const int grid = reduce_geometry(rows, C, &rpb, &c4b, &slabs);
-    hipStream_t st = as_stream(stream);
 #define LAUNCH_RED(D, M) \
     hipLaunchKernelGGL((bn_bwd_reduce_kernel<D, M, T>), dim3(grid, slabs), dim3(256), 0, st, gy, mask, x, mean, rstd, x2, mean2, rstd2, sums, rows, c4b, C / 4, rpb, scale, shift)
     if (bits && !mask) return LOANS_EINVAL;
@@ -750,14 +989,14 @@ extern "C" int loans_bn_bwd_coeffs_f32(const double* sums, int32_t C, int64_t co
     return LOANS_OK;
 }
 
-extern "C" int loans_bn_bwd_coeffs_rep_f32(const double* sums, int32_t replicas, int32_t C, int64_t count, const float* gamma,
-                                           const float* mean, const float* rstd, float* ggamma, float* gbeta, float* k1,
-                                           float* k2, float* k3, void* stream) {
+extern "C" int loans_bn_bwd_coeffs_rep_f32(const double* sums, int32_t replicas, int32_t rep_stride, int32_t centred, int32_t C,
+                                           int64_t count, const float* gamma, const float* mean, const float* rstd, float* ggamma,
+                                           float* gbeta, float* k1, float* k2, float* k3, void* stream) {
     if (!sums || !gamma || !mean || !rstd || !ggamma || !gbeta || !k1 || !k2 || !k3 || C <= 0 || count <= 0 || replicas <= 0 ||
-        replicas > 32)
+        replicas > 32 || rep_stride < 2 * C)
         return LOANS_EINVAL;
-    hipLaunchKernelGGL(bn_bwd_coeffs_rep_kernel, dim3((C + 7) / 8), dim3(256), 0, as_stream(stream), sums, replicas, C,
-                       1.0 / (double)count, gamma, mean, rstd, ggamma, gbeta, k1, k2, k3);
+    hipLaunchKernelGGL(bn_bwd_coeffs_rep_kernel, dim3((C + 7) / 8), dim3(256), 0, as_stream(stream), sums, replicas, rep_stride,
+                       centred, C, 1.0 / (double)count, gamma, mean, rstd, ggamma, gbeta, k1, k2, k3);
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;
 }
@@ -771,9 +1010,21 @@ static int bn_bwd_apply_impl(const T* gy, const T* mask, const T* x, const float
     if (bits && !mask) return LOANS_EINVAL;
     if (x2 && (!k1b || !k2b || !k3b || !gx2)) return LOANS_EINVAL;
     if (scale && (!shift || mask || x2)) return LOANS_EINVAL;
+    hipStream_t st = as_stream(stream);
+    if (const int U = units_per_row<T>(C)) {
+        const int64_t nunits = rows * U;
+        const int g16 = grid_for(nunits, 256, 256 * 16);
+#define LAUNCH_P16(D, M) \
+    hipLaunchKernelGGL((bn_bwd_apply_u16_kernel<D, M, T>), dim3(g16), dim3(256), 0, st, gy, mask, x, k1, k2, k3, gx, x2, k1b, k2b, k3b, gx2, nunits, U, scale, shift)
+        if (x2) { if (bits) LAUNCH_P16(true, 3); else if (mask) LAUNCH_P16(true, 1); else LAUNCH_P16(true, 0); }
+        else if (scale) LAUNCH_P16(false, 2);
+        else { if (bits) LAUNCH_P16(false, 3); else if (mask) LAUNCH_P16(false, 1); else LAUNCH_P16(false, 0); }
+#undef LAUNCH_P16
+        LOANS_LAUNCH_CHECK();
+        return LOANS_OK;
+    }
     const int64_t n4 = rows * (C / 4);
     const int grid = grid_for(n4, 256);
-    hipStream_t st = as_stream(stream);
 #define LAUNCH_APP(D, M) \
     hipLaunchKernelGGL((bn_bwd_apply_kernel<D, M, T>), dim3(grid), dim3(256), 0, st, gy, mask, x, k1, k2, k3, gx, x2, k1b, k2b, k3b, gx2, n4, C / 4, scale, shift)
     if (x2) { if (bits) LAUNCH_APP(true, 3); else if (mask) LAUNCH_APP(true, 1); else LAUNCH_APP(true, 0); }
@@ -883,4 +1134,36 @@ extern "C" int loans_colsum_bf16(const void* x, float* out, int64_t rows, int32_
     hipLaunchKernelGGL(colsum_kernel<__bf16>, dim3(grid, slabs), dim3(256), 0, as_stream(stream), static_cast<const __bf16*>(x), out, rows, c4b, C / 4, rpb);
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;
+}
+
+// ---- BN-backward reduction into REPLICATED accumulators (round 3) ---------------------------------------------------------------
+// One entry per storage type for all mask forms: mask_kind 0 = none, 1 = g * (mask tensor > 0), 2 = g * (x scale + shift > 0) (the
+// BN's own ReLU; `scale` / `shift`), 3 = sign bits (one byte per four channels).  `sums`: fp64 [replicas][2][C] (dual, x2 given:
+// [replicas][4][C] = [sum g | sum g xhat | sum g | sum g xhat2]), zeroed by the caller, summed by loans_bn_bwd_coeffs_rep_f32
+// (centred = 0, rep_stride = 2 C or 4 C).  Needs a channel count the 16-byte-unit kernel tiles (C / V a divisor of 256, V = 4
+// fp32 / 8 bf16 channels).
+template <typename T>
+static int bn_bwd_reduce_rep(const void* gy, const void* mask, int mask_kind, const void* x, const float* mean, const float* rstd,
+                             const void* x2, const float* mean2, const float* rstd2, const float* scale, const float* shift,
+                             double* sums, int replicas, int64_t rows, int C, void* stream) {
+    if (mask_kind < 0 || mask_kind > 3 || replicas < 2) return LOANS_EINVAL;
+    if ((mask_kind == 1 || mask_kind == 3) != (mask != nullptr)) return LOANS_EINVAL;
+    if ((mask_kind == 2) != (scale != nullptr)) return LOANS_EINVAL;
+    return bn_bwd_reduce_impl<T>(static_cast<const T*>(gy), static_cast<const T*>(mask), static_cast<const T*>(x), mean, rstd,
+                                 static_cast<const T*>(x2), mean2, rstd2, sums, rows, C, stream, scale, shift, mask_kind == 3,
+                                 replicas);
+}
+
+extern "C" int loans_bn_bwd_reduce_rep_f32(const float* gy, const void* mask, int32_t mask_kind, const float* x, const float* mean,
+                                           const float* rstd, const float* x2, const float* mean2, const float* rstd2,
+                                           const float* scale, const float* shift, double* sums, int32_t replicas, int64_t rows,
+                                           int32_t C, void* stream) {
+    return bn_bwd_reduce_rep<float>(gy, mask, mask_kind, x, mean, rstd, x2, mean2, rstd2, scale, shift, sums, replicas, rows, C, stream);
+}
+
+extern "C" int loans_bn_bwd_reduce_rep_bf16(const void* gy, const void* mask, int32_t mask_kind, const void* x, const float* mean,
+                                            const float* rstd, const void* x2, const float* mean2, const float* rstd2,
+                                            const float* scale, const float* shift, double* sums, int32_t replicas, int64_t rows,
+                                            int32_t C, void* stream) {
+    return bn_bwd_reduce_rep<__bf16>(gy, mask, mask_kind, x, mean, rstd, x2, mean2, rstd2, scale, shift, sums, replicas, rows, C, stream);
 }

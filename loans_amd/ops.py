@@ -1481,6 +1481,63 @@ def maxpool_relu_bwd(gy, idx, x, st):
 BN_XMASK = os.environ.get('LOANS_BN_XMASK', '1') != '0'
 
 
+# LOANS_BN_REPLICAS=0: the BN-backward reductions add into one accumulator per channel again (rounds 1-2)
+BN_REPLICAS = os.environ.get('LOANS_BN_REPLICAS', '1') != '0'
+
+
+def bn_units_ok(C_, s16):
+    """the 16-byte-unit BN kernels tile this channel count: C / V a divisor of 256 (V = 8 bf16 / 4 fp32 channels)"""
+    v = 8 if s16 else 4
+    return C_ % v == 0 and C_ // v <= 256 and 256 % (C_ // v) == 0
+
+
+def _bn_backward_rep(lib, gy, mask, x, st, gamma, ggamma, gbeta, x2, st2, gamma2, ggamma2, gbeta2, mask_is_own_relu):
+    """bn_backward on the 16-byte-unit kernels with replicated accumulators: reduce (every mask form through one entry) ->
+    coefficients from the replicas -> apply"""
+    C_ = x.shape[-1]
+    rows = x.numel() // C_
+    dual = x2 is not None
+    s16 = _is16(x)
+    s = _stream()
+    assert _is16(gy) == s16 and (x2 is None or _is16(x2) == s16)
+    own = mask_is_own_relu and BN_XMASK and not dual and mask is not None
+    bits = None if own else (getattr(mask, 'relu_bits', None) if (mask is not None and BN_BITS) else None)
+    if bits is not None:
+        assert bits.numel() == rows * (C_ // 4)
+    kind = 2 if own else (3 if bits is not None else (1 if mask is not None else 0))
+    mten = None if kind in (0, 2) else (bits if kind == 3 else mask)
+    assert kind != 1 or _is16(mask) == s16
+    ns = 4 if dual else 2
+    sums = _zeros_f64((STATS_REPLICAS, ns, C_), x.device)
+    red = lib.loans_bn_bwd_reduce_rep_bf16 if s16 else lib.loans_bn_bwd_reduce_rep_f32
+    check(red(_ptr(gy), _ptr(mten), kind, _ptr(x), _ptr(st.mean), _ptr(st.rstd), _ptr(x2), _ptr(st2.mean if dual else None),
+              _ptr(st2.rstd if dual else None), _ptr(st.scale if own else None), _ptr(st.shift if own else None), _ptr(sums),
+              STATS_REPLICAS, rows, C_, s), 'loans_bn_bwd_reduce_rep')
+    k = torch.empty((6 if dual else 3, C_), device=x.device, dtype=torch.float32)
+    check(lib.loans_bn_bwd_coeffs_rep_f32(_ptr(sums), STATS_REPLICAS, ns * C_, 0, C_, rows, _ptr(gamma), _ptr(st.mean),
+                                          _ptr(st.rstd), _ptr(ggamma), _ptr(gbeta), _ptr(k[0]), _ptr(k[1]), _ptr(k[2]), s),
+          'loans_bn_bwd_coeffs_rep_f32')
+    gx = torch.empty_like(x)
+    if own:
+        app = lib.loans_bn_bwd_apply_xmask_bf16 if s16 else lib.loans_bn_bwd_apply_xmask_f32
+        check(app(_ptr(gy), _ptr(x), _ptr(st.scale), _ptr(st.shift), _ptr(k[0]), _ptr(k[1]), _ptr(k[2]), _ptr(gx), rows, C_, s),
+              'loans_bn_bwd_apply_xmask')
+        return gx
+    gx2 = None
+    if dual:
+        check(lib.loans_bn_bwd_coeffs_rep_f32(_ptr(sums[0, 2]), STATS_REPLICAS, ns * C_, 0, C_, rows, _ptr(gamma2), _ptr(st2.mean),
+                                              _ptr(st2.rstd), _ptr(ggamma2), _ptr(gbeta2), _ptr(k[3]), _ptr(k[4]), _ptr(k[5]), s),
+              'loans_bn_bwd_coeffs_rep_f32')
+        gx2 = torch.empty_like(x2)
+    if kind == 3:
+        app = lib.loans_bn_bwd_apply_bits_bf16 if s16 else lib.loans_bn_bwd_apply_bits_f32
+    else:
+        app = lib.loans_bn_bwd_apply_bf16 if s16 else lib.loans_bn_bwd_apply_f32
+    check(app(_ptr(gy), _ptr(mten), _ptr(x), _ptr(k[0]), _ptr(k[1]), _ptr(k[2]), _ptr(gx), _ptr(x2), _ptr(k[3]) if dual else 0,
+              _ptr(k[4]) if dual else 0, _ptr(k[5]) if dual else 0, _ptr(gx2), rows, C_, s), 'loans_bn_bwd_apply')
+    return (gx, gx2) if dual else gx
+
+
 def bn_backward(gy, mask, x, st, gamma, ggamma, gbeta, x2=None, st2=None, gamma2=None, ggamma2=None, gbeta2=None,
                 mask_is_own_relu=False):
     """Training-mode BN backward for one or two BNs fed by the same upstream gradient
@@ -1491,6 +1548,8 @@ def bn_backward(gy, mask, x, st, gamma, ggamma, gbeta, x2=None, st2=None, gamma2
     C_ = x.shape[-1]
     rows = x.numel() // C_
     dual = x2 is not None
+    if BN_REPLICAS and bn_units_ok(C_, _is16(x)):
+        return _bn_backward_rep(lib, gy, mask, x, st, gamma, ggamma, gbeta, x2, st2, gamma2, ggamma2, gbeta2, mask_is_own_relu)
     if mask_is_own_relu and BN_XMASK and not dual and mask is not None:
         s = _stream()
         s16 = _is16(x)
@@ -1549,7 +1608,7 @@ def bn_backward_from_sums(gy, x, st, sums, gamma, ggamma, gbeta):
     s16 = _is16(x)
     assert _is16(gy) == s16 and sums.numel() == STATS_REPLICAS * 2 * C_
     k = torch.empty((3, C_), device=x.device, dtype=torch.float32)
-    check(lib.loans_bn_bwd_coeffs_rep_f32(_ptr(sums), STATS_REPLICAS, C_, rows, _ptr(gamma), _ptr(st.mean), _ptr(st.rstd),
+    check(lib.loans_bn_bwd_coeffs_rep_f32(_ptr(sums), STATS_REPLICAS, 2 * C_, 1, C_, rows, _ptr(gamma), _ptr(st.mean), _ptr(st.rstd),
                                           _ptr(ggamma), _ptr(gbeta), _ptr(k[0]), _ptr(k[1]), _ptr(k[2]), s),
           'loans_bn_bwd_coeffs_rep_f32')
     gx = torch.empty_like(x)

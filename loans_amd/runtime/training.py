@@ -224,6 +224,10 @@ class MultithreadIterator(SerialIterator):
         self._queue = self._mid = self._thread = self._thread2 = None
         for t in threads:
             t.join()
+        if self.device is not None and threads:         # the finish thread's pinned staging buffers go with it
+            from ..common.datasets.resample import release_staging
+            for t in threads:
+                release_staging(t.ident)
 
     # ---- consumer side ----------------------------------------------------------------------------------------------
     def reset(self):
