@@ -582,14 +582,8 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_u16_kernel(const T* gy, cons
     }
     const uint8_t* bits = reinterpret_cast<const uint8_t*>(mask);
     const int64_t stride = (int64_t)gridDim.x * 256;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nunits; i += stride) {
-        f32x4 g[NV], xv[NV], mv[NV], xw[NV], o[NV];
-        uint8_t mb[NV];
-        unit16<T>::ld(gy + i * V, g);
-        unit16<T>::ld(x + i * V, xv);
-        if (MASK == 1) unit16<T>::ld(mask + i * V, mv);
-        if (MASK == 3) ld_bits<NV>(bits + i * NV, mb);
-        if (DUAL) unit16<T>::ld(x2 + i * V, xw);
+    auto one = [&](int64_t i, f32x4* g, const f32x4* xv, const f32x4* mv, const uint8_t* mb, const f32x4* xw) {
+        f32x4 o[NV];
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
             if (MASK == 1) g[q] = maskpos4(g[q], mv[q]);
@@ -603,6 +597,32 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_u16_kernel(const T* gy, cons
             for (int q = 0; q < NV; ++q) o[q] = b1[q] * g[q] + b2[q] * xw[q] + b3[q];
             unit16<T>::st(gx2 + i * V, o);
         }
+    };
+    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
+    for (; i + stride < nunits; i += 2 * stride) {          // two units in flight
+        f32x4 g[2][NV], xv[2][NV], mv[2][NV], xw[2][NV];
+        uint8_t mb[2][NV];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            const int64_t j = i + u * stride;
+            unit16<T>::ld(gy + j * V, g[u]);
+            unit16<T>::ld(x + j * V, xv[u]);
+            if (MASK == 1) unit16<T>::ld(mask + j * V, mv[u]);
+            if (MASK == 3) ld_bits<NV>(bits + j * NV, mb[u]);
+            if (DUAL) unit16<T>::ld(x2 + j * V, xw[u]);
+        }
+        one(i, g[0], xv[0], mv[0], mb[0], xw[0]);
+        one(i + stride, g[1], xv[1], mv[1], mb[1], xw[1]);
+    }
+    if (i < nunits) {
+        f32x4 g[NV], xv[NV], mv[NV], xw[NV];
+        uint8_t mb[NV];
+        unit16<T>::ld(gy + i * V, g);
+        unit16<T>::ld(x + i * V, xv);
+        if (MASK == 1) unit16<T>::ld(mask + i * V, mv);
+        if (MASK == 3) ld_bits<NV>(bits + i * NV, mb);
+        if (DUAL) unit16<T>::ld(x2 + i * V, xw);
+        one(i, g, xv, mv, mb, xw);
     }
 }
 
@@ -614,10 +634,12 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_u16_kernel(const T* gy, con
                                                                 const float* rstd, const T* x2, const float* mean2,
                                                                 const float* rstd2, double* sums, int64_t rows, int U,
                                                                 int rows_per_block, const float* scale, const float* shift,
-                                                                int replicas) {
+                                                                int replicas, int UB) {
     constexpr int V = unit16<T>::V, NV = unit16<T>::NV, NS = DUAL ? 3 : 2;
     __shared__ f32x4 red[NS * NV][256];
-    const int tid = threadIdx.x, cu = tid % U, rl = tid / U, RL = 256 / U;
+    // wide rows are cut into slabs of UB units (blockIdx.y): a block's final atomics are 2 x its channels, and with all of a
+    // 2048-channel row in one block they outnumbered the loads 1 : 16 (fp64 atomics retire ~20 x slower than fp32 ones)
+    const int tid = threadIdx.x, cl = tid % UB, cu = blockIdx.y * UB + cl, rl = tid / UB, RL = 256 / UB;
     const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
     int64_t r1 = r0 + rows_per_block;
     if (r1 > rows) r1 = rows;
@@ -631,15 +653,10 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_u16_kernel(const T* gy, con
         sg[q] = sgx[q] = sgx2[q] = f32x4{0.f, 0.f, 0.f, 0.f};
     }
     const uint8_t* bits = reinterpret_cast<const uint8_t*>(mask);
-    for (int64_t r = r0 + rl; r < r1; r += RL) {
-        const int64_t i = r * U + cu;
-        f32x4 g[NV], xv[NV], mv[NV], xw[NV];
-        uint8_t mb[NV];
-        unit16<T>::ld(gy + i * V, g);
-        unit16<T>::ld(x + i * V, xv);
-        if (MASK == 1) unit16<T>::ld(mask + i * V, mv);
-        if (MASK == 3) ld_bits<NV>(bits + i * NV, mb);
-        if (DUAL) unit16<T>::ld(x2 + i * V, xw);
+    // UF rows per iteration, their loads issued before any arithmetic: a thread that waits for one 16-byte load pair at a
+    // time leaves the CU with ~16 KB in flight (wide-channel tensors run one block per CU), a quarter of what HBM needs
+    constexpr int UF = DUAL ? 2 : 4;
+    auto fold = [&](f32x4* g, const f32x4* xv, const f32x4* mv, const uint8_t* mb, const f32x4* xw) {
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
             if (MASK == 1) g[q] = maskpos4(g[q], mv[q]);
@@ -649,6 +666,33 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_u16_kernel(const T* gy, con
             sgx[q] += g[q] * ((xv[q] - mu[q]) * rs[q]);
             if (DUAL) sgx2[q] += g[q] * ((xw[q] - mu2[q]) * rs2[q]);
         }
+    };
+    int64_t r = r0 + rl;
+    for (; r + (int64_t)(UF - 1) * RL < r1; r += (int64_t)UF * RL) {
+        f32x4 g[UF][NV], xv[UF][NV], mv[UF][NV], xw[UF][NV];
+        uint8_t mb[UF][NV];
+#pragma unroll
+        for (int u = 0; u < UF; ++u) {
+            const int64_t i = (r + (int64_t)u * RL) * U + cu;
+            unit16<T>::ld(gy + i * V, g[u]);
+            unit16<T>::ld(x + i * V, xv[u]);
+            if (MASK == 1) unit16<T>::ld(mask + i * V, mv[u]);
+            if (MASK == 3) ld_bits<NV>(bits + i * NV, mb[u]);
+            if (DUAL) unit16<T>::ld(x2 + i * V, xw[u]);
+        }
+#pragma unroll
+        for (int u = 0; u < UF; ++u) fold(g[u], xv[u], mv[u], mb[u], xw[u]);
+    }
+    for (; r < r1; r += RL) {
+        const int64_t i = r * U + cu;
+        f32x4 g[NV], xv[NV], mv[NV], xw[NV];
+        uint8_t mb[NV];
+        unit16<T>::ld(gy + i * V, g);
+        unit16<T>::ld(x + i * V, xv);
+        if (MASK == 1) unit16<T>::ld(mask + i * V, mv);
+        if (MASK == 3) ld_bits<NV>(bits + i * NV, mb);
+        if (DUAL) unit16<T>::ld(x2 + i * V, xw);
+        fold(g, xv, mv, mb, xw);
     }
 #pragma unroll
     for (int q = 0; q < NV; ++q) {
@@ -657,7 +701,7 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_u16_kernel(const T* gy, con
         if (DUAL) red[2 * NV + q][tid] = sgx2[q];
     }
     __syncthreads();
-    if (tid < U) {
+    if (tid < UB) {
         const int C = U * V;
         // `replicas` accumulators [replica][2 | 4][C], picked by block: thousands of blocks adding to the same 2 C addresses
         // cost more than the pass itself (measured: +0.1 ms per 1024 blocks on 128 addresses)
@@ -666,9 +710,9 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_u16_kernel(const T* gy, con
         for (int q = 0; q < NV; ++q) {
             f32x4 a = sg[q], b = sgx[q], c2 = sgx2[q];
             for (int k = 1; k < RL; ++k) {
-                a += red[q][tid + k * U];
-                b += red[NV + q][tid + k * U];
-                if (DUAL) c2 += red[2 * NV + q][tid + k * U];
+                a += red[q][tid + k * UB];
+                b += red[NV + q][tid + k * UB];
+                if (DUAL) c2 += red[2 * NV + q][tid + k * UB];
             }
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
@@ -922,13 +966,14 @@ static int bn_bwd_reduce_impl(const T* gy, const T* mask, const T* x, const floa
     const int U = units_per_row<T>(C);
     if (replicas > 1 && !U) return LOANS_EINVAL;            // replicated accumulators: the 16-byte-unit kernel only
     if (U) {
-        const int RL = 256 / U;
-        const int max_blocks = replicas > 1 ? 4096 : 1024;  // un-replicated sums: every block adds to the same 2 C addresses
+        const int UB = U <= 16 ? U : 16, slabs = U / UB;    // >= 256-byte row segments per block
+        const int RL = 256 / UB;
+        const int max_blocks = (replicas > 1 ? 4096 : 1024) / slabs;  // un-replicated sums: every block adds to the same addresses
         int64_t rpb16 = ((rows + max_blocks - 1) / max_blocks + RL - 1) / RL * RL;
-        if (rpb16 < 8 * RL) rpb16 = 8 * RL;
+        if (rpb16 < 32 * RL) rpb16 = 32 * RL;       // >= 32 rows per thread: a block ends with 2 (dual: 4) fp64 atomics per channel
         const int g16 = (int)((rows + rpb16 - 1) / rpb16);
 #define LAUNCH_R16(D, M) \
-    hipLaunchKernelGGL((bn_bwd_reduce_u16_kernel<D, M, T>), dim3(g16), dim3(256), 0, st, gy, mask, x, mean, rstd, x2, mean2, rstd2, sums, rows, U, (int)rpb16, scale, shift, replicas)
+    hipLaunchKernelGGL((bn_bwd_reduce_u16_kernel<D, M, T>), dim3(g16, slabs), dim3(256), 0, st, gy, mask, x, mean, rstd, x2, mean2, rstd2, sums, rows, U, (int)rpb16, scale, shift, replicas, UB)
         if (x2) { if (bits) LAUNCH_R16(true, 3); else if (mask) LAUNCH_R16(true, 1); else LAUNCH_R16(true, 0); }
         else if (scale) LAUNCH_R16(false, 2);
         else { if (bits) LAUNCH_R16(false, 3); else if (mask) LAUNCH_R16(false, 1); else LAUNCH_R16(false, 0); }
