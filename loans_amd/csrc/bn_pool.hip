@@ -728,6 +728,73 @@ __global__ __launch_bounds__(256) void bn_bwd_reduce_u16_kernel(const T* gy, con
     }
 }
 
+
+// ---- the stem's pool on 16-byte units (round 3; see the unit16 kernels above) -----------------------------------------------------
+// One thread per (pooled pixel, 16-byte channel unit); the thread's channels never change (the unit count per row divides the
+// block size), so the BN coefficients live in registers: 0.127 -> 0.109 ms on a quarter of configs[2]'s conv1 output.  The same
+// treatment of the fused BACKWARD (one 16-byte unit per 2 x 2 patch / per pooled pixel with whole-unit window loads) was built
+// and measured SLOWER than the kernels above (apply 0.39 -> 0.83 ms, reduce 0.16 -> 0.28 ms at 100-126 VGPRs): removed.
+template <int NV> __device__ __forceinline__ void ld_idx(const uint8_t* p, uint8_t* k) {
+    if (NV == 1) { const uchar4 a = *reinterpret_cast<const uchar4*>(p); k[0] = a.x; k[1] = a.y; k[2] = a.z; k[3] = a.w; }
+    else {
+        const uint2 a = *reinterpret_cast<const uint2*>(p);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { k[e] = (uint8_t)(a.x >> (8 * e)); k[4 + e] = (uint8_t)(a.y >> (8 * e)); }
+    }
+}
+template <int NV> __device__ __forceinline__ void st_idx(uint8_t* p, const int* k) {
+    if (NV == 1) *reinterpret_cast<uchar4*>(p) = make_uchar4(k[0], k[1], k[2], k[3]);
+    else {
+        uint2 a;
+        a.x = (unsigned)k[0] | ((unsigned)k[1] << 8) | ((unsigned)k[2] << 16) | ((unsigned)k[3] << 24);
+        a.y = (unsigned)k[4] | ((unsigned)k[5] << 8) | ((unsigned)k[6] << 16) | ((unsigned)k[7] << 24);
+        *reinterpret_cast<uint2*>(p) = a;
+    }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bn_relu_maxpool_u16_kernel(const T* x, const float* scale, const float* shift, T* y,
+                                                                  uint8_t* idx, int B, int H, int W, int U, int OH, int OW) {
+    constexpr int V = unit16<T>::V, NV = unit16<T>::NV;
+    const int cu = threadIdx.x % U, pl = threadIdx.x / U, PL = 256 / U;      // PL output pixels of a row per block pass
+    f32x4 s[NV], t[NV];
+#pragma unroll
+    for (int q = 0; q < NV; ++q) { s[q] = ld4(scale + cu * V + 4 * q); t[q] = ld4(shift + cu * V + 4 * q); }
+    for (int row = blockIdx.y; row < B * OH; row += gridDim.y) {
+        const int b = row / OH, oh = row - b * OH;
+        for (int ow = blockIdx.x * PL + pl; ow < OW; ow += gridDim.x * PL) {
+            f32x4 best[NV];
+            int arg[V];
+#pragma unroll
+            for (int q = 0; q < NV; ++q) best[q] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+#pragma unroll
+            for (int e = 0; e < V; ++e) arg[e] = 0;
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                const int ih = oh * 2 + r;
+                if (ih >= H) continue;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    const int iw = ow * 2 + c;
+                    if (iw >= W) continue;
+                    f32x4 v[NV];
+                    unit16<T>::ld(x + ((((int64_t)b * H + ih) * W + iw) * U + cu) * V, v);
+#pragma unroll
+                    for (int q = 0; q < NV; ++q) {
+                        v[q] = relu4(v[q] * s[q] + t[q]);
+#pragma unroll
+                        for (int e = 0; e < 4; ++e)
+                            if (v[q][e] > best[q][e]) { best[q][e] = v[q][e]; arg[4 * q + e] = r * 3 + c; }
+                    }
+                }
+            }
+            const int64_t o = (((int64_t)row * OW + ow) * U + cu) * V;
+            unit16<T>::st(y + o, best);
+            st_idx<NV>(idx + o, arg);
+        }
+    }
+}
+
 // a channel count the 16-byte-unit kernels tile: U = C / V units per row, U <= 256 and 256 % U == 0
 template <typename T> static inline int units_per_row(int C) {
     constexpr int V = unit16<T>::V;
@@ -842,6 +909,14 @@ static int bn_relu_maxpool_impl(const TO* x, const float* scale, const float* sh
     if (!x || !scale || !shift || !y || !idx || B <= 0 || H < 3 || W < 3 || C <= 0 || (C & 3)) return LOANS_EINVAL;
     if (OH != (H - 2) / 2 + 1 || OW != (W - 2) / 2 + 1) return LOANS_EINVAL;   // cover_all out size, k=3 s=2 p=0
     if ((int64_t)B * H >= ((int64_t)1 << 31) || (int64_t)W * (C / 4) >= ((int64_t)1 << 31)) return LOANS_ERANGE;
+    if (const int U = units_per_row<TO>(C)) {
+        const int PL = 256 / U;
+        const dim3 g16((OW + PL - 1) / PL, (unsigned)min((int64_t)B * OH, (int64_t)65535));
+        hipLaunchKernelGGL(bn_relu_maxpool_u16_kernel<TO>, g16, dim3(256), 0, as_stream(stream), x, scale, shift, y, idx, B, H, W, U,
+                           OH, OW);
+        LOANS_LAUNCH_CHECK();
+        return LOANS_OK;
+    }
     const dim3 grid((OW * (C / 4) + 255) / 256, (unsigned)min((int64_t)B * OH, (int64_t)65535));
     hipLaunchKernelGGL(bn_relu_maxpool_kernel<TO>, grid, dim3(256), 0, as_stream(stream), x, scale,
                        shift, y, idx, B, H, W, C / 4, OH, OW);

@@ -1638,12 +1638,12 @@ def pool_bn_backward(gy, idx, x, st, gamma, ggamma, gbeta, gbias=None):
     s16 = _is16(x)
     assert _is16(gy) == s16
     s = _stream()
+    app_fn = lib.loans_pool_bn_bwd_apply_bf16 if s16 else lib.loans_pool_bn_bwd_apply_f32
+    k = torch.empty((3, C_), device=x.device, dtype=torch.float32)
     sums = _zeros_f64((2, C_), x.device)
     red_fn = lib.loans_pool_bn_bwd_reduce_bf16 if s16 else lib.loans_pool_bn_bwd_reduce_f32
-    app_fn = lib.loans_pool_bn_bwd_apply_bf16 if s16 else lib.loans_pool_bn_bwd_apply_f32
     check(red_fn(_ptr(gy), _ptr(idx), _ptr(x), _ptr(st.scale), _ptr(st.shift), _ptr(st.mean), _ptr(st.rstd), _ptr(sums),
                  B, H, W, C_, OH, OW, s), 'loans_pool_bn_bwd_reduce')
-    k = torch.empty((3, C_), device=x.device, dtype=torch.float32)
     check(lib.loans_bn_bwd_coeffs_f32(_ptr(sums), C_, B * H * W, _ptr(gamma), _ptr(st.mean), _ptr(st.rstd), _ptr(ggamma),
                                       _ptr(gbeta), _ptr(k[0]), _ptr(k[1]), _ptr(k[2]), s), 'loans_bn_bwd_coeffs_f32')
     gx = torch.empty_like(x)

@@ -73,3 +73,18 @@ rec('bn_relu_maxpool (B/4)', t(lambda: ops.bn_relu_maxpool(xs, sts)), xs.numel()
 gy = torch.randn_like(y)
 rec('pool_bn_backward (reduce + apply, B/4)', t(lambda: ops.pool_bn_backward(gy, idx, xs, sts, onesp, zerosp.clone(), zerosp.clone(), gbias=zerosp.clone())),
     (y.numel() * (es + 1) + xs.numel() * es // 1) + (y.numel() * (es + 1) + 2 * xs.numel() * es))
+
+# the two passes of the stem tail separately (C ABI calls; LOANS_POOL_U16 selects the kernel forms)
+lib = ops._lib.load()
+B_, H_, C_ = Bp, Hp, Cp
+OH = OW = y.shape[1]
+sums = torch.zeros((2, C_), device='cuda', dtype=torch.float64)
+k = torch.ones((3, C_), device='cuda')
+gxs = torch.empty_like(xs)
+gb = torch.zeros(C_, device='cuda')
+rec('  pool_bn_bwd_reduce alone', t(lambda: ops.check(lib.loans_pool_bn_bwd_reduce_bf16(
+    gy.data_ptr(), idx.data_ptr(), xs.data_ptr(), sts.scale.data_ptr(), sts.shift.data_ptr(), sts.mean.data_ptr(), sts.rstd.data_ptr(),
+    sums.data_ptr(), B_, H_, H_, C_, OH, OW, ops._stream()), 'r')), y.numel() * (es + 1) + xs.numel() * es)
+rec('  pool_bn_bwd_apply alone', t(lambda: ops.check(lib.loans_pool_bn_bwd_apply_bf16(
+    gy.data_ptr(), idx.data_ptr(), xs.data_ptr(), sts.scale.data_ptr(), sts.shift.data_ptr(), k[0].data_ptr(), k[1].data_ptr(),
+    k[2].data_ptr(), gxs.data_ptr(), gb.data_ptr(), B_, H_, H_, C_, OH, OW, ops._stream()), 'a')), y.numel() * (es + 1) + 2 * xs.numel() * es)
