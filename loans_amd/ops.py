@@ -148,9 +148,10 @@ _TUNE_LOADED = {}        # shape key -> {mode: tile} read from a file: a proposa
 def _tune_stamp():
     """what a table's timings were taken on: entries are only trusted on the same chip and tile-id schema"""
     if not torch.cuda.is_available():
-        return {"device": None, "compute_units": 0, "schema": TUNE_SCHEMA}
+        return {"arch": None, "compute_units": 0, "schema": TUNE_SCHEMA}
     p = torch.cuda.get_device_properties(torch.cuda.current_device())
-    return {"device": p.name, "compute_units": int(p.multi_processor_count), "schema": TUNE_SCHEMA}
+    # the ISA name, not the marketing name (which some boxes of the pool report as an empty string)
+    return {"arch": str(getattr(p, 'gcnArchName', '')).split(':')[0], "compute_units": int(p.multi_processor_count), "schema": TUNE_SCHEMA}
 
 
 def save_tune_table(path):
@@ -171,7 +172,7 @@ def load_tune_table(path):
     with open(path) as f:
         doc = json.load(f)
     stamp = doc.get("stamp")
-    if stamp is not None and stamp != _tune_stamp():
+    if stamp is not None and any(stamp.get(k) != v for k, v in _tune_stamp().items()):
         return 0
     if stamp is None and doc.get("entries") and TUNE_SCHEMA > 2:
         return 0                    # a table from before the stamps (rounds 1-2): mode keys and tile offers have changed since

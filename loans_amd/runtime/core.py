@@ -466,18 +466,18 @@ class ParamArena:
         self.params = [p for _, p in hot]
         total = 0
         for p in self.params:
-            total += (p.size + 3) // 4 * 4
+            total += (p.size + 7) // 8 * 8
         for name in getattr(root, 'cold_links', ()):
             self.cold_offsets[name] = total
             grp = [p for k, p in named if k.startswith('/' + name + '/')]
             self.params += grp
             for p in grp:
-                total += (p.size + 3) // 4 * 4
+                total += (p.size + 7) // 8 * 8
         total = 0
         self.offsets = []
         for p in self.params:
             self.offsets.append(total)
-            total += (p.size + 3) // 4 * 4          # keep every view 16-byte aligned
+            total += (p.size + 7) // 8 * 8          # every view 32-byte aligned: its bf16 shadow (ops._WeightPrep) then is 16-byte aligned
         self.numel = total
         host = np.zeros(total, np.float32)
         for p, o in zip(self.params, self.offsets):
