@@ -795,6 +795,96 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_u16_kernel(const T* x, co
     }
 }
 
+
+// pool_bn_bwd_apply_kernel with the thread's four channels fixed (C4 divides the block size): coefficients in registers, no
+// division per element -- the 2 x 2-patch scheme itself unchanged (the 16-byte-unit form of it ran slower, see above)
+template <typename T>
+__global__ __launch_bounds__(256) void pool_bn_bwd_apply_v4_kernel(const T* gy, const uint8_t* idx, const T* x, const float* scale,
+                                                                   const float* shift, const float* k1, const float* k2,
+                                                                   const float* k3, T* gx, float* gxsum, int B, int H, int W,
+                                                                   int C4, int OH, int OW, int gx_reps) {
+    const int PH = (H + 1) >> 1, PW = (W + 1) >> 1;
+    const int tid = threadIdx.x, c4 = tid % C4, pl = tid / C4, PL = 256 / C4;
+    const f32x4 sc = ld4(scale + c4 * 4), sh = ld4(shift + c4 * 4);
+    const f32x4 c1 = ld4(k1 + c4 * 4), c2 = ld4(k2 + c4 * 4), c3 = ld4(k3 + c4 * 4);
+    f32x4 bsum = {0.f, 0.f, 0.f, 0.f};
+    for (int row = blockIdx.y; row < B * PH; row += gridDim.y) {
+        const int b = row / PH, a = row - b * PH;
+        for (int pb = blockIdx.x * PL + pl; pb < PW; pb += gridDim.x * PL) {
+            f32x4 g[2][2];
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) g[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int wi = 0; wi < 2; ++wi) {
+                const int oh = a - 1 + wi;
+                if (oh < 0 || oh >= OH) continue;
+#pragma unroll
+                for (int wj = 0; wj < 2; ++wj) {
+                    const int ow = pb - 1 + wj;
+                    if (ow < 0 || ow >= OW) continue;
+                    const int64_t o = ((((int64_t)b * OH + oh) * OW + ow) * C4 + c4) * 4;
+                    const uchar4 av = *reinterpret_cast<const uchar4*>(idx + o);
+                    const f32x4 gv = io4<T>::ld(gy + o);
+#pragma unroll
+                    for (int i = 0; i < 2; ++i) {
+                        const int kr = i + 2 - 2 * wi;
+                        if (kr > 2) continue;
+#pragma unroll
+                        for (int j = 0; j < 2; ++j) {
+                            const int kq = j + 2 - 2 * wj;
+                            if (kq > 2) continue;
+                            const int k = kr * 3 + kq;
+                            if (av.x == k) g[i][j].x += gv.x;
+                            if (av.y == k) g[i][j].y += gv.y;
+                            if (av.z == k) g[i][j].z += gv.z;
+                            if (av.w == k) g[i][j].w += gv.w;
+                        }
+                    }
+                }
+            }
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const int ih = 2 * a + i;
+                if (ih >= H) continue;
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int iw = 2 * pb + j;
+                    if (iw >= W) continue;
+                    const int64_t p = ((((int64_t)b * H + ih) * W + iw) * C4 + c4) * 4;
+                    const f32x4 xv = io4<T>::ld(x + p);
+                    const f32x4 v = c1 * maskpos4(g[i][j], xv * sc + sh) + c2 * xv + c3;
+                    io4<T>::st(gx + p, v);
+                    bsum += v;
+                }
+            }
+        }
+    }
+    if (gxsum) {
+        __shared__ f32x4 red[256];
+        red[tid] = bsum;
+        __syncthreads();
+        if (tid < C4) {
+            for (int k = tid + C4; k < 256; k += C4) bsum += red[k];
+            // gx_reps replicas [rep][C]: the blocks' closing atomics on ONE set of C addresses made the pass slower the more
+            // blocks it had (0.33 ms at 1024 blocks, 0.50 at 4096 on a quarter of configs[2]'s conv1 output)
+            float* dst = gxsum + (size_t)((blockIdx.y * gridDim.x + blockIdx.x) % gx_reps) * C4 * 4;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) atomic_add_f32(dst + tid * 4 + e, bsum[e]);
+        }
+    }
+}
+
+// dst[c] += sum over r of src[r][c]
+__global__ void fold_replicas_kernel(const float* src, float* dst, int reps, int C) {
+    const int c = blockIdx.x * blockDim.x + threadIdx.x;
+    if (c >= C) return;
+    float a = 0.f;
+    for (int r = 0; r < reps; ++r) a += src[(size_t)r * C + c];
+    dst[c] += a;
+}
+
 // a channel count the 16-byte-unit kernels tile: U = C / V units per row, U <= 256 and 256 % U == 0
 template <typename T> static inline int units_per_row(int C) {
     constexpr int V = unit16<T>::V;
@@ -981,7 +1071,7 @@ static int pool_bn_bwd_reduce_impl(const T* gy, const uint8_t* idx, const T* x, 
 template <typename T>
 static int pool_bn_bwd_apply_impl(const T* gy, const uint8_t* idx, const T* x, const float* scale, const float* shift,
                                   const float* k1, const float* k2, const float* k3, T* gx, float* gxsum, int32_t B,
-                                  int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream) {
+                                  int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream, int gx_reps = 1) {
     if (!gy || !idx || !x || !scale || !shift || !k1 || !k2 || !k3 || !gx || B <= 0 || H < 3 || W < 3 || C <= 0 || (C & 3))
         return LOANS_EINVAL;
     if (gxsum && (C / 4 > 256 || 256 % (C / 4))) return LOANS_EINVAL;
@@ -990,6 +1080,16 @@ static int pool_bn_bwd_apply_impl(const T* gy, const uint8_t* idx, const T* x, c
     if ((int64_t)B * PH >= ((int64_t)1 << 31) || (int64_t)PW * (C / 4) >= ((int64_t)1 << 31)) return LOANS_ERANGE;
     // <= ~2048 blocks (8 per CU; the loops are grid-stride): every block ends with C float atomics on the same two
     // cache lines of gxsum, and 32 k blocks of them cost more than the pass itself
+    if (gx_reps < 1 || gx_reps > 64) return LOANS_EINVAL;
+    if (gx_reps > 1) {
+        if (!gxsum || C / 4 > 256 || 256 % (C / 4)) return LOANS_EINVAL;
+        const int PL = 256 / (C / 4), gxb = (PW + PL - 1) / PL;
+        const dim3 g4(gxb, (unsigned)min((int64_t)B * PH, (int64_t)max(1, 4096 / gxb)));
+        hipLaunchKernelGGL(pool_bn_bwd_apply_v4_kernel<T>, g4, dim3(256), 0, as_stream(stream), gy, idx, x, scale, shift, k1, k2, k3,
+                           gx, gxsum, B, H, W, C / 4, OH, OW, gx_reps);
+        LOANS_LAUNCH_CHECK();
+        return LOANS_OK;
+    }
     const int gx_blocks = (PW * (C / 4) + 255) / 256;
     const dim3 grid(gx_blocks, (unsigned)min((int64_t)B * PH, (int64_t)max(1, 2048 / gx_blocks)));
     hipLaunchKernelGGL(pool_bn_bwd_apply_kernel<T>, grid, dim3(256), 0, as_stream(stream), gy, idx, x, scale, shift, k1, k2,
@@ -1286,4 +1386,30 @@ extern "C" int loans_bn_bwd_reduce_rep_bf16(const void* gy, const void* mask, in
                                             const float* scale, const float* shift, double* sums, int32_t replicas, int64_t rows,
                                             int32_t C, void* stream) {
     return bn_bwd_reduce_rep<__bf16>(gy, mask, mask_kind, x, mean, rstd, x2, mean2, rstd2, scale, shift, sums, replicas, rows, C, stream);
+}
+
+// the fused pool backward's apply pass with the bias-gradient sums going into `replicas` accumulators gxsum_rep[replicas][C]
+// (zeroed by the caller, folded into the bias gradient by loans_fold_replicas_f32); C / 4 must divide 256
+extern "C" int loans_pool_bn_bwd_apply_rep_f32(const float* gy, const uint8_t* idx, const float* x, const float* scale,
+                                               const float* shift, const float* k1, const float* k2, const float* k3, float* gx,
+                                               float* gxsum_rep, int32_t replicas, int32_t B, int32_t H, int32_t W, int32_t C,
+                                               int32_t OH, int32_t OW, void* stream) {
+    if (replicas < 2) return LOANS_EINVAL;
+    return pool_bn_bwd_apply_impl<float>(gy, idx, x, scale, shift, k1, k2, k3, gx, gxsum_rep, B, H, W, C, OH, OW, stream, replicas);
+}
+
+extern "C" int loans_pool_bn_bwd_apply_rep_bf16(const void* gy, const uint8_t* idx, const void* x, const float* scale,
+                                                const float* shift, const float* k1, const float* k2, const float* k3, void* gx,
+                                                float* gxsum_rep, int32_t replicas, int32_t B, int32_t H, int32_t W, int32_t C,
+                                                int32_t OH, int32_t OW, void* stream) {
+    if (replicas < 2) return LOANS_EINVAL;
+    return pool_bn_bwd_apply_impl<__bf16>(static_cast<const __bf16*>(gy), idx, static_cast<const __bf16*>(x), scale, shift, k1, k2, k3,
+                                          static_cast<__bf16*>(gx), gxsum_rep, B, H, W, C, OH, OW, stream, replicas);
+}
+
+extern "C" int loans_fold_replicas_f32(const float* src, float* dst, int32_t replicas, int32_t C, void* stream) {
+    if (!src || !dst || replicas <= 0 || C <= 0) return LOANS_EINVAL;
+    hipLaunchKernelGGL(fold_replicas_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), src, dst, replicas, C);
+    LOANS_LAUNCH_CHECK();
+    return LOANS_OK;
 }

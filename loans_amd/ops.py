@@ -727,8 +727,10 @@ def _conv_fprop16(lib, x, w, geo, out, bias, stats, relu_in, addend, tile):
         halo = _halo_tiles(geo, geo.Cin, geo.Cout, (geo.Ho, geo.Wo), relu_in) + _wide16_tiles(geo.Cout, geo.B * geo.Ho * geo.Wo)
         sk = () if geo.dense else _splitk16_candidates(geo.B * geo.Ho * geo.Wo, geo.Cout, geo.w_numel // geo.Cout)
         stem = (TILE_STEM,) if (STEM_DIRECT and geo.dense and not relu_in and addend is None and stem16_tile_rows(geo)) else ()
+        # (relu_in is part of the key: the weight-stationary tiles do not take it, so a tile tuned without it may not apply)
         tile = _tuned_tile(geo, 'bf16s_fprop' + ('_stats' if stats is not None else '') + ('_h' if halo else '') +
-                           ('_sk' if sk else '') + ('_st' if stem else ''), run, _IGEMM16_TILES + halo + sk + stem)
+                           ('_sk' if sk else '') + ('_st' if stem else '') + ('_relu' if relu_in else ''), run,
+                           _IGEMM16_TILES + halo + sk + stem)
     d = _with_flags(geo.fwd, flags, tile)
     _count_flops('fprop', geo)
     log = EVENT_LOG
@@ -1648,6 +1650,14 @@ def pool_bn_backward(gy, idx, x, st, gamma, ggamma, gbeta, gbias=None):
     check(lib.loans_bn_bwd_coeffs_f32(_ptr(sums), C_, B * H * W, _ptr(gamma), _ptr(st.mean), _ptr(st.rstd), _ptr(ggamma),
                                       _ptr(gbeta), _ptr(k[0]), _ptr(k[1]), _ptr(k[2]), s), 'loans_bn_bwd_coeffs_f32')
     gx = torch.empty_like(x)
+    if gbias is not None and BN_REPLICAS and C_ // 4 <= 256 and 256 % (C_ // 4) == 0:
+        # the bias-gradient sums go through 32 replicas (fp32 views of the step's zeroed accumulator pool), then one fold
+        reps = _zeros_f64((STATS_REPLICAS // 2, C_), x.device).view(torch.float32).view(STATS_REPLICAS, C_)
+        rep_fn = lib.loans_pool_bn_bwd_apply_rep_bf16 if s16 else lib.loans_pool_bn_bwd_apply_rep_f32
+        check(rep_fn(_ptr(gy), _ptr(idx), _ptr(x), _ptr(st.scale), _ptr(st.shift), _ptr(k[0]), _ptr(k[1]), _ptr(k[2]), _ptr(gx),
+                     _ptr(reps), STATS_REPLICAS, B, H, W, C_, OH, OW, s), 'loans_pool_bn_bwd_apply_rep')
+        check(lib.loans_fold_replicas_f32(_ptr(reps), _ptr(gbias), STATS_REPLICAS, C_, s), 'loans_fold_replicas_f32')
+        return gx
     check(app_fn(_ptr(gy), _ptr(idx), _ptr(x), _ptr(st.scale), _ptr(st.shift), _ptr(k[0]), _ptr(k[1]), _ptr(k[2]), _ptr(gx),
                  _ptr(gbias), B, H, W, C_, OH, OW, s), 'loans_pool_bn_bwd_apply')
     return gx

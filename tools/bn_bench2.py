@@ -85,6 +85,10 @@ gb = torch.zeros(C_, device='cuda')
 rec('  pool_bn_bwd_reduce alone', t(lambda: ops.check(lib.loans_pool_bn_bwd_reduce_bf16(
     gy.data_ptr(), idx.data_ptr(), xs.data_ptr(), sts.scale.data_ptr(), sts.shift.data_ptr(), sts.mean.data_ptr(), sts.rstd.data_ptr(),
     sums.data_ptr(), B_, H_, H_, C_, OH, OW, ops._stream()), 'r')), y.numel() * (es + 1) + xs.numel() * es)
+reps = torch.zeros((32, C_), device='cuda')
+rec('  pool_bn_bwd_apply alone, replicated gxsum', t(lambda: ops.check(lib.loans_pool_bn_bwd_apply_rep_bf16(
+    gy.data_ptr(), idx.data_ptr(), xs.data_ptr(), sts.scale.data_ptr(), sts.shift.data_ptr(), k[0].data_ptr(), k[1].data_ptr(),
+    k[2].data_ptr(), gxs.data_ptr(), reps.data_ptr(), 32, B_, H_, H_, C_, OH, OW, ops._stream()), 'a')), y.numel() * (es + 1) + 2 * xs.numel() * es)
 rec('  pool_bn_bwd_apply alone', t(lambda: ops.check(lib.loans_pool_bn_bwd_apply_bf16(
     gy.data_ptr(), idx.data_ptr(), xs.data_ptr(), sts.scale.data_ptr(), sts.shift.data_ptr(), k[0].data_ptr(), k[1].data_ptr(),
     k[2].data_ptr(), gxs.data_ptr(), gb.data_ptr(), B_, H_, H_, C_, OH, OW, ops._stream()), 'a')), y.numel() * (es + 1) + 2 * xs.numel() * es)
