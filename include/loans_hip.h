@@ -353,6 +353,13 @@ int loans_bn_bwd_reduce_rep_f32(const float* gy, const void* mask, int32_t mask_
 int loans_bn_bwd_reduce_rep_bf16(const void* gy, const void* mask, int32_t mask_kind, const void* x, const float* mean,
                                  const float* rstd, const void* x2, const float* mean2, const float* rstd2, const float* scale,
                                  const float* shift, double* sums, int32_t replicas, int64_t rows, int32_t C, void* stream);
+/* the stem tail's reduction (loans_pool_bn_bwd_reduce_*) into replicated accumulators [replicas][2][C] (round 3) */
+int loans_pool_bn_bwd_reduce_rep_f32(const float* gy, const uint8_t* idx, const float* x, const float* scale, const float* shift,
+                                     const float* mean, const float* rstd, double* sums, int32_t replicas, int32_t B, int32_t H,
+                                     int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream);
+int loans_pool_bn_bwd_reduce_rep_bf16(const void* gy, const uint8_t* idx, const void* x, const float* scale, const float* shift,
+                                      const float* mean, const float* rstd, double* sums, int32_t replicas, int32_t B, int32_t H,
+                                      int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream);
 /* loans_pool_bn_bwd_apply_* with the bias-gradient sums (gxsum) going into `replicas` accumulators gxsum_rep[replicas][C], zeroed by
  * the caller and folded into the bias gradient by loans_fold_replicas_f32 (dst[c] += sum_r src[r][c]): every block closes with C float
  * atomics, and on ONE set of addresses they made the pass slower the more blocks it had.  C / 4 must divide 256.  (round 3) */

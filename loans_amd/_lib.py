@@ -119,6 +119,8 @@ SIGNATURES = {
     'loans_bn_bwd_reduce_f32': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p],
     'loans_bn_bwd_coeffs_f32': [_p, _i32, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     'loans_bn_bwd_coeffs_rep_f32': [_p, _i32, _i32, _i32, _i32, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p],
+    'loans_pool_bn_bwd_reduce_rep_f32': [_p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p],
+    'loans_pool_bn_bwd_reduce_rep_bf16': [_p, _p, _p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _p],
     'loans_pool_bn_bwd_apply_rep_f32': [_p] * 10 + [_i32] * 7 + [_p],
     'loans_pool_bn_bwd_apply_rep_bf16': [_p] * 10 + [_i32] * 7 + [_p],
     'loans_fold_replicas_f32': [_p, _p, _i32, _i32, _p],

@@ -281,7 +281,7 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_reduce_kernel(const T* gy, co
                                                                  const float* scale, const float* shift,
                                                                  const float* mean, const float* rstd, double* sums,
                                                                  int rows, int H, int W, int OH, int OW,
-                                                                 int C4, int C4T, int rows_per_block) {
+                                                                 int C4, int C4T, int rows_per_block, int replicas) {
     __shared__ f32x4 red[2][256];
     const int tid = threadIdx.x;
     const int cl = tid % C4, rl = tid / C4, RL = 256 / C4;
@@ -317,6 +317,7 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_reduce_kernel(const T* gy, co
             sgx += red[1][tid + k * C4];
         }
         const int C = C4T * 4;
+        sums += (size_t)(blockIdx.x % replicas) * 2 * C;        // [replicas][2][C], see loans_bn_bwd_reduce_rep_*
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             atomic_add_f64(sums + cg * 4 + e, (double)sg[e]);
@@ -1054,16 +1055,24 @@ extern "C" int loans_maxpool_relu_bwd_bf16(const void* gy, const uint8_t* idx, c
 template <typename T>
 static int pool_bn_bwd_reduce_impl(const T* gy, const uint8_t* idx, const T* x, const float* scale, const float* shift,
                                    const float* mean, const float* rstd, double* sums, int32_t B, int32_t H, int32_t W,
-                                   int32_t C, int32_t OH, int32_t OW, void* stream) {
+                                   int32_t C, int32_t OH, int32_t OW, void* stream, int replicas = 1) {
     if (!gy || !idx || !x || !scale || !shift || !mean || !rstd || !sums || B <= 0 || H < 3 || W < 3) return LOANS_EINVAL;
+    if (replicas < 1 || replicas > 32) return LOANS_EINVAL;
     if (!reduce_channels_ok(C)) return LOANS_EINVAL;
     if (OH != (H - 2) / 2 + 1 || OW != (W - 2) / 2 + 1) return LOANS_EINVAL;
     const int64_t rows = (int64_t)B * OH * OW;
     if (rows >= ((int64_t)1 << 31)) return LOANS_ERANGE;
     int rpb, c4b, slabs;
-    const int grid = reduce_geometry(rows, C, &rpb, &c4b, &slabs);
+    int grid = reduce_geometry(rows, C, &rpb, &c4b, &slabs);
+    if (replicas > 1) {             // replicated accumulators: four times the blocks (the closing atomics no longer collide)
+        const int RL = 256 / c4b;
+        int64_t r4 = ((rows + 4095) / 4096 + RL - 1) / RL * RL;
+        if (r4 < 8 * RL) r4 = 8 * RL;
+        rpb = (int)r4;
+        grid = (int)((rows + rpb - 1) / rpb);
+    }
     hipLaunchKernelGGL(pool_bn_bwd_reduce_kernel<T>, dim3(grid, slabs), dim3(256), 0, as_stream(stream), gy, idx, x, scale,
-                       shift, mean, rstd, sums, (int)rows, H, W, OH, OW, c4b, C / 4, rpb);
+                       shift, mean, rstd, sums, (int)rows, H, W, OH, OW, c4b, C / 4, rpb, replicas);
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;
 }
@@ -1412,4 +1421,22 @@ extern "C" int loans_fold_replicas_f32(const float* src, float* dst, int32_t rep
     hipLaunchKernelGGL(fold_replicas_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), src, dst, replicas, C);
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;
+}
+
+// the stem tail's reduction into replicated accumulators [replicas][2][C] (see loans_bn_bwd_reduce_rep_*)
+extern "C" int loans_pool_bn_bwd_reduce_rep_f32(const float* gy, const uint8_t* idx, const float* x, const float* scale,
+                                                const float* shift, const float* mean, const float* rstd, double* sums,
+                                                int32_t replicas, int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW,
+                                                void* stream) {
+    if (replicas < 2) return LOANS_EINVAL;
+    return pool_bn_bwd_reduce_impl<float>(gy, idx, x, scale, shift, mean, rstd, sums, B, H, W, C, OH, OW, stream, replicas);
+}
+
+extern "C" int loans_pool_bn_bwd_reduce_rep_bf16(const void* gy, const uint8_t* idx, const void* x, const float* scale,
+                                                 const float* shift, const float* mean, const float* rstd, double* sums,
+                                                 int32_t replicas, int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW,
+                                                 void* stream) {
+    if (replicas < 2) return LOANS_EINVAL;
+    return pool_bn_bwd_reduce_impl<__bf16>(static_cast<const __bf16*>(gy), idx, static_cast<const __bf16*>(x), scale, shift, mean, rstd,
+                                           sums, B, H, W, C, OH, OW, stream, replicas);
 }

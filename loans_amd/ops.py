@@ -1643,12 +1643,21 @@ def pool_bn_backward(gy, idx, x, st, gamma, ggamma, gbeta, gbias=None):
     s = _stream()
     app_fn = lib.loans_pool_bn_bwd_apply_bf16 if s16 else lib.loans_pool_bn_bwd_apply_f32
     k = torch.empty((3, C_), device=x.device, dtype=torch.float32)
-    sums = _zeros_f64((2, C_), x.device)
-    red_fn = lib.loans_pool_bn_bwd_reduce_bf16 if s16 else lib.loans_pool_bn_bwd_reduce_f32
-    check(red_fn(_ptr(gy), _ptr(idx), _ptr(x), _ptr(st.scale), _ptr(st.shift), _ptr(st.mean), _ptr(st.rstd), _ptr(sums),
-                 B, H, W, C_, OH, OW, s), 'loans_pool_bn_bwd_reduce')
-    check(lib.loans_bn_bwd_coeffs_f32(_ptr(sums), C_, B * H * W, _ptr(gamma), _ptr(st.mean), _ptr(st.rstd), _ptr(ggamma),
-                                      _ptr(gbeta), _ptr(k[0]), _ptr(k[1]), _ptr(k[2]), s), 'loans_bn_bwd_coeffs_f32')
+    if BN_REPLICAS:
+        sums = _zeros_f64((STATS_REPLICAS, 2, C_), x.device)
+        red_fn = lib.loans_pool_bn_bwd_reduce_rep_bf16 if s16 else lib.loans_pool_bn_bwd_reduce_rep_f32
+        check(red_fn(_ptr(gy), _ptr(idx), _ptr(x), _ptr(st.scale), _ptr(st.shift), _ptr(st.mean), _ptr(st.rstd), _ptr(sums),
+                     STATS_REPLICAS, B, H, W, C_, OH, OW, s), 'loans_pool_bn_bwd_reduce_rep')
+        check(lib.loans_bn_bwd_coeffs_rep_f32(_ptr(sums), STATS_REPLICAS, 2 * C_, 0, C_, B * H * W, _ptr(gamma), _ptr(st.mean),
+                                              _ptr(st.rstd), _ptr(ggamma), _ptr(gbeta), _ptr(k[0]), _ptr(k[1]), _ptr(k[2]), s),
+              'loans_bn_bwd_coeffs_rep_f32')
+    else:
+        sums = _zeros_f64((2, C_), x.device)
+        red_fn = lib.loans_pool_bn_bwd_reduce_bf16 if s16 else lib.loans_pool_bn_bwd_reduce_f32
+        check(red_fn(_ptr(gy), _ptr(idx), _ptr(x), _ptr(st.scale), _ptr(st.shift), _ptr(st.mean), _ptr(st.rstd), _ptr(sums),
+                     B, H, W, C_, OH, OW, s), 'loans_pool_bn_bwd_reduce')
+        check(lib.loans_bn_bwd_coeffs_f32(_ptr(sums), C_, B * H * W, _ptr(gamma), _ptr(st.mean), _ptr(st.rstd), _ptr(ggamma),
+                                          _ptr(gbeta), _ptr(k[0]), _ptr(k[1]), _ptr(k[2]), s), 'loans_bn_bwd_coeffs_f32')
     gx = torch.empty_like(x)
     if gbias is not None and BN_REPLICAS and C_ // 4 <= 256 and 256 % (C_ // 4) == 0:
         # the bias-gradient sums go through 32 replicas (fp32 views of the step's zeroed accumulator pool), then one fold

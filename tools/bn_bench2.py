@@ -82,6 +82,10 @@ sums = torch.zeros((2, C_), device='cuda', dtype=torch.float64)
 k = torch.ones((3, C_), device='cuda')
 gxs = torch.empty_like(xs)
 gb = torch.zeros(C_, device='cuda')
+sums_rep = torch.zeros((32, 2, C_), device='cuda', dtype=torch.float64)
+rec('  pool_bn_bwd_reduce alone, replicated', t(lambda: ops.check(lib.loans_pool_bn_bwd_reduce_rep_bf16(
+    gy.data_ptr(), idx.data_ptr(), xs.data_ptr(), sts.scale.data_ptr(), sts.shift.data_ptr(), sts.mean.data_ptr(), sts.rstd.data_ptr(),
+    sums_rep.data_ptr(), 32, B_, H_, H_, C_, OH, OW, ops._stream()), 'r')), y.numel() * (es + 1) + xs.numel() * es)
 rec('  pool_bn_bwd_reduce alone', t(lambda: ops.check(lib.loans_pool_bn_bwd_reduce_bf16(
     gy.data_ptr(), idx.data_ptr(), xs.data_ptr(), sts.scale.data_ptr(), sts.shift.data_ptr(), sts.mean.data_ptr(), sts.rstd.data_ptr(),
     sums.data_ptr(), B_, H_, H_, C_, OH, OW, ops._stream()), 'r')), y.numel() * (es + 1) + xs.numel() * es)
