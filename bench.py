@@ -389,6 +389,17 @@ def run_workload(w, comm, local_rank, retune):
     log, ops.EVENT_LOG = ops.EVENT_LOG, None
     flop_count, ops.FLOP_COUNT = ops.FLOP_COUNT, None
 
+    # what the HOST needs to enqueue one step (after the timed region, not part of it): with the GPU idle at the start of
+    # each call, update() returns as soon as its last launch is queued.  A value near ms_per_step means the step is launch-bound
+    host_ms = []
+    for _ in range(3):
+        torch.cuda.synchronize()
+        h0 = time.perf_counter()
+        updater.update()
+        host_ms.append((time.perf_counter() - h0) * 1e3)
+    torch.cuda.synchronize()
+    host_enqueue_ms = float(np.median(host_ms))
+
     # what a bracket of two HIP events measures with NOTHING between them: the events are packets of their own in the
     # queue, and that time is not the kernel's (rocprofv3's per-kernel durations do not contain it either)
     ev_overhead_ms = 0.0
@@ -417,6 +428,7 @@ def run_workload(w, comm, local_rank, retune):
                    "per_gpu_batch": B, "global_batch": B * world, "frame": "3x%dx%d" % (hw, hw),
                    "crop": "3x%dx%d" % (crop, crop), "parallelism": "dp%d" % world, "world_size": world, "dist_backend": comm.backend,
                    "baseline_config": config_label(w, world), "hip_graph": bool(w.graph), "init_steps": init_steps,
+                   "host_enqueue_ms_per_step": round(host_enqueue_ms, 3),
                    "activation_storage": w.storage,
                    "tune_table": ("read %d shapes from %s" % (tune_loaded, os.path.relpath(tune_file, ROOT))) if tune_loaded
                    else "autotuned in this run"},

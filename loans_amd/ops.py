@@ -7,6 +7,7 @@ fallback: without the built library ``_lib.load()`` raises.
 """
 import ctypes as C
 import os
+import time
 
 import numpy as np
 
@@ -65,6 +66,17 @@ def _igemm_fn(lib):
 # When bench.py sets this to a list, conv_fprop brackets each launch with HIP events recorded on the
 # launch stream and appends (tag, algorithmic_flops, start_event, end_event).
 EVENT_LOG = None
+# development probe (tools/host_lead.py): a list makes `probe(name)` record a HIP event on the current stream together with
+# the host's clock at the moment it was enqueued -- where in a step the host runs ahead of the GPU, and where it does not
+PROBE_LOG = None
+
+
+def probe(name):
+    log = PROBE_LOG
+    if log is not None:
+        ev = torch.cuda.Event(enable_timing=True)
+        ev.record()
+        log.append((name, ev, time.perf_counter()))
 # When bench.py sets this to a dict, every convolution launch (forward, data gradient, weight gradient) adds its ALGORITHMIC
 # FLOP (2 per MAC, logical input channels, no padding / im2col redundancy) under 'fprop' / 'dgrad' / 'wgrad'.
 FLOP_COUNT = None
@@ -1000,6 +1012,8 @@ ASYNC_WGRAD = os.environ.get('LOANS_ASYNC_WGRAD', '1') != '0'
 # while a step is being recorded into a hipGraph the side streams fork from / join the capturing stream, so the graph keeps
 # the eager step's concurrency (weight gradients beside the data-gradient chain, the assessor's chain beside the localizer's)
 CAPTURE_STREAMS = os.environ.get('LOANS_CAPTURE_STREAMS', '1') != '0'
+# HIP stream priority of the weight-gradient stream (0 = normal like the main stream, 1 = low, -1 = high): experiment knob
+SIDE_PRIORITY = int(os.environ.get('LOANS_SIDE_PRIORITY', '0'))
 _side = {}
 _side_dirty = set()
 
@@ -1007,7 +1021,7 @@ _side_dirty = set()
 def _side_stream(device):
     st = _side.get(device.index)
     if st is None:
-        st = _side[device.index] = torch.cuda.Stream(device=device)
+        st = _side[device.index] = torch.cuda.Stream(device=device, priority=SIDE_PRIORITY)
     return st
 
 

@@ -21,13 +21,19 @@ from ..runtime.core import Variable, report, reporter
 # backward (the 4-channel crop gradient: 1.2 ms, the stem's pool / BN passes: 1.1 ms at B = 256) and the tails of its
 # launches: 54.8 -> 52.9 ms per step.  Results are identical: same kernels, same operands, same order per chain.
 CONCURRENT_CHAINS = os.environ.get('LOANS_CONCURRENT_CHAINS', '1') != '0'
+# LOANS_EARLY_CHAIN=1 enqueues that chain FIRST (it needs nothing of this step's localizer), in the reference's D(real)-before-
+# D(fake) order, so that it runs beside the localizer's FORWARD, whose BN / pooling passes leave the matrix cores idle and have
+# no weight gradients to fill them: fp32 B = 256 50.7 -> 49.9 ms, bf16 configs unchanged (round 3).  Not the default: the
+# localizer's conv-forward launches then share the GPU with it, and the per-launch durations bench.py's roofline, the rocprofv3
+# trace and the PMC passes are built on (8.8 ms per step alone) read 15.8 ms -- a property of the schedule, not of the kernel.
+EARLY_CHAIN = os.environ.get('LOANS_EARLY_CHAIN', '0') != '0'
 _fork = {}
 
 
 def _fork_stream(device):
     st = _fork.get(device.index)
     if st is None:
-        st = _fork[device.index] = torch.cuda.Stream(device=device)
+        st = _fork[device.index] = torch.cuda.Stream(device=device, priority=int(os.environ.get('LOANS_FORK_PRIORITY', '0')))
     return st
 
 
@@ -112,8 +118,30 @@ class SheepAssessor(training.StandardUpdater):
 
         if not concurrent:
             y_real = self.discriminator(real_images)
+        early = concurrent and EARLY_CHAIN
 
+        ops.probe('step begin')
+        if early:
+            # the assessor's own chain needs nothing of this step's localizer: it is enqueued FIRST, in the reference's
+            # order (sheep_updater.py:37: D(real) before D(fake)), and runs beside the localizer's forward, whose BN /
+            # pooling passes leave the matrix cores idle
+            self.discriminator.cleargrads()
+            self.localizer.cleargrads()
+            for param in self.discriminator.params():
+                param.skip_grad_when_disabled = True
+            main = torch.cuda.current_stream()
+            fork = _fork_stream(main.device)
+            fork.wait_stream(main)
+            with torch.cuda.stream(fork):
+                y_real = self.discriminator(real_images)
+                real_forward_done = torch.cuda.Event()
+                real_forward_done.record(fork)
+                loss_dis = mean_squared_error(y_real, labels)
+                loss_dis.backward()
         x_fake, bboxes = self.localizer(fake_images)
+        ops.probe('localizer forward enqueued')
+        if early:
+            main.wait_event(real_forward_done)     # the BN running statistics of the assessor: D(real)'s update, then D(fake)'s
         y_fake = self.discriminator(x_fake)
 
         localization_labels = xp.full((len(y_fake), 1), self.localizer_target, dtype=xp.float32,
@@ -123,7 +151,8 @@ class SheepAssessor(training.StandardUpdater):
         for regularizer in self.regularizers:
             loss_localizer += regularizer.calc_loss(bboxes, Size._make(fake_images.shape[-2:]))
 
-        if concurrent:
+        ops.probe('losses enqueued')
+        if concurrent and not early:
             # the reference's second half (sheep_updater.py:55-66), enqueued first and on its own stream; both
             # gradient arenas are cleared before the fork because clearing joins the weight-gradient stream
             self.discriminator.cleargrads()
@@ -144,7 +173,9 @@ class SheepAssessor(training.StandardUpdater):
 
         if not concurrent:
             self.localizer.cleargrads()
+        ops.probe('assessor chain enqueued (fork stream)')
         loss_localizer.backward()
+        ops.probe('localizer backward enqueued')
         # Data parallel: the localizer's gradient all-reduce (50 MB) is started here and overlaps the assessor's backward
         # below, which touches neither those gradients nor the localizer's parameters; the Adam step then lands where
         # the reference has it in effect (both updates are independent) -- `overlap` is False on a single GPU
@@ -178,6 +209,7 @@ class SheepAssessor(training.StandardUpdater):
             discriminator_optimizer.update()
 
         report({'loss_dis': loss_dis})
+        ops.probe('step end')
 
 
 SheepUpdater = SheepAssessor

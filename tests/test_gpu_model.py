@@ -60,12 +60,14 @@ def test_localizer_assessor_forward_parity(shape):
         np.testing.assert_allclose(st[k], lp[k], rtol=1e-4, atol=1e-5)
 
 
-@pytest.mark.parametrize("concurrent", [True, False])
-def test_update_core_gradients_and_parameters_parity(concurrent, monkeypatch):
-    """both issue orders of the step: the assessor's own chain on a second stream beside the localizer's backward
-    (sheep_updater.CONCURRENT_CHAINS, the default) and the reference's sequential order"""
+@pytest.mark.parametrize("order", ['beside-forward', 'beside-backward', 'sequential'])
+def test_update_core_gradients_and_parameters_parity(order, monkeypatch):
+    """the three issue orders of the step: the assessor's own chain on a second stream, enqueued first and running beside the
+    localizer's forward (sheep_updater.EARLY_CHAIN) or enqueued at the losses and running beside the localizer's backward (the
+    default), and the reference's sequential order on one stream"""
     from loans_amd.sheep import sheep_updater
-    monkeypatch.setattr(sheep_updater, 'CONCURRENT_CHAINS', concurrent)
+    monkeypatch.setattr(sheep_updater, 'CONCURRENT_CHAINS', order != 'sequential')
+    monkeypatch.setattr(sheep_updater, 'EARLY_CHAIN', order == 'beside-forward')
     B, H, W, crop = 4, 64, 64, (16, 16)
     loc, dis = build_pair(3, crop)
     frames, real, labels = inputs(4, B, H, W, crop)
