@@ -496,22 +496,57 @@ __global__ __launch_bounds__(256) void igemm_finalize_kernel(float* out, const f
 template <typename T> struct unit16;
 template <> struct unit16<float> {
     static constexpr int V = 4, NV = 1;
+    typedef f32x4 raw_t;
+    template <bool NT = false> static __device__ __forceinline__ raw_t ldr(const float* p) {
+        if (NT) return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p));
+        return *reinterpret_cast<const f32x4*>(p);
+    }
+    static __device__ __forceinline__ void cvt(raw_t r, f32x4* v) { v[0] = r; }
     static __device__ __forceinline__ void ld(const float* p, f32x4* v) { v[0] = *reinterpret_cast<const f32x4*>(p); }
-    static __device__ __forceinline__ void st(float* p, const f32x4* v) { *reinterpret_cast<f32x4*>(p) = v[0]; }
+    template <bool NT = false> static __device__ __forceinline__ void st(float* p, const f32x4* v) {
+        if (NT) __builtin_nontemporal_store(v[0], reinterpret_cast<f32x4*>(p));
+        else *reinterpret_cast<f32x4*>(p) = v[0];
+    }
 };
 template <> struct unit16<__bf16> {
     static constexpr int V = 8, NV = 2;
     typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
-    static __device__ __forceinline__ void ld(const __bf16* p, f32x4* v) {
-        const bf16x8 r = *reinterpret_cast<const bf16x8*>(p);
+    typedef bf16x8 raw_t;
+    template <bool NT = false> static __device__ __forceinline__ raw_t ldr(const __bf16* p) {
+        if (NT) return __builtin_nontemporal_load(reinterpret_cast<const bf16x8*>(p));
+        return *reinterpret_cast<const bf16x8*>(p);
+    }
+    static __device__ __forceinline__ void cvt(raw_t r, f32x4* v) {
         v[0] = __builtin_convertvector(__builtin_shufflevector(r, r, 0, 1, 2, 3), f32x4);
         v[1] = __builtin_convertvector(__builtin_shufflevector(r, r, 4, 5, 6, 7), f32x4);
     }
-    static __device__ __forceinline__ void st(__bf16* p, const f32x4* v) {
+    static __device__ __forceinline__ void ld(const __bf16* p, f32x4* v) { cvt(ldr(p), v); }
+    template <bool NT = false> static __device__ __forceinline__ void st(__bf16* p, const f32x4* v) {
         const loans_bf16x4 a = __builtin_convertvector(v[0], loans_bf16x4), b = __builtin_convertvector(v[1], loans_bf16x4);
-        *reinterpret_cast<bf16x8*>(p) = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+        const bf16x8 r = __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7);
+        if (NT) __builtin_nontemporal_store(r, reinterpret_cast<bf16x8*>(p));
+        else *reinterpret_cast<bf16x8*>(p) = r;
     }
 };
+
+// The units one block streams (round 3, tools/stream_patterns.hip): its own CONTIGUOUS slab, a multiple of 256 units long so
+// that a thread's channel unit stays tid % U, walked 256 units at a time with SLAB_UNR steps in flight.  Two reads + one write
+// of 512 MiB bf16 tensors: 5.3-5.8 TB/s like this against 4.3-4.8 for a grid-stride walk of persistent blocks (the form of
+// the first u16 kernels: every block touching every part of the tensor) -- what an HBM page sees is a dense burst, not a
+// trickle from 4096 blocks.  NT: non-temporal loads and stores (+5 % on tensors far beyond the 256 MB Infinity Cache).
+constexpr int SLAB_UNR = 4;
+struct Slab { int64_t i, end; };
+__device__ __forceinline__ Slab slab_of(int64_t nunits) {
+    const int64_t per = ((nunits + gridDim.x - 1) / gridDim.x + 255) & ~(int64_t)255;
+    const int64_t lo = (int64_t)blockIdx.x * per;
+    return Slab{lo + threadIdx.x, lo + per < nunits ? lo + per : nunits};
+}
+static inline int slab_grid(int64_t nunits) { return grid_for(nunits, 256 * SLAB_UNR, 8192); }
+// LOANS_BN_NT: 0 never, 1 always, unset: tensors of at least 96 MB (they cannot stay in the Infinity Cache with their partners)
+static inline bool slab_nt(int64_t tensor_bytes) {
+    static const int mode = [] { const char* e = getenv("LOANS_BN_NT"); return e && *e ? atoi(e) : -1; }();
+    return mode < 0 ? tensor_bytes >= (96ll << 20) : mode != 0;
+}
 
 // one byte of sign bits per four channels: a unit owns NV consecutive bytes
 template <int NV> __device__ __forceinline__ void st_bits(uint8_t* p, const f32x4* v) {
@@ -523,11 +558,12 @@ template <int NV> __device__ __forceinline__ void ld_bits(const uint8_t* p, uint
     else { const uint16_t w = *reinterpret_cast<const uint16_t*>(p); b[0] = (uint8_t)(w & 255); b[1] = (uint8_t)(w >> 8); }
 }
 
-template <int MODE, bool BITS, typename T>
+template <int MODE, bool BITS, bool NT, typename T>
 __global__ __launch_bounds__(256) void bn_apply_u16_kernel(const T* x, const float* scale, const float* shift, const T* x2,
                                                            const float* scale2, const float* shift2, T* y, int64_t nunits,
                                                            int U, int relu, uint8_t* signbits) {
     constexpr int V = unit16<T>::V, NV = unit16<T>::NV;
+    typedef typename unit16<T>::raw_t raw_t;
     const int cu = threadIdx.x % U;             // this thread's channel unit, the same in every iteration
     f32x4 s[NV], t[NV], s2[NV], t2[NV];
 #pragma unroll
@@ -535,9 +571,10 @@ __global__ __launch_bounds__(256) void bn_apply_u16_kernel(const T* x, const flo
         s[q] = ld4(scale + cu * V + 4 * q); t[q] = ld4(shift + cu * V + 4 * q);
         if (MODE == 2) { s2[q] = ld4(scale2 + cu * V + 4 * q); t2[q] = ld4(shift2 + cu * V + 4 * q); }
     }
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    auto one = [&](int64_t i, const f32x4* xv, const f32x4* rv) {
-        f32x4 v[NV];
+    auto one = [&](int64_t i, raw_t xr, raw_t rr) {
+        f32x4 v[NV], xv[NV], rv[NV];
+        unit16<T>::cvt(xr, xv);
+        if (MODE != 0) unit16<T>::cvt(rr, rv);
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
             v[q] = xv[q] * s[q] + t[q];
@@ -545,33 +582,36 @@ __global__ __launch_bounds__(256) void bn_apply_u16_kernel(const T* x, const flo
             if (MODE == 2) v[q] += rv[q] * s2[q] + t2[q];
             if (relu) v[q] = relu4(v[q]);
         }
-        unit16<T>::st(y + i * V, v);
+        unit16<T>::template st<NT>(y + i * V, v);
         if (BITS) st_bits<NV>(signbits + i * NV, v);
     };
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    for (; i + stride < nunits; i += 2 * stride) {          // two units in flight
-        f32x4 a[NV], b[NV], ra[NV], rb[NV];
-        unit16<T>::ld(x + i * V, a);
-        unit16<T>::ld(x + (i + stride) * V, b);
-        if (MODE != 0) { unit16<T>::ld(x2 + i * V, ra); unit16<T>::ld(x2 + (i + stride) * V, rb); }
-        one(i, a, ra);
-        one(i + stride, b, rb);
+    Slab sl = slab_of(nunits);
+    int64_t i = sl.i;
+    for (; i + (SLAB_UNR - 1) * 256 < sl.end; i += SLAB_UNR * 256) {
+        raw_t a[SLAB_UNR], r[SLAB_UNR];
+#pragma unroll
+        for (int u = 0; u < SLAB_UNR; ++u) {
+            a[u] = unit16<T>::template ldr<NT>(x + (i + u * 256) * V);
+            if (MODE != 0) r[u] = unit16<T>::template ldr<NT>(x2 + (i + u * 256) * V);
+        }
+#pragma unroll
+        for (int u = 0; u < SLAB_UNR; ++u) one(i + u * 256, a[u], r[u]);
     }
-    if (i < nunits) {
-        f32x4 a[NV], ra[NV];
-        unit16<T>::ld(x + i * V, a);
-        if (MODE != 0) unit16<T>::ld(x2 + i * V, ra);
-        one(i, a, ra);
+    for (; i < sl.end; i += 256) {
+        raw_t a = unit16<T>::template ldr<NT>(x + i * V), r = a;
+        if (MODE != 0) r = unit16<T>::template ldr<NT>(x2 + i * V);
+        one(i, a, r);
     }
 }
 
 // gx = k1 g + k2 x + k3 (and gx2 for the second BN of a dual); MASK as in bn_bwd_apply_kernel
-template <bool DUAL, int MASK, typename T>
+template <bool DUAL, int MASK, bool NT, typename T>
 __global__ __launch_bounds__(256) void bn_bwd_apply_u16_kernel(const T* gy, const T* mask, const T* x, const float* k1,
                                                                const float* k2, const float* k3, T* gx, const T* x2,
                                                                const float* k1b, const float* k2b, const float* k3b, T* gx2,
                                                                int64_t nunits, int U, const float* scale, const float* shift) {
     constexpr int V = unit16<T>::V, NV = unit16<T>::NV;
+    typedef typename unit16<T>::raw_t raw_t;
     const int cu = threadIdx.x % U;
     f32x4 a1[NV], a2[NV], a3[NV], b1[NV], b2[NV], b3[NV], sc[NV], sh[NV];
 #pragma unroll
@@ -582,9 +622,12 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_u16_kernel(const T* gy, cons
         if (MASK == 2) { sc[q] = ld4(scale + c); sh[q] = ld4(shift + c); }
     }
     const uint8_t* bits = reinterpret_cast<const uint8_t*>(mask);
-    const int64_t stride = (int64_t)gridDim.x * 256;
-    auto one = [&](int64_t i, f32x4* g, const f32x4* xv, const f32x4* mv, const uint8_t* mb, const f32x4* xw) {
-        f32x4 o[NV];
+    auto one = [&](int64_t i, raw_t gr, raw_t xr, raw_t mr, const uint8_t* mb, raw_t wr) {
+        f32x4 o[NV], g[NV], xv[NV], mv[NV], xw[NV];
+        unit16<T>::cvt(gr, g);
+        unit16<T>::cvt(xr, xv);
+        if (MASK == 1) unit16<T>::cvt(mr, mv);
+        if (DUAL) unit16<T>::cvt(wr, xw);
 #pragma unroll
         for (int q = 0; q < NV; ++q) {
             if (MASK == 1) g[q] = maskpos4(g[q], mv[q]);
@@ -592,37 +635,36 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_u16_kernel(const T* gy, cons
             if (MASK == 3) g[q] = maskbits4(g[q], mb[q]);
             o[q] = a1[q] * g[q] + a2[q] * xv[q] + a3[q];
         }
-        unit16<T>::st(gx + i * V, o);
+        unit16<T>::template st<NT>(gx + i * V, o);
         if (DUAL) {
 #pragma unroll
             for (int q = 0; q < NV; ++q) o[q] = b1[q] * g[q] + b2[q] * xw[q] + b3[q];
-            unit16<T>::st(gx2 + i * V, o);
+            unit16<T>::template st<NT>(gx2 + i * V, o);
         }
     };
-    int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x;
-    for (; i + stride < nunits; i += 2 * stride) {          // two units in flight
-        f32x4 g[2][NV], xv[2][NV], mv[2][NV], xw[2][NV];
-        uint8_t mb[2][NV];
+    Slab sl = slab_of(nunits);
+    int64_t i = sl.i;
+    for (; i + (SLAB_UNR - 1) * 256 < sl.end; i += SLAB_UNR * 256) {
+        raw_t g[SLAB_UNR], xv[SLAB_UNR], mv[SLAB_UNR], xw[SLAB_UNR];
+        uint8_t mb[SLAB_UNR][NV];
 #pragma unroll
-        for (int u = 0; u < 2; ++u) {
-            const int64_t j = i + u * stride;
-            unit16<T>::ld(gy + j * V, g[u]);
-            unit16<T>::ld(x + j * V, xv[u]);
-            if (MASK == 1) unit16<T>::ld(mask + j * V, mv[u]);
+        for (int u = 0; u < SLAB_UNR; ++u) {
+            const int64_t j = i + u * 256;
+            g[u] = unit16<T>::template ldr<NT>(gy + j * V);
+            xv[u] = unit16<T>::template ldr<NT>(x + j * V);
+            if (MASK == 1) mv[u] = unit16<T>::template ldr<NT>(mask + j * V);
             if (MASK == 3) ld_bits<NV>(bits + j * NV, mb[u]);
-            if (DUAL) unit16<T>::ld(x2 + j * V, xw[u]);
+            if (DUAL) xw[u] = unit16<T>::template ldr<NT>(x2 + j * V);
         }
-        one(i, g[0], xv[0], mv[0], mb[0], xw[0]);
-        one(i + stride, g[1], xv[1], mv[1], mb[1], xw[1]);
+#pragma unroll
+        for (int u = 0; u < SLAB_UNR; ++u) one(i + u * 256, g[u], xv[u], mv[u], mb[u], xw[u]);
     }
-    if (i < nunits) {
-        f32x4 g[NV], xv[NV], mv[NV], xw[NV];
+    for (; i < sl.end; i += 256) {
+        raw_t g = unit16<T>::template ldr<NT>(gy + i * V), xv = unit16<T>::template ldr<NT>(x + i * V), mv = g, xw = g;
         uint8_t mb[NV];
-        unit16<T>::ld(gy + i * V, g);
-        unit16<T>::ld(x + i * V, xv);
-        if (MASK == 1) unit16<T>::ld(mask + i * V, mv);
+        if (MASK == 1) mv = unit16<T>::template ldr<NT>(mask + i * V);
         if (MASK == 3) ld_bits<NV>(bits + i * NV, mb);
-        if (DUAL) unit16<T>::ld(x2 + i * V, xw);
+        if (DUAL) xw = unit16<T>::template ldr<NT>(x2 + i * V);
         one(i, g, xv, mv, mb, xw);
     }
 }
@@ -949,11 +991,14 @@ static int bn_apply_impl(const T* x, const float* scale, const float* shift, con
     hipStream_t st = as_stream(stream);
     if (const int U = units_per_row<T>(C)) {
         const int64_t nunits = rows * U;
-        const int g16 = grid_for(nunits, 256, 256 * 16);
-#define LAUNCH_A16(M, B_) hipLaunchKernelGGL((bn_apply_u16_kernel<M, B_, T>), dim3(g16), dim3(256), 0, st, x, scale, shift, x2, scale2, shift2, y, nunits, U, relu, signbits)
+        const int g16 = slab_grid(nunits);
+        const bool nt = slab_nt(nunits * 16);
+#define LAUNCH_A16_(M, B_, N_) hipLaunchKernelGGL((bn_apply_u16_kernel<M, B_, N_, T>), dim3(g16), dim3(256), 0, st, x, scale, shift, x2, scale2, shift2, y, nunits, U, relu, signbits)
+#define LAUNCH_A16(M, B_) do { if (nt) LAUNCH_A16_(M, B_, true); else LAUNCH_A16_(M, B_, false); } while (0)
         if (signbits) { if (mode == 0) LAUNCH_A16(0, true); else if (mode == 1) LAUNCH_A16(1, true); else LAUNCH_A16(2, true); }
         else { if (mode == 0) LAUNCH_A16(0, false); else if (mode == 1) LAUNCH_A16(1, false); else LAUNCH_A16(2, false); }
 #undef LAUNCH_A16
+#undef LAUNCH_A16_
         LOANS_LAUNCH_CHECK();
         return LOANS_OK;
     }
@@ -1242,13 +1287,16 @@ static int bn_bwd_apply_impl(const T* gy, const T* mask, const T* x, const float
     hipStream_t st = as_stream(stream);
     if (const int U = units_per_row<T>(C)) {
         const int64_t nunits = rows * U;
-        const int g16 = grid_for(nunits, 256, 256 * 16);
-#define LAUNCH_P16(D, M) \
-    hipLaunchKernelGGL((bn_bwd_apply_u16_kernel<D, M, T>), dim3(g16), dim3(256), 0, st, gy, mask, x, k1, k2, k3, gx, x2, k1b, k2b, k3b, gx2, nunits, U, scale, shift)
+        const int g16 = slab_grid(nunits);
+        const bool nt = slab_nt(nunits * 16);
+#define LAUNCH_P16_(D, M, N_) \
+    hipLaunchKernelGGL((bn_bwd_apply_u16_kernel<D, M, N_, T>), dim3(g16), dim3(256), 0, st, gy, mask, x, k1, k2, k3, gx, x2, k1b, k2b, k3b, gx2, nunits, U, scale, shift)
+#define LAUNCH_P16(D, M) do { if (nt) LAUNCH_P16_(D, M, true); else LAUNCH_P16_(D, M, false); } while (0)
         if (x2) { if (bits) LAUNCH_P16(true, 3); else if (mask) LAUNCH_P16(true, 1); else LAUNCH_P16(true, 0); }
         else if (scale) LAUNCH_P16(false, 2);
         else { if (bits) LAUNCH_P16(false, 3); else if (mask) LAUNCH_P16(false, 1); else LAUNCH_P16(false, 0); }
 #undef LAUNCH_P16
+#undef LAUNCH_P16_
         LOANS_LAUNCH_CHECK();
         return LOANS_OK;
     }
