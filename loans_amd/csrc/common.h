@@ -1,6 +1,7 @@
 // Shared device/host helpers for the gfx950 kernels (not part of the C ABI).
 #pragma once
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 #include <stdint.h>
 #include "loans_hip.h"
 
@@ -83,6 +84,23 @@ __device__ __forceinline__ double wave_sum_d(double v) {
 // hardware fp atomics (no CAS loop): global_atomic_add_f32 / _f64
 __device__ __forceinline__ void atomic_add_f32(float* p, float v) { unsafeAtomicAdd(p, v); }
 __device__ __forceinline__ void atomic_add_f64(double* p, double v) { unsafeAtomicAdd(p, v); }
+
+// Cache policy of the convolution kernels' output stores (round 3): large outputs are written NON-TEMPORAL (buffer-store aux
+// bit 1), so that their lines do not push the weights and halo rows other blocks are still reading out of L2 / the Infinity
+// Cache.  Timed alone and back to back a write-heavy layer gains 13-27 % (ResNet-50's 1x1 expansions 0.227 -> 0.181 ms) -- but
+// most of that is the NEXT repetition finding its input still cached; inside the step, where every input was written just
+// before by another kernel, it is worth 1.5-2 % on the ResNet-50 localizer (31.4 -> 30.9 ms on one box) and nothing
+// measurable on the ResNet-18 configurations (tools/pointwise_probe.py for the solo numbers).
+// LOANS_CONV_NT_MB: smallest output in MB that is written non-temporal (default 16; -1 = never).
+#define LOANS_STORE_B128(v, rs, off, nt)                                              \
+    do {                                                                              \
+        if (nt) __builtin_amdgcn_raw_buffer_store_b128((v), (rs), (off), 0, 2);       \
+        else __builtin_amdgcn_raw_buffer_store_b128((v), (rs), (off), 0, 0);          \
+    } while (0)
+static inline int loans_conv_nt(size_t out_bytes) {
+    static const long mb = [] { const char* e = getenv("LOANS_CONV_NT_MB"); return e && *e ? atol(e) : 16L; }();
+    return mb >= 0 && out_bytes >= ((size_t)mb << 20);
+}
 
 static inline int grid_for(int64_t work_items, int block, int max_blocks = 256 * 8) {
     int64_t g = (work_items + block - 1) / block;

@@ -40,6 +40,7 @@ struct Halo16Args {
     int nx, ny, dymin, dxmin, sdy, sdx;     // the taps are an ny x nx grid: dy = dy0 + row * sdy, dx = dx0 + col * sdx, sd = +-1
     int HH, HW;                             // halo image of a tile: (TH + ny - 1) x (TW + nx - 1) pixels
     unsigned in_bytes, w_bytes, out_bytes;
+    int nt_out;         // output stores non-temporal (loans_conv_nt)
     int dbg;                                // experiment bits (LOANS_EXPERIMENT builds only; 0 in the product library)
 };
 
@@ -295,12 +296,15 @@ __global__ __launch_bounds__(64 * WM * WN) void halo16_kernel(const Halo16Args a
     float* Cs = reinterpret_cast<float*>(smem);
     __syncthreads();
     if (f_stats) {
-        int nvalid = 0;
+        int nvalid = TM * 16;           // a tile inside the image (block-uniform): every row counts, the row table is not read
+        if (y0 + TH > d.outH || x0 + TW > d.outW) {
+            nvalid = 0;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int e = 0; e < 16; ++e)
-                nvalid += opix[wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h] != 0xFFFFFFFFu;
+                for (int e = 0; e < 16; ++e)
+                    nvalid += opix[wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h] != 0xFFFFFFFFu;
+        }
         const float cnt = (float)nvalid;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -407,7 +411,7 @@ __global__ __launch_bounds__(64 * WM * WN) void halo16_kernel(const Halo16Args a
                 bn_s2[q] += gm * (y2[q] - bn_mean[q]);
             }
         }
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_out, (int)off, 0, 0);
+        LOANS_STORE_B128(__builtin_bit_cast(u32x4, o), rs_out, (int)off, a.nt_out);
     }
     if (f_bnsums) {
         __syncthreads();
@@ -613,7 +617,7 @@ __global__ __launch_bounds__(512, 1) void ws8_kernel(const Halo16Args a, int nti
                 const bf16x4_t ol = __builtin_convertvector(lo, bf16x4_t), oh = __builtin_convertvector(hi, bf16x4_t);
                 o[0] = ol[0]; o[1] = ol[1]; o[2] = ol[2]; o[3] = ol[3];
                 o[4] = oh[0]; o[5] = oh[1]; o[6] = oh[2]; o[7] = oh[3];
-                if (!HDBG(8)) __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_out, (int)off, 0, 0);
+                if (!HDBG(8)) LOANS_STORE_B128(__builtin_bit_cast(u32x4, o), rs_out, (int)off, a.nt_out);
             }
         }
     }
@@ -863,7 +867,7 @@ __global__ __launch_bounds__(512, 1) void wsw_kernel(const Halo16Args a, int nun
                     bn_s2[q] += gm * (y2[q] - bn_mean[q]);
                 }
             }
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_out, (int)off, 0, 0);
+            LOANS_STORE_B128(__builtin_bit_cast(u32x4, o), rs_out, (int)off, a.nt_out);
         }
     }
     if (f_bnsums) {
@@ -972,6 +976,7 @@ int loans_halo16_launch(const void* in, const void* w, void* out, const float* b
     a.Ktot = d->ntaps * d->Cin;
     a.cchunks = d->Cin / BKH;
     a.in_bytes = in_bytes; a.w_bytes = w_bytes; a.out_bytes = out_bytes;
+    a.nt_out = loans_conv_nt(out_bytes);
     a.dbg = 0;
 #ifdef LOANS_EXPERIMENT
     if (const char* e = getenv("LOANS_HALO_DBG")) a.dbg = atoi(e);

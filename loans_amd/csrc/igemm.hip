@@ -71,6 +71,7 @@ struct IgemmArgs {
     int tail_groups;    // 8-deep k groups of the last chunk that hold any real K (1..4)
     int bf16;           // 1: round the operands to bf16 and use the bf16 MFMA (fp32 accumulate)
     int dma;            // 1: LDS-DMA staging of the operand tiles (LOANS_TILE_DMA; fp32 arm)
+    int nt_out;         // output stores non-temporal (loans_conv_nt)
     int dbg;            // experiment bits (LOANS_EXPERIMENT builds only; 0 in the product library)
     unsigned in_bytes, w_bytes, out_bytes;
     struct {            // nx > 0: taps are an ny x nx grid, dy = dy0 + row*sdy, dx = dx0 + col*sdx, sd* = +-1
@@ -741,10 +742,14 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
 #endif
         if (f_out16) {
             typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-            __builtin_amdgcn_raw_buffer_store_b64(__builtin_bit_cast(u32x2, __builtin_convertvector(v, bf16x4_t)), rs_out, (int)off, 0, 0);
+            {
+                const u32x2 ov = __builtin_bit_cast(u32x2, __builtin_convertvector(v, bf16x4_t));
+                if (a.nt_out) __builtin_amdgcn_raw_buffer_store_b64(ov, rs_out, (int)off, 0, 2);
+                else __builtin_amdgcn_raw_buffer_store_b64(ov, rs_out, (int)off, 0, 0);
+            }
             continue;
         }
-        __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, v), rs_out, (int)off, 0, 0);
+        LOANS_STORE_B128(__builtin_bit_cast(u32x4, v), rs_out, (int)off, a.nt_out);
     }
     if (f_bnsums) {
         // the threads that share a channel quad (same oc4, RSTEP rows apart) are summed through LDS, then one fp64 atomic per
@@ -946,6 +951,7 @@ static int igemm_impl(const float* in, const float* w, float* out, const float* 
         a.in_bytes = (unsigned)ib;
         a.w_bytes = (unsigned)wb;
         a.out_bytes = (unsigned)ob;
+        a.nt_out = loans_conv_nt((size_t)ob);
     }
     detect_tap_grid(d, a);
     if (pair) {

@@ -46,6 +46,7 @@ struct Igemm16Args {
     const __bf16* addend;
     loans_igemm_desc d;
     int M, Ktot, nchunks, tiles_m, tiles_n;
+    int nt_out;         // output stores non-temporal (loans_conv_nt)
     int dbg;            // experiment bits (LOANS_EXPERIMENT builds only)
     unsigned in_bytes, w_bytes, out_bytes;
     struct {            // nx > 0: taps are an ny x nx grid, dy = dy0 + row*sdy, dx = dx0 + col*sdx, sd* = +-1
@@ -423,12 +424,17 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm16_kernel(const Igemm16Args
     float* Cs = reinterpret_cast<float*>(smem);          // [BM / passes][LDC]
     __syncthreads();
     if (f_stats) {
-        int nvalid = 0;
+        // rows of this lane that exist (the bias term of the sums counts them): all of them unless this is the last, ragged tile
+        // (block-uniform test; the row table is only consulted there -- 16 TM LDS reads per lane otherwise)
+        int nvalid = TM * 16;
+        if ((tm + 1) * BM > a.M) {
+            nvalid = 0;
 #pragma unroll
-        for (int i = 0; i < TM; ++i)
+            for (int i = 0; i < TM; ++i)
 #pragma unroll
-            for (int e = 0; e < 16; ++e)
-                nvalid += opix[wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h] != 0xFFFFFFFFu;
+                for (int e = 0; e < 16; ++e)
+                    nvalid += opix[wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h] != 0xFFFFFFFFu;
+        }
         const float cnt = (float)nvalid;
 #pragma unroll
         for (int j = 0; j < TN; ++j) {
@@ -563,7 +569,7 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm16_kernel(const Igemm16Args
                     bn_s2[q] += gm * (y2[q] - bn_mean[q]);
                 }
             }
-            __builtin_amdgcn_raw_buffer_store_b128(__builtin_bit_cast(u32x4, o), rs_out, (int)off, 0, 0);
+            LOANS_STORE_B128(__builtin_bit_cast(u32x4, o), rs_out, (int)off, a.nt_out);
         }
     }
     if (f_bnsums) {
@@ -969,6 +975,7 @@ static int igemm_bf16s_impl(const void* in, const void* w, void* out, const floa
         const int64_t ob = (int64_t)d->B * d->outH * d->outW * d->Cout * 2;
         if (ib >= 0xFFFFFFF0ll || wb >= 0xFFFFFFF0ll || ob >= 0xFFFFFFF0ll) return LOANS_ERANGE;   // 32-bit buffer offsets
         a.in_bytes = (unsigned)ib; a.w_bytes = (unsigned)wb; a.out_bytes = (unsigned)ob;
+        a.nt_out = loans_conv_nt((size_t)ob);
         if (pair) a.tensor_bytes = (unsigned)(ob / 2);
     }
     detect_tap_grid16(d, a);

@@ -16,6 +16,9 @@
 
 namespace {
 
+constexpr int STEM_F_NT = 0x40000000;        // internal flag bit: output stores non-temporal (loans_conv_nt; common.h)
+
+
 constexpr int SK = 22;              // K columns per kernel row (21 real + 1 zero weight)
 constexpr int SKT = 7 * SK;         // 154
 constexpr int WLD = 65;             // LDS row stride of the k-major weights (conflict-free transposing writes)
@@ -130,7 +133,9 @@ __global__ __launch_bounds__(256) void stem7_kernel(const float* in, const float
             const float v = acc[i][e] + bv;
             s += v;
             q2 += v * v;
-            obase[(size_t)(p0 + (e & 3) + 8 * (e >> 2)) * 64] = v;
+            float* op = obase + (size_t)(p0 + (e & 3) + 8 * (e >> 2)) * 64;
+            if (flags & STEM_F_NT) __builtin_nontemporal_store(v, op);
+            else *op = v;
         }
     }
     if (flags & LOANS_F_STATS) {
@@ -150,7 +155,8 @@ int launch_stem7(const float* in, const float* w, float* out, const float* bias,
     static loans_device_once lds_limit_set;       // per template instance = per kernel, one bit per device
     auto kern = stem7_kernel<TMW>;
     if (int rc_ = loans_raise_lds_limit(lds_limit_set, reinterpret_cast<const void*>(kern), STEM_LDS_MAX)) return rc_;
-    hipLaunchKernelGGL(kern, dim3(B * (Ho / R)), dim3(256), lds, st, in, w, out, bias, stats, Hp, Wp3, Ho, Wo, R, flags);
+    const int nt = loans_conv_nt((size_t)B * Ho * Wo * 64 * 4) ? STEM_F_NT : 0;
+    hipLaunchKernelGGL(kern, dim3(B * (Ho / R)), dim3(256), lds, st, in, w, out, bias, stats, Hp, Wp3, Ho, Wo, R, flags | nt);
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;
 }
@@ -305,8 +311,12 @@ __global__ __launch_bounds__(256, 2) void stem7_bf16_kernel(const TIN* in, const
                 const f32x4 lo = *reinterpret_cast<const f32x4*>(Cs + px * S16_LDC + 8 * g8);
                 const f32x4 hi = *reinterpret_cast<const f32x4*>(Cs + px * S16_LDC + 8 * g8 + 4);
                 const sbf16x4 l4 = __builtin_convertvector(lo, sbf16x4), h4 = __builtin_convertvector(hi, sbf16x4);
-                if (mt * 32 + px < npx)
-                    *reinterpret_cast<sbf16x8*>(otile + (size_t)px * 64 + 8 * g8) = __builtin_shufflevector(l4, h4, 0, 1, 2, 3, 4, 5, 6, 7);
+                if (mt * 32 + px < npx) {
+                    const sbf16x8 ov = __builtin_shufflevector(l4, h4, 0, 1, 2, 3, 4, 5, 6, 7);
+                    sbf16x8* op = reinterpret_cast<sbf16x8*>(otile + (size_t)px * 64 + 8 * g8);
+                    if (flags & STEM_F_NT) __builtin_nontemporal_store(ov, op);
+                    else *op = ov;
+                }
             }
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the slab is rewritten by the next tile
             __builtin_amdgcn_wave_barrier();
@@ -510,8 +520,9 @@ int stem7_bf16_launch(const TIN* in, const TIN* w, void* out, const float* bias,
     if (cus <= 0) return LOANS_EINVAL;
     const int units = d->B * (d->gridH / R);
     const int nblk = units < 2 * cus ? units : 2 * cus;
+    const int nt = loans_conv_nt((size_t)d->B * d->gridH * d->gridW * 64 * 2) ? STEM_F_NT : 0;
     hipLaunchKernelGGL(kern, dim3(nblk), dim3(256), lds, st, in, w, reinterpret_cast<__bf16*>(out), bias, stats,
-                       d->inH, d->inW, d->gridH, d->gridW, R, units, d->flags);
+                       d->inH, d->inW, d->gridH, d->gridW, R, units, d->flags | nt);
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;
 }

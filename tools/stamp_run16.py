@@ -12,7 +12,7 @@ dbg = os.path.join(csrc, 'libloans_hip_stamps.so')
 if not os.path.exists(dbg):
     subprocess.check_call('/opt/rocm/bin/hipcc -O3 -std=c++17 -fPIC --offload-arch=gfx950 -munsafe-fp-atomics -DLOANS_STAMPS '
                           '-I%s/include -shared -o %s %s' % (ROOT, dbg, ' '.join('%s/%s' % (csrc, f) for f in (
-                              'igemm.hip', 'igemm_bf16.hip', 'halo_bf16.hip', 'stem.hip', 'smalln.hip', 'cropgrad.hip', 'bn_pool.hip', 'misc.hip', 'insight.hip',
+                              'igemm.hip', 'igemm_bf16.hip', 'halo_bf16.hip', 'wgrad_halo_bf16.hip', 'weightprep.hip', 'stem.hip', 'smalln.hip', 'cropgrad.hip', 'bn_pool.hip', 'misc.hip', 'insight.hip',
                               'resample.hip', 'augment.hip'))), shell=True)
 if len(sys.argv) < 11:
     sys.exit(0)         # build only (the GPU box has no reason to compile)
