@@ -291,21 +291,50 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_reduce_kernel(const T* gy, co
     const f32x4 sc = ld4(scale + cg * 4), sh = ld4(shift + cg * 4), mu = ld4(mean + cg * 4), rs = ld4(rstd + cg * 4);
     f32x4 sg = {0.f, 0.f, 0.f, 0.f}, sgx = sg;
     if (rl < RL) {
-        for (int r = r0 + rl; r < r1; r += RL) {          // r = (b * OH + oh) * OW + ow
+        // PF pooled elements per trip: their (gradient, argmax) loads go out together, then the PF x 4 gathers those argmaxes
+        // address, then the arithmetic -- two memory latencies per PF elements instead of per element
+        constexpr int PF = 4;
+        auto gather = [&](int r, uchar4 a, float* xv) {          // r = (b * OH + oh) * OW + ow
             const int ow = r % OW, t = r / OW, oh = t % OH, b = t / OH;
-            const int64_t o = ((int64_t)r * C4T + cg) * 4;
-            const f32x4 g = io4<T>::ld(gy + o);
-            const uchar4 a = *reinterpret_cast<const uchar4*>(idx + o);
             const int64_t base = (((int64_t)b * H + oh * 2) * W + ow * 2) * C4T * 4 + cg * 4;
             const int ks[4] = {a.x, a.y, a.z, a.w};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int kr = ks[e] / 3, kq = ks[e] - kr * 3;
-                const float xv = ldf(x + base + ((int64_t)kr * W + kq) * C4T * 4 + e);
-                const float ge = (xv * sc[e] + sh[e]) > 0.f ? g[e] : 0.f;
-                sg[e] += ge;
-                sgx[e] += ge * ((xv - mu[e]) * rs[e]);
+                xv[e] = ldf(x + base + ((int64_t)kr * W + kq) * C4T * 4 + e);
             }
+        };
+        auto fold = [&](f32x4 g, const float* xv) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const float ge = (xv[e] * sc[e] + sh[e]) > 0.f ? g[e] : 0.f;
+                sg[e] += ge;
+                sgx[e] += ge * ((xv[e] - mu[e]) * rs[e]);
+            }
+        };
+        int r = r0 + rl;
+        for (; r + (PF - 1) * RL < r1; r += PF * RL) {
+            f32x4 g[PF];
+            uchar4 a[PF];
+            float xv[PF][4];
+#pragma unroll
+            for (int u = 0; u < PF; ++u) {
+                const int64_t o = ((int64_t)(r + u * RL) * C4T + cg) * 4;
+                g[u] = io4<T>::ld(gy + o);
+                a[u] = *reinterpret_cast<const uchar4*>(idx + o);
+            }
+#pragma unroll
+            for (int u = 0; u < PF; ++u) gather(r + u * RL, a[u], xv[u]);
+#pragma unroll
+            for (int u = 0; u < PF; ++u) fold(g[u], xv[u]);
+        }
+        for (; r < r1; r += RL) {
+            const int64_t o = ((int64_t)r * C4T + cg) * 4;
+            const f32x4 g = io4<T>::ld(gy + o);
+            const uchar4 a = *reinterpret_cast<const uchar4*>(idx + o);
+            float xv[4];
+            gather(r, a, xv);
+            fold(g, xv);
         }
     }
     red[0][tid] = sg;
@@ -813,16 +842,23 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_u16_kernel(const T* x, co
             for (int q = 0; q < NV; ++q) best[q] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
 #pragma unroll
             for (int e = 0; e < V; ++e) arg[e] = 0;
+            // the nine window loads first (clamped addresses; a load behind each bounds test is a memory latency of its own)
+            typename unit16<T>::raw_t raw[3][3];
 #pragma unroll
-            for (int r = 0; r < 3; ++r) {
-                const int ih = oh * 2 + r;
-                if (ih >= H) continue;
+            for (int r = 0; r < 3; ++r)
 #pragma unroll
                 for (int c = 0; c < 3; ++c) {
-                    const int iw = ow * 2 + c;
-                    if (iw >= W) continue;
+                    const int ih = min(oh * 2 + r, H - 1), iw = min(ow * 2 + c, W - 1);
+                    raw[r][c] = unit16<T>::ldr(x + ((((int64_t)b * H + ih) * W + iw) * U + cu) * V);
+                }
+#pragma unroll
+            for (int r = 0; r < 3; ++r) {
+                if (oh * 2 + r >= H) continue;
+#pragma unroll
+                for (int c = 0; c < 3; ++c) {
+                    if (ow * 2 + c >= W) continue;
                     f32x4 v[NV];
-                    unit16<T>::ld(x + ((((int64_t)b * H + ih) * W + iw) * U + cu) * V, v);
+                    unit16<T>::cvt(raw[r][c], v);
 #pragma unroll
                     for (int q = 0; q < NV; ++q) {
                         v[q] = relu4(v[q] * s[q] + t[q]);
@@ -855,6 +891,32 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_apply_v4_kernel(const T* gy, 
     for (int row = blockIdx.y; row < B * PH; row += gridDim.y) {
         const int b = row / PH, a = row - b * PH;
         for (int pb = blockIdx.x * PL + pl; pb < PW; pb += gridDim.x * PL) {
+            // all twelve loads of the patch are issued before any arithmetic (clamped addresses, validity kept aside): with a
+            // load behind every bounds test the thread paid two memory latencies per patch, one after the other
+            f32x4 gv[2][2], xv[2][2];
+            uchar4 av[2][2];
+            bool wok[2][2], xok[2][2];
+            int64_t xp[2][2];
+#pragma unroll
+            for (int wi = 0; wi < 2; ++wi)
+#pragma unroll
+                for (int wj = 0; wj < 2; ++wj) {
+                    const int oh = a - 1 + wi, ow = pb - 1 + wj;
+                    wok[wi][wj] = (unsigned)oh < (unsigned)OH && (unsigned)ow < (unsigned)OW;
+                    const int ohc = min(max(oh, 0), OH - 1), owc = min(max(ow, 0), OW - 1);
+                    const int64_t o = ((((int64_t)b * OH + ohc) * OW + owc) * C4 + c4) * 4;
+                    av[wi][wj] = *reinterpret_cast<const uchar4*>(idx + o);
+                    gv[wi][wj] = io4<T>::ld(gy + o);
+                }
+#pragma unroll
+            for (int i = 0; i < 2; ++i)
+#pragma unroll
+                for (int j = 0; j < 2; ++j) {
+                    const int ih = 2 * a + i, iw = 2 * pb + j;
+                    xok[i][j] = ih < H && iw < W;
+                    xp[i][j] = ((((int64_t)b * H + min(ih, H - 1)) * W + min(iw, W - 1)) * C4 + c4) * 4;
+                    xv[i][j] = io4<T>::ld(x + xp[i][j]);
+                }
             f32x4 g[2][2];
 #pragma unroll
             for (int i = 0; i < 2; ++i)
@@ -862,15 +924,10 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_apply_v4_kernel(const T* gy, 
                 for (int j = 0; j < 2; ++j) g[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
             for (int wi = 0; wi < 2; ++wi) {
-                const int oh = a - 1 + wi;
-                if (oh < 0 || oh >= OH) continue;
 #pragma unroll
                 for (int wj = 0; wj < 2; ++wj) {
-                    const int ow = pb - 1 + wj;
-                    if (ow < 0 || ow >= OW) continue;
-                    const int64_t o = ((((int64_t)b * OH + oh) * OW + ow) * C4 + c4) * 4;
-                    const uchar4 av = *reinterpret_cast<const uchar4*>(idx + o);
-                    const f32x4 gv = io4<T>::ld(gy + o);
+                    const f32x4 gw = wok[wi][wj] ? gv[wi][wj] : f32x4{0.f, 0.f, 0.f, 0.f};
+                    const uchar4 aw = av[wi][wj];
 #pragma unroll
                     for (int i = 0; i < 2; ++i) {
                         const int kr = i + 2 - 2 * wi;
@@ -880,29 +937,23 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_apply_v4_kernel(const T* gy, 
                             const int kq = j + 2 - 2 * wj;
                             if (kq > 2) continue;
                             const int k = kr * 3 + kq;
-                            if (av.x == k) g[i][j].x += gv.x;
-                            if (av.y == k) g[i][j].y += gv.y;
-                            if (av.z == k) g[i][j].z += gv.z;
-                            if (av.w == k) g[i][j].w += gv.w;
+                            if (aw.x == k) g[i][j].x += gw.x;
+                            if (aw.y == k) g[i][j].y += gw.y;
+                            if (aw.z == k) g[i][j].z += gw.z;
+                            if (aw.w == k) g[i][j].w += gw.w;
                         }
                     }
                 }
             }
 #pragma unroll
-            for (int i = 0; i < 2; ++i) {
-                const int ih = 2 * a + i;
-                if (ih >= H) continue;
+            for (int i = 0; i < 2; ++i)
 #pragma unroll
                 for (int j = 0; j < 2; ++j) {
-                    const int iw = 2 * pb + j;
-                    if (iw >= W) continue;
-                    const int64_t p = ((((int64_t)b * H + ih) * W + iw) * C4 + c4) * 4;
-                    const f32x4 xv = io4<T>::ld(x + p);
-                    const f32x4 v = c1 * maskpos4(g[i][j], xv * sc + sh) + c2 * xv + c3;
-                    io4<T>::st(gx + p, v);
+                    if (!xok[i][j]) continue;
+                    const f32x4 v = c1 * maskpos4(g[i][j], xv[i][j] * sc + sh) + c2 * xv[i][j] + c3;
+                    io4<T>::st(gx + xp[i][j], v);
                     bsum += v;
                 }
-            }
         }
     }
     if (gxsum) {

@@ -728,12 +728,15 @@ __global__ __launch_bounds__(256) void igemm_kernel(const IgemmArgs a) {
         } else if (f_add) {
             v += __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_add, (int)off, 0, 0));
         }
-        if (f_bnsums && off != 0xFFFFFFFFu) {
+        if (f_bnsums) {
+            // (block-uniform test only: the load of a row that does not exist goes out of range and returns zeros, its gradient is
+            // forced to zero -- a per-lane test around the load kept the unrolled rows' loads from being issued together)
             const f32x4 y = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_ref, (int)off, 0, 0));
             const f32x4 z = y * bn_scale + bn_shift;
+            const bool live = off != 0xFFFFFFFFu;
             f32x4 gm;
-            gm.x = z.x > 0.f ? v.x : 0.f; gm.y = z.y > 0.f ? v.y : 0.f;
-            gm.z = z.z > 0.f ? v.z : 0.f; gm.w = z.w > 0.f ? v.w : 0.f;
+            gm.x = (live && z.x > 0.f) ? v.x : 0.f; gm.y = (live && z.y > 0.f) ? v.y : 0.f;
+            gm.z = (live && z.z > 0.f) ? v.z : 0.f; gm.w = (live && z.w > 0.f) ? v.w : 0.f;
             bn_s1 += gm;
             bn_s2 += gm * (y - bn_mean);
         }

@@ -557,11 +557,13 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm16_kernel(const Igemm16Args
             const bf16x4_t ol = __builtin_convertvector(lo, bf16x4_t), oh = __builtin_convertvector(hi, bf16x4_t);
             o[0] = ol[0]; o[1] = ol[1]; o[2] = ol[2]; o[3] = ol[3];
             o[4] = oh[0]; o[5] = oh[1]; o[6] = oh[2]; o[7] = oh[3];
-            if (f_bnsums && off != 0xFFFFFFFFu) {
+            if (f_bnsums) {          // block-uniform; a row that does not exist loads zeros and its gradient is zeroed below
                 // the BN's input tile; the sums take the ROUNDED gradient (what the apply pass will read back)
                 const bf16x8_t yv = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_ref, (int)off, 0, 0));
                 const f32x4 y2[2] = {cvt_lo(yv), cvt_hi(yv)};
-                const f32x4 g2[2] = {__builtin_convertvector(ol, f32x4), __builtin_convertvector(oh, f32x4)};
+                const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+                const bool live = off != 0xFFFFFFFFu;
+                const f32x4 g2[2] = {live ? __builtin_convertvector(ol, f32x4) : zero4, live ? __builtin_convertvector(oh, f32x4) : zero4};
 #pragma unroll
                 for (int q = 0; q < 2; ++q) {
                     const f32x4 gm = keep_pos(g2[q], y2[q] * bn_scale[q] + bn_shift[q]);

@@ -558,7 +558,11 @@ def test_data_gradient_takes_the_bn_backward_sums(storage, tiles, case):
             gg0, gb0, gg1, gb1 = z(), z(), z(), z()
             two_pass = ops.bn_backward(plain, act, yd, st, dev(gamma), gg0, gb0, mask_is_own_relu=True)
             fused, sums = ops.conv_dgrad(gyd, wd, geo, tile=tile, bn_sums=(yd, st))
-            assert torch.equal(fused, plain), tile
+            if tile == 0:       # the autotuner's picks, made separately for the two forms: a halo tile walks K chunk-major, the
+                # implicit GEMM tap-major -- equal to fp32 rounding of the accumulators, bit for bit only on the SAME tile
+                assert rel_err(fused.float().cpu().numpy(), plain.float().cpu().numpy()) < (BF16_EPS if s16 else 1e-6), tile
+            else:
+                assert torch.equal(fused, plain), tile
             one_pass = ops.bn_backward_from_sums(fused, yd, st, sums, dev(gamma), gg1, gb1)
             tol = 2 * BF16_EPS if s16 else 2e-5
             assert rel_err(one_pass.float().cpu().numpy(), two_pass.float().cpu().numpy()) < tol, tile
