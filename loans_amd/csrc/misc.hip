@@ -102,12 +102,22 @@ __global__ __launch_bounds__(256) void linear_fwd_kernel(const T* x, const float
     for (int n = 0; n < N; ++n) {
         const float* wr = W + (int64_t)n * K;
         float acc = 0.f;
-        for (int k = threadIdx.x * 4; k < K; k += 256 * 4) {
-            f32x4 xv = io4<T>::ld(xr + k);
+        auto fma4 = [&](f32x4 xv, f32x4 wv) {
             if (act_in) { xv.x = fmaxf(xv.x, 0.f); xv.y = fmaxf(xv.y, 0.f); xv.z = fmaxf(xv.z, 0.f); xv.w = fmaxf(xv.w, 0.f); }
-            const f32x4 wv = ld4(wr + k);
             acc += xv.x * wv.x + xv.y * wv.y + xv.z * wv.z + xv.w * wv.w;
+        };
+        // one block per sample walks K = 41 472 (the assessor's head) in 40 trips: eight trips' loads go out together, or every
+        // trip waits for its own two (77 us at B = 256 for 42 MB: a latency chain, not a stream)
+        constexpr int LU = 8;
+        int k = threadIdx.x * 4;
+        for (; k + (LU - 1) * 1024 < K; k += LU * 1024) {
+            f32x4 xv[LU], wv[LU];
+#pragma unroll
+            for (int u = 0; u < LU; ++u) { xv[u] = io4<T>::ld(xr + k + u * 1024); wv[u] = ld4(wr + k + u * 1024); }
+#pragma unroll
+            for (int u = 0; u < LU; ++u) fma4(xv[u], wv[u]);
         }
+        for (; k < K; k += 1024) fma4(io4<T>::ld(xr + k), ld4(wr + k));
         acc = block_sum(acc, sh);
         if (threadIdx.x == 0) {
             float v = acc + (b ? b[n] : 0.f);
@@ -129,13 +139,15 @@ template <typename T>
 __global__ __launch_bounds__(256) void linear_bwd_x_kernel(const T* x, const float* W, const float* y,
                                                            const float* gy, T* gx, int B, int K4, int N,
                                                            int act_in, int act_out) {
-    const int64_t total = (int64_t)B * K4;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t s = i / K4, k = (i - s * K4) * 4;
+    // grid = (column blocks, samples): no 64-bit division per element, the sample's gz values are uniform per block
+    const int64_t s = blockIdx.y;
+    for (int kq = blockIdx.x * blockDim.x + threadIdx.x; kq < K4; kq += gridDim.x * blockDim.x) {
+        const int64_t i = s * K4 + kq;
+        f32x4 xv = {1.f, 1.f, 1.f, 1.f};
+        if (act_in) xv = io4<T>::ld(x + i * 4);
         f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-        for (int n = 0; n < N; ++n) acc += ld4(W + (int64_t)n * K4 * 4 + k) * gz_of(y, gy, s * N + n, act_out);
+        for (int n = 0; n < N; ++n) acc += ld4(W + ((int64_t)n * K4 + kq) * 4) * gz_of(y, gy, s * N + n, act_out);
         if (act_in) {
-            const f32x4 xv = io4<T>::ld(x + i * 4);
             acc.x = xv.x > 0.f ? acc.x : 0.f; acc.y = xv.y > 0.f ? acc.y : 0.f;
             acc.z = xv.z > 0.f ? acc.z : 0.f; acc.w = xv.w > 0.f ? acc.w : 0.f;
         }
@@ -506,7 +518,7 @@ static int linear_bwd_impl(const T* x, const float* W, const float* y, const flo
     hipStream_t st = as_stream(stream);
     const int K4 = K / 4;
     if (gx) {
-        hipLaunchKernelGGL(linear_bwd_x_kernel<T>, dim3(grid_for((int64_t)B * K4, 256)), dim3(256), 0, st, x, W, y, gy, gx, B, K4, N, act_in, act_out);
+        hipLaunchKernelGGL(linear_bwd_x_kernel<T>, dim3(grid_for(K4, 256, 64), B), dim3(256), 0, st, x, W, y, gy, gx, B, K4, N, act_in, act_out);
         LOANS_LAUNCH_CHECK();
     }
     if (gW) {
