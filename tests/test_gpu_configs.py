@@ -190,10 +190,14 @@ def _check_units(report, n_units):
         # BN normalises over >= 512 samples per channel -- against 4e-3 / 5e-2 for the same units compared with the UN-rounded
         # oracle.  The stages behind res5 see 2 x 8 x 8 and 2 x 4 x 4 samples per channel at this batch: a rounding that falls
         # the other way moves their statistics-dependent terms further (outputs up to 2e-3, gradients up to 5e-2).
+        # The gradient figures are not constants of the code: the autotuner's tile picks (a halo tile walks K chunk-major, the
+        # implicit GEMM tap-major) and the order of the weight gradients' float atomics change which activations round the other
+        # way -- four runs of the SAME build gave 0.75e-2 .. 1.43e-2 for res5 of the ResNet-50 localizer, a fifth 1.55e-2.  The
+        # bound sits at 2.5e-2: above that spread, half of what the un-rounded oracle gives.
         tight = n >= 512
         assert e_out < (1e-3 if tight else 5e-3) and neq < (0.03 if tight else 0.3), (name, e_out, neq)
-        assert e_gx < (1.5e-2 if tight else 8e-2), (name, e_gx)
-        assert max(errs.values()) < (1.5e-2 if tight else 8e-2), (name, errs)
+        assert e_gx < (2.5e-2 if tight else 8e-2), (name, e_gx)
+        assert max(errs.values()) < (2.5e-2 if tight else 8e-2), (name, errs)
 
 
 def test_cfg2_bf16_every_layer_in_situ_against_bf16_rounded_oracle(bf16_arm, deterministic_forward):
