@@ -760,6 +760,30 @@ __global__ __launch_bounds__(512, 1) void wsw_kernel(const Halo16Args a, int nun
         const int y0 = 2 * uy, x0 = 16 * ux;
         if (u != gw) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
         __builtin_amdgcn_wave_barrier();
+        // The epilogue's operands (ReLU reference / addend of a data gradient, the BN input of LOANS_F_BNSUMS) are requested HERE,
+        // a unit's worth of MFMAs ahead of their use and -- the point -- BEFORE the next unit's image: vector memory operations
+        // retire in order, so a load issued behind that DMA made the epilogue wait for the whole image to land (+83 us on a
+        // 164 us res2 data gradient with BN sums).
+        unsigned eoff[4];
+        bf16x8_t e_ref[4], e_add[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const int px = it * 8 + (lane >> 3);
+            const int y = y0 + (px >> 4), x = x0 + (px & 15);
+            const bool pok = y < d.outH && x < d.outW;
+            eoff[it] = pok ? ((unsigned)((b * d.outH + y) * d.outW + x) * (unsigned)d.Cout * 2u + (unsigned)oc8 * 16u) | cbad : 0xFFFFFFFFu;
+        }
+        if (f_mask || f_addmask || f_bnsums) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+                e_ref[it] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_ref, (int)eoff[it], 0, 0));
+        }
+        if (f_add) {
+#pragma unroll
+            for (int it = 0; it < 4; ++it)
+                e_add[it] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_add, (int)eoff[it], 0, 0));
+        }
+        asm volatile("" ::: "memory");
         f32x16 acc0, acc1;
 #pragma unroll
         for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
@@ -836,31 +860,24 @@ __global__ __launch_bounds__(512, 1) void wsw_kernel(const Halo16Args a, int nun
         __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
-            const int px = it * 8 + (lane >> 3);
-            const int y = y0 + (px >> 4), x = x0 + (px & 15);
-            const bool pok = y < d.outH && x < d.outW;
-            const unsigned off = pok ? ((unsigned)((b * d.outH + y) * d.outW + x) * (unsigned)d.Cout * 2u + (unsigned)oc8 * 16u) | cbad : 0xFFFFFFFFu;
+            const unsigned off = eoff[it];
             if (f_mask || f_addmask) {
-                const bf16x8_t rf = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_ref, (int)off, 0, 0));
-                const f32x4 rl = lo4(rf), rh = hi4(rf);
+                const f32x4 rl = lo4(e_ref[it]), rh = hi4(e_ref[it]);
                 if (f_mask) { lo[it] = keep_pos(lo[it], rl); hi[it] = keep_pos(hi[it], rh); }
                 if (f_add) {
-                    const bf16x8_t ad = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_add, (int)off, 0, 0));
-                    f32x4 al = lo4(ad), ah = hi4(ad);
+                    f32x4 al = lo4(e_add[it]), ah = hi4(e_add[it]);
                     if (f_addmask) { al = keep_pos(al, rl); ah = keep_pos(ah, rh); }
                     lo[it] += al; hi[it] += ah;
                 }
             } else if (f_add) {
-                const bf16x8_t ad = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_add, (int)off, 0, 0));
-                lo[it] += lo4(ad); hi[it] += hi4(ad);
+                lo[it] += lo4(e_add[it]); hi[it] += hi4(e_add[it]);
             }
             bf16x8_t o;
             const bf16x4_t ol = __builtin_convertvector(lo[it], bf16x4_t), oh = __builtin_convertvector(hi[it], bf16x4_t);
             o[0] = ol[0]; o[1] = ol[1]; o[2] = ol[2]; o[3] = ol[3];
             o[4] = oh[0]; o[5] = oh[1]; o[6] = oh[2]; o[7] = oh[3];
-            if (f_bnsums) {          // block-uniform; a row that does not exist loads zeros and its gradient is zeroed below
-                const bf16x8_t yv = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_ref, (int)off, 0, 0));
-                const f32x4 y2[2] = {lo4(yv), hi4(yv)};
+            if (f_bnsums) {          // block-uniform; a row that does not exist loaded zeros and its gradient is zeroed below
+                const f32x4 y2[2] = {lo4(e_ref[it]), hi4(e_ref[it])};
                 const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
                 const bool live = off != 0xFFFFFFFFu;
                 const f32x4 g2[2] = {live ? __builtin_convertvector(ol, f32x4) : zero4, live ? __builtin_convertvector(oh, f32x4) : zero4};
