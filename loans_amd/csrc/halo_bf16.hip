@@ -334,14 +334,6 @@ __global__ __launch_bounds__(64 * WM * WN) void halo16_kernel(const Halo16Args a
             }
         }
     }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-                Cs[(wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * LDC + wn * TN * 32 + j * 32 + r] = acc[i][j][e];
-    __syncthreads();
 
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)a.out_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_ref = __builtin_amdgcn_make_buffer_rsrc(
@@ -375,34 +367,58 @@ __global__ __launch_bounds__(64 * WM * WN) void halo16_kernel(const Halo16Args a
             bn_shift[q] = *reinterpret_cast<const f32x4*>(a.bias + 3 * d.Cout + col0 + 4 * q);
         }
     }
+    // The epilogue's operands (ReLU reference, addend, the BN input of LOANS_F_BNSUMS) are requested BEFORE the tile goes through the
+    // staging area: inside the store loop every load waited behind the previous row's store (vector memory operations retire in
+    // order) and paid its own latency, once per row.
+    constexpr int NIT = BM / RSTEP;
+    unsigned eoff[NIT];
+    bf16x8_t e_ref[NIT], e_add[NIT];
 #pragma unroll
-    for (int p = 0; p < BM / RSTEP; ++p) {
+    for (int p = 0; p < NIT; ++p) {
+        const unsigned po = opix[r0 + p * RSTEP];
+        eoff[p] = (po + coff) | (po == 0xFFFFFFFFu ? 0xFFFFFFFFu : 0u) | cbad;
+    }
+    if (f_mask || f_addmask || f_bnsums) {
+#pragma unroll
+        for (int p = 0; p < NIT; ++p)
+            e_ref[p] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_ref, (int)eoff[p], 0, 0));
+    }
+    if (f_add) {
+#pragma unroll
+        for (int p = 0; p < NIT; ++p)
+            e_add[p] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_add, (int)eoff[p], 0, 0));
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                Cs[(wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * LDC + wn * TN * 32 + j * 32 + r] = acc[i][j][e];
+    __syncthreads();
+#pragma unroll
+    for (int p = 0; p < NIT; ++p) {
         const int row = r0 + p * RSTEP;
-        const unsigned po = opix[row];
-        const unsigned off = (po + coff) | (po == 0xFFFFFFFFu ? 0xFFFFFFFFu : 0u) | cbad;
+        const unsigned off = eoff[p];
         f32x4 lo = *reinterpret_cast<const f32x4*>(Cs + row * LDC + oc8 * 8) + b_lo;
         f32x4 hi = *reinterpret_cast<const f32x4*>(Cs + row * LDC + oc8 * 8 + 4) + b_hi;
         if (f_mask || f_addmask) {
-            const bf16x8_t rf = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_ref, (int)off, 0, 0));
-            const f32x4 rl = lo4(rf), rh = hi4(rf);
+            const f32x4 rl = lo4(e_ref[p]), rh = hi4(e_ref[p]);
             if (f_mask) { lo = keep_pos(lo, rl); hi = keep_pos(hi, rh); }
             if (f_add) {
-                const bf16x8_t ad = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_add, (int)off, 0, 0));
-                f32x4 al = lo4(ad), ah = hi4(ad);
+                f32x4 al = lo4(e_add[p]), ah = hi4(e_add[p]);
                 if (f_addmask) { al = keep_pos(al, rl); ah = keep_pos(ah, rh); }
                 lo += al; hi += ah;
             }
         } else if (f_add) {
-            const bf16x8_t ad = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_add, (int)off, 0, 0));
-            lo += lo4(ad); hi += hi4(ad);
+            lo += lo4(e_add[p]); hi += hi4(e_add[p]);
         }
         bf16x8_t o;
         const bf16x4_t ol = __builtin_convertvector(lo, bf16x4_t), oh = __builtin_convertvector(hi, bf16x4_t);
         o[0] = ol[0]; o[1] = ol[1]; o[2] = ol[2]; o[3] = ol[3];
         o[4] = oh[0]; o[5] = oh[1]; o[6] = oh[2]; o[7] = oh[3];
-        if (f_bnsums) {          // block-uniform; a row that does not exist loads zeros and its gradient is zeroed below
-            const bf16x8_t yv = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_ref, (int)off, 0, 0));
-            const f32x4 y2[2] = {lo4(yv), hi4(yv)};
+        if (f_bnsums) {          // block-uniform; a row that does not exist loaded zeros and its gradient is zeroed below
+            const f32x4 y2[2] = {lo4(e_ref[p]), hi4(e_ref[p])};
             const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
             const bool live = off != 0xFFFFFFFFu;
             const f32x4 g2[2] = {live ? __builtin_convertvector(ol, f32x4) : zero4, live ? __builtin_convertvector(oh, f32x4) : zero4};

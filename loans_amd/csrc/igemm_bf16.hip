@@ -502,8 +502,31 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm16_kernel(const Igemm16Args
     constexpr int EP = igemm16_epilogue_passes<BM, BN>();
     constexpr int PR = BM / EP;
     static_assert(PR % (TM * 32) == 0 || (TM * 32) % PR == 0, "a wave's rows fall into whole passes");
+    constexpr int NIT = PR / RSTEP;         // rows a thread stores per pass
+    constexpr bool EARLY_REF = TM * TN <= 4;    // the 128 x 64 wave tiles (128 live accumulators) take the reference after the staging too
+    constexpr int LG = EARLY_REF ? NIT : 1;     // rows per load group behind the staging (those tiles: row by row, as before --
+                                                // any group of loads beside their accumulators spills, and the spills cost more)
+    static_assert(NIT % LG == 0, "whole load groups");
 #pragma unroll 1
     for (int ep = 0; ep < EP; ++ep) {
+        // The pass's epilogue operands (ReLU reference, addend, the BN input of LOANS_F_BNSUMS) are requested BEFORE the tile goes
+        // through the staging area: inside the store loop every load waited behind the previous row's store (vector memory
+        // operations retire in order) and paid its own latency, eight times per pass.
+        constexpr int NA = EARLY_REF ? NIT : 1;     // (row by row: one slot, re-used)
+        unsigned eoff[NA];
+        bf16x8_t e_ref[NA], e_add[NA];
+        if (EARLY_REF && !a.partial) {
+#pragma unroll
+            for (int p = 0; p < NIT; ++p) {
+                const unsigned po = opix[ep * PR + r0 + p * RSTEP];
+                eoff[p] = (po + coff) | (po == 0xFFFFFFFFu ? 0xFFFFFFFFu : 0u) | cbad;
+            }
+            if (f_mask || f_addmask || f_bnsums) {
+#pragma unroll
+                for (int p = 0; p < NIT; ++p)
+                    e_ref[p] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_ref, (int)eoff[p], 0, 0));
+            }
+        }
         if (ep) __syncthreads();            // the previous pass has been read
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
@@ -532,35 +555,51 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm16_kernel(const Igemm16Args
             }
             continue;
         }
+        // the addends (and, for the 128-accumulator wave tiles, the reference) are requested per group of LG rows, all of a group
+        // together, once the pass's accumulators have gone to LDS: beside the early reference and all accumulators they spilled
 #pragma unroll
-        for (int p = 0; p < PR / RSTEP; ++p) {
+        for (int p = 0; p < NIT; ++p) {
+            if (p % LG == 0) {
+                if (!EARLY_REF) {
+#pragma unroll
+                    for (int q = p; q < p + LG; ++q) {
+                        const unsigned po = opix[ep * PR + r0 + q * RSTEP];
+                        eoff[q % NA] = (po + coff) | (po == 0xFFFFFFFFu ? 0xFFFFFFFFu : 0u) | cbad;
+                    }
+                }
+                if (!EARLY_REF && (f_mask || f_addmask || f_bnsums)) {
+#pragma unroll
+                    for (int q = p; q < p + LG; ++q)
+                        e_ref[q % NA] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_ref, (int)eoff[q % NA], 0, 0));
+                }
+                if (f_add) {
+#pragma unroll
+                    for (int q = p; q < p + LG; ++q)
+                        e_add[q % NA] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_add, (int)eoff[q % NA], 0, 0));
+                }
+            }
             const int row = r0 + p * RSTEP;
-            const unsigned po = opix[ep * PR + row];
-            const unsigned off = (po + coff) | (po == 0xFFFFFFFFu ? 0xFFFFFFFFu : 0u) | cbad;
+            const unsigned off = eoff[p % NA];
             f32x4 lo = *reinterpret_cast<const f32x4*>(Cs + row * LDC + oc8 * 8) + b_lo;
             f32x4 hi = *reinterpret_cast<const f32x4*>(Cs + row * LDC + oc8 * 8 + 4) + b_hi;
             if (f_mask || f_addmask) {
-                const bf16x8_t rf = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_ref, (int)off, 0, 0));
-                const f32x4 rl = cvt_lo(rf), rh = cvt_hi(rf);
+                const f32x4 rl = cvt_lo(e_ref[p % NA]), rh = cvt_hi(e_ref[p % NA]);
                 if (f_mask) { lo = keep_pos(lo, rl); hi = keep_pos(hi, rh); }
                 if (f_add) {
-                    const bf16x8_t ad = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_add, (int)off, 0, 0));
-                    f32x4 al = cvt_lo(ad), ah = cvt_hi(ad);
+                    f32x4 al = cvt_lo(e_add[p % NA]), ah = cvt_hi(e_add[p % NA]);
                     if (f_addmask) { al = keep_pos(al, rl); ah = keep_pos(ah, rh); }
                     lo += al; hi += ah;
                 }
             } else if (f_add) {
-                const bf16x8_t ad = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_add, (int)off, 0, 0));
-                lo += cvt_lo(ad); hi += cvt_hi(ad);
+                lo += cvt_lo(e_add[p % NA]); hi += cvt_hi(e_add[p % NA]);
             }
             bf16x8_t o;
             const bf16x4_t ol = __builtin_convertvector(lo, bf16x4_t), oh = __builtin_convertvector(hi, bf16x4_t);
             o[0] = ol[0]; o[1] = ol[1]; o[2] = ol[2]; o[3] = ol[3];
             o[4] = oh[0]; o[5] = oh[1]; o[6] = oh[2]; o[7] = oh[3];
-            if (f_bnsums) {          // block-uniform; a row that does not exist loads zeros and its gradient is zeroed below
+            if (f_bnsums) {          // block-uniform; a row that does not exist loaded zeros and its gradient is zeroed below
                 // the BN's input tile; the sums take the ROUNDED gradient (what the apply pass will read back)
-                const bf16x8_t yv = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_ref, (int)off, 0, 0));
-                const f32x4 y2[2] = {cvt_lo(yv), cvt_hi(yv)};
+                const f32x4 y2[2] = {cvt_lo(e_ref[p % NA]), cvt_hi(e_ref[p % NA])};
                 const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
                 const bool live = off != 0xFFFFFFFFu;
                 const f32x4 g2[2] = {live ? __builtin_convertvector(ol, f32x4) : zero4, live ? __builtin_convertvector(oh, f32x4) : zero4};
