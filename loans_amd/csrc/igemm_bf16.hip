@@ -18,6 +18,7 @@
 // Diagnostic build only (tools/stamp_run16.py): per-wave cycle sums of the K-loop phases of the first 64 blocks.
 __device__ unsigned long long g_stamps16[64 * 4 * 8];
 __device__ unsigned long long g_stamps16b[64 * 4 * 4];     // per wave: kernel entry, K loop begin, K loop end, kernel exit
+__device__ unsigned long long g_stamps16c[64 * 4 * 4];     // per wave: last chunk done, statistics done, staging pass 0 stored, pass 1 stored
 #define STAMP16(t)                                                                       \
     do {                                                                                 \
         __builtin_amdgcn_sched_barrier(0);                                               \
@@ -414,6 +415,11 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm16_kernel(const Igemm16Args
         }
     }
 
+#ifdef LOANS_STAMPS
+    unsigned long long t_e0 = 0, t_e1 = 0, t_e2 = 0;
+    STAMP16(t_e0);
+    if (logical < 64 && (tid & 63) == 0 && tid < 256) g_stamps16c[(logical * 4 + (tid >> 6)) * 4 + 0] = t_e0;
+#endif
     // ---- epilogue: BN statistics from the fp32 accumulators, tile staged through LDS (fp32) so that every lane
     // converts and stores 8 contiguous channels (16 bytes of bf16)
     const bool f_bias = d.flags & LOANS_F_BIAS, f_stats = d.flags & LOANS_F_STATS;
@@ -462,6 +468,10 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm16_kernel(const Igemm16Args
             }
         }
     }
+#ifdef LOANS_STAMPS
+    STAMP16(t_e1);
+    if (logical < 64 && (tid & 63) == 0 && tid < 256) g_stamps16c[(logical * 4 + (tid >> 6)) * 4 + 1] = t_e1;
+#endif
     constexpr int CPR = BN / 8;                 // 8-channel units per row
     constexpr int RSTEP = NT / CPR;            // rows covered by the block per pass
     const int oc8 = tid % CPR, r0 = tid / CPR;
@@ -612,6 +622,10 @@ __global__ __launch_bounds__(64 * WM * WN) void igemm16_kernel(const Igemm16Args
             }
             LOANS_STORE_B128(__builtin_bit_cast(u32x4, o), rs_out, (int)off, a.nt_out);
         }
+#ifdef LOANS_STAMPS
+        STAMP16(t_e2);
+        if (logical < 64 && (tid & 63) == 0 && tid < 256 && ep < 2) g_stamps16c[(logical * 4 + (tid >> 6)) * 4 + 2 + ep] = t_e2;
+#endif
     }
     if (f_bnsums) {
         // per block: the threads that share a channel unit (same oc8, RSTEP rows apart) are summed through LDS, then one fp64
@@ -1248,6 +1262,9 @@ extern "C" int loans_wgrad_bf16s(const void* x, const void* gy, float* dw, const
 }
 
 #ifdef LOANS_STAMPS
+extern "C" int loans_debug_read_stamps16c(unsigned long long* host, int n) {
+    return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps16c), sizeof(unsigned long long) * n);
+}
 extern "C" int loans_debug_read_stamps16b(unsigned long long* host, int n) {
     return (int)hipMemcpyFromSymbol(host, HIP_SYMBOL(g_stamps16b), sizeof(unsigned long long) * n);
 }

@@ -45,6 +45,14 @@ sb = bufb.reshape(64, 4, 4).astype(np.float64)
 pro, loop, epi = sb[..., 1] - sb[..., 0], sb[..., 2] - sb[..., 1], sb[..., 3] - sb[..., 2]
 print('   per block (median of the first 64 tiles): prologue %.0f  K loop %.0f  last chunk + epilogue %.0f cycles; first-wave entries span %.0f cycles' % (
     np.median(pro), np.median(loop), np.median(epi), sb[..., 0].max() - sb[..., 0].min()))
+bufc = np.zeros(64 * 4 * 4, np.uint64)
+lib.loans_debug_read_stamps16c.argtypes = [ctypes.c_void_p, ctypes.c_int]
+assert lib.loans_debug_read_stamps16c(bufc.ctypes.data, bufc.size) == 0
+sc = bufc.reshape(64, 4, 4).astype(np.float64)
+last, stats, p0, p1 = sc[..., 0] - sb[..., 2], sc[..., 1] - sc[..., 0], sc[..., 2] - sc[..., 1], sc[..., 3] - sc[..., 2]
+tail = sb[..., 3] - np.where(sc[..., 3] > 0, sc[..., 3], sc[..., 2])
+print('   epilogue (median): last chunk %.0f  statistics %.0f  staging pass 0 + stores %.0f  pass 1 + stores %.0f  after the last pass %.0f cycles' % (
+    np.median(last), np.median(stats), np.median(p0), np.median(p1) if (sc[..., 3] > 0).any() else 0, np.median(tail)))
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 e0.record()
 for _ in range(10):
