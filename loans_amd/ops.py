@@ -401,10 +401,22 @@ def _halo_tiles(geo, gathered_channels, out_channels, out_hw, relu_in=False):
     return tiles
 
 
+# LOANS_TUNE_COLD=1 (experiment): a 512 MB fill between the timed launches of the autotuner, so that every candidate finds its
+# operands in HBM, where the step's previous kernel left them, and not in the 256 MB Infinity Cache, where the candidate's own
+# previous repetition did
+TUNE_COLD = os.environ.get('LOANS_TUNE_COLD', '0') != '0'
+_cold = {}
+
+
 def _time_call(fn, reps=5):
     fn()
     best = float('inf')
     for _ in range(reps):
+        if TUNE_COLD:
+            dev = torch.cuda.current_device()
+            if dev not in _cold:
+                _cold[dev] = torch.empty(512 << 20, device='cuda', dtype=torch.uint8)
+            _cold[dev].zero_()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
         fn()
