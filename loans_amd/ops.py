@@ -1030,11 +1030,46 @@ _side = {}
 _side_dirty = set()
 
 
+# Consecutive weight gradients are independent of each other: with LOANS_WGRAD_STREAMS = n > 1 they rotate over n streams, so that
+# the tail of one launch (its last, partly empty round of tiles; its closing float atomics) runs under the main loop of the
+# next.  Measured (round 3, same box, two pairs): fp32 configs[1] 50.24 -> 49.71 ms with two streams -- the fp32 weight gradients
+# run 3-6 rounds of 128 x 128 tiles with a ragged last one --, bf16 configs[2] / ResNet-50 +0.06 / +0.15 ms (their launches are
+# one or two rounds of long blocks that already fill the machine; a second launch beside them only takes CUs from the first).
+# Default: two streams while the fp32 kernels are selected, one on the bf16 arms.
+_WGRAD_STREAMS_ENV = os.environ.get('LOANS_WGRAD_STREAMS', '')
+_side_more = {}
+_side_turn = {}
+
+
+def wgrad_streams():
+    if _WGRAD_STREAMS_ENV:
+        return max(1, min(4, int(_WGRAD_STREAMS_ENV)))
+    return 2 if COMPUTE == 'f32' else 1
+
+
 def _side_stream(device):
+    """the weight-gradient stream; with several: the FIRST, after it has been made to wait for the others -- what callers that
+    order something behind every weight gradient issued so far (the staged exchange) rely on"""
     st = _side.get(device.index)
     if st is None:
         st = _side[device.index] = torch.cuda.Stream(device=device, priority=SIDE_PRIORITY)
+    for other in _side_more.get(device.index, ()):
+        st.wait_stream(other)
     return st
+
+
+def _wgrad_stream(device):
+    n = wgrad_streams()
+    idx = device.index
+    if n == 1 and idx not in _side_more:
+        return _side_stream(device)
+    if idx not in _side:
+        _side[idx] = torch.cuda.Stream(device=device, priority=SIDE_PRIORITY)
+    more = _side_more.setdefault(idx, [])
+    while len(more) < n - 1:
+        more.append(torch.cuda.Stream(device=device, priority=SIDE_PRIORITY))
+    turn = _side_turn[idx] = (_side_turn.get(idx, 0) + 1) % n
+    return _side[idx] if turn == 0 else more[turn - 1]
 
 
 def join_side_stream(device=None):
@@ -1042,7 +1077,10 @@ def join_side_stream(device=None):
     for idx in list(_side_dirty):
         if device is not None and device.index != idx:
             continue
-        torch.cuda.current_stream(idx).wait_stream(_side[idx])
+        cur = torch.cuda.current_stream(idx)
+        cur.wait_stream(_side[idx])
+        for other in _side_more.get(idx, ()):
+            cur.wait_stream(other)
         _side_dirty.discard(idx)
 
 
@@ -1056,7 +1094,7 @@ def conv_wgrad(x, gy, dw, geo, relu_in=False, splits=0, tile=0):
     """dw[Cout,k,k,Cin] += sum over pixels (atomic accumulate into the gradient arena)."""
     if ASYNC_WGRAD and geo.tuned.get(_wgrad_key(x, gy, relu_in)) is not None \
             and (CAPTURE_STREAMS or not torch.cuda.is_current_stream_capturing()):
-        side = _side_stream(x.device)
+        side = _wgrad_stream(x.device)
         side.wait_stream(torch.cuda.current_stream(x.device))
         x.record_stream(side)
         gy.record_stream(side)

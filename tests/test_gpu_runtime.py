@@ -136,3 +136,35 @@ def test_weight_preparation_once_per_step():
             ops.begin_step(dev0)
             ops.end_step()
         assert (w.data_ptr(), geo.key, bf16) not in ops._weight_preps[0].repacks
+
+
+def test_weight_gradients_rotate_over_their_streams(monkeypatch):
+    """LOANS_WGRAD_STREAMS (round 3; two streams by default on the fp32 kernels): consecutive weight gradients go to different
+    streams, `join_side_stream` / the staged exchange's `_side_stream` wait for all of them, and the gradients are those of the
+    single-stream order."""
+    rng = np.random.RandomState(5)
+    geo = ops.ConvGeometry(4, 20, 24, 64, 64, 3, 1, 1)
+    x = dev(rng.standard_normal((4, 20, 24, 64)).astype(np.float32))
+    gys = [dev(rng.standard_normal((4, 20, 24, 64)).astype(np.float32)) for _ in range(4)]
+    ops.conv_wgrad(x, gys[0], torch.zeros(64, 3, 3, 64, device='cuda'), geo)        # autotune outside the comparison
+    ops.join_side_stream()
+    torch.cuda.synchronize()
+    got = {}
+    for n in ('1', '3'):
+        monkeypatch.setattr(ops, '_WGRAD_STREAMS_ENV', n)
+        used = []
+        real = ops._conv_wgrad
+        monkeypatch.setattr(ops, '_conv_wgrad', lambda *a, **k: (used.append(torch.cuda.current_stream().cuda_stream), real(*a, **k))[1])
+        dws = [torch.zeros(64, 3, 3, 64, device='cuda') for _ in gys]
+        for gy, dw in zip(gys, dws):
+            ops.conv_wgrad(x, gy, dw, geo)
+        assert ops._side_dirty
+        ops.join_side_stream()          # the current stream now waits for every one of them
+        got[n] = [dw.clone() for dw in dws]
+        assert not ops._side_dirty
+        monkeypatch.setattr(ops, '_conv_wgrad', real)
+        assert len(set(used)) == int(n) and torch.cuda.current_stream().cuda_stream not in used, used
+        if n == '3':
+            assert used[0] != used[1] != used[2] and used[3] == used[0]
+    for a, b in zip(got['1'], got['3']):
+        np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-5, atol=1e-4)
