@@ -184,7 +184,7 @@ def workload_of(args, **over):
     from types import SimpleNamespace
     w = SimpleNamespace(image_size=args.image_size, batch=args.batch or 256, dtype=args.dtype, storage=args.storage,
                         resnet50=args.resnet50, target_size=args.target_size, steps=args.steps, warmup=args.warmup,
-                        graph=args.graph, tune_file=args.tune_file, traffic_file=args.traffic_file, early_chain=False)
+                        graph=args.graph, tune_file=args.tune_file, traffic_file=args.traffic_file)
     for k, v in over.items():
         setattr(w, k, v)
     w.storage = w.storage or ('bf16' if w.dtype == 'bf16' else 'f32')
@@ -372,8 +372,6 @@ def run_workload(w, comm, local_rank, retune):
     # kernel-tile autotuning and lazily created links happen on the first step a shape is seen; with --warmup 0 that
     # one-off initialisation would land in the timed region, so it gets a step of its own (reported as init_steps)
     init_steps = 1 if w.warmup == 0 else 0
-    from loans_amd.sheep import sheep_updater
-    chain_order, sheep_updater.EARLY_CHAIN = sheep_updater.EARLY_CHAIN, sheep_updater.EARLY_CHAIN or w.early_chain
     for _ in range(init_steps + w.warmup):
         updater.update()
 
@@ -401,7 +399,6 @@ def run_workload(w, comm, local_rank, retune):
         host_ms.append((time.perf_counter() - h0) * 1e3)
     torch.cuda.synchronize()
     host_enqueue_ms = float(np.median(host_ms))
-    sheep_updater.EARLY_CHAIN = chain_order
 
     # what a bracket of two HIP events measures with NOTHING between them: the events are packets of their own in the
     # queue, and that time is not the kernel's (rocprofv3's per-kernel durations do not contain it either)
@@ -483,22 +480,6 @@ def main():
             leg = run_workload(workload_of(args, **over), comm, local_rank, retune)
             leg["metric"] = "localizer+assessor train images/sec"
             secondary[label] = leg
-    variants = {}
-    if world == 1 and (is_default or args.secondary_shape) and not args.no_secondary:
-        # the same workload with the assessor's own chain enqueued first, beside the localizer's forward (LOANS_EARLY_CHAIN=1,
-        # DESIGN 7c): faster on the fp32 step, not the default because the conv-forward launches `roofline` times then share
-        # the GPU -- reported beside the primary leg, which stays the product's default schedule
-        gc.collect()
-        torch.cuda.empty_cache()
-        leg = run_workload(workload_of(args, early_chain=True, steps=args.secondary_steps if args.secondary_shape else args.steps,
-                                       warmup=args.secondary_warmup if args.secondary_shape else args.warmup), comm, local_rank, False)
-        variants["primary workload with LOANS_EARLY_CHAIN=1"] = {
-            "value": leg["value"], "unit": leg["unit"], "ms_per_step": leg["ms_per_step"], "steps": leg["steps"],
-            "warmup": leg["warmup"], "dtype": leg["dtype"],
-            "note": "the assessor's own chain enqueued first and running beside the localizer's forward; not the default "
-                    "schedule: the localizer's conv-forward launches then share the GPU (their per-launch time, the basis of "
-                    "`roofline`, reads %.2f ms per step here against %.2f in the primary leg)"
-                    % (leg["roofline"]["conv_fwd_ms_per_step"], primary["roofline"]["conv_fwd_ms_per_step"])}
     if rank != 0:
         parallel.shutdown()
         return
@@ -510,8 +491,6 @@ def main():
     }
     if secondary:
         out["secondary"] = secondary
-    if variants:
-        out["variants"] = variants
     if world == 1 and not args.no_cpu_baseline and not args.resnet50 and args.dtype == 'f32':
         out["cpu_baseline"] = cpu_baseline(args, args.image_size, args.target_size)
     print(json.dumps(out), flush=True)

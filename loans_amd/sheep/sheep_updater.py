@@ -26,6 +26,8 @@ CONCURRENT_CHAINS = os.environ.get('LOANS_CONCURRENT_CHAINS', '1') != '0'
 # no weight gradients to fill them: fp32 B = 256 50.7 -> 49.9 ms, bf16 configs unchanged (round 3).  Not the default: the
 # localizer's conv-forward launches then share the GPU with it, and the per-launch durations bench.py's roofline, the rocprofv3
 # trace and the PMC passes are built on (8.8 ms per step alone) read 15.8 ms -- a property of the schedule, not of the kernel.
+# Superseded by the second weight-gradient stream (ops.wgrad_streams): with it the default order measures 49.9-50.0 ms and this
+# one 50.2-50.3 on the same box.
 EARLY_CHAIN = os.environ.get('LOANS_EARLY_CHAIN', '0') != '0'
 _fork = {}
 
