@@ -275,3 +275,21 @@ def test_tune_table_round_trip(tmp_path, monkeypatch):
     json.dump(doc, open(path, 'w'))
     assert ops.load_tune_table(path) == 0 and not ops._TUNE_LOADED
     g.tuned.clear(); gd.tuned.clear()
+
+
+def test_weight_gradient_stream_count_follows_the_arm(monkeypatch):
+    """ops.wgrad_streams (round 3): two streams while the fp32 kernels are selected (their launches end in ragged rounds the
+    next launch can run under), one on the bf16 arms (measured slower with two); LOANS_WGRAD_STREAMS overrides, clamped to 1..4."""
+    from loans_amd import ops
+    old = ops.COMPUTE
+    try:
+        monkeypatch.setattr(ops, '_WGRAD_STREAMS_ENV', '')
+        ops.set_compute_dtype('f32')
+        assert ops.wgrad_streams() == 2
+        ops.set_compute_dtype('bf16')
+        assert ops.wgrad_streams() == 1
+        for env, want in (('1', 1), ('3', 3), ('9', 4), ('0', 1)):
+            monkeypatch.setattr(ops, '_WGRAD_STREAMS_ENV', env)
+            assert ops.wgrad_streams() == want
+    finally:
+        ops.set_compute_dtype(old)
