@@ -24,16 +24,20 @@ def _read_image_as_array(path, dtype):
     return image.transpose(2, 0, 1)                     # CHW
 
 
+def _as_pil(image, image_mode):
+    """A CHW (or HW) array holding 0..255 as a PIL image of ``image_mode``; values are cut to uint8 the way ``astype`` cuts them."""
+    pixels = numpy.asarray(image).astype(numpy.uint8)
+    if pixels.ndim == 3:
+        pixels = numpy.moveaxis(pixels, 0, -1)
+    return Image.fromarray(pixels).convert(image_mode)
+
+
 def resize_image(image, image_size, image_mode='RGB'):
-    if len(image.shape) == 2:
-        pil_image = Image.fromarray(image.astype('uint8'))
-    else:
-        pil_image = Image.fromarray(image.transpose(1, 2, 0).astype('uint8'))
-    pil_image = pil_image.convert(image_mode)
-    pil_image = pil_image.resize((image_size[1], image_size[0]), Image.LANCZOS)
-    if image_mode == 'L':
-        return numpy.asarray(pil_image).astype(numpy.float32)
-    return numpy.asarray(pil_image).transpose(2, 0, 1).astype(numpy.float32)
+    """Pillow's LANCZOS resize to ``image_size`` = (height, width) -- the resampler resample.hip restates bit for bit
+    (reference common/datasets/image_dataset.py:16-28).  float32 CHW, or HW for a single-band mode."""
+    height, width = image_size
+    resized = numpy.asarray(_as_pil(image, image_mode).resize((width, height), Image.LANCZOS), dtype=numpy.float32)
+    return resized if resized.ndim == 2 else numpy.moveaxis(resized, -1, 0)
 
 
 def random_crop(image, size):
@@ -64,13 +68,10 @@ def resize_bbox(bbox, in_size, out_size):
 class ImageDataset:
 
     def __init__(self, paths, root='.', dtype=numpy.float32, **kwargs):
-        self.image_size = kwargs.pop('image_size', None)
-        self.image_mode = kwargs.pop('image_mode', 'RGB')
-        self.transform_probability = kwargs.pop('transform_probability', 0)
-        self.use_imgaug = kwargs.pop('use_imgaug', True)
-        self.min_crop_ratio = kwargs.pop('min_crop_ratio', 0.6)
-        self.max_crop_ratio = kwargs.pop('max_crop_ratio', 0.9)
-        self.crop_always = kwargs.pop('crop_always', False)
+        # the reference's keywords and defaults (common/datasets/image_dataset.py:50-56)
+        for name, default in (('image_size', None), ('image_mode', 'RGB'), ('transform_probability', 0), ('use_imgaug', True),
+                              ('min_crop_ratio', 0.6), ('max_crop_ratio', 0.9), ('crop_always', False)):
+            setattr(self, name, kwargs.pop(name, default))
         # the imgaug branch draws from a stream of its own (reseed() restarts it): get_example and device_batch consume one
         # set of draws per example, in call order
         self._aug_rng = random.Random(kwargs.pop('augment_seed', None))
@@ -130,8 +131,8 @@ class ImageDataset:
         """resize + ``/ 255`` of one augmented example (reference :92-98); no random draws"""
         if self.image_size is not None:
             image = resize_image(image, self.image_size, image_mode=self.image_mode)
-        if len(image.shape) == 2:
-            image = image[None, ...]
+        if image.ndim == 2:                                 # single-band mode: a channel axis of one
+            image = image[numpy.newaxis]
         return numpy.ascontiguousarray(image / 255, dtype=numpy.float32)
 
     def get_example(self, i):
@@ -233,13 +234,15 @@ class LabeledImageDataset:
         self._pairs = self._pairs[:new_size]
 
     def check_for_bad_label(self, label, image_size):
-        error_text = ("Label can not be scaled correctly are you sure you created the dataset correctly, and provided "
-                      f"the correct sizes? Image size: {image_size}, label: {label}")
-        ten_percent_extra = [size * 0.1 for size in image_size]
-        assert (label[:, 0] >= 0 - ten_percent_extra[0]).all(), error_text
-        assert (label[:, 1] >= 0 - ten_percent_extra[1]).all(), error_text
-        assert (label[:, 2] <= image_size[0] + ten_percent_extra[0]).all(), error_text
-        assert (label[:, 3] <= image_size[1] + ten_percent_extra[1]).all(), error_text
+        """Boxes are (y_min, x_min, y_max, x_max) in pixels of the frame as it was read; one that leaves the frame by more than
+        a tenth of the frame's side means labels and images do not belong together (reference :137-145: AssertionError)."""
+        height, width = image_size
+        slack_y, slack_x = height * 0.1, width * 0.1
+        fits = (label[:, 0] >= -slack_y).all() and (label[:, 1] >= -slack_x).all() and \
+            (label[:, 2] <= height + slack_y).all() and (label[:, 3] <= width + slack_x).all()
+        if not fits:
+            raise AssertionError(f'bounding boxes {label} do not lie in a frame of {height} x {width} px (+- 10 %): '
+                                 'was the dataset written for other image sizes?')
 
     def _base_example(self, i):
         path, label = self._pairs[i]
@@ -253,24 +256,23 @@ class LabeledImageDataset:
             print(e)
             image, label = self._base_example(0)
 
-        if len(label.shape) > 0 and len(label) % 4 == 0:
-            num_bboxes = len(label) // 4
-            label = numpy.reshape(label, (num_bboxes, -1))
+        if label.ndim and len(label) % 4 == 0:
+            label = label.reshape(len(label) // 4, -1)              # a flat run of corner values: one row per box
 
-        if image.shape[0] == 1:
-            image = numpy.tile(image, (3, 1, 1))
+        if image.shape[0] == 1:                                     # greyscale file: three equal channels
+            image = numpy.repeat(image, 3, axis=0)
         image = image[:3]
 
         if self.image_size is not None:
-            image_size = image.shape[-2:]
-            if len(label.shape) > 1:
-                self.check_for_bad_label(label, image_size)
-                label = resize_bbox(label.astype(numpy.float32), image_size, self.image_size)
-            image = resize_image(image, self.image_size, image_mode=self.image_mode)
+            read_size = image.shape[-2:]
+            if label.ndim > 1:                                      # boxes follow the frame to its new size
+                self.check_for_bad_label(label, read_size)
+                label = resize_bbox(label.astype(numpy.float32), read_size, self.image_size)
             label = label.astype(self._label_dtype)
+            image = resize_image(image, self.image_size, image_mode=self.image_mode)
 
-        if len(image.shape) == 2:
-            image = image[None, ...]
+        if image.ndim == 2:
+            image = image[numpy.newaxis]
 
         image = numpy.ascontiguousarray(image / 255, dtype=numpy.float32)
         if self.return_dummy_scores:

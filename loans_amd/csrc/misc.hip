@@ -382,15 +382,19 @@ __global__ __launch_bounds__(256) void grid_loss_bwd_kernel(const float* grid, c
         if (kind == 0) {
             const float tly_s = (tly + 1.f) / 2.f * imgH, bly_s = (bly + 1.f) / 2.f * imgH;
             const float tlx_s = (tlx + 1.f) / 2.f * imgW, trx_s = (trx + 1.f) / 2.f * imgW;
-            const float m1 = (tly_s - bly_s) > 0.f ? gl / (float)B * (imgH / 2.f) : 0.f;
-            const float m2 = (tlx_s - trx_s) > 0.f ? gl / (float)B * (imgW / 2.f) : 0.f;
+            // F.maximum(distance, zeros), common/utils.py:169,175: Chainer's Maximum gives the gradient to its first argument
+            // where x1 >= x2 -- an exact tie (distance == 0) passes it
+            const float m1 = (tly_s - bly_s) >= 0.f ? gl / (float)B * (imgH / 2.f) : 0.f;
+            const float m2 = (tlx_s - trx_s) >= 0.f ? gl / (float)B * (imgW / 2.f) : 0.f;
             dy[0] += m1;
             dy[(th - 1) * tw] -= m1;
             dx[0] += m2;
             dx[tw - 1] -= m2;
         } else {
             const float s = gl * oob_scale;
-            auto d = [&](float v) { return ((v + 1.f) < 0.f ? -s : 0.f) + ((v - 1.f) > 0.f ? s : 0.f); };
+            // common/utils.py:312-313: |min(v + 1, 0)| has gradient sign(min(v + 1, 0)) -- zero at the tie v == -1 --,
+            // max(v - 1, 0) passes the gradient where v - 1 >= 0 (Chainer's Maximum: x1 >= x2), tie included
+            auto d = [&](float v) { return ((v + 1.f) < 0.f ? -s : 0.f) + ((v - 1.f) >= 0.f ? s : 0.f); };
             dx[0] += d(tlx);
             dy[0] += d(tly);
             dx[tw - 1] += d(trx);

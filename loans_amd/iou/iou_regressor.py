@@ -133,7 +133,10 @@ class MyResNet50Layers(ResNet50Layers):
 
     @property
     def functions(self):
-        funcs = super().functions
-        for key in self.keys_to_remove:
-            del funcs[key]
-        return funcs
+        """the parent's layer table without the entries named at construction (reference iou/iou_regressor.py:10-15; a name
+        the parent does not have is an error there too)"""
+        table = super().functions
+        missing = [key for key in self.keys_to_remove if key not in table]
+        if missing:
+            raise KeyError(missing[0])
+        return type(table)((key, funcs) for key, funcs in table.items() if key not in self.keys_to_remove)

@@ -426,8 +426,26 @@ def _time_call(fn, reps=5):
     return best
 
 
+# How a problem shape gets its tile when neither this process nor a loaded table has one:
+#   'time'  (default; bench.py, the trainer): every candidate is timed on the shape, the fastest is kept -- the pick depends on
+#           the box, on what else the GPU is doing and on chance where two tiles are within noise of each other;
+#   'fixed' (the parity test session, tests/conftest.py): candidate number crc32(shape, mode, LOANS_TUNE_SALT) % n -- the same
+#           kernels on every box and in every run, and over the layer shapes of a network nearly every tile form on offer.
+#           A test session never times: TIMED_PICKS counts the picks that timing decided and conftest asserts it stays put.
+TUNE_POLICY = os.environ.get('LOANS_TUNE_POLICY', 'time')
+TUNE_SALT = os.environ.get('LOANS_TUNE_SALT', '0')
+TIMED_PICKS = 0
+assert TUNE_POLICY in ('time', 'fixed'), TUNE_POLICY
+
+
+def _fixed_pick(geo, mode, candidates):
+    import zlib
+    return candidates[zlib.crc32(('%s|%s|%s' % (_tune_key_str(geo.key), mode, TUNE_SALT)).encode()) % len(candidates)]
+
+
 def _tuned_tile(geo, mode, run, candidates):
     """run(tile) launches the op into scratch buffers."""
+    global TIMED_PICKS
     tile = geo.tuned.get(mode)
     if tile is not None:
         return tile
@@ -436,10 +454,18 @@ def _tuned_tile(geo, mode, run, candidates):
         return 0
     if COMPUTE == 'bf16':
         candidates = [t for t in candidates if not (t & 16)]
+    candidates = list(candidates)
     tile = _TUNE_LOADED.get(geo.key, {}).get(mode)
     if tile is not None and tile in candidates:         # a file's proposal, still on offer for this problem
         geo.tuned[mode] = tile
         return tile
+    if TUNE_POLICY == 'fixed':
+        tile = geo.tuned[mode] = _fixed_pick(geo, mode, candidates)
+        if os.environ.get('LOANS_TUNE_VERBOSE'):
+            print('[tune] %-5s B=%d %dx%dx%d -> %d k%d s%d : fixed pick, tile %d of %s' % (
+                mode, geo.B, geo.H, geo.W, geo.Cin, geo.Cout, geo.k, geo.stride, tile, candidates), flush=True)
+        return tile
+    TIMED_PICKS += 1
     times = {t: _time_call(lambda: run(t)) for t in candidates}
     tile = min(times, key=times.get)
     geo.tuned[mode] = tile

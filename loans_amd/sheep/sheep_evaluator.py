@@ -94,11 +94,10 @@ class SheepMAPEvaluator:
         self.device = device
 
     def extract_corners(self, bboxes):
-        top = bboxes[:, 1, 0, 0]
-        left = bboxes[:, 0, 0, 0]
-        bottom = bboxes[:, 1, -1, -1]
-        right = bboxes[:, 0, -1, -1]
-        return np.stack([top, left, bottom, right], axis=1)
+        """(top, left, bottom, right) of every sampling grid: channel 1 is y, channel 0 is x; first and last grid point
+        (reference sheep/sheep_evaluator.py:19-24)"""
+        first, last = bboxes[:, :, 0, 0], bboxes[:, :, -1, -1]          # (B, [x, y]) each
+        return np.stack([first[:, 1], first[:, 0], last[:, 1], last[:, 0]], axis=1)
 
     def scale_bboxes(self, bboxes, image_size):
         bboxes = (bboxes + 1) / 2

@@ -373,8 +373,10 @@ def direction_loss(grids, image_size):
     d2 = tlx - trx
     loss = np.maximum(d1, 0).mean() + np.maximum(d2, 0).mean()
     gg = np.zeros_like(grids)
-    m1 = (d1 > 0).astype(grids.dtype) / B * (H / 2.0)
-    m2 = (d2 > 0).astype(grids.dtype) / B * (W / 2.0)
+    # F.maximum(distance, zeros) (common/utils.py:169,175): Chainer 4.1's Maximum routes the gradient with `x1 >= x2`
+    # (gx1 = gy * (x1 >= x2), gx2 = gy * (x1 < x2)) -- at an exact tie it goes to the FIRST argument, here `distance`
+    m1 = (d1 >= 0).astype(grids.dtype) / B * (H / 2.0)
+    m2 = (d2 >= 0).astype(grids.dtype) / B * (W / 2.0)
     gg[:, 1, 0, 0] += m1
     gg[:, 1, th - 1, 0] -= m1
     gg[:, 0, 0, 0] += m2
@@ -390,7 +392,10 @@ def out_of_image_loss(grids):
     top = bbox + 1
     bottom = bbox - 1
     loss = np.abs(np.minimum(top, 0)).sum() + np.maximum(bottom, 0).sum()
-    gb = -(top < 0).astype(grids.dtype) + (bottom > 0).astype(grids.dtype)
+    # common/utils.py:312-313.  bottom: F.maximum(bottom_loss, zeros) passes the gradient where bottom_loss >= 0 (tie included,
+    # see direction_loss).  top: F.absolute(F.minimum(top_loss, zeros)) -- Minimum passes it where top_loss <= 0, but
+    # Absolute's backward is sign(x) * gy and sign(0) = 0: at the tie top_loss == 0 nothing comes back.
+    gb = -(top < 0).astype(grids.dtype) + (bottom >= 0).astype(grids.dtype)
     gg = np.zeros_like(grids)
     gg[:, 0, 0, 0] += gb[0:B]
     gg[:, 1, 0, 0] += gb[B:2 * B]

@@ -39,6 +39,19 @@ def _l2(a, ref):
     return float(np.linalg.norm(a - ref) / (np.linalg.norm(ref) + 1e-300))
 
 
+def _ulp_profile(a, o):
+    """Where two bf16 tensors differ, in units of the bf16 spacing at max(|o|, rms(o)):
+    (fraction that differs at all, fraction that differs by MORE than one spacing, largest difference in spacings).
+    Elements below the tensor's rms are measured against the spacing at the rms: what reaches an element from upstream is an
+    absolute perturbation (a sum over K products), so a value that happens to cancel to near zero is not held to its own,
+    arbitrarily small, ulp."""
+    a, o = np.asarray(a, np.float64), np.asarray(o, np.float64)
+    rms = float(np.sqrt(np.mean(o * o))) or 1.0
+    ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(o), rms))) - 7)
+    d = np.abs(a - o) / ulp
+    return float((d > 0).mean()), float((d > 1.0).mean()), float(d.max())
+
+
 def _whole_net_active(loc):
     """frames taller than 300 px: res6 and res7 are inside the arena's active prefix (for the ResNet-50 localizer everything
     but Chainer's unused fc6 head, which sits behind them)"""
@@ -135,7 +148,7 @@ def _teacher_forced_units(loc_cls, oracle_cls, B, H, W, crop, seed):
     head = {'param_predictor/W': _l2(loc.param_predictor.W.grad_logical(), gW),
             'param_predictor/b': _l2(loc.param_predictor.b.grad_logical(), gb),
             'd loss / d features': _l2(_nchw(feat.grad), g_feat)}
-    report.append(('head', 0.0, 0.0, head['d loss / d features'], head, 1 << 30))
+    report.append(('head', 0.0, (0.0, 0.0, 0.0), head['d loss / d features'], head, 1 << 30))
     assert max(head.values()) < 1e-3, head
     g = feat.grad
 
@@ -157,7 +170,7 @@ def _teacher_forced_units(loc_cls, oracle_cls, B, H, W, crop, seed):
         a = _nchw(out.data)
         errs = param_errs(list(units[i].params()), grads)
         assert len(errs) >= 6
-        report.append((key_of[id(next(iter(units[i].params())))].rsplit('/', 2)[0], _l2(a, o_out), float((a != o_out).mean()),
+        report.append((key_of[id(next(iter(units[i].params())))].rsplit('/', 2)[0], _l2(a, o_out), _ulp_profile(a, o_out),
                        _l2(_nchw(leaf.grad), o_gx), errs, a.shape[0] * a.shape[2] * a.shape[3]))
         g = leaf.grad
 
@@ -176,26 +189,45 @@ def _teacher_forced_units(loc_cls, oracle_cls, B, H, W, crop, seed):
         stem.bwd(C.max_pool_bwd(sr.shape, idx, _nchw(g), 3, 2, 0) * (sr > 0), grads, need_gx=False)
     a = _nchw(ins[0].data)
     errs = param_errs([fe.conv1.W, fe.bn1.gamma, fe.bn1.beta], grads)
-    report.append(('stem', _l2(a, o_pool), float((a != o_pool).mean()), 0.0, errs, a.shape[0] * a.shape[2] * a.shape[3]))
+    report.append(('stem', _l2(a, o_pool), _ulp_profile(a, o_pool), 0.0, errs, a.shape[0] * a.shape[2] * a.shape[3]))
     return report
 
 
 def _check_units(report, n_units):
-    for name, e_out, neq, e_gx, errs, n in reversed(report):
-        print('%-28s out L2 %.2e (differing elements %.4f)  gx L2 %.2e  parameter gradients L2 max %.2e (%s)'
-              % (name, e_out, neq, e_gx, max(errs.values()), max(errs, key=errs.get).rsplit('/', 2)[-2]))
+    """Bounds on one residual unit (teacher-forced: same bf16 input, same bf16 output gradient on both sides).
+
+    With the tiles pinned (conftest: LOANS_TUNE_POLICY=fixed) and split-K off (fixture deterministic_forward) every figure below
+    is a constant of the code: the forward and the data gradients have no atomics, the BN sums are fp64 (their order moves
+    1e-16, a bf16 rounding flips on that with probability ~1e-13), and the weight gradients' float atomics move 1e-7 of figures
+    bounded at 1e-2.  Round 3's box-to-box spread of these figures came from the TIMING autotuner choosing between tiles that
+    walk K in different orders.
+
+    OUTPUT, as an ulp histogram (`_ulp_profile`; replaces round 3's "differing elements < 0.03", a measured constant).  Both
+    sides round the same real number v + delta to bf16, where delta is (i) fp32-vs-fp64 accumulation, ~1e-6 |v|, and (ii) what
+    upstream elements that rounded the other way -- a fraction p of them, each off by one spacing = 2^-8 .. 2^-7 of itself --
+    add up to after a K-term contraction and a BN: a random sum with std ~ sqrt(p) 2^-8 rms.  Two roundings of values delta
+    apart differ by at most one spacing when |delta| < one spacing, so:
+      * "differs at all" has probability ~ |delta| / spacing ~ sqrt(p): a few per cent after three convolutions -- printed,
+        NOT bounded: it is the quantity that moved 0.019 .. 0.036 between boxes in round 3 while nothing was wrong;
+      * "differs by more than one spacing" needs |delta| > 1 spacing = a > 3 sigma event at p = 0.1: bounded at 1 %
+        (10 % where a BN normalises over fewer than 512 samples per channel: there a statistic that moved by one rounding shifts
+        a whole channel);
+      * no element further than 4 spacings (16 in the small-sample stages).
+    The L2 bound 1e-3 says the same in aggregate: sqrt(0.12 differing) x 2^-8 x 0.75 = 1e-3.
+
+    GRADIENTS.  A unit's backward differs from the oracle's where a ReLU mask differs: a pre-activation y = x s + t whose x
+    rounded the other way (fraction p <= 0.1, by 2^-8 |x|) AND that lies within that distance of zero (fraction ~ 2^-7 x pdf(0)
+    x sigma_y ~ 4e-3 for a normalised y) -- q ~ 4e-4 of the mask; a gradient that gains or loses a fraction q of its terms is
+    off by sqrt(q) = 2e-2 in the L2 norm.  Bound 2.5e-2 (measured 3e-4 .. 1.6e-2); in the stages behind res5 (2 x 8 x 8 and
+    2 x 4 x 4 samples per channel at this batch) one flipped element is 1/128 .. 1/32 of a channel's statistics: 8e-2."""
+    for name, e_out, (neq, over1, dmax), e_gx, errs, n in reversed(report):
+        print('%-28s out L2 %.2e (differ %.4f, by > 1 bf16 spacing %.5f, max %.1f spacings)  gx L2 %.2e  parameter gradients L2 max %.2e (%s)'
+              % (name, e_out, neq, over1, dmax, e_gx, max(errs.values()), max(errs, key=errs.get).rsplit('/', 2)[-2]))
     assert len(report) == n_units + 2
-    for name, e_out, neq, e_gx, errs, n in report:
-        # Measured (this test; single units in isolation give the same): outputs 1e-5 .. 7e-4, gradients 3e-4 .. 1.3e-2 where a
-        # BN normalises over >= 512 samples per channel -- against 4e-3 / 5e-2 for the same units compared with the UN-rounded
-        # oracle.  The stages behind res5 see 2 x 8 x 8 and 2 x 4 x 4 samples per channel at this batch: a rounding that falls
-        # the other way moves their statistics-dependent terms further (outputs up to 2e-3, gradients up to 5e-2).
-        # The gradient figures are not constants of the code: the autotuner's tile picks (a halo tile walks K chunk-major, the
-        # implicit GEMM tap-major) and the order of the weight gradients' float atomics change which activations round the other
-        # way -- four runs of the SAME build gave 0.75e-2 .. 1.43e-2 for res5 of the ResNet-50 localizer, a fifth 1.55e-2.  The
-        # bound sits at 2.5e-2: above that spread, half of what the un-rounded oracle gives.
+    for name, e_out, (neq, over1, dmax), e_gx, errs, n in report:
         tight = n >= 512
-        assert e_out < (1e-3 if tight else 5e-3) and neq < (0.03 if tight else 0.3), (name, e_out, neq)
+        assert e_out < (1e-3 if tight else 5e-3), (name, e_out)
+        assert over1 <= (0.01 if tight else 0.1) and dmax <= (4.0 if tight else 16.0), (name, neq, over1, dmax)
         assert e_gx < (2.5e-2 if tight else 8e-2), (name, e_gx)
         assert max(errs.values()) < (2.5e-2 if tight else 8e-2), (name, errs)
 

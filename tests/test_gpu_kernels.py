@@ -609,6 +609,57 @@ def test_spatial_transformer_forward_backward():
     np.testing.assert_allclose(gt.cpu().numpy(), gt_ref, rtol=1e-4, atol=1e-5)
 
 
+def test_regulariser_gradients_at_exact_ties():
+    """SURVEY 8c-style known answer for common/utils.py:165-178,303-316 at an exact tie (tests/test_oracle_kat.py::test_kat9 is
+    the oracle's twin): Chainer's Maximum hands the gradient to its first argument where x1 >= x2, Absolute's backward is
+    sign(x) gy.  theta = identity: TR_x - 1 == 0 and BL_y - 1 == 0 -> gradient 1 there, TL_x + 1 == 0 and TL_y + 1 == 0 ->
+    nothing.  Expected values are written out, not taken from the oracle."""
+    from loans_amd import ops
+    th, tw, B = 5, 6, 3
+    one = torch.ones((), device='cuda')
+    theta = torch.tensor([[1., 0, 0], [0, 1., 0]], device='cuda').expand(B, 2, 3).contiguous()
+    grid = ops.st_grid_fwd(theta, (th, tw))
+    g = grid.cpu().numpy()
+    assert (g[:, 0, 0, tw - 1] == 1.0).all() and (g[:, 1, th - 1, 0] == 1.0).all()      # the kernel's linspace ends exactly on 1
+    assert (g[:, 0, 0, 0] == -1.0).all() and (g[:, 1, 0, 0] == -1.0).all()
+    assert float(ops.grid_loss_fwd(grid, 1)) == 0.0
+    want = np.zeros_like(g)
+    want[:, 0, 0, tw - 1] = 1.0
+    want[:, 1, th - 1, 0] = 1.0
+    np.testing.assert_array_equal(ops.grid_loss_bwd(grid, one, 1).cpu().numpy(), want)
+    np.testing.assert_array_equal(C.out_of_image_loss(g)[1], want)
+    # data-parallel scale of the batch SUM (oob_scale = world size) multiplies the tie's gradient like any other
+    np.testing.assert_array_equal(ops.grid_loss_bwd(grid, one, 1, oob_scale=4.0).cpu().numpy(), 4.0 * want)
+    # zero-height box: TL_y - BL_y == 0 exactly
+    theta = torch.tensor([[1., 0, 0], [0, 0, 0.25]], device='cuda').expand(B, 2, 3).contiguous()
+    grid = ops.st_grid_fwd(theta, (th, tw))
+    assert float(ops.grid_loss_fwd(grid, 0, 48, 64)) == 0.0
+    want = np.zeros_like(g)
+    want[:, 1, 0, 0] = 48 / 2.0 / B
+    want[:, 1, th - 1, 0] = -48 / 2.0 / B
+    np.testing.assert_array_equal(ops.grid_loss_bwd(grid, one, 0, 48, 64).cpu().numpy(), want)
+    np.testing.assert_array_equal(C.direction_loss(grid.cpu().numpy(), (48, 64))[1], want)
+
+
+def test_tie_gradient_reaches_param_predictor_through_the_model():
+    """The same tie through the product's call surface: a localizer whose param_predictor says theta = identity exactly
+    (W = 0, b = [1,0,0,0,1,0]); OutOfImageLossCalculator.calc_loss(points).backward() leaves d loss / d b = sum over the batch of
+    [TR_x's xs = 1, (masked), 1, (masked), BL_y's ys = 1, 1] = [B, 0, B, 0, B, B]."""
+    import loans_amd
+    B, crop = 3, (16, 16)
+    np.random.seed(0)
+    loc = loans_amd.SheepLocalizer(crop)
+    loc.param_predictor.b.set_logical(np.array([1, 0, 0, 0, 1, 0], np.float32))
+    from loans_amd.datasets import synthetic
+    rois, points = loc(dev(synthetic.make_frames(1, B, 64, 64)))
+    assert torch.equal(loc.last_transform_params.data, torch.tensor([[1., 0, 0], [0, 1., 0]], device='cuda').expand(B, 2, 3))
+    loss = loans_amd.OutOfImageLossCalculator(torch).calc_loss(points, loans_amd.Size(64, 64))
+    assert float(loss.data) == 0.0
+    loc.cleargrads()
+    loss.backward()
+    np.testing.assert_array_equal(loc.param_predictor.b.grad_logical(), np.array([B, 0, B, 0, B, B], np.float32))
+
+
 def test_losses_and_heads():
     from loans_amd import ops
     rng = np.random.RandomState(4)

@@ -574,9 +574,10 @@ def test_residual_unit_bf16_storage(kind):
         loans_amd.set_compute_dtype('f32')
 
 
-def test_split_k_autotuned_step():
-    """With split-K offered to the autotuner (the default outside this test session) a small-batch joint step gives the same
-    losses, theta and parameter gradients as the order-preserving kernels to fp32 summation-order accuracy."""
+def test_split_k_autotuned_step(timed_autotune):
+    """With split-K offered to the TIMING autotuner (the default outside this test session: fixture timed_autotune) a
+    small-batch joint step gives the same losses, theta and parameter gradients as the order-preserving kernels to fp32
+    summation-order accuracy -- whatever the timing picks on this box."""
     from loans_amd import ops
     B, H, W, crop = 4, 96, 96, (16, 16)
     frames, real, labels = inputs(51, B, H, W, crop)

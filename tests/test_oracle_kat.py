@@ -135,3 +135,30 @@ def test_adam_first_step_is_chainer_placement():
     # amsgrad: vhat never decreases
     C.adam_amsgrad_update(p, np.zeros(3), m, v, vh, 2, alpha=1e-3)
     assert np.all(vh >= v)
+
+
+def test_kat9_ties_follow_chainers_maximum_and_absolute():
+    """Chainer 4.1 routes the gradient of F.maximum(x1, x2) with `x1 >= x2` (F.minimum: `x1 <= x2`): at an exact tie it goes to
+    the first argument.  The regularisers call them as F.maximum(distance, zeros) / F.maximum(bottom_loss, zeros)
+    (common/utils.py:169,175,313), so a corner sitting EXACTLY on the image border, or a box of exactly zero extent, still
+    receives the gradient; F.absolute(F.minimum(top_loss, zeros)) (:312) does not: Absolute's backward is sign(x) gy and
+    sign(0) = 0.  theta = identity puts TR_x and BL_y exactly on +1 and TL_x, TL_y exactly on -1."""
+    th, tw, B = 5, 6, 3
+    theta = np.tile(np.array([[1, 0, 0], [0, 1, 0]], np.float32), (B, 1, 1))
+    grid, _ = C.st_grid_fwd(theta, (th, tw))
+    assert grid[0, 0, 0, tw - 1] == 1.0 and grid[0, 1, th - 1, 0] == 1.0 and grid[0, 0, 0, 0] == -1.0 and grid[0, 1, 0, 0] == -1.0
+    loss, gg = C.out_of_image_loss(grid)
+    assert loss == 0
+    want = np.zeros_like(grid)
+    want[:, 0, 0, tw - 1] = 1.0          # TR_x - 1 == 0: max(bottom_loss, 0) passes the gradient at the tie
+    want[:, 1, th - 1, 0] = 1.0          # BL_y - 1 == 0
+    np.testing.assert_array_equal(gg, want)                   # TL_x + 1 == 0, TL_y + 1 == 0: sign(0) = 0, nothing
+    # a box of zero height: TL_y - BL_y == 0 exactly -> the direction term passes H / (2 B) to TL_y and its negative to BL_y
+    theta = np.tile(np.array([[1, 0, 0], [0, 0, 0.25]], np.float32), (B, 1, 1))
+    grid, _ = C.st_grid_fwd(theta, (th, tw))
+    loss, gg = C.direction_loss(grid, (48, 64))
+    assert loss == 0
+    want = np.zeros_like(grid)
+    want[:, 1, 0, 0] = 48 / 2.0 / B
+    want[:, 1, th - 1, 0] = -48 / 2.0 / B
+    np.testing.assert_array_equal(gg, want)                   # (TL_x - TR_x = -64 < 0: no horizontal term)

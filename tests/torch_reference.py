@@ -73,6 +73,9 @@ def assessor(p, x):
 
 
 def regularisers(points, image_hw):
+    # (torch's relu / clamp give an exact tie NO gradient, Chainer's F.maximum(x, zeros) gives it to x: this composition
+    # cross-checks the oracle away from ties only; the tie convention has its own known-answer tests,
+    # tests/test_oracle_kat.py::test_kat9_ties_follow_chainers_maximum_and_absolute)
     H, W = image_hw
     th, tw = points.shape[-2:]
     g = (points + 1) / 2

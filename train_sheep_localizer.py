@@ -103,14 +103,13 @@ class SyntheticValidationFrames:
 
 
 def load_train_paths(train_file, with_label=False):
-    """``.json`` file lists (reference :24-32): ``[{"image": path, "bounding_boxes": [[...]]}, ...]``"""
-    with open(train_file) as handle:
-        train_data = json.load(handle)
-    paths = [item["image"] for item in train_data]
-    if with_label:
-        labels = [item['bounding_boxes'][0] for item in train_data]
-        return list(zip(paths, labels))
-    return paths
+    """The reference's ``.json`` ground-truth lists (its train_sheep_localizer.py:24-32): one record per frame,
+    ``{"image": path, "bounding_boxes": [box, ...]}``.  Plain path list, or (path, first box) pairs for the labelled datasets."""
+    with open(train_file) as f:
+        records = json.load(f)
+    if not with_label:
+        return [record['image'] for record in records]
+    return [(record['image'], record['bounding_boxes'][0]) for record in records]
 
 
 def load_pretrained_model(model_file, model):
