@@ -18,8 +18,18 @@ _WORKER = os.path.join(os.path.dirname(os.path.abspath(__file__)), '_decode_work
 
 class DecodeFarm:
 
+    # requests a worker may have outstanding: its stdin pipe holds 64 KiB, a path is at most PATH_MAX = 4096 bytes -- eight
+    # always fit, so the parent never blocks writing requests while the worker blocks writing a frame nobody reads (with a
+    # whole share written up front, a large batch on few processes with long paths did exactly that: a deadlock without a
+    # timeout).  Eight frames ahead is more than the reply pipe holds anyway.
+    WINDOW = 8
+
     def __init__(self, n_processes):
         self.n = max(1, int(n_processes))
+        self.procs = []
+        self._start()
+
+    def _start(self):
         env = dict(os.environ, OMP_NUM_THREADS='1', OPENBLAS_NUM_THREADS='1', MKL_NUM_THREADS='1')
         self.procs = [subprocess.Popen([sys.executable, '-u', _WORKER], stdin=subprocess.PIPE, stdout=subprocess.PIPE, env=env)
                       for _ in range(self.n)]
@@ -31,13 +41,24 @@ class DecodeFarm:
                 pass
 
     def _serve(self, job):
-        """one worker's share of a batch: send every path, then read every reply (the worker decodes ahead into its pipe)"""
+        """one worker's share of a batch: at most WINDOW requests outstanding -- a new one goes out for every reply read -- so
+        the worker decodes ahead into its pipe and neither side can fill the other's"""
         k, paths = job
         proc = self.procs[k]
-        proc.stdin.write(b''.join(p.encode('utf-8') + b'\n' for p in paths))
-        proc.stdin.flush()
+        sent = 0
+
+        def send(upto):
+            nonlocal sent
+            if upto > sent:
+                try:
+                    proc.stdin.write(b''.join(p.encode('utf-8') + b'\n' for p in paths[sent:upto]))
+                    proc.stdin.flush()
+                except (BrokenPipeError, ValueError):
+                    raise RuntimeError('decode worker %d died (exit code %s)' % (k, proc.poll())) from None
+                sent = upto
         out = []
-        for p in paths:
+        for i in range(len(paths)):
+            send(min(len(paths), i + self.WINDOW))
             head = proc.stdout.read(12)
             if len(head) != 12:
                 raise RuntimeError('decode worker %d died (exit code %s)' % (k, proc.poll()))
@@ -60,7 +81,14 @@ class DecodeFarm:
         8-bit image, 2 = unreadable).  ``map_fn``: the ``map`` of a thread pool with at least ``n`` threads."""
         paths = list(paths)
         shares = [(k, paths[k::self.n]) for k in range(self.n) if paths[k::self.n]]
-        results = list(map_fn(self._serve, shares))
+        try:
+            results = list(map_fn(self._serve, shares))
+        except BaseException:
+            # one worker failed: the others' pipes may still hold replies nobody will read, so none of them can be trusted
+            # with the next batch -- the whole farm is replaced before the error goes up
+            self.close()
+            self._start()
+            raise
         out = [None] * len(paths)
         for (k, _), frames in zip(shares, results):
             out[k::self.n] = frames

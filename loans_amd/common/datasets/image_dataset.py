@@ -40,15 +40,15 @@ def resize_image(image, image_size, image_mode='RGB'):
     return resized if resized.ndim == 2 else numpy.moveaxis(resized, -1, 0)
 
 
-def random_crop(image, size):
+def random_crop(image, size, rng=random):
     H, W = image.shape[-2:]
-    y = random.randint(0, H - size[0]) if H > size[0] else 0
-    x = random.randint(0, W - size[1]) if W > size[1] else 0
+    y = rng.randint(0, H - size[0]) if H > size[0] else 0
+    x = rng.randint(0, W - size[1]) if W > size[1] else 0
     return image[:, y:y + size[0], x:x + size[1]]
 
 
-def random_flip(image, x_random=False):
-    if x_random and random.choice([True, False]):
+def random_flip(image, x_random=False, rng=random):
+    if x_random and rng.choice([True, False]):
         image = image[:, :, ::-1]
     return image
 
@@ -72,8 +72,10 @@ class ImageDataset:
         for name, default in (('image_size', None), ('image_mode', 'RGB'), ('transform_probability', 0), ('use_imgaug', True),
                               ('min_crop_ratio', 0.6), ('max_crop_ratio', 0.9), ('crop_always', False)):
             setattr(self, name, kwargs.pop(name, default))
-        # the imgaug branch draws from a stream of its own (reseed() restarts it): get_example and device_batch consume one
-        # set of draws per example, in call order
+        # BOTH augmentation branches draw from a stream that belongs to this dataset (reseed() restarts it): get_example and
+        # device_batch consume one set of draws per example, in call order.  (The reference's naive branch draws from the global
+        # `random` module; with two iterators preparing batches on threads of their own -- train and reference -- two datasets
+        # on ONE global stream interleave their draws in thread-timing order and a seeded run is not reproducible)
         self._aug_rng = random.Random(kwargs.pop('augment_seed', None))
         if isinstance(paths, str):
             with open(paths) as paths_file:
@@ -116,11 +118,12 @@ class ImageDataset:
             return apply_host(u8, rows).astype(self._dtype).transpose(2, 0, 1)
         if imgaug_rows:
             rows = [[0] * 8] * 3
-        if not self.use_imgaug and random.random() < self.transform_probability:
-            if self.crop_always or random.random() <= 0.5:
-                crop_ratio = random.uniform(self.min_crop_ratio, self.max_crop_ratio)
-                image = random_crop(image, tuple([int(size * crop_ratio) for size in image.shape[-2:]]))
-            image = random_flip(image, x_random=True)
+        rng = self._aug_rng
+        if not self.use_imgaug and rng.random() < self.transform_probability:
+            if self.crop_always or rng.random() <= 0.5:
+                crop_ratio = rng.uniform(self.min_crop_ratio, self.max_crop_ratio)
+                image = random_crop(image, tuple([int(size * crop_ratio) for size in image.shape[-2:]]), rng)
+            image = random_flip(image, x_random=True, rng=rng)
         return (image, rows) if imgaug_rows else image
 
     def _decoded(self, i, imgaug_rows=False):
@@ -168,11 +171,12 @@ class ImageDataset:
         rows = self._imgaug_rows(image.transpose(2, 0, 1))
         if rows is not None:
             return image, rows
-        if not self.use_imgaug and random.random() < self.transform_probability:
-            if self.crop_always or random.random() <= 0.5:
-                crop_ratio = random.uniform(self.min_crop_ratio, self.max_crop_ratio)
-                image = random_crop(image.transpose(2, 0, 1), tuple([int(size * crop_ratio) for size in image.shape[:2]])).transpose(1, 2, 0)
-            image = random_flip(image.transpose(2, 0, 1), x_random=True).transpose(1, 2, 0)
+        rng = self._aug_rng
+        if not self.use_imgaug and rng.random() < self.transform_probability:
+            if self.crop_always or rng.random() <= 0.5:
+                crop_ratio = rng.uniform(self.min_crop_ratio, self.max_crop_ratio)
+                image = random_crop(image.transpose(2, 0, 1), tuple([int(size * crop_ratio) for size in image.shape[:2]]), rng).transpose(1, 2, 0)
+            image = random_flip(image.transpose(2, 0, 1), x_random=True, rng=rng).transpose(1, 2, 0)
         return image, [[0] * 8] * 3
 
     def decode_batch(self, indices, map_fn=map, farm=None):

@@ -63,25 +63,49 @@ def launch_if_parent(script, argv=None, flag='--gpus'):
     env.setdefault('OMP_NUM_THREADS', str(max(1, (os.cpu_count() or n) // n)))
     # the ranks live in a session of their own: a signal that ends the parent (Ctrl-C, a scheduler's SIGTERM, a closed
     # terminal) is passed on to the WHOLE group -- torch.distributed.run and every rank -- so that no rank is left holding a GPU
-    proc = subprocess.Popen(command(os.path.abspath(script), argv, n), env=env, start_new_session=True)
-    got = []
-
-    def forward(signum, frame):
-        got.append(signum)
-        _signal_group(proc, signum)
-
-    for sig in (signal.SIGINT, signal.SIGTERM, signal.SIGHUP):
-        signal.signal(sig, forward)
-    while True:
-        try:
-            rc = proc.wait(timeout=GRACE_SECONDS if got else None)
-            break
-        except subprocess.TimeoutExpired:        # signalled, and the group did not wind down in time
-            _signal_group(proc, signal.SIGKILL)
+    rc, got = run_group(command(os.path.abspath(script), argv, n), env)
     sys.stdout.flush()
     if got:
         sys.exit(128 + got[0])
     sys.exit(rc if rc >= 0 else 128 - rc)
+
+
+def run_group(cmd, env=None, grace_seconds=None):
+    """Run ``cmd`` as a process group of its own and wait for it.  SIGINT / SIGTERM / SIGHUP that reach THIS process are passed
+    on to the whole group; a group that has not wound down ``grace_seconds`` after the first signal (a rank hung in a
+    collective, a child that ignores SIGTERM) gets SIGKILL.  Returns (exit code, [signals received]).
+
+    The handlers are in place BEFORE the child exists and only record the signal: with them installed after Popen a signal
+    in between killed the parent and orphaned the new session; and a handler that signals from inside a blocking
+    ``proc.wait()`` never gets the wait re-entered with a timeout (PEP 475 retries waitpid), so the grace period never ran.
+    The wait is a short poll instead, and everything -- forwarding, the clock, the escalation -- happens in this loop."""
+    import time
+    grace = GRACE_SECONDS if grace_seconds is None else grace_seconds
+    got = []
+    sigs = (signal.SIGINT, signal.SIGTERM, signal.SIGHUP)
+    old = {sig: signal.signal(sig, lambda signum, frame: got.append(signum)) for sig in sigs}
+    try:
+        proc = subprocess.Popen(cmd, env=env, start_new_session=True)
+        forwarded, t_first, killed = 0, None, False
+        while True:
+            try:
+                rc = proc.wait(timeout=0.2)
+                break
+            except subprocess.TimeoutExpired:
+                pass
+            while forwarded < len(got):                     # pass on what arrived since the last look
+                _signal_group(proc, got[forwarded])
+                forwarded += 1
+                t_first = t_first if t_first is not None else time.monotonic()
+            if t_first is not None and not killed and time.monotonic() - t_first > grace:
+                _signal_group(proc, signal.SIGKILL)         # signalled, and the group did not wind down in time
+                killed = True
+        if got:
+            _signal_group(proc, signal.SIGKILL)             # the leader is gone: no member of its group may outlive the launch
+    finally:
+        for sig, handler in old.items():
+            signal.signal(sig, handler)
+    return rc, got
 
 
 GRACE_SECONDS = 15.0

@@ -1332,18 +1332,25 @@ class _WeightPrep:
         self.dirty = False
         self.live = False          # inside a step whose begin_step prepared everything registered so far
         self.prepared = set()      # keys filled by this step's batch launch
-        self.shadow_ok = set()     # ids of arenas whose bf16 shadow was cast by this step's begin_step
+        self.shadow_ok = {}        # id(arena) -> floats of its bf16 shadow cast by THIS step's begin_step
         self.step = 0
+        # a captured hipGraph has the job table's address and every destination buffer of its entries baked into its
+        # loans_repack_dgrad_batch launch; replays refresh neither `used` nor `step`.  Tables and keys that were current during a
+        # capture are therefore kept for good: never freed by a rebuild (an eager step of another shape adds entries and makes
+        # a NEW table), never evicted as stale.
+        self.captured_tables, self.captured_keys = [], set()
 
     def begin(self, device):
         lib = _lib.load()
         st = _stream()
-        self.prepared, self.shadow_ok = set(), set()
+        self.prepared, self.shadow_ok = set(), {}
         self.live = True
         self.step += 1
+        capturing = torch.cuda.is_current_stream_capturing()
         # entries no step has asked for lately belong to a model or a batch shape that is gone: dropped with their buffers
-        stale = [k for k in self.order if self.repacks[k]['used'] < self.step - 2]
-        if stale and not torch.cuda.is_current_stream_capturing():
+        # (never the entries a captured graph writes to)
+        stale = [k for k in self.order if self.repacks[k]['used'] < self.step - 2 and k not in self.captured_keys]
+        if stale and not capturing:
             for k in stale:
                 del self.repacks[k]
             self.order = [k for k in self.order if k in self.repacks]
@@ -1354,11 +1361,14 @@ class _WeightPrep:
                 if arena is None:
                     self.arenas.remove(ref)
                     continue
-                n = (arena.active_numel + 3) // 4 * 4
+                # the WHOLE arena, not the active prefix: the prefix this step will use is only set later (the localizer's
+                # __call__ looks at the frame height), so a step whose frames cross 224 / 300 px would read res6 / res7 -- or
+                # Chainer's fc6 -- from a shadow that last step's shorter cast never wrote.  36 M floats:
+                # 40 us.  _bf16_shadow checks every view against the length recorded here.
                 if getattr(arena, 'data16', None) is None:
                     arena.data16 = torch.empty(arena.numel, device=arena.device, dtype=BF16)
-                check(lib.loans_cast_bf16(_ptr(arena.data), _ptr(arena.data16), min(n, arena.numel), st), 'loans_cast_bf16')
-                self.shadow_ok.add(id(arena))
+                check(lib.loans_cast_bf16(_ptr(arena.data), _ptr(arena.data16), arena.numel, st), 'loans_cast_bf16')
+                self.shadow_ok[id(arena)] = arena.numel
         if not self.order:
             self.dirty = False
             return
@@ -1372,11 +1382,14 @@ class _WeightPrep:
                     tile += job.tiles_co * job.tiles_ci * job.ntaps
                     i += 1
             raw = np.frombuffer(bytes(jobs), dtype=np.uint8).copy()
-            if torch.cuda.is_current_stream_capturing():
+            if capturing:
                 raise RuntimeError('the weight-preparation table changed inside a captured step')
             self.table_host = torch.from_numpy(raw)
             self.table = self.table_host.to(device)
             self.njobs, self.total_tiles, self.dirty = i, tile, False
+        if capturing and not any(t is self.table for t in self.captured_tables):
+            self.captured_tables.append(self.table)
+            self.captured_keys.update(self.order)
         check(lib.loans_repack_dgrad_batch(_ptr(self.table), self.njobs, self.total_tiles, st), 'loans_repack_dgrad_batch')
         self.prepared = set(self.order)
 
@@ -1401,11 +1414,12 @@ def _bf16_shadow(w):
     ptr = w.data_ptr()
     for ref in wp.arenas:
         arena = ref()
-        if arena is None or id(arena) not in wp.shadow_ok:
+        cast = wp.shadow_ok.get(id(arena)) if arena is not None else None
+        if cast is None:
             continue
         base = arena.data.data_ptr()
         off = ptr - base
-        if 0 <= off and off + w.numel() * 4 <= arena.active_numel * 4 and off % 4 == 0 and w.is_contiguous():
+        if 0 <= off and off // 4 + w.numel() <= cast and off % 4 == 0 and w.is_contiguous():
             return arena.data16[off // 4:off // 4 + w.numel()].view(w.shape)
     return None
 

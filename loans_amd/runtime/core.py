@@ -166,6 +166,10 @@ class Variable:
                     push(x.creator)
                 else:
                     x.grad = grads[id(x)]
+        if retain_grad:     # Chainer's backward(retain_grad=True): intermediate variables keep the gradient that reached them
+            for i, v in keep.items():
+                if i in grads:
+                    v.grad = grads[i]
 
 
 def as_variable(x):

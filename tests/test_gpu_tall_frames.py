@@ -2,6 +2,19 @@
 fp64 oracle: every localizer gradient (res6 / res7 included) before Adam, then one whole `update_core` -- res6 / res7 move,
 the arena's active prefix is the whole arena, Adam-AMSGrad lands where the oracle's does.
 
+How the comparison is cut (round 4).  The gradient of a bilinear sampler with respect to its grid is DISCONTINUOUS in theta:
+a sample point that crosses a pixel boundary switches to another pair of pixels, and on frames with pixel-scale texture that
+changes its term by O(1).  At 320 x 304 px a theta that differs in its sixth digit (fp32 against fp64: 1.7e-6 here) moves the
+560 x 3 sample points of a crop by 3e-4 px, one or two of them cross a boundary, and d loss / d theta -- hence EVERY backbone
+gradient, which is linear in it -- differs by 3e-3 .. 4e-2: the fp32 ORACLE is that far from the fp64 one
+(measured, `worst32` below).  That is a property of the operator, not of an implementation.  So the chain is compared in
+three links, each on identical inputs, each to a tolerance that means something:
+  1. sampler + regularisers: the oracle's backward evaluated AT THE HIP GRID (same sample points) from the HIP crop gradient
+     -> d loss / d points to 1e-4, d loss / d theta to 1e-4;
+  2. backbone incl. res6 / res7: the oracle's backward started from the HIP d loss / d theta -> every parameter gradient to
+     1e-3 (the fp32 oracle itself: 1e-5, measured on the CPU);
+  3. the free-running gradients, for the record, within 10 x the fp32 oracle's own distance from the fp64 one.
+
 PARITY UNPINNED: the oracle is this repo's restatement of Chainer's arithmetic, the reference holds no vectors.
 """
 import numpy as np
@@ -16,7 +29,13 @@ from tests.test_gpu_model import _updater
 pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures('kernel_selection')]
 
 
+def _stage_of(key):
+    key = key.lstrip('/')
+    return key.split('/')[0] if key.startswith('res') else (key.split('/')[1] if '/res' in key else 'head / stem')
+
+
 def test_res6_res7_gradients_and_update_parity(deterministic_forward):
+    from oracle import chainer_ops as C
     B, H, W, crop = 3, 320, 304, (20, 28)
     loc, dis = build_pair(41, crop)
     frames, real, labels = inputs(42, B, H, W, crop)
@@ -26,6 +45,7 @@ def test_res6_res7_gradients_and_update_parity(deterministic_forward):
     lp, dp = oracle_params(loc, np.float64), oracle_params(dis, np.float64)
     lp32, dp32 = oracle_params(loc, np.float32), oracle_params(dis, np.float32)
     lp0 = {k: v.copy() for k, v in lp.items()}
+    dp0 = {k: v.copy() for k, v in dp.items()}
 
     f64 = [a.astype(np.float64) for a in (frames, real, labels)]
     res = M.update_core(lp, dp, M.AdamAMSGrad(lp), M.AdamAMSGrad(dp), f64[0], f64[1], f64[2], crop,
@@ -34,9 +54,10 @@ def test_res6_res7_gradients_and_update_parity(deterministic_forward):
                         rng=np.random.RandomState(0), return_grads=True)
     assert any(k.startswith('res7/') for k in res['loc_grads']) and any(k.startswith('res6/') for k in res['loc_grads'])
 
-    # ---- 1. the localizer chain's gradients, before Adam (the first half of update_core by hand) ----
+    # ---- the localizer chain's gradients, before Adam (the first half of update_core by hand) ----
     x_fake, bboxes = loc(dev(frames))
     assert loc.arena.active_numel == loc.arena.numel            # res6 and res7 are inside the active prefix
+    theta = loc.last_transform_params
     y_fake = dis(x_fake)
     loss = loans_amd.functions.mean_squared_error(y_fake, torch.full((B, 1), 1.0, device='cuda'))
     size = loans_amd.Size(H, W)
@@ -44,64 +65,98 @@ def test_res6_res7_gradients_and_update_parity(deterministic_forward):
     loss = loss + loans_amd.OutOfImageLossCalculator(torch).calc_loss(bboxes, size)
     dis.disable_update()
     loc.cleargrads()
-    loss.backward()
+    loss.backward(retain_grad=True)                             # Chainer's switch: x_fake, bboxes, theta keep their gradients
     dis.enable_update()
     np.testing.assert_allclose(float(loss.data), res['loss_localizer'], rtol=1e-4)
-    # res7's BNs normalise over B x 3 x 3 = 27 samples per channel: ill-conditioned in fp32 for ANY implementation -- a last-bit
-    # difference in the forward comes back 1e4 times larger in the gradients of every stage below.  How ill-conditioned, the
-    # fp32 ORACLE's own distance from the fp64 one says (e32); the bound follows it where it exceeds the 1e-3 of the 64 x 64
-    # test.  Per STAGE, not per tensor: e and e32 are two draws of the same rounding noise, and one tensor's e32 happening to
-    # come out small says nothing about the conditioning of the 15-odd tensors of its stage (round 4: with another, equally
-    # valid, tile for conv1 res4/1/bn2/beta read e = 1.4e-2 against its own e32 = 1.4e-3 while res4's largest e32 was higher).
-    stage_of = lambda key: (key.split('/')[1] if key.startswith('/res') else key.split('/')[2] if 'res' in key else 'head')   # noqa: E731
-    worst, worst32, errs = {}, {}, {}
+    np.testing.assert_allclose(theta.data.cpu().numpy(), res['theta'], atol=1e-4)
+    np.testing.assert_allclose(x_fake.data.cpu().numpy(), res['rois'], atol=5e-4)        # theta's 1e-6 x 160 px x image slopes
+
+    # ---- 1. sampler backward + regularisers + grid backward on the HIP sample points ----
+    pts = bboxes.data.cpu().numpy().astype(np.float64)
+    g_rois = x_fake.grad.cpu().numpy().astype(np.float64)
+    assert g_rois.shape == (B, 3) + crop and np.abs(g_rois).max() > 0
+    g_pts_ref = C.st_sampler_bwd_grid(f64[0], pts, g_rois) + C.direction_loss(pts, (H, W))[1] + C.out_of_image_loss(pts)[1]
+    e_pts = rel_err(bboxes.grad.cpu().numpy(), g_pts_ref)
+    _, coords = C.st_grid_fwd(res['theta'], crop)
+    g_theta_hip = theta.grad.cpu().numpy().astype(np.float64)
+    e_theta = rel_err(g_theta_hip, C.st_grid_bwd(coords, g_pts_ref))
+    # the assessor's data gradient down to the crops (its inputs differ by the 5e-4 above: ReLU masks of a few elements)
+    oracle_dis = M.Assessor(dp0)
+    y_o = oracle_dis.forward(x_fake.data.cpu().numpy().astype(np.float64))
+    e_rois = rel_err(g_rois, oracle_dis.backward(C.mse_bwd(y_o, np.ones_like(y_o)), None, need_gx=True))
+    print('d loss / d rois %.2e, d loss / d points %.2e, d loss / d theta %.2e (oracle evaluated on the HIP tensors)' % (e_rois, e_pts, e_theta))
+    assert e_rois < 1e-4 and e_pts < 1e-4 and e_theta < 1e-4
+
+    # ---- 2. the backbone, res6 / res7 included, from the HIP d loss / d theta ----
+    oloc = M.Localizer(lp0, crop, train=True, rng=np.random.RandomState(0))
+    oloc.forward(f64[0])
+    forced = {}
+    gpooled, gW, gb = C.linear_bwd(oloc.pooled, lp0['param_predictor/W'], (g_theta_hip * oloc.mask).reshape(-1, 6), True)
+    forced['param_predictor/W'], forced['param_predictor/b'] = gW, gb
+    g = C.gap_bwd(oloc.feat.shape, gpooled)
+    for blk in reversed(oloc.blocks):
+        g = blk.bwd(g, forced)
+    g = C.max_pool_bwd(oloc.stem_relu.shape, oloc.pool_idx, g, 3, 2, 0) * (oloc.stem_relu > 0)
+    oloc.stem.bwd(g, forced, need_gx=False)
+    worst_forced, worst, worst32, errs = {}, {}, {}, {}
     for key, p in loc.namedparams():
         ref = res['loc_grads'].get(key[1:])
-        assert ref is not None, key                              # at this height every parameter has a gradient
+        assert ref is not None and key[1:] in forced, key        # at this height every parameter has a gradient
         if key == '/feature_extractor/conv1/b':
             continue                                             # analytically zero (BN follows): rounding noise
+        st = _stage_of(key)
+        e = rel_err(p.grad_logical(), forced[key[1:]])
+        worst_forced[st] = max(worst_forced.get(st, 0.0), e)
+        assert e < 1e-3, (key, e)
         errs[key] = rel_err(p.grad_logical(), ref)
-        e32 = rel_err(r32['loc_grads'][key[1:]], ref)            # the fp32 ORACLE's own distance from fp64 on this tensor
-        worst[stage_of(key)] = max(worst.get(stage_of(key), 0.0), errs[key])
-        worst32[stage_of(key)] = max(worst32.get(stage_of(key), 0.0), e32)
-    print('fp32 oracle vs fp64 oracle, worst per stage:    ', {k: '%.2e' % v for k, v in sorted(worst32.items())})
-    for key, e in errs.items():
-        assert e < max(1e-3, 10 * worst32[stage_of(key)]), (key, e, worst32[stage_of(key)])
-    print('worst relative gradient error per stage:', {k: '%.2e' % v for k, v in sorted(worst.items())})
-    assert 'res6' in worst and 'res7' in worst
+        worst[st] = max(worst.get(st, 0.0), errs[key])
+        worst32[st] = max(worst32.get(st, 0.0), rel_err(r32['loc_grads'][key[1:]], ref))
+    print('from the HIP d loss / d theta, worst per stage:    ', {k: '%.2e' % v for k, v in sorted(worst_forced.items())})
+    assert 'res6' in worst_forced and 'res7' in worst_forced
 
-    # ---- 2. one whole update_core from the same initial state ----
+    # ---- 3. free-running, for the record: within 10 x what the fp32 oracle is from the fp64 one (all of it the sampler's) ----
+    print('free-running against the fp64 oracle, per stage:   ', {k: '%.2e' % v for k, v in sorted(worst.items())})
+    print('fp32 oracle against the fp64 oracle, per stage:    ', {k: '%.2e' % v for k, v in sorted(worst32.items())})
+    drift = max(worst32.values())
+    for key, e in errs.items():
+        assert e < max(1e-3, 10 * drift), (key, e, drift)
+
+    # ---- 4. one whole update_core from the same initial state ----
     for _, link, n in loc.namedpersistents():                    # undo the running-statistics update of the pass above
         v = getattr(link, n)
         if torch.is_tensor(v):
             v.fill_(1.0 if n == 'avg_var' else 0.0)
     upd = _updater(loc, dis, frames, real, labels)
+    seen = {}
+
+    def keep_gradients(opt):                                     # Chainer's optimiser hook: after the backward, before the step
+        seen.update({k[1:]: p.grad_logical().copy() for k, p in opt.target.namedparams()})
+    upd.get_optimizer('opt_gen').add_hook(keep_gradients)
+    upd.get_optimizer('opt_dis').add_hook(keep_gradients)
     upd.update()
     obs = loans_amd.reporter.observation
     np.testing.assert_allclose(float(obs['loss_localizer']), res['loss_localizer'], rtol=1e-4, atol=1e-6)
     np.testing.assert_allclose(float(obs['loss_dis']), res['loss_dis'], rtol=1e-4, atol=1e-6)
-    new_loc = loc.state_dict_chainer()
+    new_loc, new_dis = loc.state_dict_chainer(), dis.state_dict_chainer()
     moved = {'res6': 0.0, 'res7': 0.0}
-    for key in lp:
-        if not M.is_trainable(key) or key == 'feature_extractor/conv1/b':
-            continue
-        d = np.abs(new_loc[key] - lp[key])
-        # Adam is sign-like on step 1 (|update| ~ lr whatever the gradient's size): entries whose gradient is rounding noise may
-        # flip sign -- never more than ~2 lr apart, off by more than 5 % of lr on at most 0.2 % of the entries (the criterion of
-        # test_update_core_gradients_and_parameters_parity)
-        assert d.max() < 2.1e-3, key
-        # ... or as many as the fp32 ORACLE itself flips against the fp64 one on this tensor
-        # (lp32 was stepped by r32 above); a 64-entry BN vector may hold one such entry
-        n32 = int(np.sum(np.abs(lp32[key].astype(np.float64) - lp[key]) > 5e-5))
-        assert np.sum(d > 5e-5) <= max(2e-3 * d.size, 3 * n32, 2), (key, int(np.sum(d > 5e-5)), n32, d.size)
-        for st in moved:
-            if key.startswith(st + '/'):
-                moved[st] = max(moved[st], float(np.abs(new_loc[key] - lp0[key]).max()))
+    # Adam-AMSGrad with Chainer's eps placement, applied by the ORACLE to the gradients the HIP step produced: on step 1 the
+    # update is lr * g / (|g| + eps') -- sign-like, so parameters are only comparable for equal gradients -- and the fused
+    # kernel must land within fp32 rounding of it on every float of both arenas, the cold stages included
+    for new, start in ((new_loc, lp0), (new_dis, dp0)):
+        for key, p0 in start.items():
+            if not M.is_trainable(key):
+                continue
+            want = p0.copy()
+            C.adam_amsgrad_update(want, seen[key].astype(np.float64), np.zeros_like(want), np.zeros_like(want), np.zeros_like(want), 1)
+            np.testing.assert_allclose(new[key], want, rtol=0, atol=2e-6, err_msg=key)
+            for st in moved:
+                if key.startswith(st + '/'):
+                    moved[st] = max(moved[st], float(np.abs(new[key] - p0).max()))
     assert moved['res6'] > 5e-4 and moved['res7'] > 5e-4, moved   # both cold stages were trained (~lr per entry)
-    new_dis = dis.state_dict_chainer()
-    for key in dp:
-        d = np.abs(new_dis[key] - dp[key])
-        assert np.mean(d > 5e-5) < 2e-3, (key, np.mean(d > 5e-5))
+    # and against the free-running oracle step: no entry further than Adam's two steps of lr apart
+    for key in lp:
+        if M.is_trainable(key) and key != 'feature_extractor/conv1/b':
+            assert np.abs(new_loc[key] - lp[key]).max() < 2.1e-3, key
     # BN running statistics of the cold stages moved as the oracle's did
     for k in ('res6/0/bn1/avg_mean', 'res7/1/bn2/avg_var'):
         np.testing.assert_allclose(new_loc[k], lp[k], rtol=1e-3, atol=1e-5)

@@ -114,3 +114,49 @@ def test_sigterm_to_the_parent_ends_every_rank():
         for k in psutil.Process().children(recursive=True):
             if 'bench.py' in ' '.join(k.cmdline()):
                 k.kill()
+
+
+def test_a_child_that_ignores_sigterm_is_killed_after_the_grace_period():
+    """ADVICE (round 3): the SIGKILL escalation never ran -- the wait was entered without a timeout and, after the handler had
+    run, silently re-entered without one.  A child that ignores SIGTERM (a rank hung in a collective behaves the same) must be
+    gone `grace_seconds` after the signal, and the launcher must report the kill."""
+    import signal
+    import time
+    child = "import signal, time; signal.signal(signal.SIGTERM, signal.SIG_IGN); print('up', flush=True); time.sleep(600)"
+    parent = ("import sys; sys.path.insert(0, %r); from loans_amd import launch; "
+              "rc, got = launch.run_group([sys.executable, '-c', %r], grace_seconds=1.0); print('rc', rc, 'got', got, flush=True)"
+              % (ROOT, child))
+    p = subprocess.Popen([sys.executable, '-c', parent], stdout=subprocess.PIPE, text=True)
+    try:
+        assert p.stdout.readline().strip() == 'up'
+        t0 = time.time()
+        p.send_signal(signal.SIGTERM)
+        out, _ = p.communicate(timeout=30)
+        assert time.time() - t0 < 10, 'the grace period did not end the child'
+        assert out.strip() == 'rc %d got [%d]' % (-signal.SIGKILL, signal.SIGTERM), out
+    finally:
+        if p.poll() is None:
+            p.kill()
+
+
+def test_a_signal_between_handler_setup_and_child_start_is_not_lost():
+    """the handlers exist before the child does: a signal recorded while Popen is still running is forwarded on the first turn
+    of the wait loop (the child below exits 0 on SIGTERM; without the forward it would sleep its 600 s)"""
+    import signal
+    import time
+    from loans_amd import launch
+    child = "import signal, sys, time; signal.signal(signal.SIGTERM, lambda *a: sys.exit(0)); time.sleep(600)"
+    real_popen = subprocess.Popen
+
+    def popen_then_signal(*a, **kw):
+        proc = real_popen(*a, **kw)
+        time.sleep(1.0)                                   # let the child install its handler
+        os.kill(os.getpid(), signal.SIGTERM)              # arrives "during Popen": only recorded
+        return proc
+    launch.subprocess.Popen, saved = popen_then_signal, launch.subprocess.Popen
+    try:
+        t0 = time.time()
+        rc, got = launch.run_group([sys.executable, '-c', child], grace_seconds=20.0)
+    finally:
+        launch.subprocess.Popen = saved
+    assert got == [signal.SIGTERM] and rc == 0 and time.time() - t0 < 15

@@ -5,6 +5,7 @@
 ``MultithreadIterator`` that feeds the loop: pooled decode, SerialIterator's order and epoch bookkeeping."""
 import random
 
+import pytest
 import numpy as np
 
 from tests._input_files import write_files
@@ -68,7 +69,7 @@ def test_multithread_iterator_is_serial_iterator_with_a_pool(tmp_path):
         random.seed(3)
         it = training.SerialIterator(a, 4, shuffle=True, seed=9)
         want = [(np.stack(next(it)), it.epoch, it.is_new_epoch, it.epoch_detail) for _ in range(6)]
-        random.seed(3)          # the naive branch draws from the global stream (reference :86-90)
+        random.seed(4)          # ... and the global stream does not matter: both branches draw from the dataset's own
         mt = training.MultithreadIterator(b, 4, shuffle=True, seed=9, n_threads=3, n_prefetch=1)
         for ref_batch, epoch, new, detail in want:
             got = np.stack(next(mt))
@@ -127,3 +128,72 @@ def test_decode_farm_gives_the_bytes_of_the_in_process_decode(tmp_path):
                 pass
     finally:
         farm.close()
+
+
+def test_decode_farm_share_larger_than_a_pipe_and_a_dead_worker(tmp_path):
+    """ADVICE (round 3).  (i) A worker's share whose request bytes exceed the stdin pipe (64 KiB: here 120 frames behind a
+    700-character directory name, ~85 KB of paths on ONE worker, with frames larger than the reply pipe) used to deadlock:
+    the parent blocked writing requests while the worker blocked writing frames.  Requests now go out WINDOW at a time.
+    (ii) When one worker dies mid-batch the others' pipes hold unread replies: the farm is rebuilt before the error is raised,
+    and the next batch decodes normally."""
+    import threading
+    from concurrent.futures import ThreadPoolExecutor
+    from PIL import Image
+    from loans_amd.common.datasets.decode_farm import DecodeFarm
+    deep = tmp_path
+    for part in ('d' * 230, 'e' * 230, 'f' * 230):
+        deep = deep / part
+    deep.mkdir(parents=True)
+    rng = np.random.RandomState(1)
+    frames = [rng.randint(0, 256, (300, 400, 3)).astype(np.uint8) for _ in range(3)]          # 360 KB each
+    for i, f in enumerate(frames):
+        Image.fromarray(f).save(str(deep / ('%d.png' % i)))
+    paths = [str(deep / ('%d.png' % (i % 3))) for i in range(120)]
+    assert sum(len(p) + 1 for p in paths) > 65536
+    farm = DecodeFarm(1)
+    try:
+        with ThreadPoolExecutor(2) as pool:
+            result = []
+            t = threading.Thread(target=lambda: result.append(farm.decode(paths, pool.map)), daemon=True)
+            t.start()
+            t.join(120)
+            assert not t.is_alive(), 'the farm deadlocked on a share larger than its request pipe'
+            assert len(result[0]) == 120 and all((a == frames[i % 3]).all() for i, a in enumerate(result[0]))
+    finally:
+        farm.close()
+    farm = DecodeFarm(2)
+    try:
+        with ThreadPoolExecutor(2) as pool:
+            old = list(farm.procs)
+            old[1].kill()
+            old[1].wait()
+            with pytest.raises(RuntimeError, match='decode worker 1 died'):
+                farm.decode(paths[:6], pool.map)
+            assert len(farm.procs) == 2 and not any(p in old for p in farm.procs)               # a new farm
+            got = farm.decode(paths[:6], pool.map)
+            assert all((a == frames[i % 3]).all() for i, a in enumerate(got))
+    finally:
+        farm.close()
+
+
+def test_two_iterators_on_threads_do_not_share_a_random_stream(tmp_path):
+    """ADVICE (round 3): with --no-imgaug the train and the reference iterator each prepare batches on a producer thread of their
+    own; drawing from the global `random` module they interleaved on one stream in thread-timing order.  Each dataset now owns
+    its stream: two iterators running side by side give what each gives alone."""
+    from loans_amd.common.datasets.image_dataset import ImageDataset
+    from loans_amd.runtime import training
+    train, _, _ = write_files(tmp_path)
+    mk = lambda seed: ImageDataset(train, str(tmp_path), image_size=(40, 40), use_imgaug=False,      # noqa: E731
+                                   transform_probability=0.9, augment_seed=seed)
+    alone = []
+    for seed in (1, 2):
+        it = training.SerialIterator(mk(seed), 4, shuffle=True, seed=seed)
+        alone.append([np.stack(next(it)) for _ in range(5)])
+    its = [training.MultithreadIterator(mk(seed), 4, shuffle=True, seed=seed, n_threads=2, n_prefetch=3) for seed in (1, 2)]
+    try:
+        for k in range(5):
+            for it, want in zip(its, alone):
+                np.testing.assert_array_equal(np.stack(next(it)), want[k])
+    finally:
+        for it in its:
+            it.finalize()
