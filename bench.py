@@ -81,9 +81,10 @@ def parse():
                          "profiles/<tag>_<b256|cfg3|r50>_conv_fwd_hbm_traffic.json of the newest committed round for those workloads")
     ap.add_argument('--no-secondary', action='store_true',
                     help="only the primary leg (the rocprofv3 passes of tools/profile_round.sh profile one workload per command)")
-    ap.add_argument('--secondary', default='cfg3,r50',
+    ap.add_argument('--secondary', default='cfg3,r50,b16',
                     help="secondary legs run after the default primary workload at N = 1: cfg3 = configs[2] (bf16, 128 x 3 x 512 x 512), "
-                         "r50 = one GPU's share of configs[4] (ResNet-50 localizer, bf16, 64 x 3 x 512 x 512)")
+                         "r50 = one GPU's share of configs[4] (ResNet-50 localizer, bf16, 64 x 3 x 512 x 512), b16 = the reference's "
+                         "own default batch (-b 16, 224 x 224, fp32: the launch-bound regime), eager and as a hipGraph")
     ap.add_argument('--secondary-steps', type=int, default=10)
     ap.add_argument('--secondary-warmup', type=int, default=3)
     ap.add_argument('--secondary-shape', default=None,
@@ -161,7 +162,7 @@ def dry_run(args):
     parallel.shutdown()
 
 
-PROFILE_TAGS = ('r3', 'r2')          # newest first: the committed rocprofv3 evidence a default workload is tied to
+PROFILE_TAGS = ('r4', 'r3', 'r2')          # newest first: the committed rocprofv3 evidence a default workload is tied to
 
 # The workloads with committed evidence under profiles/ (<tag>_<name>_tune.json = the tile table the timed run, the kernel trace
 # and the PMC passes of tools/profile_round.sh all ran on; <tag>_<name>_conv_fwd_hbm_traffic.json = the PMC bytes)
@@ -436,19 +437,29 @@ def run_workload(w, comm, local_rank, retune):
     }
 
 
+B16_EAGER, B16_GRAPH = "reference default (-b 16, 224 x 224), eager", "reference default (-b 16, 224 x 224), hipGraph"
+
+
 def secondary_legs(args):
     """The other single-GPU configurations of BASELINE.json, measured in the same process after the primary leg so that the
     driver's one bench line carries them: configs[2] (bf16 joint step, 128 x 3 x 512 x 512) and one GPU's share of configs[4]
     (ResNet-50 localizer, bf16, 64 x 3 x 512 x 512).  --secondary-shape B,HW shrinks both (schema tests on tiny shapes)."""
-    legs = [("configs[2]", dict(image_size=512, batch=128, dtype='bf16', storage='bf16', resnet50=False)),
-            ("configs[4] per GPU", dict(image_size=512, batch=64, dtype='bf16', storage='bf16', resnet50=True))]
+    legs = [("configs[2]", 'cfg3', dict(image_size=512, batch=128, dtype='bf16', storage='bf16', resnet50=False)),
+            ("configs[4] per GPU", 'r50', dict(image_size=512, batch=64, dtype='bf16', storage='bf16', resnet50=True)),
+            # the reference's own defaults (train_sheep_localizer.py:56-58: -b 16, 224 x 224, crop 75 x 75): ~600 launches of a
+            # few microseconds each -- the regime a captured step is for
+            (B16_EAGER, 'b16', dict(image_size=224, batch=16, dtype='f32', storage='f32', resnet50=False, graph=False)),
+            (B16_GRAPH, 'b16', dict(image_size=224, batch=16, dtype='f32', storage='f32', resnet50=False, graph=True))]
     want = [s for s in args.secondary.split(',') if s]
-    legs = [l for l, key in zip(legs, ('cfg3', 'r50')) if key in want]
-    for _, over in legs:
-        over.update(steps=args.secondary_steps, warmup=args.secondary_warmup, graph=False, tune_file=None, traffic_file=None)
+    legs = [(label, over) for label, key, over in legs if key in want]
+    for label, over in legs:
+        over.setdefault('graph', False)
+        over.update(steps=args.secondary_steps, warmup=args.secondary_warmup, tune_file=None, traffic_file=None)
         if args.secondary_shape:
             b, hw = (int(v) for v in args.secondary_shape.split(','))
             over.update(batch=b, image_size=hw)
+        elif label in (B16_EAGER, B16_GRAPH):
+            over.update(steps=max(30, args.secondary_steps))           # 6 ms steps: 30 of them for a stable figure
     return legs
 
 
@@ -480,6 +491,8 @@ def main():
             leg = run_workload(workload_of(args, **over), comm, local_rank, retune)
             leg["metric"] = "localizer+assessor train images/sec"
             secondary[label] = leg
+        if B16_EAGER in secondary and B16_GRAPH in secondary and rank == 0:
+            secondary[B16_GRAPH]["graph_over_eager"] = round(secondary[B16_GRAPH]["value"] / secondary[B16_EAGER]["value"], 3)
     if rank != 0:
         parallel.shutdown()
         return

@@ -539,6 +539,13 @@ int loans_adam_amsgrad_devlr_f32(float* p, const float* g, float* m, float* v, f
                                  const float* lr_t_dev, double beta1, double beta2, double eps, double eta,
                                  double weight_decay_rate, double grad_scale, void* stream);
 
+/* plain Adam -- chainer.optimizers.Adam's default amsgrad=False (train_sheep_localizer.py:130 passes amsgrad=True; the class
+ * surface takes both): the same update with sqrt(v) in the denominator, no vhat.  lr_t_dev != NULL: the rate is read from
+ * device memory (hipGraph), lr_t is ignored */
+int loans_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, double lr_t, const float* lr_t_dev,
+                   double beta1, double beta2, double eps, double eta, double weight_decay_rate, double grad_scale,
+                   void* stream);
+
 /* ---- input contract on the GPU (common/datasets/image_dataset.py:16-28 `resize_image` -> Pillow
  *      Image.resize(LANCZOS); :98 `image / 255`).  Bit-exact restatement of Pillow's 8-bit two-pass resampler
  *      (libImaging/Resample.c): per output coordinate a window bounds[2*i] = first input index, bounds[2*i+1] = taps, and

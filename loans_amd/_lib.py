@@ -144,6 +144,7 @@ SIGNATURES = {
     'loans_grid_loss_bwd_f32': [_p, _p, _p, _i32, _f32, _f32, _f32, _i32, _i32, _i32, _p],
     'loans_adam_amsgrad_f32': [_p, _p, _p, _p, _p, _i64, _f64, _f64, _f64, _f64, _f64, _f64, _f64, _p],
     'loans_adam_amsgrad_devlr_f32': [_p, _p, _p, _p, _p, _i64, _p, _f64, _f64, _f64, _f64, _f64, _f64, _p],
+    'loans_adam_f32': [_p, _p, _p, _p, _i64, _f64, _p, _f64, _f64, _f64, _f64, _f64, _f64, _p],
 }
 
 _lib = None

@@ -414,23 +414,29 @@ __device__ __forceinline__ void adam1(float& p, float g, float& m, float& v, flo
     p -= h.eta * (h.lr_t * m / (sqrtf(vh) + h.eps) + h.wd * p);
 }
 
+// vh == nullptr: plain Adam (chainer.optimizers.Adam's default amsgrad=False) -- the denominator is sqrt(v) itself
 __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, float* m, float* v, float* vh, int64_t n,
                                                    AdamHyper h, const float* lr_dev) {
     if (lr_dev) h.lr_t = *lr_dev;       // step-dependent rate read from device memory: the launch can live in a hipGraph
+    const bool ams = vh != nullptr;
     const int64_t n4 = n >> 2;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-        f32x4 pp = ld4(p + i * 4), gg = ld4(g + i * 4), mm = ld4(m + i * 4), vv = ld4(v + i * 4), hh = ld4(vh + i * 4);
+        f32x4 pp = ld4(p + i * 4), gg = ld4(g + i * 4), mm = ld4(m + i * 4), vv = ld4(v + i * 4);
+        f32x4 hh = ams ? ld4(vh + i * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float a = pp[e], b = mm[e], c = vv[e], d = hh[e];
-            adam1(a, gg[e], b, c, d, h);
+            adam1(a, gg[e], b, c, d, h);            // v >= 0: with d = 0 the max is v
             pp[e] = a; mm[e] = b; vv[e] = c; hh[e] = d;
         }
-        st4(p + i * 4, pp); st4(m + i * 4, mm); st4(v + i * 4, vv); st4(vh + i * 4, hh);
+        st4(p + i * 4, pp); st4(m + i * 4, mm); st4(v + i * 4, vv);
+        if (ams) st4(vh + i * 4, hh);
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const int64_t i = n4 * 4 + threadIdx.x;
-        adam1(p[i], g[i], m[i], v[i], vh[i], h);
+        float d = ams ? vh[i] : 0.f;
+        adam1(p[i], g[i], m[i], v[i], d, h);
+        if (ams) vh[i] = d;
     }
 }
 
@@ -662,6 +668,19 @@ extern "C" int loans_adam_amsgrad_devlr_f32(float* p, const float* g, float* m, 
     h.eps = (float)eps; h.eta = (float)eta; h.wd = (float)weight_decay_rate; h.gscale = (float)grad_scale;
     hipLaunchKernelGGL(adam_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, as_stream(stream), p, g, m, v, vhat, n, h,
                        lr_t_dev);
+    LOANS_LAUNCH_CHECK();
+    return LOANS_OK;
+}
+
+extern "C" int loans_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, double lr_t, const float* lr_t_dev,
+                              double beta1, double beta2, double eps, double eta, double weight_decay_rate, double grad_scale,
+                              void* stream) {
+    if (!p || !g || !m || !v || n <= 0) return LOANS_EINVAL;
+    AdamHyper h;
+    h.lr_t = (float)lr_t; h.omb1 = (float)(1.0 - beta1); h.omb2 = (float)(1.0 - beta2);
+    h.eps = (float)eps; h.eta = (float)eta; h.wd = (float)weight_decay_rate; h.gscale = (float)grad_scale;
+    hipLaunchKernelGGL(adam_kernel, dim3(grid_for((n + 3) / 4, 256)), dim3(256), 0, as_stream(stream), p, g, m, v, (float*)nullptr, n,
+                       h, lr_t_dev);
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;
 }

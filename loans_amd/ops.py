@@ -1970,7 +1970,16 @@ def grid_loss_bwd(grid, gloss, kind, img_h=0.0, img_w=0.0, oob_scale=1.0):
 
 
 def adam_amsgrad(p, g, m, v, vhat, lr_t, beta1, beta2, eps, eta, weight_decay_rate, grad_scale=1.0):
-    """lr_t: a Python float, or a 1-element device tensor read by the kernel when it runs (graph-capturable)."""
+    """lr_t: a Python float, or a 1-element device tensor read by the kernel when it runs (graph-capturable).
+    vhat=None: plain Adam (amsgrad=False)."""
+    if vhat is None:
+        dev_lr = torch.is_tensor(lr_t)
+        if dev_lr:
+            assert lr_t.dtype == torch.float32 and lr_t.numel() == 1 and lr_t.is_cuda
+        check(_lib.load().loans_adam_f32(_ptr(p), _ptr(g), _ptr(m), _ptr(v), p.numel(), 0.0 if dev_lr else lr_t,
+                                         _ptr(lr_t) if dev_lr else 0, beta1, beta2, eps, eta, weight_decay_rate, grad_scale,
+                                         _stream()), 'loans_adam_f32')
+        return
     if torch.is_tensor(lr_t):
         assert lr_t.dtype == torch.float32 and lr_t.numel() == 1 and lr_t.is_cuda
         check(_lib.load().loans_adam_amsgrad_devlr_f32(_ptr(p), _ptr(g), _ptr(m), _ptr(v), _ptr(vhat), p.numel(), _ptr(lr_t),

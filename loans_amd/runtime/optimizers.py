@@ -20,8 +20,6 @@ from .. import ops
 class Adam:
 
     def __init__(self, alpha=0.001, beta1=0.9, beta2=0.999, eps=1e-8, eta=1.0, weight_decay_rate=0, amsgrad=False):
-        if not amsgrad:
-            raise NotImplementedError("the LoANs trainer only uses amsgrad=True")
         self.hyperparam = SimpleNamespace(alpha=alpha, beta1=beta1, beta2=beta2, eps=eps, eta=eta,
                                           weight_decay_rate=weight_decay_rate, amsgrad=amsgrad)
         self.t = 0
@@ -81,7 +79,12 @@ class Adam:
 
     def update(self, lossfun=None, *args, **kwds):
         if lossfun is not None:
-            raise NotImplementedError("update(lossfun) is not used by the LoANs updater")
+            # chainer.GradientMethod.update(lossfun, *args): evaluate, clear, differentiate, then the step below
+            # (the LoANs updater calls update() bare, sheep_updater.py:52,66)
+            loss = lossfun(*args, **kwds)
+            self.target.cleargrads()
+            loss.backward()
+            del loss
         if not any(p.update_rule.enabled for p in self.target.params()):
             return
         arena = self._ensure_state()
@@ -127,7 +130,7 @@ class Adam:
         else:
             self.t += 1
             lr = self.lr
-        ops.adam_amsgrad(arena.data[:n], arena.grad[:n], m[:n], v[:n], vhat[:n], lr, hp.beta1, hp.beta2,
+        ops.adam_amsgrad(arena.data[:n], arena.grad[:n], m[:n], v[:n], vhat[:n] if hp.amsgrad else None, lr, hp.beta1, hp.beta2,
                          hp.eps, hp.eta, hp.weight_decay_rate, grad_scale)
 
     def _exchange_active(self):
@@ -175,6 +178,14 @@ class Adam:
         if not self._exchange_active():
             return
         self._exchange(self._ensure_state(), 0)
+
+    def exchange_wait(self):
+        """Make the current stream wait for every exchange started so far and forget them -- for a caller that applies the
+        step itself (the captured update of a data-parallel hipGraph, sheep_updater._capture_segments: the graph recorded
+        "already exchanged", so nothing inside it waits)."""
+        for work in self._pending:
+            work.wait()
+        self._pending, self._exchanged_from = [], None
 
     def prepare_capture(self):
         """Allocate what a captured update reads at replay time -- outside the capture, so that neither the buffer nor

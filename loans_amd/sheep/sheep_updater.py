@@ -55,6 +55,7 @@ class SheepAssessor(training.StandardUpdater):
         self.use_graph = kwargs.pop('use_graph', False)
         self.graph_warmup = kwargs.pop('graph_warmup', 2)
         self._graph = None
+        self._segment_split = None      # set while a data-parallel step is being captured in two segments (_capture_segments)
 
         super().__init__(*args, **kwargs)
 
@@ -70,10 +71,21 @@ class SheepAssessor(training.StandardUpdater):
             real_images, labels = self.converter(batch, self.device)[:2]
             batch = next(self.get_iterator('main'))
             fake_images = self.converter(batch, self.device)
-            if self.use_graph and not (self.comm is not None and getattr(self.comm, 'active', False)):
+            if self.use_graph and self._graph_legal():
                 self._graph_step(real_images, labels, fake_images)
             else:
                 self._step(real_images, labels, fake_images)
+
+    def _dist_active(self):
+        return self.comm is not None and getattr(self.comm, 'active', False)
+
+    def _graph_legal(self):
+        """A single process captures any schedule.  Under data parallel the step is captured in TWO segments with the gradient
+        exchange between them (`_capture_segments`), which needs both backward chains complete at one point of the schedule:
+        the concurrent chains (the default) or a frozen assessor."""
+        if not self._dist_active():
+            return True
+        return self.freeze_discriminator or (CONCURRENT_CHAINS and ops.CAPTURE_STREAMS and not EARLY_CHAIN)
 
     def _graph_step(self, real_images, labels, fake_images):
         """Eager for the first iterations (tile autotuning, lazy links, first-launch attributes), then capture the step on
@@ -89,20 +101,64 @@ class SheepAssessor(training.StandardUpdater):
                 opt.prepare_capture()
             ops.join_side_stream()
             torch.cuda.synchronize()
-            graph = torch.cuda.CUDAGraph()
             before = dict(reporter.observation)
-            with torch.cuda.graph(graph):
-                self._step(*static)
+            if self._dist_active():
+                graphs = self._capture_segments(static)
+            else:
+                graphs = [torch.cuda.CUDAGraph()]
+                with torch.cuda.graph(graphs[0]):
+                    self._step(*static)
             obs = {k: v for k, v in reporter.observation.items() if before.get(k) is not v}
-            g = self._graph = {'graph': graph, 'static': static, 'obs': obs, 'shapes': [tuple(t.shape) for t in static]}
+            g = self._graph = {'graphs': graphs, 'static': static, 'obs': obs, 'shapes': [tuple(t.shape) for t in static]}
         if [tuple(t.shape) for t in ins] != g['shapes']:
             return self._step(real_images, labels, fake_images)
         for s, t in zip(g['static'], ins):
             s.copy_(t, non_blocking=True)
+        opts = self._exchanging_optimizers() if len(g['graphs']) > 1 else []
+        g['graphs'][0].replay()                 # single process: the whole step; data parallel: everything up to both backwards
+        for opt in opts:
+            opt.update_begin()                  # the whole active prefix of each gradient arena, RCCL beside RCCL
+        for opt in opts:
+            opt.exchange_wait()                 # this stream waits for the collectives' streams
         for opt in self.get_all_optimizers().values():
             opt.begin_replay()
-        g['graph'].replay()
+        for graph in g['graphs'][1:]:
+            graph.replay()                      # the two Adam steps on the summed gradients
         report(g['obs'])
+
+    def _exchanging_optimizers(self):
+        opts = [self.get_optimizer('opt_gen')] + ([] if self.freeze_discriminator else [self.get_optimizer('opt_dis')])
+        return [o for o in opts if o._exchange_active()]
+
+    def _capture_segments(self, static):
+        """hipGraph replay under data parallel (round 4): a collective cannot sit inside the captured step -- the staged exchange
+        is driven from host callbacks in the backward, and a graph that bakes in RCCL's kernels ties the capture to one
+        communicator state -- so the step is captured as TWO graphs out of one memory pool and the exchange runs between their
+        replays: graph 1 = both forward passes and both backward chains (every gradient of both arenas complete), eager
+        all-reduce of the two arenas, graph 2 = the two fused Adam steps.  `_step_body` calls the split at that point."""
+        graphs = [torch.cuda.CUDAGraph(), torch.cuda.CUDAGraph()]
+        pool = torch.cuda.graph_pool_handle()
+        opts = self._exchanging_optimizers()
+        current = torch.cuda.current_stream()
+        stream = torch.cuda.Stream(device=current.device)
+        stream.wait_stream(current)
+
+        def split():
+            graphs[0].capture_end()
+            for opt in opts:                    # what graph 2 records is "the exchange has happened": scale by 1 / world size
+                opt._exchanged_from, opt._pending = 0, []
+            graphs[1].capture_begin(pool=pool)
+
+        with torch.cuda.stream(stream):
+            graphs[0].capture_begin(pool=pool)
+            self._segment_split = split
+            try:
+                self._step(*static)
+            finally:
+                self._segment_split = None
+            graphs[1].capture_end()
+        current.wait_stream(stream)
+        return graphs
 
     def _step(self, real_images, labels, fake_images):
         ops.begin_step(torch.device('cuda', torch.cuda.current_device()))     # one memset for the step's accumulators
@@ -178,6 +234,27 @@ class SheepAssessor(training.StandardUpdater):
         ops.probe('assessor chain enqueued (fork stream)')
         loss_localizer.backward()
         ops.probe('localizer backward enqueued')
+        if self._segment_split is not None:
+            # a data-parallel step being captured (_capture_segments): segment 1 ends here with both chains' gradients
+            # complete on the capture stream, segment 2 is the two updates on gradients that have been exchanged in between
+            assert concurrent or self.freeze_discriminator
+            if concurrent:
+                main.wait_stream(fork)
+            else:
+                loss_dis = mean_squared_error(y_real, labels)
+            ops.join_side_stream()
+            self._segment_split()
+            localizer_optimizer.update()
+            report({'loss_localizer': loss_localizer})
+            self.discriminator.enable_update()
+            x_fake.unchain_backward()
+            bboxes.unchain_backward()
+            if not self.freeze_discriminator:
+                self.localizer.cleargrads()
+                discriminator_optimizer.update()
+            report({'loss_dis': loss_dis})
+            ops.probe('step end')
+            return
         # Data parallel: the localizer's gradient all-reduce (50 MB) is started here and overlaps the assessor's backward
         # below, which touches neither those gradients nor the localizer's parameters; the Adam step then lands where
         # the reference has it in effect (both updates are independent) -- `overlap` is False on a single GPU

@@ -415,11 +415,15 @@ def adam_lr(alpha, beta1, beta2, t):
 
 
 def adam_amsgrad_update(p, g, m, v, vhat, t, alpha=0.001, beta1=0.9, beta2=0.999,
-                        eps=1e-8, eta=1.0, weight_decay_rate=0.0):
-    """In-place update of (p, m, v, vhat); ``t`` is the 1-based step count."""
+                        eps=1e-8, eta=1.0, weight_decay_rate=0.0, amsgrad=True):
+    """In-place update of (p, m, v, vhat); ``t`` is the 1-based step count.  ``amsgrad=False`` (Chainer's default; the
+    trainer passes True, train_sheep_localizer.py:130-134): the denominator is sqrt(v), ``vhat`` is left alone."""
     dt = p.dtype.type
     m += dt(1 - beta1) * (g - m)
     v += dt(1 - beta2) * (g * g - v)
-    np.maximum(vhat, v, out=vhat)
+    if amsgrad:
+        np.maximum(vhat, v, out=vhat)
+    else:
+        vhat = v
     lr = adam_lr(alpha, beta1, beta2, t)
     p -= dt(eta) * (dt(lr) * m / (np.sqrt(vhat) + dt(eps)) + dt(weight_decay_rate) * p)

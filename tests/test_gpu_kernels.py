@@ -723,6 +723,50 @@ def test_adam_amsgrad_matches_chainer_placement():
         np.testing.assert_allclose(vhd.cpu().numpy(), vh, rtol=1e-5, atol=1e-30)
 
 
+def test_adam_without_amsgrad_and_update_with_a_loss_function():
+    """The rest of chainer.optimizers.Adam's surface (stubs): amsgrad=False (Chainer's default) steps with
+    sqrt(v) itself -- v falls when the gradients shrink, vhat would not --, and update(lossfun, *args) evaluates the loss,
+    clears the gradients, runs the backward and steps."""
+    import loans_amd
+    from loans_amd import ops
+    rng = np.random.RandomState(6)
+    n = 1003
+    p = rng.standard_normal(n).astype(np.float32)
+    pr, m, v = p.copy(), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    pa, ma, va, vha = p.copy(), np.zeros(n, np.float32), np.zeros(n, np.float32), np.zeros(n, np.float32)
+    pd, md, vd = dev(p), torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda')
+    for t in range(1, 6):
+        g = (rng.standard_normal(n) * 10.0 ** (-t)).astype(np.float32)          # shrinking gradients: v falls below its maximum
+        C.adam_amsgrad_update(pr, g, m, v, None, t, alpha=1e-3, amsgrad=False)
+        C.adam_amsgrad_update(pa, g, ma, va, vha, t, alpha=1e-3)
+        ops.adam_amsgrad(pd, dev(g), md, vd, None, C.adam_lr(1e-3, .9, .999, t), .9, .999, 1e-8, 1.0, 0.0)
+        np.testing.assert_allclose(pd.cpu().numpy(), pr, rtol=0, atol=2e-7)
+        np.testing.assert_allclose(vd.cpu().numpy(), v, rtol=1e-5, atol=1e-30)
+    assert np.abs(pr - pa).max() > 1e-4                                          # ... and that is not the AMSGrad trajectory
+    # through the optimiser object, with a loss function: theta of a fresh localizer pulled towards zero
+    np.random.seed(0)
+    crop = (16, 16)
+    loc = loans_amd.SheepLocalizer(crop)
+    from loans_amd.datasets import synthetic
+    frames = dev(synthetic.make_frames(1, 2, 64, 64))
+    opt = loans_amd.Adam(alpha=1e-2).setup(loc)
+    assert opt.hyperparam.amsgrad is False
+    loc.finalize(torch.device('cuda', 0))
+    loc.param_predictor.b.grad_view.fill_(123.0)                                # a stale gradient: update(lossfun) clears it
+
+    def lossfun(images):
+        rois, points = loc(images)
+        return loans_amd.functions.mean_squared_error(loc.last_transform_params, torch.zeros(2, 2, 3, device='cuda'))
+    b0 = loc.param_predictor.b.get_logical().copy()
+    opt.update(lossfun, frames)
+    b1 = loc.param_predictor.b.get_logical()
+    # d mse / d b = 2 theta / 12 summed over the batch = [.8, 0, 0, 0, .8, 0] * 2 * 2 / 12 (the stale 123 was cleared);
+    # step 1 of Adam moves every entry with a gradient by alpha against its sign, the masked entries not at all
+    np.testing.assert_allclose(loc.param_predictor.b.grad_logical(), np.array([.8, 0, 0, 0, .8, 0]) * 4 / 12, rtol=1e-5, atol=1e-7)
+    np.testing.assert_allclose(b1 - b0, [-1e-2, 0, 0, 0, -1e-2, 0], rtol=1e-4, atol=1e-8)
+    assert opt.t == 1
+
+
 def _bf16_round(a):
     """Round-to-nearest-even fp32 -> bf16 -> fp32 (the conversion v_cvt_pk_bf16_f32 performs)."""
     return torch.from_numpy(np.ascontiguousarray(a, np.float32)).to(torch.bfloat16).to(torch.float32).numpy()

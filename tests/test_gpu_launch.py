@@ -49,7 +49,13 @@ def test_bench_secondary_legs_schema():
                                       '--secondary-warmup', '1'] + TINY))
     assert out['dtype'] == 'f32' and out['config']['activation_storage'] == 'f32' and out['config']['frame'] == '3x64x64'
     sec = out['secondary']
+    b16 = {k: sec.pop(k) for k in list(sec) if k.startswith('reference default')}
     assert sorted(sec) == ['configs[2]', 'configs[4] per GPU']
+    # the reference's default batch, eager and as a hipGraph (here shrunk like the others): fp32, the same workload twice
+    eager, graph = b16['reference default (-b 16, 224 x 224), eager'], b16['reference default (-b 16, 224 x 224), hipGraph']
+    assert eager['dtype'] == graph['dtype'] == 'f32' and not eager['config']['hip_graph'] and graph['config']['hip_graph']
+    assert eager['value'] > 0 and graph['value'] > 0
+    assert abs(graph['graph_over_eager'] - graph['value'] / eager['value']) < 1e-2 and graph['roofline'] is None
     for name, leg in sec.items():
         assert leg['dtype'] == 'bf16' and leg['config']['activation_storage'] == 'bf16' and leg['config']['frame'] == '3x320x320'
         assert leg['config']['per_gpu_batch'] == 2 and leg['steps'] == 2 and leg['unit'] == 'images/s'

@@ -107,3 +107,86 @@ def test_two_rank_data_parallel_step_against_oracle(tmp_path):
         assert np.mean(d > 5e-5) < 2e-3, (k, np.mean(d > 5e-5))
         checked += 1
     assert checked > 60
+
+
+def _worker_graph(rank, world, port, outdir):
+    """eager and captured (use_graph=True) updaters side by side on every rank: same initial weights, same batches"""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world),
+                      LOCAL_RANK=str(rank), LOANS_DIST_BACKEND='gloo')
+    import torch
+    import loans_amd
+    from loans_amd import ops, parallel
+    from loans_amd.runtime import training
+    from tests.gpu_util import build_pair, dev, inputs
+    ops.SPLITK = False                                  # order-preserving forward: what is compared is the schedule
+    comm = parallel.init_from_env()
+    assert comm.active and comm.size == world
+    steps, Bg = 6, 4
+    batches = [inputs(60 + 10 * i + rank, Bg, HW, HW, CROP) for i in range(3)]
+    out = {}
+    for mode in ('eager', 'graph'):
+        loc, dis = build_pair(7, CROP)
+        with loans_amd.using_config('enable_backprop', False):
+            dis(dev(batches[0][1]))
+        loc.finalize(torch.device('cuda', 0))
+        comm.bcast_data(loc)
+        comm.bcast_data(dis)
+        og = parallel.create_multi_node_optimizer(loans_amd.Adam(alpha=1e-4, amsgrad=True).setup(loc), comm)
+        od = parallel.create_multi_node_optimizer(loans_amd.Adam(alpha=1e-4, amsgrad=True).setup(dis), comm)
+        upd = loans_amd.SheepAssessor(
+            models=[loc, dis], iterator={'main': training.DeviceBatchIterator([dev(b[0]) for b in batches]),
+                                         'real': training.DeviceBatchIterator([(dev(b[1]), dev(b[2])) for b in batches])},
+            optimizer={'opt_gen': og, 'opt_dis': od}, converter=training.identity_converter, device=0, comm=comm,
+            use_graph=(mode == 'graph'))
+        calls, plain = [], comm.allreduce_range
+        comm.allreduce_range = lambda arena, lo, hi, async_op=False: (calls.append((arena is loc.arena, lo, hi, async_op)),
+                                                                        plain(arena, lo, hi, async_op))[1]
+        losses = []
+        for _ in range(steps):
+            upd.update()
+            obs = loans_amd.reporter.observation
+            losses.append((float(obs['loss_localizer']), float(obs['loss_dis'])))
+        comm.allreduce_range = plain
+        torch.cuda.synchronize()
+        assert og.t == steps and od.t == steps
+        if mode == 'graph':
+            g = upd._graph
+            assert g is not None and len(g['graphs']) == 2         # two segments, the exchange between them
+            # two eager warm-up steps exchange in stages (3 + 1 calls each); the capture pass exchanges nothing; every replay
+            # exchanges each arena whole, asynchronously, between the two graphs
+            replayed = calls[8:]
+            assert replayed == [(True, 0, loc.arena.active_numel, True), (False, 0, dis.arena.active_numel, True)] * (steps - 2), replayed
+        else:
+            assert upd._graph is None
+        out[mode] = (losses, loc.state_dict_chainer(), dis.state_dict_chainer())
+        np.savez(os.path.join(outdir, '%s_loc_%d.npz' % (mode, rank)), **out[mode][1])
+        np.savez(os.path.join(outdir, '%s_dis_%d.npz' % (mode, rank)), **out[mode][2])
+    np.save(os.path.join(outdir, 'losses_%d.npy' % rank), np.array([out['eager'][0], out['graph'][0]]))
+    comm.barrier()
+    parallel.shutdown()
+
+
+def test_two_rank_captured_step_matches_eager(tmp_path):
+    """hipGraph replay under data parallel (round 4): the step is captured in two segments -- both
+    backward chains | both Adam steps -- and the gradient exchange runs between their replays.  Two ranks, six steps over three
+    different batches: the captured run follows the eager one (same tolerances as the single-process
+    test_graph_captured_step_matches_eager: weight gradients are summed with float atomics in both), and in BOTH modes the
+    replicas end bit-identical -- the data-parallel invariant."""
+    mp.spawn(_worker_graph, args=(WORLD, _free_port(), str(tmp_path)), nprocs=WORLD, join=True)
+    load = lambda n: dict(np.load(os.path.join(str(tmp_path), n)))       # noqa: E731
+    for mode in ('eager', 'graph'):
+        for what in ('loc', 'dis'):
+            a, b = load('%s_%s_0.npz' % (mode, what)), load('%s_%s_1.npz' % (mode, what))
+            for k in a:
+                if 'avg_' not in k and not k.endswith('/N'):               # BN running statistics are local to a shard
+                    np.testing.assert_array_equal(a[k], b[k], err_msg='%s %s' % (mode, k))
+    for rank in range(WORLD):
+        l_eager, l_graph = np.load(os.path.join(str(tmp_path), 'losses_%d.npy' % rank))
+        np.testing.assert_allclose(l_graph, l_eager, rtol=5e-4, atol=1e-6)
+    e, g = load('eager_loc_0.npz'), load('graph_loc_0.npz')
+    for k in ('param_predictor/W', 'param_predictor/b', 'feature_extractor/conv1/W', 'feature_extractor/res5/1/conv2/W',
+              'feature_extractor/bn1/avg_mean'):
+        assert np.abs(g[k] - e[k]).max() < 2e-3 * np.abs(e[k]).max() + 1e-6, k
+    e, g = load('eager_dis_0.npz'), load('graph_dis_0.npz')
+    for k in ('r0/c0/W', 'l4/W'):
+        assert np.abs(g[k] - e[k]).max() < 2e-3 * np.abs(e[k]).max() + 1e-6, k
