@@ -377,7 +377,9 @@ def run_workload(w, comm, local_rank, retune):
         updater.update()
 
     # ---- timed region: exactly K steps between barrier + synchronize ----
-    ops.EVENT_LOG = [] if rank == 0 else None          # HIP events around the conv-forward launches
+    # HIP events around the conv-forward launches (not under a hipGraph: a replay runs no host code, and events recorded while
+    # the step is being captured cannot be read)
+    ops.EVENT_LOG = [] if (rank == 0 and not w.graph) else None
     ops.FLOP_COUNT = {} if rank == 0 else None         # algorithmic FLOP of every convolution launch of the timed steps
     comm.barrier()
     torch.cuda.synchronize()

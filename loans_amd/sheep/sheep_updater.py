@@ -115,13 +115,13 @@ class SheepAssessor(training.StandardUpdater):
         for s, t in zip(g['static'], ins):
             s.copy_(t, non_blocking=True)
         opts = self._exchanging_optimizers() if len(g['graphs']) > 1 else []
+        for opt in self.get_all_optimizers().values():
+            opt.begin_replay()                  # this step's bias-corrected rate into device memory, BEFORE the captured Adam reads it
         g['graphs'][0].replay()                 # single process: the whole step; data parallel: everything up to both backwards
         for opt in opts:
             opt.update_begin()                  # the whole active prefix of each gradient arena, RCCL beside RCCL
         for opt in opts:
             opt.exchange_wait()                 # this stream waits for the collectives' streams
-        for opt in self.get_all_optimizers().values():
-            opt.begin_replay()
         for graph in g['graphs'][1:]:
             graph.replay()                      # the two Adam steps on the summed gradients
         report(g['obs'])

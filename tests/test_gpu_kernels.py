@@ -737,9 +737,10 @@ def test_adam_without_amsgrad_and_update_with_a_loss_function():
     pd, md, vd = dev(p), torch.zeros(n, device='cuda'), torch.zeros(n, device='cuda')
     for t in range(1, 6):
         g = (rng.standard_normal(n) * 10.0 ** (-t)).astype(np.float32)          # shrinking gradients: v falls below its maximum
-        C.adam_amsgrad_update(pr, g, m, v, None, t, alpha=1e-3, amsgrad=False)
-        C.adam_amsgrad_update(pa, g, ma, va, vha, t, alpha=1e-3)
-        ops.adam_amsgrad(pd, dev(g), md, vd, None, C.adam_lr(1e-3, .9, .999, t), .9, .999, 1e-8, 1.0, 0.0)
+        # beta2 = 0.5: v follows the shrinking gradients within a step or two, vhat would stay at its first value
+        C.adam_amsgrad_update(pr, g, m, v, None, t, alpha=1e-3, beta2=.5, amsgrad=False)
+        C.adam_amsgrad_update(pa, g, ma, va, vha, t, alpha=1e-3, beta2=.5)
+        ops.adam_amsgrad(pd, dev(g), md, vd, None, C.adam_lr(1e-3, .9, .5, t), .9, .5, 1e-8, 1.0, 0.0)
         np.testing.assert_allclose(pd.cpu().numpy(), pr, rtol=0, atol=2e-7)
         np.testing.assert_allclose(vd.cpu().numpy(), v, rtol=1e-5, atol=1e-30)
     assert np.abs(pr - pa).max() > 1e-4                                          # ... and that is not the AMSGrad trajectory

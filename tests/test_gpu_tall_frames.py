@@ -98,21 +98,23 @@ def test_res6_res7_gradients_and_update_parity(deterministic_forward):
         g = blk.bwd(g, forced)
     g = C.max_pool_bwd(oloc.stem_relu.shape, oloc.pool_idx, g, 3, 2, 0) * (oloc.stem_relu > 0)
     oloc.stem.bwd(g, forced, need_gx=False)
-    worst_forced, worst, worst32, errs = {}, {}, {}, {}
+    worst_forced, worst, worst32, errs, forced_errs = {}, {}, {}, {}, {}
     for key, p in loc.namedparams():
         ref = res['loc_grads'].get(key[1:])
         assert ref is not None and key[1:] in forced, key        # at this height every parameter has a gradient
         if key == '/feature_extractor/conv1/b':
             continue                                             # analytically zero (BN follows): rounding noise
         st = _stage_of(key)
-        e = rel_err(p.grad_logical(), forced[key[1:]])
+        e = forced_errs[key] = rel_err(p.grad_logical(), forced[key[1:]])
         worst_forced[st] = max(worst_forced.get(st, 0.0), e)
-        assert e < 1e-3, (key, e)
         errs[key] = rel_err(p.grad_logical(), ref)
         worst[st] = max(worst.get(st, 0.0), errs[key])
         worst32[st] = max(worst32.get(st, 0.0), rel_err(r32['loc_grads'][key[1:]], ref))
     print('from the HIP d loss / d theta, worst per stage:    ', {k: '%.2e' % v for k, v in sorted(worst_forced.items())})
+    print('   largest:', sorted(((v, k) for k, v in forced_errs.items()), reverse=True)[:12])
     assert 'res6' in worst_forced and 'res7' in worst_forced
+    for key, e in forced_errs.items():
+        assert e < 1e-3, (key, e)
 
     # ---- 3. free-running, for the record: within 10 x what the fp32 oracle is from the fp64 one (all of it the sampler's) ----
     print('free-running against the fp64 oracle, per stage:   ', {k: '%.2e' % v for k, v in sorted(worst.items())})
