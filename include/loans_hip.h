@@ -552,6 +552,19 @@ int loans_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, doub
  *      ks int32 coefficients in 22-bit fixed point (tables from loans_amd/common/datasets/resample.py); horizontal pass
  *      into tmp [B][inH][outW][3], vertical pass into dst.  src is [B][inH][inW][3] uint8 RGB.
  *      _u8: dst [B][outH][outW][3] uint8;  _u8_f32: dst [B][3][outH][outW] float32 = resized / 255 (the hot path's frames). ---- */
+/* A batch of frames of DIFFERENT sizes (the naive crop branch of ImageDataset, image_dataset.py:86-90, gives every frame a
+ * size of its own) resized to one outH x outW batch in ONE launch pair.  One job per frame: byte offsets of the frame in
+ * `src` ([inH][inW][3] uint8) and of its intermediate in `tmp` ([inH][outW][3]), and the int32-word offsets of ITS coefficient
+ * tables in `tables` (per axis: bounds [out][2], coefficients [out][ks]); frame j writes dst[j] ([3][outH][outW] float32 =
+ * resized / 255), i.e. the batch is produced in job order.  jobs / tables are device memory; max_inH = the tallest frame. */
+typedef struct loans_resample_job {
+    int64_t src_off, tmp_off;
+    int32_t inH, inW;
+    int32_t hb_off, hk_off, hks;
+    int32_t vb_off, vk_off, vks;
+} loans_resample_job;
+int loans_resize_ragged_u8_f32(const uint8_t* src, uint8_t* tmp, float* dst, const loans_resample_job* jobs, int32_t njobs,
+                               const int32_t* tables, int32_t max_inH, int32_t outH, int32_t outW, void* stream);
 int loans_resize_lanczos_u8(const uint8_t* src, uint8_t* tmp, uint8_t* dst, int32_t B, int32_t inH, int32_t inW,
                             int32_t outH, int32_t outW, const int32_t* hbounds, const int32_t* hk, int32_t hks,
                             const int32_t* vbounds, const int32_t* vk, int32_t vks, void* stream);

@@ -106,6 +106,7 @@ SIGNATURES = {
     'loans_repack_dgrad_batch': [_p, _i32, _i32, _p],
     'loans_resize_lanczos_u8': [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _i32, _p, _p, _i32, _p],
     'loans_resize_lanczos_u8_f32': [_p, _p, _p, _i32, _i32, _i32, _i32, _i32, _p, _p, _i32, _p, _p, _i32, _p],
+    'loans_resize_ragged_u8_f32': [_p, _p, _p, _p, _i32, _p, _i32, _i32, _i32, _p],
     'loans_u8hwc3_to_f32chw': [_p, _p, _i32, _i32, _i32, _p],
     'loans_prep_images_f32': [_p, _p, _i32, _i32, _i32, _p],
     'loans_prep_images_dense_f32': [_p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p],

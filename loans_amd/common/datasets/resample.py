@@ -138,6 +138,73 @@ def resize_lanczos(frames_u8, out_hw, as_float=True, filt='lanczos'):
     return out
 
 
+# mirror of loans_resample_job (include/loans_hip.h)
+RESAMPLE_JOB = np.dtype([('src_off', '<i8'), ('tmp_off', '<i8'), ('inH', '<i4'), ('inW', '<i4'), ('hb_off', '<i4'), ('hk_off', '<i4'),
+                         ('hks', '<i4'), ('vb_off', '<i4'), ('vk_off', '<i4'), ('vks', '<i4')])
+assert RESAMPLE_JOB.itemsize == 48
+
+
+class _TableArena:
+    """The coefficient tables of every (input size, output size, filter) seen so far, packed into ONE device int32 buffer so
+    that a kernel can find any frame's tables by offset (loans_resize_ragged_u8_f32).  The naive crop branch draws a few
+    hundred distinct sizes; a table is uploaded the first time its size appears and never again."""
+
+    def __init__(self, device, words=4 << 20):
+        self.device, self.buf, self.used, self.where = device, torch.empty(words, device=device, dtype=torch.int32), 0, {}
+
+    def offsets(self, in_size, out_size, filt):
+        key = (in_size, out_size, filt)
+        hit = self.where.get(key)
+        if hit is None:
+            b, k, ks = resample_coeffs(in_size, out_size, filt)
+            need = b.size + k.size
+            if self.used + need > self.buf.numel():          # full: start over (every size is one table rebuild away)
+                torch.cuda.current_stream(self.device).synchronize()
+                self.used, self.where = 0, {}
+                if need > self.buf.numel():
+                    self.buf = torch.empty(2 * need, device=self.device, dtype=torch.int32)
+            flat = torch.from_numpy(np.concatenate([b.ravel(), k.ravel()]))
+            self.buf[self.used:self.used + need].copy_(flat)
+            hit = self.where[key] = (self.used, self.used + b.size, ks)
+            self.used += need
+        return hit
+
+
+_arenas = {}
+
+
+def resize_ragged(dev_all, frames, out_hw, filt='lanczos'):
+    """`frames` = [(byte offset in dev_all, H, W)] in batch order, every frame a uint8 [H][W][3] image inside the device buffer
+    `dev_all`: Pillow's resize of each to out_hw and `/ 255`, as ONE launch pair -> [N][3][oh][ow] float32 in that order."""
+    dev = dev_all.device
+    oh, ow = int(out_hw[0]), int(out_hw[1])
+    arena = _arenas.get(dev)
+    if arena is None:
+        arena = _arenas[dev] = _TableArena(dev)
+    for _ in range(2):                   # a reset of the arena in the middle of a batch invalidates earlier offsets: once more
+        start = arena.where
+        jobs = np.zeros(len(frames), RESAMPLE_JOB)
+        tmp_off = 0
+        for j, (off, H, W) in enumerate(frames):
+            hb, hk, hks = arena.offsets(W, ow, filt)
+            vb, vk, vks = arena.offsets(H, oh, filt)
+            jobs[j] = (off, tmp_off, H, W, hb, hk, hks, vb, vk, vks)
+            tmp_off += (H * ow * 3 + 15) & ~15
+        if arena.where is start:
+            break
+    ring, slot, host = _staging.get(jobs.nbytes, kind='jobs')
+    host[:jobs.nbytes].numpy()[:] = jobs.view(np.uint8)
+    jobs_d = host[:jobs.nbytes].to(dev, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(dev))
+    ring['events'][slot] = ev
+    tmp = torch.empty(tmp_off, device=dev, dtype=torch.uint8)
+    out = torch.empty((len(frames), 3, oh, ow), device=dev, dtype=torch.float32)
+    check(_lib.load().loans_resize_ragged_u8_f32(_ptr(dev_all), _ptr(tmp), _ptr(out), _ptr(jobs_d), len(frames), _ptr(arena.buf),
+                                                 max(H for _, H, _ in frames), oh, ow, _stream()), 'loans_resize_ragged_u8_f32')
+    return out
+
+
 class _Staging:
     """Pinned host buffers for the uint8 upload, re-used from batch to batch (``pin_memory()`` of a fresh 200 MB tensor per
     batch cost more than the upload itself).  Two buffers per calling thread take turns; each carries the event of the last
@@ -146,9 +213,9 @@ class _Staging:
     def __init__(self):
         self.slots = {}
 
-    def get(self, nbytes):
+    def get(self, nbytes, kind='frames'):
         import threading
-        key = threading.get_ident()
+        key = (threading.get_ident(), kind)
         ring = self.slots.setdefault(key, {'i': 0, 'bufs': [None, None], 'events': [None, None]})
         i = ring['i'] = (ring['i'] + 1) % 2
         if ring['events'][i] is not None:
@@ -160,9 +227,8 @@ class _Staging:
 
     def drop(self, thread_ident):
         """forget (and free) the buffers of a thread that is gone -- a feed iterator's finish thread"""
-        ring = self.slots.pop(thread_ident, None)
-        if ring is not None:
-            for ev in ring['events']:
+        for key in [k for k in self.slots if k[0] == thread_ident]:
+            for ev in self.slots.pop(key)['events']:
                 if ev is not None:
                     ev.synchronize()
 
@@ -205,6 +271,15 @@ def frames_to_device(images, out_hw, device, augment_rows=None, map_fn=map):
     ev = torch.cuda.Event()
     ev.record(torch.cuda.current_stream(device))
     ring['events'][slot] = ev
+    if augment_rows is None and len(spans) > 1:
+        # many sizes (the naive crop branch: up to one size per frame): ONE launch pair for the whole batch, in input order.
+        # Per size group this used to be two launches, three allocations and an index upload that synchronised the stream --
+        # 128 groups per batch ran the GPU stages at 2 700 frames/s (profiles/r3_feed_bench.txt)
+        where = {}
+        for (H, W), idx, o in spans:
+            for n, i in enumerate(idx):
+                where[i] = (o + n * H * W * 3, H, W)
+        return resize_ragged(dev_all, [where[i] for i in range(len(images))], out_hw)
     out = None
     for (H, W), idx, o in spans:
         frames = dev_all[o:o + len(idx) * H * W * 3].view(len(idx), H, W, 3)

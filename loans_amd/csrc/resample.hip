@@ -87,6 +87,65 @@ __global__ __launch_bounds__(256) void u8hwc3_to_f32chw_kernel(const uint8_t* sr
     }
 }
 
+// ---- a batch of frames of DIFFERENT sizes in one launch pair (the reference's naive augmentation branch, common/datasets/
+// image_dataset.py:86-90, crops every frame to a size of its own before `resize_image`).  One job per frame: where it lies in
+// the packed source / intermediate buffers and where ITS coefficient tables lie in `tables` (int32 words: bounds [out][2],
+// then coefficients [out][ks], per axis).  blockIdx.y = the frame, blockIdx.x strides over its output pixels; frame j writes
+// slot j of dst, so the batch comes out in input order without a gather.
+__global__ __launch_bounds__(256) void resample_h_ragged_kernel(const uint8_t* src, uint8_t* tmp, const loans_resample_job* jobs,
+                                                                const int32_t* tables, int outW) {
+    const loans_resample_job j = jobs[blockIdx.y];
+    const int32_t* bounds = tables + j.hb_off;
+    const int32_t* kk = tables + j.hk_off;
+    const uint8_t* s = src + j.src_off;
+    uint8_t* d = tmp + j.tmp_off;
+    const int total = j.inH * outW;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int xx = i % outW, row = i / outW;
+        const int xmin = bounds[2 * xx], n = bounds[2 * xx + 1];
+        const int32_t* k = kk + (int64_t)xx * j.hks;
+        const uint8_t* p = s + ((int64_t)row * j.inW + xmin) * 3;
+        int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
+        for (int x = 0; x < n; ++x) {
+            const int w = k[x];
+            s0 += (int)p[3 * x] * w;
+            s1 += (int)p[3 * x + 1] * w;
+            s2 += (int)p[3 * x + 2] * w;
+        }
+        uint8_t* o = d + (int64_t)i * 3;
+        o[0] = (uint8_t)clip8(s0); o[1] = (uint8_t)clip8(s1); o[2] = (uint8_t)clip8(s2);
+    }
+}
+
+__global__ __launch_bounds__(256) void resample_v_ragged_kernel(const uint8_t* tmp, float* dst, const loans_resample_job* jobs,
+                                                                const int32_t* tables, int outH, int outW) {
+    const loans_resample_job j = jobs[blockIdx.y];
+    const int32_t* bounds = tables + j.vb_off;
+    const int32_t* kk = tables + j.vk_off;
+    const uint8_t* s = tmp + j.tmp_off;
+    const int64_t plane = (int64_t)outH * outW;
+    float* out = dst + (int64_t)blockIdx.y * 3 * plane;
+    const int total = outH * outW;
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const int x = i % outW, yy = i / outW;
+        const int ymin = bounds[2 * yy], n = bounds[2 * yy + 1];
+        const int32_t* k = kk + (int64_t)yy * j.vks;
+        const uint8_t* p = s + ((int64_t)ymin * outW + x) * 3;
+        int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
+        for (int y = 0; y < n; ++y) {
+            const int w = k[y];
+            const uint8_t* q = p + (int64_t)y * outW * 3;
+            s0 += (int)q[0] * w;
+            s1 += (int)q[1] * w;
+            s2 += (int)q[2] * w;
+        }
+        float* o = out + i;
+        o[0] = (float)clip8(s0) / 255.f;
+        o[plane] = (float)clip8(s1) / 255.f;
+        o[2 * plane] = (float)clip8(s2) / 255.f;
+    }
+}
+
 bool table_ok(const int32_t* b, const int32_t* k, int ks) { return b && k && ks > 0; }
 
 }  // namespace
@@ -128,6 +187,21 @@ extern "C" int loans_u8hwc3_to_f32chw(const uint8_t* src, float* dst, int32_t B,
     if (!src || !dst || B <= 0 || H <= 0 || W <= 0) return LOANS_EINVAL;
     hipLaunchKernelGGL(u8hwc3_to_f32chw_kernel, dim3(grid_for((int64_t)B * H * W, 256)), dim3(256), 0, as_stream(stream), src,
                        dst, B, (int64_t)H * W);
+    LOANS_LAUNCH_CHECK();
+    return LOANS_OK;
+}
+
+extern "C" int loans_resize_ragged_u8_f32(const uint8_t* src, uint8_t* tmp, float* dst, const loans_resample_job* jobs,
+                                          int32_t njobs, const int32_t* tables, int32_t max_inH, int32_t outH, int32_t outW,
+                                          void* stream) {
+    if (!src || !tmp || !dst || !jobs || !tables || njobs <= 0 || njobs > 65535 || max_inH <= 0 || outH <= 0 || outW <= 0)
+        return LOANS_EINVAL;
+    if ((int64_t)max_inH * outW >= ((int64_t)1 << 30)) return LOANS_ERANGE;
+    hipStream_t st = as_stream(stream);
+    const int bh = (int)(((int64_t)max_inH * outW + 255) / 256), bv = (outH * outW + 255) / 256;
+    hipLaunchKernelGGL(resample_h_ragged_kernel, dim3(bh < 64 ? bh : 64, njobs), dim3(256), 0, st, src, tmp, jobs, tables, outW);
+    LOANS_LAUNCH_CHECK();
+    hipLaunchKernelGGL(resample_v_ragged_kernel, dim3(bv < 64 ? bv : 64, njobs), dim3(256), 0, st, tmp, dst, jobs, tables, outH, outW);
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;
 }
