@@ -152,22 +152,24 @@ class _TableArena:
     def __init__(self, device, words=4 << 20):
         self.device, self.buf, self.used, self.where = device, torch.empty(words, device=device, dtype=torch.int32), 0, {}
 
-    def offsets(self, in_size, out_size, filt):
-        key = (in_size, out_size, filt)
-        hit = self.where.get(key)
-        if hit is None:
-            b, k, ks = resample_coeffs(in_size, out_size, filt)
-            need = b.size + k.size
-            if self.used + need > self.buf.numel():          # full: start over (every size is one table rebuild away)
-                torch.cuda.current_stream(self.device).synchronize()
-                self.used, self.where = 0, {}
-                if need > self.buf.numel():
-                    self.buf = torch.empty(2 * need, device=self.device, dtype=torch.int32)
-            flat = torch.from_numpy(np.concatenate([b.ravel(), k.ravel()]))
-            self.buf[self.used:self.used + need].copy_(flat)
-            hit = self.where[key] = (self.used, self.used + b.size, ks)
-            self.used += need
-        return hit
+    def ensure(self, keys):
+        """make the tables of every key resident; returns {key: (bounds offset, coefficient offset, ksize)}"""
+        tables = {k: resample_coeffs(*k) for k in keys if k not in self.where}
+        need = sum(b.size + c.size for b, c, _ in tables.values())
+        if self.used + need > self.buf.numel():
+            # full: start over with this batch's tables (launches that read the old contents are ahead of the copies below
+            # on the same stream)
+            tables = {k: resample_coeffs(*k) for k in keys}
+            need = sum(b.size + c.size for b, c, _ in tables.values())
+            self.used, self.where = 0, {}
+            if need > self.buf.numel():
+                self.buf = torch.empty(2 * need, device=self.device, dtype=torch.int32)
+        for k, (b, c, ks) in tables.items():
+            n = b.size + c.size
+            self.buf[self.used:self.used + n].copy_(torch.from_numpy(np.concatenate([b.ravel(), c.ravel()])))
+            self.where[k] = (self.used, self.used + b.size, ks)
+            self.used += n
+        return {k: self.where[k] for k in keys}
 
 
 _arenas = {}
@@ -181,17 +183,12 @@ def resize_ragged(dev_all, frames, out_hw, filt='lanczos'):
     arena = _arenas.get(dev)
     if arena is None:
         arena = _arenas[dev] = _TableArena(dev)
-    for _ in range(2):                   # a reset of the arena in the middle of a batch invalidates earlier offsets: once more
-        start = arena.where
-        jobs = np.zeros(len(frames), RESAMPLE_JOB)
-        tmp_off = 0
-        for j, (off, H, W) in enumerate(frames):
-            hb, hk, hks = arena.offsets(W, ow, filt)
-            vb, vk, vks = arena.offsets(H, oh, filt)
-            jobs[j] = (off, tmp_off, H, W, hb, hk, hks, vb, vk, vks)
-            tmp_off += (H * ow * 3 + 15) & ~15
-        if arena.where is start:
-            break
+    at = arena.ensure({(W, ow, filt) for _, _, W in frames} | {(H, oh, filt) for _, H, _ in frames})
+    jobs = np.zeros(len(frames), RESAMPLE_JOB)
+    tmp_off = 0
+    for j, (off, H, W) in enumerate(frames):
+        jobs[j] = (off, tmp_off, H, W) + at[(W, ow, filt)] + at[(H, oh, filt)]
+        tmp_off += (H * ow * 3 + 15) & ~15
     ring, slot, host = _staging.get(jobs.nbytes, kind='jobs')
     host[:jobs.nbytes].numpy()[:] = jobs.view(np.uint8)
     jobs_d = host[:jobs.nbytes].to(dev, non_blocking=True)

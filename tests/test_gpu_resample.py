@@ -110,3 +110,31 @@ def test_imgaug_branch_gpu_equals_host(tmp_path):
     ds.reseed(21)
     dev_ = ds.device_batch(range(4), 'cuda:0')
     np.testing.assert_array_equal(dev_.cpu().numpy(), host)
+
+
+def test_ragged_batch_one_launch_pair_against_pillow(monkeypatch):
+    """loans_resize_ragged_u8_f32 (round 4): a batch in which every frame has a size of its own -- what the reference's naive
+    crop branch produces (image_dataset.py:86-90) -- resized by ONE launch pair, frame j into slot j, bit for bit Pillow's
+    LANCZOS + `/ 255`; down- and up-scaling, an unchanged axis, a frame that already has the output size, a single pixel.
+    A coefficient-table arena that is too small for the batch starts over and the batch still comes out right."""
+    from PIL import Image
+    from loans_amd.common.datasets import resample
+    rng = np.random.RandomState(11)
+    sizes = [(int(h), int(w)) for h, w in zip(rng.randint(20, 300, 37), rng.randint(20, 400, 37))]
+    sizes += [(96, 128), (96, 300), (300, 128), (1, 1), (480, 640), (96, 128)]
+    frames = [rng.randint(0, 256, (h, w, 3)).astype(np.uint8) for h, w in sizes]
+    ref = np.stack([np.asarray(Image.fromarray(f).resize((128, 96), Image.LANCZOS)).transpose(2, 0, 1).astype(np.float32) / 255
+                    for f in frames])
+    launches = []
+    lib = resample._lib.load()
+    real = lib.loans_resize_ragged_u8_f32
+    monkeypatch.setattr(lib, 'loans_resize_ragged_u8_f32', lambda *a: (launches.append(a[4]), real(*a))[1])
+    got = resample.frames_to_device(frames, (96, 128), 'cuda:0')
+    assert launches == [len(frames)]                                     # one call for the whole batch
+    np.testing.assert_array_equal(got.cpu().numpy(), ref)
+    # the same frames through an arena that cannot hold all their tables at once: it starts over, batches stay right
+    dev = torch.device('cuda', 0)
+    monkeypatch.setitem(resample._arenas, dev, resample._TableArena(dev, words=40000))
+    for k in range(4):
+        sl = slice(6 * k, 6 * k + 6)
+        np.testing.assert_array_equal(resample.frames_to_device(frames[sl], (96, 128), 'cuda:0').cpu().numpy(), ref[sl])

@@ -24,7 +24,12 @@ ap.add_argument('--files', type=int, default=512)
 ap.add_argument('--processes', type=int, default=0, help='decode processes (0: threads)')
 ap.add_argument('--no-imgaug', action='store_true')
 ap.add_argument('--jpeg', action='store_true')
+ap.add_argument('--cores', type=int, default=0,
+                help="pin this process and its decode workers to the first N cores: ONE rank's share of the host (an 8-GPU node with "
+                     "64 cores gives each rank 8; the 1-GPU box this runs on has 16)")
 args = ap.parse_args()
+if args.cores:
+    os.sched_setaffinity(0, set(sorted(os.sched_getaffinity(0))[:args.cores]))
 
 from loans_amd.common.datasets.image_dataset import ImageDataset      # noqa: E402
 from loans_amd.datasets import synthetic                                # noqa: E402
@@ -72,6 +77,8 @@ for _ in range(args.batches):
 torch.cuda.synchronize()
 whole = args.batches * args.b / (time.perf_counter() - t0)
 feed.finalize()
+if args.cores:
+    print('host share: %d cores (affinity of this process and its decode workers)' % len(os.sched_getaffinity(0)))
 print('frames %dx%d %s -> %dx%d, batch %d, %d decode %s, augmentation %s' % (
     args.frames[0], args.frames[1], 'JPEG' if args.jpeg else 'PNG', args.out[0], args.out[1], args.b, args.processes or args.threads,
     'processes' if args.processes else 'threads',
