@@ -84,13 +84,19 @@ def _nchw(t):
     return t.float().cpu().numpy().transpose(0, 3, 1, 2).astype(np.float64)
 
 
-def _teacher_forced_units(loc_cls, oracle_cls, B, H, W, crop, seed):
+def _teacher_forced_units(loc_cls, oracle_cls, B, H, W, crop, seed, emulate=True):
     """Every conv / BN layer of the localizer IN SITU -- real weights, real activations and real gradients of a B x 3 x H x W
     step of the bf16 arm -- against the bf16-rounding oracle, unit by unit: each unit's oracle twin gets the tensors the HIP
     unit actually received (its bf16 input on the way up, its bf16 output gradient on the way down) and must reproduce what the
     HIP unit produced.  Free-running the two networks side by side instead compares little: a bf16 network amplifies a one-ulp
     difference by 2 - 3 x per residual unit (measured: 2e-5 after the stem, 4.5e-2 after 13 units), so after the first
-    rounding that falls the other way the two runs decorrelate -- which says nothing about either."""
+    rounding that falls the other way the two runs decorrelate -- which says nothing about either.
+    ``emulate=False``: the fp32 arm against the plain fp64 oracle (tests/test_gpu_tall_frames.py: there the free-running chain is
+    ill-conditioned for another reason -- near-constant channels at 27 .. 300 samples per channel multiply a gradient
+    perturbation by gamma / sqrt(var + eps) up to 223 per BN -- and the units in situ agree to 2e-6)."""
+    import contextlib
+    rounding = M.emulate_bf16_storage if emulate else contextlib.nullcontext
+    q = C.round_bf16 if emulate else (lambda a: a)
     from loans_amd.functions import blocks, global_average_pooling_2d, linear, reshape, rotation_dropout, spatial_transformer_grid
     from loans_amd.runtime.core import Variable
     np.random.seed(seed)
@@ -122,7 +128,7 @@ def _teacher_forced_units(loc_cls, oracle_cls, B, H, W, crop, seed):
         h = u(h)
         ins.append(h)
     feat = Variable(ins[-1].data, requires_grad=True)
-    assert feat.data.dtype == torch.bfloat16
+    assert feat.data.dtype == (torch.bfloat16 if emulate else torch.float32)
 
     # ---- head (fp32 on both sides): GAP -> Linear -> rotation dropout -> grid -> the two regularisers ----
     pooled = global_average_pooling_2d(feat)
@@ -144,7 +150,7 @@ def _teacher_forced_units(loc_cls, oracle_cls, B, H, W, crop, seed):
     assert np.abs(g_pts).max() > 0                                # the regularisers are active for this seed
     g_theta = C.st_grid_bwd(coords, g_pts) * mask
     g_pooled, gW, gb = C.linear_bwd(o_pooled, lp['param_predictor/W'], g_theta.reshape(-1, 6), True)
-    g_feat = C.round_bf16(C.gap_bwd(f64.shape, g_pooled))
+    g_feat = q(C.gap_bwd(f64.shape, g_pooled))
     head = {'param_predictor/W': _l2(loc.param_predictor.W.grad_logical(), gW),
             'param_predictor/b': _l2(loc.param_predictor.b.grad_logical(), gb),
             'd loss / d features': _l2(_nchw(feat.grad), g_feat)}
@@ -163,7 +169,7 @@ def _teacher_forced_units(loc_cls, oracle_cls, B, H, W, crop, seed):
         loc.cleargrads()
         out.backward()
         ops.join_side_stream()
-        with M.emulate_bf16_storage():
+        with rounding():
             o_out = o_units[i].fwd(_nchw(ins[i].data))
             grads = {}
             o_gx = o_units[i].bwd(_nchw(g), grads)
@@ -181,7 +187,7 @@ def _teacher_forced_units(loc_cls, oracle_cls, B, H, W, crop, seed):
     loc.cleargrads()
     pooled_hip.backward()
     ops.join_side_stream()
-    with M.emulate_bf16_storage():
+    with rounding():
         stem = M._ConvBN(lp, 'feature_extractor/conv1', 'feature_extractor/bn1', 2, 3, True)
         sr = M._q(C.relu(stem.fwd(M._q(C.prepare_images(frames.astype(np.float64))))))
         o_pool, idx = C.max_pool_fwd(sr, 3, 2, 0)

@@ -2,20 +2,24 @@
 fp64 oracle: every localizer gradient (res6 / res7 included) before Adam, then one whole `update_core` -- res6 / res7 move,
 the arena's active prefix is the whole arena, Adam-AMSGrad lands where the oracle's does.
 
-How the comparison is cut (round 4).  The gradient of a bilinear sampler with respect to its grid is DISCONTINUOUS in theta:
-a sample point that crosses a pixel boundary switches to another pair of pixels, and on frames with pixel-scale texture that
-changes its term by O(1).  At 320 x 304 px a theta that differs in its sixth digit (fp32 against fp64: 1.7e-6 here) moves the
-560 x 3 sample points of a crop by 3e-4 px, one or two of them cross a boundary, and d loss / d theta -- hence EVERY backbone
-gradient, which is linear in it -- differs by 3e-3 .. 4e-2: the fp32 ORACLE is that far from the fp64 one
-(measured, `worst32` below).  That is a property of the operator, not of an implementation.  So the chain is compared in
-three links, each on identical inputs, each to a tolerance that means something:
+How the comparison is cut (round 4).  Free-running, the backbone gradients of this configuration are ill-conditioned for ANY
+fp32 implementation: the fp32 ORACLE is 1e-2 .. 4e-2 away from the fp64 one per stage (printed below as `worst32`), the HIP path
+1e-2 .. 1.4e-1 -- while every single kernel is exact.  Two mechanisms, both measured: (i) the gradient of a bilinear sampler with
+respect to its grid is DISCONTINUOUS in theta -- a sample point that crosses a pixel boundary switches to another pair of
+pixels; at 320 x 304 px a theta that differs in its sixth digit moves the 560 x 3 sample points of a crop by 3e-4 px and one
+or two of them cross: d loss / d theta differs by 3e-3 between the two oracle precisions; (ii) a BN backward subtracts from its
+gradient the projections on 1 and x_hat, a difference of nearly equal terms for the gradient that comes down from the global
+average pooling (spatially constant at the top), so RELATIVE differences grow from BN to BN although no gain exceeds 3 (teacher-
+forcing d loss / d theta alone left the HIP-vs-oracle distances where they were).  So the chain is compared link by link, each
+link on identical inputs, each to a tolerance that means something:
   1. sampler + regularisers: the oracle's backward evaluated AT THE HIP GRID (same sample points) from the HIP crop gradient
-     -> d loss / d points to 1e-4, d loss / d theta to 1e-4;
-  2. backbone incl. res6 / res7: the oracle's backward started from the HIP d loss / d theta -> every parameter gradient to
-     1e-3 (the fp32 oracle itself: 1e-5, measured on the CPU);
-  3. the free-running gradients, for the record, within 10 x the fp32 oracle's own distance from the fp64 one.
-
-PARITY UNPINNED: the oracle is this repo's restatement of Chainer's arithmetic, the reference holds no vectors.
+     -> d loss / d rois, d loss / d points, d loss / d theta to 1e-4 (measured 4e-7);
+  2. backbone incl. res6 / res7: every residual unit, the stem and the head IN SITU, teacher-forced -- the unit's oracle twin
+     gets the tensors the HIP unit received (tests/test_gpu_configs.py:_teacher_forced_units, here without the bf16 rounding) ->
+     outputs, input gradients and all parameter gradients to 1e-4 (measured 2e-6; conv1's weight gradient, a sum over 73 k
+     sparse pixels, 2.4e-4 against a bound of 1e-3);
+  3. the free-running gradients, for the record, within 10 x the fp32 oracle's own distance from the fp64 one;
+  4. Adam-AMSGrad on both arenas, res6 / res7 included: the oracle's update applied to the gradients the HIP step produced.
 """
 import numpy as np
 import pytest
@@ -32,6 +36,23 @@ pytestmark = [pytest.mark.gpu, pytest.mark.usefixtures('kernel_selection')]
 def _stage_of(key):
     key = key.lstrip('/')
     return key.split('/')[0] if key.startswith('res') else (key.split('/')[1] if '/res' in key else 'head / stem')
+
+
+def test_every_unit_in_situ_with_res6_and_res7_active(deterministic_forward):
+    """link 2 of the module docstring: stem, the 12 residual units (res2 .. res7) and the head of a 3 x 320 x 304 step, each on the
+    tensors the HIP chain really produced, against the fp64 oracle."""
+    from tests.test_gpu_configs import _teacher_forced_units
+    report = _teacher_forced_units(loans_amd.SheepLocalizer, M.Localizer, 3, 320, 304, (20, 28), 41, emulate=False)
+    assert len(report) == 12 + 2
+    for name, e_out, prof, e_gx, errs, n in reversed(report):
+        worst = max(errs, key=errs.get)
+        print('%-28s out L2 %.2e  gx L2 %.2e  parameter gradients L2 max %.2e (%s)  %d samples per channel'
+              % (name, e_out, e_gx, errs[worst], worst, n))
+    assert {'res6/0', 'res6/1', 'res7/0', 'res7/1'} <= {r[0] for r in report}
+    for name, e_out, prof, e_gx, errs, n in report:
+        assert e_out < 1e-4 and e_gx < 1e-4, (name, e_out, e_gx)
+        for key, e in errs.items():
+            assert e < (1e-3 if key.endswith('conv1/W') and name == 'stem' else 1e-4), (key, e)
 
 
 def test_res6_res7_gradients_and_update_parity(deterministic_forward):
@@ -87,36 +108,20 @@ def test_res6_res7_gradients_and_update_parity(deterministic_forward):
     print('d loss / d rois %.2e, d loss / d points %.2e, d loss / d theta %.2e (oracle evaluated on the HIP tensors)' % (e_rois, e_pts, e_theta))
     assert e_rois < 1e-4 and e_pts < 1e-4 and e_theta < 1e-4
 
-    # ---- 2. the backbone, res6 / res7 included, from the HIP d loss / d theta ----
-    oloc = M.Localizer(lp0, crop, train=True, rng=np.random.RandomState(0))
-    oloc.forward(f64[0])
-    forced = {}
-    gpooled, gW, gb = C.linear_bwd(oloc.pooled, lp0['param_predictor/W'], (g_theta_hip * oloc.mask).reshape(-1, 6), True)
-    forced['param_predictor/W'], forced['param_predictor/b'] = gW, gb
-    g = C.gap_bwd(oloc.feat.shape, gpooled)
-    for blk in reversed(oloc.blocks):
-        g = blk.bwd(g, forced)
-    g = C.max_pool_bwd(oloc.stem_relu.shape, oloc.pool_idx, g, 3, 2, 0) * (oloc.stem_relu > 0)
-    oloc.stem.bwd(g, forced, need_gx=False)
-    worst_forced, worst, worst32, errs, forced_errs = {}, {}, {}, {}, {}
+    # ---- 2. the backbone, res6 / res7 included: every unit in situ (its own test function below shares the helper) ----
+    worst, worst32, errs = {}, {}, {}
     for key, p in loc.namedparams():
         ref = res['loc_grads'].get(key[1:])
-        assert ref is not None and key[1:] in forced, key        # at this height every parameter has a gradient
+        assert ref is not None, key                              # at this height every parameter has a gradient
         if key == '/feature_extractor/conv1/b':
             continue                                             # analytically zero (BN follows): rounding noise
         st = _stage_of(key)
-        e = forced_errs[key] = rel_err(p.grad_logical(), forced[key[1:]])
-        worst_forced[st] = max(worst_forced.get(st, 0.0), e)
         errs[key] = rel_err(p.grad_logical(), ref)
         worst[st] = max(worst.get(st, 0.0), errs[key])
         worst32[st] = max(worst32.get(st, 0.0), rel_err(r32['loc_grads'][key[1:]], ref))
-    print('from the HIP d loss / d theta, worst per stage:    ', {k: '%.2e' % v for k, v in sorted(worst_forced.items())})
-    print('   largest:', sorted(((v, k) for k, v in forced_errs.items()), reverse=True)[:12])
-    assert 'res6' in worst_forced and 'res7' in worst_forced
-    for key, e in forced_errs.items():
-        assert e < 1e-3, (key, e)
+    assert 'res6' in worst and 'res7' in worst
 
-    # ---- 3. free-running, for the record: within 10 x what the fp32 oracle is from the fp64 one (all of it the sampler's) ----
+    # ---- 3. free-running, for the record: within 10 x what the fp32 oracle is from the fp64 one ----
     print('free-running against the fp64 oracle, per stage:   ', {k: '%.2e' % v for k, v in sorted(worst.items())})
     print('fp32 oracle against the fp64 oracle, per stage:    ', {k: '%.2e' % v for k, v in sorted(worst32.items())})
     drift = max(worst32.values())
