@@ -17,7 +17,9 @@ link on identical inputs, each to a tolerance that means something:
   2. backbone incl. res6 / res7: every residual unit, the stem and the head IN SITU, teacher-forced -- the unit's oracle twin
      gets the tensors the HIP unit received (tests/test_gpu_configs.py:_teacher_forced_units, here without the bf16 rounding) ->
      outputs, input gradients and all parameter gradients to 1e-4 (measured 2e-6; conv1's weight gradient, a sum over 73 k
-     sparse pixels, 2.4e-4 against a bound of 1e-3);
+     sparse pixels, 2.4e-4 against a bound of 1e-3).  A pre-activation that is zero to rounding may fall on either side of a
+     ReLU: the oracle's backward takes the HIP decision there (`_force_relu_ties`: one such element in res3/1 moved that
+     unit's beta gradient by 1e-3) and the test fails if the decisions differ on anything that is not a tie;
   3. the free-running gradients, for the record, within 10 x the fp32 oracle's own distance from the fp64 one;
   4. Adam-AMSGrad on both arenas, res6 / res7 included: the oracle's update applied to the gradients the HIP step produced.
 """
@@ -46,8 +48,8 @@ def test_every_unit_in_situ_with_res6_and_res7_active(deterministic_forward):
     assert len(report) == 12 + 2
     for name, e_out, prof, e_gx, errs, n in reversed(report):
         worst = max(errs, key=errs.get)
-        print('%-28s out L2 %.2e  gx L2 %.2e  parameter gradients L2 max %.2e (%s)  %d samples per channel'
-              % (name, e_out, e_gx, errs[worst], worst, n))
+        print('%-28s out L2 %.2e  gx L2 %.2e  parameter gradients L2 max %.2e (%s)  %d samples per channel, %d ReLU ties'
+              % (name, e_out, e_gx, errs[worst], worst, n, prof[-1]))
     assert {'res6/0', 'res6/1', 'res7/0', 'res7/1'} <= {r[0] for r in report}
     for name, e_out, prof, e_gx, errs, n in report:
         assert e_out < 1e-4 and e_gx < 1e-4, (name, e_out, e_gx)
