@@ -251,6 +251,9 @@ def test_captured_step_survives_eager_steps_of_another_shape(deterministic_forwa
         assert (upd._graph is not None) == use_graph
         runs.append((losses, loc.state_dict_chainer()))
     (l0, p0), (l1, p1) = runs
-    np.testing.assert_allclose(np.array(l1), np.array(l0), rtol=5e-4, atol=1e-6)
+    # (four frames per step: a ReLU / pooling decision that flips on the last bit of a weight -- both runs sum their weight
+    # gradients with float atomics -- moves a later loss by 1e-3; what a freed table or buffer would do is garbage or a fault)
+    np.testing.assert_allclose(np.array(l1)[:4], np.array(l0)[:4], rtol=5e-4, atol=1e-6)
+    np.testing.assert_allclose(np.array(l1), np.array(l0), rtol=1e-2, atol=1e-6)
     for k in ('param_predictor/W', 'feature_extractor/conv1/W', 'feature_extractor/res5/1/conv2/W', 'feature_extractor/res3/0/conv1/W'):
         assert np.abs(p1[k] - p0[k]).max() < 2e-3 * np.abs(p0[k]).max() + 1e-5, k

@@ -58,6 +58,24 @@ def test_every_unit_in_situ_with_res6_and_res7_active(deterministic_forward):
             assert e < (1e-3 if key.endswith('conv1/W') and name == 'stem' else 1e-4), (key, e)
 
 
+def test_resnet50_every_unit_in_situ_with_res6_and_res7_active(deterministic_forward):
+    """SURVEY 8a a17 / 8f.4 in fp32: stem, the 16 Chainer bottlenecks, the 4 chainercv ones (res6 / res7) and the head of a
+    `Resnet50SheepLocalizer` step at 2 x 320 x 304, each on the tensors the HIP chain really produced, against the fp64 oracle
+    (the whole-network comparison of tests/test_gpu_model.py::test_resnet50_localizer_forward_and_gradient_parity is
+    rounding-noise dominated: 53 BNs over a handful of samples; this one is not)."""
+    from tests.test_gpu_configs import _teacher_forced_units
+    report = _teacher_forced_units(loans_amd.Resnet50SheepLocalizer, M.Localizer50, 2, 320, 304, (20, 28), 43, emulate=False)
+    assert len(report) == 20 + 2
+    for name, e_out, prof, e_gx, errs, n in reversed(report):
+        worst = max(errs, key=errs.get)
+        print('%-28s out L2 %.2e  gx L2 %.2e  parameter gradients L2 max %.2e (%s)  %d samples per channel, %d ReLU ties'
+              % (name, e_out, e_gx, errs[worst], worst, n, prof[-1]))
+    for name, e_out, prof, e_gx, errs, n in report:
+        assert e_out < 1e-4 and e_gx < 1e-4, (name, e_out, e_gx)
+        for key, e in errs.items():
+            assert e < (1e-3 if key.endswith('conv1/W') and name == 'stem' else 1e-4), (key, e)
+
+
 def test_res6_res7_gradients_and_update_parity(deterministic_forward):
     from oracle import chainer_ops as C
     B, H, W, crop = 3, 320, 304, (20, 28)
