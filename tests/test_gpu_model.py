@@ -653,8 +653,12 @@ def test_graph_captured_step_matches_eager(deterministic_forward):
         runs.append((losses, loc.state_dict_chainer(), dis.state_dict_chainer()))
     (l0, p0, d0), (l1, p1, d1) = runs
     np.testing.assert_allclose(np.array(l1), np.array(l0), rtol=2e-4, atol=1e-6)
-    for k in ('param_predictor/W', 'param_predictor/b', 'feature_extractor/conv1/W', 'feature_extractor/res5/1/conv2/W',
-              'feature_extractor/bn1/avg_mean'):
-        assert rel_err(p1[k], p0[k]) < 2e-3, k
-    for k in ('r0/c0/W', 'l4/W'):
-        assert rel_err(d1[k], d0[k]) < 2e-3, k
+    # Adam's step is sign-like (|update| <= ~lr): an entry whose gradient is rounding noise may walk the other way in one run --
+    # never further apart than both runs' six steps together, and further than ONE step on less than 1 % of a tensor
+    lr, steps = 1e-4, 6
+    for got, ref, keys in ((p1, p0, ('param_predictor/W', 'param_predictor/b', 'feature_extractor/conv1/W',
+                                      'feature_extractor/res5/1/conv2/W')), (d1, d0, ('r0/c0/W', 'l4/W'))):
+        for k in keys:
+            d = np.abs(got[k] - ref[k])
+            assert d.max() <= 2 * steps * lr and np.mean(d > lr) < 1e-2, (k, float(d.max()), float(np.mean(d > lr)))
+    assert rel_err(p1['feature_extractor/bn1/avg_mean'], p0['feature_extractor/bn1/avg_mean']) < 2e-3

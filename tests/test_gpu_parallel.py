@@ -186,10 +186,17 @@ def test_two_rank_captured_step_matches_eager(tmp_path):
         # gradients are summed with float atomics in both runs -- moves a later loss by 1e-3; measured 2.4e-3 after six steps)
         np.testing.assert_allclose(l_graph[:3], l_eager[:3], rtol=5e-4, atol=1e-6)      # warm-up steps + the first replay
         np.testing.assert_allclose(l_graph, l_eager, rtol=1e-2, atol=1e-6)
+    # Parameters: Adam's step is sign-like (|update| <= ~lr whatever the gradient's size), so an entry whose gradient is
+    # rounding noise may walk the other way in one run: never further apart than both runs' steps together, 2 x 6 x lr, and
+    # further than ONE step (lr) on less than 1 % of a tensor's entries (measured: 3e-4 at the worst entry, none beyond lr)
+    lr, steps = 1e-4, 6
+    for what, keys in (('loc', ('param_predictor/W', 'param_predictor/b', 'feature_extractor/conv1/W',
+                                 'feature_extractor/res5/1/conv2/W', 'feature_extractor/res3/0/conv1/W')),
+                       ('dis', ('r0/c0/W', 'r1/c1/W', 'l4/W'))):
+        e, g = load('eager_%s_0.npz' % what), load('graph_%s_0.npz' % what)
+        for k in keys:
+            d = np.abs(g[k] - e[k])
+            assert d.max() <= 2 * steps * lr and np.mean(d > lr) < 1e-2, (k, float(d.max()), float(np.mean(d > lr)))
+            assert np.abs(e[k] - load('eager_%s_1.npz' % what)[k]).max() == 0
     e, g = load('eager_loc_0.npz'), load('graph_loc_0.npz')
-    for k in ('param_predictor/W', 'param_predictor/b', 'feature_extractor/conv1/W', 'feature_extractor/res5/1/conv2/W',
-              'feature_extractor/bn1/avg_mean'):
-        assert np.abs(g[k] - e[k]).max() < 2e-3 * np.abs(e[k]).max() + 1e-6, k
-    e, g = load('eager_dis_0.npz'), load('graph_dis_0.npz')
-    for k in ('r0/c0/W', 'l4/W'):
-        assert np.abs(g[k] - e[k]).max() < 2e-3 * np.abs(e[k]).max() + 1e-6, k
+    np.testing.assert_allclose(g['feature_extractor/bn1/avg_mean'], e['feature_extractor/bn1/avg_mean'], rtol=2e-3, atol=1e-5)
