@@ -31,8 +31,8 @@ SUITE_ORDER = (
     'test_gpu_kernels',
     # 2. fp32 model + golden fixtures
     'test_golden', 'test_gpu_model', 'test_gpu_tall_frames',
-    # 3. BASELINE configs[1] at full size
-    'test_gpu_fullsize',
+    # 3. BASELINE configs[1] at full size; the tiles bench.py times, at bench.py's shapes
+    'test_gpu_fullsize', 'test_gpu_tune_tables',
     # 4. BASELINE configs[3]: data parallel, the self-contained launch
     'test_gpu_parallel', 'test_gpu_launch',
     # 5. callers either side of the path: trainer, input path, resampling, runtime / snapshots, insights

@@ -146,6 +146,11 @@ def _worker_graph(rank, world, port, outdir):
             upd.update()
             obs = loans_amd.reporter.observation
             losses.append((float(obs['loss_localizer']), float(obs['loss_dis'])))
+            if mode == 'graph' and upd._graph is not None:
+                # the captured Adam reads its bias-corrected rate from device memory: what sits there after a replay is THIS
+                # step's rate (the first version of the two-graph replay refreshed it after the replay: one step stale)
+                for opt in (og, od):
+                    assert float(opt._lr_dev) == float(np.float32(opt.lr)), (opt.t, float(opt._lr_dev), opt.lr)
         comm.allreduce_range = plain
         torch.cuda.synchronize()
         assert og.t == steps and od.t == steps
@@ -185,7 +190,7 @@ def test_two_rank_captured_step_matches_eager(tmp_path):
         # (four frames per rank and step: one ReLU / pooling decision that flips on the last bit of a weight -- the weight
         # gradients are summed with float atomics in both runs -- moves a later loss by 1e-3; measured 2.4e-3 after six steps)
         np.testing.assert_allclose(l_graph[:3], l_eager[:3], rtol=5e-4, atol=1e-6)      # warm-up steps + the first replay
-        np.testing.assert_allclose(l_graph, l_eager, rtol=1e-2, atol=1e-6)
+        np.testing.assert_allclose(l_graph, l_eager, rtol=4e-2, atol=1e-6)      # (over tile assignments: <= 1.2e-2; a stale Adam rate: 1.1e-1)
     # Parameters: Adam's step is sign-like (|update| <= ~lr whatever the gradient's size), so an entry whose gradient is
     # rounding noise may walk the other way in one run: never further apart than both runs' steps together, 2 x 6 x lr, and
     # further than ONE step (lr) on less than 1 % of a tensor's entries (measured: 3e-4 at the worst entry, none beyond lr)

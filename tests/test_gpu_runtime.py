@@ -254,6 +254,10 @@ def test_captured_step_survives_eager_steps_of_another_shape(deterministic_forwa
     # (four frames per step: a ReLU / pooling decision that flips on the last bit of a weight -- both runs sum their weight
     # gradients with float atomics -- moves a later loss by 1e-3; what a freed table or buffer would do is garbage or a fault)
     np.testing.assert_allclose(np.array(l1)[:4], np.array(l0)[:4], rtol=5e-4, atol=1e-6)
-    np.testing.assert_allclose(np.array(l1), np.array(l0), rtol=1e-2, atol=1e-6)
+    np.testing.assert_allclose(np.array(l1), np.array(l0), rtol=4e-2, atol=1e-6)       # (measured over tile assignments: <= 1.2e-2)
+    # Adam's step is sign-like: an entry whose gradient is rounding noise may walk the other way in one run -- never further
+    # apart than both runs' ten steps together, and further than ONE step on less than 1 % of a tensor
+    lr, steps = 1e-4, len(seq)
     for k in ('param_predictor/W', 'feature_extractor/conv1/W', 'feature_extractor/res5/1/conv2/W', 'feature_extractor/res3/0/conv1/W'):
-        assert np.abs(p1[k] - p0[k]).max() < 2e-3 * np.abs(p0[k]).max() + 1e-5, k
+        d = np.abs(p1[k] - p0[k])
+        assert d.max() <= 2 * steps * lr and np.mean(d > lr) < 1e-2, (k, float(d.max()), float(np.mean(d > lr)))
