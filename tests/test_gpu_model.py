@@ -652,7 +652,7 @@ def test_graph_captured_step_matches_eager(deterministic_forward):
         assert (upd._graph is not None) == use_graph
         runs.append((losses, loc.state_dict_chainer(), dis.state_dict_chainer()))
     (l0, p0, d0), (l1, p1, d1) = runs
-    np.testing.assert_allclose(np.array(l1)[:3], np.array(l0)[:3], rtol=2e-4, atol=1e-6)      # two eager steps, the first replay
+    np.testing.assert_allclose(np.array(l1)[0], np.array(l0)[0], rtol=1e-6)                  # same weights, deterministic forward
     np.testing.assert_allclose(np.array(l1), np.array(l0), rtol=4e-2, atol=1e-6)      # (a stale Adam rate in the replays: 1.1e-1)
     for opt in upd.get_all_optimizers().values():
         assert float(opt._lr_dev) == float(np.float32(opt.lr))

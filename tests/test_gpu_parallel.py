@@ -189,7 +189,7 @@ def test_two_rank_captured_step_matches_eager(tmp_path):
         l_eager, l_graph = np.load(os.path.join(str(tmp_path), 'losses_%d.npy' % rank))
         # (four frames per rank and step: one ReLU / pooling decision that flips on the last bit of a weight -- the weight
         # gradients are summed with float atomics in both runs -- moves a later loss by 1e-3; measured 2.4e-3 after six steps)
-        np.testing.assert_allclose(l_graph[:3], l_eager[:3], rtol=5e-4, atol=1e-6)      # warm-up steps + the first replay
+        np.testing.assert_allclose(l_graph[0], l_eager[0], rtol=1e-6)                   # same weights, deterministic forward
         np.testing.assert_allclose(l_graph, l_eager, rtol=4e-2, atol=1e-6)      # (over tile assignments: <= 1.2e-2; a stale Adam rate: 1.1e-1)
     # Parameters: Adam's step is sign-like (|update| <= ~lr whatever the gradient's size), so an entry whose gradient is
     # rounding noise may walk the other way in one run: never further apart than both runs' steps together, 2 x 6 x lr, and

