@@ -86,7 +86,14 @@ def test_update_core_gradients_and_parameters_parity(order, monkeypatch):
     res = M.update_core(lp, dp, og, od, frames.astype(np.float64), real.astype(np.float64),
                         labels.astype(np.float64), crop, rng=np.random.RandomState(0), return_grads=True)
 
-    # run the HIP step but look at the gradients before they are cleared: replicate update_core's halves
+    # Chainer's optimiser hooks run after the backward and before the step: the gradients each Adam really consumed
+    seen = {}
+
+    def keep_gradients(opt):
+        seen.update({k[1:]: p.grad_logical().copy() for k, p in opt.target.namedparams()})
+    upd.get_optimizer('opt_gen').add_hook(keep_gradients)
+    upd.get_optimizer('opt_dis').add_hook(keep_gradients)
+    lp_start, dp_start = oracle_params(loc, np.float64), oracle_params(dis, np.float64)
     upd.update()
     obs = loans_amd.reporter.observation
     np.testing.assert_allclose(float(obs['loss_localizer']), res['loss_localizer'], rtol=1e-4, atol=1e-6)
@@ -109,11 +116,20 @@ def test_update_core_gradients_and_parameters_parity(order, monkeypatch):
             continue
         d = np.abs(new_loc[key] - lp[key])
         assert d.max() < 2.1e-3, key                      # never more than ~2 * lr apart
-        assert np.mean(d > 5e-5) < 2e-3, (key, np.mean(d > 5e-5))
+        assert np.mean(d > 5e-5) < 1e-2, (key, np.mean(d > 5e-5))       # (measured < 2e-3: entries whose gradient is rounding noise)
     new_dis = dis.state_dict_chainer()
     for key in dp:
         d = np.abs(new_dis[key] - dp[key])
-        assert np.mean(d > 5e-5) < 2e-3, (key, np.mean(d > 5e-5))
+        assert np.mean(d > 5e-5) < 1e-2, (key, np.mean(d > 5e-5))
+    # ... and exactly: the ORACLE's Adam-AMSGrad (Chainer's eps placement) applied to the gradients the HIP step produced lands
+    # where the fused kernel landed, on every float of both arenas (sign-like steps are only comparable for equal gradients)
+    for new, start in ((new_loc, lp_start), (new_dis, dp_start)):
+        for key, p0 in start.items():
+            if M.is_trainable(key) and not key.startswith(('res6', 'res7')):
+                want = p0.copy()
+                z = np.zeros_like(want)
+                C.adam_amsgrad_update(want, seen[key].astype(np.float64), z.copy(), z.copy(), z.copy(), 1)
+                np.testing.assert_allclose(new[key], want, rtol=0, atol=2e-6, err_msg=key)
 
 
 def test_localizer_gradients_parity():

@@ -235,7 +235,11 @@ def test_captured_step_survives_eager_steps_of_another_shape(deterministic_forwa
     seq = [a, a, a, a, b, b, b, b, a, a]
     runs = []
     for use_graph in (False, True):
-        loc, dis = build_pair(313, crop)
+        # the well-conditioned start of test_graph_captured_step_matches_eager: a fresh localizer (theta = 0.8 x identity: no
+        # corner near the image border, where the out-of-image term has its kink) with a small seeded param_predictor.W
+        np.random.seed(313)
+        loc, dis = loans_amd.SheepLocalizer(crop), loans_amd.ResnetAssessor()
+        loc.param_predictor.W.set_logical((2e-3 * np.random.RandomState(3).standard_normal((6, 512))).astype(np.float32))
         with loans_amd.using_config('enable_backprop', False):
             dis(dev(a[1]))
         upd = _updater(loc, dis, *a, lr=1e-4, use_graph=use_graph)
