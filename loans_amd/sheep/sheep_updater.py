@@ -149,13 +149,30 @@ class SheepAssessor(training.StandardUpdater):
                 opt._exchanged_from, opt._pending = 0, []
             graphs[1].capture_begin(pool=pool)
 
+        state = {'open': None}
+
+        def split_tracked():
+            split()
+            state['open'] = graphs[1]
+
         with torch.cuda.stream(stream):
             graphs[0].capture_begin(pool=pool)
-            self._segment_split = split
+            state['open'] = graphs[0]
+            self._segment_split = split_tracked
             try:
                 self._step(*static)
+            except BaseException:
+                # leave no capture open behind an error: the stream would stay in capture mode and every later launch fail
+                try:
+                    state['open'].capture_end()
+                except Exception:
+                    pass
+                raise
             finally:
                 self._segment_split = None
+            if state['open'] is not graphs[1]:
+                graphs[0].capture_end()
+                raise RuntimeError('the step never reached its segment split (both backward chains complete): not captured')
             graphs[1].capture_end()
         current.wait_stream(stream)
         return graphs
