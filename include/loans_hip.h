@@ -556,12 +556,14 @@ int loans_adam_f32(float* p, const float* g, float* m, float* v, int64_t n, doub
  * size of its own) resized to one outH x outW batch in ONE launch pair.  One job per frame: byte offsets of the frame in
  * `src` ([inH][inW][3] uint8) and of its intermediate in `tmp` ([inH][outW][3]), and the int32-word offsets of ITS coefficient
  * tables in `tables` (per axis: bounds [out][2], coefficients [out][ks]); frame j writes dst[j] ([3][outH][outW] float32 =
- * resized / 255), i.e. the batch is produced in job order.  jobs / tables are device memory; max_inH = the tallest frame. */
+ * resized / 255), i.e. the batch is produced in job order.  jobs / tables are device memory; max_inH = the tallest frame.
+ * A frame may be stored mirrored (`flip`): the host then stages contiguous rows instead of reversing 3-byte pixels. */
 typedef struct loans_resample_job {
     int64_t src_off, tmp_off;
     int32_t inH, inW;
     int32_t hb_off, hk_off, hks;
     int32_t vb_off, vk_off, vks;
+    int32_t flip;               /* != 0: the frame is the horizontal mirror of the buffer (random_flip, image_dataset.py:40-44) */
 } loans_resample_job;
 int loans_resize_ragged_u8_f32(const uint8_t* src, uint8_t* tmp, float* dst, const loans_resample_job* jobs, int32_t njobs,
                                const int32_t* tables, int32_t max_inH, int32_t outH, int32_t outW, void* stream);

@@ -140,8 +140,8 @@ def resize_lanczos(frames_u8, out_hw, as_float=True, filt='lanczos'):
 
 # mirror of loans_resample_job (include/loans_hip.h)
 RESAMPLE_JOB = np.dtype([('src_off', '<i8'), ('tmp_off', '<i8'), ('inH', '<i4'), ('inW', '<i4'), ('hb_off', '<i4'), ('hk_off', '<i4'),
-                         ('hks', '<i4'), ('vb_off', '<i4'), ('vk_off', '<i4'), ('vks', '<i4')])
-assert RESAMPLE_JOB.itemsize == 48
+                         ('hks', '<i4'), ('vb_off', '<i4'), ('vk_off', '<i4'), ('vks', '<i4'), ('flip', '<i4'), ('_pad', '<i4')])
+assert RESAMPLE_JOB.itemsize == 56
 
 
 class _TableArena:
@@ -176,18 +176,19 @@ _arenas = {}
 
 
 def resize_ragged(dev_all, frames, out_hw, filt='lanczos'):
-    """`frames` = [(byte offset in dev_all, H, W)] in batch order, every frame a uint8 [H][W][3] image inside the device buffer
+    """`frames` = [(byte offset in dev_all, H, W[, mirrored])] in batch order, every frame a uint8 [H][W][3] image inside the device buffer
     `dev_all`: Pillow's resize of each to out_hw and `/ 255`, as ONE launch pair -> [N][3][oh][ow] float32 in that order."""
     dev = dev_all.device
     oh, ow = int(out_hw[0]), int(out_hw[1])
     arena = _arenas.get(dev)
     if arena is None:
         arena = _arenas[dev] = _TableArena(dev)
-    at = arena.ensure({(W, ow, filt) for _, _, W in frames} | {(H, oh, filt) for _, H, _ in frames})
+    frames = [tuple(f) + (False,) * (4 - len(f)) for f in frames]
+    at = arena.ensure({(W, ow, filt) for _, _, W, _ in frames} | {(H, oh, filt) for _, H, _, _ in frames})
     jobs = np.zeros(len(frames), RESAMPLE_JOB)
     tmp_off = 0
-    for j, (off, H, W) in enumerate(frames):
-        jobs[j] = (off, tmp_off, H, W) + at[(W, ow, filt)] + at[(H, oh, filt)]
+    for j, (off, H, W, mirrored) in enumerate(frames):
+        jobs[j] = (off, tmp_off, H, W) + at[(W, ow, filt)] + at[(H, oh, filt)] + (int(bool(mirrored)), 0)
         tmp_off += (H * ow * 3 + 15) & ~15
     ring, slot, host = _staging.get(jobs.nbytes, kind='jobs')
     host[:jobs.nbytes].numpy()[:] = jobs.view(np.uint8)
@@ -198,7 +199,7 @@ def resize_ragged(dev_all, frames, out_hw, filt='lanczos'):
     tmp = torch.empty(tmp_off, device=dev, dtype=torch.uint8)
     out = torch.empty((len(frames), 3, oh, ow), device=dev, dtype=torch.float32)
     check(_lib.load().loans_resize_ragged_u8_f32(_ptr(dev_all), _ptr(tmp), _ptr(out), _ptr(jobs_d), len(frames), _ptr(arena.buf),
-                                                 max(H for _, H, _ in frames), oh, ow, _stream()), 'loans_resize_ragged_u8_f32')
+                                                 max(f[1] for f in frames), oh, ow, _stream()), 'loans_resize_ragged_u8_f32')
     return out
 
 
@@ -259,9 +260,14 @@ def frames_to_device(images, out_hw, device, augment_rows=None, map_fn=map):
     ring, slot, host = _staging.get(total)
     host_np = host.numpy()
 
+    # a horizontally flipped view (random_flip of the naive branch: a negative stride along W) would be copied 3 bytes at a
+    # time; it is staged as it lies in memory -- whole rows -- and mirrored by the resampling kernel (ragged path only)
+    ragged = augment_rows is None and len(groups) > 1
+    mirrored = [ragged and im.strides[1] < 0 for im in images]
+
     def stage(job):
         i, o, H, W = job
-        np.copyto(host_np[o:o + H * W * 3].reshape(H, W, 3), images[i])
+        np.copyto(host_np[o:o + H * W * 3].reshape(H, W, 3), images[i][:, ::-1] if mirrored[i] else images[i])
 
     list(map_fn(stage, jobs))
     dev_all = host[:total].to(device, non_blocking=True)
@@ -275,7 +281,7 @@ def frames_to_device(images, out_hw, device, augment_rows=None, map_fn=map):
         where = {}
         for (H, W), idx, o in spans:
             for n, i in enumerate(idx):
-                where[i] = (o + n * H * W * 3, H, W)
+                where[i] = (o + n * H * W * 3, H, W, mirrored[i])
         return resize_ragged(dev_all, [where[i] for i in range(len(images))], out_hw)
     out = None
     for (H, W), idx, o in spans:

@@ -104,13 +104,16 @@ __global__ __launch_bounds__(256) void resample_h_ragged_kernel(const uint8_t* s
         const int xx = i % outW, row = i / outW;
         const int xmin = bounds[2 * xx], n = bounds[2 * xx + 1];
         const int32_t* k = kk + (int64_t)xx * j.hks;
-        const uint8_t* p = s + ((int64_t)row * j.inW + xmin) * 3;
+        // j.flip: the frame is the horizontal mirror of what lies in memory (random_flip of the naive branch,
+        // image_dataset.py:40-44,90): pixel x of the frame is pixel inW - 1 - x of the buffer
+        const uint8_t* p = s + ((int64_t)row * j.inW + (j.flip ? j.inW - 1 - xmin : xmin)) * 3;
+        const int step = j.flip ? -3 : 3;
         int s0 = 1 << (PRECISION_BITS - 1), s1 = s0, s2 = s0;
         for (int x = 0; x < n; ++x) {
             const int w = k[x];
-            s0 += (int)p[3 * x] * w;
-            s1 += (int)p[3 * x + 1] * w;
-            s2 += (int)p[3 * x + 2] * w;
+            s0 += (int)p[step * x] * w;
+            s1 += (int)p[step * x + 1] * w;
+            s2 += (int)p[step * x + 2] * w;
         }
         uint8_t* o = d + (int64_t)i * 3;
         o[0] = (uint8_t)clip8(s0); o[1] = (uint8_t)clip8(s1); o[2] = (uint8_t)clip8(s2);

@@ -1054,6 +1054,36 @@ CAPTURE_STREAMS = os.environ.get('LOANS_CAPTURE_STREAMS', '1') != '0'
 SIDE_PRIORITY = int(os.environ.get('LOANS_SIDE_PRIORITY', '0'))
 _side = {}
 _side_dirty = set()
+# LOANS_WGRAD_CUS=n (round 4): the weight-gradient stream(s) are created with a CU mask (hipExtStreamCreateWithCUMask) that
+# leaves them n of every 8 consecutive CUs -- whatever the numbering, every XCD keeps n / 8 of its CUs for them -- so that the
+# HBM-bound BN / pooling passes of the main stream always find (8 - n) / 8 of the machine free instead of time-slicing with
+# blocks that own whole CUs' register files (those passes run at 1.3 - 2 TB/s in situ against 4 - 5 alone).
+WGRAD_CUS_OF_8 = int(os.environ.get('LOANS_WGRAD_CUS', '0'))
+
+
+def side_stream_cus(device=None):
+    """CUs the weight-gradient streams may use (block-count candidates of the weight gradients are laid out for these)"""
+    cus = torch.cuda.get_device_properties(torch.cuda.current_device() if device is None else device).multi_processor_count
+    return cus * WGRAD_CUS_OF_8 // 8 if 0 < WGRAD_CUS_OF_8 < 8 else cus
+
+
+def _new_side_stream(device):
+    if not 0 < WGRAD_CUS_OF_8 < 8:
+        return torch.cuda.Stream(device=device, priority=SIDE_PRIORITY)
+    import ctypes
+    hip = ctypes.CDLL('libamdhip64.so')
+    total = torch.cuda.get_device_properties(device).multi_processor_count
+    words = (total + 31) // 32
+    mask = (ctypes.c_uint32 * words)()
+    for i in range(total):
+        if i % 8 < WGRAD_CUS_OF_8:
+            mask[i // 32] |= 1 << (i % 32)
+    handle = ctypes.c_void_p()
+    with torch.cuda.device(device):
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(handle), words, mask)
+    if rc != 0 or not handle.value:
+        raise RuntimeError('hipExtStreamCreateWithCUMask failed with %d' % rc)
+    return torch.cuda.ExternalStream(handle.value, device=device)
 
 
 # Consecutive weight gradients are independent of each other: with LOANS_WGRAD_STREAMS = n > 1 they rotate over n streams, so that
@@ -1078,7 +1108,7 @@ def _side_stream(device):
     order something behind every weight gradient issued so far (the staged exchange) rely on"""
     st = _side.get(device.index)
     if st is None:
-        st = _side[device.index] = torch.cuda.Stream(device=device, priority=SIDE_PRIORITY)
+        st = _side[device.index] = _new_side_stream(device)
     for other in _side_more.get(device.index, ()):
         st.wait_stream(other)
     return st
@@ -1090,10 +1120,10 @@ def _wgrad_stream(device):
     if n == 1 and idx not in _side_more:
         return _side_stream(device)
     if idx not in _side:
-        _side[idx] = torch.cuda.Stream(device=device, priority=SIDE_PRIORITY)
+        _side[idx] = _new_side_stream(device)
     more = _side_more.setdefault(idx, [])
     while len(more) < n - 1:
-        more.append(torch.cuda.Stream(device=device, priority=SIDE_PRIORITY))
+        more.append(_new_side_stream(device))
     turn = _side_turn[idx] = (_side_turn.get(idx, 0) + 1) % n
     return _side[idx] if turn == 0 else more[turn - 1]
 
@@ -1118,8 +1148,8 @@ def _wgrad_key(x, gy, relu_in):
 
 def conv_wgrad(x, gy, dw, geo, relu_in=False, splits=0, tile=0):
     """dw[Cout,k,k,Cin] += sum over pixels (atomic accumulate into the gradient arena)."""
-    if ASYNC_WGRAD and geo.tuned.get(_wgrad_key(x, gy, relu_in)) is not None \
-            and (CAPTURE_STREAMS or not torch.cuda.is_current_stream_capturing()):
+    tuned = geo.tuned.get(_wgrad_key(x, gy, relu_in)) is not None or 0 < WGRAD_CUS_OF_8 < 8      # (masked stream: tuned THERE)
+    if ASYNC_WGRAD and tuned and (CAPTURE_STREAMS or not torch.cuda.is_current_stream_capturing()):
         side = _wgrad_stream(x.device)
         side.wait_stream(torch.cuda.current_stream(x.device))
         x.record_stream(side)
@@ -1142,7 +1172,7 @@ def _wgrad_candidates(geo, tiles, chunk_px, dims=None):
     rounds at 118), so slot-aligned counts are offered beside the default and its half / double."""
     K = geo.w_numel // geo.Cout
     chunks = (geo.B * geo.Ho * geo.Wo + chunk_px - 1) // chunk_px
-    cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+    cus = side_stream_cus()
     out = []
     for t in tiles:
         bco, bj, per_cu = (dims or _WGRAD_TILE_DIMS)[t]
@@ -1175,7 +1205,7 @@ def wghalo_tiles(geo):
 def _wghalo_candidates(geo):
     """(tile | blocks per channel-tile pair << 8): whole rounds of the machine's block slots (two 4-wave blocks or one 8-wave
     block per CU), 0 = the library's default"""
-    cus = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+    cus = side_stream_cus()
     ntiles = geo.B * ((geo.H + 7) // 8) * ((geo.W + 15) // 16)
     out = []
     for t in wghalo_tiles(geo):

@@ -123,7 +123,11 @@ def test_ragged_batch_one_launch_pair_against_pillow(monkeypatch):
     sizes = [(int(h), int(w)) for h, w in zip(rng.randint(20, 300, 37), rng.randint(20, 400, 37))]
     sizes += [(96, 128), (96, 300), (300, 128), (1, 1), (480, 640), (96, 128)]
     frames = [rng.randint(0, 256, (h, w, 3)).astype(np.uint8) for h, w in sizes]
-    ref = np.stack([np.asarray(Image.fromarray(f).resize((128, 96), Image.LANCZOS)).transpose(2, 0, 1).astype(np.float32) / 255
+    # every third frame is a horizontally flipped VIEW and every fifth a cropped one (what random_flip / random_crop hand over):
+    # the flipped ones are staged un-mirrored and mirrored by the kernel
+    frames = [f[:, ::-1] if i % 3 == 0 else (f[1:, 2:] if i % 5 == 0 and min(f.shape[:2]) > 4 else f) for i, f in enumerate(frames)]
+    assert any(f.strides[1] < 0 for f in frames)
+    ref = np.stack([np.asarray(Image.fromarray(np.ascontiguousarray(f)).resize((128, 96), Image.LANCZOS)).transpose(2, 0, 1).astype(np.float32) / 255
                     for f in frames])
     launches = []
     lib = resample._lib.load()
