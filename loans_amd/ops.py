@@ -117,8 +117,35 @@ BN_DECAY = 0.9
 RUNNING_VAR_INCLUDES_EPS = 1
 
 
+_raw_stream, _raw_device = torch._C._cuda_getCurrentRawStream, torch._C._cuda_getDevice
+
+
 def _stream():
-    return torch.cuda.current_stream().cuda_stream
+    """the current HIP stream of the current device as the `void* stream` of the C ABI.  (torch.cuda.current_stream().cuda_stream
+    builds a Stream object and resolves the device index in Python on the way: 8 us, three thousand times per ResNet-50 step
+    -- a fifth of the host's enqueue time, tools/host_profile.py; these two calls are the same lookup in C.)"""
+    return _raw_stream(_raw_device())
+
+
+def _memo(fn):
+    """candidate lists / launch plans are pure functions of the geometry and of the module's switches, yet were rebuilt on EVERY
+    call of a convolution wrapper, tuned or not (1.4 ms of host time per ResNet-50 step for the weight gradients alone)"""
+    cache = {}
+
+    def wrapped(*args, **kw):
+        if kw:
+            return fn(*args, **kw)
+        key = (tuple(id(a) if isinstance(a, dict) else a for a in args), SPLITK, HALO, WGHALO, CLASS_LAUNCH, FINETAIL,
+               STEM_DIRECT, COMPUTE, STORAGE, WGRAD_CUS_OF_8)
+        try:
+            return cache[key]
+        except KeyError:
+            v = cache[key] = fn(*args)
+            return v
+        except TypeError:               # an unhashable argument: not memoised
+            return fn(*args)
+    wrapped.__name__, wrapped.__doc__, wrapped.uncached = fn.__name__, fn.__doc__, fn
+    return wrapped
 
 
 def _ptr(t):
@@ -346,6 +373,7 @@ TILE_256x256 = 9        # LOANS_TILE_256x256 (loans_igemm_bf16s): eight 128 x 64
 TILE_DEEP = 32          # LOANS_TILE_DEEP: a longer LDS ring for grids of about one block per CU
 
 
+@_memo
 def _wide16_tiles(columns, rows=None):
     """further tile forms of loans_igemm_bf16s by GEMM shape: 256 x 256 where the columns fill it, the deep-ring forms of the
     small tiles where the grid is small (at most four 64 x 64 blocks per CU of an MI355X)"""
@@ -355,6 +383,7 @@ def _wide16_tiles(columns, rows=None):
     return t
 
 
+@_memo
 def _splitk16_candidates(rows, out_channels, ktot):
     """split-K forms of the bf16 implicit GEMM (loans_igemm_bf16s_splitk) for grids that cannot fill the machine: few tiles,
     long K (res6 / res7 at 512 px, everything at small batch).  tile id = base tile | (splits << 8)."""
@@ -386,6 +415,7 @@ def _igemm16_splitk(lib, src, d_list, out, flags, tile, bias, stats, ref, addend
           'loans_igemm_finalize_bf16')
 
 
+@_memo
 def _halo_tiles(geo, gathered_channels, out_channels, out_hw, relu_in=False):
     """halo-tile candidates of a bf16-storage convolution / data gradient (the conditions of loans_halo16_covers), offered
     where a 8 x 16 pixel tile is not mostly empty"""
@@ -487,6 +517,7 @@ def reduce_channels_ok(C_):
 SPLITK = os.environ.get('LOANS_SPLITK', '1') != '0'
 
 
+@_memo
 def _splitk_candidates(M, Cout, nchunks):
     """split-K forms of the 64x64 tile (LOANS_TILE_SPLITK) for grids that cannot fill the machine: few tiles, long K --
     the deep layers at small batch and single-image inference.  tile id = 3 | (splits << 8)."""
@@ -517,6 +548,7 @@ def _igemm_splitk(lib, fn_in, w, out, d_list, flags, tile, bias, stats, ref, add
 TILE_STEM = 10          # LOANS_TILE_STEM: the dense RGB stem as a direct convolution (csrc/stem.hip)
 
 
+@_memo
 def stem_tile_rows(geo):
     """output rows per block of LOANS_TILE_STEM for this geometry, 0 = not covered (loans_stem7_rows of csrc/stem.hip)"""
     if not (geo.dense and geo.k == 7 and geo.stride == 2 and geo.pad == 3 and geo.Cout == 64):
@@ -533,6 +565,7 @@ def stem_tile_rows(geo):
     return 0
 
 
+@_memo
 def stem_wgrad_ok(geo):
     """LOANS_TILE_STEM of loans_wgrad_f32 covers this geometry (loans_stem7_wgrad_launch of csrc/stem.hip)"""
     if not (STEM_DIRECT and geo.dense and geo.k == 7 and geo.stride == 2 and geo.pad == 3 and geo.Cout == 64):
@@ -542,6 +575,7 @@ def stem_wgrad_ok(geo):
     return 2 * ((7 * geo.Wp * 3 * 4 + 1023) // 1024 + (geo.Wo + 3) // 4) * 1024 <= 156 * 1024
 
 
+@_memo
 def stem16_tile_rows(geo):
     """output rows per unit of LOANS_TILE_STEM on the bf16 MFMA (loans_stem7_bf16_rows of csrc/stem.hip), 0 = not covered"""
     if not (geo.dense and geo.k == 7 and geo.stride == 2 and geo.pad == 3 and geo.Cout == 64):
@@ -562,6 +596,7 @@ FINETAIL = os.environ.get('LOANS_FINETAIL', '1') != '0'
 STEM_DIRECT = os.environ.get('LOANS_STEM_DIRECT', '1') != '0'
 
 
+@_memo
 def _finetail_plan(M, Cout, nchunks, device):
     """(rows computed at full K, K slices of the remaining tiles) of LOANS_TILE_FINETAIL -- the arithmetic of igemm_impl"""
     cus = torch.cuda.get_device_properties(device).multi_processor_count
@@ -969,6 +1004,7 @@ TILE_CLASSES = 1 << 16
 CLASS_LAUNCH = os.environ.get('LOANS_CLASS_LAUNCH', '1') != '0'
 
 
+@_memo
 def _class_candidates(geo):
     if not CLASS_LAUNCH or COMPUTE != 'f32' or not 2 <= len(geo.dgrad) <= 4 or max(d.ntaps for d, _, _ in geo.dgrad) > 16:
         return ()
@@ -1165,6 +1201,7 @@ _WGRAD_TILE_DIMS = {1: (128, 128, 2), 3: (64, 64, 4), 5: (64, 128, 3)}      # ti
 _WGRAD16_TILE_DIMS = {1: (128, 128, 3), 3: (64, 64, 5), 5: (64, 128, 4), 9: (256, 256, 1)}    # bf16 tiles: smaller LDS images, register-bound
 
 
+@_memo
 def _wgrad_candidates(geo, tiles, chunk_px, dims=None):
     """(tile, splits) candidates of a weight gradient, encoded tile | splits << 8 (0 = the library's default).  The
     reduction over pixels is cut into `splits` slices per output tile; how many blocks that makes against the machine's
@@ -1192,6 +1229,7 @@ TILE_WGHALO_64, TILE_WGHALO_128 = 38, 39
 WGHALO = os.environ.get('LOANS_WGHALO', '1') != '0'
 
 
+@_memo
 def wghalo_tiles(geo):
     """the halo weight-gradient tiles that cover this geometry (loans_wgrad_halo16_covers), where an 8 x 16 pixel tile is not
     mostly empty"""
@@ -1202,6 +1240,7 @@ def wghalo_tiles(geo):
     return (TILE_WGHALO_64,) + ((TILE_WGHALO_128,) if geo.Cout % 128 == 0 else ())
 
 
+@_memo
 def _wghalo_candidates(geo):
     """(tile | blocks per channel-tile pair << 8): whole rounds of the machine's block slots (two 4-wave blocks or one 8-wave
     block per CU), 0 = the library's default"""
