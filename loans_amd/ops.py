@@ -1184,17 +1184,36 @@ def _wgrad_key(x, gy, relu_in):
 
 def conv_wgrad(x, gy, dw, geo, relu_in=False, splits=0, tile=0):
     """dw[Cout,k,k,Cin] += sum over pixels (atomic accumulate into the gradient arena)."""
-    tuned = geo.tuned.get(_wgrad_key(x, gy, relu_in)) is not None or 0 < WGRAD_CUS_OF_8 < 8      # (masked stream: tuned THERE)
-    if ASYNC_WGRAD and tuned and (CAPTURE_STREAMS or not torch.cuda.is_current_stream_capturing()):
+    masked = 0 < WGRAD_CUS_OF_8 < 8
+    tuned = geo.tuned.get(_wgrad_key(x, gy, relu_in)) is not None
+    if ASYNC_WGRAD and (tuned or masked) and (CAPTURE_STREAMS or not torch.cuda.is_current_stream_capturing()):
         side = _wgrad_stream(x.device)
-        side.wait_stream(torch.cuda.current_stream(x.device))
+        side.wait_stream(_current_stream_obj(x.device.index))
         x.record_stream(side)
         gy.record_stream(side)
         _side_dirty.add(x.device.index)
-        with torch.cuda.stream(side):
-            _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile)
+        if tuned and not geo.dense:
+            # the launch goes to the side stream by handle: making it torch's current stream (a context manager: two Python-level
+            # stream switches per weight gradient) cost 2 ms of host time per ResNet-50 step; nothing is allocated on this path
+            _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile, stream=side.cuda_stream)
+        else:
+            with torch.cuda.stream(side):       # (a masked stream is tuned THERE; the dense stem's mask pass allocates)
+                _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile)
         return
     _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile)
+
+
+_stream_objs = {}
+
+
+def _current_stream_obj(idx):
+    """torch's Stream object of the current stream, looked up by raw handle (torch.cuda.current_stream() resolves the device in
+    Python and builds a new object every time)"""
+    raw = _raw_stream(idx)
+    st = _stream_objs.get((idx, raw))
+    if st is None:
+        st = _stream_objs[(idx, raw)] = torch.cuda.current_stream(idx)
+    return st
 
 
 _WGRAD_TILE_DIMS = {1: (128, 128, 2), 3: (64, 64, 4), 5: (64, 128, 3)}      # tile id -> (BCO, BJ, blocks per CU by LDS)
@@ -1259,7 +1278,7 @@ def _wghalo_candidates(geo):
     return tuple(out)
 
 
-def _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile):
+def _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile, stream=None):
     lib = _lib.load()
     _count_flops('wgrad', geo)
     assert dw.numel() == geo.w_numel and x.numel() == geo.in_numel
@@ -1291,10 +1310,11 @@ def _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile):
     if tile >> 8:
         tile, splits = tile & 0xFF, tile >> 8
     d = _with_flags(geo.fwd, fl, tile)
-    check(wfn(_ptr(x), _ptr(gy), _ptr(dw), C.byref(d), splits, _stream()), 'loans_wgrad')
+    st = stream if stream is not None else _stream()
+    check(wfn(_ptr(x), _ptr(gy), _ptr(dw), C.byref(d), splits, st), 'loans_wgrad')
     if geo.dense and tile != TILE_STEM:         # the direct kernel never writes those columns
         # the window-padding columns of the dense layout saw real pixels: their "gradient" is not one
-        check(lib.loans_mul_f32(_ptr(dw), _ptr(geo.wmask(x.device)), _ptr(dw), dw.numel(), _stream()), 'loans_mul_f32')
+        check(lib.loans_mul_f32(_ptr(dw), _ptr(geo.wmask(x.device)), _ptr(dw), dw.numel(), st), 'loans_mul_f32')
 
 
 # --------------------------------------------------------------------------- #

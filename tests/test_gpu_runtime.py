@@ -154,7 +154,8 @@ def test_weight_gradients_rotate_over_their_streams(monkeypatch):
         monkeypatch.setattr(ops, '_WGRAD_STREAMS_ENV', n)
         used = []
         real = ops._conv_wgrad
-        monkeypatch.setattr(ops, '_conv_wgrad', lambda *a, **k: (used.append(torch.cuda.current_stream().cuda_stream), real(*a, **k))[1])
+        # (a tuned weight gradient is launched on its side stream by handle: `stream=`, not torch's current stream)
+        monkeypatch.setattr(ops, '_conv_wgrad', lambda *a, **k: (used.append(k.get('stream') or torch.cuda.current_stream().cuda_stream), real(*a, **k))[1])
         dws = [torch.zeros(64, 3, 3, 64, device='cuda') for _ in gys]
         for gy, dw in zip(gys, dws):
             ops.conv_wgrad(x, gy, dw, geo)
