@@ -1192,7 +1192,7 @@ def conv_wgrad(x, gy, dw, geo, relu_in=False, splits=0, tile=0):
         x.record_stream(side)
         gy.record_stream(side)
         _side_dirty.add(x.device.index)
-        if tuned and not geo.dense:
+        if tuned and not geo.dense and WGRAD_BY_HANDLE:
             # the launch goes to the side stream by handle: making it torch's current stream (a context manager: two Python-level
             # stream switches per weight gradient) cost 2 ms of host time per ResNet-50 step; nothing is allocated on this path
             _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile, stream=side.cuda_stream)
@@ -1203,6 +1203,7 @@ def conv_wgrad(x, gy, dw, geo, relu_in=False, splits=0, tile=0):
     _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile)
 
 
+WGRAD_BY_HANDLE = os.environ.get('LOANS_WGRAD_BY_HANDLE', '1') != '0'
 _stream_objs = {}
 
 
