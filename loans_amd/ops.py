@@ -117,7 +117,8 @@ BN_DECAY = 0.9
 RUNNING_VAR_INCLUDES_EPS = 1
 
 
-_raw_stream, _raw_device = torch._C._cuda_getCurrentRawStream, torch._C._cuda_getDevice
+_raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None) or (lambda idx: torch.cuda.current_stream(idx).cuda_stream)
+_raw_device = getattr(torch._C, '_cuda_getDevice', None) or torch.cuda.current_device
 
 
 def _stream():
@@ -140,6 +141,8 @@ def _memo(fn):
         try:
             return cache[key]
         except KeyError:
+            if len(cache) >= 8192:      # (keys hold their geometries alive: a process that keeps making new ones starts over)
+                cache.clear()
             v = cache[key] = fn(*args)
             return v
         except TypeError:               # an unhashable argument: not memoised
