@@ -117,6 +117,13 @@ BN_DECAY = 0.9
 RUNNING_VAR_INCLUDES_EPS = 1
 
 
+def _variant(geo, *what):
+    """key of geo.tuned under which a wrapper keeps the tile it resolved for one call variant (which flags, which switches):
+    later calls skip building the candidate lists, the mode string and the tuning closure -- pure host time, 600 convolution
+    calls per ResNet-50 step.  Lives in geo.tuned, so whatever clears a shape's picks clears these too; never saved to a table."""
+    return '~%r' % ((what, SPLITK, HALO, WGHALO, CLASS_LAUNCH, FINETAIL, STEM_DIRECT, COMPUTE, STORAGE, WGRAD_CUS_OF_8, TUNE_POLICY),)
+
+
 _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None) or (lambda idx: torch.cuda.current_stream(idx).cuda_stream)
 _raw_device = getattr(torch._C, '_cuda_getDevice', None) or torch.cuda.current_device
 
@@ -198,7 +205,8 @@ def _tune_stamp():
 
 def save_tune_table(path):
     import json
-    table = {_tune_key_str(k): dict(v) for k, v in sorted(_TUNE_CACHE.items()) if v}
+    table = {_tune_key_str(k): {m: t for m, t in v.items() if not m.startswith('~')} for k, v in sorted(_TUNE_CACHE.items()) if v}
+    table = {k: v for k, v in table.items() if v}
     with open(path, 'w') as f:
         json.dump({"what": "loans_amd tile table: (B,H,W,Cin,Cout,k,stride,pad,dense) -> {mode: tile id | splits << 8 | class launch << 16}",
                    "stamp": _tune_stamp(), "entries": table}, f, indent=1, sort_keys=True)
@@ -645,6 +653,9 @@ def conv_fprop(x, w, geo, out=None, bias=None, stats=None, relu_in=False, addend
             (F_STATS if stats is not None else 0) | (F_ADDEND if addend is not None else 0) | geo.base_flags
     assert x.numel() == geo.in_numel and w.numel() == geo.w_numel
     if tile == 0:
+        vkey = _variant(geo, 'fprop', stats is not None, out_bf16, addend is None, relu_in, bias is not None)
+        tile = geo.tuned.get(vkey, 0)
+    if tile == 0:
         tflags = flags & (F_RELU_IN | F_STATS | F_DENSE | F_OUT_BF16)
         sstats = stats_buffer(geo.Cout, x.device) if stats is not None else None
 
@@ -671,6 +682,7 @@ def conv_fprop(x, w, geo, out=None, bias=None, stats=None, relu_in=False, addend
         tile = _tuned_tile(geo, COMPUTE + 'fprop' + ('_stats' if stats is not None else '') + ('_sk' if sk else '') +
                            ('_ft' if ft else '') + ('_st' if stem else ''), run,
                            _FPROP_TILES + sk + ft + stem)   # fp32 scratch output: the tile choice carries over
+        geo.tuned[vkey] = tile
     d = _with_flags(geo.fwd, flags, tile)
     _count_flops('fprop', geo)
     log = EVENT_LOG
@@ -726,6 +738,9 @@ def conv_fprop_pair(x, w_a, w_b, geo_a, geo_b, stats_a=None, stats_b=None, tile=
     out_a, out_b = mk(geo_a), mk(geo_b)
     flags = F_STATS if stats_a is not None else 0
     if tile == 0:
+        vkey = _variant(geo_a, 'pair', geo_b.Cout, flags)
+        tile = geo_a.tuned.get(vkey, 0)
+    if tile == 0:
         sa = stats_buffer(geo_a.Cout, x.device) if flags else None
         sb = stats_buffer(geo_b.Cout, x.device) if flags else None
         ta, tb = mk(geo_a), mk(geo_b)
@@ -734,6 +749,7 @@ def conv_fprop_pair(x, w_a, w_b, geo_a, geo_b, stats_a=None, stats_b=None, tile=
             check(lib.loans_igemm_pair_f32(_ptr(x), _ptr(w_a), _ptr(ta), _ptr(sa), _ptr(w_b), _ptr(tb), _ptr(sb), geo_b.Cout,
                                            C.byref(_with_flags(geo_a.fwd, flags, t)), _stream()), 'loans_igemm_pair_f32[tune]')
         tile = _tuned_tile(geo_a, 'f32fprop_pair%d%s' % (geo_b.Cout, '_stats' if flags else ''), run, _PAIR_TILES)
+        geo_a.tuned[vkey] = tile
     _count_flops('fprop', geo_a)
     _count_flops('fprop', geo_b)
     log = EVENT_LOG
@@ -763,6 +779,9 @@ def _conv_fprop_pair16(lib, x, w_a, w_b, geo_a, geo_b, stats_a, stats_b, tile):
     flags = F_STATS if stats_a is not None else 0
     mk = lambda: torch.empty((2, geo_a.B, geo_a.Ho, geo_a.Wo, geo_a.Cout), device=x.device, dtype=BF16)      # noqa: E731
     if tile == 0:
+        vkey = _variant(geo_a, 'pair16', flags)
+        tile = geo_a.tuned.get(vkey, 0)
+    if tile == 0:
         sa = stats_buffer(geo_a.Cout, x.device) if flags else None
         sb = stats_buffer(geo_a.Cout, x.device) if flags else None
         scratch = mk()
@@ -772,6 +791,7 @@ def _conv_fprop_pair16(lib, x, w_a, w_b, geo_a, geo_b, stats_a, stats_b, tile):
                                              C.byref(_with_flags(geo_a.fwd, flags, t)), _stream()), 'loans_igemm_pair_bf16s[tune]')
         tile = _tuned_tile(geo_a, 'bf16s_fprop_pair' + ('_stats' if flags else ''), run,
                            _PAIR16_TILES + _wide16_tiles(2 * geo_a.Cout, geo_a.B * geo_a.Ho * geo_a.Wo))
+        geo_a.tuned[vkey] = tile
     out = mk()
     _count_flops('fprop', geo_a)
     _count_flops('fprop', geo_b)
@@ -801,6 +821,9 @@ def _conv_fprop16(lib, x, w, geo, out, bias, stats, relu_in, addend, tile):
     flags = (F_RELU_IN if relu_in else 0) | (F_BIAS if bias is not None else 0) | (F_STATS if stats is not None else 0) | \
             (F_ADDEND if addend is not None else 0) | geo.base_flags
     if tile == 0:
+        vkey = _variant(geo, 'fprop16', stats is not None, relu_in, addend is None, bias is not None)
+        tile = geo.tuned.get(vkey, 0)
+    if tile == 0:
         tflags = flags & (F_STATS | F_RELU_IN | F_DENSE)
         sstats = stats_buffer(geo.Cout, x.device) if stats is not None else None
 
@@ -819,6 +842,7 @@ def _conv_fprop16(lib, x, w, geo, out, bias, stats, relu_in, addend, tile):
         tile = _tuned_tile(geo, 'bf16s_fprop' + ('_stats' if stats is not None else '') + ('_h' if halo else '') +
                            ('_sk' if sk else '') + ('_st' if stem else '') + ('_relu' if relu_in else ''), run,
                            _IGEMM16_TILES + halo + sk + stem)
+        geo.tuned[vkey] = tile
     d = _with_flags(geo.fwd, flags, tile)
     _count_flops('fprop', geo)
     log = EVENT_LOG
@@ -874,6 +898,9 @@ def _conv_dgrad16(lib, gy, w, geo, out, mask_ref, addend, addend_mask_ref, tile,
     # take the addend, handled above by a copy) and an addend aliasing `out` do not go through it
     sk_ok = not geo.dgrad_has_empty_class and not (addend is not None and addend.data_ptr() == out.data_ptr())
     if tile == 0:
+        vkey = _variant(geo, 'dgrad16', sk_ok, bn_sums is not None)
+        tile = geo.tuned.get(vkey, 0)
+    if tile == 0:
         def run(t):
             scratch = torch.empty((geo.B, geo.H, geo.W, geo.Cin), device=gy.device, dtype=BF16)
             if t >> 8:
@@ -891,6 +918,7 @@ def _conv_dgrad16(lib, gy, w, geo, out, mask_ref, addend, addend_mask_ref, tile,
             halo = tuple(t for t in halo if t != TILE_WS64)
         tile = _tuned_tile(geo, 'bf16s_dgrad' + ('_h' if halo else '') + ('_sk' if sk else '') + ('_bn' if bn_sums is not None else ''),
                            run, _IGEMM16_TILES + halo + sk)
+        geo.tuned[vkey] = tile
     if tile >> 8:
         assert sk_ok and bn_sums is None
         _igemm16_splitk(lib, gy, dl, out, flags, tile, None, None, ref, addend, rows_in, geo.Cin, st)
@@ -968,6 +996,9 @@ def conv_dgrad(gy, w, geo, out=None, mask_ref=None, addend=None, addend_mask_ref
     dl = [(d, wp[off:]) for d, _, off in geo.dgrad]
     rows_in = geo.B * geo.H * geo.W
     if tile == 0:
+        vkey = _variant(geo, 'dgrad', bn_sums is not None, inplace_masked)
+        tile = geo.tuned.get(vkey, 0)
+    if tile == 0:
         def run(t):
             scratch = torch.empty((geo.B, geo.H, geo.W, geo.Cin), device=gy.device, dtype=torch.float32)
             if t & TILE_CLASSES:
@@ -989,6 +1020,7 @@ def conv_dgrad(gy, w, geo, out=None, mask_ref=None, addend=None, addend_mask_ref
             sk = _splitk_candidates(cls_rows, geo.Cin, (min(d.ntaps for d, _, _ in geo.dgrad) * geo.Cout + 31) // 32)
             cands, key = cands + sk, key + ('_sk' if sk else '')
         tile = _tuned_tile(geo, key, run, cands)
+        geo.tuned[vkey] = tile
     if tile & TILE_CLASSES:
         _igemm_classes(lib, gy, wp, out, geo, flags, tile & 0xFF, ref, addend, st)
         return out
@@ -1295,6 +1327,9 @@ def _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile, stream=None):
         assert _is16(gy) == s16, 'x and gy must share their storage type'
     wfn = lib.loans_wgrad_bf16s if s16 else (lib.loans_wgrad_bf16_f32 if COMPUTE == 'bf16' else lib.loans_wgrad_f32)
     if tile == 0:
+        vkey = _variant(geo, 'wgrad', s16, _is16(gy), relu_in, splits)
+        tile = geo.tuned.get(vkey, 0)
+    if tile == 0:
         def run(t):
             scratch = torch.empty(dw.numel(), device=x.device, dtype=torch.float32)
             check(wfn(_ptr(x), _ptr(gy), _ptr(scratch), C.byref(_with_flags(geo.fwd, fl, t & 0xFF)), (t >> 8) or splits,
@@ -1311,6 +1346,7 @@ def _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile, stream=None):
             cands = tuple(cands) + (TILE_STEM,)
         tile = _tuned_tile(geo, _wgrad_key(x, gy, relu_in) + ('' if splits == 0 else '_s%d' % splits) + ('_st' if stem else ''),
                            run, cands)
+        geo.tuned[vkey] = tile
     if tile >> 8:
         tile, splits = tile & 0xFF, tile >> 8
     d = _with_flags(geo.fwd, fl, tile)
