@@ -352,3 +352,30 @@ def test_fixed_tile_policy_is_deterministic_and_never_times(monkeypatch):
     finally:
         ops._TUNE_LOADED.pop(g.key)
         g.tuned.clear()
+
+
+def test_resolved_variants_live_with_the_tile_picks_and_stay_out_of_tables(tmp_path, monkeypatch):
+    """ops._variant (round 4): a convolution wrapper keeps the tile it resolved for one call variant under a '~' key of
+    geo.tuned, so that tuned calls build no candidate lists.  Those keys depend on the module's switches (another switch
+    state resolves afresh), die with the shape's picks, and are never written to a tile table."""
+    import json
+    from loans_amd import ops
+    g = ops.ConvGeometry(5, 20, 24, 64, 64, 3, 1, 1)
+    g.tuned.clear()
+    k1 = ops._variant(g, 'fprop16', True, False, True, False)
+    assert k1.startswith('~') and k1 == ops._variant(g, 'fprop16', True, False, True, False)
+    assert k1 != ops._variant(g, 'fprop16', False, False, True, False)
+    monkeypatch.setattr(ops, 'SPLITK', not ops.SPLITK)
+    assert ops._variant(g, 'fprop16', True, False, True, False) != k1           # another switch state: resolved afresh
+    monkeypatch.undo()
+    g.tuned.update({k1: 7, 'bf16s_fprop_stats': 7})
+    path = str(tmp_path / 'tune.json')
+    ops.save_tune_table(path)
+    saved = json.load(open(path))['entries'][ops._tune_key_str(g.key)]
+    assert saved == {'bf16s_fprop_stats': 7}                                     # the variant key stays in the process
+    g.tuned.clear()                                                              # (what conftest's timed_autotune fixture does)
+    assert ops.ConvGeometry(5, 20, 24, 64, 64, 3, 1, 1).tuned == {}
+    # the memoised candidate functions follow the switches too
+    a = ops._class_candidates(ops.ConvGeometry(4, 56, 56, 64, 128, 3, 2, 1))
+    monkeypatch.setattr(ops, 'CLASS_LAUNCH', False)
+    assert a and ops._class_candidates(ops.ConvGeometry(4, 56, 56, 64, 128, 3, 2, 1)) == ()
