@@ -140,12 +140,12 @@ def parse_args(argv=None):
     parser.add_argument("--port", type=int, default=1337, help="(BBOXPlotter: accepted, not used)")
     parser.add_argument("--test-image", help="(BBOXPlotter: accepted, not used)")
     parser.add_argument("--anchor-image", help="(accepted, not used)")
-    parser.add_argument("--rl", dest="resume_localizer", help="path to snapshot that is to be used to resume training of localizer")
-    parser.add_argument("--rd", dest="resume_discriminator", help="path to snapshot that is to be used to pre-initialize discriminator")
-    parser.add_argument("--use-resnet-18", action='store_true', default=False, help="Use Resnet-18 for localization")
-    parser.add_argument("--localizer-target", type=float, default=1.0, help="target iou for localizer to reach in the interval [0,1]")
+    parser.add_argument("--rl", dest="resume_localizer", help="localizer snapshot (.npz) to start from (reference --rl)")
+    parser.add_argument("--rd", dest="resume_discriminator", help="assessor snapshot (.npz) to start from; also FREEZES the assessor (reference --rd)")
+    parser.add_argument("--use-resnet-18", action='store_true', default=False, help="ResNet-18-variant localizer (sheep/resnet.py) instead of the ResNet-50 one")
+    parser.add_argument("--localizer-target", type=float, default=1.0, help="the IoU score the localizer is trained towards, in [0, 1]")
     parser.add_argument("--no-imgaug", action='store_false', dest='use_imgaug', default=True,
-                        help="disable image augmentation with `imgaug`, but use naive image augmentation instead")
+                        help="the naive crop / flip augmentation instead of the imgaug pipeline")
     # ---- extensions ----
     parser.add_argument("--validation", dest='validation', action='store_true', help="(default; kept for older command lines)")
     parser.add_argument("--iterations", type=int, default=None, help="stop after this many iterations (before --num-epoch epochs)")
