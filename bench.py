@@ -393,12 +393,17 @@ def run_workload(w, comm, local_rank, retune):
     ops.FLOP_COUNT = {} if rank == 0 else None         # algorithmic FLOP of every convolution launch of the timed steps
     comm.barrier()
     torch.cuda.synchronize()
+    mem0 = torch.cuda.memory_stats(dev)
     t0 = time.perf_counter()
     for _ in range(w.steps):
         updater.update()
     torch.cuda.synchronize()
     comm.barrier()
     elapsed = comm.allreduce_max(time.perf_counter() - t0)
+    mem1 = torch.cuda.memory_stats(dev)
+    # diagnostics only (measurement hygiene): device allocations / allocator retries INSIDE the timed region -- a
+    # steady-state step should make none (everything comes from torch's cache); a hipMalloc / hipFree there synchronises the device
+    allocator = {k: int(mem1.get(k, 0) - mem0.get(k, 0)) for k in ('num_device_alloc', 'num_device_free', 'num_alloc_retries')}
     log, ops.EVENT_LOG = ops.EVENT_LOG, None
     flop_count, ops.FLOP_COUNT = ops.FLOP_COUNT, None
 
@@ -442,6 +447,7 @@ def run_workload(w, comm, local_rank, retune):
                    "crop": "3x%dx%d" % (crop, crop), "parallelism": "dp%d" % world, "world_size": world, "dist_backend": comm.backend,
                    "baseline_config": config_label(w, world), "hip_graph": bool(w.graph), "init_steps": init_steps,
                    "host_enqueue_ms_per_step": round(host_enqueue_ms, 3),
+                   "allocator_in_timed_region": allocator,
                    "activation_storage": w.storage,
                    "tune_table": ("read %d shapes from %s" % (tune_loaded, os.path.relpath(tune_file, ROOT))) if tune_loaded
                    else "autotuned in this run"},
