@@ -239,7 +239,7 @@ def conv_forward_roofline(w, log, flop_count, ev_overhead_ms, ms_per_step, world
     if w.dtype != 'bf16':
         kernels = "igemm_kernel + stem7_kernel"
     elif w.resnet50:
-        kernels = "igemm16_kernel (1x1 and 3x3) + halo16 kernels + stem7_bf16_kernel"
+        kernels = "igemm16_kernel (1x1 and 3x3) + halo16 kernels + pw16_kernel (res2 / res3 expansions) + stem7_bf16_kernel"
     else:
         kernels = "igemm16_kernel + halo16 / ws8 / wsw kernels + stem7_bf16_kernel"
     roofline = {"bound": "mfma", "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",

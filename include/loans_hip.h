@@ -133,6 +133,11 @@ typedef struct loans_igemm_desc {
                                       input channels x ALL nine taps and walks 8 x 16 pixel tiles; gradient tile and input halo tile staged once per
                                       tile, a tap is a window shift in LDS (csrc/wgrad_halo_bf16.hip).  splits = blocks per channel-tile pair */
 #define LOANS_TILE_WGHALO_128  39  /* the same with 128 output channels per block on eight waves (Cout % 128 == 0) */
+#define LOANS_TILE_PW          40  /* loans_igemm_bf16s, 1 x 1 / 1 forward geometries with Cin in {64, 128}, Cout % 64 == 0, Cout <= 512, flags STATS or none
+                                      (ResNet-50's res2 / res3 bottleneck expansions): a wave owns 32-pixel strips, operands go global -> VGPR
+                                      in MFMA fragment layout (never through LDS), output rows leave through a per-wave LDS slab; `w` must be
+                                      the weights in FRAGMENT ORDER (loans_pw_pack_bf16).  Outputs bit-identical to the other tiles
+                                      (csrc/pw_bf16.hip) */
 #define LOANS_TILE_HALO_256x64 12  /* 16 x 16 pixels x 64 output channels, Cin = 64 (one chunk): the res2 convolutions */
 #define LOANS_TILE_SPLITK(s) ((s) << 8) /* loans_igemm_f32, OR-ed onto a tile shape, s = 2..255: split-K for small grids (few tiles, long K:
                                   the deep layers at small batch, single-image inference).  Block (tile, i) contracts every s-th
@@ -206,6 +211,10 @@ int loans_wgrad_bf16_f32(const float* x, const float* gy, float* dw,
  * dx[] count bf16 ELEMENTS and must be even (the 16-byte K units are then 4-byte aligned), Cin % 8 == 0. */
 int loans_igemm_bf16s(const void* in, const void* w, void* out, const float* bias, double* stats,
                       const void* ref, const void* addend, const loans_igemm_desc* d, void* stream);
+/* The weights of a 1 x 1 convolution, [Cout][Cin] bf16, in the order LOANS_TILE_PW reads them -- one 1 KiB block per (32 output
+ * channels, 16 input channels) MFMA B fragment: packed[((nt * Cin / 16 + ks) * 64 + lane) * 8 + j] =
+ * w[nt * 32 + lane % 32][ks * 16 + lane / 32 * 8 + j].  Cout % 32 == 0, Cin % 16 == 0; `packed` holds Cout x Cin bf16. */
+int loans_pw_pack_bf16(const void* w, void* packed, int32_t Cout, int32_t Cin, void* stream);
 /* Two forward convolutions of the SAME bf16 input with the same geometry AND the same channel count (BasicA's conv1 and its
  * strided conv shortcut, sheep/resnet.py:128-133) as ONE GEMM with 2 x Cout columns: w_ab = [2][Cout][ntaps][Cin] (a's
  * matrix, then b's), out_ab = [2][B][outH][outW][Cout] (two ordinary tensors back to back).  Unlike loans_igemm_pair_f32

@@ -67,6 +67,7 @@ SIGNATURES = {
     'loans_igemm_f32': [_p, _p, _p, _p, _p, _p, _p, C.POINTER(IgemmDesc), _p],
     'loans_igemm_classes_f32': [_p, C.POINTER(_p), _p, _p, _p, C.POINTER(IgemmDesc), _i32, _p],
     'loans_igemm_pair_bf16s': [_p, _p, _p, _p, _p, C.POINTER(IgemmDesc), _p],
+    'loans_pw_pack_bf16': [_p, _p, C.c_int32, C.c_int32, _p],
     'loans_igemm_pair_f32': [_p, _p, _p, _p, _p, _p, _p, _i32, C.POINTER(IgemmDesc), _p],
     'loans_igemm_finalize_f32': [_p, _p, _p, _p, _p, _i32, _i64, _i32, _p],
     'loans_igemm_bf16_f32': [_p, _p, _p, _p, _p, _p, _p, C.POINTER(IgemmDesc), _p],

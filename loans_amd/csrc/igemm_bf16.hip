@@ -1047,6 +1047,10 @@ static int igemm_bf16s_impl(const void* in, const void* w, void* out, const floa
         if (partial || splits > 1) return LOANS_EINVAL;
         return loans_stem7_bf16s_launch(in, w, out, bias, stats, d, st);
     }
+    if (tile == LOANS_TILE_PW) {            // short-K 1 x 1 convolutions, operands never in LDS (pw_bf16.hip); w in fragment order
+        if (partial || splits > 1 || pair) return LOANS_EINVAL;
+        return loans_pw16_launch(in, w, out, stats, d, st);
+    }
     switch (tile) {
         case LOANS_TILE_128x128: return launch_igemm16<128, 128, 2, 2>(a, st);
         case LOANS_TILE_128x64: return launch_igemm16<128, 64, 2, 2>(a, st);

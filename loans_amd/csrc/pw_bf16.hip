@@ -1,0 +1,201 @@
+// LOANS_TILE_PW: the 1 x 1 / 1 convolutions with a SHORT K and a wide output -- ResNet-50's bottleneck expansions of res2 / res3
+// (common/net.py:59-66 via sheep/resnet.py's ResNet-50 block: conv3 64 -> 256 at 128 x 128, 128 -> 512 at 64 x 64), whose bytes
+// are four fifths output.  The implicit-GEMM tiles of igemm_bf16.hip stage both operands in LDS, contract, and then run a two-pass
+// epilogue, one block per CU, in sequence: 0.50 / 0.44 of the HBM bound on those two layers (profiles/r4_r50_bench.json).
+//
+// This form keeps NO operand in LDS.  A wave owns strips of 32 pixels: the strip's A fragments (32 x K bf16) go global -> VGPR
+// once, 16 bytes per lane and K step, which IS the 32x32x16 MFMA operand layout; the weight fragments (N x K x 2 <= 128 KB: L1 / L2
+// resident) come global -> VGPR per use from a copy in FRAGMENT ORDER (loans_pw_pack_bf16: one coalesced 1 KiB load per fragment;
+// from the [Cout][Cin] layout the same loads touch 32 rows x 32 bytes and the kernel is a third slower, tools/pw_probe.hip), one
+// 32 x 32 accumulator tile at a time, the next tile's fragments requested before this tile's MFMAs; a finished tile is rounded,
+// transposed through a per-wave LDS slab that holds HALF a pixel row ([32][N / 2 + 8] bf16) and written as runs of N bytes per
+// pixel, non-temporal when the output is large; the next strip's A fragments are in flight under the second half's stores.  No
+// block barrier in the loop: up to 16 waves per CU drift apart and cover each other's latencies.  BN statistics (LOANS_F_STATS)
+// are the fp32 accumulators' sums: per tile and lane over 16 rows in fp32 (a fixed order), from there in DOUBLE -- per block in LDS
+// (ds_add_f64), once per block with fp64 atomics into the block's replica -- so that, like the tiled kernels' sums, they do not
+// depend on the order in which waves and blocks arrive (fp32 LDS atomics made the BN statistics, and with them the whole forward,
+// differ in the last bit from run to run).  The products and their order (K
+// ascending from a zero accumulator) are those of loans_igemm_bf16s' other tiles: the outputs are bit-identical to theirs.
+#include "common.h"
+
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+template <int K, int NC, bool STATS, int OCC>
+__global__ __launch_bounds__(256, OCC) void pw16_kernel(const __bf16* __restrict__ A, const u32x4* __restrict__ W,
+                                                                   __bf16* __restrict__ out, double* __restrict__ stats, int M, int N_,
+                                                                   int nstrips, int nt_out) {
+    const int N = NC ? NC : N_;             // NC != 0: the column count is a compile-time constant (slab rows at immediate offsets)
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int KS = K / 16;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int half = N / 2, pitch = half + 8;        // bf16 elements per staged half pixel row
+    double* sums = reinterpret_cast<double*>(smem);  // [2][N], only with stats
+    __bf16* slab = reinterpret_cast<__bf16*>(smem + (STATS ? (size_t)2 * N * sizeof(double) : 0)) + (size_t)wave * 32 * pitch;
+    const int wave_id = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
+    const int upr = half / 8, tiles_half = half / 32;
+    if (STATS) {
+        for (int i = threadIdx.x; i < 2 * N; i += 256) sums[i] = 0.0;
+        __syncthreads();
+    }
+    auto load_a = [&](int s, u32x4* a) {
+        // rows past M (the ragged last strip) are zero operands: their accumulators are zero -- nothing for the sums, never stored
+        const bool live = s * 32 + r < M;
+        const int row = live ? s * 32 + r : M - 1;
+        const u32x4 zero = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const u32x4 v = *reinterpret_cast<const u32x4*>(A + (size_t)row * K + ks * 16 + h * 8);
+            a[ks] = live ? v : zero;
+        }
+    };
+    auto load_w = [&](int nt, u32x4* b) {           // fragment order (loans_pw_pack_bf16): one coalesced 1 KiB load per fragment
+        const u32x4* wf = W + (size_t)nt * KS * 64 + lane;
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) b[ks] = wf[ks * 64];
+    };
+    u32x4 a[KS], an[KS];
+    if (wave_id < nstrips) load_a(wave_id, a);
+    for (int s = wave_id; s < nstrips; s += nwaves) {
+        const int m0 = s * 32;
+        u32x4 b[KS], bn[KS];
+        load_w(0, b);
+#pragma unroll 1
+        for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll 1
+            for (int t = 0; t < tiles_half; ++t) {
+                const int nt = hf * tiles_half + t;
+                load_w(nt + 1 < N / 32 ? nt + 1 : 0, bn);          // (the last request wraps to tile 0: the next strip's first)
+                f32x16 acc;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[ks]), __builtin_bit_cast(bf16x8_t, b[ks]), acc, 0, 0, 0);
+                __bf16* col = slab + 4 * h * pitch + t * 32 + r;         // this lane's column of the slab; its 16 rows at fixed offsets
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) {
+                    const f32x2 v = {acc[e], acc[e + 1]};
+                    const bf16x2_t p = __builtin_convertvector(v, bf16x2_t);
+                    col[((e & 3) + 8 * (e >> 2)) * pitch] = p[0];
+                    col[((e & 3) + 1 + 8 * (e >> 2)) * pitch] = p[1];
+                }
+                if (STATS) {
+                    f32x2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};             // (v_pk_add_f32 / v_pk_fma_f32: the kernel is VALU-issue bound)
+#pragma unroll
+                    for (int e = 0; e < 16; e += 2) {
+                        const f32x2 v = {acc[e], acc[e + 1]};
+                        s2 += v;
+                        q2 = v * v + q2;
+                    }
+                    // v_permlane32_swap: (sum, squares) of the two half-waves -> lanes 0..31 hold the channel's sum over all 32 rows,
+                    // lanes 32..63 its sum of squares; ONE ds_add_f64 on 64 distinct addresses (no LDS round trip to wait for)
+                    // (as inline assembly: this compiler's __builtin_amdgcn_permlane32_swap returns its first result twice; the
+                    // s_nop cover the VALU-write -> swap and swap -> VALU-read wait states the compiler no longer sees)
+                    float sm = s2[0] + s2[1], sq = q2[0] + q2[1];
+                    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(sm), "+v"(sq));
+                    atomic_add_f64(sums + h * N + nt * 32 + r, (double)(sm + sq));
+                }
+#pragma unroll
+                for (int ks = 0; ks < KS; ++ks) b[ks] = bn[ks];
+            }
+            if (hf == 1 && s + nwaves < nstrips) load_a(s + nwaves, an);     // in flight under the store phase
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int u = lane; u < 32 * upr; u += 64) {
+                const int pr = u / upr, cu = u - pr * upr;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(slab + pr * pitch + cu * 8);
+                if (m0 + pr < M) {
+                    u32x4* dst = reinterpret_cast<u32x4*>(out + (size_t)(m0 + pr) * N + hf * half + cu * 8);
+                    if (nt_out) __builtin_nontemporal_store(v, dst);
+                    else *dst = v;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) a[ks] = an[ks];
+    }
+    if (STATS) {
+        __syncthreads();
+        double* st = stats + (size_t)(blockIdx.x % LOANS_STATS_REPLICAS) * 2 * N;
+        for (int i = threadIdx.x; i < 2 * N; i += 256)
+            if (sums[i] != 0.0) atomic_add_f64(st + i, sums[i]);
+    }
+}
+
+// weights [Cout][Cin] bf16 -> fragment order: packed[((nt * KS + ks) * 64 + lane) * 8 + j] = w[nt * 32 + (lane & 31)][ks * 16 + (lane >> 5) * 8 + j]
+__global__ __launch_bounds__(256) void pw16_pack_kernel(const u32x4* __restrict__ w, u32x4* __restrict__ packed, int N, int K) {
+    const int KS = K / 16, total = N / 32 * KS * 64;
+    for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+        const int lane = i & 63, f = i >> 6, ks = f % KS, nt = f / KS;
+        packed[i] = w[((size_t)(nt * 32 + (lane & 31)) * K + ks * 16 + (lane >> 5) * 8) / 8];
+    }
+}
+
+extern "C" int loans_pw_pack_bf16(const void* w, void* packed, int32_t Cout, int32_t Cin, void* stream) {
+    if (!w || !packed || Cout <= 0 || Cout % 32 != 0 || Cin <= 0 || Cin % 16 != 0) return LOANS_EINVAL;
+    const int total = Cout / 32 * (Cin / 16) * 64;
+    hipLaunchKernelGGL(pw16_pack_kernel, dim3(grid_for(total, 256, 64)), dim3(256), 0, as_stream(stream), static_cast<const u32x4*>(w),
+                       static_cast<u32x4*>(packed), Cout, Cin);
+    LOANS_LAUNCH_CHECK();
+    return LOANS_OK;
+}
+
+// what LOANS_TILE_PW covers: a 1 x 1 / 1 forward geometry (grid = input = output pixels), Cin in {64, 128}, Cout a multiple of 64
+// up to 512, flags STATS or none
+int loans_pw16_covers(const loans_igemm_desc* d) {
+    if (d->ntaps != 1 || d->dy[0] != 0 || d->dx[0] != 0) return 0;
+    if (d->isy != 1 || d->isx != 1 || d->osy != 1 || d->osx != 1 || d->oy0 != 0 || d->ox0 != 0) return 0;
+    if (d->gridH != d->inH || d->gridW != d->inW || d->gridH != d->outH || d->gridW != d->outW) return 0;
+    if (d->Cin != 64 && d->Cin != 128) return 0;
+    if (d->Cout % 64 != 0 || d->Cout < 64 || d->Cout > 512) return 0;
+    if (d->flags & ~LOANS_F_STATS) return 0;
+    return 1;
+}
+
+template <int K, int NC, bool STATS, int OCC>
+static int pw16_launch_n(const void* in, const void* w, void* out, double* stats, int M, int N, int nt_out, hipStream_t st) {
+    static loans_device_once lds_limit_set;
+    const int nstrips = (M + 31) / 32;
+    const size_t lds = (size_t)4 * 32 * (N / 2 + 8) * 2 + (STATS ? (size_t)2 * N * sizeof(double) : 0);
+    const void* kern = reinterpret_cast<const void*>(pw16_kernel<K, NC, STATS, OCC>);
+    if (lds > 64 * 1024) {
+        const int rc = loans_raise_lds_limit(lds_limit_set, kern, 80 * 1024);
+        if (rc != LOANS_OK) return rc;
+    }
+    const int cus = loans_device_cus();
+    if (cus <= 0) return LOANS_EINVAL;
+    int blocks = cus * OCC;
+    if (blocks > (nstrips + 3) / 4) blocks = (nstrips + 3) / 4;
+    hipLaunchKernelGGL((pw16_kernel<K, NC, STATS, OCC>), dim3(blocks), dim3(256), lds, st, static_cast<const __bf16*>(in), static_cast<const u32x4*>(w),
+                       static_cast<__bf16*>(out), stats, M, N, nstrips, nt_out);
+    LOANS_LAUNCH_CHECK();
+    return LOANS_OK;
+}
+
+// the two shapes of the ResNet-50 localizer (N = 4 K) have the column count folded into the code
+template <int K, bool STATS>
+static int pw16_launch_k(const void* in, const void* w, void* out, double* stats, int M, int N, int nt_out, hipStream_t st) {
+    // resident blocks per CU: K = 64: 4 (<= 128 VGPRs; the statistics form with a run-time N needs 141: 3), K = 128: 2
+    constexpr int OCC = K <= 64 ? 4 : 2;
+    if (N == 4 * K) return pw16_launch_n<K, 4 * K, STATS, OCC>(in, w, out, stats, M, N, nt_out, st);
+    return pw16_launch_n<K, 0, STATS, (K <= 64 && STATS) ? 3 : OCC>(in, w, out, stats, M, N, nt_out, st);
+}
+
+int loans_pw16_launch(const void* in, const void* w, void* out, double* stats, const loans_igemm_desc* d, hipStream_t st) {
+    if (!loans_pw16_covers(d)) return LOANS_EINVAL;
+    const int64_t M64 = (int64_t)d->B * d->gridH * d->gridW;
+    if (M64 <= 0 || M64 > 0x7FFFFFFF - 64) return LOANS_ERANGE;
+    const int M = (int)M64, N = d->Cout;
+    double* stp = (d->flags & LOANS_F_STATS) ? stats : nullptr;
+    const int nt_out = loans_conv_nt((size_t)M * N * 2);
+    if ((d->flags & LOANS_F_STATS) && !stats) return LOANS_EINVAL;
+    if (d->Cin == 64)
+        return stp ? pw16_launch_k<64, true>(in, w, out, stp, M, N, nt_out, st) : pw16_launch_k<64, false>(in, w, out, stp, M, N, nt_out, st);
+    return stp ? pw16_launch_k<128, true>(in, w, out, stp, M, N, nt_out, st) : pw16_launch_k<128, false>(in, w, out, stp, M, N, nt_out, st);
+}

@@ -144,7 +144,7 @@ def _memo(fn):
         if kw:
             return fn(*args, **kw)
         key = (tuple(id(a) if isinstance(a, dict) else a for a in args), SPLITK, HALO, WGHALO, CLASS_LAUNCH, FINETAIL,
-               STEM_DIRECT, COMPUTE, STORAGE, WGRAD_CUS_OF_8)
+               STEM_DIRECT, COMPUTE, STORAGE, WGRAD_CUS_OF_8, PW)
         try:
             return cache[key]
         except KeyError:
@@ -378,6 +378,28 @@ TILE_WSW64 = 37              # weights stationary, every wave on its own 2 x 16 
 HALO = os.environ.get('LOANS_HALO', '1') != '0'
 
 
+TILE_PW = 40                 # LOANS_TILE_PW (csrc/pw_bf16.hip): short-K 1 x 1 convolutions, operands never in LDS
+PW = os.environ.get('LOANS_PW', '1') != '0'
+
+
+@_memo
+def _pw_tiles(geo, plain):
+    """LOANS_TILE_PW where loans_pw16_covers holds: a 1 x 1 / 1 convolution, Cin 64 or 128, Cout a multiple of 64 up to 512, no
+    epilogue beyond the BN statistics (plain = no ReLU on the input, no bias, no addend).  ResNet-50's res2 / res3 expansions."""
+    if not PW or not plain or geo.dense or geo.k != 1 or geo.stride != 1 or geo.pad != 0:
+        return ()
+    if geo.Cin not in (64, 128) or geo.Cout % 64 or geo.Cout > 512:
+        return ()
+    return (TILE_PW,)
+
+
+def _pw_packed(lib, w16, geo, st):
+    """the weights in LOANS_TILE_PW's fragment order (32 - 128 KB: one small launch per call)"""
+    packed = torch.empty(geo.Cout * geo.Cin, device=w16.device, dtype=BF16)
+    check(lib.loans_pw_pack_bf16(_ptr(w16), _ptr(packed), geo.Cout, geo.Cin, st), 'loans_pw_pack_bf16')
+    return packed
+
+
 TILE_256x256 = 9        # LOANS_TILE_256x256 (loans_igemm_bf16s): eight 128 x 64 wave tiles, for GEMMs with >= 256 columns
 
 
@@ -449,11 +471,11 @@ TUNE_COLD = os.environ.get('LOANS_TUNE_COLD', '0') != '0'
 _cold = {}
 
 
-def _time_call(fn, reps=5):
+def _time_call(fn, reps=5, cold=False):
     fn()
     best = float('inf')
     for _ in range(reps):
-        if TUNE_COLD:
+        if TUNE_COLD or cold:
             dev = torch.cuda.current_device()
             if dev not in _cold:
                 _cold[dev] = torch.empty(512 << 20, device='cuda', dtype=torch.uint8)
@@ -484,7 +506,7 @@ def _fixed_pick(geo, mode, candidates):
     return candidates[zlib.crc32(('%s|%s|%s' % (_tune_key_str(geo.key), mode, TUNE_SALT)).encode()) % len(candidates)]
 
 
-def _tuned_tile(geo, mode, run, candidates):
+def _tuned_tile(geo, mode, run, candidates, cold=False):
     """run(tile) launches the op into scratch buffers."""
     global TIMED_PICKS
     tile = geo.tuned.get(mode)
@@ -507,7 +529,7 @@ def _tuned_tile(geo, mode, run, candidates):
                 mode, geo.B, geo.H, geo.W, geo.Cin, geo.Cout, geo.k, geo.stride, tile, candidates), flush=True)
         return tile
     TIMED_PICKS += 1
-    times = {t: _time_call(lambda: run(t)) for t in candidates}
+    times = {t: _time_call(lambda: run(t), cold=cold) for t in candidates}
     tile = min(times, key=times.get)
     geo.tuned[mode] = tile
     if os.environ.get('LOANS_TUNE_VERBOSE'):
@@ -833,15 +855,20 @@ def _conv_fprop16(lib, x, w, geo, out, bias, stats, relu_in, addend, tile):
                 _igemm16_splitk(lib, x, [(geo.fwd, w16)], scratch, tflags, t, None, sstats, None, None,
                                 geo.B * geo.Ho * geo.Wo, geo.Cout, _stream())
                 return
-            check(lib.loans_igemm_bf16s(_ptr(x), _ptr(w16), _ptr(scratch), 0, _ptr(sstats), 0, 0,
+            wt = _pw_packed(lib, w16, geo, _stream()) if t == TILE_PW else w16        # (its packing launch is part of its price)
+            check(lib.loans_igemm_bf16s(_ptr(x), _ptr(wt), _ptr(scratch), 0, _ptr(sstats), 0, 0,
                                         C.byref(_with_flags(geo.fwd, tflags, t)), _stream()), 'loans_igemm_bf16s[tune]')
+        # where LOANS_TILE_PW is on offer the candidates are timed COLD (a 512 MB fill before every launch): these layers write four
+        # times what they read, and a back-to-back repetition flatters the tiles that re-read a cached input -- in the step the
+        # 256 x 256 tile takes 0.120 ms on res3's expansion and this one 0.096, timed warm it is 0.107 against 0.110
+        pw = _pw_tiles(geo, not relu_in and addend is None and bias is None)
         halo = _halo_tiles(geo, geo.Cin, geo.Cout, (geo.Ho, geo.Wo), relu_in) + _wide16_tiles(geo.Cout, geo.B * geo.Ho * geo.Wo)
         sk = () if geo.dense else _splitk16_candidates(geo.B * geo.Ho * geo.Wo, geo.Cout, geo.w_numel // geo.Cout)
         stem = (TILE_STEM,) if (STEM_DIRECT and geo.dense and not relu_in and addend is None and stem16_tile_rows(geo)) else ()
         # (relu_in is part of the key: the weight-stationary tiles do not take it, so a tile tuned without it may not apply)
         tile = _tuned_tile(geo, 'bf16s_fprop' + ('_stats' if stats is not None else '') + ('_h' if halo else '') +
-                           ('_sk' if sk else '') + ('_st' if stem else '') + ('_relu' if relu_in else ''), run,
-                           _IGEMM16_TILES + halo + sk + stem)
+                           ('_sk' if sk else '') + ('_st' if stem else '') + ('_relu' if relu_in else '') + ('_pw' if pw else ''), run,
+                           _IGEMM16_TILES + halo + sk + stem + pw, cold=bool(pw))
         geo.tuned[vkey] = tile
     d = _with_flags(geo.fwd, flags, tile)
     _count_flops('fprop', geo)
@@ -853,13 +880,16 @@ def _conv_fprop16(lib, x, w, geo, out, bias, stats, relu_in, addend, tile):
         _igemm16_splitk(lib, x, [(geo.fwd, w16)], out, flags, tile, bias, stats, None, addend,
                         geo.B * geo.Ho * geo.Wo, geo.Cout, _stream())
     else:
+        if tile == TILE_PW:
+            w16 = _pw_packed(lib, w16, geo, _stream())
         check(lib.loans_igemm_bf16s(_ptr(x), _ptr(w16), _ptr(out), _ptr(bias), _ptr(stats), 0, _ptr(addend),
                                     C.byref(d), _stream()), 'loans_igemm_bf16s[fprop]')
     if log is not None:
         ev1.record()
         log.append(('fprop_bn' if stats is not None else 'fprop',
-                    2 * geo.B * geo.Ho * geo.Wo * geo.Cout * geo.k * geo.k * geo.cin_logical, ev0, ev1, 2 if tile >> 8 else 1, 1,
-                    _conv_bytes(geo, x, w16, out)))          # split-K: the partial launch and the finalize pass (the memset is torch's)
+                    2 * geo.B * geo.Ho * geo.Wo * geo.Cout * geo.k * geo.k * geo.cin_logical, ev0, ev1, 2 if tile >> 8 or tile == TILE_PW else 1, 1,
+                    _conv_bytes(geo, x, w16, out)))          # split-K: the partial launch and the finalize pass (the memset is torch's);
+        #                                                      LOANS_TILE_PW: the weight packing launch and the convolution
     return out
 
 

@@ -362,6 +362,45 @@ def test_conv_halo_tiles_bf16_storage(case, tile):
     same(gx3, ops.conv_dgrad(gyd, wd, geo, addend=d16(_nhwc(addx)), addend_mask_ref=d16(_nhwc(ref_t)), tile=1), exact_d)
 
 
+@pytest.mark.parametrize("case", [(2, 64, 16, 16, 256), (3, 64, 7, 9, 256), (1, 64, 5, 5, 64), (2, 128, 12, 20, 512), (3, 128, 3, 11, 128),
+                                  (1, 64, 1, 1, 512), (2, 64, 33, 47, 192), (4, 128, 64, 64, 512)])
+def test_conv_pointwise_tile_bf16_storage(case):
+    """LOANS_TILE_PW (csrc/pw_bf16.hip): the short-K 1 x 1 convolutions (ResNet-50's res2 / res3 expansions) with the operands
+    fed global -> VGPR and the weights in fragment order -- against the oracle on the bf16-rounded operands, and BIT FOR BIT
+    against the implicit-GEMM tile (same products, same order); the BN statistics to fp32 summation order.  Ragged last strips
+    (pixel counts that are no multiple of 32), one-pixel inputs, more strips than resident waves."""
+    from loans_amd import ops
+    B, Cin, H, W, Cout = case
+    rng = np.random.RandomState(5)
+    x = _r(rng.standard_normal((B, Cin, H, W)))
+    w = (rng.standard_normal((Cout, Cin, 1, 1)) / np.sqrt(Cin)).astype(np.float32)
+    geo = ops.ConvGeometry(B, H, W, Cin, Cout, 1, 1, 0)
+    assert ops._pw_tiles(geo, True) == (ops.TILE_PW,) and ops._pw_tiles(geo, False) == ()
+    xd, wd = d16(_nhwc(x)), dev(_nhwc(w))
+    y_ref = C.conv2d_fwd(x.astype(np.float64), _r(w).astype(np.float64), None, 1, 0)[0]
+    s_p, s_g = ops.stats_buffer(Cout, 'cuda'), ops.stats_buffer(Cout, 'cuda')
+    sentinel = torch.full((B * H * W * Cout + 64,), 7.0, device='cuda', dtype=torch.bfloat16)
+    y = ops.conv_fprop(xd, wd, geo, out=sentinel[:B * H * W * Cout].view(B, H, W, Cout), stats=s_p, tile=ops.TILE_PW)
+    y_g = ops.conv_fprop(xd, wd, geo, stats=s_g, tile=1)
+    assert y.dtype == torch.bfloat16 and rel_err(_nchw(y), y_ref) < BF16_EPS
+    assert torch.equal(y, y_g)
+    assert bool((sentinel[B * H * W * Cout:] == 7.0).all())            # nothing written past the last pixel
+    sp, sg = s_p.sum(0).cpu().numpy(), s_g.sum(0).cpu().numpy()
+    np.testing.assert_allclose(sp, sg, rtol=1e-5, atol=1e-3)
+    np.testing.assert_allclose(sp[0], y_ref.sum(axis=(0, 2, 3)), rtol=1e-4, atol=2e-3)
+    np.testing.assert_allclose(sp[1], (y_ref ** 2).sum(axis=(0, 2, 3)), rtol=1e-4, atol=2e-3)
+    assert torch.equal(ops.conv_fprop(xd, wd, geo, tile=ops.TILE_PW), y_g)       # the form without statistics
+    # the statistics do not depend on the order in which waves and blocks arrive (fp64 from the per-lane sums on): the BN
+    # coefficients, hence the forward, are the same bit for bit in every run (the fixture deterministic_forward relies on it)
+    for _ in range(3):
+        s_r = ops.stats_buffer(Cout, 'cuda')
+        ops.conv_fprop(xd, wd, geo, stats=s_r, tile=ops.TILE_PW)
+        assert torch.equal(s_r.sum(0), s_p.sum(0))
+    # an epilogue it does not have is refused, not ignored
+    with pytest.raises(RuntimeError):
+        ops.conv_fprop(xd, wd, geo, bias=dev(np.zeros(Cout, np.float32)), tile=ops.TILE_PW)
+
+
 @pytest.mark.parametrize("case", [(2, 256, 7, 7, 512, 3, 2, 1), (3, 512, 4, 4, 512, 3, 1, 1), (2, 128, 9, 9, 128, 4, 2, 1),
                                   (2, 512, 8, 8, 64, 3, 1, 1)])
 @pytest.mark.parametrize("tile", [3 | (2 << 8), 3 | (4 << 8), 2 | (8 << 8)])

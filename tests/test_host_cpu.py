@@ -254,7 +254,7 @@ def test_tune_table_round_trip(tmp_path, monkeypatch):
     assert g.tuned == {} and ops._TUNE_LOADED[g.key] == {'f32fprop_stats': 19, 'f32wgrad': 3 | (7 << 8)}
     ran = []
     monkeypatch.setattr(ops, 'TUNE_POLICY', 'time')                   # (the test session's default is 'fixed', conftest.py)
-    monkeypatch.setattr(ops, '_time_call', lambda fn, reps=5: (fn(), float(len(ran)))[1])
+    monkeypatch.setattr(ops, '_time_call', lambda fn, reps=5, cold=False: (fn(), float(len(ran)))[1])
     run = ran.append
     # on offer: taken without timing anything
     assert ops._tuned_tile(g, 'f32fprop_stats', run, (1, 2, 19)) == 19 and not ran

@@ -26,6 +26,11 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 // v2: weights pre-packed in MFMA fragment order (Wp[(nt * KS + ks) * 64 + lane] = the 16 bytes lane (r, h) needs for column tile
 // nt, K step ks: one fully coalesced 1 KiB load per fragment), the next tile's fragments requested before this tile's MFMAs, the
 // next strip's A fragments requested before this strip's store phase, the slab holds HALF the columns (8 KB per wave: 16 waves per CU)
+#ifdef UNPACKED      // the weights as the library holds them, [N][K]: a fragment load touches 32 rows x 32 bytes
+#define WLOAD(nt_, ks_) (*reinterpret_cast<const u32x4*>(reinterpret_cast<const __bf16*>(Wp) + (size_t)((nt_) * 32 + r) * K + (ks_) * 16 + h * 8))
+#else
+#define WLOAD(nt_, ks_) Wp[((size_t)(nt_) * KS + (ks_)) * 64 + lane]
+#endif
 template <int K>
 __global__ __launch_bounds__(256, K <= 64 ? 4 : 2) void pw_kernel(const __bf16* __restrict__ A, const u32x4* __restrict__ Wp, __bf16* __restrict__ out,
                                                      int M, int N, int nstrips) {
@@ -48,13 +53,13 @@ __global__ __launch_bounds__(256, K <= 64 ? 4 : 2) void pw_kernel(const __bf16* 
         const int m0 = s * 32;
         u32x4 b[KS], bn[KS];
 #pragma unroll
-        for (int ks = 0; ks < KS; ++ks) b[ks] = Wp[(size_t)ks * 64 + lane];
+        for (int ks = 0; ks < KS; ++ks) b[ks] = WLOAD(0, ks);
         for (int hf = 0; hf < 2; ++hf) {
             for (int t = 0; t < tiles_half; ++t) {
                 const int nt = hf * tiles_half + t;
                 const int nn = nt + 1 < N / 32 ? nt + 1 : 0;            // (the last prefetch wraps to tile 0: the next strip's first)
 #pragma unroll
-                for (int ks = 0; ks < KS; ++ks) bn[ks] = Wp[((size_t)nn * KS + ks) * 64 + lane];
+                for (int ks = 0; ks < KS; ++ks) bn[ks] = WLOAD(nn, ks);
                 f32x16 acc;
 #pragma unroll
                 for (int e = 0; e < 16; ++e) acc[e] = 0.f;
@@ -130,7 +135,11 @@ int main(int argc, char** argv) {
                 for (int lane = 0; lane < 64; ++lane)
                     for (int j = 0; j < 8; ++j)
                         hP[(((size_t)nt * KS + ks) * 64 + lane) * 8 + j] = hW[(size_t)(nt * 32 + (lane & 31)) * K + ks * 16 + (lane >> 5) * 8 + j];
+#ifdef UNPACKED
+        CHECK(hipMemcpy(W, hW.data(), hW.size() * 2, hipMemcpyHostToDevice));
+#else
         CHECK(hipMemcpy(W, hP.data(), hP.size() * 2, hipMemcpyHostToDevice));
+#endif
     }
     CHECK(hipMemset(out, 0xFF, (size_t)M * N * 2));
     const u32x4* Wq = reinterpret_cast<const u32x4*>(W);
