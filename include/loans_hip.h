@@ -133,8 +133,8 @@ typedef struct loans_igemm_desc {
                                       input channels x ALL nine taps and walks 8 x 16 pixel tiles; gradient tile and input halo tile staged once per
                                       tile, a tap is a window shift in LDS (csrc/wgrad_halo_bf16.hip).  splits = blocks per channel-tile pair */
 #define LOANS_TILE_WGHALO_128  39  /* the same with 128 output channels per block on eight waves (Cout % 128 == 0) */
-#define LOANS_TILE_PW          40  /* loans_igemm_bf16s, 1 x 1 / 1 forward geometries with Cin in {64, 128}, Cout % 64 == 0, Cout <= 512, flags STATS or none
-                                      (ResNet-50's res2 / res3 bottleneck expansions): a wave owns 32-pixel strips, operands go global -> VGPR
+#define LOANS_TILE_PW          40  /* loans_igemm_bf16s, 1 x 1 / 1 forward geometries with Cin in {64, 128}, Cout % 64 == 0, Cout <= 512, or Cin = 256,
+                                      Cout % 128 == 0, Cout <= 1024; flags STATS or none (ResNet-50's res2 / res3 / res4 bottleneck expansions): a wave owns 32-pixel strips, operands go global -> VGPR
                                       in MFMA fragment layout (never through LDS), output rows leave through a per-wave LDS slab; `w` must be
                                       the weights in FRAGMENT ORDER (loans_pw_pack_bf16).  Outputs bit-identical to the other tiles
                                       (csrc/pw_bf16.hip) */

@@ -128,6 +128,105 @@ __global__ __launch_bounds__(256, OCC) void pw16_kernel(const __bf16* __restrict
     }
 }
 
+// K = 256 (res4's expansions, 256 -> 1024 at 32 x 32): the strip's A fragments are 64 VGPRs, so the weights of a tile come in two
+// halves of eight fragments (the second half requested before the first half's MFMAs, the next tile's first half before the
+// second's), the next strip's pixels are not prefetched (at B = 64 there is one strip per resident wave anyway), and the slab holds
+// 128 columns.  Everything else as above; 2 blocks per CU.
+template <int NC, bool STATS>
+__global__ __launch_bounds__(256, 2) void pw16_k256_kernel(const __bf16* __restrict__ A, const u32x4* __restrict__ W, __bf16* __restrict__ out,
+                                                           double* __restrict__ stats, int M, int N_, int nstrips, int nt_out) {
+    const int N = NC ? NC : N_;
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    constexpr int K = 256, KS = 16, PC = 128, pitch = PC + 8, upr = PC / 8;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    double* sums = reinterpret_cast<double*>(smem);
+    __bf16* slab = reinterpret_cast<__bf16*>(smem + (STATS ? (size_t)2 * N * sizeof(double) : 0)) + (size_t)wave * 32 * pitch;
+    const int wave_id = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
+    const int phases = N / PC;
+    if (STATS) {
+        for (int i = threadIdx.x; i < 2 * N; i += 256) sums[i] = 0.0;
+        __syncthreads();
+    }
+    auto load_w = [&](int nt, int part, u32x4* b) {
+        const u32x4* wf = W + ((size_t)nt * KS + part * 8) * 64 + lane;
+#pragma unroll
+        for (int ks = 0; ks < 8; ++ks) b[ks] = wf[ks * 64];
+    };
+    for (int s = wave_id; s < nstrips; s += nwaves) {
+        const int m0 = s * 32;
+        u32x4 a[KS], b0[8], b1[8];
+        {
+            const bool live = m0 + r < M;
+            const int row = live ? m0 + r : M - 1;
+            const u32x4 zero = {0u, 0u, 0u, 0u};
+#pragma unroll
+            for (int ks = 0; ks < KS; ++ks) {
+                const u32x4 v = *reinterpret_cast<const u32x4*>(A + (size_t)row * K + ks * 16 + h * 8);
+                a[ks] = live ? v : zero;
+            }
+        }
+        load_w(0, 0, b0);
+#pragma unroll 1
+        for (int ph = 0; ph < phases; ++ph) {
+#pragma unroll 1
+            for (int t = 0; t < PC / 32; ++t) {
+                const int nt = ph * (PC / 32) + t;
+                load_w(nt, 1, b1);
+                f32x16 acc;
+#pragma unroll
+                for (int e = 0; e < 16; ++e) acc[e] = 0.f;
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[ks]), __builtin_bit_cast(bf16x8_t, b0[ks]), acc, 0, 0, 0);
+                load_w(nt + 1 < N / 32 ? nt + 1 : 0, 0, b0);
+#pragma unroll
+                for (int ks = 0; ks < 8; ++ks)
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8_t, a[8 + ks]), __builtin_bit_cast(bf16x8_t, b1[ks]), acc, 0, 0, 0);
+                __bf16* col = slab + 4 * h * pitch + t * 32 + r;
+#pragma unroll
+                for (int e = 0; e < 16; e += 2) {
+                    const f32x2 v = {acc[e], acc[e + 1]};
+                    const bf16x2_t p = __builtin_convertvector(v, bf16x2_t);
+                    col[((e & 3) + 8 * (e >> 2)) * pitch] = p[0];
+                    col[((e & 3) + 1 + 8 * (e >> 2)) * pitch] = p[1];
+                }
+                if (STATS) {
+                    f32x2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};
+#pragma unroll
+                    for (int e = 0; e < 16; e += 2) {
+                        const f32x2 v = {acc[e], acc[e + 1]};
+                        s2 += v;
+                        q2 = v * v + q2;
+                    }
+                    float sm = s2[0] + s2[1], sq = q2[0] + q2[1];
+                    asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1\n\ts_nop 1" : "+v"(sm), "+v"(sq));
+                    atomic_add_f64(sums + h * N + nt * 32 + r, (double)(sm + sq));
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            for (int u = lane; u < 32 * upr; u += 64) {
+                const int pr = u / upr, cu = u - pr * upr;
+                const u32x4 v = *reinterpret_cast<const u32x4*>(slab + pr * pitch + cu * 8);
+                if (m0 + pr < M) {
+                    u32x4* dst = reinterpret_cast<u32x4*>(out + (size_t)(m0 + pr) * N + ph * PC + cu * 8);
+                    if (nt_out) __builtin_nontemporal_store(v, dst);
+                    else *dst = v;
+                }
+            }
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+        }
+    }
+    if (STATS) {
+        __syncthreads();
+        double* st = stats + (size_t)(blockIdx.x % LOANS_STATS_REPLICAS) * 2 * N;
+        for (int i = threadIdx.x; i < 2 * N; i += 256)
+            if (sums[i] != 0.0) atomic_add_f64(st + i, sums[i]);
+    }
+}
+
 // weights [Cout][Cin] bf16 -> fragment order: packed[((nt * KS + ks) * 64 + lane) * 8 + j] = w[nt * 32 + (lane & 31)][ks * 16 + (lane >> 5) * 8 + j]
 __global__ __launch_bounds__(256) void pw16_pack_kernel(const u32x4* __restrict__ w, u32x4* __restrict__ packed, int N, int K) {
     const int KS = K / 16, total = N / 32 * KS * 64;
@@ -146,14 +245,18 @@ extern "C" int loans_pw_pack_bf16(const void* w, void* packed, int32_t Cout, int
     return LOANS_OK;
 }
 
-// what LOANS_TILE_PW covers: a 1 x 1 / 1 forward geometry (grid = input = output pixels), Cin in {64, 128}, Cout a multiple of 64
-// up to 512, flags STATS or none
+// what LOANS_TILE_PW covers: a 1 x 1 / 1 forward geometry (grid = input = output pixels), Cin in {64, 128} with Cout a multiple of 64
+// up to 512, or Cin = 256 with Cout a multiple of 128 up to 1024; flags STATS or none
 int loans_pw16_covers(const loans_igemm_desc* d) {
     if (d->ntaps != 1 || d->dy[0] != 0 || d->dx[0] != 0) return 0;
     if (d->isy != 1 || d->isx != 1 || d->osy != 1 || d->osx != 1 || d->oy0 != 0 || d->ox0 != 0) return 0;
     if (d->gridH != d->inH || d->gridW != d->inW || d->gridH != d->outH || d->gridW != d->outW) return 0;
-    if (d->Cin != 64 && d->Cin != 128) return 0;
-    if (d->Cout % 64 != 0 || d->Cout < 64 || d->Cout > 512) return 0;
+    if (d->Cin == 256) {
+        if (d->Cout % 128 != 0 || d->Cout < 128 || d->Cout > 1024) return 0;
+    } else {
+        if (d->Cin != 64 && d->Cin != 128) return 0;
+        if (d->Cout % 64 != 0 || d->Cout < 64 || d->Cout > 512) return 0;
+    }
     if (d->flags & ~LOANS_F_STATS) return 0;
     return 1;
 }
@@ -178,6 +281,20 @@ static int pw16_launch_n(const void* in, const void* w, void* out, double* stats
     return LOANS_OK;
 }
 
+template <int NC, bool STATS>
+static int pw16_launch_k256(const void* in, const void* w, void* out, double* stats, int M, int N, int nt_out, hipStream_t st) {
+    const int nstrips = (M + 31) / 32;
+    const size_t lds = (size_t)4 * 32 * (128 + 8) * 2 + (STATS ? (size_t)2 * N * sizeof(double) : 0);       // <= 50 KB
+    const int cus = loans_device_cus();
+    if (cus <= 0) return LOANS_EINVAL;
+    int blocks = cus * 2;
+    if (blocks > (nstrips + 3) / 4) blocks = (nstrips + 3) / 4;
+    hipLaunchKernelGGL((pw16_k256_kernel<NC, STATS>), dim3(blocks), dim3(256), lds, st, static_cast<const __bf16*>(in),
+                       static_cast<const u32x4*>(w), static_cast<__bf16*>(out), stats, M, N, nstrips, nt_out);
+    LOANS_LAUNCH_CHECK();
+    return LOANS_OK;
+}
+
 // the two shapes of the ResNet-50 localizer (N = 4 K) have the column count folded into the code
 template <int K, bool STATS>
 static int pw16_launch_k(const void* in, const void* w, void* out, double* stats, int M, int N, int nt_out, hipStream_t st) {
@@ -195,6 +312,10 @@ int loans_pw16_launch(const void* in, const void* w, void* out, double* stats, c
     double* stp = (d->flags & LOANS_F_STATS) ? stats : nullptr;
     const int nt_out = loans_conv_nt((size_t)M * N * 2);
     if ((d->flags & LOANS_F_STATS) && !stats) return LOANS_EINVAL;
+    if (d->Cin == 256) {
+        if (N == 1024) return stp ? pw16_launch_k256<1024, true>(in, w, out, stp, M, N, nt_out, st) : pw16_launch_k256<1024, false>(in, w, out, stp, M, N, nt_out, st);
+        return stp ? pw16_launch_k256<0, true>(in, w, out, stp, M, N, nt_out, st) : pw16_launch_k256<0, false>(in, w, out, stp, M, N, nt_out, st);
+    }
     if (d->Cin == 64)
         return stp ? pw16_launch_k<64, true>(in, w, out, stp, M, N, nt_out, st) : pw16_launch_k<64, false>(in, w, out, stp, M, N, nt_out, st);
     return stp ? pw16_launch_k<128, true>(in, w, out, stp, M, N, nt_out, st) : pw16_launch_k<128, false>(in, w, out, stp, M, N, nt_out, st);

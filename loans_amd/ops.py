@@ -384,10 +384,13 @@ PW = os.environ.get('LOANS_PW', '1') != '0'
 
 @_memo
 def _pw_tiles(geo, plain):
-    """LOANS_TILE_PW where loans_pw16_covers holds: a 1 x 1 / 1 convolution, Cin 64 or 128, Cout a multiple of 64 up to 512, no
-    epilogue beyond the BN statistics (plain = no ReLU on the input, no bias, no addend).  ResNet-50's res2 / res3 expansions."""
+    """LOANS_TILE_PW where loans_pw16_covers holds: a 1 x 1 / 1 convolution, Cin 64 or 128 with Cout a multiple of 64 up to 512 or
+    Cin 256 with Cout a multiple of 128 up to 1024, no epilogue beyond the BN statistics (plain = no ReLU on the input, no bias, no
+    addend).  ResNet-50's res2 / res3 / res4 expansions."""
     if not PW or not plain or geo.dense or geo.k != 1 or geo.stride != 1 or geo.pad != 0:
         return ()
+    if geo.Cin == 256:
+        return (TILE_PW,) if geo.Cout % 128 == 0 and geo.Cout <= 1024 else ()
     if geo.Cin not in (64, 128) or geo.Cout % 64 or geo.Cout > 512:
         return ()
     return (TILE_PW,)

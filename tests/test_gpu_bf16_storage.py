@@ -363,7 +363,8 @@ def test_conv_halo_tiles_bf16_storage(case, tile):
 
 
 @pytest.mark.parametrize("case", [(2, 64, 16, 16, 256), (3, 64, 7, 9, 256), (1, 64, 5, 5, 64), (2, 128, 12, 20, 512), (3, 128, 3, 11, 128),
-                                  (1, 64, 1, 1, 512), (2, 64, 33, 47, 192), (4, 128, 64, 64, 512)])
+                                  (1, 64, 1, 1, 512), (2, 64, 33, 47, 192), (4, 128, 64, 64, 512),
+                                  (2, 256, 8, 8, 1024), (3, 256, 5, 7, 256), (1, 256, 3, 3, 128), (5, 256, 32, 32, 1024)])
 def test_conv_pointwise_tile_bf16_storage(case):
     """LOANS_TILE_PW (csrc/pw_bf16.hip): the short-K 1 x 1 convolutions (ResNet-50's res2 / res3 expansions) with the operands
     fed global -> VGPR and the weights in fragment order -- against the oracle on the bf16-rounded operands, and BIT FOR BIT
@@ -399,6 +400,23 @@ def test_conv_pointwise_tile_bf16_storage(case):
     # an epilogue it does not have is refused, not ignored
     with pytest.raises(RuntimeError):
         ops.conv_fprop(xd, wd, geo, bias=dev(np.zeros(Cout, np.float32)), tile=ops.TILE_PW)
+
+
+def test_conv_pointwise_tile_more_strips_than_waves():
+    """LOANS_TILE_PW with more 32-pixel strips than the grid has waves (every wave walks several strips: the persistent loop, the
+    prefetch of the next strip's pixels), at ResNet-50's three expansion shapes -- bit for bit against the implicit-GEMM tile."""
+    from loans_amd import ops
+    cus = torch.cuda.get_device_properties(0).multi_processor_count
+    for Cin, Cout, per_cu in ((64, 256, 16), (128, 512, 8), (256, 1024, 8)):
+        pixels = 32 * (cus * per_cu * 2 + 3) + 5                      # two strips and a bit per resident wave, a ragged last one
+        geo = ops.ConvGeometry(1, 1, pixels, Cin, Cout, 1, 1, 0)
+        g = torch.Generator(device='cuda').manual_seed(Cin)
+        x = torch.randn((1, 1, pixels, Cin), device='cuda', generator=g).to(torch.bfloat16)
+        w = torch.randn((Cout, 1, 1, Cin), device='cuda', generator=g) / Cin ** 0.5
+        s_p, s_g = ops.stats_buffer(Cout, 'cuda'), ops.stats_buffer(Cout, 'cuda')
+        y = ops.conv_fprop(x, w, geo, stats=s_p, tile=ops.TILE_PW)
+        assert torch.equal(y, ops.conv_fprop(x, w, geo, stats=s_g, tile=1))
+        np.testing.assert_allclose(s_p.sum(0).cpu().numpy(), s_g.sum(0).cpu().numpy(), rtol=1e-5, atol=1e-2)
 
 
 @pytest.mark.parametrize("case", [(2, 256, 7, 7, 512, 3, 2, 1), (3, 512, 4, 4, 512, 3, 1, 1), (2, 128, 9, 9, 128, 4, 2, 1),

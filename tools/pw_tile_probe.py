@@ -25,7 +25,7 @@ def timed(fn, cold, reps=8):
     return best
 
 
-for name, Cin, HW, Cout in [('res2 expand', 64, 128, 256), ('res3 expand', 128, 64, 512)]:
+for name, Cin, HW, Cout in [('res2 expand', 64, 128, 256), ('res3 expand', 128, 64, 512), ('res4 expand', 256, 32, 1024)]:
     geo = ops.ConvGeometry(B, HW, HW, Cin, Cout, 1, 1, 0)
     x = torch.randn((B, HW, HW, Cin), device='cuda').to(torch.bfloat16)
     w = (torch.randn((Cout, 1, 1, Cin), device='cuda') * 0.05).to(torch.bfloat16)
