@@ -14,8 +14,9 @@
 // are the fp32 accumulators' sums: per tile and lane over 16 rows in fp32 (a fixed order), from there in DOUBLE -- per block in LDS
 // (ds_add_f64), once per block with fp64 atomics into the block's replica -- so that, like the tiled kernels' sums, they do not
 // depend on the order in which waves and blocks arrive (fp32 LDS atomics made the BN statistics, and with them the whole forward,
-// differ in the last bit from run to run).  The products and their order (K
-// ascending from a zero accumulator) are those of loans_igemm_bf16s' other tiles: the outputs are bit-identical to theirs.
+// differ in the last bit from run to run; and ds_add_f32 is the slower instruction on this chip: 184 against 158 us on res2's
+// expansion).  The products and their order (K ascending from a zero accumulator) are those of loans_igemm_bf16s' other tiles: the
+// outputs are bit-identical to theirs.  Cin = 256 (res4's expansions): pw16_k256_kernel below.
 #include "common.h"
 
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
@@ -84,7 +85,7 @@ __global__ __launch_bounds__(256, OCC) void pw16_kernel(const __bf16* __restrict
                     col[((e & 3) + 1 + 8 * (e >> 2)) * pitch] = p[1];
                 }
                 if (STATS) {
-                    f32x2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};             // (v_pk_add_f32 / v_pk_fma_f32: the kernel is VALU-issue bound)
+                    f32x2 s2 = {0.f, 0.f}, q2 = {0.f, 0.f};             // (v_pk_add_f32 / v_pk_fma_f32: half the VALU instructions)
 #pragma unroll
                     for (int e = 0; e < 16; e += 2) {
                         const f32x2 v = {acc[e], acc[e + 1]};
