@@ -215,6 +215,16 @@ int loans_igemm_bf16s(const void* in, const void* w, void* out, const float* bia
  * channels, 16 input channels) MFMA B fragment: packed[((nt * Cin / 16 + ks) * 64 + lane) * 8 + j] =
  * w[nt * 32 + lane % 32][ks * 16 + lane / 32 * 8 + j].  Cout % 32 == 0, Cin % 16 == 0; `packed` holds Cout x Cin bf16. */
 int loans_pw_pack_bf16(const void* w, void* packed, int32_t Cout, int32_t Cin, void* stream);
+/* The same for every LOANS_TILE_PW layer of a step in ONE launch, from the fp32 master weights (rounded to nearest even): job j packs
+ * src [Cout][Cin] fp32 into dst (Cout x Cin bf16, fragment order); first_unit = the sum of Cout x Cin / 8 over the jobs before it,
+ * total_units that sum over all jobs.  `jobs_dev` is a table in DEVICE memory, caller-owned, alive until the launch has run. */
+typedef struct loans_pw_pack_job {
+    const void* src;
+    void* dst;
+    int32_t Cout, Cin;
+    int32_t first_unit, reserved;
+} loans_pw_pack_job;
+int loans_pw_pack_batch_f32(const loans_pw_pack_job* jobs_dev, int32_t njobs, int32_t total_units, void* stream);
 /* Two forward convolutions of the SAME bf16 input with the same geometry AND the same channel count (BasicA's conv1 and its
  * strided conv shortcut, sheep/resnet.py:128-133) as ONE GEMM with 2 x Cout columns: w_ab = [2][Cout][ntaps][Cin] (a's
  * matrix, then b's), out_ab = [2][B][outH][outW][Cout] (two ordinary tensors back to back).  Unlike loans_igemm_pair_f32

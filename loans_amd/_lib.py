@@ -41,6 +41,11 @@ class RepackJob(C.Structure):
                [('tapsel', C.c_int32 * REPACK_JOB_TAPS)] + [(n, C.c_int32) for n in ('first_tile', 'tiles_co', 'tiles_ci', 'dst_bf16')]
 
 
+class PwPackJob(C.Structure):
+    """Mirror of ``loans_pw_pack_job``."""
+    _fields_ = [('src', C.c_void_p), ('dst', C.c_void_p)] + [(n, C.c_int32) for n in ('Cout', 'Cin', 'first_unit', 'reserved')]
+
+
 class SmallConv(C.Structure):
     """Mirror of ``loans_small_conv``."""
     _fields_ = [(n, C.c_int32) for n in ('k', 'stride', 'pad', 'outH', 'outW')]
@@ -68,6 +73,7 @@ SIGNATURES = {
     'loans_igemm_classes_f32': [_p, C.POINTER(_p), _p, _p, _p, C.POINTER(IgemmDesc), _i32, _p],
     'loans_igemm_pair_bf16s': [_p, _p, _p, _p, _p, C.POINTER(IgemmDesc), _p],
     'loans_pw_pack_bf16': [_p, _p, C.c_int32, C.c_int32, _p],
+    'loans_pw_pack_batch_f32': [_p, C.c_int32, C.c_int32, _p],
     'loans_igemm_pair_f32': [_p, _p, _p, _p, _p, _p, _p, _i32, C.POINTER(IgemmDesc), _p],
     'loans_igemm_finalize_f32': [_p, _p, _p, _p, _p, _i32, _i64, _i32, _p],
     'loans_igemm_bf16_f32': [_p, _p, _p, _p, _p, _p, _p, C.POINTER(IgemmDesc), _p],

@@ -246,6 +246,37 @@ extern "C" int loans_pw_pack_bf16(const void* w, void* packed, int32_t Cout, int
     return LOANS_OK;
 }
 
+// every LOANS_TILE_PW layer's weights of a step in ONE launch, straight from the fp32 masters (rounded to nearest even, like the
+// bf16 shadow loans_cast_bf16 makes): unit u of the launch = one 16-byte group of job j's packed matrix, j found by bisection over
+// first_unit
+__global__ __launch_bounds__(256) void pw16_pack_batch_kernel(const loans_pw_pack_job* __restrict__ jobs, int njobs, int total_units) {
+    for (int u = blockIdx.x * 256 + threadIdx.x; u < total_units; u += gridDim.x * 256) {
+        int lo = 0, hi = njobs - 1;
+        while (lo < hi) {
+            const int mid = (lo + hi + 1) >> 1;
+            if (jobs[mid].first_unit <= u) lo = mid; else hi = mid - 1;
+        }
+        const loans_pw_pack_job j = jobs[lo];
+        const int i = u - j.first_unit, KS = j.Cin / 16;
+        const int lane = i & 63, f = i >> 6, ks = f % KS, nt = f / KS;
+        const float* src = static_cast<const float*>(j.src) + (size_t)(nt * 32 + (lane & 31)) * j.Cin + ks * 16 + (lane >> 5) * 8;
+        const f32x4 lo4 = *reinterpret_cast<const f32x4*>(src), hi4 = *reinterpret_cast<const f32x4*>(src + 4);
+        const loans_bf16x4 l = __builtin_convertvector(lo4, loans_bf16x4), hh = __builtin_convertvector(hi4, loans_bf16x4);
+        bf16x8_t o;
+        o[0] = l[0]; o[1] = l[1]; o[2] = l[2]; o[3] = l[3];
+        o[4] = hh[0]; o[5] = hh[1]; o[6] = hh[2]; o[7] = hh[3];
+        reinterpret_cast<bf16x8_t*>(j.dst)[i] = o;
+    }
+}
+
+extern "C" int loans_pw_pack_batch_f32(const loans_pw_pack_job* jobs_dev, int32_t njobs, int32_t total_units, void* stream) {
+    if (!jobs_dev || njobs <= 0 || total_units <= 0) return LOANS_EINVAL;
+    hipLaunchKernelGGL(pw16_pack_batch_kernel, dim3(grid_for(total_units, 256, 1024)), dim3(256), 0, as_stream(stream), jobs_dev, njobs,
+                       total_units);
+    LOANS_LAUNCH_CHECK();
+    return LOANS_OK;
+}
+
 // what LOANS_TILE_PW covers: a 1 x 1 / 1 forward geometry (grid = input = output pixels), Cin in {64, 128} with Cout a multiple of 64
 // up to 512, or Cin = 256 with Cout a multiple of 128 up to 1024; flags STATS or none
 int loans_pw16_covers(const loans_igemm_desc* d) {

@@ -396,9 +396,35 @@ def _pw_tiles(geo, plain):
     return (TILE_PW,)
 
 
-def _pw_packed(lib, w16, geo, st):
-    """the weights in LOANS_TILE_PW's fragment order (32 - 128 KB: one small launch per call)"""
-    packed = torch.empty(geo.Cout * geo.Cin, device=w16.device, dtype=BF16)
+PW_PACK_CALLS = 0           # per-call packing launches (tests: a prepared step makes none)
+
+
+def _pw_packed(lib, w, w16, geo, st):
+    """the weights in LOANS_TILE_PW's fragment order.  Inside a step: the buffer this step's begin_step filled for (w, Cout, Cin) -- all
+    such layers in one launch, from the fp32 masters (_WeightPrep.begin) -- or, the first time a layer asks, a buffer registered for
+    the next steps and packed now; outside a step (tests, inference) one small launch per call."""
+    global PW_PACK_CALLS
+    wp = _weight_preps.get(w.device.index)
+    packed = None
+    # (Cin = 256 stays per call: its 512 KB matrix, packed at begin_step, has left the L2 by the time res4 runs, and the tile loop
+    # of 2048 waves in step then pays an HBM miss per fragment group -- 0.082 ms in the step against 0.060 with the packing launch
+    # right in front of it as the warm-up; the 32 / 128 KB matrices of res2 / res3 do not care: 0.148 -> 0.139, 0.088 -> 0.084)
+    if wp is not None and wp.live and WEIGHT_PREP and w.dtype == torch.float32 and w.is_contiguous() and geo.Cin < 256:
+        key = (w.data_ptr(), geo.Cout, geo.Cin)
+        entry = wp.pw.get(key)
+        if entry is not None:
+            entry['used'] = wp.step
+            if key in wp.pw_prepared:
+                return entry['buf']
+        elif len(wp.pw_order) < _MAX_PREP_JOBS and not torch.cuda.is_current_stream_capturing():
+            entry = wp.pw[key] = {'buf': torch.empty(geo.Cout * geo.Cin, device=w.device, dtype=BF16), 'w': w, 'used': wp.step}
+            wp.pw_order.append(key)
+            wp.pw_dirty = True
+        if entry is not None:
+            packed = entry['buf']
+    if packed is None:
+        packed = torch.empty(geo.Cout * geo.Cin, device=w16.device, dtype=BF16)
+    PW_PACK_CALLS += 1
     check(lib.loans_pw_pack_bf16(_ptr(w16), _ptr(packed), geo.Cout, geo.Cin, st), 'loans_pw_pack_bf16')
     return packed
 
@@ -858,7 +884,7 @@ def _conv_fprop16(lib, x, w, geo, out, bias, stats, relu_in, addend, tile):
                 _igemm16_splitk(lib, x, [(geo.fwd, w16)], scratch, tflags, t, None, sstats, None, None,
                                 geo.B * geo.Ho * geo.Wo, geo.Cout, _stream())
                 return
-            wt = _pw_packed(lib, w16, geo, _stream()) if t == TILE_PW else w16        # (its packing launch is part of its price)
+            wt = _pw_packed(lib, w, w16, geo, _stream()) if t == TILE_PW else w16
             check(lib.loans_igemm_bf16s(_ptr(x), _ptr(wt), _ptr(scratch), 0, _ptr(sstats), 0, 0,
                                         C.byref(_with_flags(geo.fwd, tflags, t)), _stream()), 'loans_igemm_bf16s[tune]')
         # where LOANS_TILE_PW is on offer the candidates are timed COLD (a 512 MB fill before every launch): these layers write four
@@ -884,15 +910,18 @@ def _conv_fprop16(lib, x, w, geo, out, bias, stats, relu_in, addend, tile):
                         geo.B * geo.Ho * geo.Wo, geo.Cout, _stream())
     else:
         if tile == TILE_PW:
-            w16 = _pw_packed(lib, w16, geo, _stream())
+            packs = PW_PACK_CALLS
+            w16 = _pw_packed(lib, w, w16, geo, _stream())
+            packs = PW_PACK_CALLS - packs           # 1 outside a prepared step (the packing launch), else 0
         check(lib.loans_igemm_bf16s(_ptr(x), _ptr(w16), _ptr(out), _ptr(bias), _ptr(stats), 0, _ptr(addend),
                                     C.byref(d), _stream()), 'loans_igemm_bf16s[fprop]')
     if log is not None:
         ev1.record()
         log.append(('fprop_bn' if stats is not None else 'fprop',
-                    2 * geo.B * geo.Ho * geo.Wo * geo.Cout * geo.k * geo.k * geo.cin_logical, ev0, ev1, 2 if tile >> 8 or tile == TILE_PW else 1, 1,
+                    2 * geo.B * geo.Ho * geo.Wo * geo.Cout * geo.k * geo.k * geo.cin_logical, ev0, ev1,
+                    2 if tile >> 8 else (1 + packs if tile == TILE_PW else 1), 1,
                     _conv_bytes(geo, x, w16, out)))          # split-K: the partial launch and the finalize pass (the memset is torch's);
-        #                                                      LOANS_TILE_PW: the weight packing launch and the convolution
+        #                                                      LOANS_TILE_PW outside a prepared step: the packing launch and the convolution
     return out
 
 
@@ -1501,6 +1530,39 @@ class _WeightPrep:
         # capture are therefore kept for good: never freed by a rebuild (an eager step of another shape adds entries and makes
         # a NEW table), never evicted as stale.
         self.captured_tables, self.captured_keys = [], set()
+        # LOANS_TILE_PW's fragment-order weights: (weight pointer, Cout, Cin) -> persistent packed buffer, all filled by one
+        # loans_pw_pack_batch_f32 launch per step; the same life cycle as the re-packs
+        self.pw, self.pw_order, self.pw_table, self.pw_units = {}, [], None, 0
+        self.pw_dirty, self.pw_prepared, self.captured_pw_keys = False, set(), set()
+
+    def _begin_pw(self, device, lib, st, capturing):
+        self.pw_prepared = set()
+        stale = [k for k in self.pw_order if self.pw[k]['used'] < self.step - 2 and k not in self.captured_pw_keys]
+        if stale and not capturing:
+            for k in stale:
+                del self.pw[k]
+            self.pw_order = [k for k in self.pw_order if k in self.pw]
+            self.pw_dirty = True
+        if not self.pw_order:
+            self.pw_dirty = False
+            return
+        if self.pw_dirty:
+            if capturing:           # a host -> device copy cannot be captured: this step packs per call (into the same buffers)
+                return
+            jobs = (_lib.PwPackJob * len(self.pw_order))()
+            unit = 0
+            for i, k in enumerate(self.pw_order):
+                e = self.pw[k]
+                jobs[i].src, jobs[i].dst, jobs[i].Cout, jobs[i].Cin, jobs[i].first_unit = k[0], e['buf'].data_ptr(), k[1], k[2], unit
+                unit += k[1] * k[2] // 8
+            raw = np.frombuffer(bytes(jobs), dtype=np.uint8).copy()
+            self.pw_table = torch.from_numpy(raw).to(device)        # (a NEW tensor: a captured graph keeps the one it was captured with)
+            self.pw_units, self.pw_njobs, self.pw_dirty = unit, len(self.pw_order), False
+        if capturing and not any(t is self.pw_table for t in self.captured_tables):
+            self.captured_tables.append(self.pw_table)
+            self.captured_pw_keys.update(self.pw_order)
+        check(lib.loans_pw_pack_batch_f32(_ptr(self.pw_table), self.pw_njobs, self.pw_units, st), 'loans_pw_pack_batch_f32')
+        self.pw_prepared = set(self.pw_order)
 
     def begin(self, device):
         lib = _lib.load()
@@ -1531,6 +1593,7 @@ class _WeightPrep:
                     arena.data16 = torch.empty(arena.numel, device=arena.device, dtype=BF16)
                 check(lib.loans_cast_bf16(_ptr(arena.data), _ptr(arena.data16), arena.numel, st), 'loans_cast_bf16')
                 self.shadow_ok[id(arena)] = arena.numel
+        self._begin_pw(device, lib, st, capturing)
         if not self.order:
             self.dirty = False
             return

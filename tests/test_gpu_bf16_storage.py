@@ -402,6 +402,51 @@ def test_conv_pointwise_tile_bf16_storage(case):
         ops.conv_fprop(xd, wd, geo, bias=dev(np.zeros(Cout, np.float32)), tile=ops.TILE_PW)
 
 
+def test_pointwise_weights_are_packed_by_the_steps_preparation():
+    """Inside a step the fragment-order weights of every LOANS_TILE_PW layer come from ONE launch at begin_step
+    (loans_pw_pack_batch_f32, from the fp32 masters): a layer is packed per call only the first time it asks; the batch follows
+    the weights from step to step, takes layers that join later, and forgets layers no step has used lately."""
+    from loans_amd import ops
+    device = torch.device('cuda', 0)
+    g = torch.Generator(device='cuda').manual_seed(3)
+    layers = []
+    for B, H, Cin, Cout in ((2, 16, 64, 256), (3, 9, 128, 512), (1, 12, 256, 1024)):
+        geo = ops.ConvGeometry(B, H, H, Cin, Cout, 1, 1, 0)
+        x = torch.randn((B, H, H, Cin), device='cuda', generator=g).to(torch.bfloat16)
+        w = torch.randn((Cout, 1, 1, Cin), device='cuda', generator=g) / Cin ** 0.5
+        layers.append((geo, x, w))
+
+    def step(active, expect_packs):
+        refs = [ops.conv_fprop(x, w, geo, tile=1) for geo, x, w in active]           # outside the step: cast per call
+        ops.begin_step(device)
+        try:
+            before = ops.PW_PACK_CALLS
+            for (geo, x, w), ref in zip(active, refs):
+                assert torch.equal(ops.conv_fprop(x, w, geo, tile=ops.TILE_PW), ref)
+            assert ops.PW_PACK_CALLS - before == expect_packs
+        finally:
+            ops.end_step()
+
+    step(layers[:1], 1)                     # first sight: registered, packed per call
+    for _, _, w in layers:
+        w.mul_(1.25)                        # "the optimisers have moved the weights"
+    step(layers[:1], 0)                     # from begin_step's batch, with the new values
+    step(layers[:2], 1)                     # a layer that joins later is packed per call once ...
+    for _, _, w in layers:
+        w.add_(0.01)
+    step(layers[:2], 0)                     # ... and rides in the batch from then on
+    step(layers[1:2], 0)
+    step(layers, 1)                         # Cin = 256 is packed per call in every step (its packing launch is its L2 warm-up)
+    step(layers, 1)
+    wp = ops._weight_preps[0]
+    assert len(wp.pw) == 2
+    for _ in range(4):                      # entries no step has asked for lately go, with their buffers
+        ops.begin_step(device)
+        ops.end_step()
+    assert not wp.pw and not wp.pw_order
+    step(layers[:1], 1)
+
+
 def test_conv_pointwise_tile_more_strips_than_waves():
     """LOANS_TILE_PW with more 32-pixel strips than the grid has waves (every wave walks several strips: the persistent loop, the
     prefetch of the next strip's pixels), at ResNet-50's three expansion shapes -- bit for bit against the implicit-GEMM tile."""

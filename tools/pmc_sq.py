@@ -17,7 +17,7 @@ ids = sorted(disp)
 prep = [i for i in ids if 'prep_' in disp[i]['name']]
 seg = [i for i in ids if prep[-2] <= i < prep[-1]]
 gap = max(k for k, i in enumerate(seg) if 'gap_fwd_kernel' in disp[i]['name'])
-fwd = [disp[i] for i in seg[:gap] if "igemm" in disp[i]["name"] or "stem7" in disp[i]["name"] or "halo16" in disp[i]["name"] or "ws8_kernel" in disp[i]["name"] or "wsw_kernel" in disp[i]["name"] or "pw16_" in disp[i]["name"]]
+fwd = [disp[i] for i in seg[:gap] if "igemm" in disp[i]["name"] or "stem7" in disp[i]["name"] or "halo16" in disp[i]["name"] or "ws8_kernel" in disp[i]["name"] or "wsw_kernel" in disp[i]["name"] or ("pw16_" in disp[i]["name"] and "pack_batch" not in disp[i]["name"])]
 tot = collections.Counter()
 for d in fwd:
     tot.update(d['c'])

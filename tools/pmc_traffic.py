@@ -22,7 +22,7 @@ def conv_fwd_rows(path, counter):
     gap = max(i for i, r in enumerate(seg) if 'gap_fwd_kernel' in r['Kernel_Name'])       # end of the localizer's conv forward (ResNet-50: pool5, then the one behind res6 / res7)
     # what bench.py brackets: implicit-GEMM launches (a BasicA pair is one, a two-shape split two), the direct stem kernel,
     # the finalize pass of a fine-tail / split-K conv
-    return [r for r in seg[:gap] if 'igemm' in r['Kernel_Name'] or 'stem7' in r['Kernel_Name'] or 'halo16' in r['Kernel_Name'] or 'ws8_kernel' in r['Kernel_Name'] or 'wsw_kernel' in r['Kernel_Name'] or 'pw16_' in r['Kernel_Name']]
+    return [r for r in seg[:gap] if 'igemm' in r['Kernel_Name'] or 'stem7' in r['Kernel_Name'] or 'halo16' in r['Kernel_Name'] or 'ws8_kernel' in r['Kernel_Name'] or 'wsw_kernel' in r['Kernel_Name'] or ('pw16_' in r['Kernel_Name'] and 'pack_batch' not in r['Kernel_Name'])]
 
 
 def main():

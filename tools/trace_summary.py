@@ -25,7 +25,7 @@ print('one step (prep_kernel to prep_kernel): span %.1f us, sum of kernel durati
 for k, v in tot.most_common(30):
     print('%10.1f us %5d launches  avg %9.1f us  %s' % (v, cnt[k], v / cnt[k], k))
 gap = max(i for i, r in enumerate(seg) if 'gap_fwd_kernel' in r['Kernel_Name'])       # end of the localizer's conv forward (ResNet-50: pool5, then the one behind res6 / res7)
-fwd = [r for r in seg[:gap] if 'igemm' in r['Kernel_Name'] or 'stem7' in r['Kernel_Name'] or 'halo16' in r['Kernel_Name'] or 'ws8_kernel' in r['Kernel_Name'] or 'wsw_kernel' in r['Kernel_Name'] or 'pw16_' in r['Kernel_Name']]     # the backbone's convs; a LOANS_TILE_SPLIT conv is two launches
+fwd = [r for r in seg[:gap] if 'igemm' in r['Kernel_Name'] or 'stem7' in r['Kernel_Name'] or 'halo16' in r['Kernel_Name'] or 'ws8_kernel' in r['Kernel_Name'] or 'wsw_kernel' in r['Kernel_Name'] or ('pw16_' in r['Kernel_Name'] and 'pack_batch' not in r['Kernel_Name'])]     # the backbone's convs; a LOANS_TILE_SPLIT conv is two launches
 t = sum(dur(r) for r in fwd)
 # optional: batch, MFMA peak (TFLOP/s) and algorithmic conv-forward FLOP per image of the run (defaults: configs[1], fp32)
 B = int(sys.argv[2]) if len(sys.argv) > 2 else 256
@@ -52,7 +52,7 @@ def union(iv):
 
 
 iv = [(int(r['Start_Timestamp']), int(r['End_Timestamp']), r['Kernel_Name']) for r in seg]
-mf = [(s, e) for s, e, n in iv if 'igemm' in n or 'wgrad' in n or 'stem7' in n or 'halo16' in n or 'ws8_kernel' in n or 'wsw_kernel' in n or 'pw16_' in n or 'crop_dgrad' in n]
+mf = [(s, e) for s, e, n in iv if 'igemm' in n or 'wgrad' in n or 'stem7' in n or 'halo16' in n or 'ws8_kernel' in n or 'wsw_kernel' in n or ('pw16_k' in n) or 'crop_dgrad' in n]
 al = [(s, e) for s, e, n in iv]
 t0, t1 = min(s for s, _ in al), max(e for _, e in al)
 print('\ntimeline of the step: %.2f ms; some kernel running %.2f ms (%.1f %%); an MFMA GEMM running %.2f ms (%.1f %%); '
@@ -77,7 +77,7 @@ for s, e in holes:
     inside = collections.Counter()
     for ks, ke, n in iv:
         ov = min(e, ke) - max(s, ks)
-        if ov > 0 and not ('igemm' in n or 'wgrad' in n or 'stem7' in n or 'halo16' in n or 'ws8_kernel' in n or 'wsw_kernel' in n or 'pw16_' in n or 'crop_dgrad' in n):
+        if ov > 0 and not ('igemm' in n or 'wgrad' in n or 'stem7' in n or 'halo16' in n or 'ws8_kernel' in n or 'wsw_kernel' in n or ('pw16_k' in n) or 'crop_dgrad' in n):
             inside['torch fill/copy' if 'at::native' in n else short(n)] += ov
     print('  +%8.1f us  %7.1f us  %s' % ((s - t0) / 1e3, (e - s) / 1e3,
                                           ', '.join('%s %.0f' % (k, v / 1e3) for k, v in inside.most_common(4))))
