@@ -379,3 +379,26 @@ def test_resolved_variants_live_with_the_tile_picks_and_stay_out_of_tables(tmp_p
     a = ops._class_candidates(ops.ConvGeometry(4, 56, 56, 64, 128, 3, 2, 1))
     monkeypatch.setattr(ops, 'CLASS_LAUNCH', False)
     assert a and ops._class_candidates(ops.ConvGeometry(4, 56, 56, 64, 128, 3, 2, 1)) == ()
+
+
+def test_pointwise_tile_offer_host_logic(monkeypatch):
+    """LOANS_TILE_PW is offered exactly where loans_pw16_covers (csrc/pw_bf16.hip) accepts the problem: a 1 x 1 / 1 convolution
+    without padding, no epilogue beyond the BN statistics, Cin 64 / 128 with Cout a multiple of 64 up to 512, or Cin 256 with Cout a
+    multiple of 128 up to 1024 -- and nowhere else (a tile the launcher refuses would fail the autotuner's timing run)."""
+    from loans_amd import ops
+    G = ops.ConvGeometry
+    yes = [G(2, 16, 16, 64, 256, 1, 1, 0), G(1, 5, 7, 64, 64, 1, 1, 0), G(2, 8, 8, 64, 512, 1, 1, 0), G(2, 8, 8, 128, 512, 1, 1, 0),
+           G(2, 8, 8, 128, 192, 1, 1, 0), G(2, 8, 8, 256, 1024, 1, 1, 0), G(2, 8, 8, 256, 128, 1, 1, 0)]
+    no = [G(2, 16, 16, 64, 256, 3, 1, 1),         # not 1 x 1
+          G(2, 16, 16, 64, 256, 1, 2, 0),         # strided
+          G(2, 16, 16, 64, 96, 1, 1, 0),          # Cout not a multiple of 64
+          G(2, 16, 16, 64, 576, 1, 1, 0),         # Cout beyond the slab
+          G(2, 16, 16, 32, 128, 1, 1, 0), G(2, 16, 16, 512, 2048, 1, 1, 0),       # Cin the kernels are not built for
+          G(2, 16, 16, 256, 192, 1, 1, 0), G(2, 16, 16, 256, 2048, 1, 1, 0)]       # Cin = 256: 128-column phases, Cout <= 1024
+    for g in yes:
+        assert ops._pw_tiles(g, True) == (ops.TILE_PW,), g.key
+        assert ops._pw_tiles(g, False) == (), g.key               # ReLU on the input / bias / addend: not this tile's epilogue
+    for g in no:
+        assert ops._pw_tiles(g, True) == (), g.key
+    monkeypatch.setattr(ops, 'PW', False)                         # LOANS_PW=0 (the switch is part of the memo key)
+    assert ops._pw_tiles(yes[0], True) == ()
