@@ -252,7 +252,7 @@ int loans_repack_dgrad_bf16(const float* src, void* dst, int32_t Cout, int32_t C
 /* All data-gradient weight re-packs of a step in ONE launch (csrc/weightprep.hip).  `jobs_dev`: a table of `njobs` jobs in DEVICE
  * memory, caller-owned and kept alive while launches that read it are in flight (built once: sources are parameter views of a
  * fixed arena, destinations persistent buffers).  Job i covers the blocks [first_tile, first_tile + tiles_co * tiles_ci * ntaps)
- * with tiles_co = ceil(Cout / 32), tiles_ci = ceil(Cin / 32); first_tile ascending from 0, `total_tiles` = their sum.  Each job
+ * with tiles_co = ceil(Cout / 64), tiles_ci = ceil(Cin / 64); first_tile ascending from 0, `total_tiles` = their sum.  Each job
  * is one loans_repack_dgrad_f32 (dst_bf16 = 0) or loans_repack_dgrad_bf16 (dst_bf16 = 1) call with at most
  * LOANS_REPACK_JOB_TAPS selected taps.  Replaces the per-class launches in front of every F.convolution_2d backward-data
  * (sheep/resnet.py:121-160, common/net.py:15-65). */

@@ -12,31 +12,36 @@ namespace {
 
 typedef __bf16 bf16_t;
 
-// dst[ci][t][co] = src[co][tapsel[t]][ci] through a 32 x 33 LDS tile (both sides coalesced); one block = one 32 x 32 tile of
-// one tap of one job
+// dst[ci][t][co] = src[co][tapsel[t]][ci] through a 64 x 65 LDS tile; one block = one 64 x 64 tile of one tap of one job: a wave
+// reads one 256-byte row of the source per load (16 in flight per thread) and writes one 128 / 256-byte run of the destination per
+// store.  (32 x 32 tiles -- 128-byte reads, 64-byte bf16 writes, four times the blocks -- took 190 us for ResNet-50's 94 MB.)
+constexpr int RT = 64;
 template <typename T>
-__device__ __forceinline__ void repack_tile(const loans_repack_job& j, int local, float (*tile)[33]) {
-    const int tiles = j.tiles_co * j.tiles_ci;
-    const int t = local / tiles;
-    const int rem = local - t * tiles;
-    const int co0 = (rem % j.tiles_co) * 32, ci0 = (rem / j.tiles_co) * 32;
-    const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+__device__ __forceinline__ void repack_tile(const loans_repack_job& j, int local, float (*tile)[RT + 1]) {
+    // the tap varies fastest over the blocks: blocks that run together read the taps of the SAME weight rows -- runs that lie 4 Cin
+    // bytes apart, one DRAM page -- instead of the same tap of rows that lie nine taps apart
+    const int rem = local / j.ntaps;
+    const int t = local - rem * j.ntaps;
+    const int co0 = (rem % j.tiles_co) * RT, ci0 = (rem / j.tiles_co) * RT;
+    const int tx = threadIdx.x & (RT - 1), ty = threadIdx.x / RT;
     const int st = j.tapsel[t];
     const float* src = static_cast<const float*>(j.src);
     T* dst = static_cast<T*>(j.dst);
-    for (int k = ty; k < 32; k += 8) {
+#pragma unroll 4
+    for (int k = ty; k < RT; k += 256 / RT) {
         const int co = co0 + k, ci = ci0 + tx;
         tile[k][tx] = (co < j.Cout && ci < j.Cin) ? src[((int64_t)co * j.src_taps + st) * j.Cin + ci] : 0.f;
     }
     __syncthreads();
-    for (int k = ty; k < 32; k += 8) {
+#pragma unroll 4
+    for (int k = ty; k < RT; k += 256 / RT) {
         const int ci = ci0 + k, co = co0 + tx;
         if (ci < j.Cin && co < j.Cout) dst[((int64_t)ci * j.ntaps + t) * j.Cout + co] = (T)tile[tx][k];
     }
 }
 
 __global__ __launch_bounds__(256) void repack_batch_kernel(const loans_repack_job* jobs, int njobs) {
-    __shared__ float tile[32][33];
+    __shared__ float tile[RT][RT + 1];
     // the job of this block: the last one whose first tile is <= blockIdx.x (uniform: scalar loads)
     int lo = 0, hi = njobs - 1;
     const int b = blockIdx.x;

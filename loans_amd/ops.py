@@ -1674,7 +1674,7 @@ def _prepacked_dgrad_weights(w, geo, bf16):
             j.Cout, j.Cin, j.src_taps, j.ntaps = geo.Cout, geo.Cin, geo.k * geo.k, d.ntaps
             for t in range(d.ntaps):
                 j.tapsel[t] = tapsel[t]
-            j.tiles_co, j.tiles_ci, j.dst_bf16 = (geo.Cout + 31) // 32, (geo.Cin + 31) // 32, int(bool(bf16))
+            j.tiles_co, j.tiles_ci, j.dst_bf16 = (geo.Cout + 63) // 64, (geo.Cin + 63) // 64, int(bool(bf16))
             jobs.append(j)
         entry = wp.repacks[key] = {'buf': buf, 'jobs': jobs, 'w': w, 'used': wp.step}      # `w` keeps the source (its arena) alive
         wp.order.append(key)
