@@ -1,0 +1,31 @@
+#!/usr/bin/env python
+"""Development probe: the Adam-AMSGrad update and the arena cast ALONE (nothing else on the device), operands cold, at the
+ResNet-50 localizer's and the assessor's parameter counts -- against what they take at the end of a step (profiles/r4_r50_trace_summary.txt:
+2.2 / 1.7 TB/s)."""
+import os
+import sys
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import torch                # noqa: E402
+from loans_amd import ops   # noqa: E402
+
+scrub = torch.empty(512 << 20, device='cuda', dtype=torch.uint8)
+
+
+def timed(fn, reps=6):
+    fn()
+    best = 1e9
+    for _ in range(reps):
+        scrub.zero_()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(); fn(); e1.record(); e1.synchronize()
+        best = min(best, e0.elapsed_time(e1))
+    return best
+
+
+for n in (25_600_000, 11_200_000):
+    p, g, m, v, vh = (torch.rand(n, device='cuda') * 0.01 for _ in range(5))
+    ms = timed(lambda: ops.adam_amsgrad(p, g, m, v, vh, 1e-4, 0.9, 0.999, 1e-8, 1.0, 0.0))
+    print('adam_amsgrad n = %d: %.3f ms = %.2f TB/s (36 bytes per parameter)' % (n, ms, n * 36 / ms * 1e-9), flush=True)
+    ms = timed(lambda: ops.cast_bf16(p))
+    print('cast_bf16    n = %d: %.3f ms = %.2f TB/s (6 bytes per parameter)' % (n, ms, n * 6 / ms * 1e-9), flush=True)
