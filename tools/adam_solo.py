@@ -49,7 +49,7 @@ def timed_hot(fn, reps=6):
     return best, worst
 
 
-for n in (25_600_000, 11_200_000):
+for n in (25_600_000, 36_000_000, 48_000_000, 78_000_000):
     p, g, m, v, vh = (torch.rand(n, device='cuda') * 0.01 for _ in range(5))
     ms = timed(lambda: ops.adam_amsgrad(p, g, m, v, vh, 1e-4, 0.9, 0.999, 1e-8, 1.0, 0.0))
     print('adam_amsgrad n = %d: %.3f ms = %.2f TB/s (36 bytes per parameter)' % (n, ms, n * 36 / ms * 1e-9), flush=True)
