@@ -14,7 +14,7 @@ typedef __bf16 bf16_t;
 
 // dst[ci][t][co] = src[co][tapsel[t]][ci] through a 64 x 65 LDS tile; one block = one 64 x 64 tile of one tap of one job: a wave
 // reads one 256-byte row of the source per load (16 in flight per thread) and writes one 128 / 256-byte run of the destination per
-// store.  (32 x 32 tiles -- 128-byte reads, 64-byte bf16 writes, four times the blocks -- took 190 us for ResNet-50's 94 MB.)
+// store.  (32 x 32 tiles -- 128-byte reads, 64-byte bf16 writes, four times the blocks -- took 190 us for the 512 px ResNet-50 localizer's ~300 MB of weights, this 145.)
 constexpr int RT = 64;
 template <typename T>
 __device__ __forceinline__ void repack_tile(const loans_repack_job& j, int local, float (*tile)[RT + 1]) {
