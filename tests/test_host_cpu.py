@@ -402,3 +402,34 @@ def test_pointwise_tile_offer_host_logic(monkeypatch):
         assert ops._pw_tiles(g, True) == (), g.key
     monkeypatch.setattr(ops, 'PW', False)                         # LOANS_PW=0 (the switch is part of the memo key)
     assert ops._pw_tiles(yes[0], True) == ()
+
+
+def test_struct_mirrors_have_the_headers_layout(tmp_path):
+    """Every struct of include/loans_hip.h that crosses the C ABI has a Python mirror (ctypes.Structure in loans_amd/_lib.py, a NumPy
+    record dtype for the resampling jobs): sizes and field offsets are compared with what a C compiler makes of the header."""
+    import ctypes
+    import subprocess
+    from loans_amd import _lib
+    from loans_amd.common.datasets.resample import RESAMPLE_JOB
+    mirrors = {'loans_igemm_desc': _lib.IgemmDesc, 'loans_repack_job': _lib.RepackJob, 'loans_pw_pack_job': _lib.PwPackJob,
+               'loans_small_conv': _lib.SmallConv}
+    probes = [('loans_%s' % n.split('loans_')[1], f) for n, m in mirrors.items() for f, _ in m._fields_]
+    job_fields = [f for f in RESAMPLE_JOB.names if not f.startswith('_')]         # ('_pad' = the struct's tail padding)
+    probes += [('loans_resample_job', f) for f in job_fields]
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "loans_hip.h"', 'int main(void) {']
+    for s in list(mirrors) + ['loans_resample_job']:
+        src.append('  printf("%s %%zu\\n", sizeof(%s));' % (s, s))
+    for s, f in probes:
+        src.append('  printf("%s.%s %%zu\\n", offsetof(%s, %s));' % (s, f, s, f))
+    src += ['  return 0;', '}']
+    c_file, exe = tmp_path / 'layout.c', tmp_path / 'layout'
+    c_file.write_text('\n'.join(src))
+    subprocess.check_call(['gcc', '-I', os.path.join(ROOT, 'include'), '-o', str(exe), str(c_file)])
+    got = dict(line.split() for line in subprocess.check_output([str(exe)]).decode().splitlines())
+    for s, m in mirrors.items():
+        assert int(got[s]) == ctypes.sizeof(m), s
+        for f, _ in m._fields_:
+            assert int(got['%s.%s' % (s, f)]) == getattr(m, f).offset, (s, f)
+    assert int(got['loans_resample_job']) == RESAMPLE_JOB.itemsize
+    for f in job_fields:
+        assert int(got['loans_resample_job.%s' % f]) == RESAMPLE_JOB.fields[f][1], f
