@@ -236,6 +236,19 @@ int loans_igemm_pair_bf16s(const void* in, const void* w_ab, void* out_ab, doubl
  * they lie and transposed by the fragment reads (ds_read_b64_tr_b16).  Tiles 128x128, 64x64, 64x128, and 256x256 (512 threads, one
  * block per CU) for layers with >= 256 output channels. */
 int loans_wgrad_bf16s(const void* x, const void* gy, float* dw, const loans_igemm_desc* d, int32_t splits, void* stream);
+/* The same gradient WITHOUT atomics (round 5; replaces the backward-filter of F.convolution_2d at sheep/resnet.py:121-160 like the
+ * call above): every block STORES its raw partial tile into slab s = its pixel slice of `ws` ([slabs][Cout][ntaps * Cin] floats, the
+ * layout of dw; caller-owned, at least loans_wgrad_bf16s_ws_floats(d, splits) floats, no need to clear it), then
+ * loans_fold_slabs_f32 adds the slabs to dw in a FIXED order on the same stream: two runs give bit-identical gradients, and a
+ * launch closes with plain 128-byte-row stores plus one streaming pass instead of one fp32 atomic per partial sum (the halo form
+ * ends with 18.9 M of them whatever the layer).  dw must not be written by another stream between the two launches. */
+int loans_wgrad_bf16s_ws(const void* x, const void* gy, float* dw, const loans_igemm_desc* d, int32_t splits,
+                         float* ws, int64_t ws_floats, void* stream);
+/* floats of workspace that call takes for (d, splits) -- host arithmetic only, nothing is launched; < 0: a LOANS_E* code */
+int64_t loans_wgrad_bf16s_ws_floats(const loans_igemm_desc* d, int32_t splits);
+/* dst[i] += ws[0][i] + ws[1][i] + ... + ws[slabs - 1][i] for i < n (n % 4 == 0, 16-byte aligned pointers): every output is summed
+ * by ONE thread group in an order that depends on (n, slabs) only -- deterministic, no atomics. */
+int loans_fold_slabs_f32(const float* ws, float* dst, int64_t n, int32_t slabs, void* stream);
 /* Split-K on bf16 storage for grids that cannot fill the machine (res6 / res7 at 512 px: 2048 - 8192 rows, K = 4608): block
  * (tile, s) contracts every `splits`-th slice of K and ADDS its raw fp32 tile to `partial` [B * outH * outW][Cout] (zeroed by the
  * caller; the descriptor's flags may only carry RELU_IN / DENSE; the implicit-GEMM tiles only); the parity classes of a strided

@@ -81,6 +81,8 @@ SIGNATURES = {
     'loans_wgrad_bf16_f32': [_p, _p, _p, C.POINTER(IgemmDesc), _i32, _p],
     'loans_igemm_bf16s': [_p, _p, _p, _p, _p, _p, _p, C.POINTER(IgemmDesc), _p],
     'loans_wgrad_bf16s': [_p, _p, _p, C.POINTER(IgemmDesc), _i32, _p],
+    'loans_wgrad_bf16s_ws': [_p, _p, _p, C.POINTER(IgemmDesc), _i32, _p, _i64, _p],
+    'loans_fold_slabs_f32': [_p, _p, _i64, _i32, _p],
     'loans_cast_bf16': [_p, _p, _i64, _p],
     'loans_repack_dgrad_bf16': [_p, _p, _i32, _i32, _i32, C.POINTER(_i32), _i32, _p],
     'loans_bn_apply_bf16': [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p],
@@ -173,6 +175,8 @@ def load():
         fn.argtypes = argtypes
         fn.restype = C.c_int
     lib.loans_hip_version.restype = C.c_char_p
+    lib.loans_wgrad_bf16s_ws_floats.argtypes = [C.POINTER(IgemmDesc), _i32]
+    lib.loans_wgrad_bf16s_ws_floats.restype = C.c_int64
     lib.loans_hip_version.argtypes = []
     _lib = lib
     return lib

@@ -135,5 +135,6 @@ int loans_pw16_launch(const void* in, const void* w, void* out, double* stats, c
 // wgrad_halo_bf16.hip: weight gradient of stride-1 3 x 3 convolutions on bf16 storage with all taps in one block
 // (LOANS_TILE_WGHALO_*; internal, reached through loans_wgrad_bf16s)
 int loans_wgrad_halo16_covers(const loans_igemm_desc* d, int tile);
+int loans_wgrad_halo16_slabs(const loans_igemm_desc* d, int tile, int splits);
 int loans_wgrad_halo16_launch(const void* x, const void* gy, float* dw, const loans_igemm_desc* d, int tile, int splits,
-                              unsigned x_bytes, unsigned gy_bytes, hipStream_t st);
+                              unsigned x_bytes, unsigned gy_bytes, float* ws, int* slabs, hipStream_t st);

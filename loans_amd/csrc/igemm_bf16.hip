@@ -746,6 +746,10 @@ struct Wgrad16Args {
     loans_igemm_desc d;
     int M, Ktot, tiles_co, tiles_j, splits, chunks_per_split;
     unsigned x_bytes, gy_bytes;
+    // partial slabs (loans_wgrad_bf16s_ws): block (tile, split) STORES its raw tile into slab `split` of `ws` ([splits][Cout][Ktot],
+    // the layout of dw) instead of adding it to dw with atomics; loans_fold_slabs_f32 sums the slabs in a fixed order
+    float* ws;
+    int64_t slab;
 };
 
 constexpr int WPC = 32;     // pixels (reduction rows) per staged chunk
@@ -922,6 +926,7 @@ __global__ __launch_bounds__(64 * NWV) void wgrad16_kernel(const Wgrad16Args a) 
         }
     }
 
+    float* const slab = a.ws ? a.ws + (int64_t)split * a.slab : nullptr;     // (every block writes its whole tile: an idle one its zeros)
 #pragma unroll
     for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -930,17 +935,17 @@ __global__ __launch_bounds__(64 * NWV) void wgrad16_kernel(const Wgrad16Args a) 
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int co = tco * BCO + wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                if (co < d.Cout && jc < a.Ktot) atomic_add_f32(a.dw + (int64_t)co * a.Ktot + jc, acc[i][j][e]);
+                if (co < d.Cout && jc < a.Ktot) {
+                    if (slab) slab[(int64_t)co * a.Ktot + jc] = acc[i][j][e];
+                    else atomic_add_f32(a.dw + (int64_t)co * a.Ktot + jc, acc[i][j][e]);
+                }
             }
         }
 }
 
-template <int BCO, int BJ, int NWV, bool RELU>
-int launch_wgrad16_r(Wgrad16Args& a, int splits_req, hipStream_t st) {
-    static loans_device_once lds_limit_set;       // per template instance = per kernel, one bit per device
-    constexpr size_t lds = (size_t)2 * WPC * ((BCO + 32) + (BJ + 32)) * 2;
-    auto kern = wgrad16_kernel<BCO, BJ, NWV, RELU>;
-    if (int rc_ = loans_raise_lds_limit(lds_limit_set, reinterpret_cast<const void*>(kern), lds)) return rc_;
+// the pixel slices per output tile a request runs (0 = the default); sets the tile grid of `a`
+template <int BCO, int BJ>
+int plan_wgrad16(Wgrad16Args& a, int splits_req) {
     a.tiles_co = (a.d.Cout + BCO - 1) / BCO;
     a.tiles_j = (a.Ktot + BJ - 1) / BJ;
     const int total_chunks = (a.M + WPC - 1) / WPC;
@@ -955,6 +960,16 @@ int launch_wgrad16_r(Wgrad16Args& a, int splits_req, hipStream_t st) {
     if (splits > total_chunks) splits = total_chunks;
     a.chunks_per_split = (total_chunks + splits - 1) / splits;
     a.splits = (total_chunks + a.chunks_per_split - 1) / a.chunks_per_split;
+    return a.splits;
+}
+
+template <int BCO, int BJ, int NWV, bool RELU>
+int launch_wgrad16_r(Wgrad16Args& a, int splits_req, hipStream_t st) {
+    static loans_device_once lds_limit_set;       // per template instance = per kernel, one bit per device
+    constexpr size_t lds = (size_t)2 * WPC * ((BCO + 32) + (BJ + 32)) * 2;
+    auto kern = wgrad16_kernel<BCO, BJ, NWV, RELU>;
+    if (int rc_ = loans_raise_lds_limit(lds_limit_set, reinterpret_cast<const void*>(kern), lds)) return rc_;
+    plan_wgrad16<BCO, BJ>(a, splits_req);
     hipLaunchKernelGGL(kern, dim3(a.tiles_co * a.tiles_j * a.splits), dim3(64 * NWV), lds, st, a);
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;
@@ -1213,9 +1228,12 @@ extern "C" int loans_repack_dgrad_bf16(const float* src, void* dst, int32_t Cout
     return LOANS_OK;
 }
 
-extern "C" int loans_wgrad_bf16s(const void* x, const void* gy, float* dw, const loans_igemm_desc* d,
-                                 int32_t splits, void* stream) {
-    if (!d || !x || !gy || !dw) return LOANS_EINVAL;
+// One implementation behind loans_wgrad_bf16s (atomics into dw), loans_wgrad_bf16s_ws (partial slabs + fold) and
+// loans_wgrad_bf16s_ws_floats (plan only: *need = floats of workspace the request takes, nothing is launched)
+static int wgrad_bf16s_impl(const void* x, const void* gy, float* dw, const loans_igemm_desc* d, int32_t splits, float* ws,
+                            int64_t ws_floats, int64_t* need, void* stream) {
+    const bool plan_only = need != nullptr;
+    if (!d || (!plan_only && (!x || !gy || !dw))) return LOANS_EINVAL;
     if (d->B <= 0 || d->inH <= 0 || d->inW <= 0 || d->Cin <= 0 || (d->Cin & 7)) return LOANS_EINVAL;
     if (d->outH <= 0 || d->outW <= 0 || d->Cout <= 0 || (d->Cout & 7)) return LOANS_EINVAL;
     if (d->gridH <= 0 || d->gridW <= 0 || d->osy <= 0 || d->osx <= 0 || d->isy <= 0 || d->isx <= 0) return LOANS_EINVAL;
@@ -1247,6 +1265,8 @@ extern "C" int loans_wgrad_bf16s(const void* x, const void* gy, float* dw, const
     a.x = static_cast<const __bf16*>(x); a.gy = static_cast<const __bf16*>(gy); a.dw = dw; a.d = *d;
     a.M = d->B * d->gridH * d->gridW;
     a.Ktot = d->ntaps * d->Cin;
+    a.ws = nullptr;
+    a.slab = (int64_t)d->Cout * a.Ktot;
     {
         const int64_t xb = (int64_t)d->B * d->inH * d->inW * (dense ? 1 : d->Cin) * 2;
         const int64_t gb = (int64_t)d->B * d->outH * d->outW * d->Cout * 2;
@@ -1256,13 +1276,47 @@ extern "C" int loans_wgrad_bf16s(const void* x, const void* gy, float* dw, const
     hipStream_t st = as_stream(stream);
     int tile = d->tile;
     if (tile == 0) tile = (d->Cout <= 64) ? (a.Ktot <= 64 ? LOANS_TILE_64x64 : LOANS_TILE_64x128) : LOANS_TILE_128x128;
-    if (tile == LOANS_TILE_WGHALO_64 || tile == LOANS_TILE_WGHALO_128)
-        return loans_wgrad_halo16_launch(x, gy, dw, d, tile, splits, a.x_bytes, a.gy_bytes, st);
-    if (tile == LOANS_TILE_64x64) return launch_wgrad16<64, 64>(a, splits, st);
-    if (tile == LOANS_TILE_128x128) return launch_wgrad16<128, 128>(a, splits, st);
-    if (tile == LOANS_TILE_64x128) return launch_wgrad16<64, 128>(a, splits, st);
-    if (tile == LOANS_TILE_256x256) return launch_wgrad16<256, 256, 8>(a, splits, st);
-    return LOANS_EINVAL;
+    const bool halo = tile == LOANS_TILE_WGHALO_64 || tile == LOANS_TILE_WGHALO_128;
+    // the slabs this request writes: one per pixel slice (the launchers' own arithmetic)
+    int slabs;
+    if (halo) slabs = loans_wgrad_halo16_slabs(d, tile, splits);
+    else if (tile == LOANS_TILE_64x64) slabs = plan_wgrad16<64, 64>(a, splits);
+    else if (tile == LOANS_TILE_128x128) slabs = plan_wgrad16<128, 128>(a, splits);
+    else if (tile == LOANS_TILE_64x128) slabs = plan_wgrad16<64, 128>(a, splits);
+    else if (tile == LOANS_TILE_256x256) slabs = plan_wgrad16<256, 256>(a, splits);
+    else return LOANS_EINVAL;
+    if (slabs < 1) return slabs < 0 ? slabs : LOANS_EINVAL;
+    if (plan_only) { *need = (int64_t)slabs * a.slab; return LOANS_OK; }
+    const bool use_ws = ws != nullptr;
+    if (use_ws) {
+        if (ws_floats < (int64_t)slabs * a.slab) return LOANS_EINVAL;
+        a.ws = ws;
+    }
+    int rc;
+    if (halo) rc = loans_wgrad_halo16_launch(x, gy, dw, d, tile, splits, a.x_bytes, a.gy_bytes, a.ws, nullptr, st);
+    else if (tile == LOANS_TILE_64x64) rc = launch_wgrad16<64, 64>(a, splits, st);
+    else if (tile == LOANS_TILE_128x128) rc = launch_wgrad16<128, 128>(a, splits, st);
+    else if (tile == LOANS_TILE_64x128) rc = launch_wgrad16<64, 128>(a, splits, st);
+    else rc = launch_wgrad16<256, 256, 8>(a, splits, st);
+    if (rc != LOANS_OK || !use_ws) return rc;
+    return loans_fold_slabs_f32(ws, dw, a.slab, slabs, stream);
+}
+
+extern "C" int loans_wgrad_bf16s(const void* x, const void* gy, float* dw, const loans_igemm_desc* d,
+                                 int32_t splits, void* stream) {
+    return wgrad_bf16s_impl(x, gy, dw, d, splits, nullptr, 0, nullptr, stream);
+}
+
+extern "C" int loans_wgrad_bf16s_ws(const void* x, const void* gy, float* dw, const loans_igemm_desc* d, int32_t splits,
+                                    float* ws, int64_t ws_floats, void* stream) {
+    if (!ws) return LOANS_EINVAL;
+    return wgrad_bf16s_impl(x, gy, dw, d, splits, ws, ws_floats, nullptr, stream);
+}
+
+extern "C" int64_t loans_wgrad_bf16s_ws_floats(const loans_igemm_desc* d, int32_t splits) {
+    int64_t need = 0;
+    const int rc = wgrad_bf16s_impl(nullptr, nullptr, nullptr, d, splits, nullptr, 0, &need, nullptr);
+    return rc == LOANS_OK ? need : (int64_t)rc;
 }
 
 #ifdef LOANS_STAMPS

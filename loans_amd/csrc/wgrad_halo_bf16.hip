@@ -50,6 +50,10 @@ struct WgHaloArgs {
     int pairs_co, pairs_c;          // channel tile grid
     int tiles_per_block;
     unsigned x_bytes, gy_bytes;
+    // partial slabs (loans_wgrad_bf16s_ws): block (pair, split) STORES its raw tile into slab `split` of `ws` ([splits][Cout][9 Cin],
+    // the layout of dw) instead of adding it to dw with atomics; loans_fold_slabs_f32 then sums the slabs in a fixed order
+    float* ws;
+    int64_t slab;
 };
 
 __device__ __forceinline__ int xcd_remap(int id, int nblk) {
@@ -194,8 +198,10 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void wgrad_halo16_kerne
         }
     }
 
-    // dw[co][(i, j)][c] += acc: fp32 atomics into the gradient arena (one per element and block)
+    // dw[co][(i, j)][c] += acc: fp32 atomics into the gradient arena (one per element and block), or -- with a workspace --
+    // plain stores of the raw tile into this block's slab (every block writes its whole tile, also an idle one its zeros)
     const int ktot = 9 * a.Cin;
+    float* const slab = a.ws ? a.ws + (int64_t)split * a.slab : nullptr;
     if constexpr (WGH_DBG & 1) {        // every accumulator stays live
         float sum = 0.f;
 #pragma unroll
@@ -213,17 +219,15 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void wgrad_halo16_kerne
 #pragma unroll
             for (int e = 0; e < 16; ++e) {
                 const int co = tco * BCO + wm * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-                atomic_add_f32(a.dw + (int64_t)co * ktot + col, acc[i * 3 + j][e]);
+                if (slab) slab[(int64_t)co * ktot + col] = acc[i * 3 + j][e];
+                else atomic_add_f32(a.dw + (int64_t)co * ktot + col, acc[i * 3 + j][e]);
             }
         }
 }
 
-template <int BCO, int NWV, bool RELU>
-int launch(WgHaloArgs& a, int splits_req, hipStream_t st) {
-    static loans_device_once lds_limit_set;
-    constexpr size_t lds = (size_t)(TH * TW * (BCO + 32) + HH * HW * SX) * 2;
-    auto kern = wgrad_halo16_kernel<BCO, NWV, RELU>;
-    if (int rc_ = loans_raise_lds_limit(lds_limit_set, reinterpret_cast<const void*>(kern), lds)) return rc_;
+// blocks per channel-tile pair the launcher runs for a request (0 = its default), or an error code (< 0); sets the tile grid of `a`
+template <int BCO, int NWV>
+int plan_splits(WgHaloArgs& a, int splits_req) {
     a.pairs_co = a.Cout / BCO;
     a.pairs_c = a.Cin / BC;
     const int npairs = a.pairs_co * a.pairs_c;
@@ -233,16 +237,35 @@ int launch(WgHaloArgs& a, int splits_req, hipStream_t st) {
         if (cus <= 0) return LOANS_EINVAL;
         const int slots = cus * (NWV == 4 ? 2 : 1);
         splits = (2 * slots + npairs - 1) / npairs;                 // about two rounds of the machine's block slots
-        const int max_splits = (a.ntiles + 3) / 4;                  // >= 4 pixel tiles per block: 9 * 32 * 32 atomics each
+        const int max_splits = (a.ntiles + 3) / 4;                  // >= 4 pixel tiles per block: 9 * 32 * 32 partial sums each
         if (splits > max_splits) splits = max_splits;
     }
     if (splits > a.ntiles) splits = a.ntiles;
     if (splits < 1) splits = 1;
     a.tiles_per_block = (a.ntiles + splits - 1) / splits;
-    splits = (a.ntiles + a.tiles_per_block - 1) / a.tiles_per_block;
-    hipLaunchKernelGGL(kern, dim3(npairs * splits), dim3(64 * NWV), lds, st, a);
+    return (a.ntiles + a.tiles_per_block - 1) / a.tiles_per_block;
+}
+
+template <int BCO, int NWV, bool RELU>
+int launch(WgHaloArgs& a, int splits_req, hipStream_t st, int* slabs) {
+    static loans_device_once lds_limit_set;
+    constexpr size_t lds = (size_t)(TH * TW * (BCO + 32) + HH * HW * SX) * 2;
+    auto kern = wgrad_halo16_kernel<BCO, NWV, RELU>;
+    const int splits = plan_splits<BCO, NWV>(a, splits_req);
+    if (splits < 0) return splits;
+    if (slabs) *slabs = splits;
+    if (int rc_ = loans_raise_lds_limit(lds_limit_set, reinterpret_cast<const void*>(kern), lds)) return rc_;
+    hipLaunchKernelGGL(kern, dim3(a.pairs_co * a.pairs_c * splits), dim3(64 * NWV), lds, st, a);
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;
+}
+
+void fill_args(WgHaloArgs& a, const loans_igemm_desc* d) {
+    a.B = d->B; a.H = d->inH; a.W = d->inW; a.Cin = d->Cin; a.Cout = d->Cout;
+    a.dy0 = d->dy[0]; a.dx0 = d->dx[0];
+    a.tiles_y = (a.H + TH - 1) / TH; a.tiles_x = (a.W + TW - 1) / TW;
+    a.ntiles = a.B * a.tiles_y * a.tiles_x;
+    a.slab = (int64_t)d->Cout * 9 * d->Cin;
 }
 
 }  // namespace
@@ -263,18 +286,26 @@ int loans_wgrad_halo16_covers(const loans_igemm_desc* d, int tile) {
     return 1;
 }
 
+// slabs the launch below would write for this request (>= 1), or an error code
+int loans_wgrad_halo16_slabs(const loans_igemm_desc* d, int tile, int splits) {
+    if (!loans_wgrad_halo16_covers(d, tile)) return LOANS_EINVAL;
+    WgHaloArgs a;
+    fill_args(a, d);
+    return tile == LOANS_TILE_WGHALO_64 ? plan_splits<64, 4>(a, splits) : plan_splits<128, 8>(a, splits);
+}
+
+// ws = nullptr: dw += the gradient by fp32 atomics.  ws != nullptr: the blocks store raw partial tiles into `*slabs` slabs of
+// Cout * 9 * Cin floats (the caller folds them, loans_fold_slabs_f32); dw is not touched
 int loans_wgrad_halo16_launch(const void* x, const void* gy, float* dw, const loans_igemm_desc* d, int tile, int splits,
-                              unsigned x_bytes, unsigned gy_bytes, hipStream_t st) {
+                              unsigned x_bytes, unsigned gy_bytes, float* ws, int* slabs, hipStream_t st) {
     if (!loans_wgrad_halo16_covers(d, tile)) return LOANS_EINVAL;
     WgHaloArgs a;
     a.x = static_cast<const __bf16*>(x); a.gy = static_cast<const __bf16*>(gy); a.dw = dw;
-    a.B = d->B; a.H = d->inH; a.W = d->inW; a.Cin = d->Cin; a.Cout = d->Cout;
-    a.dy0 = d->dy[0]; a.dx0 = d->dx[0];
-    a.tiles_y = (a.H + TH - 1) / TH; a.tiles_x = (a.W + TW - 1) / TW;
-    a.ntiles = a.B * a.tiles_y * a.tiles_x;
+    fill_args(a, d);
     a.x_bytes = x_bytes; a.gy_bytes = gy_bytes;
+    a.ws = ws;
     const bool relu = d->flags & LOANS_F_RELU_IN;
     if (tile == LOANS_TILE_WGHALO_64)
-        return relu ? launch<64, 4, true>(a, splits, st) : launch<64, 4, false>(a, splits, st);
-    return relu ? launch<128, 8, true>(a, splits, st) : launch<128, 8, false>(a, splits, st);
+        return relu ? launch<64, 4, true>(a, splits, st, slabs) : launch<64, 4, false>(a, splits, st, slabs);
+    return relu ? launch<128, 8, true>(a, splits, st, slabs) : launch<128, 8, false>(a, splits, st, slabs);
 }

@@ -121,7 +121,7 @@ def _variant(geo, *what):
     """key of geo.tuned under which a wrapper keeps the tile it resolved for one call variant (which flags, which switches):
     later calls skip building the candidate lists, the mode string and the tuning closure -- pure host time, 600 convolution
     calls per ResNet-50 step.  Lives in geo.tuned, so whatever clears a shape's picks clears these too; never saved to a table."""
-    return '~%r' % ((what, SPLITK, HALO, WGHALO, CLASS_LAUNCH, FINETAIL, STEM_DIRECT, COMPUTE, STORAGE, WGRAD_CUS_OF_8, TUNE_POLICY),)
+    return '~%r' % ((what, SPLITK, HALO, WGHALO, CLASS_LAUNCH, FINETAIL, STEM_DIRECT, COMPUTE, STORAGE, WGRAD_CUS_OF_8, TUNE_POLICY, PW),)
 
 
 _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None) or (lambda idx: torch.cuda.current_stream(idx).cuda_stream)
@@ -1376,6 +1376,34 @@ def _wghalo_candidates(geo):
     return tuple(out)
 
 
+# Weight gradients of the bf16-storage arm without atomics (round 5): the blocks store raw partial tiles into slabs of a
+# workspace and one deterministic pass folds them into the gradient arena (loans_wgrad_bf16s_ws).  One workspace per (device,
+# stream), grown to the largest request: launches on one stream run one after the other and may share it.
+# LOANS_WGRAD_SLABS=0: fp32 atomics into the arena again (the order of the sums then changes from run to run).
+WGRAD_SLABS = os.environ.get('LOANS_WGRAD_SLABS', '1') != '0'
+_wgrad_ws = {}
+
+
+def _wgrad_workspace(lib, geo, desc, tile, splits, device, st):
+    """(tensor, floats needed) for loans_wgrad_bf16s_ws on stream handle `st`, or None where it does not apply (a request the
+    library rejects; a workspace that would have to grow while a hipGraph is being captured)"""
+    plan = geo.__dict__.setdefault('_ws_need', {})
+    need = plan.get((tile, splits))
+    if need is None:
+        need = plan[(tile, splits)] = int(lib.loans_wgrad_bf16s_ws_floats(C.byref(desc), splits))
+    if need <= 0:
+        return None
+    key = (device.index, st)
+    ws = _wgrad_ws.get(key)
+    if ws is None or ws.numel() < need:
+        if torch.cuda.is_current_stream_capturing():
+            return None
+        ws = _wgrad_ws[key] = torch.empty(max(need, 1 << 22), device=device, dtype=torch.float32)
+        if st != _stream():
+            ws.record_stream(torch.cuda.ExternalStream(st, device=device))      # allocated on the current stream, used on `st`
+    return ws, need
+
+
 def _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile, stream=None):
     lib = _lib.load()
     _count_flops('wgrad', geo)
@@ -1394,7 +1422,13 @@ def _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile, stream=None):
     if tile == 0:
         def run(t):
             scratch = torch.empty(dw.numel(), device=x.device, dtype=torch.float32)
-            check(wfn(_ptr(x), _ptr(gy), _ptr(scratch), C.byref(_with_flags(geo.fwd, fl, t & 0xFF)), (t >> 8) or splits,
+            dt = _with_flags(geo.fwd, fl, t & 0xFF)
+            ws = _wgrad_workspace(lib, geo, dt, t & 0xFF, (t >> 8) or splits, x.device, _stream()) if (s16 and WGRAD_SLABS) else None
+            if ws is not None:
+                check(lib.loans_wgrad_bf16s_ws(_ptr(x), _ptr(gy), _ptr(scratch), C.byref(dt), (t >> 8) or splits, _ptr(ws[0]), ws[1],
+                                               _stream()), 'loans_wgrad_bf16s_ws[tune]')
+                return
+            check(wfn(_ptr(x), _ptr(gy), _ptr(scratch), C.byref(dt), (t >> 8) or splits,
                       _stream()), 'loans_wgrad[tune]')
         cands = _WGRAD16_TILES if s16 else _WGRAD_TILES
         if s16 and geo.Cout % 256 == 0:
@@ -1413,7 +1447,11 @@ def _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile, stream=None):
         tile, splits = tile & 0xFF, tile >> 8
     d = _with_flags(geo.fwd, fl, tile)
     st = stream if stream is not None else _stream()
-    check(wfn(_ptr(x), _ptr(gy), _ptr(dw), C.byref(d), splits, st), 'loans_wgrad')
+    ws = _wgrad_workspace(lib, geo, d, tile, splits, x.device, st) if (s16 and WGRAD_SLABS) else None
+    if ws is not None:
+        check(lib.loans_wgrad_bf16s_ws(_ptr(x), _ptr(gy), _ptr(dw), C.byref(d), splits, _ptr(ws[0]), ws[1], st), 'loans_wgrad_bf16s_ws')
+    else:
+        check(wfn(_ptr(x), _ptr(gy), _ptr(dw), C.byref(d), splits, st), 'loans_wgrad')
     if geo.dense and tile != TILE_STEM:         # the direct kernel never writes those columns
         # the window-padding columns of the dense layout saw real pixels: their "gradient" is not one
         check(lib.loans_mul_f32(_ptr(dw), _ptr(geo.wmask(x.device)), _ptr(dw), dw.numel(), st), 'loans_mul_f32')

@@ -147,6 +147,61 @@ def test_weight_gradient_halo_tiles(case, tile):
     assert rel_err(dw.cpu().numpy().transpose(0, 3, 1, 2), gwr_ref) < 1e-5
 
 
+
+@pytest.mark.parametrize("case", [(3, 64, 14, 14, 64, 3, 1, 1, 38), (2, 128, 20, 33, 128, 3, 1, 1, 39), (2, 128, 20, 33, 128, 3, 1, 1, 1),
+                                  (4, 64, 16, 16, 256, 1, 1, 0, 1), (2, 64, 15, 13, 128, 3, 2, 1, 3), (2, 256, 8, 8, 256, 3, 1, 1, 9),
+                                  (3, 128, 9, 9, 128, 4, 2, 1, 5)])
+@pytest.mark.parametrize("splits", [0, 1, 7])
+def test_weight_gradient_slabs_are_deterministic_and_equal_the_atomic_form(case, splits, monkeypatch):
+    """loans_wgrad_bf16s_ws (round 5): blocks store raw partial tiles into workspace slabs, loans_fold_slabs_f32 adds them to dw in a
+    fixed order.  Every tile form (plain GEMM tiles incl. the 512-thread one, the halo tiles), 1x1 / 3x3 / 4x4, strided: (a) two runs
+    give BIT-IDENTICAL gradients; (b) the result equals the oracle on the bf16-rounded operands to 1e-5 like the atomic form,
+    which it agrees with to fp32 rounding; (c) accumulation into a non-zero dw."""
+    from loans_amd import ops
+    B, Cin, H, W, Cout, k, stride, pad, tile = case
+    rng = np.random.RandomState(23)
+    x = _r(rng.standard_normal((B, Cin, H, W)))
+    geo = ops.ConvGeometry(B, H, W, Cin, Cout, k, stride, pad)
+    gy = _r(rng.standard_normal((B, Cout, geo.Ho, geo.Wo)))
+    w = np.zeros((Cout, Cin, k, k))
+    _, col = C.conv2d_fwd(x.astype(np.float64), w, None, stride, pad)
+    _, gw_ref, _ = C.conv2d_bwd(x.shape, col, w, gy.astype(np.float64), stride, pad, False, need_gx=False)
+    xd, gyd = d16(_nhwc(x)), d16(_nhwc(gy))
+    assert ops.WGRAD_SLABS
+    runs = []
+    for _ in range(2):
+        dw = torch.zeros((Cout, k, k, Cin), device='cuda')
+        ops._conv_wgrad(xd, gyd, dw, geo, False, splits, tile)
+        runs.append(dw)
+    assert torch.equal(runs[0], runs[1])
+    got = runs[0].cpu().numpy().transpose(0, 3, 1, 2)
+    assert rel_err(got, gw_ref) < 1e-5, rel_err(got, gw_ref)
+    start = rng.standard_normal((Cout, k, k, Cin)).astype(np.float32)
+    dw = dev(start)
+    ops._conv_wgrad(xd, gyd, dw, geo, False, splits, tile)
+    assert rel_err((dw.cpu().numpy() - start).transpose(0, 3, 1, 2), gw_ref) < 1e-5
+    monkeypatch.setattr(ops, 'WGRAD_SLABS', False)
+    atomic = torch.zeros((Cout, k, k, Cin), device='cuda')
+    ops._conv_wgrad(xd, gyd, atomic, geo, False, splits, tile)
+    assert rel_err(got, atomic.cpu().numpy().transpose(0, 3, 1, 2)) < 1e-5
+
+
+def test_fold_slabs_every_thread_shape():
+    """loans_fold_slabs_f32 on every (units, slabs) regime of its thread map (1 .. 32 threads across the slabs of a unit), against a
+    float64 sum; dst accumulates"""
+    from loans_amd import _lib, ops
+    import ctypes
+    lib = _lib.load()
+    rng = np.random.RandomState(3)
+    for n, slabs in [(64, 1), (4096, 3), (36864, 512), (147456, 128), (10752, 341), (2359296, 8), (1024, 40), (4, 700)]:
+        ws = rng.standard_normal((slabs, n)).astype(np.float32)
+        base = rng.standard_normal(n).astype(np.float32)
+        dst = dev(base)
+        _lib.check(lib.loans_fold_slabs_f32(ops._ptr(dev(ws)), ops._ptr(dst), n, slabs, ops._stream()), 'loans_fold_slabs_f32')
+        want = base.astype(np.float64) + ws.astype(np.float64).sum(0)
+        np.testing.assert_allclose(dst.cpu().numpy(), want, rtol=0, atol=2e-6 * max(1.0, np.sqrt(slabs)) * 4)
+
+
 def test_bn_passes_bf16_storage():
     """bn_apply (3 modes), bn_backward (single / dual, with and without the ReLU mask) on bf16 tensors against the
     fp32 kernels fed the same (already rounded) values"""
