@@ -83,6 +83,7 @@ SIGNATURES = {
     'loans_wgrad_bf16s': [_p, _p, _p, C.POINTER(IgemmDesc), _i32, _p],
     'loans_wgrad_bf16s_ws': [_p, _p, _p, C.POINTER(IgemmDesc), _i32, _p, _i64, _p],
     'loans_fold_slabs_f32': [_p, _p, _i64, _i32, _p],
+    'loans_wgrad_bf16s_ws_floats': [C.POINTER(IgemmDesc), _i32],
     'loans_cast_bf16': [_p, _p, _i64, _p],
     'loans_repack_dgrad_bf16': [_p, _p, _i32, _i32, _i32, C.POINTER(_i32), _i32, _p],
     'loans_bn_apply_bf16': [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p],
@@ -157,6 +158,9 @@ SIGNATURES = {
     'loans_adam_f32': [_p, _p, _p, _p, _i64, _f64, _p, _f64, _f64, _f64, _f64, _f64, _f64, _p],
 }
 
+# every entry point returns int (0 / LOANS_E* / hipError_t) except:
+RESTYPES = {'loans_wgrad_bf16s_ws_floats': C.c_int64}
+
 _lib = None
 
 
@@ -173,10 +177,8 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)          # AttributeError if the symbol is missing
         fn.argtypes = argtypes
-        fn.restype = C.c_int
+        fn.restype = RESTYPES.get(name, C.c_int)
     lib.loans_hip_version.restype = C.c_char_p
-    lib.loans_wgrad_bf16s_ws_floats.argtypes = [C.POINTER(IgemmDesc), _i32]
-    lib.loans_wgrad_bf16s_ws_floats.restype = C.c_int64
     lib.loans_hip_version.argtypes = []
     _lib = lib
     return lib

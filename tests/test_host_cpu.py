@@ -121,6 +121,8 @@ def test_every_entry_point_rejects_null_pointers(lib):
     tapsel = (ctypes.c_int32 * 1)(0)
     null_table = (ctypes.c_void_p * 4)()
     for name, argtypes in sorted(_lib.SIGNATURES.items()):
+        if name in _lib.RESTYPES:           # host-side planners (no pointers to reject): a size, not a status
+            continue
         args = []
         for t in argtypes:
             if t is ctypes.c_void_p:
