@@ -162,7 +162,7 @@ def dry_run(args):
     parallel.shutdown()
 
 
-PROFILE_TAGS = ('r4', 'r3', 'r2')          # newest first: the committed rocprofv3 evidence a default workload is tied to
+PROFILE_TAGS = ('r5', 'r4', 'r3', 'r2')          # newest first: the committed rocprofv3 evidence a default workload is tied to
 
 # The workloads with committed evidence under profiles/ (<tag>_<name>_tune.json = the tile table the timed run, the kernel trace
 # and the PMC passes of tools/profile_round.sh all ran on; <tag>_<name>_conv_fwd_hbm_traffic.json = the PMC bytes)
@@ -266,7 +266,7 @@ def conv_forward_roofline(w, log, flop_count, ev_overhead_ms, ms_per_step, world
         e[0] += 1
         e[1] += ms
     t_bound = t_bound_rw = t_meas = 0.0
-    n_hbm = 0
+    n_hbm = n_warn = 0
     layers = []
     for (flops, (rd, wr)), (cnt, ms) in sorted(per.items(), key=lambda kv: -kv[1][1]):
         t_f = flops / (peak * 1e12) * 1e3
@@ -285,8 +285,11 @@ def conv_forward_roofline(w, log, flop_count, ev_overhead_ms, ms_per_step, world
         # fast (launches of a few microseconds, where the bracket correction is the measurement, are exempt: tiny test shapes)
         if ms / cnt > 10 * ev_overhead_ms:
             # (the write-priced figure is NOT asserted: 4.6 TB/s is what a plain fill kernel reaches, not a law -- LOANS_TILE_PW's
-            # non-temporal row stores under its reads run res2's expansions at 1.00 of it)
+            # non-temporal row stores under its reads run res2's expansions at 1.00 of it; it is reported as a warning instead)
             assert layer["frac"] <= 1.0, ("conv-forward layer above its roofline", layer)
+            if layer["frac_write_priced"] > 1.05:
+                layer["warning"] = "above the write-priced bound by more than 5 %: check the byte count"
+                n_warn += 1
         layers.append(layer)
     roofline["binding"] = {
         "rule": "per launch max(algorithmic bytes / %.1f TB/s, algorithmic FLOP / %.0f TFLOP/s); algorithmic bytes = the input "
@@ -294,7 +297,7 @@ def conv_forward_roofline(w, log, flop_count, ev_overhead_ms, ms_per_step, world
         "frac": round(t_bound / max(t_meas, 1e-9), 4), "bound_ms_per_step": round(t_bound / steps, 3),
         "rule_write_priced": "reads at %.1f TB/s, writes at %.1f TB/s (tools/chip_peaks, profiles/r2_chip_peaks.txt)" % (HBM_READ_TBS, HBM_WRITE_TBS),
         "frac_write_priced": round(t_bound_rw / max(t_meas, 1e-9), 4),
-        "hbm_bound_launches_per_step": n_hbm // steps, "layers": layers}
+        "hbm_bound_launches_per_step": n_hbm // steps, "layers_above_write_priced_bound": n_warn, "layers": layers}
     # HBM bytes per launch from the PMC passes committed under profiles/ (FETCH_SIZE x2 + WRITE_SIZE, separate
     # rocprofv3 runs of this same command on the SAME tile table, see --tune-file / tools/profile_round.sh).  The file
     # carries the launch count of its own pass: bytes are divided by THAT, and a file whose pass launched other
@@ -329,6 +332,41 @@ def conv_forward_roofline(w, log, flop_count, ev_overhead_ms, ms_per_step, world
             "frac": round(step_flop / (ms_per_step * 1e-3) / 1e12 / peak, 4)}
     return roofline
 
+
+
+def whole_step_binding(w, class_count, ms_per_step, world):
+    """`roofline.whole_step.binding`: the WHOLE step priced like the conv forward -- per kernel class the algorithmic FLOP and bytes
+    of one step (counted live by loans_amd/ops.py: CLASS_COUNT) against max(bytes / 6.3 TB/s, FLOP / MFMA peak), beside the kernel
+    time of that class in the committed rocprofv3 trace of this workload on this tile table (profiles/<round>_<name>_class_times.json,
+    tools/class_times.py; null without one).  Two bounds for the step: `bound_ms_sum` = every class at its own roofline, one
+    after the other (no credit for overlap between streams); `bound_ms_machine` = max(all bytes / HBM rate, all FLOP / peak)."""
+    steps = w.steps
+    peak = (BF16_MFMA_PEAK_TFLOPS if w.dtype == 'bf16' else FP32_MFMA_PEAK_TFLOPS) * 1e12
+    bw = HBM_ACHIEVABLE_TBS * 1e12
+    name = STD_WORKLOADS.get((w.image_size, w.batch, w.dtype, w.storage, w.target_size, w.resnet50))
+    path = _profile_file(name, 'class_times') if (name and world == 1 and not w.graph) else None
+    measured = json.load(open(path))["kernel_ms"] if path else {}
+    classes, tot_f, tot_b, bound_sum = {}, 0, 0, 0.0
+    for cls, (flop, rd, wr) in sorted(class_count.items()):
+        flop, rd, wr = flop // steps, rd // steps, wr // steps
+        t_f, t_b = flop / peak * 1e3, (rd + wr) / bw * 1e3
+        b = max(t_f, t_b)
+        m = measured.get(cls)
+        classes[cls] = {"gflop": round(flop / 1e9, 1), "mbytes": round((rd + wr) / 1e6, 1), "bound": "mfma" if t_f >= t_b else "hbm",
+                        "bound_ms": round(b, 4), "kernel_ms": m, "frac": round(b / m, 3) if m else None,
+                        "gap_ms": round(m - b, 3) if m else None}
+        tot_f, tot_b, bound_sum = tot_f + flop, tot_b + rd + wr, bound_sum + b
+    machine = max(tot_f / peak, tot_b / bw) * 1e3
+    out = {"rule": "per class max(algorithmic bytes / %.1f TB/s, algorithmic FLOP / %.0f TFLOP/s), summed; kernel_ms from %s"
+                   % (HBM_ACHIEVABLE_TBS, peak / 1e12, os.path.relpath(path, ROOT) if path else "no committed trace of this workload"),
+           "classes": classes, "bound_ms_sum": round(bound_sum, 3), "bound_ms_machine": round(machine, 3),
+           "gbytes_per_step": round(tot_b / 1e9, 2), "tflop_per_step": round(tot_f / 1e12, 3),
+           "binding_frac": round(bound_sum / ms_per_step, 4), "machine_frac": round(machine / ms_per_step, 4)}
+    if measured:
+        gaps = sorted(((c, v["gap_ms"]) for c, v in classes.items() if v["gap_ms"] is not None), key=lambda kv: -kv[1])
+        out["largest_gaps"] = [{"class": c, "gap_ms": g} for c, g in gaps[:3]]
+        out["kernel_ms_sum"] = round(sum(v for v in measured.values()), 3)
+    return out
 
 def run_workload(w, comm, local_rank, retune):
     """One leg: build the models of workload `w`, W warm-up steps, exactly K timed steps between barrier + synchronize on
@@ -393,6 +431,7 @@ def run_workload(w, comm, local_rank, retune):
     # the step is being captured cannot be read)
     ops.EVENT_LOG = [] if (rank == 0 and not w.graph) else None
     ops.FLOP_COUNT = {} if rank == 0 else None         # algorithmic FLOP of every convolution launch of the timed steps
+    ops.CLASS_COUNT = {} if rank == 0 else None        # algorithmic FLOP / bytes of EVERY launch, per kernel class
     comm.barrier()
     torch.cuda.synchronize()
     mem0 = torch.cuda.memory_stats(dev)
@@ -408,6 +447,7 @@ def run_workload(w, comm, local_rank, retune):
     allocator = {k: int(mem1.get(k, 0) - mem0.get(k, 0)) for k in ('num_device_alloc', 'num_device_free', 'num_alloc_retries')}
     log, ops.EVENT_LOG = ops.EVENT_LOG, None
     flop_count, ops.FLOP_COUNT = ops.FLOP_COUNT, None
+    class_count, ops.CLASS_COUNT = ops.CLASS_COUNT, None
 
     # what the HOST needs to enqueue one step (after the timed region, not part of it): with the GPU idle at the start of
     # each call, update() returns as soon as its last launch is queued.  A value near ms_per_step means the step is launch-bound
@@ -440,6 +480,8 @@ def run_workload(w, comm, local_rank, retune):
     ms_per_step = elapsed / w.steps * 1e3
     value = B * world * w.steps / elapsed
     roofline = conv_forward_roofline(w, log, flop_count, ev_overhead_ms, ms_per_step, world) if log else None
+    if roofline is not None and class_count:
+        roofline.setdefault("whole_step", {})["binding"] = whole_step_binding(w, class_count, ms_per_step, world)
     backbone = "ResNet-50" if w.resnet50 else "ResNet-18"
     return {
         "value": round(value, 2), "unit": "images/s", "steps": w.steps, "warmup": w.warmup, "ms_per_step": round(ms_per_step, 3),
@@ -515,12 +557,12 @@ def main():
             # reported and the line says so.  The primary leg is never repeated: the contract times exactly K steps once.
             ref_ms = _reference_ms(workload_of(args, **over))
             if rank == 0 and ref_ms and leg["ms_per_step"] > 1.3 * ref_ms:
+                # (no selection -- the FIRST measurement stays the leg's figure, the repeat is attached beside it)
                 again = run_workload(workload_of(args, **over), comm, local_rank, retune)
-                first = leg["ms_per_step"]
-                if again["ms_per_step"] < leg["ms_per_step"]:
-                    leg = again
-                leg["remeasured"] = {"why": "first measurement %.3f ms/step was more than 1.3 x the committed %.3f" % (first, ref_ms),
-                                     "ms_per_step": [first, again["ms_per_step"]]}
+                leg["remeasured"] = {"why": "this measurement was more than 1.3 x the committed %.3f ms/step; measured once more, "
+                                            "both reported, the first one kept" % ref_ms,
+                                     "ms_per_step": [leg["ms_per_step"], again["ms_per_step"]],
+                                     "value": [leg["value"], again["value"]]}
             leg["metric"] = "localizer+assessor train images/sec"
             secondary[label] = leg
         if B16_EAGER in secondary and B16_GRAPH in secondary and rank == 0:

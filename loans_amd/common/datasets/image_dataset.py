@@ -65,6 +65,13 @@ def resize_bbox(bbox, in_size, out_size):
     return bbox
 
 
+class _ShapeOnly:
+    """what the augmentation's random draws look at when a frame is not on the host"""
+
+    def __init__(self, shape):
+        self.shape = tuple(shape)
+
+
 class ImageDataset:
 
     def __init__(self, paths, root='.', dtype=numpy.float32, **kwargs):
@@ -77,6 +84,13 @@ class ImageDataset:
         # `random` module; with two iterators preparing batches on threads of their own -- train and reference -- two datasets
         # on ONE global stream interleave their draws in thread-timing order and a seeded run is not reproducible)
         self._aug_rng = random.Random(kwargs.pop('augment_seed', None))
+        # decode once (frame_cache.py; not in the reference): `frame_cache_gb` > 0 keeps every decoded frame -- in HBM
+        # (`frame_cache_where='device'`) or in host memory ('host') -- up to that many GB; only `decode_batch` / `finish_batch`
+        # (the training feed) use it, `get_example` reads the file as the reference does
+        gb, where = kwargs.pop('frame_cache_gb', 0), kwargs.pop('frame_cache_where', 'device')
+        self._cache = None
+        if gb and gb > 0:
+            self.enable_frame_cache(gb, where)
         if isinstance(paths, str):
             with open(paths) as paths_file:
                 paths = [path.strip() for path in paths_file]
@@ -90,6 +104,14 @@ class ImageDataset:
 
     def reseed(self, seed):
         self._aug_rng = random.Random(seed)
+
+    def enable_frame_cache(self, gigabytes, where='device'):
+        """keep decoded frames for the next epochs (frame_cache.py).  The naive crop / flip branch hands strided views of a frame
+        to the resize: it always caches on the host."""
+        from .frame_cache import FrameCache
+        naive = (not self.use_imgaug) and self.transform_probability > 0
+        self._cache = FrameCache(int(gigabytes * (1 << 30)), 'host' if (naive or where == 'host') else 'device')
+        return self._cache
 
     def _imgaug_rows(self, image_chw):
         """the imgaug branch's draws for one example (None: branch off)"""
@@ -187,26 +209,43 @@ class ImageDataset:
         if self.image_mode != 'RGB' or self.image_size is None:
             raise ValueError('device_batch covers the training configuration: RGB frames resized to image_size')
         indices = list(indices)
+        cache = self._cache
+        cached = {i: cache.lookup(i) for i in indices} if cache is not None else {}
+        todo = [i for i in indices if cached.get(i) is None]
         if farm is not None:        # decode processes (decode_farm.py): Pillow's decoders hold the GIL, threads do not scale
-            images = farm.decode([os.path.join(self._root, self._paths[i]) for i in indices], map_fn)
+            fresh = farm.decode([os.path.join(self._root, self._paths[i]) for i in todo], map_fn) if todo else []
         else:
-            images = list(map_fn(self._read_u8, indices))
+            fresh = list(map_fn(self._read_u8, todo))
+        fresh = dict(zip(todo, fresh))
         frames, rows = [], []
-        for i, image in zip(indices, images):
-            if image is None or isinstance(image, int):          # not an 8-bit file, or unreadable (the read raises here)
-                image, r = self._augment(self._read(i), imgaug_rows=True)
-                image = image.transpose(1, 2, 0).astype(numpy.uint8)
-            else:
+        for i in indices:
+            image = cached.get(i)
+            if image is None:
+                image = fresh[i]
+                if image is None or isinstance(image, int):          # not an 8-bit file, or unreadable (the read raises here)
+                    image, r = self._augment(self._read(i), imgaug_rows=True)
+                    frames.append(image.transpose(1, 2, 0).astype(numpy.uint8))
+                    rows.append(r)
+                    continue
+                if cache is not None:
+                    cache.keep_host(i, image)
+            if isinstance(image, numpy.ndarray):
                 image, r = self._augment_u8(image)
+            else:                                       # resident in HBM: the draws need the frame's size only
+                r = self._imgaug_rows(_ShapeOnly((3,) + image.shape[:2])) or [[0] * 8] * 3
             frames.append(image)                      # possibly a strided view (crop / flip): frames_to_device copies it once
             rows.append(r)
-        return frames, (rows if self.use_imgaug and self.transform_probability > 0 else None)
+        rows = rows if self.use_imgaug and self.transform_probability > 0 else None
+        return (frames, rows, indices) if (cache is not None and cache.where == 'device') else (frames, rows)
 
     def finish_batch(self, decoded, device, map_fn=map):
         """Device half: upload the uint8 frames, run the imgaug stages, the LANCZOS resize, ``/ 255`` and the CHW layout on the
         GPU (resample.py / augment.py, the bytes of the host path).  ``map_fn`` spreads the copies into the pinned staging
         buffer over a pool."""
         from .resample import frames_to_device
+        if len(decoded) == 3:                           # frames resident in HBM among them (frame_cache.py)
+            frames, rows, indices = decoded
+            return self._cache.assemble(frames, rows, indices, self.image_size, device, map_fn)
         frames, rows = decoded
         return frames_to_device(frames, self.image_size, device, augment_rows=rows, map_fn=map_fn)
 

@@ -180,9 +180,12 @@ def resize_ragged(dev_all, frames, out_hw, filt='lanczos'):
     `dev_all`: Pillow's resize of each to out_hw and `/ 255`, as ONE launch pair -> [N][3][oh][ow] float32 in that order."""
     dev = dev_all.device
     oh, ow = int(out_hw[0]), int(out_hw[1])
-    arena = _arenas.get(dev)
+    # one arena per (device, stream): a feeding iterator finishes its batches on a stream of its own, and an arena's "full: start
+    # over" / regrow are only ordered against the launches of the stream that calls them (ADVICE r4)
+    akey = (dev, torch.cuda.current_stream(dev).cuda_stream)
+    arena = _arenas.get(akey)
     if arena is None:
-        arena = _arenas[dev] = _TableArena(dev)
+        arena = _arenas[akey] = _TableArena(dev)
     frames = [tuple(f) + (False,) * (4 - len(f)) for f in frames]
     at = arena.ensure({(W, ow, filt) for _, _, W, _ in frames} | {(H, oh, filt) for _, H, _, _ in frames})
     jobs = np.zeros(len(frames), RESAMPLE_JOB)
@@ -209,12 +212,14 @@ class _Staging:
     copy that read it, and is only overwritten once that copy has finished."""
 
     def __init__(self):
-        self.slots = {}
+        import threading
+        self.slots, self.lock = {}, threading.Lock()       # (the dict is shared by every feeding thread: guarded; a ring is its thread's own)
 
     def get(self, nbytes, kind='frames'):
         import threading
         key = (threading.get_ident(), kind)
-        ring = self.slots.setdefault(key, {'i': 0, 'bufs': [None, None], 'events': [None, None]})
+        with self.lock:
+            ring = self.slots.setdefault(key, {'i': 0, 'bufs': [None, None], 'events': [None, None]})
         i = ring['i'] = (ring['i'] + 1) % 2
         if ring['events'][i] is not None:
             ring['events'][i].synchronize()
@@ -225,8 +230,10 @@ class _Staging:
 
     def drop(self, thread_ident):
         """forget (and free) the buffers of a thread that is gone -- a feed iterator's finish thread"""
-        for key in [k for k in self.slots if k[0] == thread_ident]:
-            for ev in self.slots.pop(key)['events']:
+        with self.lock:
+            gone = [self.slots.pop(k) for k in [k for k in self.slots if k[0] == thread_ident]]
+        for ring in gone:
+            for ev in ring['events']:
                 if ev is not None:
                     ev.synchronize()
 
@@ -236,6 +243,26 @@ _staging = _Staging()
 
 def release_staging(thread_ident):
     _staging.drop(thread_ident)
+
+
+def upload_frames(images, device, map_fn=map):
+    """uint8 HWC RGB arrays of ONE size -> a device tensor [N][H][W][3]: staged into the thread's pinned ring (``map_fn`` spreads
+    the copies over a pool), one asynchronous upload"""
+    device = torch.device(device)
+    H, W = images[0].shape[:2]
+    per = H * W * 3
+    ring, slot, host = _staging.get(per * len(images))
+    host_np = host.numpy()
+
+    def stage(k):
+        np.copyto(host_np[k * per:(k + 1) * per].reshape(H, W, 3), images[k])
+
+    list(map_fn(stage, range(len(images))))
+    dev_all = host[:per * len(images)].to(device, non_blocking=True)
+    ev = torch.cuda.Event()
+    ev.record(torch.cuda.current_stream(device))
+    ring['events'][slot] = ev
+    return dev_all.view(len(images), H, W, 3)
 
 
 def frames_to_device(images, out_hw, device, augment_rows=None, map_fn=map):

@@ -99,6 +99,11 @@ class StemFunction(Function):
     def backward(self, inputs, gys):
         _require_train()
         _, W, b, gamma, beta = self.inputs
+        if ops.stem_backward_fused_ok(self.x, self.c, self.geo):
+            # bf16 storage arm: conv1's gradient tensor is never materialised (csrc/stem_bwd_bf16.hip)
+            ops.stem_backward_fused(gys[0].contiguous(), self.idx, self.c, self.st, gamma.data, gamma.grad_view, beta.grad_view,
+                                    b.grad_view, self.x, W.grad_view, self.geo)
+            return None, None, None, None, None
         gc = ops.pool_bn_backward(gys[0].contiguous(), self.idx, self.c, self.st, gamma.data, gamma.grad_view,
                                   beta.grad_view, gbias=b.grad_view)
         ops.conv_wgrad(self.x, gc, W.grad_view, self.geo)

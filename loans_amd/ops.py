@@ -111,6 +111,33 @@ def _count_flops(kind, geo):
     if FLOP_COUNT is not None:
         FLOP_COUNT[kind] = FLOP_COUNT.get(kind, 0) + 2 * geo.B * geo.Ho * geo.Wo * geo.Cout * geo.k * geo.k * geo.cin_logical
 
+
+# When bench.py sets this to a dict, every wrapper adds the ALGORITHMIC work of its launch(es) under a kernel class --
+# [FLOP, bytes read, bytes written]: 2 FLOP per MAC of a contraction (logical channels, no padding), every tensor a pass must touch
+# once, in its storage type (a BN backward that takes its own sums reads its operands twice: the sums must be complete before
+# the first output) -- `roofline.whole_step.binding` prices the step's classes against max(bytes / HBM rate, FLOP / MFMA peak).
+# Classes follow what a kernel trace can tell apart by name (tools/class_times.py): conv (forward + data gradient), wgrad,
+# bn_fwd, bn_bwd, stem (pool forward, the stem's backward), crop (STN sampler + the crop gradient), heads, optimizer (+ the
+# step's weight preparation and memsets).
+CLASS_COUNT = None
+
+
+def _nbytes(*tensors):
+    return sum(t.numel() * t.element_size() for t in tensors if t is not None)
+
+
+def _acct(cls, flop=0, rd=0, wr=0):
+    c = CLASS_COUNT
+    if c is not None:
+        e = c.setdefault(cls, [0, 0, 0])
+        e[0] += flop
+        e[1] += rd
+        e[2] += wr
+
+
+def _conv_flop(geo):
+    return 2 * geo.B * geo.Ho * geo.Wo * geo.Cout * geo.k * geo.k * geo.cin_logical
+
 BN_EPS = 2e-5          # chainer.links.BatchNormalization default (sheep/resnet.py:44)
 BN_DECAY = 0.9
 # Chainer 4.1.0's CPU path folds eps into the running variance (see oracle/chainer_ops.py)
@@ -414,6 +441,8 @@ def _pw_packed(lib, w, w16, geo, st):
         entry = wp.pw.get(key)
         if entry is not None:
             entry['used'] = wp.step
+            if torch.cuda.is_current_stream_capturing():
+                wp.captured_pw_keys.add(key)       # a graph being recorded has this buffer's address baked in: never evicted
             if key in wp.pw_prepared:
                 return entry['buf']
         elif len(wp.pw_order) < _MAX_PREP_JOBS and not torch.cuda.is_current_stream_capturing():
@@ -559,6 +588,8 @@ def _tuned_tile(geo, mode, run, candidates, cold=False):
         return tile
     TIMED_PICKS += 1
     times = {t: _time_call(lambda: run(t), cold=cold) for t in candidates}
+    if not TUNE_COLD:
+        _cold.clear()           # the 512 MB fill buffer of a cold-timed shape is not kept for the life of the process
     tile = min(times, key=times.get)
     geo.tuned[mode] = tile
     if os.environ.get('LOANS_TUNE_VERBOSE'):
@@ -736,6 +767,9 @@ def conv_fprop(x, w, geo, out=None, bias=None, stats=None, relu_in=False, addend
         geo.tuned[vkey] = tile
     d = _with_flags(geo.fwd, flags, tile)
     _count_flops('fprop', geo)
+    if CLASS_COUNT is not None:
+        rd, wr = _conv_bytes(geo, x, w, out)
+        _acct('conv', _conv_flop(geo), rd + _nbytes(addend), wr)
     log = EVENT_LOG
     if log is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -803,6 +837,9 @@ def conv_fprop_pair(x, w_a, w_b, geo_a, geo_b, stats_a=None, stats_b=None, tile=
         geo_a.tuned[vkey] = tile
     _count_flops('fprop', geo_a)
     _count_flops('fprop', geo_b)
+    if CLASS_COUNT is not None:
+        rd, wr = _sum_bytes(_conv_bytes(geo_a, x, w_a, out_a), _conv_bytes(geo_b, None, w_b, out_b))
+        _acct('conv', _conv_flop(geo_a) + _conv_flop(geo_b), rd, wr)
     log = EVENT_LOG
     if log is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -846,6 +883,9 @@ def _conv_fprop_pair16(lib, x, w_a, w_b, geo_a, geo_b, stats_a, stats_b, tile):
     out = mk()
     _count_flops('fprop', geo_a)
     _count_flops('fprop', geo_b)
+    if CLASS_COUNT is not None:
+        rd, wr = _sum_bytes(_conv_bytes(geo_a, x, w_ab[:n], out[0]), _conv_bytes(geo_b, None, w_ab[n:], out[1]))
+        _acct('conv', _conv_flop(geo_a) + _conv_flop(geo_b), rd, wr)
     log = EVENT_LOG
     if log is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -901,6 +941,9 @@ def _conv_fprop16(lib, x, w, geo, out, bias, stats, relu_in, addend, tile):
         geo.tuned[vkey] = tile
     d = _with_flags(geo.fwd, flags, tile)
     _count_flops('fprop', geo)
+    if CLASS_COUNT is not None:
+        rd, wr = _conv_bytes(geo, x, w16, out)
+        _acct('conv', _conv_flop(geo), rd + _nbytes(addend), wr)
     log = EVENT_LOG
     if log is not None:
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -1012,6 +1055,11 @@ def conv_dgrad(gy, w, geo, out=None, mask_ref=None, addend=None, addend_mask_ref
     lib = _lib.load()
     assert gy.numel() == geo.B * geo.Ho * geo.Wo * geo.Cout
     _count_flops('dgrad', geo)
+    if CLASS_COUNT is not None:
+        es = 2 if (_is16(gy) and geo.Cin != 4) else 4
+        _acct('crop' if geo.Cin == 4 else 'conv', _conv_flop(geo),
+              _nbytes(gy, w, mask_ref, addend, addend_mask_ref, bn_sums[0] if bn_sums is not None else None),
+              geo.B * geo.H * geo.W * geo.Cin * es)
     if _is16(gy) and geo.Cin != 4:
         return _conv_dgrad16(lib, gy, w, geo, out, mask_ref, addend, addend_mask_ref, tile, bn_sums)
     if out is None:
@@ -1166,7 +1214,9 @@ def crop_dgrad(gy_a, w_a, geo_a, gy_b=None, w_b=None, geo_b=None, addend=None):
     for gy, g in ((gy_a, geo_a), (gy_b, geo_b)):
         if gy is not None:
             _count_flops('dgrad', g)
+            _acct('crop', _conv_flop(g), _nbytes(gy))
     out = torch.empty((geo_a.B, geo_a.H, geo_a.W, 4), device=gy_a.device, dtype=torch.float32)
+    _acct('crop', 0, _nbytes(addend), _nbytes(out))
     mk = lambda g: _lib.SmallConv(g.k, g.stride, g.pad, g.Ho, g.Wo)      # noqa: E731
     ca, cb = mk(geo_a), (mk(geo_b) if geo_b is not None else None)
     fn = lib.loans_crop_dgrad_bf16_f32 if _is16(gy_a) else lib.loans_crop_dgrad_f32
@@ -1407,6 +1457,7 @@ def _wgrad_workspace(lib, geo, desc, tile, splits, device, st):
 def _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile, stream=None):
     lib = _lib.load()
     _count_flops('wgrad', geo)
+    _acct('wgrad', _conv_flop(geo), _nbytes(x, gy), _nbytes(dw))
     assert dw.numel() == geo.w_numel and x.numel() == geo.in_numel
     fl = (F_RELU_IN if relu_in else 0) | geo.base_flags
     s16 = _is16(x)
@@ -1470,6 +1521,7 @@ def prep_images(images_nchw, geo=None):
     B, c, H, W = images_nchw.shape
     assert c == 3
     _chk(images_nchw, 'images')
+    _acct('heads', 0, _nbytes(images_nchw), B * H * W * 3 * (2 if (STORAGE == 'bf16' and DENSE_BF16) else 4))
     if geo is not None and geo.dense:
         assert (geo.B, geo.H, geo.W) == (B, H, W)
         # bf16 storage arm: the frames leave this kernel as bf16 (the same rounding the bf16 arm applies to fp32 frames
@@ -1630,6 +1682,7 @@ class _WeightPrep:
                 if getattr(arena, 'data16', None) is None:
                     arena.data16 = torch.empty(arena.numel, device=arena.device, dtype=BF16)
                 check(lib.loans_cast_bf16(_ptr(arena.data), _ptr(arena.data16), arena.numel, st), 'loans_cast_bf16')
+                _acct('optimizer', 0, arena.numel * 4, arena.numel * 2)
                 self.shadow_ok[id(arena)] = arena.numel
         self._begin_pw(device, lib, st, capturing)
         if not self.order:
@@ -1654,6 +1707,9 @@ class _WeightPrep:
             self.captured_tables.append(self.table)
             self.captured_keys.update(self.order)
         check(lib.loans_repack_dgrad_batch(_ptr(self.table), self.njobs, self.total_tiles, st), 'loans_repack_dgrad_batch')
+        if CLASS_COUNT is not None:
+            n = sum(self.repacks[k]['buf'].numel() for k in self.order)
+            _acct('optimizer', 0, n * 4, sum(_nbytes(self.repacks[k]['buf']) for k in self.order))
         self.prepared = set(self.order)
 
 
@@ -1807,6 +1863,7 @@ def bn_apply(x, st, relu=True, residual=None, x2=None, st2=None, want_bits=False
         mode, second = 2, x2
     lib = _lib.load()
     assert second is None or second.dtype == x.dtype
+    _acct('bn_fwd', 0, _nbytes(x, second), _nbytes(y) + (rows * (C_ // 4) if (want_bits and relu and BN_BITS) else 0))
     if want_bits and relu and BN_BITS:
         bits = torch.empty(rows * (C_ // 4), device=x.device, dtype=torch.uint8)
         fn = lib.loans_bn_apply_bits_bf16 if _is16(x) else lib.loans_bn_apply_bits_f32
@@ -1828,6 +1885,7 @@ def bn_relu_maxpool(x, st):
     s16 = _is16(x)
     y = torch.empty((B, OH, OW, C_), device=x.device, dtype=x.dtype)
     idx = torch.empty((B, OH, OW, C_), device=x.device, dtype=torch.uint8)
+    _acct('stem', 0, _nbytes(x), _nbytes(y, idx))
     lib = _lib.load()
     fn = lib.loans_bn_relu_maxpool_bf16 if s16 else lib.loans_bn_relu_maxpool_f32
     check(fn(_ptr(x), _ptr(st.scale), _ptr(st.shift), _ptr(y), _ptr(idx), B, H, W, C_, OH, OW, _stream()),
@@ -1918,6 +1976,11 @@ def bn_backward(gy, mask, x, st, gamma, ggamma, gbeta, x2=None, st2=None, gamma2
     C_ = x.shape[-1]
     rows = x.numel() // C_
     dual = x2 is not None
+    if CLASS_COUNT is not None:
+        own = mask_is_own_relu and BN_XMASK and not dual and mask is not None
+        bits = None if own else (getattr(mask, 'relu_bits', None) if (mask is not None and BN_BITS) else None)
+        m = None if own else (bits if bits is not None else mask)
+        _acct('bn_bwd', 0, 2 * _nbytes(gy, x, x2, m), _nbytes(x) * (2 if dual else 1))       # sums, then apply: two passes
     if BN_REPLICAS and bn_units_ok(C_, _is16(x)):
         return _bn_backward_rep(lib, gy, mask, x, st, gamma, ggamma, gbeta, x2, st2, gamma2, ggamma2, gbeta2, mask_is_own_relu)
     if mask_is_own_relu and BN_XMASK and not dual and mask is not None:
@@ -1976,6 +2039,7 @@ def bn_backward_from_sums(gy, x, st, sums, gamma, ggamma, gbeta):
     rows = x.numel() // C_
     s = _stream()
     s16 = _is16(x)
+    _acct('bn_bwd', 0, _nbytes(gy, x), _nbytes(x))              # the sums rode in the data gradient's epilogue: one pass
     assert _is16(gy) == s16 and sums.numel() == STATS_REPLICAS * 2 * C_
     k = torch.empty((3, C_), device=x.device, dtype=torch.float32)
     check(lib.loans_bn_bwd_coeffs_rep_f32(_ptr(sums), STATS_REPLICAS, 2 * C_, 1, C_, rows, _ptr(gamma), _ptr(st.mean), _ptr(st.rstd),
@@ -1999,6 +2063,7 @@ def pool_bn_backward(gy, idx, x, st, gamma, ggamma, gbeta, gbias=None):
     up to summation order (and, on bf16 tensors, without the rounding of the intermediate)."""
     B, H, W, C_ = x.shape
     OH, OW = gy.shape[1], gy.shape[2]
+    _acct('stem', 0, 2 * _nbytes(gy, idx) + 2 * _nbytes(x), _nbytes(x))        # sums over the pooled gradient (gathers x), then gx
     if not (FUSED_STEM_TAIL and reduce_channels_ok(C_) and C_ <= 1024):
         gx = bn_backward(maxpool_relu_bwd(gy, idx, x, st), None, x, st, gamma, ggamma, gbeta)
         if gbias is not None:
@@ -2039,6 +2104,48 @@ def pool_bn_backward(gy, idx, x, st, gamma, ggamma, gbeta, gbias=None):
     return gx
 
 
+# The stem's backward of the bf16 storage arm in one kernel behind the BN sums (csrc/stem_bwd_bf16.hip, round 5): conv1's gradient
+# tensor is rebuilt tile by tile and contracted with the frames at once -- never written, never read back.
+# LOANS_STEM_BWD_FUSED=0: loans_pool_bn_bwd_apply_rep_bf16 -> loans_wgrad_bf16s(dense) -> the mask pass again.
+STEM_BWD_FUSED = os.environ.get('LOANS_STEM_BWD_FUSED', '1') != '0'
+
+
+def stem_backward_fused_ok(frames, y, geo):
+    """loans_stem_bwd_bf16 covers this stem: the dense 7x7 / 2, 3 -> 64 geometry on bf16 frames and a bf16 conv output"""
+    return STEM_BWD_FUSED and geo.dense and geo.k == 7 and geo.stride == 2 and geo.pad == 3 and geo.Cout == 64 and \
+        _is16(frames) and _is16(y) and y.is_contiguous() and frames.is_contiguous() and \
+        geo.B * geo.Hp * geo.Wp * 3 * 2 < 0x7FFFFFF0 and geo.B * geo.Ho * geo.Wo * 64 * 2 < 0x7FFFFFF0
+
+
+def stem_backward_fused(gy, idx, y, st, gamma, ggamma, gbeta, gbias, frames, dw, geo):
+    """pool_bn_backward(...) followed by conv_wgrad(frames, gx, dw, geo) without gx: the BN's two sums and its coefficients as
+    before (one reduction pass over the pooled gradient), then ONE kernel that rebuilds gx tiles in registers, adds their
+    per-channel sums to gbias and contracts them with the frames into dw.  On the current stream (it is the last kernel of
+    the localizer's backward: nothing is left to run beside a weight gradient on the side stream)."""
+    lib = _lib.load()
+    B, H, W, C_ = y.shape
+    OH, OW = gy.shape[1], gy.shape[2]
+    assert stem_backward_fused_ok(frames, y, geo) and C_ == 64 and _is16(gy) and gy.is_contiguous() and dw.numel() == geo.w_numel
+    s = _stream()
+    k = torch.empty((3, C_), device=y.device, dtype=torch.float32)
+    sums = _zeros_f64((STATS_REPLICAS, 2, C_), y.device)
+    check(lib.loans_pool_bn_bwd_reduce_rep_bf16(_ptr(gy), _ptr(idx), _ptr(y), _ptr(st.scale), _ptr(st.shift), _ptr(st.mean), _ptr(st.rstd),
+                                                _ptr(sums), STATS_REPLICAS, B, H, W, C_, OH, OW, s), 'loans_pool_bn_bwd_reduce_rep')
+    check(lib.loans_bn_bwd_coeffs_rep_f32(_ptr(sums), STATS_REPLICAS, 2 * C_, 0, C_, B * H * W, _ptr(gamma), _ptr(st.mean),
+                                          _ptr(st.rstd), _ptr(ggamma), _ptr(gbeta), _ptr(k[0]), _ptr(k[1]), _ptr(k[2]), s),
+          'loans_bn_bwd_coeffs_rep_f32')
+    need = int(lib.loans_stem_bwd_bf16_ws_floats(B, H, W))
+    key = (y.device.index, s)
+    ws = _wgrad_ws.get(key)
+    if ws is None or ws.numel() < need:
+        ws = _wgrad_ws[key] = torch.empty(max(need, 1 << 22), device=y.device, dtype=torch.float32)
+    _count_flops('wgrad', geo)
+    _acct('stem', _conv_flop(geo), 2 * _nbytes(gy, idx) + 2 * _nbytes(y) + _nbytes(frames), _nbytes(dw))     # gx is never stored
+    check(lib.loans_stem_bwd_bf16(_ptr(frames), _ptr(y), _ptr(gy), _ptr(idx), _ptr(st.scale), _ptr(st.shift), _ptr(k[0]), _ptr(k[1]),
+                                  _ptr(k[2]), _ptr(dw), _ptr(gbias), _ptr(ws), ws.numel(), B, geo.Hp, geo.Wp * 3, H, W, OH, OW, s),
+          'loans_stem_bwd_bf16')
+
+
 def colsum_acc(x, out):
     C_ = x.shape[-1]
     lib = _lib.load()
@@ -2052,6 +2159,7 @@ def colsum_acc(x, out):
 def gap_fwd(x):
     B, H, W, C_ = x.shape
     y = torch.empty((B, C_), device=x.device, dtype=torch.float32)
+    _acct('heads', 0, _nbytes(x), _nbytes(y))
     lib = _lib.load()
     fn = lib.loans_gap_fwd_bf16_f32 if _is16(x) else lib.loans_gap_fwd_f32
     check(fn(_ptr(x), _ptr(y), B, H * W, C_, _stream()), 'loans_gap_fwd')
@@ -2061,6 +2169,7 @@ def gap_fwd(x):
 def gap_bwd(gy, shape, dtype=torch.float32):
     B, H, W, C_ = shape
     gx = torch.empty(shape, device=gy.device, dtype=dtype)
+    _acct('heads', 0, _nbytes(gy), _nbytes(gx))
     lib = _lib.load()
     fn = lib.loans_gap_bwd_f32_bf16 if dtype == BF16 else lib.loans_gap_bwd_f32
     check(fn(_ptr(gy), _ptr(gx), B, H * W, C_, _stream()), 'loans_gap_bwd')
@@ -2072,6 +2181,7 @@ def linear_fwd(x, W, b, act_in=False, act_out=False):
     K = x.numel() // B
     N = W.numel() // K
     y = torch.empty((B, N), device=x.device, dtype=torch.float32)
+    _acct('heads', 2 * B * K * N, _nbytes(x, W), _nbytes(y))
     lib = _lib.load()
     fn = lib.loans_linear_fwd_bf16 if _is16(x) else lib.loans_linear_fwd_f32
     check(fn(_ptr(x), _ptr(W), _ptr(b), _ptr(y), B, K, N, int(act_in), int(act_out), _stream()), 'loans_linear_fwd')
@@ -2083,6 +2193,7 @@ def linear_bwd(x, W, y, gy, gW=None, gb=None, need_gx=True, act_in=False, act_ou
     K = x.numel() // B
     N = W.numel() // K
     gx = torch.empty_like(x) if need_gx else None
+    _acct('heads', (4 if need_gx else 2) * B * K * N, _nbytes(x, W, gy), _nbytes(gx, gW))
     lib = _lib.load()
     fn = lib.loans_linear_bwd_bf16 if _is16(x) else lib.loans_linear_bwd_f32
     check(fn(_ptr(x), _ptr(W), _ptr(y), _ptr(gy), _ptr(gx), _ptr(gW), _ptr(gb),
@@ -2186,6 +2297,7 @@ def st_sampler_fwd(images_nchw, grid):
     B, _, H, W = images_nchw.shape
     th, tw = grid.shape[2:]
     rois = torch.empty((B, th, tw, 4), device=grid.device, dtype=torch.float32)
+    _acct('crop', 0, _nbytes(grid) + 4 * 3 * 4 * B * th * tw, _nbytes(rois))        # four taps of three channels per crop pixel
     check(_lib.load().loans_st_sampler_fwd_f32(_ptr(images_nchw), _ptr(grid), _ptr(rois), B, H, W, th, tw, _stream()),
           'loans_st_sampler_fwd_f32')
     return rois
@@ -2195,6 +2307,7 @@ def st_sampler_bwd_grid(images_nchw, grid, grois):
     B, _, H, W = images_nchw.shape
     th, tw = grid.shape[2:]
     ggrid = torch.empty_like(grid)
+    _acct('crop', 0, _nbytes(grid, grois) + 4 * 3 * 4 * B * th * tw, _nbytes(ggrid))
     check(_lib.load().loans_st_sampler_bwd_grid_f32(_ptr(images_nchw), _ptr(grid), _ptr(grois), _ptr(ggrid), 0,
                                                     B, H, W, th, tw, _stream()), 'loans_st_sampler_bwd_grid_f32')
     return ggrid
@@ -2235,6 +2348,7 @@ def grid_loss_bwd(grid, gloss, kind, img_h=0.0, img_w=0.0, oob_scale=1.0):
 def adam_amsgrad(p, g, m, v, vhat, lr_t, beta1, beta2, eps, eta, weight_decay_rate, grad_scale=1.0):
     """lr_t: a Python float, or a 1-element device tensor read by the kernel when it runs (graph-capturable).
     vhat=None: plain Adam (amsgrad=False)."""
+    _acct('optimizer', 0, _nbytes(p, g, m, v, vhat), _nbytes(p, m, v, vhat))
     if vhat is None:
         dev_lr = torch.is_tensor(lr_t)
         if dev_lr:

@@ -104,9 +104,13 @@ class Adam:
                 grad_scale = 1.0 / self.comm.size
         self.grad_scale = grad_scale        # data parallel: the arena holds the SUM over ranks, the kernel applies 1 / world size
         if self._hooks:
-            if torch.cuda.is_current_stream_capturing():
-                raise RuntimeError('optimizer hooks run on the host: not inside a captured step')
-            self.call_hooks()
+            if arena.grad.is_cuda and torch.cuda.is_current_stream_capturing():
+                # hooks run on the host.  A data-parallel step is captured in two segments with the exchange between their
+                # replays (sheep_updater._capture_segments): there the replay loop calls the hooks at that point of every step
+                if not getattr(self, 'hooks_by_replay', False):
+                    raise RuntimeError('optimizer hooks run on the host: not inside a captured step')
+            else:
+                self.call_hooks()
         hp = self.hyperparam
         m, v, vhat = self._state
         # parameters beyond the prefix the current graph touches have no gradient.  Those that never had one are skipped

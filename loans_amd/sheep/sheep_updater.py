@@ -122,6 +122,9 @@ class SheepAssessor(training.StandardUpdater):
             opt.update_begin()                  # the whole active prefix of each gradient arena, RCCL beside RCCL
         for opt in opts:
             opt.exchange_wait()                 # this stream waits for the collectives' streams
+        for opt in opts:
+            if opt._hooks:                      # chainer's hook point: gradients complete (here: exchanged), step not yet applied
+                opt.call_hooks()
         for graph in g['graphs'][1:]:
             graph.replay()                      # the two Adam steps on the summed gradients
         report(g['obs'])
@@ -147,6 +150,7 @@ class SheepAssessor(training.StandardUpdater):
             graphs[0].capture_end()
             for opt in opts:                    # what graph 2 records is "the exchange has happened": scale by 1 / world size
                 opt._exchanged_from, opt._pending = 0, []
+                opt.hooks_by_replay = True      # ... and the replay loop below calls the optimiser hooks between the two graphs
             graphs[1].capture_begin(pool=pool)
 
         state = {'open': None}

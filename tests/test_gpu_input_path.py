@@ -49,6 +49,34 @@ def test_device_feed_equals_stack_of_get_example(tmp_path, use_imgaug, n_process
     assert 3 <= changed <= 17, changed
 
 
+
+@pytest.mark.parametrize("use_imgaug,where", [(True, 'device'), (True, 'host'), (False, 'device')])
+def test_decode_once_cache_keeps_the_bytes(tmp_path, use_imgaug, where):
+    """frame_cache.py (round 5; not in the reference, whose ImageDataset decodes every frame every epoch): with the decoded frames
+    kept in HBM (a batch = a device-side gather) or in host memory, the loop still receives ``stack(get_example(i))`` bit for bit
+    -- over THREE epochs of a seeded run (the first fills the cache, the others are served from it), mixed frame sizes, both
+    augmentation branches (the naive crop / flip branch caches on the host whatever was asked: it resizes strided views)."""
+    from loans_amd.common.datasets.image_dataset import ImageDataset
+    from loans_amd.runtime import training
+    train, _, _ = write_files(tmp_path)
+    mk = lambda **kw: ImageDataset(train, str(tmp_path), image_size=(64, 64), dtype=np.float32, use_imgaug=use_imgaug,   # noqa: E731
+                                   transform_probability=0.5, augment_seed=21, **kw)
+    host_ds, dev_ds = mk(), mk(frame_cache_gb=1, frame_cache_where=where)
+    assert dev_ds._cache.where == ('host' if not use_imgaug else where)
+    n_batches = 3 * ((len(dev_ds) + 3) // 4) + 1
+    random.seed(8)
+    order = training.SerialIterator(host_ds, 4, shuffle=True, seed=2)
+    want = [np.stack(next(order)) for _ in range(n_batches)]
+    random.seed(8)
+    feed = training.MultithreadIterator(dev_ds, 4, shuffle=True, seed=2, n_threads=4, n_prefetch=2, device=0)
+    for ref in want:
+        np.testing.assert_array_equal(next(feed).cpu().numpy(), ref)
+    feed.finalize()
+    c = dev_ds._cache
+    assert len(c) == len(dev_ds) and c.hits >= len(dev_ds), (len(c), c.hits, c.misses)        # every frame decoded once, then served
+    assert c.misses <= len(dev_ds) + 8, c.misses                                              # (+ the batches in flight at the epoch's end)
+
+
 def test_trainer_runs_from_files_with_augmentation(tmp_path, monkeypatch):
     """the reference's command line on generator-written files: 4 iterations, validation at the log interval, snapshots in the
     timestamped log directory with a JSON log whose first entry carries the configuration"""

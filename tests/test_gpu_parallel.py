@@ -51,8 +51,20 @@ def _worker(rank, world, port, outdir):
     calls, plain = [], comm.allreduce_range
     comm.allreduce_range = lambda arena, lo, hi, async_op=False: (calls.append((arena is loc.arena, lo, hi, async_op)),
                                                                     plain(arena, lo, hi, async_op))[1]
+    # what each Adam really consumes: the exchanged arena times the scale the kernel applies (chainer's hook point: after the
+    # gradients are complete, before the step).  Adam's step is invariant to a constant gradient scale, so the parameters
+    # alone cannot see a wrong 1 / world size, a bucket summed twice or a skipped one.
+    seen = {}
+
+    def keep_exchanged(opt, tag):
+        torch.cuda.synchronize()
+        seen.update({tag + k[1:]: p.grad_logical() * opt.grad_scale for k, p in opt.target.namedparams()})
+    og.add_hook(lambda opt: keep_exchanged(opt, 'loc:'), name='keep_loc')
+    od.add_hook(lambda opt: keep_exchanged(opt, 'dis:'), name='keep_dis')
     upd.update()
     torch.cuda.synchronize()
+    assert og.grad_scale == 1.0 / world and od.grad_scale == 1.0 / world
+    np.savez(os.path.join(outdir, 'grads_%d.npz' % rank), **seen)
     # the localizer's gradients travelled in three parts started DURING its backward (res5 + head first, then res4, the rest
     # when the backward ended), together exactly the active prefix; the assessor's in one piece at its update
     plan = parallel.exchange_plan(loc)
@@ -86,6 +98,19 @@ def test_two_rank_data_parallel_step_against_oracle(tmp_path):
                             rng=np.random.RandomState(0), return_grads=True, oob_scale=float(WORLD))
         gl = out['loc_grads'] if gl is None else {k: gl[k] + v for k, v in out['loc_grads'].items()}
         gd = out['dis_grads'] if gd is None else {k: gd[k] + v for k, v in out['dis_grads'].items()}
+    # the gradients each rank's Adam consumed: the oracle's per-shard gradients, averaged -- on BOTH ranks, for both models
+    for r in range(WORLD):
+        got = load('grads_%d.npz' % r)
+        n = 0
+        for tag, ref in (('loc:', gl), ('dis:', gd)):
+            for k, v in ref.items():
+                if k == 'feature_extractor/conv1/b':
+                    continue               # analytically zero (a BN follows): rounding noise on both sides
+                want = v / WORLD
+                err = np.abs(got[tag + k] - want).max() / (np.abs(want).max() + 1e-30)
+                assert err < 2e-4, (r, tag + k, err)
+                n += 1
+        assert n == 65 + 11
     M.AdamAMSGrad(lp0).update({k: v / WORLD for k, v in gl.items()})
     M.AdamAMSGrad(dp0).update({k: v / WORLD for k, v in gd.items()})
     # Adam is sign-like on step 1 (|update| ~ lr whatever the gradient magnitude), so near-zero gradients may flip:
@@ -144,7 +169,14 @@ def _worker_graph(rank, world, port, outdir):
         calls, plain = [], comm.allreduce_range
         comm.allreduce_range = lambda arena, lo, hi, async_op=False: (calls.append((arena is loc.arena, lo, hi, async_op)),
                                                                         plain(arena, lo, hi, async_op))[1]
-        losses = []
+        losses, kept = [], {}
+
+        def keep(opt, tag):
+            if len(losses) == 2:            # the third step: the first REPLAY in graph mode (two eager warm-up steps, then the capture)
+                torch.cuda.synchronize()
+                kept.update({tag + k[1:]: p.grad_logical() * opt.grad_scale for k, p in opt.target.namedparams()})
+        og.add_hook(lambda opt: keep(opt, 'loc:'), name='keep_loc')
+        od.add_hook(lambda opt: keep(opt, 'dis:'), name='keep_dis')
         for _ in range(steps):
             upd.update()
             obs = loans_amd.reporter.observation
@@ -167,6 +199,8 @@ def _worker_graph(rank, world, port, outdir):
         else:
             assert upd._graph is None
         out[mode] = (losses, loc.state_dict_chainer(), dis.state_dict_chainer())
+        assert len(kept) >= 66 + 11, len(kept)
+        np.savez(os.path.join(outdir, '%s_grads_%d.npz' % (mode, rank)), **kept)
         np.savez(os.path.join(outdir, '%s_loc_%d.npz' % (mode, rank)), **out[mode][1])
         np.savez(os.path.join(outdir, '%s_dis_%d.npz' % (mode, rank)), **out[mode][2])
     np.save(os.path.join(outdir, 'losses_%d.npy' % rank), np.array([out['eager'][0], out['graph'][0]]))
@@ -188,6 +222,18 @@ def test_two_rank_captured_step_matches_eager(tmp_path):
             for k in a:
                 if 'avg_' not in k and not k.endswith('/N'):               # BN running statistics are local to a shard
                     np.testing.assert_array_equal(a[k], b[k], err_msg='%s %s' % (mode, k))
+    # the gradients the two Adam steps consumed at the first REPLAY (exchange between the two graphs, 1 / world size applied by
+    # the captured kernel; the optimiser hooks run from the replay loop) against the eager step's at the same point of the
+    # trajectory: a wrong scale is a factor, a skipped bucket a run of zeros -- both far outside the atomics' noise
+    for rank in range(WORLD):
+        ge, gg = load('eager_grads_%d.npz' % rank), load('graph_grads_%d.npz' % rank)
+        for k in ge:
+            ref = np.abs(ge[k]).max()
+            if ref == 0 or k.endswith('conv1/b'):
+                assert np.abs(gg[k]).max() <= 1e-12 + ref * 10 or k.endswith('conv1/b'), k
+                continue
+            assert np.abs(gg[k] - ge[k]).max() <= 2e-2 * ref, (rank, k, np.abs(gg[k] - ge[k]).max() / ref)
+            assert abs(np.linalg.norm(gg[k]) / np.linalg.norm(ge[k]) - 1.0) < 5e-3, (rank, k)
     for rank in range(WORLD):
         l_eager, l_graph = np.load(os.path.join(str(tmp_path), 'losses_%d.npy' % rank))
         # (four frames per rank and step: one ReLU / pooling decision that flips on the last bit of a weight -- the weight

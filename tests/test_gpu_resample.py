@@ -138,7 +138,7 @@ def test_ragged_batch_one_launch_pair_against_pillow(monkeypatch):
     np.testing.assert_array_equal(got.cpu().numpy(), ref)
     # the same frames through an arena that cannot hold all their tables at once: it starts over, batches stay right
     dev = torch.device('cuda', 0)
-    monkeypatch.setitem(resample._arenas, dev, resample._TableArena(dev, words=40000))
+    monkeypatch.setitem(resample._arenas, (dev, torch.cuda.current_stream(dev).cuda_stream), resample._TableArena(dev, words=40000))
     for k in range(4):
         sl = slice(6 * k, 6 * k + 6)
         np.testing.assert_array_equal(resample.frames_to_device(frames[sl], (96, 128), 'cuda:0').cpu().numpy(), ref[sl])

@@ -134,6 +134,68 @@ def test_two_rank_gloo_data_parallel():
     assert q.get(timeout=5) == 'ok'
 
 
+
+def _worker_r50(rank, world, port, out):
+    """four ranks, the ResNet-50 localizer with res6 / res7 active (512 px frames): ~75 M gradient floats, several 64 MiB buckets
+    per part of the staged exchange"""
+    os.environ.update(MASTER_ADDR='127.0.0.1', MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world), LOCAL_RANK=str(rank))
+    torch.set_num_threads(2)
+    import loans_amd
+    from loans_amd import parallel
+    comm = parallel.init_from_env(backend='gloo')
+    assert (comm.size, comm.rank) == (world, rank)
+    np.random.seed(5)
+    loc = loans_amd.Resnet50SheepLocalizer((16, 16))
+    arena = loc.finalize(torch.device('cpu'))
+    arena.set_active(None)                                      # frames taller than 300 px: everything is active
+    n = arena.active_numel
+    assert n == arena.numel and n > 60_000_000
+    gen = lambda r: torch.randn(n, generator=torch.Generator().manual_seed(500 + r))      # noqa: E731
+    arena.grad.copy_(gen(rank))
+    opt = parallel.create_multi_node_optimizer(loans_amd.Adam(alpha=1e-3, amsgrad=True).setup(loc), comm)
+    plan = parallel.exchange_plan(loc)
+    calls, plain = [], comm.allreduce_range
+    comm.allreduce_range = lambda a, lo, hi, async_op=False: (calls.append((lo, hi)), plain(a, lo, hi, async_op))[1]
+    hook = loc.feature_extractor.__dict__['_stage_hook']
+    hook('res5')
+    hook('res4')
+    opt.update_begin()                                          # the rest: [0, res4)
+    for w in opt._pending:
+        w.wait()
+    assert calls == [(plan['res5'], n), (plan['res4'], plan['res5']), (0, plan['res4'])], (calls, plan)
+    B = parallel.BUCKET_FLOATS
+    buckets = [-(-(hi - lo) // B) for lo, hi in calls]
+    assert buckets[0] >= 3 and sum(buckets) >= 5, buckets       # [res5 .. end) alone is several 64 MiB collectives
+    total = gen(0)
+    for r in range(1, world):
+        total += gen(r)
+    # every float of every bucket exactly once: the sum of the four ranks' gradients (fp32 sums in gloo's ring order) -- a bucket
+    # summed twice or skipped is off by O(1)
+    err = (arena.grad - total).abs().max().item()
+    assert err <= 1e-5, err
+    opt._pending, opt._exchanged_from = [], None
+    if rank == 0:
+        out.put(('ok', buckets))
+    comm.barrier()
+    dist.destroy_process_group()
+
+
+def test_four_rank_gloo_staged_exchange_resnet50_512px():
+    """exchange_plan on the ResNet-50 localizer at 512 px (res6 / res7 active), four ranks, 64 MiB buckets: the
+    three parts cover the arena exactly once, every bucket carries the four-rank sum, the kernel's scale is 1 / 4."""
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_r50, args=(r, 4, port, q)) for r in range(4)]
+    for p in procs:
+        p.start()
+    for p in procs:
+        p.join(timeout=600)
+    assert all(p.exitcode == 0 for p in procs), [p.exitcode for p in procs]
+    tag, buckets = q.get(timeout=5)
+    assert tag == 'ok' and sum(buckets) >= 5
+
+
 def test_updater_scales_batch_sum_regulariser_by_world_size():
     import loans_amd
     from loans_amd.runtime import training

@@ -23,6 +23,7 @@ ap.add_argument('--batches', type=int, default=12)
 ap.add_argument('--files', type=int, default=512)
 ap.add_argument('--processes', type=int, default=0, help='decode processes (0: threads)')
 ap.add_argument('--no-imgaug', action='store_true')
+ap.add_argument('--cache', default='', choices=['', 'device', 'host'], help='decode once (frame_cache.py): also time the epochs after the first')
 ap.add_argument('--jpeg', action='store_true')
 ap.add_argument('--cores', type=int, default=0,
                 help="pin this process and its decode workers to the first N cores: ONE rank's share of the host (an 8-GPU node with "
@@ -77,6 +78,27 @@ for _ in range(args.batches):
 torch.cuda.synchronize()
 whole = args.batches * args.b / (time.perf_counter() - t0)
 feed.finalize()
+cached = None
+if args.cache:
+    # decode once: epoch 1 fills the cache (every file is visited once), the epochs after it are timed
+    ds.enable_frame_cache(64, args.cache)
+    feed = training.MultithreadIterator(ds, args.b, shuffle=True, n_threads=args.threads, n_prefetch=2, device=0, n_processes=args.processes)
+    per_epoch = max(1, args.files // args.b)
+    t0 = time.perf_counter()
+    for _ in range(per_epoch + 1):
+        next(feed)
+    torch.cuda.synchronize()
+    first = (per_epoch + 1) * args.b / (time.perf_counter() - t0)
+    for _ in range(2):
+        next(feed)                      # batches that were prepared before the cache was complete
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(2 * args.batches):
+        batch = next(feed)
+    torch.cuda.synchronize()
+    cached = 2 * args.batches * args.b / (time.perf_counter() - t0)
+    c = ds._cache
+    feed.finalize()
 if args.cores:
     print('host share: %d cores (affinity of this process and its decode workers)' % len(os.sched_getaffinity(0)))
 print('frames %dx%d %s -> %dx%d, batch %d, %d decode %s, augmentation %s' % (
@@ -86,3 +108,6 @@ print('frames %dx%d %s -> %dx%d, batch %d, %d decode %s, augmentation %s' % (
 print('host decode alone      : %8.0f images/s' % decode)
 print('GPU stages alone       : %8.0f images/s (upload + augment + LANCZOS + /255)' % gpu_stage)
 print('files -> device batches: %8.0f images/s (MultithreadIterator, prefetch 2)' % whole)
+if cached is not None:
+    print('decode once (%s cache): epoch 1 %8.0f images/s, epochs >= 2 %8.0f images/s (%d frames resident, %.2f GB, %d hits / %d misses)'
+          % (args.cache, first, cached, len(c), c.bytes / 1e9, c.hits, c.misses))

@@ -25,6 +25,8 @@ one () {   # one <name> <B> <peak TFLOP/s> <flop per image> <bench args...>
   rocprofv3 --kernel-trace --stats --output-format csv -d $out/${tag}_${name}_tr -- python3 bench.py --no-secondary --tune-file $tune --steps 3 --warmup 2 --no-cpu-baseline "$@" > $out/${tag}_${name}_trace.log 2>&1
   python3 tools/trace_summary.py $out/${tag}_${name}_tr $B $peak $fpi > $out/${tag}_${name}_trace_summary.txt
   cp $out/${tag}_${name}_tr/*/*kernel_stats.csv $out/${tag}_${name}_kernel_stats.csv
+  python3 tools/class_times.py $out/${tag}_${name}_tr $out/${tag}_${name}_class_times.json "bench.py $*"
+  python3 tools/step_timeline.py $out/${tag}_${name}_tr > $out/${tag}_${name}_timeline.txt
   rm -rf $out/${tag}_${name}_tr
   echo "[$name] trace done"
   rocprofv3 --pmc FETCH_SIZE --output-format csv -d $out/${tag}_${name}_f -- python3 bench.py --no-secondary --tune-file $tune --steps 2 --warmup 2 --no-cpu-baseline "$@" > $out/${tag}_${name}_fetch.log 2>&1

@@ -162,6 +162,12 @@ def parse_args(argv=None):
     parser.add_argument("--loader-processes", type=int, default=-1,
                         help="decode PROCESSES of the training-frame iterator (Pillow's decoders hold the GIL: threads do not "
                              "scale); -1: as many as --loader-threads resolves to, 0: decode on the threads")
+    parser.add_argument("--frame-cache-gb", type=float, default=16.0,
+                        help="decode once: keep up to this many GB of decoded training frames (uint8 HWC) for the following epochs, "
+                             "0 = decode every frame every epoch like the reference")
+    parser.add_argument("--frame-cache-where", default='device', choices=['device', 'host'],
+                        help="where the decoded frames live: in HBM (a batch is then a device-side gather: no decode, no staging "
+                             "copy, no upload) or in host memory (only the decode is skipped)")
     parser.add_argument("--host-input", action='store_true',
                         help="finish the frames on the host (Pillow resize in get_example) instead of on the GPU")
     parser.add_argument("--flat-log-dir", action='store_true', help="write into --log-dir itself (no <time>_<name> sub-directory)")
@@ -210,6 +216,8 @@ def build_datasets(args, rank=0):
             use_imgaug=args.use_imgaug,
             transform_probability=0.5,
             augment_seed=None if args.seed is None else args.seed + 7919 * rank,
+            frame_cache_gb=0 if args.host_input else args.frame_cache_gb,
+            frame_cache_where=args.frame_cache_where,
         )
     if args.reference_file == SYNTHETIC:
         reference = SyntheticAssessorSamples(args.dataset_size, args.target_size, seed=args.data_seed + 990 + rank)
