@@ -347,17 +347,17 @@ def whole_step_binding(w, class_count, ms_per_step, world):
     path = _profile_file(name, 'class_times') if (name and world == 1 and not w.graph) else None
     measured = json.load(open(path))["kernel_ms"] if path else {}
     classes, tot_f, tot_b, bound_sum = {}, 0, 0, 0.0
-    for cls, (flop, rd, wr) in sorted(class_count.items()):
+    for cls, (flop, rd, wr, t_launch) in sorted(class_count.items()):
         flop, rd, wr = flop // steps, rd // steps, wr // steps
         t_f, t_b = flop / peak * 1e3, (rd + wr) / bw * 1e3
-        b = max(t_f, t_b)
+        b = t_launch / steps * 1e3          # per LAUNCH max(bytes / HBM rate, FLOP / peak), summed: >= max of the class's sums
         m = measured.get(cls)
         classes[cls] = {"gflop": round(flop / 1e9, 1), "mbytes": round((rd + wr) / 1e6, 1), "bound": "mfma" if t_f >= t_b else "hbm",
                         "bound_ms": round(b, 4), "kernel_ms": m, "frac": round(b / m, 3) if m else None,
                         "gap_ms": round(m - b, 3) if m else None}
         tot_f, tot_b, bound_sum = tot_f + flop, tot_b + rd + wr, bound_sum + b
     machine = max(tot_f / peak, tot_b / bw) * 1e3
-    out = {"rule": "per class max(algorithmic bytes / %.1f TB/s, algorithmic FLOP / %.0f TFLOP/s), summed; kernel_ms from %s"
+    out = {"rule": "per launch max(algorithmic bytes / %.1f TB/s, algorithmic FLOP / %.0f TFLOP/s), summed per class; kernel_ms from %s"
                    % (HBM_ACHIEVABLE_TBS, peak / 1e12, os.path.relpath(path, ROOT) if path else "no committed trace of this workload"),
            "classes": classes, "bound_ms_sum": round(bound_sum, 3), "bound_ms_machine": round(machine, 3),
            "gbytes_per_step": round(tot_b / 1e9, 2), "tflop_per_step": round(tot_f / 1e12, 3),

@@ -611,24 +611,6 @@ int loans_u8hwc3_to_f32chw(const uint8_t* src, float* dst, int32_t B, int32_t H,
 /* library / build identification */
 const char* loans_hip_version(void);
 
-/* The stem's backward on bf16 storage behind its two BN sums, in ONE launch (+ the fold of its partial slabs), round 5:
- * max_pooling_2d(3, 2, cover_all) <- relu <- bn1 <- conv1 7x7 / 2, 3 -> 64 with bias (sheep/resnet.py:43-44,72-73).  Replaces
- * loans_pool_bn_bwd_apply_rep_bf16 -> loans_wgrad_bf16s(LOANS_F_DENSE) -> loans_mul_f32: conv1's gradient tensor
- * gx = k1 g m + k2 y + k3 (g = the pooled gradient routed by the argmax positions, m = (y scale + shift > 0)) is rebuilt tile by
- * tile in registers, rounded to bf16 as the stored tensor was, and contracted with the frames at once -- it is never written.
- *   frames     the zero-padded packed-RGB buffer of loans_prep_images_dense_bf16, [B][Hp][Wp3] bf16 (Wp3 = 3 x padded width)
- *   y          conv1's output [B][Ho][Wo][64] bf16;  gy_pooled, idx: [B][OH][OW][64] bf16 / uint8 (loans_bn_relu_maxpool_bf16)
- *   scale, shift   bn1's forward coefficients;  k1, k2, k3: its backward coefficients (loans_bn_bwd_coeffs_rep_f32)
- *   dw         conv1's weight gradient in the dense layout [64][7][24], += (the three window-padding columns of a K row get 0)
- *   gbias      [64], += sum over pixels of gx (fp32 atomics, one per channel and block)
- *   ws         caller-owned workspace of at least loans_stem_bwd_bf16_ws_floats(B, Ho, Wo) floats (partial gradients per block,
- *              folded into dw in a fixed order by loans_fold_slabs_f32 on the same stream) */
-int loans_stem_bwd_bf16(const void* frames, const void* y, const void* gy_pooled, const uint8_t* idx, const float* scale,
-                        const float* shift, const float* k1, const float* k2, const float* k3, float* dw, float* gbias, float* ws,
-                        int64_t ws_floats, int32_t B, int32_t Hp, int32_t Wp3, int32_t Ho, int32_t Wo, int32_t OH, int32_t OW,
-                        void* stream);
-int64_t loans_stem_bwd_bf16_ws_floats(int32_t B, int32_t Ho, int32_t Wo);
-
 #ifdef __cplusplus
 }
 #endif

@@ -84,8 +84,6 @@ SIGNATURES = {
     'loans_wgrad_bf16s_ws': [_p, _p, _p, C.POINTER(IgemmDesc), _i32, _p, _i64, _p],
     'loans_fold_slabs_f32': [_p, _p, _i64, _i32, _p],
     'loans_wgrad_bf16s_ws_floats': [C.POINTER(IgemmDesc), _i32],
-    'loans_stem_bwd_bf16': [_p] * 12 + [_i64] + [_i32] * 7 + [_p],
-    'loans_stem_bwd_bf16_ws_floats': [_i32, _i32, _i32],
     'loans_cast_bf16': [_p, _p, _i64, _p],
     'loans_repack_dgrad_bf16': [_p, _p, _i32, _i32, _i32, C.POINTER(_i32), _i32, _p],
     'loans_bn_apply_bf16': [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p],
@@ -161,7 +159,7 @@ SIGNATURES = {
 }
 
 # every entry point returns int (0 / LOANS_E* / hipError_t) except:
-RESTYPES = {'loans_wgrad_bf16s_ws_floats': C.c_int64, 'loans_stem_bwd_bf16_ws_floats': C.c_int64}
+RESTYPES = {'loans_wgrad_bf16s_ws_floats': C.c_int64}
 
 _lib = None
 

@@ -574,7 +574,7 @@ static inline int slab_grid(int64_t nunits) { return grid_for(nunits, 256 * SLAB
 // LOANS_BN_NT: 0 never, 1 always, unset: tensors of at least 96 MB (they cannot stay in the Infinity Cache with their partners)
 static inline bool slab_nt(int64_t tensor_bytes) {
     static const int mode = [] { const char* e = getenv("LOANS_BN_NT"); return e && *e ? atoi(e) : -1; }();
-    static const long mb = [] { const char* e = getenv("LOANS_BN_NT_MB"); return e && *e ? atol(e) : 96L; }();
+    constexpr long mb = 96;
     return mode < 0 ? tensor_bytes >= ((int64_t)mb << 20) : mode != 0;
 }
 

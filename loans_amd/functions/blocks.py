@@ -99,11 +99,6 @@ class StemFunction(Function):
     def backward(self, inputs, gys):
         _require_train()
         _, W, b, gamma, beta = self.inputs
-        if ops.stem_backward_fused_ok(self.x, self.c, self.geo):
-            # bf16 storage arm: conv1's gradient tensor is never materialised (csrc/stem_bwd_bf16.hip)
-            ops.stem_backward_fused(gys[0].contiguous(), self.idx, self.c, self.st, gamma.data, gamma.grad_view, beta.grad_view,
-                                    b.grad_view, self.x, W.grad_view, self.geo)
-            return None, None, None, None, None
         gc = ops.pool_bn_backward(gys[0].contiguous(), self.idx, self.c, self.st, gamma.data, gamma.grad_view,
                                   beta.grad_view, gbias=b.grad_view)
         ops.conv_wgrad(self.x, gc, W.grad_view, self.geo)
@@ -188,7 +183,7 @@ class ResidualUnitFunction(Function):
             # that finishes -- it then overlaps the HBM-bound BN passes that follow instead of fighting the dgrad
             # for the matrix pipes
             _, gp, bp = P[1 + 3 * (i - 1):4 + 3 * (i - 1)]
-            if ops.bn_sums_ok(self.geo[i], self.c[i - 1]) and ops.BN_XMASK:
+            if ops.bn_sums_ok(self.geo[i], self.c[i - 1]):
                 # the two sums of BN i-1's backward ride in this dgrad's epilogue (its output tile meets the BN's input tile
                 # there): the reduction pass over gh disappears, the BN backward is one pass
                 gh, sums = ops.conv_dgrad(g, W.data, self.geo[i], bn_sums=(self.c[i - 1], self.st[i - 1]))

@@ -19,14 +19,14 @@ from ._lib import (F_ADDEND, F_ADDEND_MASK, F_BIAS, F_BNSUMS, F_DENSE, F_GY_BF16
 
 # Arithmetic of the convolution contractions: 'f32' (exact fp32 MFMA, the parity path) or 'bf16' (operands rounded
 # to bf16 while staged into LDS, bf16 MFMA, fp32 accumulate; tensors stay fp32 in memory).  BASELINE configs 3 / 5.
-COMPUTE = os.environ.get('LOANS_COMPUTE', 'f32')
+COMPUTE = 'f32'
 
 
 # Storage of the activations / gradients inside the localizer's residual stages: 'f32', or 'bf16' (needs COMPUTE ==
 # 'bf16'): the stem's pool then writes bf16, every conv / BN pass of the stages reads and writes bf16 (their wrappers
 # below dispatch on the tensor's dtype) and the pooled features return to fp32.  Parameters, their gradients
 # ("fp32 grad accumulate"), BN statistics and the assessor stay fp32.
-STORAGE = os.environ.get('LOANS_STORAGE', 'f32')
+STORAGE = 'f32'
 BF16 = torch.bfloat16
 
 
@@ -113,7 +113,7 @@ def _count_flops(kind, geo):
 
 
 # When bench.py sets this to a dict, every wrapper adds the ALGORITHMIC work of its launch(es) under a kernel class --
-# [FLOP, bytes read, bytes written]: 2 FLOP per MAC of a contraction (logical channels, no padding), every tensor a pass must touch
+# [FLOP, bytes read, bytes written, seconds at the binding roofline summed per launch]: 2 FLOP per MAC of a contraction (logical channels, no padding), every tensor a pass must touch
 # once, in its storage type (a BN backward that takes its own sums reads its operands twice: the sums must be complete before
 # the first output) -- `roofline.whole_step.binding` prices the step's classes against max(bytes / HBM rate, FLOP / MFMA peak).
 # Classes follow what a kernel trace can tell apart by name (tools/class_times.py): conv (forward + data gradient), wgrad,
@@ -126,13 +126,19 @@ def _nbytes(*tensors):
     return sum(t.numel() * t.element_size() for t in tensors if t is not None)
 
 
+# what a launch is priced against (bench.py's constants; MI355X_MICROARCH.md): dense MFMA peak of the arm, achievable HBM rate
+ROOFLINE_MFMA = {'f32': 157.3e12, 'bf16': 2.5e15}
+ROOFLINE_HBM = 6.3e12
+
+
 def _acct(cls, flop=0, rd=0, wr=0):
     c = CLASS_COUNT
     if c is not None:
-        e = c.setdefault(cls, [0, 0, 0])
+        e = c.setdefault(cls, [0, 0, 0, 0.0])
         e[0] += flop
         e[1] += rd
         e[2] += wr
+        e[3] += max(flop / ROOFLINE_MFMA[COMPUTE], (rd + wr) / ROOFLINE_HBM)       # this launch at the roofline that binds IT
 
 
 def _conv_flop(geo):
@@ -148,7 +154,7 @@ def _variant(geo, *what):
     """key of geo.tuned under which a wrapper keeps the tile it resolved for one call variant (which flags, which switches):
     later calls skip building the candidate lists, the mode string and the tuning closure -- pure host time, 600 convolution
     calls per ResNet-50 step.  Lives in geo.tuned, so whatever clears a shape's picks clears these too; never saved to a table."""
-    return '~%r' % ((what, SPLITK, HALO, WGHALO, CLASS_LAUNCH, FINETAIL, STEM_DIRECT, COMPUTE, STORAGE, WGRAD_CUS_OF_8, TUNE_POLICY, PW),)
+    return '~%r' % ((what, SPLITK, HALO, WGHALO, CLASS_LAUNCH, FINETAIL, STEM_DIRECT, COMPUTE, STORAGE, TUNE_POLICY, PW),)
 
 
 _raw_stream = getattr(torch._C, '_cuda_getCurrentRawStream', None) or (lambda idx: torch.cuda.current_stream(idx).cuda_stream)
@@ -171,7 +177,7 @@ def _memo(fn):
         if kw:
             return fn(*args, **kw)
         key = (tuple(id(a) if isinstance(a, dict) else a for a in args), SPLITK, HALO, WGHALO, CLASS_LAUNCH, FINETAIL,
-               STEM_DIRECT, COMPUTE, STORAGE, WGRAD_CUS_OF_8, PW)
+               STEM_DIRECT, COMPUTE, STORAGE, PW)
         try:
             return cache[key]
         except KeyError:
@@ -389,24 +395,24 @@ def _with_flags(desc, flags, tile=0):
 # kernel is timed on it (HIP events, scratch outputs) and the fastest is kept.
 # Results do not depend on the tile: K is accumulated in the same order by all.
 # --------------------------------------------------------------------------- #
-AUTOTUNE = os.environ.get('LOANS_AUTOTUNE', '1') != '0'
+AUTOTUNE = True          # False: every launch on the library's default tile
 # candidates.  LOANS_TILE_SPLIT (6) only pays where nothing else shares the machine: in backward the dgrad launches run
 # beside the weight-gradient GEMMs of the side stream and the two-launch split measured slower there
 # +16 (LOANS_TILE_DMA): the same tile shape with its operands staged by LDS-DMA (fp32 arm only)
-_FPROP_TILES = tuple(int(t) for t in os.environ.get('LOANS_FPROP_TILES', '1,2,3,4,6,17,18,19,20,22').split(','))
-_IGEMM_TILES = tuple(int(t) for t in os.environ.get('LOANS_DGRAD_TILES', '1,2,3,17,18,19').split(','))
+_FPROP_TILES = (1, 2, 3, 4, 6, 17, 18, 19, 20, 22)
+_IGEMM_TILES = (1, 2, 3, 17, 18, 19)
 _WGRAD_TILES = (1, 3, 5)
 _WGRAD16_TILES = (1, 3, 5)
-_IGEMM16_TILES = tuple(int(t) for t in os.environ.get('LOANS_BF16S_TILES', '1,2,3,4,7').split(','))
+_IGEMM16_TILES = (1, 2, 3, 4, 7)
 # LOANS_TILE_HALO_* (csrc/halo_bf16.hip): stride-1 convolutions with the input tile staged once per 64-channel chunk
 TILE_HALO_128, TILE_HALO_256x64, TILE_HALO_128x64, TILE_HALO_128x64S, TILE_WS64 = 11, 12, 13, 14, 15
 TILE_HALO_256x128 = 36       # one 512-thread block per CU: 16 x 16 pixels x 128 output channels
 TILE_WSW64 = 37              # weights stationary, every wave on its own 2 x 16 pixel unit (no block barriers)
-HALO = os.environ.get('LOANS_HALO', '1') != '0'
+HALO = True
 
 
 TILE_PW = 40                 # LOANS_TILE_PW (csrc/pw_bf16.hip): short-K 1 x 1 convolutions, operands never in LDS
-PW = os.environ.get('LOANS_PW', '1') != '0'
+PW = True
 
 
 @_memo
@@ -522,10 +528,10 @@ def _halo_tiles(geo, gathered_channels, out_channels, out_hw, relu_in=False):
     return tiles
 
 
-# LOANS_TUNE_COLD=1 (experiment): a 512 MB fill between the timed launches of the autotuner, so that every candidate finds its
-# operands in HBM, where the step's previous kernel left them, and not in the 256 MB Infinity Cache, where the candidate's own
-# previous repetition did
-TUNE_COLD = os.environ.get('LOANS_TUNE_COLD', '0') != '0'
+# cold timing (shapes that offer LOANS_TILE_PW): a 512 MB fill between the timed launches of the autotuner, so that every candidate
+# finds its operands in HBM, where the step's previous kernel left them, and not in the 256 MB Infinity Cache, where the
+# candidate's own previous repetition did.  (For every shape -- LOANS_TUNE_COLD=1 of round 3 -- it was worth 0.6-1 % at ResNet-50
+# and nothing elsewhere: removed.)
 _cold = {}
 
 
@@ -533,7 +539,7 @@ def _time_call(fn, reps=5, cold=False):
     fn()
     best = float('inf')
     for _ in range(reps):
-        if TUNE_COLD or cold:
+        if cold:
             dev = torch.cuda.current_device()
             if dev not in _cold:
                 _cold[dev] = torch.empty(512 << 20, device='cuda', dtype=torch.uint8)
@@ -588,8 +594,7 @@ def _tuned_tile(geo, mode, run, candidates, cold=False):
         return tile
     TIMED_PICKS += 1
     times = {t: _time_call(lambda: run(t), cold=cold) for t in candidates}
-    if not TUNE_COLD:
-        _cold.clear()           # the 512 MB fill buffer of a cold-timed shape is not kept for the life of the process
+    _cold.clear()           # the 512 MB fill buffer of a cold-timed shape is not kept for the life of the process
     tile = min(times, key=times.get)
     geo.tuned[mode] = tile
     if os.environ.get('LOANS_TUNE_VERBOSE'):
@@ -685,8 +690,8 @@ def stem16_tile_rows(geo):
 
 
 TILE_FINETAIL = 8       # LOANS_TILE_FINETAIL (+16 = LDS-DMA): whole 64x64 tiles, then K-slices of the uneven rest in the same launch
-FINETAIL = os.environ.get('LOANS_FINETAIL', '1') != '0'
-STEM_DIRECT = os.environ.get('LOANS_STEM_DIRECT', '1') != '0'
+FINETAIL = True
+STEM_DIRECT = True
 
 
 @_memo
@@ -791,7 +796,7 @@ def conv_fprop(x, w, geo, out=None, bias=None, stats=None, relu_in=False, addend
 
 
 # LOANS_PAIR16=0: the bf16-storage arm launches a unit's first conv and its conv shortcut separately again
-PAIR16 = os.environ.get('LOANS_PAIR16', '1') != '0'
+PAIR16 = True
 
 
 def fprop_pair_ok(x, geo_a, geo_b):
@@ -1035,14 +1040,12 @@ def _conv_dgrad16(lib, gy, w, geo, out, mask_ref, addend, addend_mask_ref, tile,
     return out if bn_sums is None else (out, sums)
 
 
-# LOANS_BN_FUSED_SUMS=0: the inner BNs' backward sums come from their own reduction pass again
-BN_FUSED_SUMS = os.environ.get('LOANS_BN_FUSED_SUMS', '1') != '0'
 
 
 def bn_sums_ok(geo, y):
     """conv_dgrad(..., bn_sums=) covers this data gradient: one stride-parity class (stride 1), a gradient tensor the
     row-reduction layout tiles, operands in one storage type"""
-    return BN_FUSED_SUMS and len(geo.dgrad) == 1 and not geo.dgrad_has_empty_class and not geo.dense and geo.Cin != 4 and \
+    return len(geo.dgrad) == 1 and not geo.dgrad_has_empty_class and not geo.dense and geo.Cin != 4 and \
         geo.Cin % 8 == 0 and y.is_contiguous()
 
 
@@ -1146,7 +1149,7 @@ def conv_dgrad(gy, w, geo, out=None, mask_ref=None, addend=None, addend_mask_ref
 
 # tile id bit (host side only): every stride-parity class of a strided data gradient in ONE launch (loans_igemm_classes_f32)
 TILE_CLASSES = 1 << 16
-CLASS_LAUNCH = os.environ.get('LOANS_CLASS_LAUNCH', '1') != '0'
+CLASS_LAUNCH = True
 
 
 @_memo
@@ -1170,7 +1173,7 @@ def _igemm_classes(lib, gy, wp, out, geo, flags, tile, ref, addend, st):
 
 
 # LOANS_CROP_DGRAD=0: the gradient w.r.t. the 4-channel crops goes back to one loans_dgrad_c4 launch per stride-parity class
-CROP_DGRAD = os.environ.get('LOANS_CROP_DGRAD', '1') != '0'
+CROP_DGRAD = True
 
 
 def crop_dgrad_ok(geo_a, geo_b=None, gy_a=None, gy_b=None):
@@ -1229,44 +1232,24 @@ def crop_dgrad(gy_a, w_a, geo_a, gy_b=None, w_b=None, geo_b=None, addend=None):
 # Weight gradients are consumed only by the optimiser, so they run on a second HIP stream: the
 # MFMA-bound wgrad kernels overlap the HBM-bound BN / ReLU passes of the data-gradient chain and
 # fill the tails of its dgrad launches.  `join_side_stream()` is the barrier the consumers call.
-ASYNC_WGRAD = os.environ.get('LOANS_ASYNC_WGRAD', '1') != '0'
+ASYNC_WGRAD = True
 # while a step is being recorded into a hipGraph the side streams fork from / join the capturing stream, so the graph keeps
 # the eager step's concurrency (weight gradients beside the data-gradient chain, the assessor's chain beside the localizer's)
-CAPTURE_STREAMS = os.environ.get('LOANS_CAPTURE_STREAMS', '1') != '0'
-# HIP stream priority of the weight-gradient stream (0 = normal like the main stream, 1 = low, -1 = high): experiment knob
-SIDE_PRIORITY = int(os.environ.get('LOANS_SIDE_PRIORITY', '0'))
+CAPTURE_STREAMS = True
 _side = {}
 _side_dirty = set()
-# LOANS_WGRAD_CUS=n (round 4): the weight-gradient stream(s) are created with a CU mask (hipExtStreamCreateWithCUMask) that
-# leaves them n of every 8 consecutive CUs -- whatever the numbering, every XCD keeps n / 8 of its CUs for them -- so that the
-# HBM-bound BN / pooling passes of the main stream always find (8 - n) / 8 of the machine free instead of time-slicing with
-# blocks that own whole CUs' register files (those passes run at 1.3 - 2 TB/s in situ against 4 - 5 alone).
-WGRAD_CUS_OF_8 = int(os.environ.get('LOANS_WGRAD_CUS', '0'))
+# (Tried and removed, DESIGN 7c / 7d: HIP stream priorities for the side streams -- no effect in any combination --, and a CU mask
+# for the weight-gradient stream (hipExtStreamCreateWithCUMask): configs[2] 18.9 -> 25.2-26.0 ms, a masked queue changes how the
+# whole device dispatches.)
 
 
 def side_stream_cus(device=None):
     """CUs the weight-gradient streams may use (block-count candidates of the weight gradients are laid out for these)"""
-    cus = torch.cuda.get_device_properties(torch.cuda.current_device() if device is None else device).multi_processor_count
-    return cus * WGRAD_CUS_OF_8 // 8 if 0 < WGRAD_CUS_OF_8 < 8 else cus
+    return torch.cuda.get_device_properties(torch.cuda.current_device() if device is None else device).multi_processor_count
 
 
 def _new_side_stream(device):
-    if not 0 < WGRAD_CUS_OF_8 < 8:
-        return torch.cuda.Stream(device=device, priority=SIDE_PRIORITY)
-    import ctypes
-    hip = ctypes.CDLL('libamdhip64.so')
-    total = torch.cuda.get_device_properties(device).multi_processor_count
-    words = (total + 31) // 32
-    mask = (ctypes.c_uint32 * words)()
-    for i in range(total):
-        if i % 8 < WGRAD_CUS_OF_8:
-            mask[i // 32] |= 1 << (i % 32)
-    handle = ctypes.c_void_p()
-    with torch.cuda.device(device):
-        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(handle), words, mask)
-    if rc != 0 or not handle.value:
-        raise RuntimeError('hipExtStreamCreateWithCUMask failed with %d' % rc)
-    return torch.cuda.ExternalStream(handle.value, device=device)
+    return torch.cuda.Stream(device=device)
 
 
 # Consecutive weight gradients are independent of each other: with LOANS_WGRAD_STREAMS = n > 1 they rotate over n streams, so that
@@ -1275,7 +1258,7 @@ def _new_side_stream(device):
 # run 3-6 rounds of 128 x 128 tiles with a ragged last one --, bf16 configs[2] / ResNet-50 +0.06 / +0.15 ms (their launches are
 # one or two rounds of long blocks that already fill the machine; a second launch beside them only takes CUs from the first).
 # Default: two streams while the fp32 kernels are selected, one on the bf16 arms.
-_WGRAD_STREAMS_ENV = os.environ.get('LOANS_WGRAD_STREAMS', '')
+_WGRAD_STREAMS_ENV = ''          # (tests set it: '1' .. '4' overrides the default below)
 _side_more = {}
 _side_turn = {}
 
@@ -1331,26 +1314,24 @@ def _wgrad_key(x, gy, relu_in):
 
 def conv_wgrad(x, gy, dw, geo, relu_in=False, splits=0, tile=0):
     """dw[Cout,k,k,Cin] += sum over pixels (atomic accumulate into the gradient arena)."""
-    masked = 0 < WGRAD_CUS_OF_8 < 8
     tuned = geo.tuned.get(_wgrad_key(x, gy, relu_in)) is not None
-    if ASYNC_WGRAD and (tuned or masked) and (CAPTURE_STREAMS or not torch.cuda.is_current_stream_capturing()):
+    if ASYNC_WGRAD and tuned and (CAPTURE_STREAMS or not torch.cuda.is_current_stream_capturing()):
         side = _wgrad_stream(x.device)
         side.wait_stream(_current_stream_obj(x.device.index))
         x.record_stream(side)
         gy.record_stream(side)
         _side_dirty.add(x.device.index)
-        if tuned and not geo.dense and WGRAD_BY_HANDLE:
+        if not geo.dense:
             # the launch goes to the side stream by handle: making it torch's current stream (a context manager: two Python-level
             # stream switches per weight gradient) cost 2 ms of host time per ResNet-50 step; nothing is allocated on this path
             _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile, stream=side.cuda_stream)
         else:
-            with torch.cuda.stream(side):       # (a masked stream is tuned THERE; the dense stem's mask pass allocates)
+            with torch.cuda.stream(side):       # (the dense stem's mask pass allocates)
                 _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile)
         return
     _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile)
 
 
-WGRAD_BY_HANDLE = os.environ.get('LOANS_WGRAD_BY_HANDLE', '1') != '0'
 _stream_objs = {}
 
 
@@ -1393,7 +1374,7 @@ def _wgrad_candidates(geo, tiles, chunk_px, dims=None):
 
 # LOANS_TILE_WGHALO_* (csrc/wgrad_halo_bf16.hip): all nine taps of a stride-1 3x3 weight gradient in one block
 TILE_WGHALO_64, TILE_WGHALO_128 = 38, 39
-WGHALO = os.environ.get('LOANS_WGHALO', '1') != '0'
+WGHALO = True
 
 
 @_memo
@@ -1512,7 +1493,7 @@ def _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile, stream=None):
 # preprocessing / layout
 # --------------------------------------------------------------------------- #
 # LOANS_DENSE_BF16=0: the stem of the bf16 storage arm reads fp32 frames (loans_igemm_bf16_f32 + LOANS_F_OUT_BF16)
-DENSE_BF16 = os.environ.get('LOANS_DENSE_BF16', '1') != '0'
+DENSE_BF16 = True
 
 
 def prep_images(images_nchw, geo=None):
@@ -1595,7 +1576,7 @@ _zero_pools = {}
 # convolution and one re-pack per class and layer (47 + 94 launches of 4 - 20 us per step at configs[2], 72 at configs[1],
 # all on the step's critical stream).  LOANS_WEIGHT_PREP=0 restores the per-call launches.
 # --------------------------------------------------------------------------- #
-WEIGHT_PREP = os.environ.get('LOANS_WEIGHT_PREP', '1') != '0'
+WEIGHT_PREP = True
 _MAX_PREP_JOBS = 2048
 
 
@@ -1845,8 +1826,6 @@ def bn_eval_coeffs(gamma, beta, running_mean, running_var):
     return st
 
 
-# LOANS_BN_BITS=0: the final BN of a residual unit reads its ReLU mask from the unit's output tensor
-BN_BITS = os.environ.get('LOANS_BN_BITS', '1') != '0'
 
 
 def bn_apply(x, st, relu=True, residual=None, x2=None, st2=None, want_bits=False):
@@ -1863,8 +1842,8 @@ def bn_apply(x, st, relu=True, residual=None, x2=None, st2=None, want_bits=False
         mode, second = 2, x2
     lib = _lib.load()
     assert second is None or second.dtype == x.dtype
-    _acct('bn_fwd', 0, _nbytes(x, second), _nbytes(y) + (rows * (C_ // 4) if (want_bits and relu and BN_BITS) else 0))
-    if want_bits and relu and BN_BITS:
+    _acct('bn_fwd', 0, _nbytes(x, second), _nbytes(y) + (rows * (C_ // 4) if (want_bits and relu) else 0))
+    if want_bits and relu:
         bits = torch.empty(rows * (C_ // 4), device=x.device, dtype=torch.uint8)
         fn = lib.loans_bn_apply_bits_bf16 if _is16(x) else lib.loans_bn_apply_bits_f32
         check(fn(_ptr(x), _ptr(st.scale), _ptr(st.shift), _ptr(second),
@@ -1905,12 +1884,9 @@ def maxpool_relu_bwd(gy, idx, x, st):
     return gx
 
 
-# LOANS_BN_XMASK=0: always read the ReLU mask from the stored activation
-BN_XMASK = os.environ.get('LOANS_BN_XMASK', '1') != '0'
-
-
-# LOANS_BN_REPLICAS=0: the BN-backward reductions add into one accumulator per channel again (rounds 1-2)
-BN_REPLICAS = os.environ.get('LOANS_BN_REPLICAS', '1') != '0'
+# (Settled in rounds 2-3 and no longer switchable: a BN's own ReLU mask is recomputed from its input instead of read from the
+# activation; a unit's final BN reads its mask as sign bits; the reductions add into replicated accumulators.  The older kernels
+# remain as the fall-back for channel counts the 16-byte-unit kernels do not tile.)
 
 
 def bn_units_ok(C_, s16):
@@ -1928,8 +1904,8 @@ def _bn_backward_rep(lib, gy, mask, x, st, gamma, ggamma, gbeta, x2, st2, gamma2
     s16 = _is16(x)
     s = _stream()
     assert _is16(gy) == s16 and (x2 is None or _is16(x2) == s16)
-    own = mask_is_own_relu and BN_XMASK and not dual and mask is not None
-    bits = None if own else (getattr(mask, 'relu_bits', None) if (mask is not None and BN_BITS) else None)
+    own = mask_is_own_relu and not dual and mask is not None
+    bits = None if own else (getattr(mask, 'relu_bits', None) if mask is not None else None)
     if bits is not None:
         assert bits.numel() == rows * (C_ // 4)
     kind = 2 if own else (3 if bits is not None else (1 if mask is not None else 0))
@@ -1977,13 +1953,13 @@ def bn_backward(gy, mask, x, st, gamma, ggamma, gbeta, x2=None, st2=None, gamma2
     rows = x.numel() // C_
     dual = x2 is not None
     if CLASS_COUNT is not None:
-        own = mask_is_own_relu and BN_XMASK and not dual and mask is not None
-        bits = None if own else (getattr(mask, 'relu_bits', None) if (mask is not None and BN_BITS) else None)
+        own = mask_is_own_relu and not dual and mask is not None
+        bits = None if own else (getattr(mask, 'relu_bits', None) if mask is not None else None)
         m = None if own else (bits if bits is not None else mask)
         _acct('bn_bwd', 0, 2 * _nbytes(gy, x, x2, m), _nbytes(x) * (2 if dual else 1))       # sums, then apply: two passes
-    if BN_REPLICAS and bn_units_ok(C_, _is16(x)):
+    if bn_units_ok(C_, _is16(x)):
         return _bn_backward_rep(lib, gy, mask, x, st, gamma, ggamma, gbeta, x2, st2, gamma2, ggamma2, gbeta2, mask_is_own_relu)
-    if mask_is_own_relu and BN_XMASK and not dual and mask is not None:
+    if mask_is_own_relu and not dual and mask is not None:
         s = _stream()
         s16 = _is16(x)
         assert _is16(gy) == s16
@@ -2005,7 +1981,7 @@ def bn_backward(gy, mask, x, st, gamma, ggamma, gbeta, x2=None, st2=None, gamma2
     assert _is16(gy) == s16 and (mask is None or _is16(mask) == s16) and (x2 is None or _is16(x2) == s16)
     red_fn = lib.loans_bn_bwd_reduce_bf16 if s16 else lib.loans_bn_bwd_reduce_f32
     app_fn = lib.loans_bn_bwd_apply_bf16 if s16 else lib.loans_bn_bwd_apply_f32
-    bits = getattr(mask, 'relu_bits', None) if (mask is not None and BN_BITS) else None
+    bits = getattr(mask, 'relu_bits', None) if mask is not None else None
     if bits is not None:            # the mask as sign bits (ops.bn_apply(..., want_bits=True)) instead of the tensor
         assert bits.numel() == rows * (C_ // 4)
         mask = bits
@@ -2052,8 +2028,6 @@ def bn_backward_from_sums(gy, x, st, sums, gamma, ggamma, gbeta):
     return gx
 
 
-# LOANS_FUSED_STEM_TAIL=0 restores the three-pass form (maxpool_relu_bwd -> bn_backward)
-FUSED_STEM_TAIL = os.environ.get('LOANS_FUSED_STEM_TAIL', '1') != '0'
 
 
 def pool_bn_backward(gy, idx, x, st, gamma, ggamma, gbeta, gbias=None):
@@ -2064,7 +2038,7 @@ def pool_bn_backward(gy, idx, x, st, gamma, ggamma, gbeta, gbias=None):
     B, H, W, C_ = x.shape
     OH, OW = gy.shape[1], gy.shape[2]
     _acct('stem', 0, 2 * _nbytes(gy, idx) + 2 * _nbytes(x), _nbytes(x))        # sums over the pooled gradient (gathers x), then gx
-    if not (FUSED_STEM_TAIL and reduce_channels_ok(C_) and C_ <= 1024):
+    if not (reduce_channels_ok(C_) and C_ <= 1024):        # (the three-pass form: channel counts the fused pair does not tile)
         gx = bn_backward(maxpool_relu_bwd(gy, idx, x, st), None, x, st, gamma, ggamma, gbeta)
         if gbias is not None:
             colsum_acc(gx, gbias)
@@ -2075,23 +2049,15 @@ def pool_bn_backward(gy, idx, x, st, gamma, ggamma, gbeta, gbias=None):
     s = _stream()
     app_fn = lib.loans_pool_bn_bwd_apply_bf16 if s16 else lib.loans_pool_bn_bwd_apply_f32
     k = torch.empty((3, C_), device=x.device, dtype=torch.float32)
-    if BN_REPLICAS:
-        sums = _zeros_f64((STATS_REPLICAS, 2, C_), x.device)
-        red_fn = lib.loans_pool_bn_bwd_reduce_rep_bf16 if s16 else lib.loans_pool_bn_bwd_reduce_rep_f32
-        check(red_fn(_ptr(gy), _ptr(idx), _ptr(x), _ptr(st.scale), _ptr(st.shift), _ptr(st.mean), _ptr(st.rstd), _ptr(sums),
-                     STATS_REPLICAS, B, H, W, C_, OH, OW, s), 'loans_pool_bn_bwd_reduce_rep')
-        check(lib.loans_bn_bwd_coeffs_rep_f32(_ptr(sums), STATS_REPLICAS, 2 * C_, 0, C_, B * H * W, _ptr(gamma), _ptr(st.mean),
-                                              _ptr(st.rstd), _ptr(ggamma), _ptr(gbeta), _ptr(k[0]), _ptr(k[1]), _ptr(k[2]), s),
-              'loans_bn_bwd_coeffs_rep_f32')
-    else:
-        sums = _zeros_f64((2, C_), x.device)
-        red_fn = lib.loans_pool_bn_bwd_reduce_bf16 if s16 else lib.loans_pool_bn_bwd_reduce_f32
-        check(red_fn(_ptr(gy), _ptr(idx), _ptr(x), _ptr(st.scale), _ptr(st.shift), _ptr(st.mean), _ptr(st.rstd), _ptr(sums),
-                     B, H, W, C_, OH, OW, s), 'loans_pool_bn_bwd_reduce')
-        check(lib.loans_bn_bwd_coeffs_f32(_ptr(sums), C_, B * H * W, _ptr(gamma), _ptr(st.mean), _ptr(st.rstd), _ptr(ggamma),
-                                          _ptr(gbeta), _ptr(k[0]), _ptr(k[1]), _ptr(k[2]), s), 'loans_bn_bwd_coeffs_f32')
+    sums = _zeros_f64((STATS_REPLICAS, 2, C_), x.device)
+    red_fn = lib.loans_pool_bn_bwd_reduce_rep_bf16 if s16 else lib.loans_pool_bn_bwd_reduce_rep_f32
+    check(red_fn(_ptr(gy), _ptr(idx), _ptr(x), _ptr(st.scale), _ptr(st.shift), _ptr(st.mean), _ptr(st.rstd), _ptr(sums),
+                 STATS_REPLICAS, B, H, W, C_, OH, OW, s), 'loans_pool_bn_bwd_reduce_rep')
+    check(lib.loans_bn_bwd_coeffs_rep_f32(_ptr(sums), STATS_REPLICAS, 2 * C_, 0, C_, B * H * W, _ptr(gamma), _ptr(st.mean),
+                                          _ptr(st.rstd), _ptr(ggamma), _ptr(gbeta), _ptr(k[0]), _ptr(k[1]), _ptr(k[2]), s),
+          'loans_bn_bwd_coeffs_rep_f32')
     gx = torch.empty_like(x)
-    if gbias is not None and BN_REPLICAS and C_ // 4 <= 256 and 256 % (C_ // 4) == 0:
+    if gbias is not None and C_ // 4 <= 256 and 256 % (C_ // 4) == 0:
         # the bias-gradient sums go through 32 replicas (fp32 views of the step's zeroed accumulator pool), then one fold
         reps = _zeros_f64((STATS_REPLICAS // 2, C_), x.device).view(torch.float32).view(STATS_REPLICAS, C_)
         rep_fn = lib.loans_pool_bn_bwd_apply_rep_bf16 if s16 else lib.loans_pool_bn_bwd_apply_rep_f32
@@ -2102,48 +2068,6 @@ def pool_bn_backward(gy, idx, x, st, gamma, ggamma, gbeta, gbias=None):
     check(app_fn(_ptr(gy), _ptr(idx), _ptr(x), _ptr(st.scale), _ptr(st.shift), _ptr(k[0]), _ptr(k[1]), _ptr(k[2]), _ptr(gx),
                  _ptr(gbias), B, H, W, C_, OH, OW, s), 'loans_pool_bn_bwd_apply')
     return gx
-
-
-# The stem's backward of the bf16 storage arm in one kernel behind the BN sums (csrc/stem_bwd_bf16.hip, round 5): conv1's gradient
-# tensor is rebuilt tile by tile and contracted with the frames at once -- never written, never read back.
-# LOANS_STEM_BWD_FUSED=0: loans_pool_bn_bwd_apply_rep_bf16 -> loans_wgrad_bf16s(dense) -> the mask pass again.
-STEM_BWD_FUSED = os.environ.get('LOANS_STEM_BWD_FUSED', '1') != '0'
-
-
-def stem_backward_fused_ok(frames, y, geo):
-    """loans_stem_bwd_bf16 covers this stem: the dense 7x7 / 2, 3 -> 64 geometry on bf16 frames and a bf16 conv output"""
-    return STEM_BWD_FUSED and geo.dense and geo.k == 7 and geo.stride == 2 and geo.pad == 3 and geo.Cout == 64 and \
-        _is16(frames) and _is16(y) and y.is_contiguous() and frames.is_contiguous() and \
-        geo.B * geo.Hp * geo.Wp * 3 * 2 < 0x7FFFFFF0 and geo.B * geo.Ho * geo.Wo * 64 * 2 < 0x7FFFFFF0
-
-
-def stem_backward_fused(gy, idx, y, st, gamma, ggamma, gbeta, gbias, frames, dw, geo):
-    """pool_bn_backward(...) followed by conv_wgrad(frames, gx, dw, geo) without gx: the BN's two sums and its coefficients as
-    before (one reduction pass over the pooled gradient), then ONE kernel that rebuilds gx tiles in registers, adds their
-    per-channel sums to gbias and contracts them with the frames into dw.  On the current stream (it is the last kernel of
-    the localizer's backward: nothing is left to run beside a weight gradient on the side stream)."""
-    lib = _lib.load()
-    B, H, W, C_ = y.shape
-    OH, OW = gy.shape[1], gy.shape[2]
-    assert stem_backward_fused_ok(frames, y, geo) and C_ == 64 and _is16(gy) and gy.is_contiguous() and dw.numel() == geo.w_numel
-    s = _stream()
-    k = torch.empty((3, C_), device=y.device, dtype=torch.float32)
-    sums = _zeros_f64((STATS_REPLICAS, 2, C_), y.device)
-    check(lib.loans_pool_bn_bwd_reduce_rep_bf16(_ptr(gy), _ptr(idx), _ptr(y), _ptr(st.scale), _ptr(st.shift), _ptr(st.mean), _ptr(st.rstd),
-                                                _ptr(sums), STATS_REPLICAS, B, H, W, C_, OH, OW, s), 'loans_pool_bn_bwd_reduce_rep')
-    check(lib.loans_bn_bwd_coeffs_rep_f32(_ptr(sums), STATS_REPLICAS, 2 * C_, 0, C_, B * H * W, _ptr(gamma), _ptr(st.mean),
-                                          _ptr(st.rstd), _ptr(ggamma), _ptr(gbeta), _ptr(k[0]), _ptr(k[1]), _ptr(k[2]), s),
-          'loans_bn_bwd_coeffs_rep_f32')
-    need = int(lib.loans_stem_bwd_bf16_ws_floats(B, H, W))
-    key = (y.device.index, s)
-    ws = _wgrad_ws.get(key)
-    if ws is None or ws.numel() < need:
-        ws = _wgrad_ws[key] = torch.empty(max(need, 1 << 22), device=y.device, dtype=torch.float32)
-    _count_flops('wgrad', geo)
-    _acct('stem', _conv_flop(geo), 2 * _nbytes(gy, idx) + 2 * _nbytes(y) + _nbytes(frames), _nbytes(dw))     # gx is never stored
-    check(lib.loans_stem_bwd_bf16(_ptr(frames), _ptr(y), _ptr(gy), _ptr(idx), _ptr(st.scale), _ptr(st.shift), _ptr(k[0]), _ptr(k[1]),
-                                  _ptr(k[2]), _ptr(dw), _ptr(gbias), _ptr(ws), ws.numel(), B, geo.Hp, geo.Wp * 3, H, W, OH, OW, s),
-          'loans_stem_bwd_bf16')
 
 
 def colsum_acc(x, out):

@@ -92,8 +92,8 @@ def init_from_env(backend=None):
     return Communicator()
 
 
-# LOANS_STAGED_EXCHANGE=0: one exchange of the whole arena after the backward (rounds 1-2)
-STAGED_EXCHANGE = os.environ.get('LOANS_STAGED_EXCHANGE', '1') != '0'
+# the gradient arena is exchanged in parts during the backward (False: one exchange of the whole arena behind it, rounds 1-2)
+STAGED_EXCHANGE = True
 
 
 def exchange_plan(link):

@@ -35,7 +35,7 @@ _fork = {}
 def _fork_stream(device):
     st = _fork.get(device.index)
     if st is None:
-        st = _fork[device.index] = torch.cuda.Stream(device=device, priority=int(os.environ.get('LOANS_FORK_PRIORITY', '0')))
+        st = _fork[device.index] = torch.cuda.Stream(device=device)
     return st
 
 

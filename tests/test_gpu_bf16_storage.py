@@ -634,53 +634,6 @@ def test_stem_direct_bf16(case):
 
 
 
-@pytest.mark.parametrize("case", [(2, 32, 32), (3, 64, 64), (2, 96, 80), (1, 130, 66), (2, 224, 224), (2, 50, 34), (1, 22, 30), (1, 512, 512)])
-def test_stem_backward_fused_bf16(case, monkeypatch):
-    """loans_stem_bwd_bf16 (csrc/stem_bwd_bf16.hip, round 5): max-pool backward + ReLU mask + bn1 backward + conv1's weight and bias
-    gradients without conv1's gradient tensor -- against the three launches it replaces (loans_pool_bn_bwd_apply_rep_bf16 ->
-    loans_wgrad_bf16s on the dense frames -> the mask pass): the same bf16 products summed in fp32 in another order.  Output rows
-    that are no multiple of the 32-pixel chunk, odd sizes (windows that overhang), one block per chunk and many chunks per block."""
-    from loans_amd import ops
-    B, H, W = case
-    rng = np.random.RandomState(H * 3 + W)
-    geo = ops.ConvGeometry(B, H, W, 3, 64, 7, 2, 3, dense=True)
-    frames = rng.randint(0, 256, (B, 3, H, W)).astype(np.float32) / 255.0
-    ops.set_compute_dtype('bf16')
-    ops.set_storage_dtype('bf16')
-    try:
-        x = ops.prep_images(dev(frames), geo)
-        assert x.dtype == torch.bfloat16
-        y = d16(_r(rng.standard_normal((B, geo.Ho, geo.Wo, 64)) * 2 + 0.3))
-        gamma = dev((1 + 0.2 * rng.standard_normal(64)).astype(np.float32))
-        beta = dev((0.2 * rng.standard_normal(64)).astype(np.float32))
-        stats = torch.zeros((ops.STATS_REPLICAS, 2, 64), device='cuda', dtype=torch.float64)
-        flat = y.double().reshape(-1, 64)
-        stats[0, 0], stats[0, 1] = flat.sum(0), (flat * flat).sum(0)
-        st = ops.bn_finalize(stats, B * geo.Ho * geo.Wo, gamma, beta, dev(np.zeros(64, np.float32)), dev(np.ones(64, np.float32)))
-        pooled, idx = ops.bn_relu_maxpool(y, st)
-        gy = d16(_r(rng.standard_normal(tuple(pooled.shape))))
-        res = {}
-        for fused in (False, True):
-            monkeypatch.setattr(ops, 'STEM_BWD_FUSED', fused)
-            gg, gb, gbias = (torch.zeros(64, device='cuda') for _ in range(3))
-            dw = torch.zeros((64, 7, geo.kwp, 3), device='cuda')
-            if fused:
-                assert ops.stem_backward_fused_ok(x, y, geo)
-                ops.stem_backward_fused(gy, idx, y, st, gamma, gg, gb, gbias, x, dw, geo)
-            else:
-                gx = ops.pool_bn_backward(gy, idx, y, st, gamma, gg, gb, gbias=gbias)
-                ops._conv_wgrad(x, gx, dw, geo, False, 0, 0)
-            torch.cuda.synchronize()
-            res[fused] = (dw.cpu().numpy().astype(np.float64), gbias.cpu().numpy().astype(np.float64), gg.clone(), gb.clone())
-        (dw_a, bias_a, gg_a, gb_a), (dw_b, bias_b, gg_b, gb_b) = res[False], res[True]
-        assert torch.equal(gg_a, gg_b) and torch.equal(gb_a, gb_b)         # the same reduction pass and coefficient launch
-        assert np.abs(dw_a[:, :, 7:]).max() == 0 and np.abs(dw_b[:, :, 7:]).max() == 0          # window-padding columns
-        assert np.abs(dw_a - dw_b).max() <= 2e-5 * np.abs(dw_a).max(), np.abs(dw_a - dw_b).max() / np.abs(dw_a).max()
-        assert np.abs(bias_a - bias_b).max() <= 2e-5 * np.abs(bias_a).max() + 1e-4
-    finally:
-        ops.set_compute_dtype('f32')
-
-
 @pytest.mark.parametrize("case", [(2, 64, 15, 13, 128, 3, 2, 1), (3, 128, 12, 12, 256, 3, 2, 1), (2, 64, 9, 9, 64, 1, 2, 0), (5, 32, 8, 8, 96, 3, 2, 1)])
 @pytest.mark.parametrize("tile", [0, 1, 2, 3, 7, 9, 33, 35])
 def test_conv_pair_bf16_storage(case, tile):

@@ -41,6 +41,18 @@ def test_bench_single_process():
     assert out['n_gpus'] == 1 and out['config']['dist_backend'] is None and out['value'] > 0
 
 
+def test_bench_rccl_at_world_size_one():
+    """LOANS_DIST_SELFTEST=1: every collective of the data-parallel step is issued even at world size 1 -- the RCCL (nccl backend)
+    path on a one-GPU box: process group, parameter broadcast, the staged all-reduce of both gradient arenas"""
+    e = dict(os.environ, LOANS_DIST_SELFTEST='1', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT='29731')
+    e.pop('LOANS_SPLITK', None)
+    e.pop('LOANS_DIST_BACKEND', None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1'] + TINY, cwd=ROOT, env=e, timeout=900,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    out = _one_line(r)
+    assert out['config']['dist_backend'] == 'nccl' and out['config']['world_size'] == 1 and out['value'] > 0
+
+
 def test_bench_secondary_legs_schema():
     """The driver's one bench line carries the other single-GPU configurations as `secondary` legs (configs[2]: bf16 joint
     step; configs[4] per GPU: ResNet-50 localizer, bf16), each with its own roofline -- here on tiny shapes (2 x 3 x 320 x 320:
@@ -64,6 +76,11 @@ def test_bench_secondary_legs_schema():
         assert r['bound'] == 'mfma' and r['peak'] == 2500.0 and 0 < r['frac'] < 1 and 'traffic' in r
         assert 0 < r['binding']['frac'] and 0 < r['binding']['frac_write_priced'] and r['binding']['layers']
         assert 0 < r['whole_step']['frac'] < 1 and set(r['whole_step']['by_kind']) == {'dgrad', 'fprop', 'wgrad'}
+        # the whole step priced per kernel class (round 5): algorithmic bytes / FLOP counted live, bound per launch
+        b = r['whole_step']['binding']
+        assert {'conv', 'wgrad', 'bn_fwd', 'bn_bwd', 'stem', 'optimizer'} <= set(b['classes'])
+        assert 0 < b['bound_ms_machine'] <= b['bound_ms_sum'] and 0 < b['binding_frac'] < 1
+        assert all(c['bound_ms'] >= 0 and c['mbytes'] >= 0 for c in b['classes'].values())
     assert 'ResNet-50' in sec['configs[4] per GPU']['config']['workload'] and 'ResNet-18' in sec['configs[2]']['config']['workload']
     # 31 convolutions of the ResNet-18 variant at 320 px (res6 + res7), 53 + 10 of the ResNet-50 localizer
     assert '31 convs' in sec['configs[2]']['roofline']['kernel']
