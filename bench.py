@@ -71,7 +71,7 @@ def parse():
                     help="arithmetic of the conv contractions: exact fp32 MFMA (parity path) or bf16 MFMA with fp32 accumulate")
     ap.add_argument('--storage', default=None, choices=['f32', 'bf16'],
                     help="storage of the localizer's stage activations / gradients (default: bf16 with --dtype bf16, else f32)")
-    ap.add_argument('--graph', action='store_true', help='capture the step into a hipGraph after warm-up (small, launch-bound batches)')
+    ap.add_argument('--graph', action='store_true', help='capture the step into a hipGraph after warm-up: host offload only -- the replay is slower than the eager step (DESIGN 7e)')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--tune-file', default=None,
                     help="kernel-tile table: read if the file exists (the run then launches exactly those tiles -- use for the "
@@ -387,8 +387,6 @@ def run_workload(w, comm, local_rank, retune):
         tune_file = _profile_file(name, 'tune')
     if tune_file and os.path.exists(tune_file):
         tune_loaded = ops.load_tune_table(tune_file)
-    ops.set_compute_dtype(w.dtype)
-    ops.set_storage_dtype(w.storage)
 
     # ---- synthetic inputs, resident in HBM ----
     pool = 32
@@ -405,6 +403,8 @@ def run_workload(w, comm, local_rank, retune):
     localizer.param_predictor.W.set_logical(
         (1e-3 * np.random.standard_normal(localizer.param_predictor.W.logical_shape)).astype(np.float32))
     discriminator = loans_amd.ResnetAssessor()
+    localizer.set_precision(w.dtype, w.storage)       # the arithmetic is a property of the models, not of the process
+    discriminator.set_precision(w.dtype, w.storage)
     with loans_amd.using_config('enable_backprop', False):
         discriminator(real_d[:2])                     # materialise the lazy l4, build the arenas
     localizer.finalize(dev)
@@ -435,6 +435,7 @@ def run_workload(w, comm, local_rank, retune):
     comm.barrier()
     torch.cuda.synchronize()
     mem0 = torch.cuda.memory_stats(dev)
+    arena = ops.step_arena_state(dev)
     t0 = time.perf_counter()
     for _ in range(w.steps):
         updater.update()
@@ -445,6 +446,10 @@ def run_workload(w, comm, local_rank, retune):
     # diagnostics only (measurement hygiene): device allocations / allocator retries INSIDE the timed region -- a
     # steady-state step should make none (everything comes from torch's cache); a hipMalloc / hipFree there synchronises the device
     allocator = {k: int(mem1.get(k, 0) - mem0.get(k, 0)) for k in ('num_device_alloc', 'num_device_free', 'num_alloc_retries')}
+    # the step's activation workspace (ops._StepArena): its size, what one step takes from it, requests it could not serve
+    arena1 = ops.step_arena_state(dev)
+    allocator['step_arena'] = {'mbytes': round(arena1['bytes'] / 1e6, 1), 'mbytes_per_step': round(arena1['used'] / 1e6, 1),
+                               'requests_not_served': arena1['misses'] - arena['misses']}
     log, ops.EVENT_LOG = ops.EVENT_LOG, None
     flop_count, ops.FLOP_COUNT = ops.FLOP_COUNT, None
     class_count, ops.CLASS_COUNT = ops.CLASS_COUNT, None

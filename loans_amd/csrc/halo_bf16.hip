@@ -751,9 +751,15 @@ __global__ __launch_bounds__(512, 1) void wsw_kernel(const Halo16Args a, int nun
 
     // units in row-pair strips: the eight waves of a block take eight neighbouring units, the blocks of an XCD the strips next
     // to each other (their halo rows overlap: L2 hits)
-    const int gw = xcd_remap_h(blockIdx.x, gridDim.x) * 8 + wave_u, nw = gridDim.x * 8;
+    int gw = xcd_remap_h(blockIdx.x, gridDim.x) * 8 + wave_u, nw = gridDim.x * 8;
+    if (HDBG(16)) {         // experiment: four working waves per CU (one per SIMD)
+        if (wave_u >= 4) return;
+        gw = xcd_remap_h(blockIdx.x, gridDim.x) * 4 + wave_u;
+        nw = gridDim.x * 4;
+    }
     const int per_img = units_y * units_x;
     auto issue_image = [&](int u) {     // unit u's halo image into this wave's buffer
+        if (HDBG(1)) return;
         const int b = u / per_img, uu = u - b * per_img;
         const int uy = uu / units_x, ux = uu - uy * units_x;
         const int iy0 = 2 * uy + a.dymin, ix0 = 16 * ux + a.dxmin, base = b * d.inH;
@@ -818,9 +824,11 @@ __global__ __launch_bounds__(512, 1) void wsw_kernel(const Halo16Args a, int nun
         frags(0, 1, fa[1], f0[1], f1[1]);
 #pragma unroll
         for (int st = 0; st < 36; ++st) {
-            if (st + 2 < 36) frags((st + 2) >> 2, (st + 2) & 3, fa[(st + 2) % 3], f0[(st + 2) % 3], f1[(st + 2) % 3]);
-            acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st % 3], f0[st % 3], acc0, 0, 0, 0);
-            acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st % 3], f1[st % 3], acc1, 0, 0, 0);
+            if (st + 2 < 36 && !HDBG(4)) frags((st + 2) >> 2, (st + 2) & 3, fa[(st + 2) % 3], f0[(st + 2) % 3], f1[(st + 2) % 3]);
+            if (!HDBG(2)) {
+                acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st % 3], f0[st % 3], acc0, 0, 0, 0);
+                acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st % 3], f1[st % 3], acc1, 0, 0, 0);
+            }
         }
         if (f_stats) {
             float s0 = 0.f, q20 = 0.f, s1 = 0.f, q21 = 0.f;
@@ -904,7 +912,7 @@ __global__ __launch_bounds__(512, 1) void wsw_kernel(const Halo16Args a, int nun
                     bn_s2[q] += gm * (y2[q] - bn_mean[q]);
                 }
             }
-            LOANS_STORE_B128(__builtin_bit_cast(u32x4, o), rs_out, (int)off, a.nt_out);
+            if (!HDBG(8)) LOANS_STORE_B128(__builtin_bit_cast(u32x4, o), rs_out, (int)off, a.nt_out);
         }
     }
     if (f_bnsums) {

@@ -7,6 +7,7 @@ fallback: without the built library ``_lib.load()`` raises.
 """
 import ctypes as C
 import os
+import threading
 import time
 
 import numpy as np
@@ -31,6 +32,7 @@ BF16 = torch.bfloat16
 
 
 def set_compute_dtype(name):
+    """the PROCESS DEFAULT: what a model without a precision of its own (``Link.set_precision``) runs in"""
     global COMPUTE, STORAGE
     if name not in ('f32', 'bf16'):
         raise ValueError("compute dtype must be 'f32' or 'bf16'")
@@ -48,13 +50,47 @@ def set_storage_dtype(name):
     STORAGE = name
 
 
+def check_precision(compute, storage):
+    if compute not in ('f32', 'bf16') or storage not in ('f32', 'bf16'):
+        raise ValueError("compute / storage dtype must be 'f32' or 'bf16'")
+    if storage == 'bf16' and compute != 'bf16':
+        raise ValueError('bf16 storage needs bf16 compute')
+    return compute, storage
+
+
+class precision:
+    """``with ops.precision(compute, storage):`` -- the arithmetic of everything launched inside.  The dtype arm is a
+    property of the MODEL (``Link.set_precision`` in runtime/core.py): a link that has one runs its ``__call__`` inside this
+    scope, every Function remembers the scope it ran forward in and runs backward in it again, so an fp32 and a bf16 model
+    live in one process (tests/test_gpu_bf16_storage.py::test_fp32_and_bf16_models_step_in_one_process).  COMPUTE / STORAGE
+    above are the scope's current value: the process default outside any scope."""
+
+    def __init__(self, compute, storage=None):
+        self.want = check_precision(compute, storage if storage is not None else ('f32' if compute == 'f32' else 'bf16'))
+
+    def __enter__(self):
+        global COMPUTE, STORAGE
+        self.old = (COMPUTE, STORAGE)
+        COMPUTE, STORAGE = self.want
+        return self
+
+    def __exit__(self, *exc):
+        global COMPUTE, STORAGE
+        COMPUTE, STORAGE = self.old
+        return False
+
+
+def current_precision():
+    return COMPUTE, STORAGE
+
+
 def _is16(t):
     return t is not None and t.dtype == BF16
 
 
 def cast_bf16(w):
     """bf16 operand copy of an fp32 parameter tensor (weights change every step: made per use, ~microseconds)."""
-    out = torch.empty(w.shape, device=w.device, dtype=BF16)
+    out = _empty(w.shape, device=w.device, dtype=BF16)
     check(_lib.load().loans_cast_bf16(_ptr(w), _ptr(out), w.numel(), _stream()), 'loans_cast_bf16')
     return out
 
@@ -458,7 +494,7 @@ def _pw_packed(lib, w, w16, geo, st):
         if entry is not None:
             packed = entry['buf']
     if packed is None:
-        packed = torch.empty(geo.Cout * geo.Cin, device=w16.device, dtype=BF16)
+        packed = _empty(geo.Cout * geo.Cin, device=w16.device, dtype=BF16)
     PW_PACK_CALLS += 1
     check(lib.loans_pw_pack_bf16(_ptr(w16), _ptr(packed), geo.Cout, geo.Cin, st), 'loans_pw_pack_bf16')
     return packed
@@ -502,7 +538,7 @@ def _splitk16_candidates(rows, out_channels, ktot):
 def _igemm16_splitk(lib, src, d_list, out, flags, tile, bias, stats, ref, addend, rows, Cout, st):
     """split-K convolution on bf16 storage: zeroed fp32 workspace, raw partial launches (one per descriptor: the parity classes
     of a strided data gradient share the workspace), one finalize pass with the epilogue flags.  d_list = [(desc, weights)]."""
-    partial = torch.zeros((rows, Cout), device=out.device, dtype=torch.float32)
+    partial = _empty((rows, Cout), device=out.device, dtype=torch.float32).zero_()
     for d, wt in d_list:
         check(lib.loans_igemm_bf16s_splitk(_ptr(src), _ptr(wt), _ptr(partial),
                                            C.byref(_with_flags(d, flags & (F_RELU_IN | F_DENSE), tile & 0xFF)), tile >> 8, st),
@@ -561,6 +597,7 @@ def _time_call(fn, reps=5, cold=False):
 #           A test session never times: TIMED_PICKS counts the picks that timing decided and conftest asserts it stays put.
 TUNE_POLICY = os.environ.get('LOANS_TUNE_POLICY', 'time')
 TUNE_SALT = os.environ.get('LOANS_TUNE_SALT', '0')
+TUNE_VERBOSE = False        # development tools set this: one line per pick
 TIMED_PICKS = 0
 assert TUNE_POLICY in ('time', 'fixed'), TUNE_POLICY
 
@@ -588,7 +625,7 @@ def _tuned_tile(geo, mode, run, candidates, cold=False):
         return tile
     if TUNE_POLICY == 'fixed':
         tile = geo.tuned[mode] = _fixed_pick(geo, mode, candidates)
-        if os.environ.get('LOANS_TUNE_VERBOSE'):
+        if TUNE_VERBOSE:
             print('[tune] %-5s B=%d %dx%dx%d -> %d k%d s%d : fixed pick, tile %d of %s' % (
                 mode, geo.B, geo.H, geo.W, geo.Cin, geo.Cout, geo.k, geo.stride, tile, candidates), flush=True)
         return tile
@@ -597,7 +634,7 @@ def _tuned_tile(geo, mode, run, candidates, cold=False):
     _cold.clear()           # the 512 MB fill buffer of a cold-timed shape is not kept for the life of the process
     tile = min(times, key=times.get)
     geo.tuned[mode] = tile
-    if os.environ.get('LOANS_TUNE_VERBOSE'):
+    if TUNE_VERBOSE:
         print('[tune] %-5s B=%d %dx%dx%d -> %d k%d s%d : %s -> tile %d' % (
             mode, geo.B, geo.H, geo.W, geo.Cin, geo.Cout, geo.k, geo.stride,
             ' '.join('%d:%.3fms' % kv for kv in sorted(times.items())), tile), flush=True)
@@ -733,9 +770,9 @@ def conv_fprop(x, w, geo, out=None, bias=None, stats=None, relu_in=False, addend
         return _conv_fprop16(lib, x, w, geo, out, bias, stats, relu_in, addend, tile)
     if out_bf16:
         assert COMPUTE == 'bf16' and addend is None and out is None
-        out = torch.empty((geo.B, geo.Ho, geo.Wo, geo.Cout), device=x.device, dtype=BF16)
+        out = _empty((geo.B, geo.Ho, geo.Wo, geo.Cout), device=x.device, dtype=BF16)
     if out is None:
-        out = torch.empty((geo.B, geo.Ho, geo.Wo, geo.Cout), device=x.device, dtype=torch.float32)
+        out = _empty((geo.B, geo.Ho, geo.Wo, geo.Cout), device=x.device, dtype=torch.float32)
     flags = (F_RELU_IN if relu_in else 0) | (F_BIAS if bias is not None else 0) | (F_OUT_BF16 if out_bf16 else 0) | \
             (F_STATS if stats is not None else 0) | (F_ADDEND if addend is not None else 0) | geo.base_flags
     assert x.numel() == geo.in_numel and w.numel() == geo.w_numel
@@ -747,7 +784,7 @@ def conv_fprop(x, w, geo, out=None, bias=None, stats=None, relu_in=False, addend
         sstats = stats_buffer(geo.Cout, x.device) if stats is not None else None
 
         def run(t):
-            scratch = torch.empty((geo.B, geo.Ho, geo.Wo, geo.Cout), device=x.device, dtype=BF16 if out_bf16 else torch.float32)
+            scratch = _empty((geo.B, geo.Ho, geo.Wo, geo.Cout), device=x.device, dtype=BF16 if out_bf16 else torch.float32)
             if t >> 8:
                 _igemm_splitk(lib, x, w, scratch, [(geo.fwd, w)], tflags, t, None, sstats, None, None,
                               geo.B * geo.Ho * geo.Wo, geo.Cout, _stream())
@@ -824,7 +861,7 @@ def conv_fprop_pair(x, w_a, w_b, geo_a, geo_b, stats_a=None, stats_b=None, tile=
     assert fprop_pair_ok(x, geo_a, geo_b) and (stats_a is None) == (stats_b is None)
     if _is16(x):
         return _conv_fprop_pair16(lib, x, w_a, w_b, geo_a, geo_b, stats_a, stats_b, tile)
-    mk = lambda g: torch.empty((g.B, g.Ho, g.Wo, g.Cout), device=x.device, dtype=torch.float32)      # noqa: E731
+    mk = lambda g: _empty((g.B, g.Ho, g.Wo, g.Cout), device=x.device, dtype=torch.float32)      # noqa: E731
     out_a, out_b = mk(geo_a), mk(geo_b)
     flags = F_STATS if stats_a is not None else 0
     if tile == 0:
@@ -865,12 +902,12 @@ _PAIR16_TILES = (1, 2, 3, 7)
 def _conv_fprop_pair16(lib, x, w_a, w_b, geo_a, geo_b, stats_a, stats_b, tile):
     """the bf16-storage pair: weights cast into the two halves of one [2][Cout][K] matrix, outputs two views of one allocation"""
     n = geo_a.w_numel
-    w_ab = torch.empty(2 * n, device=x.device, dtype=BF16)
+    w_ab = _empty(2 * n, device=x.device, dtype=BF16)
     for i, w in enumerate((w_a, w_b)):
         assert w.numel() == n and not _is16(w)
         check(lib.loans_cast_bf16(_ptr(w), _ptr(w_ab[i * n:]), n, _stream()), 'loans_cast_bf16')
     flags = F_STATS if stats_a is not None else 0
-    mk = lambda: torch.empty((2, geo_a.B, geo_a.Ho, geo_a.Wo, geo_a.Cout), device=x.device, dtype=BF16)      # noqa: E731
+    mk = lambda: _empty((2, geo_a.B, geo_a.Ho, geo_a.Wo, geo_a.Cout), device=x.device, dtype=BF16)      # noqa: E731
     if tile == 0:
         vkey = _variant(geo_a, 'pair16', flags)
         tile = geo_a.tuned.get(vkey, 0)
@@ -908,7 +945,7 @@ def _conv_fprop_pair16(lib, x, w_a, w_b, geo_a, geo_b, stats_a, stats_b, tile):
 def _conv_fprop16(lib, x, w, geo, out, bias, stats, relu_in, addend, tile):
     """bf16-storage forward conv: x / out / addend bf16, w fp32 master weights (cast per call) or already bf16."""
     if out is None:
-        out = torch.empty((geo.B, geo.Ho, geo.Wo, geo.Cout), device=x.device, dtype=BF16)
+        out = _empty((geo.B, geo.Ho, geo.Wo, geo.Cout), device=x.device, dtype=BF16)
     assert out.dtype == BF16 and (addend is None or addend.dtype == BF16)
     assert x.numel() == geo.in_numel and w.numel() == geo.w_numel
     w16 = w if _is16(w) else _bf16_shadow(w)            # inside a step: the arena's bf16 shadow, cast whole at its start
@@ -924,7 +961,7 @@ def _conv_fprop16(lib, x, w, geo, out, bias, stats, relu_in, addend, tile):
         sstats = stats_buffer(geo.Cout, x.device) if stats is not None else None
 
         def run(t):
-            scratch = torch.empty((geo.B, geo.Ho, geo.Wo, geo.Cout), device=x.device, dtype=BF16)
+            scratch = _empty((geo.B, geo.Ho, geo.Wo, geo.Cout), device=x.device, dtype=BF16)
             if t >> 8:
                 _igemm16_splitk(lib, x, [(geo.fwd, w16)], scratch, tflags, t, None, sstats, None, None,
                                 geo.B * geo.Ho * geo.Wo, geo.Cout, _stream())
@@ -975,7 +1012,7 @@ def _conv_fprop16(lib, x, w, geo, out, bias, stats, relu_in, addend, tile):
 
 def _conv_dgrad16(lib, gy, w, geo, out, mask_ref, addend, addend_mask_ref, tile, bn_sums=None):
     if out is None:
-        out = torch.empty((geo.B, geo.H, geo.W, geo.Cin), device=gy.device, dtype=BF16)
+        out = _empty((geo.B, geo.H, geo.W, geo.Cin), device=gy.device, dtype=BF16)
     assert out.dtype == BF16 and not _is16(w)
     if geo.dgrad_has_empty_class:
         assert mask_ref is None and addend_mask_ref is None
@@ -998,7 +1035,7 @@ def _conv_dgrad16(lib, gy, w, geo, out, mask_ref, addend, addend_mask_ref, tile,
     st = _stream()
     wp = _prepacked_dgrad_weights(w, geo, True)          # inside a step: made at its start, all layers in one launch
     if wp is None:
-        wp = torch.empty(geo.dgrad_weight_floats, device=gy.device, dtype=BF16)
+        wp = _empty(geo.dgrad_weight_floats, device=gy.device, dtype=BF16)
         for d, tapsel, off in geo.dgrad:
             check(lib.loans_repack_dgrad_bf16(_ptr(w), _ptr(wp[off:]), geo.Cout, geo.Cin, geo.k * geo.k, tapsel,
                                               d.ntaps, st), 'loans_repack_dgrad_bf16')
@@ -1012,7 +1049,7 @@ def _conv_dgrad16(lib, gy, w, geo, out, mask_ref, addend, addend_mask_ref, tile,
         tile = geo.tuned.get(vkey, 0)
     if tile == 0:
         def run(t):
-            scratch = torch.empty((geo.B, geo.H, geo.W, geo.Cin), device=gy.device, dtype=BF16)
+            scratch = _empty((geo.B, geo.H, geo.W, geo.Cin), device=gy.device, dtype=BF16)
             if t >> 8:
                 _igemm16_splitk(lib, gy, dl, scratch, 0, t, None, None, None, None, rows_in, geo.Cin, st)
                 return
@@ -1066,7 +1103,7 @@ def conv_dgrad(gy, w, geo, out=None, mask_ref=None, addend=None, addend_mask_ref
     if _is16(gy) and geo.Cin != 4:
         return _conv_dgrad16(lib, gy, w, geo, out, mask_ref, addend, addend_mask_ref, tile, bn_sums)
     if out is None:
-        out = torch.empty((geo.B, geo.H, geo.W, geo.Cin), device=gy.device, dtype=torch.float32)
+        out = _empty((geo.B, geo.H, geo.W, geo.Cin), device=gy.device, dtype=torch.float32)
     if geo.dgrad_has_empty_class:
         # pixels of a tap-less stride class receive only the addend (or zero)
         assert mask_ref is None and addend_mask_ref is None
@@ -1082,7 +1119,7 @@ def conv_dgrad(gy, w, geo, out=None, mask_ref=None, addend=None, addend_mask_ref
         fl = (F_MASK if mask_ref is not None else 0) | (F_ADDEND if addend is not None else 0)
         fn = lib.loans_dgrad_c4_bf16_f32 if _is16(gy) else lib.loans_dgrad_c4_f32
         if out is None:
-            out = torch.empty((geo.B, geo.H, geo.W, geo.Cin), device=gy.device, dtype=torch.float32)
+            out = _empty((geo.B, geo.H, geo.W, geo.Cin), device=gy.device, dtype=torch.float32)
         for d, tapsel, _ in geo.dgrad:
             check(fn(_ptr(gy), _ptr(w), _ptr(out), _ptr(mask_ref), _ptr(addend),
                      C.byref(_with_flags(d, fl, 0)), tapsel, geo.k * geo.k, _stream()), 'loans_dgrad_c4')
@@ -1100,7 +1137,7 @@ def conv_dgrad(gy, w, geo, out=None, mask_ref=None, addend=None, addend_mask_ref
     st = _stream()
     wp = _prepacked_dgrad_weights(w, geo, False)         # inside a step: made at its start, all layers in one launch
     if wp is None:
-        wp = torch.empty(geo.dgrad_weight_floats, device=gy.device, dtype=torch.float32)
+        wp = _empty(geo.dgrad_weight_floats, device=gy.device, dtype=torch.float32)
         for d, tapsel, off in geo.dgrad:
             check(lib.loans_repack_dgrad_f32(_ptr(w), _ptr(wp[off:]), geo.Cout, geo.Cin, geo.k * geo.k, tapsel,
                                              d.ntaps, st), 'loans_repack_dgrad_f32')
@@ -1113,7 +1150,7 @@ def conv_dgrad(gy, w, geo, out=None, mask_ref=None, addend=None, addend_mask_ref
         tile = geo.tuned.get(vkey, 0)
     if tile == 0:
         def run(t):
-            scratch = torch.empty((geo.B, geo.H, geo.W, geo.Cin), device=gy.device, dtype=torch.float32)
+            scratch = _empty((geo.B, geo.H, geo.W, geo.Cin), device=gy.device, dtype=torch.float32)
             if t & TILE_CLASSES:
                 _igemm_classes(lib, gy, wp, scratch, geo, 0, t & 0xFF, None, None, st)
                 return
@@ -1218,7 +1255,7 @@ def crop_dgrad(gy_a, w_a, geo_a, gy_b=None, w_b=None, geo_b=None, addend=None):
         if gy is not None:
             _count_flops('dgrad', g)
             _acct('crop', _conv_flop(g), _nbytes(gy))
-    out = torch.empty((geo_a.B, geo_a.H, geo_a.W, 4), device=gy_a.device, dtype=torch.float32)
+    out = _empty((geo_a.B, geo_a.H, geo_a.W, 4), device=gy_a.device, dtype=torch.float32)
     _acct('crop', 0, _nbytes(addend), _nbytes(out))
     mk = lambda g: _lib.SmallConv(g.k, g.stride, g.pad, g.Ho, g.Wo)      # noqa: E731
     ca, cb = mk(geo_a), (mk(geo_b) if geo_b is not None else None)
@@ -1453,7 +1490,7 @@ def _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile, stream=None):
         tile = geo.tuned.get(vkey, 0)
     if tile == 0:
         def run(t):
-            scratch = torch.empty(dw.numel(), device=x.device, dtype=torch.float32)
+            scratch = _empty(dw.numel(), device=x.device, dtype=torch.float32)
             dt = _with_flags(geo.fwd, fl, t & 0xFF)
             ws = _wgrad_workspace(lib, geo, dt, t & 0xFF, (t >> 8) or splits, x.device, _stream()) if (s16 and WGRAD_SLABS) else None
             if ws is not None:
@@ -1508,12 +1545,12 @@ def prep_images(images_nchw, geo=None):
         # bf16 storage arm: the frames leave this kernel as bf16 (the same rounding the bf16 arm applies to fp32 frames
         # while it stages them) and conv1 / its weight gradient run on the bf16-storage kernels
         s16 = STORAGE == 'bf16' and DENSE_BF16 and geo.stride % 2 == 0     # odd pixel steps would misalign the K units
-        out = torch.empty((B, geo.Hp, geo.Wp, 3), device=images_nchw.device, dtype=BF16 if s16 else torch.float32)
+        out = _empty((B, geo.Hp, geo.Wp, 3), device=images_nchw.device, dtype=BF16 if s16 else torch.float32)
         fn = _lib.load().loans_prep_images_dense_bf16 if s16 else _lib.load().loans_prep_images_dense_f32
         check(fn(_ptr(images_nchw), _ptr(out), B, H, W, geo.pad, geo.Hp, geo.Wp, _stream()), 'loans_prep_images_dense')
         out.frame_hw = (H, W)
         return out
-    out = torch.empty((B, H, W, 4), device=images_nchw.device, dtype=torch.float32)
+    out = _empty((B, H, W, 4), device=images_nchw.device, dtype=torch.float32)
     check(_lib.load().loans_prep_images_f32(_ptr(images_nchw), _ptr(out), B, H, W, _stream()), 'loans_prep_images_f32')
     return out
 
@@ -1522,7 +1559,7 @@ def nchw3_to_nhwc4(x):
     B, c, H, W = x.shape
     assert c == 3
     _chk(x, 'images')
-    out = torch.empty((B, H, W, 4), device=x.device, dtype=torch.float32)
+    out = _empty((B, H, W, 4), device=x.device, dtype=torch.float32)
     check(_lib.load().loans_nchw3_to_nhwc4_f32(_ptr(x), _ptr(out), B, H, W, _stream()), 'loans_nchw3_to_nhwc4_f32')
     return out
 
@@ -1531,6 +1568,95 @@ def nchw3_to_nhwc4(x):
 # batch normalisation
 # --------------------------------------------------------------------------- #
 STATS_REPLICAS = 32      # LOANS_STATS_REPLICAS
+
+
+class _StepArena:
+    """Every tensor an op allocates inside a training step (activations, gradients, staging copies: ~700 requests per step)
+    is a slice of ONE device buffer, handed out in call order and never re-used inside the step -- 288 GB of HBM hold the SUM of
+    a step's requests (15 .. 60 GB at the bench sizes), not only their peak -- and the next step starts at offset 0 again.
+    Why not torch's caching allocator: its blocks are per stream and a block used on a side stream (the weight gradients) only
+    returns when the host has seen that stream's event; the host runs ~10 ms ahead of the GPU, so requests keep missing the cache
+    and 150 - 300 hipMalloc calls landed INSIDE the timed region of every leg, for as long as 40 steps.
+    Safety is stream order alone: all streams of a step join the main stream before its optimiser update, the next step's first
+    launch is behind that update.  Sized from the step before (the first step of a shape runs on torch's allocator and is
+    measured); a request that does not fit, a request from another thread (the feed) and everything outside begin_step ..
+    end_step falls back to ``torch.empty``.  Tensors of under 4 KiB (the reported losses, coefficient vectors) stay with torch:
+    observers read them after the step."""
+    SMALL = 4096
+    ALIGN = 256
+
+    def __init__(self):
+        self.buf, self.views, self.off, self.need, self.want, self.live, self.pinned, self.thread = None, {}, 0, 0, 0, False, [], None
+        self.misses, self.poison = 0, False
+
+    def begin(self, device):
+        capturing = torch.cuda.is_current_stream_capturing()
+        self.want = max(self.want, self.need)
+        have = self.buf.numel() if self.buf is not None else 0
+        if self.want > have and not capturing and self.want > 0:
+            size = (int(self.want * 1.06) + (64 << 20)) // 4096 * 4096
+            self.buf, self.views = None, {}
+            torch.cuda.empty_cache()            # what the sizing step left in torch's cache is this buffer's memory now
+            free, _ = torch.cuda.mem_get_info(device)
+            if size <= int(free * 0.9):
+                self.buf = torch.empty(size, device=device, dtype=torch.uint8)
+                self.views = {dt: self.buf.view(dt) for dt in (torch.float32, BF16, torch.float64, torch.uint8, torch.int32, torch.int64)}
+        if capturing and self.buf is not None and not any(b is self.buf for b in self.pinned):
+            self.pinned.append(self.buf)         # a graph captured now has this buffer's addresses baked in: it outlives the graph
+        self.off, self.need, self.live, self.thread = 0, 0, True, threading.get_ident()       # live: inside a step (sizing or serving)
+        if self.poison and self.buf is not None and not capturing:
+            self.buf.fill_(255)         # development (tools/arena_poison.py): every float of the workspace is a NaN until written
+
+    def take(self, shape, dtype):
+        n = 1
+        for d in shape:
+            n *= d
+        item = _ITEMSIZE.get(dtype)
+        if item is None:
+            return None
+        nbytes = n * item
+        if nbytes < self.SMALL:
+            return None
+        nb = (nbytes + self.ALIGN - 1) // self.ALIGN * self.ALIGN
+        self.need += nb
+        if self.buf is None or self.off + nb > self.buf.numel():
+            self.misses += 1
+            return None
+        st, acc = [0] * len(shape), 1
+        for i in range(len(shape) - 1, -1, -1):
+            st[i] = acc
+            acc *= shape[i]
+        t = self.views[dtype].as_strided(shape, st, self.off // item)
+        self.off += nb
+        return t
+
+
+_ITEMSIZE = {torch.float32: 4, torch.bfloat16: 2, torch.float64: 8, torch.uint8: 1, torch.int32: 4, torch.int64: 8}
+_step_arenas = {}
+STEP_ARENA = os.environ.get('LOANS_STEP_ARENA', '1') == '1'     # 0: every request goes to torch's caching allocator
+
+
+def _empty(shape, device, dtype):
+    """``torch.empty`` for a tensor that does not outlive the training step it is made in"""
+    a = _step_arenas.get(device.index)
+    if a is not None and a.live and a.thread == threading.get_ident():
+        t = a.take((shape,) if isinstance(shape, int) else tuple(shape), dtype)
+        if t is not None:
+            return t
+    return torch.empty(shape, device=device, dtype=dtype)
+
+
+def step_arena_state(device):
+    a = _step_arenas.get(torch.device(device).index if not isinstance(device, torch.device) else device.index)
+    if a is None:
+        return {'bytes': 0, 'used': 0, 'misses': 0}
+    return {'bytes': a.buf.numel() if a.buf is not None else 0, 'used': a.off, 'misses': a.misses}
+
+
+def _empty_like(x):
+    if not x.is_contiguous():
+        return torch.empty_like(x)
+    return _empty(x.shape, x.device, x.dtype)
 
 
 class _ZeroPool:
@@ -1650,12 +1776,12 @@ class _WeightPrep:
                 del self.repacks[k]
             self.order = [k for k in self.order if k in self.repacks]
             self.dirty = True
-        if STORAGE == 'bf16':
-            for ref in list(self.arenas):
-                arena = ref()
-                if arena is None:
-                    self.arenas.remove(ref)
-                    continue
+        for ref in list(self.arenas):
+            arena = ref()
+            if arena is None:
+                self.arenas.remove(ref)
+                continue
+            if (arena.precision or (COMPUTE, STORAGE))[1] == 'bf16':           # the model's own arm, else the process default
                 # the WHOLE arena, not the active prefix: the prefix this step will use is only set later (the localizer's
                 # __call__ looks at the frame height), so a step whose frames cross 224 / 300 px would read res6 / res7 -- or
                 # Chainer's fc6 -- from a shadow that last step's shorter cast never wrote.  36 M floats:
@@ -1767,6 +1893,8 @@ def begin_step(device):
     device = torch.device(device) if not isinstance(device, torch.device) else device
     idx = device.index if device.index is not None else torch.cuda.current_device()
     _zero_pools.setdefault(idx, _ZeroPool()).begin(torch.device('cuda', idx))
+    if STEP_ARENA:
+        _step_arenas.setdefault(idx, _StepArena()).begin(torch.device('cuda', idx))
     if WEIGHT_PREP:
         _weight_preps.setdefault(idx, _WeightPrep()).begin(torch.device('cuda', idx))
 
@@ -1775,6 +1903,8 @@ def end_step(device=None):
     """Accumulators requested after this come from `torch.zeros` again (the pool is only valid inside a step), weights are
     cast / re-packed per call again (the optimisers have moved them)."""
     for p in _zero_pools.values():
+        p.live = False
+    for p in _step_arenas.values():
         p.live = False
     for wp in _weight_preps.values():
         wp.live = False
@@ -1801,7 +1931,7 @@ class BNState:
     __slots__ = ('mean', 'rstd', 'scale', 'shift', 'count')
 
     def __init__(self, C_, device):
-        buf = torch.empty((4, C_), device=device, dtype=torch.float32)
+        buf = _empty((4, C_), device=device, dtype=torch.float32)
         self.mean, self.rstd, self.scale, self.shift = buf[0], buf[1], buf[2], buf[3]
         self.count = 0
 
@@ -1833,7 +1963,7 @@ def bn_apply(x, st, relu=True, residual=None, x2=None, st2=None, want_bits=False
     hang them on the result as ``y.relu_bits`` -- bn_backward then takes the ReLU mask from them instead of from y."""
     C_ = x.shape[-1]
     rows = x.numel() // C_
-    y = torch.empty_like(x)
+    y = _empty_like(x)
     mode = 0
     second = None
     if residual is not None:
@@ -1844,7 +1974,7 @@ def bn_apply(x, st, relu=True, residual=None, x2=None, st2=None, want_bits=False
     assert second is None or second.dtype == x.dtype
     _acct('bn_fwd', 0, _nbytes(x, second), _nbytes(y) + (rows * (C_ // 4) if (want_bits and relu) else 0))
     if want_bits and relu:
-        bits = torch.empty(rows * (C_ // 4), device=x.device, dtype=torch.uint8)
+        bits = _empty(rows * (C_ // 4), device=x.device, dtype=torch.uint8)
         fn = lib.loans_bn_apply_bits_bf16 if _is16(x) else lib.loans_bn_apply_bits_f32
         check(fn(_ptr(x), _ptr(st.scale), _ptr(st.shift), _ptr(second),
                  _ptr(st2.scale if st2 else None), _ptr(st2.shift if st2 else None),
@@ -1862,8 +1992,8 @@ def bn_relu_maxpool(x, st):
     B, H, W, C_ = x.shape
     OH, OW = conv_outsize(H, 3, 2, 0, True), conv_outsize(W, 3, 2, 0, True)
     s16 = _is16(x)
-    y = torch.empty((B, OH, OW, C_), device=x.device, dtype=x.dtype)
-    idx = torch.empty((B, OH, OW, C_), device=x.device, dtype=torch.uint8)
+    y = _empty((B, OH, OW, C_), device=x.device, dtype=x.dtype)
+    idx = _empty((B, OH, OW, C_), device=x.device, dtype=torch.uint8)
     _acct('stem', 0, _nbytes(x), _nbytes(y, idx))
     lib = _lib.load()
     fn = lib.loans_bn_relu_maxpool_bf16 if s16 else lib.loans_bn_relu_maxpool_f32
@@ -1875,7 +2005,7 @@ def bn_relu_maxpool(x, st):
 def maxpool_relu_bwd(gy, idx, x, st):
     B, H, W, C_ = x.shape
     OH, OW = gy.shape[1], gy.shape[2]
-    gx = torch.empty_like(x)
+    gx = _empty_like(x)
     lib = _lib.load()
     assert gy.dtype == x.dtype
     fn = lib.loans_maxpool_relu_bwd_bf16 if _is16(gy) else lib.loans_maxpool_relu_bwd_f32
@@ -1917,11 +2047,11 @@ def _bn_backward_rep(lib, gy, mask, x, st, gamma, ggamma, gbeta, x2, st2, gamma2
     check(red(_ptr(gy), _ptr(mten), kind, _ptr(x), _ptr(st.mean), _ptr(st.rstd), _ptr(x2), _ptr(st2.mean if dual else None),
               _ptr(st2.rstd if dual else None), _ptr(st.scale if own else None), _ptr(st.shift if own else None), _ptr(sums),
               STATS_REPLICAS, rows, C_, s), 'loans_bn_bwd_reduce_rep')
-    k = torch.empty((6 if dual else 3, C_), device=x.device, dtype=torch.float32)
+    k = _empty((6 if dual else 3, C_), device=x.device, dtype=torch.float32)
     check(lib.loans_bn_bwd_coeffs_rep_f32(_ptr(sums), STATS_REPLICAS, ns * C_, 0, C_, rows, _ptr(gamma), _ptr(st.mean),
                                           _ptr(st.rstd), _ptr(ggamma), _ptr(gbeta), _ptr(k[0]), _ptr(k[1]), _ptr(k[2]), s),
           'loans_bn_bwd_coeffs_rep_f32')
-    gx = torch.empty_like(x)
+    gx = _empty_like(x)
     if own:
         app = lib.loans_bn_bwd_apply_xmask_bf16 if s16 else lib.loans_bn_bwd_apply_xmask_f32
         check(app(_ptr(gy), _ptr(x), _ptr(st.scale), _ptr(st.shift), _ptr(k[0]), _ptr(k[1]), _ptr(k[2]), _ptr(gx), rows, C_, s),
@@ -1932,7 +2062,7 @@ def _bn_backward_rep(lib, gy, mask, x, st, gamma, ggamma, gbeta, x2, st2, gamma2
         check(lib.loans_bn_bwd_coeffs_rep_f32(_ptr(sums[0, 2]), STATS_REPLICAS, ns * C_, 0, C_, rows, _ptr(gamma2), _ptr(st2.mean),
                                               _ptr(st2.rstd), _ptr(ggamma2), _ptr(gbeta2), _ptr(k[3]), _ptr(k[4]), _ptr(k[5]), s),
               'loans_bn_bwd_coeffs_rep_f32')
-        gx2 = torch.empty_like(x2)
+        gx2 = _empty_like(x2)
     if kind == 3:
         app = lib.loans_bn_bwd_apply_bits_bf16 if s16 else lib.loans_bn_bwd_apply_bits_f32
     else:
@@ -1968,10 +2098,10 @@ def bn_backward(gy, mask, x, st, gamma, ggamma, gbeta, x2=None, st2=None, gamma2
         app_fn = lib.loans_bn_bwd_apply_xmask_bf16 if s16 else lib.loans_bn_bwd_apply_xmask_f32
         check(red_fn(_ptr(gy), _ptr(x), _ptr(st.scale), _ptr(st.shift), _ptr(st.mean), _ptr(st.rstd), _ptr(sums), rows, C_, s),
               'loans_bn_bwd_reduce_xmask')
-        k = torch.empty((3, C_), device=x.device, dtype=torch.float32)
+        k = _empty((3, C_), device=x.device, dtype=torch.float32)
         check(lib.loans_bn_bwd_coeffs_f32(_ptr(sums), C_, rows, _ptr(gamma), _ptr(st.mean), _ptr(st.rstd), _ptr(ggamma),
                                           _ptr(gbeta), _ptr(k[0]), _ptr(k[1]), _ptr(k[2]), s), 'loans_bn_bwd_coeffs_f32')
-        gx = torch.empty_like(x)
+        gx = _empty_like(x)
         check(app_fn(_ptr(gy), _ptr(x), _ptr(st.scale), _ptr(st.shift), _ptr(k[0]), _ptr(k[1]), _ptr(k[2]), _ptr(gx), rows, C_,
                      s), 'loans_bn_bwd_apply_xmask')
         return gx
@@ -1990,16 +2120,16 @@ def bn_backward(gy, mask, x, st, gamma, ggamma, gbeta, x2=None, st2=None, gamma2
     check(red_fn(_ptr(gy), _ptr(mask), _ptr(x), _ptr(st.mean), _ptr(st.rstd), _ptr(x2),
                                       _ptr(st2.mean if dual else None), _ptr(st2.rstd if dual else None),
                                       _ptr(sums), rows, C_, s), 'loans_bn_bwd_reduce_f32')
-    k = torch.empty((6 if dual else 3, C_), device=x.device, dtype=torch.float32)
+    k = _empty((6 if dual else 3, C_), device=x.device, dtype=torch.float32)
     check(lib.loans_bn_bwd_coeffs_f32(_ptr(sums), C_, rows, _ptr(gamma), _ptr(st.mean), _ptr(st.rstd), _ptr(ggamma),
                                       _ptr(gbeta), _ptr(k[0]), _ptr(k[1]), _ptr(k[2]), s), 'loans_bn_bwd_coeffs_f32')
-    gx = torch.empty_like(x)
+    gx = _empty_like(x)
     gx2 = None
     if dual:
         check(lib.loans_bn_bwd_coeffs_f32(_ptr(sums[2]), C_, rows, _ptr(gamma2), _ptr(st2.mean), _ptr(st2.rstd),
                                           _ptr(ggamma2), _ptr(gbeta2), _ptr(k[3]), _ptr(k[4]), _ptr(k[5]), s),
               'loans_bn_bwd_coeffs_f32')
-        gx2 = torch.empty_like(x2)
+        gx2 = _empty_like(x2)
     check(app_fn(_ptr(gy), _ptr(mask), _ptr(x), _ptr(k[0]), _ptr(k[1]), _ptr(k[2]), _ptr(gx),
                                      _ptr(x2), _ptr(k[3]) if dual else 0, _ptr(k[4]) if dual else 0,
                                      _ptr(k[5]) if dual else 0, _ptr(gx2), rows, C_, s), 'loans_bn_bwd_apply_f32')
@@ -2017,11 +2147,11 @@ def bn_backward_from_sums(gy, x, st, sums, gamma, ggamma, gbeta):
     s16 = _is16(x)
     _acct('bn_bwd', 0, _nbytes(gy, x), _nbytes(x))              # the sums rode in the data gradient's epilogue: one pass
     assert _is16(gy) == s16 and sums.numel() == STATS_REPLICAS * 2 * C_
-    k = torch.empty((3, C_), device=x.device, dtype=torch.float32)
+    k = _empty((3, C_), device=x.device, dtype=torch.float32)
     check(lib.loans_bn_bwd_coeffs_rep_f32(_ptr(sums), STATS_REPLICAS, 2 * C_, 1, C_, rows, _ptr(gamma), _ptr(st.mean), _ptr(st.rstd),
                                           _ptr(ggamma), _ptr(gbeta), _ptr(k[0]), _ptr(k[1]), _ptr(k[2]), s),
           'loans_bn_bwd_coeffs_rep_f32')
-    gx = torch.empty_like(x)
+    gx = _empty_like(x)
     app_fn = lib.loans_bn_bwd_apply_xmask_bf16 if s16 else lib.loans_bn_bwd_apply_xmask_f32
     check(app_fn(_ptr(gy), _ptr(x), _ptr(st.scale), _ptr(st.shift), _ptr(k[0]), _ptr(k[1]), _ptr(k[2]), _ptr(gx), rows, C_, s),
           'loans_bn_bwd_apply_xmask')
@@ -2048,7 +2178,7 @@ def pool_bn_backward(gy, idx, x, st, gamma, ggamma, gbeta, gbias=None):
     assert _is16(gy) == s16
     s = _stream()
     app_fn = lib.loans_pool_bn_bwd_apply_bf16 if s16 else lib.loans_pool_bn_bwd_apply_f32
-    k = torch.empty((3, C_), device=x.device, dtype=torch.float32)
+    k = _empty((3, C_), device=x.device, dtype=torch.float32)
     sums = _zeros_f64((STATS_REPLICAS, 2, C_), x.device)
     red_fn = lib.loans_pool_bn_bwd_reduce_rep_bf16 if s16 else lib.loans_pool_bn_bwd_reduce_rep_f32
     check(red_fn(_ptr(gy), _ptr(idx), _ptr(x), _ptr(st.scale), _ptr(st.shift), _ptr(st.mean), _ptr(st.rstd), _ptr(sums),
@@ -2056,7 +2186,7 @@ def pool_bn_backward(gy, idx, x, st, gamma, ggamma, gbeta, gbias=None):
     check(lib.loans_bn_bwd_coeffs_rep_f32(_ptr(sums), STATS_REPLICAS, 2 * C_, 0, C_, B * H * W, _ptr(gamma), _ptr(st.mean),
                                           _ptr(st.rstd), _ptr(ggamma), _ptr(gbeta), _ptr(k[0]), _ptr(k[1]), _ptr(k[2]), s),
           'loans_bn_bwd_coeffs_rep_f32')
-    gx = torch.empty_like(x)
+    gx = _empty_like(x)
     if gbias is not None and C_ // 4 <= 256 and 256 % (C_ // 4) == 0:
         # the bias-gradient sums go through 32 replicas (fp32 views of the step's zeroed accumulator pool), then one fold
         reps = _zeros_f64((STATS_REPLICAS // 2, C_), x.device).view(torch.float32).view(STATS_REPLICAS, C_)
@@ -2082,7 +2212,7 @@ def colsum_acc(x, out):
 # --------------------------------------------------------------------------- #
 def gap_fwd(x):
     B, H, W, C_ = x.shape
-    y = torch.empty((B, C_), device=x.device, dtype=torch.float32)
+    y = _empty((B, C_), device=x.device, dtype=torch.float32)
     _acct('heads', 0, _nbytes(x), _nbytes(y))
     lib = _lib.load()
     fn = lib.loans_gap_fwd_bf16_f32 if _is16(x) else lib.loans_gap_fwd_f32
@@ -2092,7 +2222,7 @@ def gap_fwd(x):
 
 def gap_bwd(gy, shape, dtype=torch.float32):
     B, H, W, C_ = shape
-    gx = torch.empty(shape, device=gy.device, dtype=dtype)
+    gx = _empty(shape, device=gy.device, dtype=dtype)
     _acct('heads', 0, _nbytes(gy), _nbytes(gx))
     lib = _lib.load()
     fn = lib.loans_gap_bwd_f32_bf16 if dtype == BF16 else lib.loans_gap_bwd_f32
@@ -2104,7 +2234,7 @@ def linear_fwd(x, W, b, act_in=False, act_out=False):
     B = x.shape[0]
     K = x.numel() // B
     N = W.numel() // K
-    y = torch.empty((B, N), device=x.device, dtype=torch.float32)
+    y = _empty((B, N), device=x.device, dtype=torch.float32)
     _acct('heads', 2 * B * K * N, _nbytes(x, W), _nbytes(y))
     lib = _lib.load()
     fn = lib.loans_linear_fwd_bf16 if _is16(x) else lib.loans_linear_fwd_f32
@@ -2116,7 +2246,7 @@ def linear_bwd(x, W, y, gy, gW=None, gb=None, need_gx=True, act_in=False, act_ou
     B = x.shape[0]
     K = x.numel() // B
     N = W.numel() // K
-    gx = torch.empty_like(x) if need_gx else None
+    gx = _empty_like(x) if need_gx else None
     _acct('heads', (4 if need_gx else 2) * B * K * N, _nbytes(x, W, gy), _nbytes(gx, gW))
     lib = _lib.load()
     fn = lib.loans_linear_bwd_bf16 if _is16(x) else lib.loans_linear_bwd_f32
@@ -2126,7 +2256,7 @@ def linear_bwd(x, W, y, gy, gW=None, gb=None, need_gx=True, act_in=False, act_ou
 
 
 def mul(x, m):
-    y = torch.empty_like(x)
+    y = _empty_like(x)
     check(_lib.load().loans_mul_f32(_ptr(x), _ptr(m), _ptr(y), x.numel(), _stream()), 'loans_mul_f32')
     return y
 
@@ -2153,7 +2283,7 @@ def channel_mean(x, cdiv=None, st=None):
     """mean over the channels of an NHWC tensor -> [B][H][W] fp32; st: apply relu(x * scale + shift) first"""
     C_ = x.shape[-1]
     rows = x.numel() // C_
-    out = torch.empty(x.shape[:-1], device=x.device, dtype=torch.float32)
+    out = _empty(x.shape[:-1], device=x.device, dtype=torch.float32)
     fn = _lib.load().loans_channel_mean_bf16 if _is16(x) else _lib.load().loans_channel_mean_f32
     check(fn(_ptr(x), _ptr(st.scale if st is not None else None), _ptr(st.shift if st is not None else None), _ptr(out), rows, C_,
              cdiv or C_, _stream()), 'loans_channel_mean')
@@ -2171,7 +2301,7 @@ def vbp_scale(feat, avg, k, s, p):
     B, fh, fw = feat.shape
     _, H, W = avg.shape
     kh, kw = H + 2 * p - s * (fh - 1), W + 2 * p - s * (fw - 1)
-    out = torch.empty_like(avg)
+    out = _empty_like(avg)
     check(_lib.load().loans_vbp_scale_f32(_ptr(feat), _ptr(avg), _ptr(out), B, fh, fw, H, W, kh, kw, s, s, p, p, _stream()),
           'loans_vbp_scale_f32')
     return out
@@ -2187,14 +2317,14 @@ def gray_fwd(rois_nhwc4):
     B, h, w, c = rois_nhwc4.shape
     assert c == 4
     _chk(rois_nhwc4, 'rois')
-    out = torch.empty((B, h, w), device=rois_nhwc4.device, dtype=torch.float32)
+    out = _empty((B, h, w), device=rois_nhwc4.device, dtype=torch.float32)
     check(_lib.load().loans_gray_fwd_f32(_ptr(rois_nhwc4), _ptr(out), B * h * w, _stream()), 'loans_gray_fwd_f32')
     return out
 
 
 def gray_bwd(g):
     _chk(g, 'gradient')
-    out = torch.empty(tuple(g.shape) + (4,), device=g.device, dtype=torch.float32)
+    out = _empty(tuple(g.shape) + (4,), device=g.device, dtype=torch.float32)
     check(_lib.load().loans_gray_bwd_f32(_ptr(g), _ptr(out), g.numel(), _stream()), 'loans_gray_bwd_f32')
     return out
 
@@ -2205,14 +2335,14 @@ def gray_bwd(g):
 def st_grid_fwd(theta, out_size):
     B = theta.shape[0]
     th, tw = out_size
-    grid = torch.empty((B, 2, th, tw), device=theta.device, dtype=torch.float32)
+    grid = _empty((B, 2, th, tw), device=theta.device, dtype=torch.float32)
     check(_lib.load().loans_st_grid_fwd_f32(_ptr(theta), _ptr(grid), B, th, tw, _stream()), 'loans_st_grid_fwd_f32')
     return grid
 
 
 def st_grid_bwd(ggrid):
     B, _, th, tw = ggrid.shape
-    gtheta = torch.empty((B, 2, 3), device=ggrid.device, dtype=torch.float32)
+    gtheta = _empty((B, 2, 3), device=ggrid.device, dtype=torch.float32)
     check(_lib.load().loans_st_grid_bwd_f32(_ptr(ggrid), _ptr(gtheta), B, th, tw, _stream()), 'loans_st_grid_bwd_f32')
     return gtheta
 
@@ -2220,7 +2350,7 @@ def st_grid_bwd(ggrid):
 def st_sampler_fwd(images_nchw, grid):
     B, _, H, W = images_nchw.shape
     th, tw = grid.shape[2:]
-    rois = torch.empty((B, th, tw, 4), device=grid.device, dtype=torch.float32)
+    rois = _empty((B, th, tw, 4), device=grid.device, dtype=torch.float32)
     _acct('crop', 0, _nbytes(grid) + 4 * 3 * 4 * B * th * tw, _nbytes(rois))        # four taps of three channels per crop pixel
     check(_lib.load().loans_st_sampler_fwd_f32(_ptr(images_nchw), _ptr(grid), _ptr(rois), B, H, W, th, tw, _stream()),
           'loans_st_sampler_fwd_f32')
@@ -2230,7 +2360,7 @@ def st_sampler_fwd(images_nchw, grid):
 def st_sampler_bwd_grid(images_nchw, grid, grois):
     B, _, H, W = images_nchw.shape
     th, tw = grid.shape[2:]
-    ggrid = torch.empty_like(grid)
+    ggrid = _empty_like(grid)
     _acct('crop', 0, _nbytes(grid, grois) + 4 * 3 * 4 * B * th * tw, _nbytes(ggrid))
     check(_lib.load().loans_st_sampler_bwd_grid_f32(_ptr(images_nchw), _ptr(grid), _ptr(grois), _ptr(ggrid), 0,
                                                     B, H, W, th, tw, _stream()), 'loans_st_sampler_bwd_grid_f32')
@@ -2241,13 +2371,13 @@ def st_sampler_bwd_grid(images_nchw, grid, grois):
 # losses / optimiser
 # --------------------------------------------------------------------------- #
 def mse_fwd(y, target=None, tconst=0.0):
-    loss = torch.empty((), device=y.device, dtype=torch.float32)
+    loss = _empty((), device=y.device, dtype=torch.float32)
     check(_lib.load().loans_mse_fwd_f32(_ptr(y), _ptr(target), tconst, _ptr(loss), y.numel(), _stream()), 'loans_mse_fwd_f32')
     return loss
 
 
 def mse_bwd(y, gloss, target=None, tconst=0.0):
-    gy = torch.empty_like(y)
+    gy = _empty_like(y)
     check(_lib.load().loans_mse_bwd_f32(_ptr(y), _ptr(target), tconst, _ptr(gloss), _ptr(gy), y.numel(), _stream()),
           'loans_mse_bwd_f32')
     return gy
@@ -2255,7 +2385,7 @@ def mse_bwd(y, gloss, target=None, tconst=0.0):
 
 def grid_loss_fwd(grid, kind, img_h=0.0, img_w=0.0, oob_scale=1.0):
     B, _, th, tw = grid.shape
-    loss = torch.empty((), device=grid.device, dtype=torch.float32)
+    loss = _empty((), device=grid.device, dtype=torch.float32)
     check(_lib.load().loans_grid_loss_fwd_f32(_ptr(grid), _ptr(loss), kind, img_h, img_w, oob_scale, B, th, tw,
                                               _stream()), 'loans_grid_loss_fwd_f32')
     return loss
@@ -2263,7 +2393,7 @@ def grid_loss_fwd(grid, kind, img_h=0.0, img_w=0.0, oob_scale=1.0):
 
 def grid_loss_bwd(grid, gloss, kind, img_h=0.0, img_w=0.0, oob_scale=1.0):
     B, _, th, tw = grid.shape
-    ggrid = torch.zeros_like(grid)
+    ggrid = _empty_like(grid).zero_()
     check(_lib.load().loans_grid_loss_bwd_f32(_ptr(grid), _ptr(gloss), _ptr(ggrid), kind, img_h, img_w, oob_scale,
                                               B, th, tw, _stream()), 'loans_grid_loss_bwd_f32')
     return ggrid

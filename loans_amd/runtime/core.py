@@ -134,7 +134,11 @@ class Variable:
             gys = tuple(None if o is None else grads.get(id(o)) for o in outs)
             if all(g is None for g in gys):
                 continue
-            gxs = f.backward(tuple(x.data for x in f.inputs), gys)
+            if f.precision != (ops.COMPUTE, ops.STORAGE):
+                with ops.precision(*f.precision):
+                    gxs = f.backward(tuple(x.data for x in f.inputs), gys)
+            else:
+                gxs = f.backward(tuple(x.data for x in f.inputs), gys)
             if not isinstance(gxs, tuple):
                 gxs = (gxs,)
             for o in outs:      # gradients of intermediate outputs are consumed
@@ -154,7 +158,7 @@ class Variable:
                     # branch's gradient, so the first accumulation goes into a buffer of this sweep's own.
                     if id(x) not in owned:
                         first = grads[id(x)]
-                        buf = torch.empty(first.shape, device=first.device, dtype=first.dtype)
+                        buf = ops._empty(first.shape, device=first.device, dtype=first.dtype)
                         buf.copy_(first)
                         grads[id(x)] = buf
                         owned.add(id(x))
@@ -183,8 +187,10 @@ class Function:
     returns ``None`` in the parameter slots of ``backward``."""
 
     def __call__(self, *inputs):
+        from .. import ops
         inputs = tuple(as_variable(x) for x in inputs)
         self.inputs = inputs
+        self.precision = (ops.COMPUTE, ops.STORAGE)       # backward runs in the arithmetic forward ran in (ops.precision)
         outs = self.forward(tuple(x.data for x in inputs))
         if not isinstance(outs, tuple):
             outs = (outs,)
@@ -208,6 +214,7 @@ class Function:
 
     rank = 0
     outputs = ()
+    precision = ('f32', 'f32')
 
     def forward(self, inputs):
         raise NotImplementedError
@@ -293,6 +300,35 @@ class Link:
         self.__dict__['name'] = None
         self.__dict__['_arena'] = None
         self.__dict__['_device'] = None
+        self.__dict__['precision'] = None
+
+    def __init_subclass__(cls, **kwargs):
+        # a link that has a precision of its own (set_precision) runs its __call__ inside that ops.precision scope
+        super().__init_subclass__(**kwargs)
+        call = cls.__dict__.get('__call__')
+        if call is not None and not getattr(call, '_scoped', False):
+            def scoped(self, *args, _call=call, **kw):
+                want = self.__dict__.get('precision')
+                if want is None:
+                    return _call(self, *args, **kw)
+                from .. import ops
+                if want == (ops.COMPUTE, ops.STORAGE):
+                    return _call(self, *args, **kw)
+                with ops.precision(*want):
+                    return _call(self, *args, **kw)
+            scoped._scoped = True
+            scoped.__doc__, scoped.__name__ = call.__doc__, '__call__'
+            cls.__call__ = scoped
+
+    def set_precision(self, compute, storage=None):
+        """The arithmetic of THIS model ('f32' | 'bf16' contractions; 'f32' | 'bf16' activations of the residual stages), for
+        every link of the tree: replaces the process-wide ops.set_compute_dtype / set_storage_dtype (which stay as the default
+        of models that never call this)."""
+        from .. import ops
+        want = ops.check_precision(compute, storage if storage is not None else ('bf16' if compute == 'bf16' else 'f32'))
+        for l in self.links():
+            l.__dict__['precision'] = want
+        return self
 
     @contextlib.contextmanager
     def init_scope(self):
@@ -495,10 +531,16 @@ class ParamArena:
             if isinstance(v, np.ndarray) and v.dtype.kind == 'f':
                 object.__setattr__(link, n, torch.from_numpy(v.astype(np.float32)).to(device))
         self.active_numel = total
+        self.root = weakref.ref(root)
         self.data16 = None          # bf16 shadow of `data`, made and refreshed by ops._WeightPrep (bf16 arm)
         if device.type == 'cuda':
             from .. import ops
             ops.register_arena(self)
+
+    @property
+    def precision(self):
+        root = self.root()
+        return root.__dict__.get('precision') if root is not None else None
 
     def set_active(self, first_unused_cold_link=None):
         """Everything from `first_unused_cold_link` on is not touched by the current graph."""

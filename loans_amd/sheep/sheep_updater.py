@@ -71,10 +71,14 @@ class SheepAssessor(training.StandardUpdater):
             real_images, labels = self.converter(batch, self.device)[:2]
             batch = next(self.get_iterator('main'))
             fake_images = self.converter(batch, self.device)
-            if self.use_graph and self._graph_legal():
-                self._graph_step(real_images, labels, fake_images)
-            else:
-                self._step(real_images, labels, fake_images)
+            # the step's own launches (the crops, the losses, begin_step's weight preparation) run in the localizer's
+            # arithmetic when it has one (Link.set_precision); the assessor's __call__ switches to its own where it differs
+            want = self.localizer.__dict__.get('precision') or ops.current_precision()
+            with ops.precision(*want):
+                if self.use_graph and self._graph_legal():
+                    self._graph_step(real_images, labels, fake_images)
+                else:
+                    self._step(real_images, labels, fake_images)
 
     def _dist_active(self):
         return self.comm is not None and getattr(self.comm, 'active', False)

@@ -474,3 +474,63 @@ def test_cfg2_conv_rows_and_bn_identities_bf16(bf16_arm):
     np.testing.assert_allclose(z.mean(dim=(0, 1, 2)).cpu().numpy(), beta.double().cpu().numpy(), atol=3e-4)
     np.testing.assert_allclose(z.var(dim=(0, 1, 2), unbiased=False).cpu().numpy(),
                                (gamma.double() ** 2 * var / (var + ops.BN_EPS)).cpu().numpy(), rtol=2e-3)
+
+
+# --------------------------------------------------------------------------------------------------------------------------
+# the dtype arm is a property of the MODEL (Link.set_precision), not of the process
+# --------------------------------------------------------------------------------------------------------------------------
+def test_fp32_and_bf16_models_step_in_one_process(monkeypatch):
+    """An fp32 and a bf16 localizer + assessor, built from the same seed, take training steps ALTERNATELY in one process; each
+    ends where the same model ends when it steps alone (same kernels, same tiles: to the scatter of the fp32 arm's atomics), the
+    bf16 model's stages hold bf16 tensors, the fp32 model's fp32, and the process default never moves."""
+    from loans_amd.sheep import resnet
+    B, H, W, crop = 4, 128, 128, (32, 32)
+    frames, real, labels = inputs(71, B, H, W, crop)
+    frames_d, real_d, labels_d = dev(frames), dev(real), dev(labels)
+
+    def make(compute):
+        loc, dis = build_pair(72, crop)
+        loc.set_precision(compute)
+        dis.set_precision(compute)
+        with loans_amd.using_config('enable_backprop', False), loans_amd.using_config('train', False):
+            dis(real_d)         # the lazy l4 draws its weights NOW, from the seeded stream: not whenever this model first steps
+        return loc, dis, _updater(loc, dis, frames_d, real_d, labels_d)
+
+    def end_state(models):
+        return [np.concatenate([m.arena.data.cpu().numpy() for m in ms[:2]]) for ms in models]
+
+    alone = []                                  # each arm alone, one after the other
+    for compute in ('f32', 'bf16'):
+        m = make(compute)
+        for _ in range(3):
+            m[2].update()
+        alone.append(m)
+    alone_state = end_state(alone)
+
+    held = {}                                   # (the stage's own precision) -> dtypes of the tensors it was handed
+    plain_call = resnet.BasicBlock.__call__
+
+    def spy(self, x):
+        held.setdefault(self.precision, set()).add((x.data if hasattr(x, 'data') else x).dtype)
+        assert ops.current_precision() == self.precision
+        return plain_call(self, x)
+    monkeypatch.setattr(resnet.BasicBlock, '__call__', spy)
+    pair = [make('f32'), make('bf16')]          # the two arms alternately
+    for it in range(3):
+        for m in pair:
+            m[2].update()
+            assert ops.current_precision() == ('f32', 'f32'), 'a step left its arithmetic behind in the process'
+    pair_state = end_state(pair)
+    assert held == {('f32', 'f32'): {torch.float32}, ('bf16', 'bf16'): {torch.bfloat16}}, held
+    errs = []
+    for compute, a, p in zip(('f32', 'bf16'), alone_state, pair_state):
+        # (not bit for bit: the fp32 arm's weight-gradient atomics and the fp64 statistics atomics add in the order blocks arrive,
+        # and Adam's sign-like step walks on that: entries whose gradient is rounding noise move +-lr per step either way)
+        d = np.abs(a - p)
+        assert float(d.max()) <= 3 * 3 * 1e-3, (compute, float(d.max()))
+        if compute == 'f32':        # (bf16: one rounding that falls the other way re-draws the sign of every small gradient behind it)
+            assert float(np.mean(d > 5e-5)) < 1e-2, (compute, float(np.mean(d > 5e-5)))
+        errs.append(float(np.linalg.norm(a - p) / np.linalg.norm(a)))
+    # the two arms are different computations: bf16 moved away from fp32 by its rounding -- not by nothing, not by much
+    gap = float(np.linalg.norm(pair_state[0] - pair_state[1]) / np.linalg.norm(pair_state[0]))
+    assert 0 < gap < 5e-2, (gap, errs)

@@ -681,3 +681,60 @@ def test_graph_captured_step_matches_eager(deterministic_forward):
             d = np.abs(got[k] - ref[k])
             assert d.max() <= 3 * steps * lr, (k, float(d.max()))
     assert rel_err(p1['feature_extractor/bn1/avg_mean'], p0['feature_extractor/bn1/avg_mean']) < 5e-2      # (running statistics of a 4-frame batch)
+
+
+@pytest.mark.parametrize("arm", ['f32', 'bf16'])
+def test_step_workspace_serves_every_request_and_changes_nothing(arm, monkeypatch, deterministic_forward):
+    """ops._StepArena ("a step that still grows torch's cache after 5 warm-ups has no fixed activation
+    workspace"): from the second step of a shape on every tensor a step allocates is a slice of one buffer -- no request is left
+    to torch's allocator, the device allocation count stands still -- and the steps compute what they compute with
+    LOANS_STEP_ARENA=0: the gradients of the first SERVED step (the second one) agree to rounding, the losses follow each other,
+    the parameters stay within Adam's walk on entries whose gradient is rounding noise."""
+    from loans_amd import ops
+    B, H, W, crop = 4, 128, 128, (32, 32)
+    frames, real, labels = inputs(81, B, H, W, crop)
+    # (a rate of 1e-9: Adam's step is sign-like, so at a real rate the entries whose gradient is rounding noise walk +-lr per step
+    # in a direction that differs between ANY two runs -- the weight gradients' atomics -- and the second step's gradients then
+    # differ by 4e-3 between two runs of the SAME configuration; tools/arena_diff.py)
+    lr, steps = 1e-9, 5
+
+    def run(arena_on):
+        monkeypatch.setattr(ops, 'STEP_ARENA', arena_on)
+        ops._step_arenas.clear()
+        loc, dis = build_pair(82, crop)
+        loc.set_precision(arm)
+        dis.set_precision(arm)
+        up = _updater(loc, dis, frames, real, labels, lr=lr)
+        grads, losses, seen = {}, [], None
+
+        def keep_gradients(opt):
+            if opt.t == 1:              # (hooks run before the step counter moves: this is the SECOND update)
+                grads[opt.target is loc] = opt.target.arena.grad.cpu().numpy().copy()
+        up.get_optimizer('opt_gen').add_hook(keep_gradients)
+        up.get_optimizer('opt_dis').add_hook(keep_gradients)
+        for it in range(steps):
+            if it == 2:
+                torch.cuda.synchronize()
+                seen = (torch.cuda.memory_stats(0)['num_device_alloc'], ops.step_arena_state(torch.device('cuda', 0))['misses'])
+            up.update()
+            obs = loans_amd.reporter.observation
+            losses.append((float(obs['loss_localizer']), float(obs['loss_dis'])))
+        torch.cuda.synchronize()
+        state = np.concatenate([m.arena.data.cpu().numpy() for m in (loc, dis)])
+        after = (torch.cuda.memory_stats(0)['num_device_alloc'], ops.step_arena_state(torch.device('cuda', 0)))
+        return state, grads, np.array(losses), seen, after
+
+    plain, g0, l0, _, _ = run(False)
+    assert not ops._step_arenas, 'LOANS_STEP_ARENA=0 made a workspace'
+    served, g1, l1, seen, after = run(True)
+    arena = after[1]
+    assert arena['bytes'] > 0 and 0 < arena['used'] <= arena['bytes']
+    assert arena['misses'] == seen[1], 'a request of steps 3 .. 5 was not served from the workspace'
+    assert after[0] == seen[0], 'steps 3 .. 5 made %d device allocations' % (after[0] - seen[0])
+    assert set(g0) == set(g1) == {True, False}
+    for which in (True, False):
+        err = float(np.linalg.norm(g1[which] - g0[which]) / np.linalg.norm(g0[which]))
+        assert err < (1e-5 if arm == 'f32' else 2e-3), (which, err)         # (bf16: one-ulp roundings that fell the other way)
+    np.testing.assert_allclose(l1[0], l0[0], rtol=1e-6)
+    np.testing.assert_allclose(l1, l0, rtol=1e-5, atol=1e-7)
+    assert float(np.abs(served - plain).max()) <= 3 * steps * lr

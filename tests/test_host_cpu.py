@@ -435,3 +435,77 @@ def test_struct_mirrors_have_the_headers_layout(tmp_path):
     assert int(got['loans_resample_job']) == RESAMPLE_JOB.itemsize
     for f in job_fields:
         assert int(got['loans_resample_job.%s' % f]) == RESAMPLE_JOB.fields[f][1], f
+
+
+# every environment switch of the product, and the test that runs its non-default arm ("<= 15 environment
+# switches, each with a test of its non-default arm").  The LOANS_*DBG* reads of csrc/ only exist in LOANS_EXPERIMENT /
+# LOANS_STAMPS builds (tools/), the LOANS_BENCH_* ones belong to bench.py's own tests (tests/test_bench_cpu.py).
+ENV_SWITCHES = {
+    'LOANS_CONCURRENT_CHAINS': 'tests/test_gpu_model.py::test_update_core_gradients_and_parameters_parity',
+    'LOANS_EARLY_CHAIN': 'tests/test_gpu_model.py::test_update_core_gradients_and_parameters_parity',
+    'LOANS_SPLITK': 'tests/test_gpu_model.py::test_split_k_autotuned_step',
+    'LOANS_TUNE_FILE': 'tests/test_host_cpu.py::test_tune_file_named_by_the_environment_is_loaded_at_import',
+    'LOANS_TUNE_POLICY': 'tests/conftest.py',
+    'LOANS_TUNE_SALT': 'tests/test_host_cpu.py::test_fixed_tile_policy_is_deterministic_and_never_times',
+    'LOANS_WGRAD_SLABS': 'tests/test_gpu_bf16_storage.py::test_weight_gradient_slabs_are_deterministic_and_equal_the_atomic_form',
+    'LOANS_STEP_ARENA': 'tests/test_gpu_model.py::test_step_workspace_serves_every_request_and_changes_nothing',
+    'LOANS_DIST_SELFTEST': 'tests/test_gpu_launch.py::test_bench_rccl_at_world_size_one',
+    'LOANS_DIST_BACKEND': 'tests/test_launch_cpu.py',
+    'LOANS_CONV_NT_MB': 'tests/test_gpu_nontemporal.py',
+    'LOANS_BN_NT': 'tests/test_gpu_nontemporal.py',
+}
+
+
+def test_environment_switches_are_few_and_each_has_a_test():
+    import glob
+    import re
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    found = set()
+    for path in glob.glob(os.path.join(root, 'loans_amd', '**', '*.py'), recursive=True) + \
+            [os.path.join(root, n) for n in ('train_sheep_localizer.py', 'evaluate.py')]:
+        found |= set(re.findall(r"environ(?:\.get\(|\[)\s*'(LOANS_[A-Z0-9_]+)'", open(path).read()))
+    for path in glob.glob(os.path.join(root, 'loans_amd', 'csrc', '*.hip')) + glob.glob(os.path.join(root, 'loans_amd', 'csrc', '*.h')):
+        guarded = 0
+        for line in open(path):
+            if re.match(r'\s*#\s*if(def)?\s.*LOANS_(EXPERIMENT|STAMPS)', line):
+                guarded += 1
+            elif guarded and re.match(r'\s*#\s*if', line):
+                guarded += 1
+            elif guarded and re.match(r'\s*#\s*endif', line):
+                guarded -= 1
+            elif not guarded:
+                found |= set(re.findall(r'getenv\("(LOANS_[A-Z0-9_]+)"\)', line))
+    assert found == set(ENV_SWITCHES), (sorted(found - set(ENV_SWITCHES)), sorted(set(ENV_SWITCHES) - found))
+    assert len(found) <= 15
+    for name, where in ENV_SWITCHES.items():
+        path, _, fn = where.partition('::')
+        text = open(os.path.join(root, path)).read()
+        assert name.replace('LOANS_', '') in text or name in text, (name, 'is not mentioned in', path)
+        if fn:
+            assert re.search(r'def %s\b' % fn, text), (fn, 'is not in', path)
+
+
+def test_tune_file_named_by_the_environment_is_loaded_at_import(tmp_path):
+    """LOANS_TUNE_FILE: a table written by ops.save_tune_table is in force from the import on"""
+    import json
+    import subprocess
+    import sys
+    from loans_amd import ops
+    geo = ops.ConvGeometry(2, 16, 16, 64, 64, 3, 1, 1)
+    path = str(tmp_path / 'tune.json')
+    old = dict(ops._TUNE_CACHE)
+    try:
+        geo.tuned['f32fprop'] = 3               # (geo.tuned IS the cache's entry of this shape)
+        ops.save_tune_table(path)
+    finally:
+        ops._TUNE_CACHE.clear()
+        ops._TUNE_CACHE.update(old)
+    assert json.load(open(path))['entries']
+    code = ("from loans_amd import ops; g = ops.ConvGeometry(2, 16, 16, 64, 64, 3, 1, 1); "
+            "print(ops._TUNE_LOADED.get(g.key, {}).get('f32fprop'))")
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    for env_value, want in ((path, '3'), ('', 'None')):
+        env = dict(os.environ, LOANS_TUNE_FILE=env_value, PYTHONPATH=root)
+        out = subprocess.run([sys.executable, '-c', code], env=env, capture_output=True, text=True, timeout=300, cwd=root)
+        assert out.returncode == 0, out.stderr[-2000:]
+        assert out.stdout.strip().splitlines()[-1] == want, (env_value, out.stdout)

@@ -4,7 +4,7 @@ the experiment build: ablation bits of the weight-stationary kernel: 1 no image 
 import os, sys
 import numpy as np
 import torch
-sys.path.insert(0, '.')
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from loans_amd import _lib, ops
 if os.environ.get('LOANS_HALO_DBG'):
     _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), 'libloans_hip_exp.so')

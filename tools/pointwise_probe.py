@@ -4,7 +4,6 @@
 import os
 import sys
 
-os.environ['LOANS_TUNE_VERBOSE'] = '1'
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch                # noqa: E402
 if os.environ.get('LOANS_EXP_LIB'):
@@ -13,6 +12,7 @@ if os.environ.get('LOANS_EXP_LIB'):
 from loans_amd import ops   # noqa: E402
 
 ops.set_compute_dtype('bf16'); ops.set_storage_dtype('bf16')
+ops.TUNE_VERBOSE = True
 B = 64
 for name, Cin, HW, Cout in [('res2 expand', 64, 128, 256), ('res2 reduce', 256, 128, 64), ('res3 expand', 128, 64, 512),
                             ('res3 reduce', 512, 64, 128), ('res4 expand', 256, 32, 1024), ('res4 reduce', 1024, 32, 256),

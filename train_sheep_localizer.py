@@ -174,7 +174,10 @@ def parse_args(argv=None):
     parser.add_argument("--record-history", action='store_true',
                         help="keep losses and theta of EVERY iteration (a host sync per iteration: parity tests only)")
     parser.add_argument("--use-graph", action='store_true', default=False,
-                        help="capture the step into a hipGraph after two eager iterations (launch-bound small batches)")
+                        help="capture the step into a hipGraph after two eager iterations.  HOST OFFLOAD ONLY: a replay costs "
+                             "1.6 - 4.8 us per node on this stack (profiles/r5_b16_graph_nodes.txt), so the captured step is 8 - 15 %% "
+                             "SLOWER than the eager one at batch 16 (6.4 vs 5.7 ms); what it saves is the host: 0.13 ms instead of "
+                             "4.4 ms of enqueue per step")
     parser.add_argument("--dtype", default='f32', choices=['f32', 'bf16'],
                         help="f32: the parity path; bf16: bf16 activations / gradients in HBM and bf16 MFMA, fp32 master "
                              "weights and gradient accumulation (not in the reference, which is fp32 only)")
@@ -249,10 +252,6 @@ def loader_threads(args, world):
 def run(args, log=print):
     """The training loop.  Returns (history, localizer, discriminator): the entries of the log intervals (every iteration with
     ``--record-history``: losses, theta of the batch -- what tests/test_gpu_trainer.py compares with the oracle's trajectory)."""
-    if args.dtype == 'bf16':
-        loans_amd.set_compute_dtype('bf16')
-        loans_amd.set_storage_dtype('bf16')
-
     comm = parallel.init_from_env()
     if comm.size > 1:
         args.gpu = int(os.environ.get('LOCAL_RANK', '0')) % torch.cuda.device_count()
@@ -272,6 +271,9 @@ def run(args, log=print):
     reference_iter = training.MultithreadIterator(reference_dataset, args.batch_size, shuffle=shuffle, **feed)
 
     localizer, discriminator = build_models(args)
+    if args.dtype == 'bf16':
+        localizer.set_precision('bf16', 'bf16')
+        discriminator.set_precision('bf16', 'bf16')
     localizer.to_gpu(args.gpu)
     discriminator.to_gpu(args.gpu)
     comm.bcast_data(localizer)
