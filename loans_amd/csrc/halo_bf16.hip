@@ -122,7 +122,7 @@ __global__ __launch_bounds__(64 * WM * WN) void halo16_kernel(const Halo16Args a
         const int qy = q / a.HW, qx = q - qy * a.HW;
         const int iy = y0 + a.dymin + qy, ix = x0 + a.dxmin + qx;
         const bool ok = pi < APIECES && qy < a.HH && (unsigned)iy < (unsigned)d.inH && (unsigned)ix < (unsigned)d.inW;
-        const int unit = (lane & 7) ^ ((q >> 1) & 7);
+        const int unit = (lane & 7) ^ ((qx >> 1) & 7);          // keyed by the image COLUMN: see read_frag
         aoff[j] = ok ? (unsigned)((b * d.inH + iy) * d.inW + ix) * (unsigned)d.Cin * 2u + (unsigned)unit * 16u : 0x80000000u;
     }
     auto dma_a = [&](int buf, int j, int cc) {
@@ -154,13 +154,21 @@ __global__ __launch_bounds__(64 * WM * WN) void halo16_kernel(const Halo16Args a
     }
     const int fkey = (r >> 1) & 7;
     const int fragB = (wn * TN * 32 + r) * BKH + ((h ^ fkey) & 7) * 8;
+    // The 16-byte unit of a pixel's 128-byte row is swizzled by the pixel's COLUMN in the halo image, (qx >> 1) & 7, not by its
+    // linear index: the 16 lanes one LDS cycle of a ds_read_b128 serves (MI355X_MICROARCH.md, LDS) are tile columns 0-3 / 12-15 of
+    // one image row and 4-11 of the next -- sixteen consecutive columns whatever the tap's shift, i.e. sixteen different
+    // (column parity, key) slots of the 256-byte LDS row.  Keyed by the linear index the second row sits HW = 18 pixels on and two
+    // of its eight lanes land on slots of the first (25-29 % of the LDS-array cycles of these kernels were bank conflicts,
+    // profiles/r5_conv_kernels_sq.txt).  (HW is even for one and three taps per row; with two the odd rows keep a 2-way overlap.)
+    const int xr = r & (TW - 1);
     auto read_frag = [&](int abuf, int bbuf, int tq, int s, bf16x8_t (&af)[TM], bf16x8_t (&bf)[TN]) {
         const __bf16* Ab = As + abuf * ABUF;
         const __bf16* Bb = Bs + bbuf * BN * BKH + (fragB ^ (s * 16));
+        const int key = (h ^ ((xr + (tq & 0xFFFF)) >> 1)) & 7;
 #pragma unroll
         for (int i = 0; i < TM; ++i) {
-            const int q = q0[i] + tq;
-            af[i] = *reinterpret_cast<const bf16x8_t*>(Ab + ((q * BKH + ((h ^ (q >> 1)) & 7) * 8) ^ (s * 16)));
+            const int q = q0[i] + (tq >> 16);
+            af[i] = *reinterpret_cast<const bf16x8_t*>(Ab + ((q * BKH + key * 8) ^ (s * 16)));
         }
 #pragma unroll
         for (int j = 0; j < TN; ++j) bf[j] = *reinterpret_cast<const bf16x8_t*>(Bb + j * 32 * BKH);
@@ -192,7 +200,7 @@ __global__ __launch_bounds__(64 * WM * WN) void halo16_kernel(const Halo16Args a
     const int ntaps = d.ntaps;
     auto tap_shift = [&](int tr, int tc) {      // halo shift of tap (tr, tc) in pixels
         const int ry = a.sdy > 0 ? tr : a.ny - 1 - tr, rx = a.sdx > 0 ? tc : a.nx - 1 - tc;
-        return ry * a.HW + rx;
+        return ((ry * a.HW + rx) << 16) | rx;       // (pixel shift, column shift)
     };
     int t = 0, tr = 0, tc = 0, cc = 0;            // current step
     int tn_ = 0, trn = 0, tcn = 0, ccn = 0;       // next step
@@ -497,7 +505,7 @@ __global__ __launch_bounds__(512, 1) void ws8_kernel(const Halo16Args a, int nti
     for (int j = 0; j < W8_APW; ++j) {
         const int q = (wave + 8 * j) * 8 + (lane >> 3);
         pqy[j] = q / a.HW;
-        pqx[j] = (q - pqy[j] * a.HW) | ((((lane & 7) ^ ((q >> 1) & 7)) * 16) << 16);          // qx | unit bytes << 16
+        pqx[j] = (q - pqy[j] * a.HW) | ((((lane & 7) ^ (((q - pqy[j] * a.HW) >> 1) & 7)) * 16) << 16);    // qx | unit bytes << 16 (keyed by the column: halo16_kernel)
         if (wave + 8 * j >= W8_APIECES || pqy[j] >= a.HH) pqy[j] = 1 << 20;                     // never inside an image
     }
     const int tiles_per_img = a.tiles_y * a.tiles_x;
@@ -562,8 +570,9 @@ __global__ __launch_bounds__(512, 1) void ws8_kernel(const Halo16Args a, int nti
         const __bf16* Ab = As + buf * W8_ABUF;
         auto frags = [&](int t, int s_, bf16x8_t& fa, bf16x8_t& f0, bf16x8_t& f1) {
             const int tr = t / 3, tc = t - tr * 3;
-            const int q = q0 + (a.sdy > 0 ? tr : 2 - tr) * a.HW + (a.sdx > 0 ? tc : 2 - tc);
-            fa = *reinterpret_cast<const bf16x8_t*>(Ab + ((q * BKH + ((h ^ (q >> 1)) & 7) * 8) ^ (s_ * 16)));
+            const int cx = a.sdx > 0 ? tc : 2 - tc;
+            const int q = q0 + (a.sdy > 0 ? tr : 2 - tr) * a.HW + cx;
+            fa = *reinterpret_cast<const bf16x8_t*>(Ab + ((q * BKH + ((h ^ (((r & 15) + cx) >> 1)) & 7) * 8) ^ (s_ * 16)));
             const __bf16* bt = Bl + t * 64 * BKH + (fragB ^ (s_ * 16));
             f0 = *reinterpret_cast<const bf16x8_t*>(bt);
             f1 = *reinterpret_cast<const bf16x8_t*>(bt + 32 * BKH);
@@ -674,8 +683,9 @@ int launch_ws8(Halo16Args& a, hipStream_t st) {
 // ws8_kernel's phases (image DMA, 72 MFMAs, statistics, staged epilogue) ADD: its eight waves work on one 16 x 16 tile and meet
 // at five barriers per tile, so nothing runs under the epilogue or under the wait for the next image (0.061 ms of skeleton +
 // 0.092 MFMA + 0.038 DMA + 0.042 epilogue per res2 convolution of configs[2]).  Here a WAVE owns its unit of work end to end --
-// 2 rows x 16 pixels of one image x all 64 output channels: it stages its own 4 x 18 pixel halo image (nine 1 KiB LDS-DMA
-// pieces into its own 9 KiB of LDS), waits on its own vmcnt, runs the same 72 MFMAs against the block's stationary weights,
+// 2 rows x 16 pixels of one image x all 64 output channels: it stages its own 4 x 18 pixel halo image (nine 1 KiB pieces
+// into its own 9 KiB of LDS; round 5: loaded into registers a whole unit ahead, see load_image), runs the same 72 MFMAs against
+// the block's stationary weights,
 // transposes the result through its own image buffer (idle by then) and stores it.  No block barrier after the weights have
 // landed: the eight waves of a CU drift apart and one wave's DMA wait and epilogue lie under the other waves' MFMAs.  The
 // price is halo: 72 staged pixels per 32 outputs instead of 324 per 256 (served by L2: the waves of a block take eight
@@ -683,6 +693,16 @@ int launch_ws8(Halo16Args& a, hipStream_t st) {
 constexpr int WSW_HW = 18, WSW_PIECES = 9, WSW_ABUF = WSW_PIECES * 8 * BKH;          // 4 x 18 = 72 halo pixels
 constexpr size_t wsw_lds_bytes() { return (size_t)W8_BELEMS * 2 + (size_t)8 * WSW_ABUF * 2; }
 
+// EPI: the launch has epilogue operands (ReLU reference / addend of a data gradient, LOANS_F_BNSUMS) -- false compiles their
+// prefetch registers and the BN coefficient state out (72 VGPRs the forward launches then have for the image in flight).
+// RS: the next image travels through registers (load_image); false: LDS-DMA, requested once the buffer is free.
+#ifndef LOANS_WSW_RS_EPI
+#define LOANS_WSW_RS_EPI 0
+#endif
+// the data-gradient launches keep the LDS-DMA image: with their epilogue operands prefetched a unit ahead the 36 image registers
+// spill (45 VGPRs) and configs[2] runs 18.84 ms against 18.11 (profiles/r5_wsw_regstage_ab.txt); -DLOANS_WSW_RS_EPI=1 builds that arm
+constexpr bool WSW_RS_EPI = LOANS_WSW_RS_EPI;
+template <bool EPI, bool RS>
 __global__ __launch_bounds__(512, 1) void wsw_kernel(const Halo16Args a, int nunits, int units_y, int units_x) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     __bf16* Bl = reinterpret_cast<__bf16*>(smem);                       // [9][64 n][64 k], rows swizzled like a B tile
@@ -707,13 +727,14 @@ __global__ __launch_bounds__(512, 1) void wsw_kernel(const Halo16Args a, int nun
     for (int j = 0; j < WSW_PIECES; ++j) {
         const int q = j * 8 + (lane >> 3);
         pqy[j] = q / WSW_HW;
-        pqx[j] = (q - pqy[j] * WSW_HW) | ((((lane & 7) ^ ((q >> 1) & 7)) * 16) << 16);            // qx | unit bytes << 16
+        pqx[j] = (q - pqy[j] * WSW_HW) | ((((lane & 7) ^ (((q - pqy[j] * WSW_HW) >> 1) & 7)) * 16) << 16);  // qx | unit bytes << 16 (keyed by the column: halo16_kernel)
     }
     const int q0 = (r >> 4) * WSW_HW + (r & 15);                        // this lane's output pixel inside the halo image
     const int fragB = r * BKH + ((h ^ ((r >> 1) & 7)) & 7) * 8;
     const bool f_bias = d.flags & LOANS_F_BIAS, f_stats = d.flags & LOANS_F_STATS;
-    const bool f_mask = d.flags & LOANS_F_MASK, f_add = d.flags & LOANS_F_ADDEND, f_addmask = d.flags & LOANS_F_ADDEND_MASK;
-    const bool f_bnsums = d.flags & LOANS_F_BNSUMS;            // see igemm16_kernel
+    const bool f_mask = EPI && (d.flags & LOANS_F_MASK), f_add = EPI && (d.flags & LOANS_F_ADDEND);
+    const bool f_addmask = EPI && (d.flags & LOANS_F_ADDEND_MASK);
+    const bool f_bnsums = EPI && (d.flags & LOANS_F_BNSUMS);            // see igemm16_kernel
     const float bv0 = (f_bias && r < d.Cout) ? a.bias[r] : 0.f, bv1 = (f_bias && r + 32 < d.Cout) ? a.bias[r + 32] : 0.f;
     double st_s0 = 0.0, st_q0 = 0.0, st_s1 = 0.0, st_q1 = 0.0;
     const __amdgpu_buffer_rsrc_t rs_out = __builtin_amdgcn_make_buffer_rsrc(a.out, 0, (int)a.out_bytes, 0x00020000);
@@ -758,8 +779,34 @@ __global__ __launch_bounds__(512, 1) void wsw_kernel(const Halo16Args a, int nun
         nw = gridDim.x * 4;
     }
     const int per_img = units_y * units_x;
-    auto issue_image = [&](int u) {     // unit u's halo image into this wave's buffer
-        if (HDBG(1)) return;
+    // The NEXT unit's halo image travels through registers: its nine 16-byte loads per lane are issued at the top of a unit,
+    // fly under that unit's 72 MFMAs and its epilogue, and are written to the wave's image buffer (ds_write_b128, the layout an
+    // LDS-DMA piece would have left) once the buffer -- image, then staging slab of the current unit -- has been read out.
+    // As LDS-DMA the image could only be requested at that point, one epilogue ahead of its use: the waves were parked on
+    // s_waitcnt for 55 % of their cycles (profiles/r5_conv_kernels_sq.txt) and there is no LDS for a second image per wave
+    // (72 KiB of weights + 8 x 9 KiB).  36 VGPRs carry what LDS could not.
+    u32x4 img[WSW_PIECES];
+    auto load_image = [&](int u) {      // unit u's halo image into registers (out-of-image pixels: out-of-range offsets, zeros)
+        const int b = u / per_img, uu = u - b * per_img;
+        const int uy = uu / units_x, ux = uu - uy * units_x;
+        const int iy0 = 2 * uy + a.dymin, ix0 = 16 * ux + a.dxmin, base = b * d.inH;
+#pragma unroll
+        for (int j = 0; j < WSW_PIECES; ++j) {
+            const int iy = iy0 + pqy[j], ix = ix0 + (pqx[j] & 0xFFFF);
+            const bool ok = (unsigned)iy < (unsigned)d.inH && (unsigned)ix < (unsigned)d.inW;
+            const unsigned off = ok ? (unsigned)((base + iy) * d.inW + ix) * 128u + ((unsigned)pqx[j] >> 16) : 0x80000000u;
+            img[j] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rs_in, (int)off, 0, 0));
+        }
+    };
+    auto write_image = [&]() {          // ... and from there into this wave's buffer: piece j, lane l at byte 1024 j + 16 l
+#pragma unroll
+        for (int j = 0; j < WSW_PIECES; ++j)
+            *reinterpret_cast<u32x4*>(reinterpret_cast<char*>(Aw) + j * 1024 + lane * 16) = img[j];
+    };
+    // The next unit's image is requested as soon as this unit's staging slab (the same LDS) has been read out -- BEFORE this
+    // unit's output stores: at the top of the loop the wave then waits for its nine DMA pieces only, with a counted vmcnt that
+    // leaves the four younger stores in flight (vector memory operations retire in order).
+    auto dma_image = [&](int u) {       // RS = false: unit u's halo image by LDS-DMA into this wave's buffer
         const int b = u / per_img, uu = u - b * per_img;
         const int uy = uu / units_x, ux = uu - uy * units_x;
         const int iy0 = 2 * uy + a.dymin, ix0 = 16 * ux + a.dxmin, base = b * d.inH;
@@ -771,17 +818,23 @@ __global__ __launch_bounds__(512, 1) void wsw_kernel(const Halo16Args a, int nun
             __builtin_amdgcn_raw_ptr_buffer_load_lds(rs_in, (lds_ptr_t)(Aw + j * 8 * BKH), 16, (int)off, 0, 0, 0);
         }
     };
-    // The next unit's image is requested as soon as this unit's staging slab (the same LDS) has been read out -- BEFORE this
-    // unit's output stores: at the top of the loop the wave then waits for its nine DMA pieces only, with a counted vmcnt that
-    // leaves the four younger stores in flight (vector memory operations retire in order).
-    if (gw < nunits) issue_image(gw);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (gw < nunits) {
+        if constexpr (RS) { load_image(gw); write_image(); }
+        else { dma_image(gw); asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+    }
     for (int u = gw; u < nunits; u += nw) {
         const int b = u / per_img, uu = u - b * per_img;
         const int uy = uu / units_x, ux = uu - uy * units_x;
         const int y0 = 2 * uy, x0 = 16 * ux;
-        if (u != gw) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
+        if constexpr (RS) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");      // the image written below (or above, the first one) is in LDS
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        } else {
+            // the wave waits for its nine DMA pieces only: a counted vmcnt leaves the four younger stores in flight
+            if (u != gw) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+        }
         // The epilogue's operands (ReLU reference / addend of a data gradient, the BN input of LOANS_F_BNSUMS) are requested HERE,
         // a unit's worth of MFMAs ahead of their use and -- the point -- BEFORE the next unit's image: vector memory operations
         // retire in order, so a load issued behind that DMA made the epilogue wait for the whole image to land (+83 us on a
@@ -795,15 +848,19 @@ __global__ __launch_bounds__(512, 1) void wsw_kernel(const Halo16Args a, int nun
             const bool pok = y < d.outH && x < d.outW;
             eoff[it] = pok ? ((unsigned)((b * d.outH + y) * d.outW + x) * (unsigned)d.Cout * 2u + (unsigned)oc8 * 16u) | cbad : 0xFFFFFFFFu;
         }
-        if (f_mask || f_addmask || f_bnsums) {
+        if (EPI && (f_mask || f_addmask || f_bnsums)) {
 #pragma unroll
             for (int it = 0; it < 4; ++it)
                 e_ref[it] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_ref, (int)eoff[it], 0, 0));
         }
-        if (f_add) {
+        if (EPI && f_add) {
 #pragma unroll
             for (int it = 0; it < 4; ++it)
                 e_add[it] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_add, (int)eoff[it], 0, 0));
+        }
+        const bool more = u + nw < nunits;
+        if constexpr (RS) {
+            if (more && !HDBG(1)) load_image(u + nw);   // behind the epilogue operands (in-order returns): they are needed first
         }
         asm volatile("" ::: "memory");
         f32x16 acc0, acc1;
@@ -811,8 +868,9 @@ __global__ __launch_bounds__(512, 1) void wsw_kernel(const Halo16Args a, int nun
         for (int e = 0; e < 16; ++e) { acc0[e] = 0.f; acc1[e] = 0.f; }
         auto frags = [&](int t, int s_, bf16x8_t& fa, bf16x8_t& f0, bf16x8_t& f1) {
             const int tr = t / 3, tc = t - tr * 3;
-            const int q = q0 + (a.sdy > 0 ? tr : 2 - tr) * WSW_HW + (a.sdx > 0 ? tc : 2 - tc);
-            fa = *reinterpret_cast<const bf16x8_t*>(Aw + ((q * BKH + ((h ^ (q >> 1)) & 7) * 8) ^ (s_ * 16)));
+            const int cx = a.sdx > 0 ? tc : 2 - tc;
+            const int q = q0 + (a.sdy > 0 ? tr : 2 - tr) * WSW_HW + cx;
+            fa = *reinterpret_cast<const bf16x8_t*>(Aw + ((q * BKH + ((h ^ (((r & 15) + cx) >> 1)) & 7) * 8) ^ (s_ * 16)));
             const __bf16* bt = Bl + t * 64 * BKH + (fragB ^ (s_ * 16));
             f0 = *reinterpret_cast<const bf16x8_t*>(bt);
             f1 = *reinterpret_cast<const bf16x8_t*>(bt + 32 * BKH);
@@ -876,12 +934,19 @@ __global__ __launch_bounds__(512, 1) void wsw_kernel(const Halo16Args a, int nun
             lo[it] = *reinterpret_cast<const f32x4*>(Cs + px * LDC + oc8 * 8) + b_lo;
             hi[it] = *reinterpret_cast<const f32x4*>(Cs + px * LDC + oc8 * 8 + 4) + b_hi;
         }
-        // the slab has been read out: the next unit's image may land in it
-        asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-        __builtin_amdgcn_wave_barrier();
-        if (u + nw < nunits) issue_image(u + nw);
-        asm volatile("" ::: "memory");          // the stores below stay behind the DMA: the counted wait relies on it
-        __builtin_amdgcn_sched_barrier(0);
+        // the slab has been read out (this wave's LDS operations execute in order): the next unit's image goes into it
+        if constexpr (RS) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+            if (more) write_image();
+        } else {
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_wave_barrier();
+            if (more && !HDBG(1)) dma_image(u + nw);
+            asm volatile("" ::: "memory");          // the stores below stay behind the DMA: the counted wait relies on it
+            __builtin_amdgcn_sched_barrier(0);
+        }
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const unsigned off = eoff[it];
@@ -948,7 +1013,10 @@ int launch_wsw(Halo16Args& a, hipStream_t st) {
     constexpr size_t lds = wsw_lds_bytes();
     static_assert(lds <= 160 * 1024, "one block per CU");
     static_assert((size_t)32 * (64 + 4) * 4 <= (size_t)WSW_ABUF * 2, "the staging slab fits the wave's image buffer");
-    if (int rc_ = loans_raise_lds_limit(lds_limit_set, reinterpret_cast<const void*>(wsw_kernel), lds)) return rc_;
+    const bool epi = a.d.flags & (LOANS_F_MASK | LOANS_F_ADDEND | LOANS_F_ADDEND_MASK | LOANS_F_BNSUMS);
+    const void* fn = epi ? reinterpret_cast<const void*>(wsw_kernel<true, WSW_RS_EPI>) : reinterpret_cast<const void*>(wsw_kernel<false, true>);
+    static loans_device_once lds_limit_set2;
+    if (int rc_ = loans_raise_lds_limit(epi ? lds_limit_set : lds_limit_set2, fn, lds)) return rc_;
     const int units_y = (a.d.outH + 1) / 2, units_x = (a.d.outW + 15) / 16;
     const int64_t nunits = (int64_t)a.d.B * units_y * units_x;
     if (nunits >= ((int64_t)1 << 31)) return LOANS_ERANGE;
@@ -956,7 +1024,8 @@ int launch_wsw(Halo16Args& a, hipStream_t st) {
     if (cus <= 0) return LOANS_EINVAL;
     const int64_t blocks_needed = (nunits + 7) / 8;
     const int64_t grid = blocks_needed < cus ? blocks_needed : cus;
-    hipLaunchKernelGGL(wsw_kernel, dim3((unsigned)grid), dim3(512), lds, st, a, (int)nunits, units_y, units_x);
+    if (epi) hipLaunchKernelGGL((wsw_kernel<true, WSW_RS_EPI>), dim3((unsigned)grid), dim3(512), lds, st, a, (int)nunits, units_y, units_x);
+    else hipLaunchKernelGGL((wsw_kernel<false, true>), dim3((unsigned)grid), dim3(512), lds, st, a, (int)nunits, units_y, units_x);
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;
 }

@@ -8,6 +8,8 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from loans_amd import _lib, ops
 if os.environ.get('LOANS_HALO_DBG'):
     _lib.LIB_PATH = os.path.join(os.path.dirname(_lib.LIB_PATH), 'libloans_hip_exp.so')
+if os.environ.get('HALO_BENCH_LIB'):            # (this tool's own variable: another build of the library, for A/B runs)
+    _lib.LIB_PATH = os.path.abspath(os.environ['HALO_BENCH_LIB'])
 B, H, W, Cin, Cout = (int(v) for v in sys.argv[1:6])
 tiles = [int(t) for t in sys.argv[6].split(',')]
 ops.set_compute_dtype('bf16'); ops.set_storage_dtype('bf16')

@@ -28,6 +28,6 @@ if tot.get('GRBM_GUI_ACTIVE'):
     if tot.get('SQ_VALU_MFMA_BUSY_CYCLES'):
         print('MFMA pipe busy: %.1f %% of SIMD-cycles' % (100 * tot['SQ_VALU_MFMA_BUSY_CYCLES'] / (cycles * 1024)))
     if tot.get('SQ_LDS_IDX_ACTIVE'):
-        # SQ counters of this family count quad-cycles (MI355X_MICROARCH.md): x 4 against GRBM cycles x 256 CUs
-        print('LDS array busy: %.1f %% of CU-cycles (SQ_LDS_IDX_ACTIVE x 4 / (cycles x 256)); conflict cycles %.1f %% of those'
-              % (100 * 4 * tot['SQ_LDS_IDX_ACTIVE'] / (cycles * 256), 100 * tot.get('SQ_LDS_BANK_CONFLICT', 0) / tot['SQ_LDS_IDX_ACTIVE']))
+        # (in cycles: x 1 reproduces the byte counts of the kernels' fragment reads at ds_read_b128's 4 cycles per KiB)
+        print('LDS array busy: %.1f %% of CU-cycles (SQ_LDS_IDX_ACTIVE / (cycles x 256)); bank-conflict cycles %.1f %% of those'
+              % (100 * tot['SQ_LDS_IDX_ACTIVE'] / (cycles * 256), 100 * tot.get('SQ_LDS_BANK_CONFLICT', 0) / tot['SQ_LDS_IDX_ACTIVE']))
