@@ -883,10 +883,14 @@ __global__ __launch_bounds__(512, 1) void wsw_kernel(const Halo16Args a, int nun
 #pragma unroll
         for (int st = 0; st < 36; ++st) {
             if (st + 2 < 36 && !HDBG(4)) frags((st + 2) >> 2, (st + 2) & 3, fa[(st + 2) % 3], f0[(st + 2) % 3], f1[(st + 2) % 3]);
+            // (pinned: left to itself the scheduler sinks every fragment read to one MFMA before its use -- s_waitcnt lgkmcnt(0 / 1)
+            // in front of nearly every MFMA, the wave parked for the LDS latency 36 times per unit)
+            __builtin_amdgcn_sched_barrier(0);
             if (!HDBG(2)) {
                 acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st % 3], f0[st % 3], acc0, 0, 0, 0);
                 acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[st % 3], f1[st % 3], acc1, 0, 0, 0);
             }
+            __builtin_amdgcn_sched_barrier(0);
         }
         if (f_stats) {
             float s0 = 0.f, q20 = 0.f, s1 = 0.f, q21 = 0.f;
