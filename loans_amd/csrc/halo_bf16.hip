@@ -270,6 +270,8 @@ __global__ __launch_bounds__(64 * WM * WN) void halo16_kernel(const Halo16Args a
         mma(fa0, fb0);
         __builtin_amdgcn_sched_barrier(0);
         relu_frag(fa1);
+        // (round 5: the same barrier WITHOUT its vmcnt wait -- wrong results, the bound of what a deeper weight ring could buy -- runs
+        // the res3 layers in the same 0.205 ms: the step's DMA is not what the waves wait for, profiles/r5_halo_kernels_ab.txt)
         __syncthreads();                        // the next step's weights (and, at a chunk's end, the next image) have landed
         t = tn_; tr = trn; tc = tcn; cc = ccn;
         next_of(tn_, trn, tcn, ccn);

@@ -178,7 +178,8 @@ __global__ __launch_bounds__(64 * NWV, NWV == 4 ? 2 : 1) void wgrad_halo16_kerne
         if constexpr (WGH_DBG & 8) continue;
         // (Tried in round 5 and dropped: the fragments of halo row rr + 1 read while row rr multiplies -- two register sets, the
         // order pinned with sched_barrier -- and with it the next tile's global loads pinned in front of the MFMAs: res2 0.181 ->
-        // 0.185 ms, res3 0.140 -> 0.148, res4 0.131 -> 0.138.  The scheduler's own order interleaves the eight transposing reads
+        // 0.185 ms, res3 0.140 -> 0.148, res4 0.131 -> 0.138; the loads alone pinned there (the scheduler sinks them to the end of
+        // the MFMAs): +1-2 %.  The scheduler's own order interleaves the eight transposing reads
         // with the previous row's MFMAs; a burst of reads in front of nine MFMAs is worse.)
         bf16x8_t ay[3];                     // gradient fragments of output rows rr, rr - 1, rr - 2 (slot = row % 3)
 #pragma unroll
