@@ -1449,6 +1449,11 @@ def _wghalo_candidates(geo):
 # stream), grown to the largest request: launches on one stream run one after the other and may share it.
 # LOANS_WGRAD_SLABS=0: fp32 atomics into the arena again (the order of the sums then changes from run to run).
 WGRAD_SLABS = os.environ.get('LOANS_WGRAD_SLABS', '1') != '0'
+# The tuned number of pixel slices of a bf16 weight gradient x this.  The tile tables are timed with the launch ALONE on the
+# device, where one or two full rounds of block slots win; in the step the weight gradients run beside the main stream, and
+# three quarters of that leave compute units to its kernels: configs[2] 18.975 -> 18.830 ms, ResNet-50 29.574 -> 29.491
+# (0.5: 18.94 / 29.43; profiles/r5_wgrad_split_scale_ab.txt, tools/ab_wgrad_scale.py)
+WGRAD_SPLIT_SCALE = 0.75
 _wgrad_ws = {}
 
 
@@ -1514,6 +1519,8 @@ def _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile, stream=None):
         geo.tuned[vkey] = tile
     if tile >> 8:
         tile, splits = tile & 0xFF, tile >> 8
+        if WGRAD_SPLIT_SCALE != 1.0 and s16:
+            splits = max(1, int(splits * WGRAD_SPLIT_SCALE))
     d = _with_flags(geo.fwd, fl, tile)
     st = stream if stream is not None else _stream()
     ws = _wgrad_workspace(lib, geo, d, tile, splits, x.device, st) if (s16 and WGRAD_SLABS) else None
@@ -1587,20 +1594,27 @@ class _StepArena:
 
     def __init__(self):
         self.buf, self.views, self.off, self.need, self.want, self.live, self.pinned, self.thread = None, {}, 0, 0, 0, False, [], None
-        self.misses, self.poison = 0, False
+        self.misses, self.poison, self.picks, self.tried = 0, False, -1, -1
 
     def begin(self, device):
         capturing = torch.cuda.is_current_stream_capturing()
-        self.want = max(self.want, self.need)
+        # what the step that just ended asked for is a step's demand -- unless it timed tile candidates (every candidate of every
+        # shape allocates its own outputs: 195 GB in a tuning step of configs[2]), which says nothing about the steps to come
+        if self.need > 0 and self.picks == TIMED_PICKS:
+            self.want = max(self.want, self.need)
+        self.picks = TIMED_PICKS
         have = self.buf.numel() if self.buf is not None else 0
-        if self.want > have and not capturing and self.want > 0:
+        if self.want > have and self.want != self.tried and not capturing:
+            self.tried = self.want                  # one attempt per demand: a buffer that does not fit is not asked for every step
             size = (int(self.want * 1.06) + (64 << 20)) // 4096 * 4096
-            self.buf, self.views = None, {}
-            torch.cuda.empty_cache()            # what the sizing step left in torch's cache is this buffer's memory now
-            free, _ = torch.cuda.mem_get_info(device)
-            if size <= int(free * 0.9):
-                self.buf = torch.empty(size, device=device, dtype=torch.uint8)
-                self.views = {dt: self.buf.view(dt) for dt in (torch.float32, BF16, torch.float64, torch.uint8, torch.int32, torch.int64)}
+            total = torch.cuda.get_device_properties(device).total_memory
+            if size <= total // 2:                  # (more than half the device for one step's tensors: leave it to torch's allocator)
+                self.buf, self.views = None, {}
+                torch.cuda.empty_cache()            # what the sizing step left in torch's cache is this buffer's memory now
+                free, _ = torch.cuda.mem_get_info(device)
+                if size <= int(free * 0.9):
+                    self.buf = torch.empty(size, device=device, dtype=torch.uint8)
+                    self.views = {dt: self.buf.view(dt) for dt in (torch.float32, BF16, torch.float64, torch.uint8, torch.int32, torch.int64)}
         if capturing and self.buf is not None and not any(b is self.buf for b in self.pinned):
             self.pinned.append(self.buf)         # a graph captured now has this buffer's addresses baked in: it outlives the graph
         self.off, self.need, self.live, self.thread = 0, 0, True, threading.get_ident()       # live: inside a step (sizing or serving)

@@ -728,7 +728,7 @@ def test_step_workspace_serves_every_request_and_changes_nothing(arm, monkeypatc
     assert not ops._step_arenas, 'LOANS_STEP_ARENA=0 made a workspace'
     served, g1, l1, seen, after = run(True)
     arena = after[1]
-    assert arena['bytes'] > 0 and 0 < arena['used'] <= arena['bytes']
+    assert arena['bytes'] > 0 and 0 < arena['used'] <= arena['bytes'] < 2 * arena['used'] + (128 << 20)
     assert arena['misses'] == seen[1], 'a request of steps 3 .. 5 was not served from the workspace'
     assert after[0] == seen[0], 'steps 3 .. 5 made %d device allocations' % (after[0] - seen[0])
     assert set(g0) == set(g1) == {True, False}
@@ -738,3 +738,29 @@ def test_step_workspace_serves_every_request_and_changes_nothing(arm, monkeypatc
     np.testing.assert_allclose(l1[0], l0[0], rtol=1e-6)
     np.testing.assert_allclose(l1, l0, rtol=1e-5, atol=1e-7)
     assert float(np.abs(served - plain).max()) <= 3 * steps * lr
+
+
+def test_step_workspace_is_not_sized_by_a_tuning_step(timed_autotune):
+    """A step that TIMES tile candidates allocates every candidate's outputs (195 GB at configs[2], which then was the size of
+    the workspace; at ResNet-50 it did not fit, and the fallback emptied torch's cache at every step: 201 ms per step instead of
+    29 -- found by tools/profile_round.sh in round 5).  Such a step's demand is ignored; the workspace is sized by a clean step."""
+    from loans_amd import ops
+    B, H, W, crop = 3, 80, 112, (24, 24)          # shapes no other test of the session has tuned
+    frames, real, labels = inputs(91, B, H, W, crop)
+    ops._step_arenas.clear()
+    loc, dis = build_pair(92, crop)
+    up = _updater(loc, dis, frames, real, labels)
+    picks = ops.TIMED_PICKS
+    up.update()
+    assert ops.TIMED_PICKS > picks, 'the first step of new shapes times its tiles under this fixture'
+    dev0 = torch.device('cuda', 0)
+    for _ in range(3):
+        up.update()
+    arena = ops.step_arena_state(dev0)
+    assert 0 < arena['used'] <= arena['bytes'] < 2 * arena['used'] + (128 << 20), arena
+    before = (torch.cuda.memory_stats(0)['num_device_alloc'], arena['misses'])
+    for _ in range(2):
+        up.update()
+    torch.cuda.synchronize()
+    after = ops.step_arena_state(dev0)
+    assert (torch.cuda.memory_stats(0)['num_device_alloc'], after['misses']) == before
