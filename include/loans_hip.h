@@ -350,6 +350,14 @@ int loans_bn_apply_f32(const float* x, const float* scale, const float* shift,
  * (sheep/resnet.py:72-73). */
 int loans_bn_relu_maxpool_f32(const float* x, const float* scale, const float* shift, float* y, uint8_t* idx,
                               int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream);
+/* (round 5) the same, and xsel[pooled element] = the RAW x at its argmax ([B][OH][OW][C], the type of x): the sums of the stem's
+ * BN backward are then loans_bn_bwd_reduce_rep_* (mask kind 2) over (gy, xsel) -- two contiguous pooled-size tensors -- instead of
+ * loans_pool_bn_bwd_reduce_*'s gather out of the four times larger x through idx (BackwardData of F.max_pooling_2d +
+ * F.batch_normalization, sheep/resnet.py:72-73).  LOANS_EINVAL for channel counts the 16-byte-unit kernel does not tile. */
+int loans_bn_relu_maxpool_sel_f32(const float* x, const float* scale, const float* shift, float* y, uint8_t* idx, float* xsel,
+                                  int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream);
+int loans_bn_relu_maxpool_sel_bf16(const void* x, const float* scale, const float* shift, void* y, uint8_t* idx, void* xsel,
+                                   int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream);
 /* gx = (sum over windows whose argmax is this pixel of gy) * (x*scale+shift > 0) */
 int loans_maxpool_relu_bwd_f32(const float* gy, const uint8_t* idx, const float* x, const float* scale,
                                const float* shift, float* gx,

@@ -126,6 +126,8 @@ SIGNATURES = {
     'loans_bn_eval_coeffs_f32': [_i32, _f32, _p, _p, _p, _p, _p, _p, _p, _p, _p],
     'loans_bn_apply_f32': [_p, _p, _p, _p, _p, _p, _p, _i64, _i32, _i32, _i32, _p],
     'loans_bn_relu_maxpool_f32': [_p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p],
+    'loans_bn_relu_maxpool_sel_f32': [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p],
+    'loans_bn_relu_maxpool_sel_bf16': [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p],
     'loans_maxpool_relu_bwd_f32': [_p, _p, _p, _p, _p, _p, _i32, _i32, _i32, _i32, _i32, _i32, _p],
     'loans_bn_bwd_reduce_f32': [_p, _p, _p, _p, _p, _p, _p, _p, _p, _i64, _i32, _p],
     'loans_bn_bwd_coeffs_f32': [_p, _i32, _i64, _p, _p, _p, _p, _p, _p, _p, _p, _p],

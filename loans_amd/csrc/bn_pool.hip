@@ -825,9 +825,11 @@ template <int NV> __device__ __forceinline__ void st_idx(uint8_t* p, const int* 
     }
 }
 
-template <typename T>
+// SEL: also writes xsel = the RAW x at each pooled element's argmax (the tensor the stem's BN-backward sums then read
+// contiguously instead of gathering it out of the four times larger x through idx: loans_bn_relu_maxpool_sel_*)
+template <typename T, bool SEL>
 __global__ __launch_bounds__(256) void bn_relu_maxpool_u16_kernel(const T* x, const float* scale, const float* shift, T* y,
-                                                                  uint8_t* idx, int B, int H, int W, int U, int OH, int OW) {
+                                                                  uint8_t* idx, T* xsel, int B, int H, int W, int U, int OH, int OW) {
     constexpr int V = unit16<T>::V, NV = unit16<T>::NV;
     const int cu = threadIdx.x % U, pl = threadIdx.x / U, PL = 256 / U;      // PL output pixels of a row per block pass
     f32x4 s[NV], t[NV];
@@ -836,10 +838,10 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_u16_kernel(const T* x, co
     for (int row = blockIdx.y; row < B * OH; row += gridDim.y) {
         const int b = row / OH, oh = row - b * OH;
         for (int ow = blockIdx.x * PL + pl; ow < OW; ow += gridDim.x * PL) {
-            f32x4 best[NV];
+            f32x4 best[NV], bestx[NV];
             int arg[V];
 #pragma unroll
-            for (int q = 0; q < NV; ++q) best[q] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY};
+            for (int q = 0; q < NV; ++q) { best[q] = f32x4{-INFINITY, -INFINITY, -INFINITY, -INFINITY}; bestx[q] = f32x4{0.f, 0.f, 0.f, 0.f}; }
 #pragma unroll
             for (int e = 0; e < V; ++e) arg[e] = 0;
             // the nine window loads first (clamped addresses; a load behind each bounds test is a memory latency of its own)
@@ -861,16 +863,21 @@ __global__ __launch_bounds__(256) void bn_relu_maxpool_u16_kernel(const T* x, co
                     unit16<T>::cvt(raw[r][c], v);
 #pragma unroll
                     for (int q = 0; q < NV; ++q) {
+                        const f32x4 raw_v = v[q];
                         v[q] = relu4(v[q] * s[q] + t[q]);
 #pragma unroll
                         for (int e = 0; e < 4; ++e)
-                            if (v[q][e] > best[q][e]) { best[q][e] = v[q][e]; arg[4 * q + e] = r * 3 + c; }
+                            if (v[q][e] > best[q][e]) {
+                                best[q][e] = v[q][e]; arg[4 * q + e] = r * 3 + c;
+                                if (SEL) bestx[q][e] = raw_v[e];
+                            }
                     }
                 }
             }
             const int64_t o = (((int64_t)row * OW + ow) * U + cu) * V;
             unit16<T>::st(y + o, best);
             st_idx<NV>(idx + o, arg);
+            if (SEL) unit16<T>::st(xsel + o, bestx);
         }
     }
 }
@@ -1093,18 +1100,25 @@ extern "C" int loans_bn_apply_bf16(const void* x, const float* scale, const floa
 
 template <typename TO>
 static int bn_relu_maxpool_impl(const TO* x, const float* scale, const float* shift, TO* y, uint8_t* idx,
-                                int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream) {
+                                int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream, TO* xsel = nullptr,
+                                bool want_sel = false) {
     if (!x || !scale || !shift || !y || !idx || B <= 0 || H < 3 || W < 3 || C <= 0 || (C & 3)) return LOANS_EINVAL;
+    if (want_sel && !xsel) return LOANS_EINVAL;
     if (OH != (H - 2) / 2 + 1 || OW != (W - 2) / 2 + 1) return LOANS_EINVAL;   // cover_all out size, k=3 s=2 p=0
     if ((int64_t)B * H >= ((int64_t)1 << 31) || (int64_t)W * (C / 4) >= ((int64_t)1 << 31)) return LOANS_ERANGE;
     if (const int U = units_per_row<TO>(C)) {
         const int PL = 256 / U;
         const dim3 g16((OW + PL - 1) / PL, (unsigned)min((int64_t)B * OH, (int64_t)65535));
-        hipLaunchKernelGGL(bn_relu_maxpool_u16_kernel<TO>, g16, dim3(256), 0, as_stream(stream), x, scale, shift, y, idx, B, H, W, U,
-                           OH, OW);
+        if (want_sel)
+            hipLaunchKernelGGL((bn_relu_maxpool_u16_kernel<TO, true>), g16, dim3(256), 0, as_stream(stream), x, scale, shift, y, idx,
+                               xsel, B, H, W, U, OH, OW);
+        else
+            hipLaunchKernelGGL((bn_relu_maxpool_u16_kernel<TO, false>), g16, dim3(256), 0, as_stream(stream), x, scale, shift, y, idx,
+                               xsel, B, H, W, U, OH, OW);
         LOANS_LAUNCH_CHECK();
         return LOANS_OK;
     }
+    if (want_sel) return LOANS_EINVAL;          // (channel counts the 16-byte-unit kernel does not tile: the caller keeps the gather)
     const dim3 grid((OW * (C / 4) + 255) / 256, (unsigned)min((int64_t)B * OH, (int64_t)65535));
     hipLaunchKernelGGL(bn_relu_maxpool_kernel<TO>, grid, dim3(256), 0, as_stream(stream), x, scale,
                        shift, y, idx, B, H, W, C / 4, OH, OW);
@@ -1120,6 +1134,17 @@ extern "C" int loans_bn_relu_maxpool_f32(const float* x, const float* scale, con
 extern "C" int loans_bn_relu_maxpool_bf16(const void* x, const float* scale, const float* shift, void* y, uint8_t* idx,
                                           int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream) {
     return bn_relu_maxpool_impl<__bf16>(static_cast<const __bf16*>(x), scale, shift, static_cast<__bf16*>(y), idx, B, H, W, C, OH, OW, stream);
+}
+
+extern "C" int loans_bn_relu_maxpool_sel_f32(const float* x, const float* scale, const float* shift, float* y, uint8_t* idx, float* xsel,
+                                             int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream) {
+    return bn_relu_maxpool_impl<float>(x, scale, shift, y, idx, B, H, W, C, OH, OW, stream, xsel, true);
+}
+
+extern "C" int loans_bn_relu_maxpool_sel_bf16(const void* x, const float* scale, const float* shift, void* y, uint8_t* idx, void* xsel,
+                                              int32_t B, int32_t H, int32_t W, int32_t C, int32_t OH, int32_t OW, void* stream) {
+    return bn_relu_maxpool_impl<__bf16>(static_cast<const __bf16*>(x), scale, shift, static_cast<__bf16*>(y), idx, B, H, W, C, OH, OW,
+                                        stream, static_cast<__bf16*>(xsel), true);
 }
 
 template <typename TG>

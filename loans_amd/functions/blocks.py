@@ -93,19 +93,22 @@ class StemFunction(Function):
         # VisualBackprop: the pooling node's input relu(bn1(conv1)) is never materialised -- its channel mean is taken from
         # the conv output and the BN coefficients (conv1's own tap needs the unpadded frames: SheepLocalizer records it)
         ops.vbp_tap(self.c, 3, 2, 0, st=self.st)
-        y, self.idx = ops.bn_relu_maxpool(self.c, self.st)
+        if config.enable_backprop and config.train:     # the backward's sums read the conv values at the argmaxes (ops.POOL_ARGMAX_VALUES)
+            y, self.idx, self.xsel = ops.bn_relu_maxpool(self.c, self.st, want_sel=True)
+        else:
+            (y, self.idx), self.xsel = ops.bn_relu_maxpool(self.c, self.st), None
         return y
 
     def backward(self, inputs, gys):
         _require_train()
         _, W, b, gamma, beta = self.inputs
         gc = ops.pool_bn_backward(gys[0].contiguous(), self.idx, self.c, self.st, gamma.data, gamma.grad_view,
-                                  beta.grad_view, gbias=b.grad_view)
+                                  beta.grad_view, gbias=b.grad_view, xsel=self.xsel)
         ops.conv_wgrad(self.x, gc, W.grad_view, self.geo)
         return None, None, None, None, None
 
     def release(self):
-        self.x = self.c = self.st = self.idx = None
+        self.x = self.c = self.st = self.idx = self.xsel = None
 
 
 class ResidualUnitFunction(Function):

@@ -2002,18 +2002,32 @@ def bn_apply(x, st, relu=True, residual=None, x2=None, st2=None, want_bits=False
     return y
 
 
-def bn_relu_maxpool(x, st):
+# The stem's pool also writes the RAW conv output at every pooled element's argmax (a pooled-size tensor): the sums of the
+# stem's BN backward then read two contiguous pooled-size tensors instead of gathering out of the four times larger conv
+# output (configs[2]: 1.34 GB -> 0.54 GB for that pass, +0.27 GB written here).  False: the gathering pass (tests of it).
+POOL_ARGMAX_VALUES = True
+
+
+def bn_relu_maxpool(x, st, want_sel=False):
+    """(y, idx), or (y, idx, xsel) with want_sel (xsel None where the 16-byte-unit kernel does not tile the channel count)"""
     B, H, W, C_ = x.shape
     OH, OW = conv_outsize(H, 3, 2, 0, True), conv_outsize(W, 3, 2, 0, True)
     s16 = _is16(x)
     y = _empty((B, OH, OW, C_), device=x.device, dtype=x.dtype)
     idx = _empty((B, OH, OW, C_), device=x.device, dtype=torch.uint8)
-    _acct('stem', 0, _nbytes(x), _nbytes(y, idx))
     lib = _lib.load()
+    if want_sel and POOL_ARGMAX_VALUES and bn_units_ok(C_, s16) and reduce_channels_ok(C_) and C_ <= 1024:
+        xsel = _empty((B, OH, OW, C_), device=x.device, dtype=x.dtype)
+        _acct('stem', 0, _nbytes(x), _nbytes(y, idx, xsel))
+        fn = lib.loans_bn_relu_maxpool_sel_bf16 if s16 else lib.loans_bn_relu_maxpool_sel_f32
+        check(fn(_ptr(x), _ptr(st.scale), _ptr(st.shift), _ptr(y), _ptr(idx), _ptr(xsel), B, H, W, C_, OH, OW, _stream()),
+              'loans_bn_relu_maxpool_sel')
+        return y, idx, xsel
+    _acct('stem', 0, _nbytes(x), _nbytes(y, idx))
     fn = lib.loans_bn_relu_maxpool_bf16 if s16 else lib.loans_bn_relu_maxpool_f32
     check(fn(_ptr(x), _ptr(st.scale), _ptr(st.shift), _ptr(y), _ptr(idx), B, H, W, C_, OH, OW, _stream()),
           'loans_bn_relu_maxpool')
-    return y, idx
+    return (y, idx, None) if want_sel else (y, idx)
 
 
 def maxpool_relu_bwd(gy, idx, x, st):
@@ -2174,14 +2188,17 @@ def bn_backward_from_sums(gy, x, st, sums, gamma, ggamma, gbeta):
 
 
 
-def pool_bn_backward(gy, idx, x, st, gamma, ggamma, gbeta, gbias=None):
+def pool_bn_backward(gy, idx, x, st, gamma, ggamma, gbeta, gbias=None, xsel=None):
     """The stem's tail backwards (max_pooling_2d -> relu -> bn1, sheep/resnet.py:72-73) without the dense gradient
     between pool and BN: gx w.r.t. the conv output x from the pooled gradient gy and the argmax positions idx;
     accumulates ggamma / gbeta (and gbias += per-channel sum of gx, conv1's bias gradient) in place.  Same result as bn_backward(maxpool_relu_bwd(gy, idx, x, st), None, x, st, ...)
     up to summation order (and, on bf16 tensors, without the rounding of the intermediate)."""
     B, H, W, C_ = x.shape
     OH, OW = gy.shape[1], gy.shape[2]
-    _acct('stem', 0, 2 * _nbytes(gy, idx) + 2 * _nbytes(x), _nbytes(x))        # sums over the pooled gradient (gathers x), then gx
+    if xsel is not None:
+        _acct('stem', 0, _nbytes(gy, xsel) + _nbytes(gy, idx) + _nbytes(x), _nbytes(x))  # sums over (gy, xsel), then gx
+    else:
+        _acct('stem', 0, 2 * _nbytes(gy, idx) + 2 * _nbytes(x), _nbytes(x))    # sums over the pooled gradient (gathers x), then gx
     if not (reduce_channels_ok(C_) and C_ <= 1024):        # (the three-pass form: channel counts the fused pair does not tile)
         gx = bn_backward(maxpool_relu_bwd(gy, idx, x, st), None, x, st, gamma, ggamma, gbeta)
         if gbias is not None:
@@ -2194,9 +2211,17 @@ def pool_bn_backward(gy, idx, x, st, gamma, ggamma, gbeta, gbias=None):
     app_fn = lib.loans_pool_bn_bwd_apply_bf16 if s16 else lib.loans_pool_bn_bwd_apply_f32
     k = _empty((3, C_), device=x.device, dtype=torch.float32)
     sums = _zeros_f64((STATS_REPLICAS, 2, C_), x.device)
-    red_fn = lib.loans_pool_bn_bwd_reduce_rep_bf16 if s16 else lib.loans_pool_bn_bwd_reduce_rep_f32
-    check(red_fn(_ptr(gy), _ptr(idx), _ptr(x), _ptr(st.scale), _ptr(st.shift), _ptr(st.mean), _ptr(st.rstd), _ptr(sums),
-                 STATS_REPLICAS, B, H, W, C_, OH, OW, s), 'loans_pool_bn_bwd_reduce_rep')
+    if xsel is not None:
+        # sum g' and sum g' xhat over the POOLED elements, g' = gy * (bn(xsel) > 0): every window's gradient lands on its argmax,
+        # whose x is xsel -- the same two sums as over the conv output's pixels, term by term
+        assert xsel.shape == gy.shape and _is16(xsel) == s16
+        red = lib.loans_bn_bwd_reduce_rep_bf16 if s16 else lib.loans_bn_bwd_reduce_rep_f32
+        check(red(_ptr(gy), None, 2, _ptr(xsel), _ptr(st.mean), _ptr(st.rstd), None, None, None, _ptr(st.scale), _ptr(st.shift),
+                  _ptr(sums), STATS_REPLICAS, gy.numel() // C_, C_, s), 'loans_bn_bwd_reduce_rep')
+    else:
+        red_fn = lib.loans_pool_bn_bwd_reduce_rep_bf16 if s16 else lib.loans_pool_bn_bwd_reduce_rep_f32
+        check(red_fn(_ptr(gy), _ptr(idx), _ptr(x), _ptr(st.scale), _ptr(st.shift), _ptr(st.mean), _ptr(st.rstd), _ptr(sums),
+                     STATS_REPLICAS, B, H, W, C_, OH, OW, s), 'loans_pool_bn_bwd_reduce_rep')
     check(lib.loans_bn_bwd_coeffs_rep_f32(_ptr(sums), STATS_REPLICAS, 2 * C_, 0, C_, B * H * W, _ptr(gamma), _ptr(st.mean),
                                           _ptr(st.rstd), _ptr(ggamma), _ptr(gbeta), _ptr(k[0]), _ptr(k[1]), _ptr(k[2]), s),
           'loans_bn_bwd_coeffs_rep_f32')

@@ -559,6 +559,16 @@ def test_stem_tail_fused_backward(shape, dtype):
     stats[0, 0] = xd.double().sum(dim=(0, 1, 2)); stats[0, 1] = (xd.double() ** 2).sum(dim=(0, 1, 2))
     st = ops.bn_finalize(stats, B * H * W, dev(gamma), dev(beta), torch.zeros(C_, device='cuda'), torch.ones(C_, device='cuda'))
     y, idx = ops.bn_relu_maxpool(xd, st)
+    # (round 5) the pool's third output: the RAW x at every pooled element's argmax -- exactly those elements, and y / idx unchanged
+    y2, idx2, xsel = ops.bn_relu_maxpool(xd, st, want_sel=True)
+    assert torch.equal(y2, y) and torch.equal(idx2, idx) and xsel is not None and xsel.dtype == xd.dtype
+    OH, OW = y.shape[1], y.shape[2]
+    ii = idx.long()
+    oh = torch.arange(OH, device='cuda').view(1, OH, 1, 1)
+    ow = torch.arange(OW, device='cuda').view(1, 1, OW, 1)
+    src = ((oh * 2 + ii // 3) * W + (ow * 2 + ii % 3))                          # argmax pixel inside its image
+    want = torch.gather(xd.reshape(B, H * W, C_), 1, src.reshape(B, OH * OW, C_)).reshape(B, OH, OW, C_)
+    assert torch.equal(xsel, want)
     gy = rng.standard_normal(tuple(y.shape)).astype(np.float32)           # NHWC
     if dtype == "bf16":
         gy = torch.from_numpy(gy).bfloat16().float().numpy()
@@ -576,6 +586,14 @@ def test_stem_tail_fused_backward(shape, dtype):
     # the bias gradient of the conv in front of a train-mode BN is analytically zero: compare on the scale of sum |gx|
     assert np.abs(gbias.cpu().numpy() - gx_ref.sum(axis=(0, 2, 3))).max() < 1e-5 * np.abs(gx_ref).sum(axis=(0, 2, 3)).max() + 1e-6
     assert rel_err(gg.cpu().numpy(), gg_ref) < 1e-4 and rel_err(gb.cpu().numpy(), gb_ref) < 1e-4
+    # the sums taken from (gy, xsel) instead of gathered out of x: the same terms in another order
+    ggs, gbs, gbias_s = torch.zeros(C_, device='cuda'), torch.zeros(C_, device='cuda'), torch.zeros(C_, device='cuda')
+    gxs = ops.pool_bn_backward(gyd, idx, xd, st, dev(gamma), ggs, gbs, gbias=gbias_s, xsel=xsel)
+    assert rel_err(_nchw(gxs.float()), gx_ref) < tol
+    assert rel_err(ggs.cpu().numpy(), gg_ref) < 1e-4 and rel_err(gbs.cpu().numpy(), gb_ref) < 1e-4
+    assert rel_err(ggs.cpu().numpy(), gg.cpu().numpy()) < 1e-5 and rel_err(gbs.cpu().numpy(), gb.cpu().numpy()) < 1e-5
+    if dtype == "f32":
+        assert rel_err(gxs.cpu().numpy(), gx.cpu().numpy()) < 1e-5
     # the three-pass form
     gg3, gb3 = torch.zeros(C_, device='cuda'), torch.zeros(C_, device='cuda')
     gx3 = ops.bn_backward(ops.maxpool_relu_bwd(gyd, idx, xd, st), None, xd, st, dev(gamma), gg3, gb3)
