@@ -9,6 +9,9 @@ import numpy as np
 import torch
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+if os.environ.get('BN_BENCH_LIB'):              # (this tool's own variable: another build of the library, for A/B runs)
+    from loans_amd import _lib
+    _lib.LIB_PATH = os.path.abspath(os.environ['BN_BENCH_LIB'])
 from loans_amd import ops  # noqa: E402
 
 
