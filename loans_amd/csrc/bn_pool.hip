@@ -565,17 +565,11 @@ template <> struct unit16<__bf16> {
 // trickle from 4096 blocks.  NT: non-temporal loads and stores (+5 % on tensors far beyond the 256 MB Infinity Cache).
 constexpr int SLAB_UNR = 4;
 struct Slab { int64_t i, end; };
-template <bool REV = false>
 __device__ __forceinline__ Slab slab_of(int64_t nunits) {
     const int64_t per = ((nunits + gridDim.x - 1) / gridDim.x + 255) & ~(int64_t)255;
-    // REV: the blocks take the slabs back to front -- a pass that follows a pass over the same tensors then starts where that one
-    // ended, on the part of them the Infinity Cache still holds
-    const int64_t lo = (int64_t)(REV ? gridDim.x - 1 - blockIdx.x : blockIdx.x) * per;
+    const int64_t lo = (int64_t)blockIdx.x * per;
     return Slab{lo + threadIdx.x, lo + per < nunits ? lo + per : nunits};
 }
-#ifndef LOANS_BN_REVERSE
-#define LOANS_BN_REVERSE 0
-#endif
 static inline int slab_grid(int64_t nunits) { return grid_for(nunits, 256 * SLAB_UNR, 8192); }
 // LOANS_BN_NT: 0 never, 1 always, unset: tensors of at least 96 MB (they cannot stay in the Infinity Cache with their partners)
 static inline bool slab_nt(int64_t tensor_bytes) {
@@ -678,7 +672,7 @@ __global__ __launch_bounds__(256) void bn_bwd_apply_u16_kernel(const T* gy, cons
             unit16<T>::template st<NT>(gx2 + i * V, o);
         }
     };
-    Slab sl = slab_of<(LOANS_BN_REVERSE != 0)>(nunits);
+    Slab sl = slab_of(nunits);
     int64_t i = sl.i;
     for (; i + (SLAB_UNR - 1) * 256 < sl.end; i += SLAB_UNR * 256) {
         raw_t g[SLAB_UNR], xv[SLAB_UNR], mv[SLAB_UNR], xw[SLAB_UNR];
