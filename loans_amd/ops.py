@@ -1454,6 +1454,7 @@ WGRAD_SLABS = os.environ.get('LOANS_WGRAD_SLABS', '1') != '0'
 # three quarters of that leave compute units to its kernels: configs[2] 18.975 -> 18.830 ms, ResNet-50 29.574 -> 29.491
 # (0.5: 18.94 / 29.43; profiles/r5_wgrad_split_scale_ab.txt, tools/ab_wgrad_scale.py)
 WGRAD_SPLIT_SCALE = 0.75
+WGRAD_SPLIT_SCALE_F32 = 1.0       # the fp32 arm is MFMA-bound on both streams: 0.75 -> 49.72 ms against 49.67, 0.5 -> 50.08 (same file)
 _wgrad_ws = {}
 
 
@@ -1519,8 +1520,9 @@ def _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile, stream=None):
         geo.tuned[vkey] = tile
     if tile >> 8:
         tile, splits = tile & 0xFF, tile >> 8
-        if WGRAD_SPLIT_SCALE != 1.0 and s16:
-            splits = max(1, int(splits * WGRAD_SPLIT_SCALE))
+        scale = WGRAD_SPLIT_SCALE if s16 else WGRAD_SPLIT_SCALE_F32
+        if scale != 1.0:
+            splits = max(1, int(splits * scale))
     d = _with_flags(geo.fwd, fl, tile)
     st = stream if stream is not None else _stream()
     ws = _wgrad_workspace(lib, geo, d, tile, splits, x.device, st) if (s16 and WGRAD_SLABS) else None

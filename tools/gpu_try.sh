@@ -1,15 +1,11 @@
 #!/bin/bash
 set -o pipefail
 mkdir -p gpurun_out
-out=gpurun_out/r5_bn_reverse_ab.txt
+out=gpurun_out/try_f32_split_scale.txt
 : > $out
-D=$PWD/loans_amd/csrc
-for shape in "128 128 128 64" "128 64 64 128" "128 32 32 256" "64 128 128 256" "64 64 64 512"; do
-  for nt in "" 0; do
-    for lib in $D/libloans_hip.so $D/libloans_hip_rev.so; do
-      echo "== $shape | LOANS_BN_NT=${nt:-default} | $(basename $lib)" >> $out
-      LOANS_BN_NT=$nt BN_BENCH_LIB=$lib python tools/bn_bench2.py $shape 2>/dev/null | grep "bn_backward" >> $out
-    done
+for round in 1 2 3; do
+  for v in 1.0 0.75 0.5; do
+    ms=$(python3 tools/ab_ops_attr.py WGRAD_SPLIT_SCALE_F32=$v --no-secondary --no-cpu-baseline 2>/dev/null | grep '^{' | tail -1 | python3 -c "import json,sys; d=json.load(sys.stdin); print(d['ms_per_step'], d['roofline'].get('conv_fwd_ms_per_step', ''))")
+    echo "round $round | fp32 default | WGRAD_SPLIT_SCALE_F32=$v | $ms" | tee -a $out
   done
 done
-cat $out
