@@ -69,6 +69,11 @@ extern "C" {
                                   while it is in registers instead of by a pass over the stored tensor (loans_bn_bwd_reduce_xmask_*); g is
                                   stored unmasked, on bf16 tensors the sums use the ROUNDED g the later passes will read.  Not with split-K /
                                   fine-tail tiles, LOANS_TILE_WS64, class launches. */
+#define LOANS_F_AFFINE_IN 1024  /* (round 5) the convolution's input operand is relu(x * scale + shift) rounded to bf16: the BatchNormalization + ReLU in
+                                  front of it (bn2 -> conv3 of a bottleneck, sheep/resnet.py:163-216) applied on load, with loans_bn_apply_bf16's
+                                  arithmetic bit for bit, so that the activation tensor between them is never written.  Forward LOANS_TILE_PW
+                                  launches of loans_igemm_bf16s only (`bias` = float[2][Cin] = scale, shift; with or without LOANS_F_STATS) and
+                                  loans_wgrad_bf16s_affine_ws */
 #define LOANS_F_GY_BF16  256   /* loans_wgrad_bf16_f32 only: `gy` is a bf16 tensor, x stays fp32 (the stem's weight gradient) */
 
 /*
@@ -244,6 +249,11 @@ int loans_wgrad_bf16s(const void* x, const void* gy, float* dw, const loans_igem
  * ends with 18.9 M of them whatever the layer).  dw must not be written by another stream between the two launches. */
 int loans_wgrad_bf16s_ws(const void* x, const void* gy, float* dw, const loans_igemm_desc* d, int32_t splits,
                          float* ws, int64_t ws_floats, void* stream);
+/* (round 5) the same with LOANS_F_AFFINE_IN in d->flags (1 x 1 / 1 convolutions, the GEMM tiles): `x` is the INPUT of the
+ * BatchNormalization in front of the convolution and `affine` its float[2][Cin] = scale, shift; the kernel contracts gy with
+ * relu(x * scale + shift) rounded to bf16 -- the tensor loans_bn_apply_bf16 would have written, bit for bit */
+int loans_wgrad_bf16s_affine_ws(const void* x, const void* gy, float* dw, const loans_igemm_desc* d, int32_t splits,
+                                float* ws, int64_t ws_floats, const float* affine, void* stream);
 /* floats of workspace that call takes for (d, splits) -- host arithmetic only, nothing is launched; < 0: a LOANS_E* code */
 int64_t loans_wgrad_bf16s_ws_floats(const loans_igemm_desc* d, int32_t splits);
 /* dst[i] += ws[0][i] + ws[1][i] + ... + ws[slabs - 1][i] for i < n (n % 4 == 0, 16-byte aligned pointers): every output is summed

@@ -16,6 +16,7 @@ F_RELU_IN, F_BIAS, F_STATS, F_MASK, F_ADDEND, F_ADDEND_MASK = 1, 2, 4, 8, 16, 32
 F_DENSE = 64
 F_OUT_BF16, F_GY_BF16 = 128, 256
 F_BNSUMS = 512
+F_AFFINE_IN = 1024
 TILE_AUTO, TILE_128x128, TILE_128x64, TILE_64x64, TILE_256x64 = 0, 1, 2, 3, 4
 TILE_256x128, TILE_DMA = 7, 16
 
@@ -82,6 +83,7 @@ SIGNATURES = {
     'loans_igemm_bf16s': [_p, _p, _p, _p, _p, _p, _p, C.POINTER(IgemmDesc), _p],
     'loans_wgrad_bf16s': [_p, _p, _p, C.POINTER(IgemmDesc), _i32, _p],
     'loans_wgrad_bf16s_ws': [_p, _p, _p, C.POINTER(IgemmDesc), _i32, _p, _i64, _p],
+    'loans_wgrad_bf16s_affine_ws': [_p, _p, _p, C.POINTER(IgemmDesc), _i32, _p, _i64, _p, _p],
     'loans_fold_slabs_f32': [_p, _p, _i64, _i32, _p],
     'loans_wgrad_bf16s_ws_floats': [C.POINTER(IgemmDesc), _i32],
     'loans_cast_bf16': [_p, _p, _i64, _p],

@@ -130,7 +130,7 @@ int loans_halo16_launch(const void* in, const void* w, void* out, const float* b
 // pw_bf16.hip: 1 x 1 / 1 convolutions with Cin in {64, 128} on bf16 storage, operands never in LDS (LOANS_TILE_PW; internal,
 // reached through loans_igemm_bf16s; `w` in loans_pw_pack_bf16's fragment order)
 int loans_pw16_covers(const loans_igemm_desc* d);
-int loans_pw16_launch(const void* in, const void* w, void* out, double* stats, const loans_igemm_desc* d, hipStream_t st);
+int loans_pw16_launch(const void* in, const void* w, void* out, double* stats, const float* aff, const loans_igemm_desc* d, hipStream_t st);
 
 // wgrad_halo_bf16.hip: weight gradient of stride-1 3 x 3 convolutions on bf16 storage with all taps in one block
 // (LOANS_TILE_WGHALO_*; internal, reached through loans_wgrad_bf16s)

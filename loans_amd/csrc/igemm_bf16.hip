@@ -750,6 +750,9 @@ struct Wgrad16Args {
     // the layout of dw) instead of adding it to dw with atomics; loans_fold_slabs_f32 sums the slabs in a fixed order
     float* ws;
     int64_t slab;
+    // LOANS_F_AFFINE_IN (1 x 1 convolutions): x is the INPUT of the BatchNormalization in front of the convolution, affine = its
+    // float[2][Cin] = scale, shift: rows go to LDS as relu(x * scale + shift) rounded to bf16 (loans_bn_apply_bf16's arithmetic)
+    const float* affine;
 };
 
 constexpr int WPC = 32;     // pixels (reduction rows) per staged chunk
@@ -836,6 +839,17 @@ __global__ __launch_bounds__(64 * NWV) void wgrad16_kernel(const Wgrad16Args a) 
     // The loop is branch-free (hipcc keeps counted waits only along straight-line code): every block runs a multiple
     // of WDEPTH chunks, the ones beyond its slice load nothing (masked like rows beyond the last image) and add zeros.
     u32x4 ry[WDEPTH][NP], rx[WDEPTH][NP];
+    // LOANS_F_AFFINE_IN: this thread's eight channels of [scale | shift] (its X column unit is fixed), and per register set the rows
+    // that were really loaded (a row beyond the tensor or the block's slice must stay a zero operand, not become relu(shift))
+    const bool aff = a.affine != nullptr;
+    f32x4 as0 = {0.f, 0.f, 0.f, 0.f}, as1 = as0, at0 = as0, at1 = as0;
+    if (aff && xtv) {
+        as0 = *reinterpret_cast<const f32x4*>(a.affine + xc8 * 8); as1 = *reinterpret_cast<const f32x4*>(a.affine + xc8 * 8 + 4);
+        at0 = *reinterpret_cast<const f32x4*>(a.affine + d.Cin + xc8 * 8); at1 = *reinterpret_cast<const f32x4*>(a.affine + d.Cin + xc8 * 8 + 4);
+    }
+    unsigned okm[WDEPTH];
+#pragma unroll
+    for (int k = 0; k < WDEPTH; ++k) okm[k] = 0u;
     int lc = c_begin;           // chunk the next load_chunk() fetches
     auto load_row = [&](int k, int p) {
         const int b = pb[p], y = py[p], x = px[p];
@@ -847,6 +861,7 @@ __global__ __launch_bounds__(64 * NWV) void wgrad16_kernel(const Wgrad16Args a) 
                             (unsigned)((unsigned)ix < (unsigned)d.inW);
         const unsigned xoff = xlin[p] | (ok - 1u);
         rx[k][p] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)xoff, 0, 0);
+        okm[k] = (okm[k] & ~(1u << p)) | (ok << p);
         int nx = x + WPC;                       // advance one chunk: exact floor((v + .5) / n) for these small integers
         const int qx = (int)(((float)nx + 0.5f) * inv_gw);
         nx -= __mul24(qx, d.gridW);
@@ -867,6 +882,16 @@ __global__ __launch_bounds__(64 * NWV) void wgrad16_kernel(const Wgrad16Args a) 
         for (int p = 0; p < NP; ++p) {
             if (ythread) *reinterpret_cast<u32x4*>(Ys + (buf * WPC + prow + RPP * p) * SY + unit * 8) = ry[k][p];
             if constexpr (RELU) rx[k][p] = __builtin_bit_cast(u32x4, relu_bf16x8(__builtin_bit_cast(bf16x8_t, rx[k][p])));
+            if (aff) {
+                const bf16x8_t v = __builtin_bit_cast(bf16x8_t, rx[k][p]);
+                f32x4 lo = cvt_lo(v) * as0 + at0, hi = cvt_hi(v) * as1 + at1;
+                lo.x = fmaxf(lo.x, 0.f); lo.y = fmaxf(lo.y, 0.f); lo.z = fmaxf(lo.z, 0.f); lo.w = fmaxf(lo.w, 0.f);
+                hi.x = fmaxf(hi.x, 0.f); hi.y = fmaxf(hi.y, 0.f); hi.z = fmaxf(hi.z, 0.f); hi.w = fmaxf(hi.w, 0.f);
+                const bf16x4_t ol = __builtin_convertvector(lo, bf16x4_t), oh = __builtin_convertvector(hi, bf16x4_t);
+                const u32x4 t = __builtin_bit_cast(u32x4, __builtin_shufflevector(ol, oh, 0, 1, 2, 3, 4, 5, 6, 7));
+                const u32x4 zero = {0u, 0u, 0u, 0u};
+                rx[k][p] = ((okm[k] >> p) & 1u) ? t : zero;
+            }
             *reinterpret_cast<u32x4*>(Xs + (buf * WPC + prow + RPP * p) * SX + unit * 8) = rx[k][p];
         }
     };
@@ -1008,6 +1033,9 @@ static int igemm_bf16s_impl(const void* in, const void* w, void* out, const floa
         }
     }
     if ((d->flags & LOANS_F_BIAS) && !bias) return LOANS_EINVAL;
+    // the BN + ReLU in front of the convolution on load: the VGPR-fed 1 x 1 kernels only, `bias` = its [scale | shift]
+    if ((d->flags & LOANS_F_AFFINE_IN) && (d->tile != LOANS_TILE_PW || !bias || partial || pair || (d->flags & ~(LOANS_F_AFFINE_IN | LOANS_F_STATS))))
+        return LOANS_EINVAL;
     if ((d->flags & LOANS_F_STATS) && !stats) return LOANS_EINVAL;
     if (d->flags & LOANS_F_BNSUMS) {        // a data gradient's epilogue takes the sums of the BN below it: nothing else rides along
         if (!ref || !bias || !stats || partial || pair) return LOANS_EINVAL;
@@ -1064,7 +1092,7 @@ static int igemm_bf16s_impl(const void* in, const void* w, void* out, const floa
     }
     if (tile == LOANS_TILE_PW) {            // short-K 1 x 1 convolutions, operands never in LDS (pw_bf16.hip); w in fragment order
         if (partial || splits > 1 || pair) return LOANS_EINVAL;
-        return loans_pw16_launch(in, w, out, stats, d, st);
+        return loans_pw16_launch(in, w, out, stats, (d->flags & LOANS_F_AFFINE_IN) ? bias : nullptr, d, st);
     }
     switch (tile) {
         case LOANS_TILE_128x128: return launch_igemm16<128, 128, 2, 2>(a, st);
@@ -1231,7 +1259,7 @@ extern "C" int loans_repack_dgrad_bf16(const float* src, void* dst, int32_t Cout
 // One implementation behind loans_wgrad_bf16s (atomics into dw), loans_wgrad_bf16s_ws (partial slabs + fold) and
 // loans_wgrad_bf16s_ws_floats (plan only: *need = floats of workspace the request takes, nothing is launched)
 static int wgrad_bf16s_impl(const void* x, const void* gy, float* dw, const loans_igemm_desc* d, int32_t splits, float* ws,
-                            int64_t ws_floats, int64_t* need, void* stream) {
+                            int64_t ws_floats, int64_t* need, void* stream, const float* affine = nullptr) {
     const bool plan_only = need != nullptr;
     if (!d || (!plan_only && (!x || !gy || !dw))) return LOANS_EINVAL;
     if (d->B <= 0 || d->inH <= 0 || d->inW <= 0 || d->Cin <= 0 || (d->Cin & 7)) return LOANS_EINVAL;
@@ -1267,6 +1295,13 @@ static int wgrad_bf16s_impl(const void* x, const void* gy, float* dw, const loan
     a.Ktot = d->ntaps * d->Cin;
     a.ws = nullptr;
     a.slab = (int64_t)d->Cout * a.Ktot;
+    a.affine = nullptr;
+    if (d->flags & LOANS_F_AFFINE_IN) {     // 1 x 1 / 1 convolutions on the GEMM tiles only; x = the BN's input, affine = [scale | shift][Cin]
+        if (plan_only) { /* the slab count does not depend on it */ }
+        else if (!affine) return LOANS_EINVAL;
+        if (d->ntaps != 1 || d->dy[0] != 0 || d->dx[0] != 0 || d->isy != 1 || d->isx != 1 || (d->flags & ~LOANS_F_AFFINE_IN)) return LOANS_EINVAL;
+        a.affine = affine;
+    }
     {
         const int64_t xb = (int64_t)d->B * d->inH * d->inW * (dense ? 1 : d->Cin) * 2;
         const int64_t gb = (int64_t)d->B * d->outH * d->outW * d->Cout * 2;
@@ -1277,6 +1312,7 @@ static int wgrad_bf16s_impl(const void* x, const void* gy, float* dw, const loan
     int tile = d->tile;
     if (tile == 0) tile = (d->Cout <= 64) ? (a.Ktot <= 64 ? LOANS_TILE_64x64 : LOANS_TILE_64x128) : LOANS_TILE_128x128;
     const bool halo = tile == LOANS_TILE_WGHALO_64 || tile == LOANS_TILE_WGHALO_128;
+    if (halo && (d->flags & LOANS_F_AFFINE_IN)) return LOANS_EINVAL;
     // the slabs this request writes: one per pixel slice (the launchers' own arithmetic)
     int slabs;
     if (halo) slabs = loans_wgrad_halo16_slabs(d, tile, splits);
@@ -1311,6 +1347,12 @@ extern "C" int loans_wgrad_bf16s_ws(const void* x, const void* gy, float* dw, co
                                     float* ws, int64_t ws_floats, void* stream) {
     if (!ws) return LOANS_EINVAL;
     return wgrad_bf16s_impl(x, gy, dw, d, splits, ws, ws_floats, nullptr, stream);
+}
+
+extern "C" int loans_wgrad_bf16s_affine_ws(const void* x, const void* gy, float* dw, const loans_igemm_desc* d, int32_t splits,
+                                           float* ws, int64_t ws_floats, const float* affine, void* stream) {
+    if (!ws || !affine || !d || !(d->flags & LOANS_F_AFFINE_IN)) return LOANS_EINVAL;
+    return wgrad_bf16s_impl(x, gy, dw, d, splits, ws, ws_floats, nullptr, stream, affine);
 }
 
 extern "C" int64_t loans_wgrad_bf16s_ws_floats(const loans_igemm_desc* d, int32_t splits) {

@@ -24,10 +24,26 @@ typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x2_t __attribute__((ext_vector_type(2)));
 typedef float f32x2 __attribute__((ext_vector_type(2)));
 
-template <int K, int NC, bool STATS, int OCC>
+// LOANS_F_AFFINE_IN: the A operand is relu(x * scale + shift) rounded to bf16 -- the BatchNormalization + ReLU in front of the
+// convolution applied while its INPUT goes global -> VGPR (loans_bn_apply_bf16's arithmetic, bit for bit: the same fp32 expression,
+// the same round-to-nearest-even): the activation tensor between bn2 and conv3 of a bottleneck is never written or read
+__device__ __forceinline__ u32x4 pw_affine_relu(u32x4 raw, const float* sp, const float* tp) {
+    typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+    const bf16x8_t v = __builtin_bit_cast(bf16x8_t, raw);
+    f32x4 lo = __builtin_convertvector(__builtin_shufflevector(v, v, 0, 1, 2, 3), f32x4);
+    f32x4 hi = __builtin_convertvector(__builtin_shufflevector(v, v, 4, 5, 6, 7), f32x4);
+    lo = lo * *reinterpret_cast<const f32x4*>(sp) + *reinterpret_cast<const f32x4*>(tp);
+    hi = hi * *reinterpret_cast<const f32x4*>(sp + 4) + *reinterpret_cast<const f32x4*>(tp + 4);
+    lo.x = fmaxf(lo.x, 0.f); lo.y = fmaxf(lo.y, 0.f); lo.z = fmaxf(lo.z, 0.f); lo.w = fmaxf(lo.w, 0.f);
+    hi.x = fmaxf(hi.x, 0.f); hi.y = fmaxf(hi.y, 0.f); hi.z = fmaxf(hi.z, 0.f); hi.w = fmaxf(hi.w, 0.f);
+    const bf16x4_t a = __builtin_convertvector(lo, bf16x4_t), b = __builtin_convertvector(hi, bf16x4_t);
+    return __builtin_bit_cast(u32x4, __builtin_shufflevector(a, b, 0, 1, 2, 3, 4, 5, 6, 7));
+}
+
+template <int K, int NC, bool STATS, int OCC, bool AFF>
 __global__ __launch_bounds__(256, OCC) void pw16_kernel(const __bf16* __restrict__ A, const u32x4* __restrict__ W,
                                                                    __bf16* __restrict__ out, double* __restrict__ stats, int M, int N_,
-                                                                   int nstrips, int nt_out) {
+                                                                   int nstrips, int nt_out, const float* __restrict__ aff) {
     const int N = NC ? NC : N_;             // NC != 0: the column count is a compile-time constant (slab rows at immediate offsets)
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int KS = K / 16;
@@ -36,12 +52,25 @@ __global__ __launch_bounds__(256, OCC) void pw16_kernel(const __bf16* __restrict
     const int half = N / 2, pitch = half + 8;        // bf16 elements per staged half pixel row
     double* sums = reinterpret_cast<double*>(smem);  // [2][N], only with stats
     __bf16* slab = reinterpret_cast<__bf16*>(smem + (STATS ? (size_t)2 * N * sizeof(double) : 0)) + (size_t)wave * 32 * pitch;
+    float* affs = reinterpret_cast<float*>(smem + (STATS ? (size_t)2 * N * sizeof(double) : 0) + (size_t)4 * 32 * pitch * 2);   // [2][K], AFF
     const int wave_id = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
     const int upr = half / 8, tiles_half = half / 32;
     if (STATS) {
         for (int i = threadIdx.x; i < 2 * N; i += 256) sums[i] = 0.0;
-        __syncthreads();
     }
+    if (AFF) {
+        for (int i = threadIdx.x; i < 2 * K; i += 256) affs[i] = aff[i];
+    }
+    if (STATS || AFF) __syncthreads();
+    auto affine = [&](int s, u32x4* a) {            // (rows past M stay zero operands)
+        const bool live = s * 32 + r < M;
+        const u32x4 zero = {0u, 0u, 0u, 0u};
+#pragma unroll
+        for (int ks = 0; ks < KS; ++ks) {
+            const u32x4 v = pw_affine_relu(a[ks], affs + ks * 16 + h * 8, affs + K + ks * 16 + h * 8);
+            a[ks] = live ? v : zero;
+        }
+    };
     auto load_a = [&](int s, u32x4* a) {
         // rows past M (the ragged last strip) are zero operands: their accumulators are zero -- nothing for the sums, never stored
         const bool live = s * 32 + r < M;
@@ -59,7 +88,7 @@ __global__ __launch_bounds__(256, OCC) void pw16_kernel(const __bf16* __restrict
         for (int ks = 0; ks < KS; ++ks) b[ks] = wf[ks * 64];
     };
     u32x4 a[KS], an[KS];
-    if (wave_id < nstrips) load_a(wave_id, a);
+    if (wave_id < nstrips) { load_a(wave_id, a); if (AFF) affine(wave_id, a); }
     for (int s = wave_id; s < nstrips; s += nwaves) {
         const int m0 = s * 32;
         u32x4 b[KS], bn[KS];
@@ -120,6 +149,7 @@ __global__ __launch_bounds__(256, OCC) void pw16_kernel(const __bf16* __restrict
         }
 #pragma unroll
         for (int ks = 0; ks < KS; ++ks) a[ks] = an[ks];
+        if (AFF && s + nwaves < nstrips) affine(s + nwaves, a);
     }
     if (STATS) {
         __syncthreads();
@@ -133,9 +163,10 @@ __global__ __launch_bounds__(256, OCC) void pw16_kernel(const __bf16* __restrict
 // halves of eight fragments (the second half requested before the first half's MFMAs, the next tile's first half before the
 // second's), the next strip's pixels are not prefetched (at B = 64 there is one strip per resident wave anyway), and the slab holds
 // 128 columns.  Everything else as above; 2 blocks per CU.
-template <int NC, bool STATS>
+template <int NC, bool STATS, bool AFF>
 __global__ __launch_bounds__(256, 2) void pw16_k256_kernel(const __bf16* __restrict__ A, const u32x4* __restrict__ W, __bf16* __restrict__ out,
-                                                           double* __restrict__ stats, int M, int N_, int nstrips, int nt_out) {
+                                                           double* __restrict__ stats, int M, int N_, int nstrips, int nt_out,
+                                                           const float* __restrict__ aff) {
     const int N = NC ? NC : N_;
     extern __shared__ __attribute__((aligned(16))) char smem[];
     constexpr int K = 256, KS = 16, PC = 128, pitch = PC + 8, upr = PC / 8;
@@ -143,12 +174,16 @@ __global__ __launch_bounds__(256, 2) void pw16_k256_kernel(const __bf16* __restr
     const int r = lane & 31, h = lane >> 5;
     double* sums = reinterpret_cast<double*>(smem);
     __bf16* slab = reinterpret_cast<__bf16*>(smem + (STATS ? (size_t)2 * N * sizeof(double) : 0)) + (size_t)wave * 32 * pitch;
+    float* affs = reinterpret_cast<float*>(smem + (STATS ? (size_t)2 * N * sizeof(double) : 0) + (size_t)4 * 32 * pitch * 2);   // [2][K], AFF
     const int wave_id = blockIdx.x * 4 + wave, nwaves = gridDim.x * 4;
     const int phases = N / PC;
     if (STATS) {
         for (int i = threadIdx.x; i < 2 * N; i += 256) sums[i] = 0.0;
-        __syncthreads();
     }
+    if (AFF) {
+        for (int i = threadIdx.x; i < 2 * K; i += 256) affs[i] = aff[i];
+    }
+    if (STATS || AFF) __syncthreads();
     auto load_w = [&](int nt, int part, u32x4* b) {
         const u32x4* wf = W + ((size_t)nt * KS + part * 8) * 64 + lane;
 #pragma unroll
@@ -163,7 +198,8 @@ __global__ __launch_bounds__(256, 2) void pw16_k256_kernel(const __bf16* __restr
             const u32x4 zero = {0u, 0u, 0u, 0u};
 #pragma unroll
             for (int ks = 0; ks < KS; ++ks) {
-                const u32x4 v = *reinterpret_cast<const u32x4*>(A + (size_t)row * K + ks * 16 + h * 8);
+                u32x4 v = *reinterpret_cast<const u32x4*>(A + (size_t)row * K + ks * 16 + h * 8);
+                if (AFF) v = pw_affine_relu(v, affs + ks * 16 + h * 8, affs + K + ks * 16 + h * 8);
                 a[ks] = live ? v : zero;
             }
         }
@@ -289,16 +325,16 @@ int loans_pw16_covers(const loans_igemm_desc* d) {
         if (d->Cin != 64 && d->Cin != 128) return 0;
         if (d->Cout % 64 != 0 || d->Cout < 64 || d->Cout > 512) return 0;
     }
-    if (d->flags & ~LOANS_F_STATS) return 0;
+    if (d->flags & ~(LOANS_F_STATS | LOANS_F_AFFINE_IN)) return 0;
     return 1;
 }
 
-template <int K, int NC, bool STATS, int OCC>
-static int pw16_launch_n(const void* in, const void* w, void* out, double* stats, int M, int N, int nt_out, hipStream_t st) {
+template <int K, int NC, bool STATS, int OCC, bool AFF>
+static int pw16_launch_n(const void* in, const void* w, void* out, double* stats, int M, int N, int nt_out, const float* aff, hipStream_t st) {
     static loans_device_once lds_limit_set;
     const int nstrips = (M + 31) / 32;
-    const size_t lds = (size_t)4 * 32 * (N / 2 + 8) * 2 + (STATS ? (size_t)2 * N * sizeof(double) : 0);
-    const void* kern = reinterpret_cast<const void*>(pw16_kernel<K, NC, STATS, OCC>);
+    const size_t lds = (size_t)4 * 32 * (N / 2 + 8) * 2 + (STATS ? (size_t)2 * N * sizeof(double) : 0) + (AFF ? (size_t)2 * K * sizeof(float) : 0);
+    const void* kern = reinterpret_cast<const void*>(pw16_kernel<K, NC, STATS, OCC, AFF>);
     if (lds > 64 * 1024) {
         const int rc = loans_raise_lds_limit(lds_limit_set, kern, 80 * 1024);
         if (rc != LOANS_OK) return rc;
@@ -307,36 +343,49 @@ static int pw16_launch_n(const void* in, const void* w, void* out, double* stats
     if (cus <= 0) return LOANS_EINVAL;
     int blocks = cus * OCC;
     if (blocks > (nstrips + 3) / 4) blocks = (nstrips + 3) / 4;
-    hipLaunchKernelGGL((pw16_kernel<K, NC, STATS, OCC>), dim3(blocks), dim3(256), lds, st, static_cast<const __bf16*>(in), static_cast<const u32x4*>(w),
-                       static_cast<__bf16*>(out), stats, M, N, nstrips, nt_out);
+    hipLaunchKernelGGL((pw16_kernel<K, NC, STATS, OCC, AFF>), dim3(blocks), dim3(256), lds, st, static_cast<const __bf16*>(in), static_cast<const u32x4*>(w),
+                       static_cast<__bf16*>(out), stats, M, N, nstrips, nt_out, aff);
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;
 }
 
-template <int NC, bool STATS>
-static int pw16_launch_k256(const void* in, const void* w, void* out, double* stats, int M, int N, int nt_out, hipStream_t st) {
+template <int NC, bool STATS, bool AFF>
+static int pw16_launch_k256(const void* in, const void* w, void* out, double* stats, int M, int N, int nt_out, const float* aff, hipStream_t st) {
     const int nstrips = (M + 31) / 32;
-    const size_t lds = (size_t)4 * 32 * (128 + 8) * 2 + (STATS ? (size_t)2 * N * sizeof(double) : 0);       // <= 50 KB
+    const size_t lds = (size_t)4 * 32 * (128 + 8) * 2 + (STATS ? (size_t)2 * N * sizeof(double) : 0) + (AFF ? (size_t)2 * 256 * sizeof(float) : 0);   // <= 52 KB
     const int cus = loans_device_cus();
     if (cus <= 0) return LOANS_EINVAL;
     int blocks = cus * 2;
     if (blocks > (nstrips + 3) / 4) blocks = (nstrips + 3) / 4;
-    hipLaunchKernelGGL((pw16_k256_kernel<NC, STATS>), dim3(blocks), dim3(256), lds, st, static_cast<const __bf16*>(in),
-                       static_cast<const u32x4*>(w), static_cast<__bf16*>(out), stats, M, N, nstrips, nt_out);
+    hipLaunchKernelGGL((pw16_k256_kernel<NC, STATS, AFF>), dim3(blocks), dim3(256), lds, st, static_cast<const __bf16*>(in),
+                       static_cast<const u32x4*>(w), static_cast<__bf16*>(out), stats, M, N, nstrips, nt_out, aff);
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;
 }
 
 // the two shapes of the ResNet-50 localizer (N = 4 K) have the column count folded into the code
-template <int K, bool STATS>
-static int pw16_launch_k(const void* in, const void* w, void* out, double* stats, int M, int N, int nt_out, hipStream_t st) {
+template <int K, bool STATS, bool AFF>
+static int pw16_launch_k(const void* in, const void* w, void* out, double* stats, int M, int N, int nt_out, const float* aff, hipStream_t st) {
     // resident blocks per CU: K = 64: 4 (<= 128 VGPRs; the statistics form with a run-time N needs 141: 3), K = 128: 2
     constexpr int OCC = K <= 64 ? 4 : 2;
-    if (N == 4 * K) return pw16_launch_n<K, 4 * K, STATS, OCC>(in, w, out, stats, M, N, nt_out, st);
-    return pw16_launch_n<K, 0, STATS, (K <= 64 && STATS) ? 3 : OCC>(in, w, out, stats, M, N, nt_out, st);
+    if (N == 4 * K) return pw16_launch_n<K, 4 * K, STATS, OCC, AFF>(in, w, out, stats, M, N, nt_out, aff, st);
+    return pw16_launch_n<K, 0, STATS, (K <= 64 && STATS) ? 3 : OCC, AFF>(in, w, out, stats, M, N, nt_out, aff, st);
 }
 
-int loans_pw16_launch(const void* in, const void* w, void* out, double* stats, const loans_igemm_desc* d, hipStream_t st) {
+template <bool AFF>
+static int pw16_launch_aff(const void* in, const void* w, void* out, double* stp, const loans_igemm_desc* d, int M, int N, int nt_out,
+                           const float* aff, hipStream_t st) {
+    if (d->Cin == 256) {
+        if (N == 1024) return stp ? pw16_launch_k256<1024, true, AFF>(in, w, out, stp, M, N, nt_out, aff, st) : pw16_launch_k256<1024, false, AFF>(in, w, out, stp, M, N, nt_out, aff, st);
+        return stp ? pw16_launch_k256<0, true, AFF>(in, w, out, stp, M, N, nt_out, aff, st) : pw16_launch_k256<0, false, AFF>(in, w, out, stp, M, N, nt_out, aff, st);
+    }
+    if (d->Cin == 64)
+        return stp ? pw16_launch_k<64, true, AFF>(in, w, out, stp, M, N, nt_out, aff, st) : pw16_launch_k<64, false, AFF>(in, w, out, stp, M, N, nt_out, aff, st);
+    return stp ? pw16_launch_k<128, true, AFF>(in, w, out, stp, M, N, nt_out, aff, st) : pw16_launch_k<128, false, AFF>(in, w, out, stp, M, N, nt_out, aff, st);
+}
+
+// aff: float[2][Cin] = scale, shift (LOANS_F_AFFINE_IN), else ignored
+int loans_pw16_launch(const void* in, const void* w, void* out, double* stats, const float* aff, const loans_igemm_desc* d, hipStream_t st) {
     if (!loans_pw16_covers(d)) return LOANS_EINVAL;
     const int64_t M64 = (int64_t)d->B * d->gridH * d->gridW;
     if (M64 <= 0 || M64 > 0x7FFFFFFF - 64) return LOANS_ERANGE;
@@ -344,11 +393,9 @@ int loans_pw16_launch(const void* in, const void* w, void* out, double* stats, c
     double* stp = (d->flags & LOANS_F_STATS) ? stats : nullptr;
     const int nt_out = loans_conv_nt((size_t)M * N * 2);
     if ((d->flags & LOANS_F_STATS) && !stats) return LOANS_EINVAL;
-    if (d->Cin == 256) {
-        if (N == 1024) return stp ? pw16_launch_k256<1024, true>(in, w, out, stp, M, N, nt_out, st) : pw16_launch_k256<1024, false>(in, w, out, stp, M, N, nt_out, st);
-        return stp ? pw16_launch_k256<0, true>(in, w, out, stp, M, N, nt_out, st) : pw16_launch_k256<0, false>(in, w, out, stp, M, N, nt_out, st);
+    if (d->flags & LOANS_F_AFFINE_IN) {
+        if (!aff) return LOANS_EINVAL;
+        return pw16_launch_aff<true>(in, w, out, stp, d, M, N, nt_out, aff, st);
     }
-    if (d->Cin == 64)
-        return stp ? pw16_launch_k<64, true>(in, w, out, stp, M, N, nt_out, st) : pw16_launch_k<64, false>(in, w, out, stp, M, N, nt_out, st);
-    return stp ? pw16_launch_k<128, true>(in, w, out, stp, M, N, nt_out, st) : pw16_launch_k<128, false>(in, w, out, stp, M, N, nt_out, st);
+    return pw16_launch_aff<false>(in, w, out, stp, d, M, N, nt_out, nullptr, st);
 }

@@ -131,12 +131,29 @@ class ResidualUnitFunction(Function):
         self.c, self.st, self.geo, self.h = [None] * n, [None] * n, [None] * n, [None] * n
         h = x
         paired = self._forward_pair(x, inputs) if self.shortcut is not None else False
+        self.onload = [False] * n       # stage i reads relu(bn_{i-1}(c[i-1])) ON LOAD: h[i-1] is never materialised (ops.BN_ON_LOAD)
         for i, (conv, bn) in enumerate(self.stages):
             W, g, b = inputs[1 + 3 * i:4 + 3 * i]
-            ops.vbp_tap(h, conv.ksize, conv.stride, conv.pad)           # main-branch convolution i and its input
-            if not (paired and i == 0):
+            if h is not None:
+                ops.vbp_tap(h, conv.ksize, conv.stride, conv.pad)       # main-branch convolution i and its input
+            if self.onload[i]:
+                geo = self.geo[i]
+                stats = _zeros_stats(conv.out_channels, x.device)
+                self.c[i] = ops.conv_fprop_affine(self.c[i - 1], self.st[i - 1], W, geo, stats=stats)
+                self.st[i] = ops.bn_finalize(stats, geo.B * geo.Ho * geo.Wo, g, b, bn.avg_mean, bn.avg_var)
+            elif not (paired and i == 0):
                 self.c[i], self.st[i], self.geo[i] = _ConvBN.forward(h, conv, bn, W, None, g, b)
             if i < n - 1:
+                # bn_i -> relu -> a 1 x 1 convolution the VGPR-fed kernels take (a bottleneck's bn2 -> conv3): the convolution and
+                # its weight gradient apply the BN while they load its input, the backward takes the BN's sums from the data
+                # gradient's epilogue and its mask from the recomputed sign -- nobody reads the activation
+                nxt = self.stages[i + 1][0]
+                if config.train and config.enable_backprop and ops.VBP_TAPS is None and not nxt.dense_rows:
+                    gnext = nxt.geometry(self.c[i].shape[0], self.c[i].shape[1], self.c[i].shape[2])
+                    if ops.affine_in_ok(gnext, self.c[i]) and ops.bn_sums_ok(gnext, self.c[i]):
+                        self.geo[i + 1], self.onload[i + 1] = gnext, True
+                        h = self.h[i] = None
+                        continue
                 h = self.h[i] = ops.bn_apply(self.c[i], self.st[i], relu=True)
         bits = config.train and config.enable_backprop     # the backward's ReLU mask as sign bits (ops.bn_apply)
         if self.shortcut is not None:
@@ -190,7 +207,10 @@ class ResidualUnitFunction(Function):
                 # the two sums of BN i-1's backward ride in this dgrad's epilogue (its output tile meets the BN's input tile
                 # there): the reduction pass over gh disappears, the BN backward is one pass
                 gh, sums = ops.conv_dgrad(g, W.data, self.geo[i], bn_sums=(self.c[i - 1], self.st[i - 1]))
-                ops.conv_wgrad(self.h[i - 1], g, W.grad_view, self.geo[i])
+                if self.onload[i]:          # (the activation was never written: the weight gradient applies the BN on load too)
+                    ops.conv_wgrad(self.c[i - 1], g, W.grad_view, self.geo[i], in_affine=self.st[i - 1])
+                else:
+                    ops.conv_wgrad(self.h[i - 1], g, W.grad_view, self.geo[i])
                 g = ops.bn_backward_from_sums(gh, self.c[i - 1], self.st[i - 1], sums, gp.data, gp.grad_view, bp.grad_view)
                 continue
             gh = ops.conv_dgrad(g, W.data, self.geo[i])

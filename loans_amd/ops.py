@@ -15,7 +15,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (F_ADDEND, F_ADDEND_MASK, F_BIAS, F_BNSUMS, F_DENSE, F_GY_BF16, F_MASK, F_OUT_BF16, F_RELU_IN, F_STATS,
+from ._lib import (F_ADDEND, F_ADDEND_MASK, F_AFFINE_IN, F_BIAS, F_BNSUMS, F_DENSE, F_GY_BF16, F_MASK, F_OUT_BF16, F_RELU_IN, F_STATS,
                    IgemmDesc, check)
 
 # Arithmetic of the convolution contractions: 'f32' (exact fp32 MFMA, the parity path) or 'bf16' (operands rounded
@@ -463,6 +463,48 @@ def _pw_tiles(geo, plain):
     if geo.Cin not in (64, 128) or geo.Cout % 64 or geo.Cout > 512:
         return ()
     return (TILE_PW,)
+
+
+# A bottleneck's bn2 -> relu -> conv3 without the activation tensor between them (round 5): conv3's forward
+# (LOANS_TILE_PW) and its weight gradient apply relu(x * scale + shift) while they load bn2's INPUT (LOANS_F_AFFINE_IN), the apply
+# pass that read it and wrote the activation disappears.  False: the activation is materialised as before.
+BN_ON_LOAD = True
+
+
+def affine_in_ok(geo, x):
+    """conv_fprop_affine / conv_wgrad(..., in_affine=) cover this convolution: bf16 storage, a shape LOANS_TILE_PW takes"""
+    return BN_ON_LOAD and PW and WGRAD_SLABS and _is16(x) and x.is_contiguous() and bool(_pw_tiles(geo, True))
+
+
+def conv_fprop_affine(x, st, w, geo, stats=None):
+    """conv(relu(x * st.scale + st.shift)) on bf16 tensors: the BN + ReLU in front of a 1 x 1 convolution applied on load, bit for
+    bit bn_apply(x, st, relu=True) followed by conv_fprop(..., tile=TILE_PW)"""
+    assert affine_in_ok(geo, x) and x.numel() == geo.in_numel
+    lib = _lib.load()
+    out = _empty((geo.B, geo.Ho, geo.Wo, geo.Cout), device=x.device, dtype=BF16)
+    w16 = w if _is16(w) else _bf16_shadow(w)
+    if w16 is None:
+        w16 = cast_bf16(w)
+    flags = F_AFFINE_IN | (F_STATS if stats is not None else 0)
+    _count_flops('fprop', geo)
+    if CLASS_COUNT is not None:
+        rd, wr = _conv_bytes(geo, x, w16, out)
+        _acct('conv', _conv_flop(geo), rd, wr)
+    log = EVENT_LOG
+    if log is not None:
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
+    packs = PW_PACK_CALLS
+    wp = _pw_packed(lib, w, w16, geo, _stream())
+    packs = PW_PACK_CALLS - packs
+    check(lib.loans_igemm_bf16s(_ptr(x), _ptr(wp), _ptr(out), _ptr(st.affine()), _ptr(stats), 0, 0,
+                                C.byref(_with_flags(geo.fwd, flags, TILE_PW)), _stream()), 'loans_igemm_bf16s[fprop, bn on load]')
+    if log is not None:
+        ev1.record()
+        log.append(('fprop_bn' if stats is not None else 'fprop',
+                    2 * geo.B * geo.Ho * geo.Wo * geo.Cout * geo.k * geo.k * geo.cin_logical, ev0, ev1, 1 + packs, 1,
+                    _conv_bytes(geo, x, w16, out)))
+    return out
 
 
 PW_PACK_CALLS = 0           # per-call packing launches (tests: a prepared step makes none)
@@ -1349,8 +1391,9 @@ def _wgrad_key(x, gy, relu_in):
            ('relu_' if relu_in else '') + 'wgrad'
 
 
-def conv_wgrad(x, gy, dw, geo, relu_in=False, splits=0, tile=0):
-    """dw[Cout,k,k,Cin] += sum over pixels (atomic accumulate into the gradient arena)."""
+def conv_wgrad(x, gy, dw, geo, relu_in=False, splits=0, tile=0, in_affine=None):
+    """dw[Cout,k,k,Cin] += sum over pixels (atomic accumulate into the gradient arena).  in_affine (a BNState; affine_in_ok): x is
+    the INPUT of the BN in front of the convolution, the kernel contracts gy with relu(x * scale + shift) rounded to bf16."""
     tuned = geo.tuned.get(_wgrad_key(x, gy, relu_in)) is not None
     if ASYNC_WGRAD and tuned and (CAPTURE_STREAMS or not torch.cuda.is_current_stream_capturing()):
         side = _wgrad_stream(x.device)
@@ -1361,12 +1404,12 @@ def conv_wgrad(x, gy, dw, geo, relu_in=False, splits=0, tile=0):
         if not geo.dense:
             # the launch goes to the side stream by handle: making it torch's current stream (a context manager: two Python-level
             # stream switches per weight gradient) cost 2 ms of host time per ResNet-50 step; nothing is allocated on this path
-            _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile, stream=side.cuda_stream)
+            _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile, stream=side.cuda_stream, in_affine=in_affine)
         else:
             with torch.cuda.stream(side):       # (the dense stem's mask pass allocates)
-                _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile)
+                _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile, in_affine=in_affine)
         return
-    _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile)
+    _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile, in_affine=in_affine)
 
 
 _stream_objs = {}
@@ -1478,7 +1521,7 @@ def _wgrad_workspace(lib, geo, desc, tile, splits, device, st):
     return ws, need
 
 
-def _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile, stream=None):
+def _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile, stream=None, in_affine=None):
     lib = _lib.load()
     _count_flops('wgrad', geo)
     _acct('wgrad', _conv_flop(geo), _nbytes(x, gy), _nbytes(dw))
@@ -1523,10 +1566,18 @@ def _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile, stream=None):
         scale = WGRAD_SPLIT_SCALE if s16 else WGRAD_SPLIT_SCALE_F32
         if scale != 1.0:
             splits = max(1, int(splits * scale))
+    if in_affine is not None:           # x is the input of the BN in front of the convolution: relu(bn(x)) applied on load
+        assert s16 and WGRAD_SLABS and fl == 0
+        fl = F_AFFINE_IN
     d = _with_flags(geo.fwd, fl, tile)
     st = stream if stream is not None else _stream()
     ws = _wgrad_workspace(lib, geo, d, tile, splits, x.device, st) if (s16 and WGRAD_SLABS) else None
-    if ws is not None:
+    if in_affine is not None:
+        if ws is None:          # (the workspace planner refused the descriptor: not a 1 x 1 / 1 convolution on a GEMM tile)
+            raise RuntimeError('loans_wgrad_bf16s_affine_ws does not cover this convolution')
+        check(lib.loans_wgrad_bf16s_affine_ws(_ptr(x), _ptr(gy), _ptr(dw), C.byref(d), splits, _ptr(ws[0]), ws[1], _ptr(in_affine.affine()),
+                                              st), 'loans_wgrad_bf16s_affine_ws')
+    elif ws is not None:
         check(lib.loans_wgrad_bf16s_ws(_ptr(x), _ptr(gy), _ptr(dw), C.byref(d), splits, _ptr(ws[0]), ws[1], st), 'loans_wgrad_bf16s_ws')
     else:
         check(wfn(_ptr(x), _ptr(gy), _ptr(dw), C.byref(d), splits, st), 'loans_wgrad')
@@ -1950,6 +2001,11 @@ class BNState:
         buf = _empty((4, C_), device=device, dtype=torch.float32)
         self.mean, self.rstd, self.scale, self.shift = buf[0], buf[1], buf[2], buf[3]
         self.count = 0
+
+    def affine(self):
+        """float[2][C] = scale, shift as one table (LOANS_F_AFFINE_IN): the two rows lie behind each other in this state's buffer"""
+        assert self.shift.data_ptr() == self.scale.data_ptr() + 4 * self.scale.numel()
+        return self.scale
 
 
 def bn_finalize(stats, count, gamma, beta, running_mean, running_var):

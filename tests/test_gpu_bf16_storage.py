@@ -743,3 +743,91 @@ def test_data_gradient_takes_the_bn_backward_sums(storage, tiles, case):
         ops.set_compute_dtype(old[0])
         if old[1] == 'bf16':
             ops.set_storage_dtype('bf16')
+
+
+@pytest.mark.parametrize("case", [(2, 64, 16, 16, 256), (3, 64, 7, 9, 256), (1, 64, 5, 5, 64), (2, 128, 12, 20, 512), (3, 128, 3, 11, 128),
+                                  (2, 64, 33, 47, 192), (2, 256, 8, 8, 1024), (3, 256, 5, 7, 256), (4, 128, 64, 64, 512)])
+def test_bn_relu_on_load_pointwise_forward_and_weight_gradient(case):
+    """LOANS_F_AFFINE_IN (round 5): a 1 x 1 convolution that reads the INPUT of the BatchNormalization + ReLU in
+    front of it and applies them on load -- forward (LOANS_TILE_PW) and weight gradient (every GEMM tile) -- is, BIT FOR BIT, the
+    apply pass followed by the plain launch: outputs, BN statistics (to the order of the fp64 atomics), weight gradients.  Ragged last
+    strips and pixel counts beyond the blocks' slices stay zero operands (relu(shift) of a row that does not exist must not enter)."""
+    from loans_amd import ops
+    B, Cin, H, W, Cout = case
+    rng = np.random.RandomState(11)
+    x = d16(rng.standard_normal((B, H, W, Cin)).astype(np.float32) * 2)
+    w = dev((rng.standard_normal((Cout, 1, 1, Cin)) / np.sqrt(Cin)).astype(np.float32))
+    gamma, beta = dev((1 + 0.3 * rng.standard_normal(Cin)).astype(np.float32)), dev((0.3 * rng.standard_normal(Cin)).astype(np.float32))
+    stats = ops.stats_buffer(Cin, 'cuda')
+    stats[0, 0] = x.double().sum(dim=(0, 1, 2)); stats[0, 1] = (x.double() ** 2).sum(dim=(0, 1, 2))
+    st = ops.bn_finalize(stats, B * H * W, gamma, beta, torch.zeros(Cin, device='cuda'), torch.ones(Cin, device='cuda'))
+    geo = ops.ConvGeometry(B, H, W, Cin, Cout, 1, 1, 0)
+    assert ops.affine_in_ok(geo, x)
+    a = ops.bn_apply(x, st, relu=True)
+    assert float((a == 0).float().mean()) > 0.1            # the ReLU does something here
+    s_ref, s_new = ops.stats_buffer(Cout, 'cuda'), ops.stats_buffer(Cout, 'cuda')
+    y_ref = ops.conv_fprop(a, w, geo, stats=s_ref, tile=ops.TILE_PW)
+    y_new = ops.conv_fprop_affine(x, st, w, geo, stats=s_new)
+    assert torch.equal(y_new, y_ref)
+    np.testing.assert_allclose(s_new.sum(0).cpu().numpy(), s_ref.sum(0).cpu().numpy(), rtol=1e-12, atol=1e-9)
+    assert torch.equal(ops.conv_fprop_affine(x, st, w, geo), y_ref)          # the form without statistics
+    gy = d16(rng.standard_normal((B, H, W, Cout)).astype(np.float32))
+    tiles = [1, 3, 5] + ([9] if Cout % 256 == 0 else [])
+    for tile in tiles:
+        for splits in (0, 3):
+            dw_ref, dw_new = torch.zeros((Cout, 1, 1, Cin), device='cuda'), torch.zeros((Cout, 1, 1, Cin), device='cuda')
+            ops._conv_wgrad(a, gy, dw_ref, geo, False, splits, tile)
+            ops._conv_wgrad(x, gy, dw_new, geo, False, splits, tile, in_affine=st)
+            assert torch.equal(dw_new, dw_ref), (tile, splits)
+    # the flag is refused where no kernel implements it (a 3 x 3 geometry, another tile), not ignored
+    with pytest.raises(RuntimeError):
+        d3 = ops.ConvGeometry(B, H, W, Cin, Cout, 3, 1, 1)
+        ops._conv_wgrad(x, gy, torch.zeros((Cout, 3, 3, Cin), device='cuda'), d3, False, 0, 1, in_affine=st)
+
+
+def test_bottleneck_with_bn_on_load_is_the_materialised_form(monkeypatch):
+    """A ResNet-50 bottleneck whose bn2 -> relu -> conv3 never writes the activation between them (ops.BN_ON_LOAD) against the same
+    unit with the apply pass: output, input gradient and every parameter gradient bit for bit."""
+    import loans_amd
+    from loans_amd import ops
+    from loans_amd.iou.iou_regressor import BottleneckB
+    from loans_amd.runtime.core import Variable
+    rng = np.random.RandomState(13)
+    B, H, W, cout, mid = 4, 12, 10, 256, 64
+    x = d16(rng.standard_normal((B, H, W, cout)).astype(np.float32))
+    gy = d16(rng.standard_normal((B, H, W, cout)).astype(np.float32))
+    res = []
+    loans_amd.set_compute_dtype('bf16')
+    loans_amd.set_storage_dtype('bf16')
+    try:
+        for on_load in (False, True):
+            monkeypatch.setattr(ops, 'BN_ON_LOAD', on_load)
+            np.random.seed(14)
+            blk = BottleneckB(cout, mid, loans_amd.links.HeNormal())
+            r2 = np.random.RandomState(15)
+            for key, p in blk.namedparams():
+                if key.endswith('/gamma'):
+                    p.set_logical((1 + 0.2 * r2.standard_normal(p.logical_shape)).astype(np.float32))
+                elif key.endswith('/beta'):
+                    p.set_logical((0.2 * r2.standard_normal(p.logical_shape)).astype(np.float32))
+            blk.finalize(torch.device('cuda', 0))
+            # (the materialised arm's conv3 on the SAME kernel: another tile gives the same outputs, but its BN statistics in
+            # another fp32 order, and bn3's coefficients then differ in the last bit)
+            g3 = blk.conv3.geometry(B, H, W)
+            monkeypatch.setitem(g3.tuned, ops._variant(g3, 'fprop16', True, False, True, False), ops.TILE_PW)
+            xv = Variable(x.clone(), requires_grad=True)
+            out = blk(xv)
+            fn = out.creator
+            assert fn.onload == [False, False, on_load] and (fn.h[1] is None) == on_load
+            out.grad = gy.clone()
+            blk.cleargrads()
+            out.backward()
+            ops.join_side_stream()
+            torch.cuda.synchronize()
+            res.append((out.data.clone(), xv.grad.clone(), {k: p.grad_logical().copy() for k, p in blk.namedparams()}))
+    finally:
+        loans_amd.set_compute_dtype('f32')
+    (o0, g0, p0), (o1, g1, p1) = res
+    assert torch.equal(o1, o0) and torch.equal(g1, g0)
+    for k in p0:
+        np.testing.assert_array_equal(p1[k], p0[k], err_msg=k)
