@@ -1,5 +1,5 @@
 #!/bin/bash
 set -o pipefail
 mkdir -p gpurun_out
-timeout -k 10 1100 python -m pytest tests/ -x -q -m gpu -p no:cacheprovider > gpurun_out/r5_gputest_full.log 2>&1; rc=$?
-echo "exit $rc"; tail -5 gpurun_out/r5_gputest_full.log
+(time python bench.py) > gpurun_out/r5_default_bench.log 2>&1; grep "^{" gpurun_out/r5_default_bench.log | tail -1 > gpurun_out/r5_default_bench.json; tail -4 gpurun_out/r5_default_bench.log | cut -c1-200
+bash tools/gputest_runs.sh 1 3
