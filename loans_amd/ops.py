@@ -1644,6 +1644,7 @@ class _StepArena:
     observers read them after the step."""
     SMALL = 4096
     ALIGN = 256
+    MAX_FRACTION = 0.5
 
     def __init__(self):
         self.buf, self.views, self.off, self.need, self.want, self.live, self.pinned, self.thread = None, {}, 0, 0, 0, False, [], None
@@ -1661,7 +1662,7 @@ class _StepArena:
             self.tried = self.want                  # one attempt per demand: a buffer that does not fit is not asked for every step
             size = (int(self.want * 1.06) + (64 << 20)) // 4096 * 4096
             total = torch.cuda.get_device_properties(device).total_memory
-            if size <= total // 2:                  # (more than half the device for one step's tensors: leave it to torch's allocator)
+            if size <= int(total * self.MAX_FRACTION):  # (more than half the device for one step's tensors: leave it to torch's allocator)
                 self.buf, self.views = None, {}
                 torch.cuda.empty_cache()            # what the sizing step left in torch's cache is this buffer's memory now
                 free, _ = torch.cuda.mem_get_info(device)
