@@ -102,6 +102,8 @@ typedef struct loans_igemm_desc {
 #define LOANS_TILE_64x64   3
 #define LOANS_TILE_256x64  4
 #define LOANS_TILE_64x128  5   /* wgrad only: 64 output channels x 128 tap-channel columns */
+#define LOANS_TILE_64x256  41  /* loans_wgrad_bf16s only: 64 output channels x 256 tap-channel columns -- layers with Cout <= 64 read their
+                                  gradient ONCE per pixel slice where K <= 256 (the RGB stem: K = 168; a bottleneck's 256 -> 64 reduction) */
 #define LOANS_TILE_SPLIT   6   /* igemm only: 128x128 tiles over the rows that fill whole machine rounds, 64x64 over the rest (two launches) */
 #define LOANS_TILE_256x128 7   /* loans_igemm_bf16s only: one 512-thread block per CU, three LDS stages (chunk c + 2 in flight) */
 #define LOANS_TILE_DEEP    32  /* loans_igemm_bf16s, OR-ed onto 128x128 / 128x64 / 64x64: a 4 / 5 / 8-stage LDS ring (3 / 4 / 7 chunks of K in

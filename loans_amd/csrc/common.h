@@ -114,6 +114,8 @@ int loans_stem7_rows(int Ho, int Wo, int Wp3, size_t* lds_bytes);
 int loans_stem7_launch(const float* in, const float* w, float* out, const float* bias, double* stats,
                        const loans_igemm_desc* d, hipStream_t st);
 int loans_stem7_wgrad_launch(const float* x, const float* gy, float* dw, const loans_igemm_desc* d, hipStream_t st);
+int loans_stem7_wgrad_bf16_slabs(const loans_igemm_desc* d);
+int loans_stem7_wgrad_bf16_launch(const void* x, const void* gy, float* dw, const loans_igemm_desc* d, float* ws, hipStream_t st);
 int loans_stem7_bf16_rows(int Ho, int Wo, int Wp3, size_t* lds_bytes);
 int loans_stem7_bf16_launch(const float* in, const float* w, void* out, const float* bias, double* stats,
                             const loans_igemm_desc* d, hipStream_t st);

@@ -466,6 +466,163 @@ __global__ __launch_bounds__(64 * SWG_NW) void stem7_wgrad_kernel(const float* x
         }
 }
 
+
+// ---- conv1's weight gradient on the bf16 MFMA (bf16 storage arm: the bf16 frame buffer of loans_prep_images_dense_bf16, a bf16
+// gradient; round 5).  As an implicit GEMM (wgrad16_kernel<64, 64>) this is the LAST launch of the joint step's backward -- it can
+// only start when the stem's BN / pool backward has written conv1's gradient, so nothing runs beside it -- and it takes 0.47 ms at
+// 128 x 3 x 512^2 for 0.20 ms of HBM traffic: K = 168 is three 64-column tiles that each gather their own 7 x 24 windows per
+// 32-pixel chunk, two MFMAs per wave between barriers (a 64 x 256 tile that reads the gradient once is SLOWER: 0.61-0.79 ms).
+// The direct form of stem7_wgrad_kernel: a block is persistent over units (one output row of one image), stages the unit's 7 input
+// rows (one contiguous run) and its gradient pixels [Wo][64] once, and contracts
+//   rows = 64 channels, columns = 147 real window positions (ky, j) in five 32-column tiles, reduction = pixels, 16 per MFMA:
+//   A = gy[ox0 + 8 h + i][channel]             (transposing LDS reads, ds_read_b64_tr_b16: the tile lies pixel-major)
+//   B = patch[ky][6 (ox0 + 8 h + i) + j]       (eight 2-byte LDS reads: consecutive pixels are 6 elements apart)
+// The eight waves split the row's 16-pixel steps and keep the whole 64 x 160 tile in registers over ALL the block's units.  The next
+// unit travels global -> registers while this one is contracted and registers -> the other LDS buffer behind it (one barrier per
+// unit); gradient rows are padded to 144 bytes in LDS (the four pixel rows of a transposing read then lie 36 banks apart).
+// One reduction over the waves through LDS at the very end; the block's tile goes to its slab of `ws` (plain stores, the
+// window-padding columns as zeros; loans_fold_slabs_f32 adds the slabs in a fixed order) or, without a workspace, to dw by atomics.
+constexpr int SWB_NW = 8;           // waves per block: two per SIMD, one block per CU
+constexpr int SWB_GS = 72;          // LDS stride of a gradient pixel (elements): 64 channels + 8
+constexpr int SWB_PX = 3;           // 16-byte pieces of the input run per thread (7 Wp3 + 14 <= 3 * 512 * 8 elements)
+constexpr int SWB_PG = 4;           // 16-byte pieces of the gradient row per thread (Wo <= 256)
+typedef unsigned su32x4 __attribute__((ext_vector_type(4)));
+
+__host__ __device__ inline int swb_x_pieces(int Wp3) { return (7 * Wp3 + 7 + 7) / 8 + 1; }     // whatever the run's lead (<= 7 elements)
+
+__global__ __launch_bounds__(64 * SWB_NW) void stem7_wgrad_bf16_kernel(const __bf16* x, const __bf16* gy, float* dw, float* ws, int Hp,
+                                                                  int Wp3, int Ho, int Wo, int units, unsigned x_bytes,
+                                                                  unsigned gy_bytes) {
+    extern __shared__ __attribute__((aligned(16))) char smem[];
+    typedef __attribute__((address_space(3))) sbf16x4* lds_b64_t;
+    const int nvx = swb_x_pieces(Wp3), nvg = Wo * 8;
+    const int patch_bytes = nvx * 16, buf_bytes = patch_bytes + Wo * SWB_GS * 2;
+    const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
+    const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(x), 0, (int)x_bytes, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(gy), 0, (int)gy_bytes, 0x00020000);
+
+    // per lane: the window position of each column tile (columns >= 147 re-read column 146; their sums are dropped)
+    int coff[SWG_CT];
+#pragma unroll
+    for (int ct = 0; ct < SWG_CT; ++ct) {
+        const int c = min(ct * 32 + r, 146);
+        const int ky = c / 21, j = c - ky * 21;
+        coff[ct] = ky * Wp3 + j + 48 * h;
+    }
+    // transposing reads of the gradient tile (as in wgrad16_kernel): 16-lane group (h, cg) takes pixels 8 h + 4 t .. + 3 and channels
+    // 16 cg .. + 15 of a 32-channel tile; lane 4 q + p of the group addresses pixel row q, channels 4 p .. 4 p + 3
+    const int li = lane & 15, fq = li >> 2, fp = li & 3, cg = (lane >> 4) & 1;
+    const int trg = (8 * h + fq) * SWB_GS + 16 * cg + 4 * fp;
+
+    f32x16 acc[2][SWG_CT];
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int ct = 0; ct < SWG_CT; ++ct)
+#pragma unroll
+            for (int e = 0; e < 16; ++e) acc[i][ct][e] = 0.f;
+
+    // unit u = output row oy of image b.  Its 7 input rows are one contiguous run of the padded buffer that starts 4-byte aligned:
+    // the copy starts at the 16-byte boundary below it and the image sits `lead` elements into the LDS buffer; pieces past the end
+    // of the tensor read zeros (buffer bounds), pieces past the end of the run the finite pixels behind it
+    su32x4 rx[SWB_PX], rg[SWB_PG];
+    auto run_of = [&](int u) { const int b = u / Ho, oy = u - b * Ho; return (unsigned)((b * Hp + 2 * oy) * Wp3) * 2u; };
+    auto fetch = [&](int u) {
+        const unsigned xal = run_of(u) & ~15u;
+        const unsigned grun = (unsigned)u * (unsigned)Wo * 128u;
+#pragma unroll
+        for (int q = 0; q < SWB_PX; ++q) {
+            const int v = tid + 64 * SWB_NW * q;
+            rx[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)((xal + 16u * (unsigned)v) | (v < nvx ? 0u : 0x80000000u)), 0, 0);
+        }
+#pragma unroll
+        for (int q = 0; q < SWB_PG; ++q) {
+            const int v = tid + 64 * SWB_NW * q;
+            rg[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_g, (int)((grun + 16u * (unsigned)v) | (v < nvg ? 0u : 0x80000000u)), 0, 0);
+        }
+    };
+    auto stash = [&](int buf) {
+        char* base = smem + buf * buf_bytes;
+#pragma unroll
+        for (int q = 0; q < SWB_PX; ++q) {
+            const int v = tid + 64 * SWB_NW * q;
+            if (v < nvx) *reinterpret_cast<su32x4*>(base + 16 * v) = rx[q];
+        }
+#pragma unroll
+        for (int q = 0; q < SWB_PG; ++q) {
+            const int v = tid + 64 * SWB_NW * q;
+            if (v < nvg) *reinterpret_cast<su32x4*>(base + patch_bytes + (v >> 3) * (SWB_GS * 2) + (v & 7) * 16) = rg[q];
+        }
+    };
+
+    const int nb = gridDim.x;
+    const int u_begin = (int)((long long)units * blockIdx.x / nb), u_end = (int)((long long)units * (blockIdx.x + 1) / nb);
+    const int ksteps = Wo >> 4;                                 // Wo % 16 == 0 (checked by the launcher)
+    int buf = 0;
+    if (u_begin < u_end) fetch(u_begin);
+    for (int u = u_begin; u < u_end; ++u) {
+        stash(buf);
+        __syncthreads();            // unit u is in LDS; every wave is done with unit u - 1 (the other buffer, rewritten at u + 1)
+        if (u + 1 < u_end) fetch(u + 1);
+        const __bf16* patch = reinterpret_cast<const __bf16*>(smem + buf * buf_bytes) + ((run_of(u) & 15u) >> 1);
+        const __bf16* gyt = reinterpret_cast<const __bf16*>(smem + buf * buf_bytes + patch_bytes);
+        for (int ks = wave; ks < ksteps; ks += SWB_NW) {
+            sbf16x8 af[2], bf[SWG_CT];
+            const __bf16* ap = gyt + 16 * ks * SWB_GS + trg;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const sbf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64_t)(ap + 32 * i));
+                const sbf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64_t)(ap + 32 * i + 4 * SWB_GS));
+                af[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+            }
+            const __bf16* bp = patch + 96 * ks;
+#pragma unroll
+            for (int ct = 0; ct < SWG_CT; ++ct)
+#pragma unroll
+                for (int i = 0; i < 8; ++i) bf[ct][i] = bp[coff[ct] + 6 * i];
+#pragma unroll
+            for (int ct = 0; ct < SWG_CT; ++ct) {
+                acc[0][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[ct], acc[0][ct], 0, 0, 0);
+                acc[1][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[ct], acc[1][ct], 0, 0, 0);
+            }
+        }
+        buf ^= 1;
+    }
+    // the waves' partial tiles -> one sum per element -> the block's slab / dw (+=)
+    float* const slab = ws ? ws + (size_t)blockIdx.x * (64 * 168) : nullptr;
+    if (slab)
+        for (int idx = tid; idx < 64 * 7 * 3; idx += 64 * SWB_NW) {
+            const int co = idx / 21, rem = idx - co * 21;
+            slab[co * 168 + (rem / 3) * 24 + 21 + rem % 3] = 0.f;
+        }
+    float* red = reinterpret_cast<float*>(smem);                // [SWB_NW][32][33]
+#pragma unroll
+    for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int ct = 0; ct < SWG_CT; ++ct) {
+            __syncthreads();
+#pragma unroll
+            for (int e = 0; e < 16; ++e)
+                red[(wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * 33 + r] = acc[i][ct][e];
+            __syncthreads();
+#pragma unroll
+            for (int q = 0; q < 1024 / (64 * SWB_NW); ++q) {
+                const int idx = tid + 64 * SWB_NW * q, row = idx >> 5, col = idx & 31;
+                float v = 0.f;
+#pragma unroll
+                for (int wv = 0; wv < SWB_NW; ++wv) v += red[(wv * 32 + row) * 33 + col];
+                const int c = ct * 32 + col;
+                if (c < 147) {
+                    const int ky = c / 21, j = c - ky * 21;
+                    const size_t o = (size_t)(i * 32 + row) * 168 + ky * 24 + j;
+                    if (slab) slab[o] = v;
+                    else atomic_add_f32(dw + o, v);
+                }
+            }
+        }
+}
+
 }  // namespace
 
 // rows per block for a frame geometry, 0 = not covered (the caller falls back to the implicit GEMM)
@@ -597,4 +754,40 @@ int loans_stem7_launch(const float* in, const float* w, float* out, const float*
         default: return LOANS_EINVAL;
     }
 #undef STEM_CASE
+}
+
+// LOANS_TILE_STEM of loans_wgrad_bf16s: `d` is the dense 7x7 / 2, Cout = 64 forward geometry on the bf16 frame buffer.
+// loans_stem7_wgrad_bf16_slabs: the blocks (= slabs of 64 x 168 floats) a launch runs, 0 = this geometry is not covered
+int loans_stem7_wgrad_bf16_slabs(const loans_igemm_desc* d) {
+    if (d->flags != LOANS_F_DENSE) return 0;
+    if (d->ntaps != 7 || d->Cin != 24 || d->Cout != 64 || d->isy != 2 || d->isx != 6) return 0;
+    if ((d->inW & 1) || (d->inH & 1) || (d->gridW & 15) || d->gridW > 64 * SWB_PG) return 0;
+    if (swb_x_pieces(d->inW) > 64 * SWB_NW * SWB_PX) return 0;
+    for (int t = 0; t < 7; ++t)
+        if (d->dy[t] != t || d->dx[t] != 0) return 0;
+    if (d->osy != 1 || d->osx != 1 || d->oy0 || d->ox0 || d->outH != d->gridH || d->outW != d->gridW) return 0;
+    if (2 * (d->gridH - 1) + 7 > d->inH || 6 * (d->gridW - 1) + 24 > d->inW) return 0;
+    const size_t lds = (size_t)2 * (swb_x_pieces(d->inW) * 16 + d->gridW * SWB_GS * 2);
+    if (lds > 156 * 1024) return 0;
+    const int cus = loans_device_cus();
+    if (cus <= 0) return 0;
+    const int64_t units = (int64_t)d->B * d->gridH;
+    return (int)(units < cus ? units : cus);
+}
+
+int loans_stem7_wgrad_bf16_launch(const void* x, const void* gy, float* dw, const loans_igemm_desc* d, float* ws, hipStream_t st) {
+    const int nblk = loans_stem7_wgrad_bf16_slabs(d);
+    if (nblk <= 0) return LOANS_EINVAL;
+    if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(gy) & 15) || (reinterpret_cast<uintptr_t>(ws) & 15)) return LOANS_EINVAL;
+    const int64_t xb = (int64_t)d->B * d->inH * d->inW * 2, gb = (int64_t)d->B * d->gridH * d->gridW * 128;
+    if (xb >= 0x7FFFFFF0ll || gb >= 0x7FFFFFF0ll) return LOANS_ERANGE;       // bit 31 of an offset marks a piece that is not loaded
+    size_t lds = (size_t)2 * (swb_x_pieces(d->inW) * 16 + d->gridW * SWB_GS * 2);
+    if (lds < (size_t)SWB_NW * 32 * 33 * sizeof(float)) lds = (size_t)SWB_NW * 32 * 33 * sizeof(float);
+    static loans_device_once lds_limit_set;
+    if (int rc_ = loans_raise_lds_limit(lds_limit_set, reinterpret_cast<const void*>(stem7_wgrad_bf16_kernel), 156 * 1024)) return rc_;
+    hipLaunchKernelGGL(stem7_wgrad_bf16_kernel, dim3(nblk), dim3(64 * SWB_NW), lds, st, reinterpret_cast<const __bf16*>(x),
+                       reinterpret_cast<const __bf16*>(gy), dw, ws, d->inH, d->inW, d->gridH, d->gridW, d->B * d->gridH, (unsigned)xb,
+                       (unsigned)gb);
+    LOANS_LAUNCH_CHECK();
+    return LOANS_OK;
 }

@@ -752,6 +752,20 @@ def stem_wgrad_ok(geo):
     return 2 * ((7 * geo.Wp * 3 * 4 + 1023) // 1024 + (geo.Wo + 3) // 4) * 1024 <= 156 * 1024
 
 
+STEM_WGRAD16_DIRECT = True      # (False: the A/B arm of tools/ab_ops_attr.py)
+
+
+def stem16_wgrad_ok(geo):
+    """LOANS_TILE_STEM of loans_wgrad_bf16s covers this geometry (loans_stem7_wgrad_bf16_slabs of csrc/stem.hip: the bf16 frame
+    buffer, rows of whole 16-pixel steps, at most 256 output pixels and 12 KB of input rows per unit)"""
+    if not (STEM_DIRECT and STEM_WGRAD16_DIRECT and geo.dense and geo.k == 7 and geo.stride == 2 and geo.pad == 3 and geo.Cout == 64):
+        return False
+    if 2 * geo.Ho + 5 > geo.Hp or geo.Hp % 2 or geo.Wo % 16 or geo.Wo > 256:
+        return False
+    pieces = (7 * geo.Wp * 3 + 14) // 8 + 1
+    return pieces <= 3 * 512 and 2 * (pieces * 16 + geo.Wo * 144) <= 156 * 1024
+
+
 @_memo
 def stem16_tile_rows(geo):
     """output rows per unit of LOANS_TILE_STEM on the bf16 MFMA (loans_stem7_bf16_rows of csrc/stem.hip), 0 = not covered"""
@@ -1426,7 +1440,8 @@ def _current_stream_obj(idx):
 
 
 _WGRAD_TILE_DIMS = {1: (128, 128, 2), 3: (64, 64, 4), 5: (64, 128, 3)}      # tile id -> (BCO, BJ, blocks per CU by LDS)
-_WGRAD16_TILE_DIMS = {1: (128, 128, 3), 3: (64, 64, 5), 5: (64, 128, 4), 9: (256, 256, 1)}    # bf16 tiles: smaller LDS images, register-bound
+_WGRAD16_TILE_DIMS = {1: (128, 128, 3), 3: (64, 64, 5), 5: (64, 128, 4), 9: (256, 256, 1), 41: (64, 256, 2)}    # bf16 tiles: smaller LDS images, register-bound
+TILE_64x256 = 41        # LOANS_TILE_64x256: Cout <= 64, 128 < K <= 256 read the gradient once per pixel slice (the RGB stem, a bottleneck's 256 -> 64)
 
 
 @_memo
@@ -1551,11 +1566,13 @@ def _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile, stream=None, in_affine=No
         cands = _WGRAD16_TILES if s16 else _WGRAD_TILES
         if s16 and geo.Cout % 256 == 0:
             cands = cands + (TILE_256x256,)         # one 512-thread block per CU (csrc/igemm_bf16.hip, wgrad16_kernel<256, 256, 8>)
+        if s16 and geo.Cout <= 64 and geo.w_numel // geo.Cout > 128:
+            cands = cands + (TILE_64x256,)
         if splits == 0:
             cands = _wgrad_candidates(geo, cands, 32, _WGRAD16_TILE_DIMS if s16 else None)
             if s16:
                 cands = tuple(cands) + _wghalo_candidates(geo)
-        stem = stem_wgrad_ok(geo) and wfn is lib.loans_wgrad_f32 and fl == F_DENSE
+        stem = fl == F_DENSE and ((stem_wgrad_ok(geo) and wfn is lib.loans_wgrad_f32) or (s16 and stem16_wgrad_ok(geo)))
         if stem:
             cands = tuple(cands) + (TILE_STEM,)
         tile = _tuned_tile(geo, _wgrad_key(x, gy, relu_in) + ('' if splits == 0 else '_s%d' % splits) + ('_st' if stem else ''),

@@ -308,12 +308,69 @@ def test_region_boundaries_bf16_storage():
             assert cb.dtype == torch.bfloat16
             assert rel_err(cb.float().cpu().numpy(), c32.cpu().numpy()) < 2 ** -7, t
             assert rel_err(sb.sum(0).cpu().numpy(), s32.sum(0).cpu().numpy()) < 1e-5, t
-        for t in (1, 3, 5):
+        assert ops.stem16_wgrad_ok(geo)
+        for t in (1, 3, 5, ops.TILE_STEM):
             dwb = torch.zeros_like(wd)
             ops._conv_wgrad(xp16, d16(gc), dwb, geo, False, 0, t)
             assert rel_err(dwb.cpu().numpy(), dw32.cpu().numpy()) < 1e-5, t
     finally:
         ops.set_compute_dtype('f32')
+
+
+@pytest.mark.parametrize("case", [(3, 96, 96), (2, 64, 160), (5, 32, 32), (1, 224, 224), (300, 32, 64)])
+def test_stem_weight_gradient_direct_bf16(case, monkeypatch):
+    """LOANS_TILE_STEM of loans_wgrad_bf16s (csrc/stem.hip: stem7_wgrad_bf16_kernel, round 5): conv1's weight gradient from the bf16
+    frame buffer and a bf16 gradient as a direct, persistent kernel, against the implicit-GEMM tile on the same operands (fp32 sums of
+    the same products: 1e-5) -- several units per block and fewer units than blocks, runs that start at every 4-byte alignment, more
+    images than compute units; the slab form is bit-reproducible, accumulates into dw and leaves the window-padding columns alone;
+    the atomic form (no workspace) agrees."""
+    from loans_amd import ops
+    B, H, W = case
+    rng = np.random.RandomState(B + H)
+    ops.set_compute_dtype('bf16'); ops.set_storage_dtype('bf16')
+    try:
+        geo = ops.ConvGeometry(B, H, W, 3, 64, 7, 2, 3, dense=True)
+        assert ops.stem16_wgrad_ok(geo)
+        xp = ops.prep_images(dev(rng.uniform(-1, 1, (B, 3, H, W)).astype(np.float32)), geo)
+        assert xp.dtype == torch.bfloat16
+        gy = d16(rng.standard_normal((B, geo.Ho, geo.Wo, 64)).astype(np.float32))
+        ref = torch.zeros((64, 7, geo.kwp, 3), device='cuda')
+        ops._conv_wgrad(xp, gy, ref, geo, False, 0, 3)
+        assert float(ref.abs().max()) > 0 and float(ref[:, :, 7:].abs().max()) == 0      # column 7 of a row is window padding
+        runs = []
+        for _ in range(2):
+            dw = torch.zeros_like(ref)
+            ops._conv_wgrad(xp, gy, dw, geo, False, 0, ops.TILE_STEM)
+            runs.append(dw)
+        assert torch.equal(runs[0], runs[1])
+        assert rel_err(runs[0].cpu().numpy(), ref.cpu().numpy()) < 1e-5
+        start = dev(rng.standard_normal(tuple(ref.shape)).astype(np.float32))
+        dw = start.clone()
+        ops._conv_wgrad(xp, gy, dw, geo, False, 0, ops.TILE_STEM)
+        assert torch.equal(dw[:, :, 7:], start[:, :, 7:])
+        assert rel_err((dw - start)[:, :, :7].cpu().numpy(), ref[:, :, :7].cpu().numpy()) < 1e-5
+        monkeypatch.setattr(ops, 'WGRAD_SLABS', False)
+        atomic = torch.zeros_like(ref)
+        ops._conv_wgrad(xp, gy, atomic, geo, False, 0, ops.TILE_STEM)
+        assert rel_err(atomic.cpu().numpy(), ref.cpu().numpy()) < 1e-5
+    finally:
+        ops.set_compute_dtype('f32'); ops.set_storage_dtype('f32')
+
+
+def test_stem_weight_gradient_direct_bf16_refuses_what_it_does_not_cover():
+    """frames whose output rows are not whole 16-pixel steps (200 px -> 100) stay on the implicit-GEMM tiles: the autotuner is not
+    offered the direct kernel, and asking for it by name is an error, not a wrong answer"""
+    from loans_amd import ops
+    ops.set_compute_dtype('bf16'); ops.set_storage_dtype('bf16')
+    try:
+        geo = ops.ConvGeometry(2, 200, 200, 3, 64, 7, 2, 3, dense=True)
+        assert not ops.stem16_wgrad_ok(geo)
+        xp = ops.prep_images(torch.rand((2, 3, 200, 200), device='cuda'), geo)
+        gy = torch.randn((2, geo.Ho, geo.Wo, 64), device='cuda').to(torch.bfloat16)
+        with pytest.raises(Exception):
+            ops._conv_wgrad(xp, gy, torch.zeros((64, 7, geo.kwp, 3), device='cuda'), geo, False, 0, ops.TILE_STEM)
+    finally:
+        ops.set_compute_dtype('f32'); ops.set_storage_dtype('f32')
 
 
 def test_assessor_edges_bf16_storage():
