@@ -102,8 +102,6 @@ typedef struct loans_igemm_desc {
 #define LOANS_TILE_64x64   3
 #define LOANS_TILE_256x64  4
 #define LOANS_TILE_64x128  5   /* wgrad only: 64 output channels x 128 tap-channel columns */
-#define LOANS_TILE_64x256  41  /* loans_wgrad_bf16s only: 64 output channels x 256 tap-channel columns -- layers with Cout <= 64 read their
-                                  gradient ONCE per pixel slice where K <= 256 (the RGB stem: K = 168; a bottleneck's 256 -> 64 reduction) */
 #define LOANS_TILE_SPLIT   6   /* igemm only: 128x128 tiles over the rows that fill whole machine rounds, 64x64 over the rest (two launches) */
 #define LOANS_TILE_256x128 7   /* loans_igemm_bf16s only: one 512-thread block per CU, three LDS stages (chunk c + 2 in flight) */
 #define LOANS_TILE_DEEP    32  /* loans_igemm_bf16s, OR-ed onto 128x128 / 128x64 / 64x64: a 4 / 5 / 8-stage LDS ring (3 / 4 / 7 chunks of K in
@@ -124,7 +122,12 @@ typedef struct loans_igemm_desc {
                                   persistent direct kernel -- per output row the 7 input rows and the row's gradient pixels arrive by
                                   LDS-DMA (double-buffered), rows = 64 channels, columns = the 147 real window positions, every wave
                                   keeps the whole 64 x 160 tile in registers over all its units; the three window-padding columns of
-                                  dw [64][7][24] are not written.  LOANS_EINVAL when two unit buffers exceed 156 KB */
+                                  dw [64][7][24] are not written.  LOANS_EINVAL when two unit buffers exceed 156 KB.
+                                  loans_wgrad_bf16s / _ws with LOANS_F_DENSE (bf16 frame buffer, bf16 gradient; `splits` ignored): the same
+                                  scheme on the bf16 MFMA, 16 pixels per step -- the gradient tile read with transposing LDS reads, the
+                                  next unit staged through registers; one slab of the workspace per block (loans_wgrad_bf16s_ws_floats
+                                  says how many) or, without one, atomics.  LOANS_EINVAL unless Wo % 16 == 0, Wo <= 256 and the unit's
+                                  7 input rows are at most 12 280 elements */
 #define LOANS_TILE_HALO_128    11  /* loans_igemm_bf16s, stride-1 geometries (forward k x k / 1 and its data gradient, k <= 3, Cin % 64 == 0):
                                       a block owns an 8 x 16 pixel tile x 128 output channels and stages the input halo image once
                                       per 64-channel chunk -- a tap is an LDS window shift, not a gather (csrc/halo_bf16.hip) */

@@ -1000,11 +1000,6 @@ int launch_wgrad16_r(Wgrad16Args& a, int splits_req, hipStream_t st) {
     return LOANS_OK;
 }
 
-#ifndef LOANS_W64x256_WAVES
-#define LOANS_W64x256_WAVES 4
-#endif
-constexpr int W64x256_WAVES = LOANS_W64x256_WAVES;
-
 template <int BCO, int BJ, int NWV = 4>
 int launch_wgrad16(Wgrad16Args& a, int splits_req, hipStream_t st) {
     return (a.d.flags & LOANS_F_RELU_IN) ? launch_wgrad16_r<BCO, BJ, NWV, true>(a, splits_req, st)
@@ -1333,7 +1328,6 @@ static int wgrad_bf16s_impl(const void* x, const void* gy, float* dw, const loan
     else if (tile == LOANS_TILE_64x64) slabs = plan_wgrad16<64, 64>(a, splits);
     else if (tile == LOANS_TILE_128x128) slabs = plan_wgrad16<128, 128>(a, splits);
     else if (tile == LOANS_TILE_64x128) slabs = plan_wgrad16<64, 128>(a, splits);
-    else if (tile == LOANS_TILE_64x256) slabs = plan_wgrad16<64, 256>(a, splits);
     else if (tile == LOANS_TILE_256x256) slabs = plan_wgrad16<256, 256>(a, splits);
     else return LOANS_EINVAL;
     if (slabs < 1) return slabs < 0 ? slabs : LOANS_EINVAL;
@@ -1348,7 +1342,6 @@ static int wgrad_bf16s_impl(const void* x, const void* gy, float* dw, const loan
     else if (tile == LOANS_TILE_64x64) rc = launch_wgrad16<64, 64>(a, splits, st);
     else if (tile == LOANS_TILE_128x128) rc = launch_wgrad16<128, 128>(a, splits, st);
     else if (tile == LOANS_TILE_64x128) rc = launch_wgrad16<64, 128>(a, splits, st);
-    else if (tile == LOANS_TILE_64x256) rc = launch_wgrad16<64, 256, W64x256_WAVES>(a, splits, st);
     else rc = launch_wgrad16<256, 256, 8>(a, splits, st);
     if (rc != LOANS_OK || !use_ws) return rc;
     return loans_fold_slabs_f32(ws, dw, a.slab, slabs, stream);

@@ -1440,8 +1440,7 @@ def _current_stream_obj(idx):
 
 
 _WGRAD_TILE_DIMS = {1: (128, 128, 2), 3: (64, 64, 4), 5: (64, 128, 3)}      # tile id -> (BCO, BJ, blocks per CU by LDS)
-_WGRAD16_TILE_DIMS = {1: (128, 128, 3), 3: (64, 64, 5), 5: (64, 128, 4), 9: (256, 256, 1), 41: (64, 256, 2)}    # bf16 tiles: smaller LDS images, register-bound
-TILE_64x256 = 41        # LOANS_TILE_64x256: Cout <= 64, 128 < K <= 256 read the gradient once per pixel slice (the RGB stem, a bottleneck's 256 -> 64)
+_WGRAD16_TILE_DIMS = {1: (128, 128, 3), 3: (64, 64, 5), 5: (64, 128, 4), 9: (256, 256, 1)}    # bf16 tiles: smaller LDS images, register-bound
 
 
 @_memo
@@ -1566,8 +1565,6 @@ def _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile, stream=None, in_affine=No
         cands = _WGRAD16_TILES if s16 else _WGRAD_TILES
         if s16 and geo.Cout % 256 == 0:
             cands = cands + (TILE_256x256,)         # one 512-thread block per CU (csrc/igemm_bf16.hip, wgrad16_kernel<256, 256, 8>)
-        if s16 and geo.Cout <= 64 and geo.w_numel // geo.Cout > 128:
-            cands = cands + (TILE_64x256,)
         if splits == 0:
             cands = _wgrad_candidates(geo, cands, 32, _WGRAD16_TILE_DIMS if s16 else None)
             if s16:

@@ -141,6 +141,8 @@ class Variable:
                 gxs = f.backward(tuple(x.data for x in f.inputs), gys)
             if not isinstance(gxs, tuple):
                 gxs = (gxs,)
+            if ops.PROBE_LOG is not None:       # development probes (tools/host_lead.py): an event behind every function's backward
+                ops.probe('  backward of ' + type(f).__name__)
             for o in outs:      # gradients of intermediate outputs are consumed
                 if o is not None and not retain_grad and o is not self:
                     grads.pop(id(o), None)

@@ -1,7 +1,7 @@
 #!/usr/bin/env python
 """Where in a step the host runs ahead of the GPU (development probe): HIP events at a few points of the joint step, each with the
 host's clock at enqueue time; both clocks are anchored at a synchronize() before the first probed step.
-usage: host_lead.py [cfg3|b256|r50]"""
+usage: host_lead.py [cfg3|b256|r50] [--fine]"""
 import os
 import sys
 import time
@@ -12,6 +12,8 @@ import bench                # noqa: E402
 from loans_amd import ops, parallel      # noqa: E402
 from loans_amd.runtime import training      # noqa: E402
 
+fine = [a for a in sys.argv[1:] if a == '--fine']        # --fine: also the event behind every function's backward
+sys.argv = [a for a in sys.argv if a != '--fine']
 what = sys.argv[1] if len(sys.argv) > 1 else 'cfg3'
 sys.argv = [sys.argv[0]]
 args = bench.parse()
@@ -45,6 +47,8 @@ step = -1
 for name, ev, host in log[1:]:
     if name == 'step begin':
         step += 1
-    if step in (0, 1, 4, 5):
+    if name.startswith('  ') and '--fine' not in fine:
+        continue
+    if step in ((4,) if fine else (0, 1, 4, 5)):
         h, g = (host - a_host) * 1e3, a_ev.elapsed_time(ev)
         print('step %d %-37s %12.3f %12.3f %10.3f' % (step, name, h, g, g - h))

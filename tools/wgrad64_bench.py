@@ -45,7 +45,7 @@ for name, B, H, W, Cin, Cout, k, s, p, dense in cases:
         dw = torch.zeros((Cout, k, k, Cin), device='cuda')
     gy = torch.randn((B, geo.Ho, geo.Wo, Cout), device='cuda').to(torch.bfloat16)
     alg = (x.numel() + gy.numel()) * 2 + dw.numel() * 4
-    cands = ops._wgrad_candidates(geo, ops._WGRAD16_TILES + (ops.TILE_64x256,), 32, ops._WGRAD16_TILE_DIMS)
+    cands = ops._wgrad_candidates(geo, ops._WGRAD16_TILES, 32, ops._WGRAD16_TILE_DIMS)
     if dense and ops.stem16_wgrad_ok(geo):
         cands = tuple(cands) + (ops.TILE_STEM,)
     res = {t: timeit(lambda: ops._conv_wgrad(x, gy, dw, geo, False, 0, t), args.reps) for t in cands}
