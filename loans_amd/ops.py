@@ -1408,7 +1408,8 @@ def _wgrad_key(x, gy, relu_in):
 def conv_wgrad(x, gy, dw, geo, relu_in=False, splits=0, tile=0, in_affine=None):
     """dw[Cout,k,k,Cin] += sum over pixels (atomic accumulate into the gradient arena).  in_affine (a BNState; affine_in_ok): x is
     the INPUT of the BN in front of the convolution, the kernel contracts gy with relu(x * scale + shift) rounded to bf16."""
-    tuned = geo.tuned.get(_wgrad_key(x, gy, relu_in)) is not None
+    key = _wgrad_key(x, gy, relu_in)
+    tuned = geo.tuned.get(key) is not None or geo.tuned.get(key + '_st') is not None      # ('_st': the stem's candidates, _conv_wgrad)
     if ASYNC_WGRAD and tuned and (CAPTURE_STREAMS or not torch.cuda.is_current_stream_capturing()):
         side = _wgrad_stream(x.device)
         side.wait_stream(_current_stream_obj(x.device.index))

@@ -211,6 +211,26 @@ def test_stem_wgrad_direct(case):
     assert rel_err(dw.cpu().numpy()[:, :, :7].transpose(0, 3, 1, 2), 2 * gw_ref) < 5e-6
 
 
+def test_stem_weight_gradient_leaves_the_calling_stream():
+    """conv_wgrad sends a weight gradient to the weight-gradient stream once its shape is tuned.  The stem's table entry is kept under
+    a key of its own (the direct kernel is among its candidates); rounds 2-5 looked it up under the plain key, found nothing and left
+    conv1's weight gradient on the calling stream for good: +0.16 ms per fp32 step (profiles/r5_issue_orders_ab.txt)."""
+    from loans_amd import ops
+    geo = ops.ConvGeometry(2, 64, 64, 3, 64, 7, 2, 3, dense=True)
+    x = ops.prep_images(torch.rand((2, 3, 64, 64), device='cuda'), geo)
+    gy = torch.randn((2, geo.Ho, geo.Wo, 64), device='cuda')
+    ref, dw = torch.zeros((64, 7, geo.kwp, 3), device='cuda'), torch.zeros((64, 7, geo.kwp, 3), device='cuda')
+    assert ops.ASYNC_WGRAD and ops.stem_wgrad_ok(geo)
+    ops.conv_wgrad(x, gy, ref, geo)                 # the first call times the candidates (on the calling stream)
+    ops.join_side_stream()
+    assert x.device.index not in ops._side_dirty
+    ops.conv_wgrad(x, gy, dw, geo)
+    assert x.device.index in ops._side_dirty        # ... the second one was handed to the weight-gradient stream
+    ops.join_side_stream()
+    torch.cuda.synchronize()
+    assert torch.allclose(dw, ref, rtol=1e-4, atol=1e-3 * float(ref.abs().max()))
+
+
 def test_prep_images_exact():
     from loans_amd import ops
     rng = np.random.RandomState(0)
