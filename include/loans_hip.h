@@ -124,10 +124,11 @@ typedef struct loans_igemm_desc {
                                   keeps the whole 64 x 160 tile in registers over all its units; the three window-padding columns of
                                   dw [64][7][24] are not written.  LOANS_EINVAL when two unit buffers exceed 156 KB.
                                   loans_wgrad_bf16s / _ws with LOANS_F_DENSE (bf16 frame buffer, bf16 gradient; `splits` ignored): the same
-                                  scheme on the bf16 MFMA, 16 pixels per step -- the gradient tile read with transposing LDS reads, the
-                                  next unit staged through registers; one slab of the workspace per block (loans_wgrad_bf16s_ws_floats
-                                  says how many) or, without one, atomics.  LOANS_EINVAL unless Wo % 16 == 0, Wo <= 256 and the unit's
-                                  7 input rows are at most 12 280 elements */
+                                  scheme on the bf16 MFMA, 16 pixels per step -- both operands read with transposing LDS reads (the
+                                  input rows staged as 12-byte cells, one per 16 bytes: a kernel row is one 32-column tile), the next
+                                  unit staged through registers; one slab of the workspace per block (loans_wgrad_bf16s_ws_floats
+                                  says how many) or, without one, atomics.  LOANS_EINVAL unless Wo % 16 == 0, Wo <= 256 and
+                                  inW == 6 (Wo + 3) (even frame widths) */
 #define LOANS_TILE_HALO_128    11  /* loans_igemm_bf16s, stride-1 geometries (forward k x k / 1 and its data gradient, k <= 3, Cin % 64 == 0):
                                       a block owns an 8 x 16 pixel tile x 128 output channels and stages the input halo image once
                                       per 64-channel chunk -- a tap is an LDS window shift, not a gather (csrc/halo_bf16.hip) */

@@ -473,68 +473,70 @@ __global__ __launch_bounds__(64 * SWG_NW) void stem7_wgrad_kernel(const float* x
 // 128 x 3 x 512^2 for 0.20 ms of HBM traffic: K = 168 is three 64-column tiles that each gather their own 7 x 24 windows per
 // 32-pixel chunk, two MFMAs per wave between barriers (a 64 x 256 tile that reads the gradient once is SLOWER: 0.61-0.79 ms).
 // The direct form of stem7_wgrad_kernel: a block is persistent over units (one output row of one image), stages the unit's 7 input
-// rows (one contiguous run) and its gradient pixels [Wo][64] once, and contracts
-//   rows = 64 channels, columns = 147 real window positions (ky, j) in five 32-column tiles, reduction = pixels, 16 per MFMA:
-//   A = gy[ox0 + 8 h + i][channel]             (transposing LDS reads, ds_read_b64_tr_b16: the tile lies pixel-major)
-//   B = patch[ky][6 (ox0 + 8 h + i) + j]       (eight 2-byte LDS reads: consecutive pixels are 6 elements apart)
-// The eight waves split the row's 16-pixel steps and keep the whole 64 x 160 tile in registers over ALL the block's units.  The next
-// unit travels global -> registers while this one is contracted and registers -> the other LDS buffer behind it (one barrier per
-// unit); gradient rows are padded to 144 bytes in LDS (the four pixel rows of a transposing read then lie 36 banks apart).
-// One reduction over the waves through LDS at the very end; the block's tile goes to its slab of `ws` (plain stores, the
+// rows and its gradient pixels [Wo][64] once, and contracts rows = 64 channels x columns = window positions over 16 pixels per MFMA.
+// Both operands lie pixel-major and are read with ds_read_b64_tr_b16 (the transposing LDS read, as in wgrad16_kernel):
+//   A = gy[ox0 + 8 h + i][channel]: rows padded to 144 bytes (the four pixel rows of a read lie 36 banks apart);
+//   B = x[2 oy + ky][6 (ox0 + 8 h + i) + j]: consecutive pixels lie 6 elements = 12 bytes apart, which no wide LDS read takes (the
+//       first version gathered eight ds_read_u16 per fragment: 640 per unit, LDS-bound at 0.215 ms without a single global load).
+//       The 7 input rows are one run of 12-byte CELLS (two frame pixels = the stride of the window), 7 (Wo + 3) of them; staged one
+//       cell per 16 bytes, pixel ox's window of a row is the 32 elements from cell ox on -- column n' = 8 a + b' is element b' of
+//       cell ox + a = window position j = 6 a + b' (b' = 6, 7 are padding, their sums are dropped) -- and a kernel row is ONE
+//       32-column MFMA tile with a pixel stride of 16 bytes: two transposing reads per fragment.  7 x 32 = 224 computed columns for
+//       147 real ones: the MFMA pipe has the room (1 800 of a unit's 5 300 HBM cycles).
+// Waves 0-3 own kernel rows 0-3, waves 4-7 rows 4-6, all 64 channels each (128 / 96 accumulator registers); the four waves of a group
+// split the row's 16-pixel steps and keep their tiles over ALL the block's units.  The next unit travels global -> registers while
+// this one is contracted (buffer_load_dwordx3 per cell), registers -> the other LDS buffer behind it: one barrier per unit.  One
+// reduction over each group's waves through LDS at the very end; the block's tile goes to its slab of `ws` (plain stores, the
 // window-padding columns as zeros; loans_fold_slabs_f32 adds the slabs in a fixed order) or, without a workspace, to dw by atomics.
 constexpr int SWB_NW = 8;           // waves per block: two per SIMD, one block per CU
 constexpr int SWB_GS = 72;          // LDS stride of a gradient pixel (elements): 64 channels + 8
-constexpr int SWB_PX = 3;           // 16-byte pieces of the input run per thread (7 Wp3 + 14 <= 3 * 512 * 8 elements)
+constexpr int SWB_PC = 4;           // input cells per thread and unit (7 (Wo + 3) <= 2048)
 constexpr int SWB_PG = 4;           // 16-byte pieces of the gradient row per thread (Wo <= 256)
 typedef unsigned su32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned su32x3 __attribute__((ext_vector_type(3)));
 
-__host__ __device__ inline int swb_x_pieces(int Wp3) { return (7 * Wp3 + 7 + 7) / 8 + 1; }     // whatever the run's lead (<= 7 elements)
+__host__ __device__ inline int swb_patch_bytes(int Wo) { return 7 * (Wo + 3) * 16; }
 
 __global__ __launch_bounds__(64 * SWB_NW) void stem7_wgrad_bf16_kernel(const __bf16* x, const __bf16* gy, float* dw, float* ws, int Hp,
                                                                   int Wp3, int Ho, int Wo, int units, unsigned x_bytes,
                                                                   unsigned gy_bytes) {
     extern __shared__ __attribute__((aligned(16))) char smem[];
     typedef __attribute__((address_space(3))) sbf16x4* lds_b64_t;
-    const int nvx = swb_x_pieces(Wp3), nvg = Wo * 8;
-    const int patch_bytes = nvx * 16, buf_bytes = patch_bytes + Wo * SWB_GS * 2;
+    const int ncr = Wo + 3, ncell = 7 * ncr, nvg = Wo * 8;      // cells per input row (Wp3 = 6 ncr: checked), per unit; gradient pieces
+    const int patch_bytes = swb_patch_bytes(Wo), buf_bytes = patch_bytes + Wo * SWB_GS * 2;
     const int tid = threadIdx.x, lane = tid & 63, r = lane & 31, h = lane >> 5;
     const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int grp = wave >> 2, wq = wave & 3;                   // kernel rows 4 grp .. (3 of them in group 1); the group's step phase
+    const int nt = grp ? 3 : 4;
     const __amdgpu_buffer_rsrc_t rs_x = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(x), 0, (int)x_bytes, 0x00020000);
     const __amdgpu_buffer_rsrc_t rs_g = __builtin_amdgcn_make_buffer_rsrc(const_cast<__bf16*>(gy), 0, (int)gy_bytes, 0x00020000);
 
-    // per lane: the window position of each column tile (columns >= 147 re-read column 146; their sums are dropped)
-    int coff[SWG_CT];
-#pragma unroll
-    for (int ct = 0; ct < SWG_CT; ++ct) {
-        const int c = min(ct * 32 + r, 146);
-        const int ky = c / 21, j = c - ky * 21;
-        coff[ct] = ky * Wp3 + j + 48 * h;
-    }
-    // transposing reads of the gradient tile (as in wgrad16_kernel): 16-lane group (h, cg) takes pixels 8 h + 4 t .. + 3 and channels
-    // 16 cg .. + 15 of a 32-channel tile; lane 4 q + p of the group addresses pixel row q, channels 4 p .. 4 p + 3
+    // transposing reads: 16-lane group (h, cg) takes pixels 8 h + 4 t .. + 3 and columns 16 cg .. + 15 of a 32-column tile; lane
+    // 4 q + p of the group addresses pixel row q, columns 4 p .. 4 p + 3 (element offsets below; the second read is 4 pixels on)
     const int li = lane & 15, fq = li >> 2, fp = li & 3, cg = (lane >> 4) & 1;
-    const int trg = (8 * h + fq) * SWB_GS + 16 * cg + 4 * fp;
+    const int trg = (8 * h + fq) * SWB_GS + 16 * cg + 4 * fp;   // gradient tile: pixel stride SWB_GS
+    const int trb = (8 * h + fq) * 8 + 16 * cg + 4 * fp;        // input cells: pixel stride 8 elements
 
-    f32x16 acc[2][SWG_CT];
+    f32x16 acc[2][4];
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int ct = 0; ct < SWG_CT; ++ct)
+        for (int t = 0; t < 4; ++t)
 #pragma unroll
-            for (int e = 0; e < 16; ++e) acc[i][ct][e] = 0.f;
+            for (int e = 0; e < 16; ++e) acc[i][t][e] = 0.f;
 
-    // unit u = output row oy of image b.  Its 7 input rows are one contiguous run of the padded buffer that starts 4-byte aligned:
-    // the copy starts at the 16-byte boundary below it and the image sits `lead` elements into the LDS buffer; pieces past the end
-    // of the tensor read zeros (buffer bounds), pieces past the end of the run the finite pixels behind it
-    su32x4 rx[SWB_PX], rg[SWB_PG];
-    auto run_of = [&](int u) { const int b = u / Ho, oy = u - b * Ho; return (unsigned)((b * Hp + 2 * oy) * Wp3) * 2u; };
+    // unit u = output row oy of image b: its 7 input rows are 7 (Wo + 3) consecutive 12-byte cells of the padded buffer (4-byte
+    // aligned), its gradient pixels Wo x 128 contiguous bytes
+    su32x3 rx[SWB_PC];
+    su32x4 rg[SWB_PG];
     auto fetch = [&](int u) {
-        const unsigned xal = run_of(u) & ~15u;
+        const int b = u / Ho, oy = u - b * Ho;
+        const unsigned xrun = (unsigned)((b * Hp + 2 * oy) * Wp3) * 2u;
         const unsigned grun = (unsigned)u * (unsigned)Wo * 128u;
 #pragma unroll
-        for (int q = 0; q < SWB_PX; ++q) {
-            const int v = tid + 64 * SWB_NW * q;
-            rx[q] = __builtin_amdgcn_raw_buffer_load_b128(rs_x, (int)((xal + 16u * (unsigned)v) | (v < nvx ? 0u : 0x80000000u)), 0, 0);
+        for (int q = 0; q < SWB_PC; ++q) {
+            const int c = tid + 64 * SWB_NW * q;
+            rx[q] = __builtin_amdgcn_raw_buffer_load_b96(rs_x, (int)((xrun + 12u * (unsigned)c) | (c < ncell ? 0u : 0x80000000u)), 0, 0);
         }
 #pragma unroll
         for (int q = 0; q < SWB_PG; ++q) {
@@ -545,9 +547,9 @@ __global__ __launch_bounds__(64 * SWB_NW) void stem7_wgrad_bf16_kernel(const __b
     auto stash = [&](int buf) {
         char* base = smem + buf * buf_bytes;
 #pragma unroll
-        for (int q = 0; q < SWB_PX; ++q) {
-            const int v = tid + 64 * SWB_NW * q;
-            if (v < nvx) *reinterpret_cast<su32x4*>(base + 16 * v) = rx[q];
+        for (int q = 0; q < SWB_PC; ++q) {
+            const int c = tid + 64 * SWB_NW * q;
+            if (c < ncell) *reinterpret_cast<su32x4*>(base + 16 * c) = su32x4{rx[q].x, rx[q].y, rx[q].z, 0u};
         }
 #pragma unroll
         for (int q = 0; q < SWB_PG; ++q) {
@@ -565,59 +567,68 @@ __global__ __launch_bounds__(64 * SWB_NW) void stem7_wgrad_bf16_kernel(const __b
         stash(buf);
         __syncthreads();            // unit u is in LDS; every wave is done with unit u - 1 (the other buffer, rewritten at u + 1)
         if (u + 1 < u_end) fetch(u + 1);
-        const __bf16* patch = reinterpret_cast<const __bf16*>(smem + buf * buf_bytes) + ((run_of(u) & 15u) >> 1);
-        const __bf16* gyt = reinterpret_cast<const __bf16*>(smem + buf * buf_bytes + patch_bytes);
-        for (int ks = wave; ks < ksteps; ks += SWB_NW) {
-            sbf16x8 af[2], bf[SWG_CT];
-            const __bf16* ap = gyt + 16 * ks * SWB_GS + trg;
+        const __bf16* cells = reinterpret_cast<const __bf16*>(smem + buf * buf_bytes) + (4 * grp * ncr) * 8 + trb;
+        const __bf16* gyt = reinterpret_cast<const __bf16*>(smem + buf * buf_bytes + patch_bytes) + trg;
+        for (int ks = wq; ks < ksteps; ks += 4) {
+            sbf16x8 af[2], bf[4];
+            const __bf16* ap = gyt + 16 * ks * SWB_GS;
 #pragma unroll
             for (int i = 0; i < 2; ++i) {
                 const sbf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64_t)(ap + 32 * i));
                 const sbf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64_t)(ap + 32 * i + 4 * SWB_GS));
                 af[i] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
             }
-            const __bf16* bp = patch + 96 * ks;
+            const __bf16* bp = cells + 16 * ks * 8;
 #pragma unroll
-            for (int ct = 0; ct < SWG_CT; ++ct)
+            for (int t = 0; t < 4; ++t)
+                if (t < nt) {
+                    const sbf16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64_t)(bp + t * ncr * 8));
+                    const sbf16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b64_t)(bp + t * ncr * 8 + 32));
+                    bf[t] = __builtin_shufflevector(lo, hi, 0, 1, 2, 3, 4, 5, 6, 7);
+                }
 #pragma unroll
-                for (int i = 0; i < 8; ++i) bf[ct][i] = bp[coff[ct] + 6 * i];
-#pragma unroll
-            for (int ct = 0; ct < SWG_CT; ++ct) {
-                acc[0][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[ct], acc[0][ct], 0, 0, 0);
-                acc[1][ct] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[ct], acc[1][ct], 0, 0, 0);
-            }
+            for (int t = 0; t < 4; ++t)
+                if (t < nt) {
+                    acc[0][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[0], bf[t], acc[0][t], 0, 0, 0);
+                    acc[1][t] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[1], bf[t], acc[1][t], 0, 0, 0);
+                }
         }
         buf ^= 1;
     }
-    // the waves' partial tiles -> one sum per element -> the block's slab / dw (+=)
+    // each group's four partial tiles -> one sum per element -> the block's slab / dw (+=)
     float* const slab = ws ? ws + (size_t)blockIdx.x * (64 * 168) : nullptr;
     if (slab)
         for (int idx = tid; idx < 64 * 7 * 3; idx += 64 * SWB_NW) {
             const int co = idx / 21, rem = idx - co * 21;
             slab[co * 168 + (rem / 3) * 24 + 21 + rem % 3] = 0.f;
         }
-    float* red = reinterpret_cast<float*>(smem);                // [SWB_NW][32][33]
+    float* red = reinterpret_cast<float*>(smem) + grp * (4 * 32 * 33);         // [4 waves][32][33] per group
+    const int gt = tid & 255;
 #pragma unroll
     for (int i = 0; i < 2; ++i)
 #pragma unroll
-        for (int ct = 0; ct < SWG_CT; ++ct) {
+        for (int t = 0; t < 4; ++t) {
             __syncthreads();
+            if (t < nt) {
 #pragma unroll
-            for (int e = 0; e < 16; ++e)
-                red[(wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * 33 + r] = acc[i][ct][e];
+                for (int e = 0; e < 16; ++e)
+                    red[(wq * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * 33 + r] = acc[i][t][e];
+            }
             __syncthreads();
+            if (t < nt) {
+                const int ky = 4 * grp + t;
 #pragma unroll
-            for (int q = 0; q < 1024 / (64 * SWB_NW); ++q) {
-                const int idx = tid + 64 * SWB_NW * q, row = idx >> 5, col = idx & 31;
-                float v = 0.f;
+                for (int q = 0; q < 4; ++q) {
+                    const int idx = gt + 256 * q, row = idx >> 5, col = idx & 31;
+                    float v = 0.f;
 #pragma unroll
-                for (int wv = 0; wv < SWB_NW; ++wv) v += red[(wv * 32 + row) * 33 + col];
-                const int c = ct * 32 + col;
-                if (c < 147) {
-                    const int ky = c / 21, j = c - ky * 21;
-                    const size_t o = (size_t)(i * 32 + row) * 168 + ky * 24 + j;
-                    if (slab) slab[o] = v;
-                    else atomic_add_f32(dw + o, v);
+                    for (int wv = 0; wv < 4; ++wv) v += red[(wv * 32 + row) * 33 + col];
+                    const int a = col >> 3, bq = col & 7, j = 6 * a + bq;
+                    if (bq < 6 && j < 21) {
+                        const size_t o = (size_t)(i * 32 + row) * 168 + ky * 24 + j;
+                        if (slab) slab[o] = v;
+                        else atomic_add_f32(dw + o, v);
+                    }
                 }
             }
         }
@@ -761,13 +772,14 @@ int loans_stem7_launch(const float* in, const float* w, float* out, const float*
 int loans_stem7_wgrad_bf16_slabs(const loans_igemm_desc* d) {
     if (d->flags != LOANS_F_DENSE) return 0;
     if (d->ntaps != 7 || d->Cin != 24 || d->Cout != 64 || d->isy != 2 || d->isx != 6) return 0;
-    if ((d->inW & 1) || (d->inH & 1) || (d->gridW & 15) || d->gridW > 64 * SWB_PG) return 0;
-    if (swb_x_pieces(d->inW) > 64 * SWB_NW * SWB_PX) return 0;
+    if ((d->inH & 1) || (d->gridW & 15) || d->gridW > 64 * SWB_PG) return 0;
+    if (d->inW != 6 * (d->gridW + 3)) return 0;                 // rows of whole 12-byte cells, Wo + 3 of them (even frame widths)
+    if (7 * (d->gridW + 3) > 64 * SWB_NW * SWB_PC) return 0;
     for (int t = 0; t < 7; ++t)
         if (d->dy[t] != t || d->dx[t] != 0) return 0;
     if (d->osy != 1 || d->osx != 1 || d->oy0 || d->ox0 || d->outH != d->gridH || d->outW != d->gridW) return 0;
-    if (2 * (d->gridH - 1) + 7 > d->inH || 6 * (d->gridW - 1) + 24 > d->inW) return 0;
-    const size_t lds = (size_t)2 * (swb_x_pieces(d->inW) * 16 + d->gridW * SWB_GS * 2);
+    if (2 * (d->gridH - 1) + 7 > d->inH) return 0;
+    const size_t lds = (size_t)2 * (swb_patch_bytes(d->gridW) + d->gridW * SWB_GS * 2);
     if (lds > 156 * 1024) return 0;
     const int cus = loans_device_cus();
     if (cus <= 0) return 0;
@@ -781,7 +793,7 @@ int loans_stem7_wgrad_bf16_launch(const void* x, const void* gy, float* dw, cons
     if ((reinterpret_cast<uintptr_t>(x) & 15) || (reinterpret_cast<uintptr_t>(gy) & 15) || (reinterpret_cast<uintptr_t>(ws) & 15)) return LOANS_EINVAL;
     const int64_t xb = (int64_t)d->B * d->inH * d->inW * 2, gb = (int64_t)d->B * d->gridH * d->gridW * 128;
     if (xb >= 0x7FFFFFF0ll || gb >= 0x7FFFFFF0ll) return LOANS_ERANGE;       // bit 31 of an offset marks a piece that is not loaded
-    size_t lds = (size_t)2 * (swb_x_pieces(d->inW) * 16 + d->gridW * SWB_GS * 2);
+    size_t lds = (size_t)2 * (swb_patch_bytes(d->gridW) + d->gridW * SWB_GS * 2);
     if (lds < (size_t)SWB_NW * 32 * 33 * sizeof(float)) lds = (size_t)SWB_NW * 32 * 33 * sizeof(float);
     static loans_device_once lds_limit_set;
     if (int rc_ = loans_raise_lds_limit(lds_limit_set, reinterpret_cast<const void*>(stem7_wgrad_bf16_kernel), 156 * 1024)) return rc_;

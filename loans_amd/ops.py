@@ -757,13 +757,12 @@ STEM_WGRAD16_DIRECT = True      # (False: the A/B arm of tools/ab_ops_attr.py)
 
 def stem16_wgrad_ok(geo):
     """LOANS_TILE_STEM of loans_wgrad_bf16s covers this geometry (loans_stem7_wgrad_bf16_slabs of csrc/stem.hip: the bf16 frame
-    buffer, rows of whole 16-pixel steps, at most 256 output pixels and 12 KB of input rows per unit)"""
+    buffer, rows of whole 16-pixel steps and whole 12-byte cells, at most 256 output pixels per row)"""
     if not (STEM_DIRECT and STEM_WGRAD16_DIRECT and geo.dense and geo.k == 7 and geo.stride == 2 and geo.pad == 3 and geo.Cout == 64):
         return False
-    if 2 * geo.Ho + 5 > geo.Hp or geo.Hp % 2 or geo.Wo % 16 or geo.Wo > 256:
+    if 2 * geo.Ho + 5 > geo.Hp or geo.Hp % 2 or geo.Wo % 16 or geo.Wo > 256 or geo.Wp != 2 * geo.Wo + 6:
         return False
-    pieces = (7 * geo.Wp * 3 + 14) // 8 + 1
-    return pieces <= 3 * 512 and 2 * (pieces * 16 + geo.Wo * 144) <= 156 * 1024
+    return 7 * (geo.Wo + 3) <= 2048 and 2 * (7 * (geo.Wo + 3) * 16 + geo.Wo * 144) <= 156 * 1024
 
 
 @_memo
