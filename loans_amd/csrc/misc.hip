@@ -7,6 +7,8 @@ namespace {
 
 __device__ __forceinline__ f32x4 ld4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ void st4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ f32x4 ldnt4(const float* p) { return __builtin_nontemporal_load(reinterpret_cast<const f32x4*>(p)); }
+__device__ __forceinline__ void stnt4(float* p, f32x4 v) { __builtin_nontemporal_store(v, reinterpret_cast<f32x4*>(p)); }
 
 // block-wide sum for 256-thread blocks; result valid in every thread
 __device__ __forceinline__ float block_sum(float v, float* sh /* >= 4 floats */) {
@@ -421,16 +423,19 @@ __global__ __launch_bounds__(256) void adam_kernel(float* p, const float* g, flo
     const bool ams = vh != nullptr;
     const int64_t n4 = n >> 2;
     for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
-        f32x4 pp = ld4(p + i * 4), gg = ld4(g + i * 4), mm = ld4(m + i * 4), vv = ld4(v + i * 4);
-        f32x4 hh = ams ? ld4(vh + i * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+        // g, m, v, vhat are read once and m, v, vhat written once per step (900 MB at the ResNet-50 localizer: nothing of it stays in
+        // the Infinity Cache anyway): non-temporal.  p stays cacheable -- the bf16 cast and the re-packs of the next step read it.
+        // Alone, 78 M / 25.6 M parameters: 0.519 -> 0.502 ms, 0.198 -> 0.179 (profiles/r5_adam_nt.txt)
+        f32x4 pp = ld4(p + i * 4), gg = ldnt4(g + i * 4), mm = ldnt4(m + i * 4), vv = ldnt4(v + i * 4);
+        f32x4 hh = ams ? ldnt4(vh + i * 4) : f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             float a = pp[e], b = mm[e], c = vv[e], d = hh[e];
             adam1(a, gg[e], b, c, d, h);            // v >= 0: with d = 0 the max is v
             pp[e] = a; mm[e] = b; vv[e] = c; hh[e] = d;
         }
-        st4(p + i * 4, pp); st4(m + i * 4, mm); st4(v + i * 4, vv);
-        if (ams) st4(vh + i * 4, hh);
+        st4(p + i * 4, pp); stnt4(m + i * 4, mm); stnt4(v + i * 4, vv);
+        if (ams) stnt4(vh + i * 4, hh);
     }
     if (blockIdx.x == 0 && threadIdx.x < (n & 3)) {
         const int64_t i = n4 * 4 + threadIdx.x;

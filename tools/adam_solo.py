@@ -7,6 +7,9 @@ import sys
 
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch                # noqa: E402
+if os.environ.get('LOANS_BENCH_LIB'):      # another build of the library
+    from loans_amd import _lib
+    _lib.LIB_PATH = os.environ['LOANS_BENCH_LIB']
 from loans_amd import ops   # noqa: E402
 
 scrub = torch.empty(512 << 20, device='cuda', dtype=torch.uint8)
