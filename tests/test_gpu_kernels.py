@@ -231,6 +231,17 @@ def test_stem_weight_gradient_leaves_the_calling_stream():
     assert torch.allclose(dw, ref, rtol=1e-4, atol=1e-3 * float(ref.abs().max()))
 
 
+@pytest.mark.parametrize("n", [4, 8, 12, 1020, (1 << 20) + 4, 5_000_004])
+def test_cast_bf16_is_round_to_nearest_even_at_every_length(n):
+    """loans_cast_bf16 (the arena's bf16 shadow): eight elements per thread, an odd last group of four; exactly torch's RNE cast,
+    ties included"""
+    from loans_amd import ops
+    x = torch.randn(n, device='cuda') * 3
+    x[:4] = torch.tensor([1.00390625, 1.01171875, -1.00390625, 3.0e38], device='cuda')     # two ties (to even: down / up), a large value
+    out = ops.cast_bf16(x)
+    assert out.dtype == torch.bfloat16 and torch.equal(out, x.to(torch.bfloat16))
+
+
 def test_prep_images_exact():
     from loans_amd import ops
     rng = np.random.RandomState(0)
