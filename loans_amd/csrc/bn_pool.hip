@@ -19,16 +19,22 @@ __device__ __forceinline__ f32x4 maskpos4(f32x4 g, f32x4 m) {
     return g;
 }
 
-__global__ void bn_finalize_kernel(const double* stats, int C, double inv_count, double adjust, float eps,
-                                   float decay, const float* gamma, const float* beta, float* rmean, float* rvar,
-                                   int eps_in_rv, float* mean, float* rstd, float* scale, float* shift) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
-    double s1 = 0.0, s2 = 0.0;
-    for (int r = 0; r < LOANS_STATS_REPLICAS; ++r) {
-        s1 += stats[(size_t)r * 2 * C + c];
-        s2 += stats[(size_t)r * 2 * C + C + c];
-    }
+// 32 lanes per channel, one replica each, folded with shuffles; EVERY load of the kernel is issued before the first wait.  (One thread
+// per channel walking the replicas was compiled to eight rounds of eight loads with a full wait each, the four parameter loads waited
+// for one by one behind them: 5.8 us per launch, 53 of them on the forward's critical path of a ResNet-50 step -- now 3.x us,
+// profiles/r5_bn_coefficient_kernels.txt.  The fp64 sums are folded as a tree now: the same value to the last bit or two of a double.)
+static_assert(LOANS_STATS_REPLICAS == 32, "bn_finalize_kernel folds one replica per lane of a 32-lane group");
+__global__ __launch_bounds__(256) void bn_finalize_kernel(const double* stats, int C, double inv_count, double adjust, float eps,
+                                                          float decay, const float* gamma, const float* beta, float* rmean, float* rvar,
+                                                          int eps_in_rv, float* mean, float* rstd, float* scale, float* shift) {
+    const int c = blockIdx.x * 8 + (threadIdx.x >> 5), r = threadIdx.x & 31;
+    const bool ok = c < C;
+    const int cc = ok ? c : 0;
+    double s1 = stats[(size_t)r * 2 * C + cc], s2 = stats[(size_t)r * 2 * C + C + cc];
+    const float g = gamma[cc], bt = beta[cc], rm = rmean[cc], rv = rvar[cc];
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o, 32); s2 += __shfl_xor(s2, o, 32); }
+    if (!ok || r != 0) return;
     const double mu = s1 * inv_count;
     double var = s2 * inv_count - mu * mu;
     if (var < 0.0) var = 0.0;
@@ -37,11 +43,11 @@ __global__ void bn_finalize_kernel(const double* stats, int C, double inv_count,
     const float muf = (float)mu;
     mean[c] = muf;
     rstd[c] = rs;
-    const float sc = gamma[c] * rs;
+    const float sc = g * rs;
     scale[c] = sc;
-    shift[c] = beta[c] - muf * sc;
-    rmean[c] = decay * rmean[c] + (1.f - decay) * muf;
-    rvar[c] = decay * rvar[c] + (1.f - decay) * (float)(adjust * (eps_in_rv ? vpe : var));
+    shift[c] = bt - muf * sc;
+    rmean[c] = decay * rm + (1.f - decay) * muf;
+    rvar[c] = decay * rv + (1.f - decay) * (float)(adjust * (eps_in_rv ? vpe : var));
 }
 
 __global__ void bn_eval_coeffs_kernel(int C, float eps, const float* gamma, const float* beta, const float* rmean,
@@ -234,21 +240,24 @@ __global__ __launch_bounds__(256) void bn_bwd_coeffs_rep_kernel(const double* su
                                                                 const float* rstd, float* ggamma, float* gbeta,
                                                                 float* k1, float* k2, float* k3) {
     const int c = blockIdx.x * 8 + (threadIdx.x >> 5), r = threadIdx.x & 31;
+    const int cc = c < C ? c : 0;
     double db = 0.0, dc = 0.0;
     if (c < C && r < reps) {
         db = sums[(size_t)r * rep_stride + c];
         dc = sums[(size_t)r * rep_stride + C + c];
     }
+    // (the parameter loads go out with the replica loads, not one by one behind the fold)
+    const float rs = rstd[cc], gm = gamma[cc], mu = mean[cc], gg0 = ggamma[cc], gb0 = gbeta[cc];
 #pragma unroll
     for (int o = 16; o > 0; o >>= 1) { db += __shfl_xor(db, o, 32); dc += __shfl_xor(dc, o, 32); }
     if (c >= C || r != 0) return;
-    const double dg = centred ? dc * (double)rstd[c] : dc;  // sum g m xhat (centred: the second sum is sum g m (y - mean))
-    ggamma[c] += (float)dg;
-    gbeta[c] += (float)db;
-    const double a = (double)gamma[c] * (double)rstd[c];
+    const double dg = centred ? dc * (double)rs : dc;  // sum g m xhat (centred: the second sum is sum g m (y - mean))
+    ggamma[c] = gg0 + (float)dg;
+    gbeta[c] = gb0 + (float)db;
+    const double a = (double)gm * (double)rs;
     k1[c] = (float)a;
-    k2[c] = (float)(-a * (double)rstd[c] * dg * inv_count);
-    k3[c] = (float)(a * ((double)mean[c] * (double)rstd[c] * dg - db) * inv_count);
+    k2[c] = (float)(-a * (double)rs * dg * inv_count);
+    k3[c] = (float)(a * ((double)mu * (double)rs * dg - db) * inv_count);
 }
 
 template <bool DUAL, int MASK, typename T>
@@ -979,12 +988,17 @@ __global__ __launch_bounds__(256) void pool_bn_bwd_apply_v4_kernel(const T* gy, 
 }
 
 // dst[c] += sum over r of src[r][c]
-__global__ void fold_replicas_kernel(const float* src, float* dst, int reps, int C) {
-    const int c = blockIdx.x * blockDim.x + threadIdx.x;
-    if (c >= C) return;
+// (32 lanes per channel, lane r takes replicas r, r + 32, ...: one round of loads in flight instead of `reps` dependent ones)
+__global__ __launch_bounds__(256) void fold_replicas_kernel(const float* src, float* dst, int reps, int C) {
+    const int c = blockIdx.x * 8 + (threadIdx.x >> 5), r0 = threadIdx.x & 31;
+    const int cc = c < C ? c : 0;
+    const float d0 = dst[cc];
     float a = 0.f;
-    for (int r = 0; r < reps; ++r) a += src[(size_t)r * C + c];
-    dst[c] += a;
+    if (c < C)
+        for (int r = r0; r < reps; r += 32) a += src[(size_t)r * C + c];
+#pragma unroll
+    for (int o = 16; o > 0; o >>= 1) a += __shfl_xor(a, o, 32);
+    if (c < C && r0 == 0) dst[c] = d0 + a;
 }
 
 // a channel count the 16-byte-unit kernels tile: U = C / V units per row, U <= 256 and 256 % U == 0
@@ -1024,7 +1038,7 @@ extern "C" int loans_bn_finalize_f32(const double* stats, int32_t C, int64_t cou
     if (!stats || !gamma || !beta || !running_mean || !running_var || !mean || !rstd || !scale || !shift) return LOANS_EINVAL;
     if (C <= 0 || count <= 0) return LOANS_EINVAL;
     const double adjust = (double)count / (count > 1 ? (double)(count - 1) : 1.0);
-    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), stats, C,
+    hipLaunchKernelGGL(bn_finalize_kernel, dim3((C + 7) / 8), dim3(256), 0, as_stream(stream), stats, C,
                        1.0 / (double)count, adjust, eps, decay, gamma, beta, running_mean, running_var,
                        eps_in_running_var, mean, rstd, scale, shift);
     LOANS_LAUNCH_CHECK();
@@ -1543,7 +1557,7 @@ extern "C" int loans_pool_bn_bwd_apply_rep_bf16(const void* gy, const uint8_t* i
 
 extern "C" int loans_fold_replicas_f32(const float* src, float* dst, int32_t replicas, int32_t C, void* stream) {
     if (!src || !dst || replicas <= 0 || C <= 0) return LOANS_EINVAL;
-    hipLaunchKernelGGL(fold_replicas_kernel, dim3((C + 255) / 256), dim3(256), 0, as_stream(stream), src, dst, replicas, C);
+    hipLaunchKernelGGL(fold_replicas_kernel, dim3((C + 7) / 8), dim3(256), 0, as_stream(stream), src, dst, replicas, C);
     LOANS_LAUNCH_CHECK();
     return LOANS_OK;
 }
