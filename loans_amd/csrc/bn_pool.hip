@@ -1290,7 +1290,12 @@ static int bn_bwd_reduce_impl(const T* gy, const T* mask, const T* x, const floa
         const int RL = 256 / UB;
         const int max_blocks = (replicas > 1 ? 4096 : 1024) / slabs;  // un-replicated sums: every block adds to the same addresses
         int64_t rpb16 = ((rows + max_blocks - 1) / max_blocks + RL - 1) / RL * RL;
-        if (rpb16 < 32 * RL) rpb16 = 32 * RL;       // >= 32 rows per thread: a block ends with 2 (dual: 4) fp64 atomics per channel
+        // >= 32 rows per thread (a block ends with 2, dual: 4, fp64 atomics per channel) -- unless that leaves most of the machine
+        // idle: the deep stages' small maps (res5 .. res7 of a 512 px step: 16 384 .. 1 024 rows) ran on 2 .. 32 blocks per channel
+        // slab, 40-70 us for 5-20 us of traffic on the main stream's critical path; down to 4 rows per thread until 512 blocks are out
+        int64_t rpt = 32;
+        while (rpt > 4 && ((rows + rpt * RL - 1) / (rpt * RL)) * slabs < 512) rpt >>= 1;
+        if (rpb16 < rpt * RL) rpb16 = rpt * RL;
         const int g16 = (int)((rows + rpb16 - 1) / rpb16);
 #define LAUNCH_R16(D, M) \
     hipLaunchKernelGGL((bn_bwd_reduce_u16_kernel<D, M, T>), dim3(g16, slabs), dim3(256), 0, st, gy, mask, x, mean, rstd, x2, mean2, rstd2, sums, rows, U, (int)rpb16, scale, shift, replicas, UB)
