@@ -125,9 +125,25 @@ def test_res6_res7_gradients_and_update_parity(deterministic_forward):
     # the assessor's data gradient down to the crops (its inputs differ by the 5e-4 above: ReLU masks of a few elements)
     oracle_dis = M.Assessor(dp0)
     y_o = oracle_dis.forward(x_fake.data.cpu().numpy().astype(np.float64))
-    e_rois = rel_err(g_rois, oracle_dis.backward(C.mse_bwd(y_o, np.ones_like(y_o)), None, need_gx=True))
+    g_rois_ref = oracle_dis.backward(C.mse_bwd(y_o, np.ones_like(y_o)), None, need_gx=True)
+    e_rois = rel_err(g_rois, g_rois_ref)
     print('d loss / d rois %.2e, d loss / d points %.2e, d loss / d theta %.2e (oracle evaluated on the HIP tensors)' % (e_rois, e_pts, e_theta))
-    assert e_rois < 1e-4 and e_pts < 1e-4 and e_theta < 1e-4
+    assert e_pts < 1e-4 and e_theta < 1e-4
+    # A ReLU input within fp32 rounding of zero may take the other branch on the device than in the fp64 oracle.  Every one of these
+    # crops has a handful of units that close (non-zero |z| < 2e-5 max|z|: 12 / 7 / 19 of ~170 000, the closest at 3e-7), and which
+    # way they fall depends on the summation order, i.e. on the tile: under LOANS_TUNE_SALT=9 one unit flips and the 17 x 13 crop
+    # pixels of its receptive field move by 1.5 % (that image: 9e-3; the other ten assignments of profiles/r5_gputest_runs.txt:
+    # 4e-7 on every image).  So: per image; an image without such a unit has to agree to 1e-4, one with them either does or stays
+    # within what a flipped unit can move, and all images but one agree outright.
+    relu_inputs = [oracle_dis.r0_h1, oracle_dis.h1, oracle_dis.r1_h1, oracle_dis.h2, oracle_dis.r2_h1, oracle_dis.h3, oracle_dis.r3_h1,
+                   oracle_dis.h4]
+    near_ties = [sum(int(((np.abs(z[b]) < 2e-5 * np.abs(z[b]).max()) & (z[b] != 0)).sum()) for z in relu_inputs) for b in range(B)]
+    e_img = [rel_err(g_rois[b], g_rois_ref[b]) for b in range(B)]
+    print('   per image:', ['%.1e' % e for e in e_img], 'ReLU inputs within 2e-5 of zero:', near_ties)
+    for b in range(B):
+        assert e_img[b] < (5e-2 if near_ties[b] else 1e-4), (b, e_img[b], near_ties[b])
+    assert sum(e < 1e-4 for e in e_img) >= B - 1, e_img
+    flipped = max([e for e in e_img if e >= 1e-4], default=0.0)      # (what a flipped unit moves the crop gradient by, 0 as a rule)
 
     # ---- 2. the backbone, res6 / res7 included: every unit in situ (its own test function below shares the helper) ----
     worst, worst32, errs = {}, {}, {}
@@ -153,7 +169,7 @@ def test_res6_res7_gradients_and_update_parity(deterministic_forward):
             '%.1e' % rel_err(r32['loc_grads'][k[1:]], res['loc_grads'][k[1:]])) for k in top])
     drift = max(worst32.values())
     for key, e in errs.items():
-        assert e < max(1e-3, 10 * drift), (key, e, drift)
+        assert e < max(1e-3, 10 * drift, 3 * flipped), (key, e, drift, flipped)
 
     # ---- 4. one whole update_core from the same initial state ----
     for _, link, n in loc.namedpersistents():                    # undo the running-statistics update of the pass above
