@@ -285,17 +285,31 @@ __global__ __launch_bounds__(256, 2) void stem7_bf16_kernel(const TIN* in, const
                 acc[1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av, bf[s][1], acc[1], 0, 0, 0);
             }
             // + bias, statistics of the fp32 result, transpose through the wave's slab
+            // (a whole tile -- every tile of a frame whose R * Wo is a multiple of 32 -- takes the form without the per-row selects:
+            // the kernel is issue-bound, 38 % of its wave cycles issue and the MFMA pipe is 25 % busy, profiles/r5_cfg3_step_sq_table.txt)
+            const bool whole = mt * 32 + 32 <= npx;
 #pragma unroll
             for (int j = 0; j < 2; ++j) {
                 float s1 = 0.f, s2 = 0.f;
+                if (whole) {
 #pragma unroll
-                for (int e = 0; e < 16; ++e) {
-                    const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
-                    const float v = acc[j][e] + bv[j];
-                    const bool ok = mt * 32 + row < npx;
-                    s1 += ok ? v : 0.f;
-                    s2 += ok ? v * v : 0.f;
-                    Cs[row * S16_LDC + 32 * j + r] = v;
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+                        const float v = acc[j][e] + bv[j];
+                        s1 += v;
+                        s2 = __builtin_fmaf(v, v, s2);
+                        Cs[row * S16_LDC + 32 * j + r] = v;
+                    }
+                } else {
+#pragma unroll
+                    for (int e = 0; e < 16; ++e) {
+                        const int row = (e & 3) + 8 * (e >> 2) + 4 * h;
+                        const float v = acc[j][e] + bv[j];
+                        const bool ok = mt * 32 + row < npx;
+                        s1 += ok ? v : 0.f;
+                        s2 = ok ? __builtin_fmaf(v, v, s2) : s2;        // (the same arithmetic as the whole tile's)
+                        Cs[row * S16_LDC + 32 * j + r] = v;
+                    }
                 }
                 us[j] += s1; uq[j] += s2;
             }
