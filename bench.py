@@ -7,21 +7,26 @@ crops, localizer-chain backward + Adam-AMSGrad, assessor-chain backward + Adam-A
 
 Workload (BASELINE.json): configs[1] shape per GPU -- batch 256 x 3 x 224 x 224 fp32 (the full joint step, a
 superset of "localizer forward+backward only").  For N>1 every rank keeps that per-GPU batch (weak scaling, the
-per-GPU work is identical at every N so the driver's efficiency compares like with like) and gradients are
-all-reduced over RCCL; `--batch 128` gives configs[3] exactly (global 1024 at N=8).  Synthetic
-paste-and-crop frames, random-init weights; inputs are resident in HBM before timing.
+per-GPU work is identical at every N) and gradients are all-reduced over RCCL.  With N>1 and no --batch the per-GPU batch
+is 128 = configs[3] as BASELINE.json states it (global 1024 at N=8); N=1 stays at 256 = configs[1], and its line carries a
+"configs[3] per GPU" secondary leg (128 x 3 x 224 x 224 on one GPU) -- the like-for-like denominator of the N>1 values.
+Synthetic paste-and-crop frames, random-init weights; inputs are resident in HBM before timing.
 
 At N = 1 with the default workload the same process then measures the other single-GPU configurations of BASELINE.json as
 short SECONDARY legs -- configs[2] (bf16 storage arm, 128 x 3 x 512 x 512) and one GPU's share of configs[4] (ResNet-50
 localizer, bf16, 64 x 3 x 512 x 512) -- and reports them under "secondary" in the same line, each with its own roofline; the
 primary keys describe the fp32 leg alone (its timed region is closed before a secondary leg starts).
 
-Prints ONE JSON line (rank 0) with the contract keys plus
+Prints ONE JSON line (rank 0), COMPACT (a few KB: `compact_line`), with the contract keys plus
   roofline     : the ResNet-18 conv-forward MFMA roofline, measured live with HIP events
                  around the forward implicit-GEMM launches (21 convs) of every timed step
                  (minus the time a bracket of two events takes with nothing in it)
   cpu_baseline : the CPU oracle ("port": NumPy restatement of the Chainer graph) timed on
-                 the host cores on a bounded sample (B=8) of the same workload (N=1 only).
+                 the host cores on a bounded sample (B=8) of the same workload (N=1 only)
+  secondary    : per leg value / ms_per_step / dtype / baseline_config / roofline_frac / binding_frac only.
+Everything else (per-layer binding tables, per-class tables, allocator diagnostics, the full secondary legs) goes to
+--detail-file (default bench_detail.json beside this script; round 5's line carried all of it, grew to 26.5 KB and the
+driver could not parse it).
 """
 import argparse
 import json
@@ -63,7 +68,7 @@ def parse():
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=10)
     ap.add_argument('--warmup', type=int, default=3)
-    ap.add_argument('--batch', type=int, default=0, help='per-GPU batch (default 256 = configs[1] for every N: weak scaling; 128 reproduces configs[3])')
+    ap.add_argument('--batch', type=int, default=0, help='per-GPU batch (default: 256 = configs[1] at N=1, 128 = configs[3] at N>1)')
     ap.add_argument('--image-size', type=int, default=224)
     ap.add_argument('--target-size', type=int, default=75)
     ap.add_argument('--resnet50', action='store_true', help='Resnet50SheepLocalizer backbone (BASELINE configs[4] architecture, fp32)')
@@ -81,16 +86,20 @@ def parse():
                          "profiles/<tag>_<b256|cfg3|r50>_conv_fwd_hbm_traffic.json of the newest committed round for those workloads")
     ap.add_argument('--no-secondary', action='store_true',
                     help="only the primary leg (the rocprofv3 passes of tools/profile_round.sh profile one workload per command)")
-    ap.add_argument('--secondary', default='cfg3,r50,b16',
+    ap.add_argument('--secondary', default='cfg3,r50,b128,b16',
                     help="secondary legs run after the default primary workload at N = 1: cfg3 = configs[2] (bf16, 128 x 3 x 512 x 512), "
-                         "r50 = one GPU's share of configs[4] (ResNet-50 localizer, bf16, 64 x 3 x 512 x 512), b16 = the reference's "
+                         "r50 = one GPU's share of configs[4] (ResNet-50 localizer, bf16, 64 x 3 x 512 x 512), b128 = one GPU's share of configs[3] "
+                         "(fp32, 128 x 3 x 224 x 224), b16 = the reference's "
                          "own default batch (-b 16, 224 x 224, fp32: the launch-bound regime), eager and as a hipGraph")
     ap.add_argument('--secondary-steps', type=int, default=10)
     ap.add_argument('--secondary-warmup', type=int, default=3)
     ap.add_argument('--secondary-shape', default=None,
                     help="B,HW: shrink the secondary legs and run them behind any primary workload (schema tests on tiny shapes)")
+    ap.add_argument('--detail-file', default=os.path.join(ROOT, 'bench_detail.json'),
+                    help="where rank 0 writes the FULL result object (per-layer / per-class tables, full secondary legs); the line on "
+                         "stdout is its compact form")
     ap.add_argument('--cpu-batch', type=int, default=8)
-    ap.add_argument('--cpu-iters', type=int, default=2)
+    ap.add_argument('--cpu-iters', type=int, default=4)
     return ap.parse_args()
 
 
@@ -162,11 +171,12 @@ def dry_run(args):
     parallel.shutdown()
 
 
-PROFILE_TAGS = ('r5', 'r4', 'r3', 'r2')          # newest first: the committed rocprofv3 evidence a default workload is tied to
+PROFILE_TAGS = ('r6', 'r5', 'r4', 'r3', 'r2')          # newest first: the committed rocprofv3 evidence a default workload is tied to
 
 # The workloads with committed evidence under profiles/ (<tag>_<name>_tune.json = the tile table the timed run, the kernel trace
 # and the PMC passes of tools/profile_round.sh all ran on; <tag>_<name>_conv_fwd_hbm_traffic.json = the PMC bytes)
 STD_WORKLOADS = {(224, 256, 'f32', 'f32', 75, False): 'b256',        # BASELINE configs[1] shape, the primary leg
+                 (224, 128, 'f32', 'f32', 75, False): 'b128',        # BASELINE configs[3], one GPU's share (128 of 1024)
                  (512, 128, 'bf16', 'bf16', 75, False): 'cfg3',     # BASELINE configs[2]
                  (512, 64, 'bf16', 'bf16', 75, True): 'r50'}        # BASELINE configs[4], one GPU's share (64 of 512)
 
@@ -193,7 +203,8 @@ def _reference_ms(w):
 def workload_of(args, **over):
     """the knobs of one leg: the command line's, or a secondary leg's overrides of them"""
     from types import SimpleNamespace
-    w = SimpleNamespace(image_size=args.image_size, batch=args.batch or 256, dtype=args.dtype, storage=args.storage,
+    # no --batch: configs[1] (256) on one GPU, configs[3] as stated (128 per GPU, global 1024 at N = 8) on several
+    w = SimpleNamespace(image_size=args.image_size, batch=args.batch or (256 if args.gpus == 1 else 128), dtype=args.dtype, storage=args.storage,
                         resnet50=args.resnet50, target_size=args.target_size, steps=args.steps, warmup=args.warmup,
                         graph=args.graph, tune_file=args.tune_file, traffic_file=args.traffic_file)
     for k, v in over.items():
@@ -212,6 +223,8 @@ def config_label(w, world):
         return "configs[3]" if (std18 and B == 128) else ("configs[1] per GPU, data parallel" if (std18 and B == 256) else "custom")
     if std18 and B == 256:
         return "configs[1]"
+    if std18 and B == 128:
+        return "configs[3] per GPU (128 of the global 1024)"
     if hw == 512 and B == 128 and not w.resnet50 and w.dtype == 'bf16':
         return "configs[2]"
     if r50:
@@ -504,6 +517,55 @@ def run_workload(w, comm, local_rank, retune):
     }
 
 
+def _pick(d, keys):
+    return {k: d[k] for k in keys if d and k in d}
+
+
+def compact_roofline(r):
+    """the `roofline` object of the stdout line: the contract keys and the few figures a reader checks them with; the tables stay
+    in the detail file"""
+    if not r:
+        return None
+    out = _pick(r, ("bound", "achieved", "peak", "unit", "frac", "traffic", "kernel", "avg_launch_ms", "launches_per_step",
+                    "conv_fwd_ms_per_step", "algorithmic_flop_per_step", "traffic_over_algorithmic"))
+    ws = r.get("whole_step") or {}
+    b = ws.get("binding") or {}
+    out["binding_frac"] = (r.get("binding") or {}).get("frac")
+    out["whole_step"] = {"frac": ws.get("frac"), "binding_frac": b.get("binding_frac"), "machine_frac": b.get("machine_frac")}
+    return out
+
+
+def compact_line(out, detail_file=None):
+    """The ONE stdout line.  Round 5 printed the whole result (26.5 KB with three per-layer tables) and the driver, which keeps a
+    bounded tail of stdout, could not parse it: the line is now the contract keys, `config`, a reduced `roofline`, `cpu_baseline`
+    and five numbers per secondary leg (tests/test_host_cpu.py holds it under 4 KB on a full-size payload)."""
+    line = {k: out[k] for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better",
+                                "scaling", "vs_baseline", "dtype", "data") if k in out}
+    line["config"] = _pick(out.get("config"), ("workload", "per_gpu_batch", "global_batch", "frame", "crop", "parallelism",
+                                               "world_size", "dist_backend", "baseline_config", "hip_graph", "activation_storage",
+                                               "tune_table"))
+    line["roofline"] = compact_roofline(out.get("roofline"))
+    if "cpu_baseline" in out:
+        line["cpu_baseline"] = out["cpu_baseline"]
+    if out.get("secondary"):
+        sec = {}
+        for label, leg in out["secondary"].items():
+            r = leg.get("roofline") or {}
+            b = (r.get("whole_step") or {}).get("binding") or {}
+            e = {"value": leg["value"], "ms_per_step": leg["ms_per_step"], "dtype": leg["dtype"],
+                 "baseline_config": leg["config"]["baseline_config"], "per_gpu_batch": leg["config"]["per_gpu_batch"],
+                 "frame": leg["config"]["frame"], "roofline_frac": r.get("frac"), "conv_fwd_ms_per_step": r.get("conv_fwd_ms_per_step"),
+                 "binding_frac": b.get("binding_frac")}
+            for k in ("graph_over_eager", "remeasured"):
+                if k in leg:
+                    e[k] = leg[k] if k != "remeasured" else leg[k]["ms_per_step"]
+            sec[label] = e
+        line["secondary"] = sec
+    if detail_file:
+        line["detail"] = os.path.relpath(detail_file, ROOT) if os.path.abspath(detail_file).startswith(ROOT) else detail_file
+    return line
+
+
 B16_EAGER, B16_GRAPH = "reference default (-b 16, 224 x 224), eager", "reference default (-b 16, 224 x 224), hipGraph"
 
 
@@ -513,6 +575,8 @@ def secondary_legs(args):
     (ResNet-50 localizer, bf16, 64 x 3 x 512 x 512).  --secondary-shape B,HW shrinks both (schema tests on tiny shapes)."""
     legs = [("configs[2]", 'cfg3', dict(image_size=512, batch=128, dtype='bf16', storage='bf16', resnet50=False)),
             ("configs[4] per GPU", 'r50', dict(image_size=512, batch=64, dtype='bf16', storage='bf16', resnet50=True)),
+            # configs[3] as BASELINE.json states it is 128 frames per GPU: what ONE GPU does with that shard (the N>1 default)
+            ("configs[3] per GPU", 'b128', dict(image_size=224, batch=128, dtype='f32', storage='f32', resnet50=False)),
             # the reference's own defaults (train_sheep_localizer.py:56-58: -b 16, 224 x 224, crop 75 x 75): ~600 launches of a
             # few microseconds each -- the regime a captured step is for
             (B16_EAGER, 'b16', dict(image_size=224, batch=16, dtype='f32', storage='f32', resnet50=False, graph=False)),
@@ -585,7 +649,14 @@ def main():
         out["secondary"] = secondary
     if world == 1 and not args.no_cpu_baseline and not args.resnet50 and args.dtype == 'f32':
         out["cpu_baseline"] = cpu_baseline(args, args.image_size, args.target_size)
-    print(json.dumps(out), flush=True)
+    detail = args.detail_file
+    try:
+        with open(detail, 'w') as f:
+            json.dump(out, f)
+    except OSError as err:                      # a read-only tree: the line still goes out
+        print('bench.py: could not write %s: %s' % (detail, err), file=sys.stderr)
+        detail = None
+    print(json.dumps(compact_line(out, detail)), flush=True)
     parallel.shutdown()
 
 

@@ -106,6 +106,8 @@ typedef struct loans_igemm_desc {
 #define LOANS_TILE_256x128 7   /* loans_igemm_bf16s only: one 512-thread block per CU, three LDS stages (chunk c + 2 in flight) */
 #define LOANS_TILE_DEEP    32  /* loans_igemm_bf16s, OR-ed onto 128x128 / 128x64 / 64x64: a 4 / 5 / 8-stage LDS ring (3 / 4 / 7 chunks of K in
                                   flight per block) for grids of about one block per CU with a long K (res6 / res7 at 512 px) */
+#define LOANS_TILE_256x256W4 41 /* loans_igemm_bf16s only: the same block tile on FOUR waves -- 256 threads, one wave per SIMD, 128 x 128 wave tiles
+                                   (256 accumulator registers of the 512-entry file): 512 B of operand fragments per MFMA instead of 768 */
 #define LOANS_TILE_256x256 9   /* loans_igemm_bf16s only: 512 threads, eight 128 x 64 wave tiles, two LDS stages; 128 FLOP per staged byte */
 #define LOANS_TILE_FINETAIL 8  /* loans_igemm_f32, forward geometry (out row = grid pixel), flags BIAS / STATS / RELU_IN / DENSE only:
                                   64x64 tiles; the tiles that share out evenly over the CUs at full K, the remaining ones (fewer than

@@ -1104,6 +1104,7 @@ static int igemm_bf16s_impl(const void* in, const void* w, void* out, const floa
         case LOANS_TILE_64x64 | LOANS_TILE_DEEP: return launch_igemm16<64, 64, 2, 2, true>(a, st);
         case LOANS_TILE_256x128: return launch_igemm16<256, 128, 4, 2>(a, st);      // 512 threads: eight 64 x 64 wave tiles
         case LOANS_TILE_256x256: return launch_igemm16<256, 256, 2, 4>(a, st);      // 512 threads: eight 128 x 64 wave tiles
+        case LOANS_TILE_256x256W4: return launch_igemm16<256, 256, 2, 2>(a, st);    // 256 threads: four 128 x 128 wave tiles, one wave per SIMD
         case LOANS_TILE_HALO_128:
         case LOANS_TILE_HALO_128x64:
         case LOANS_TILE_HALO_256x64:

@@ -1513,11 +1513,15 @@ WGRAD_SLABS = os.environ.get('LOANS_WGRAD_SLABS', '1') != '0'
 WGRAD_SPLIT_SCALE = 0.75
 WGRAD_SPLIT_SCALE_F32 = 1.0       # the fp32 arm is MFMA-bound on both streams: 0.75 -> 49.72 ms against 49.67, 0.5 -> 50.08 (same file)
 _wgrad_ws = {}
+_wgrad_ws_captured = []      # workspaces handed out while a hipGraph was being captured: the graph has their addresses baked in,
+#                              so they stay alive for the life of the process even after a larger one replaces them
 
 
 def _wgrad_workspace(lib, geo, desc, tile, splits, device, st):
     """(tensor, floats needed) for loans_wgrad_bf16s_ws on stream handle `st`, or None where it does not apply (a request the
-    library rejects; a workspace that would have to grow while a hipGraph is being captured)"""
+    library rejects; a workspace that would have to grow while a hipGraph is being captured).  A later eager step with a larger
+    need replaces the slot's workspace; one a capture has seen is kept in `_wgrad_ws_captured`, so a replayed graph never stores
+    its slabs into memory that went back to the allocator."""
     plan = geo.__dict__.setdefault('_ws_need', {})
     need = plan.get((tile, splits))
     if need is None:
@@ -1526,12 +1530,15 @@ def _wgrad_workspace(lib, geo, desc, tile, splits, device, st):
         return None
     key = (device.index, st)
     ws = _wgrad_ws.get(key)
+    capturing = torch.cuda.is_current_stream_capturing()
     if ws is None or ws.numel() < need:
-        if torch.cuda.is_current_stream_capturing():
+        if capturing:
             return None
         ws = _wgrad_ws[key] = torch.empty(max(need, 1 << 22), device=device, dtype=torch.float32)
         if st != _stream():
             ws.record_stream(torch.cuda.ExternalStream(st, device=device))      # allocated on the current stream, used on `st`
+    elif capturing and not any(b is ws for b in _wgrad_ws_captured):
+        _wgrad_ws_captured.append(ws)
     return ws, need
 
 

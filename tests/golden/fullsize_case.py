@@ -8,6 +8,10 @@ import numpy as np
 B, HW, CROP = 256, 224, (75, 75)
 SEED = 2562
 FIXTURE = 'configs1_b256_224.npz'
+# BASELINE configs[3] is the same graph on ONE rank's shard -- 128 frames per GPU (global 1024 at N = 8, local BatchNormalization
+# statistics): the same seeded models on the first 128 frames / crops (make_fullsize_golden.py --batch 128)
+SHARD_B = 128
+SHARD_FIXTURE = 'configs3_b128_224.npz'
 # BN layers whose batch statistics (read back through the running averages of one step) the fixture pins
 BN_KEYS = ('feature_extractor/bn1', 'feature_extractor/res3/0/bn3', 'feature_extractor/res5/1/bn2')
 

@@ -11,7 +11,8 @@ size.  Here conv2d_fwd / conv2d_bwd are wrapped so that the forward walks the ba
 reference, no copy) through the `col` slot, and the backward rebuilds each chunk's im2col from it: same arithmetic per
 sample, weight gradients summed chunk by chunk.
 
-    python tests/golden/make_fullsize_golden.py            (~30 min on 8 cores, ~35 GB)
+    python tests/golden/make_fullsize_golden.py                 (~30 min on 8 cores, ~35 GB)
+    python tests/golden/make_fullsize_golden.py --batch 128     tests/golden/configs3_b128_224.npz: one rank's shard of configs[3]
 """
 import os
 import resource
@@ -50,11 +51,14 @@ def lean_conv2d_bwd(x_shape, col, W, gy, stride, pad, has_bias, need_gx=True):
     return (np.concatenate(gxs) if need_gx else None), gW, gb
 
 
+BATCH = K.B
+
+
 def run(dtype, log):
     loc, dis = K.build_models()
     lp = M.cast_params(loc.state_dict_chainer(), dtype)
     dp = M.cast_params(dis.state_dict_chainer(), dtype)
-    frames, real, labels = K.build_inputs()
+    frames, real, labels = K.build_inputs(BATCH)
     t0 = time.time()
     res = M.update_core(lp, dp, M.AdamAMSGrad(lp), M.AdamAMSGrad(dp), frames.astype(dtype), real.astype(dtype),
                         labels.astype(dtype), K.CROP, rng=np.random.RandomState(0), return_grads=True)
@@ -81,6 +85,11 @@ if __name__ == '__main__':
     C.conv2d_fwd, C.conv2d_bwd = lean_conv2d_fwd, lean_conv2d_bwd
     here = os.path.dirname(os.path.abspath(__file__))
     log = lambda s: print(s, flush=True)      # noqa: E731
+    fixture = K.FIXTURE
+    if sys.argv[1:3] == ['--batch', str(K.SHARD_B)]:           # one rank's shard of configs[3]
+        BATCH, fixture = K.SHARD_B, K.SHARD_FIXTURE
+    elif sys.argv[1:]:
+        raise SystemExit('usage: make_fullsize_golden.py [--batch %d]' % K.SHARD_B)
     r32 = run(np.float32, log)
     out = {k + '_f32': v for k, v in r32.items() if not k.endswith('_keys')}
     try:
@@ -90,6 +99,6 @@ if __name__ == '__main__':
         r64 = {k: v for k, v in r32.items()}
         out['f64_missing'] = np.array(1)
     out.update(r64)
-    path = os.path.join(here, K.FIXTURE)
+    path = os.path.join(here, fixture)
     np.savez_compressed(path, **out)
     log('wrote %s (%d bytes)' % (path, os.path.getsize(path)))

@@ -134,12 +134,12 @@ def test_fresh_localizer_known_answers_full_batch():
     np.testing.assert_allclose(l256, (float(obs2['loss_localizer']), float(obs2['loss_dis'])), rtol=2e-5)
 
 
-def _newest_b256_table():
+def _newest_table(name='b256'):
     import glob
     import os
     import re
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    files = glob.glob(os.path.join(root, 'profiles', 'r*_b256_tune.json'))
+    files = glob.glob(os.path.join(root, 'profiles', 'r*_%s_tune.json' % name))
     return max(files, key=lambda f: int(re.search(r'r(\d+)', os.path.basename(f)).group(1))) if files else None
 
 
@@ -150,19 +150,37 @@ def test_configs1_against_oracle_fixture(monkeypatch):
     (tests/golden/make_fullsize_golden.py; semantics at stake: train-mode BatchNormalization over 802 816 positions per channel,
     sheep/resnet.py:129-134, and the joint step of sheep/sheep_updater.py:26-68).  Outputs at 1e-4 (the north star's bound); the
     L2 norm of every parameter gradient at max(2e-4, 5 x the float32 oracle's own distance from the float64 one) relative."""
+    from tests.golden import fullsize_case as K
+    _joint_step_against_fixture(monkeypatch, K.FIXTURE, K.B, 'b256')
+
+
+def test_configs3_shard_known_answers(monkeypatch):
+    """BASELINE configs[3] AS STATED: one rank's shard -- 128 x 3 x 224 x 224 frames per GPU (global 1024 at N = 8), fp32, local
+    BatchNormalization statistics (no sync-BN anywhere in the reference) -- on the tile table `bench.py --gpus N` (N > 1,
+    128 per GPU by default) and its `configs[3] per GPU` leg time (profiles/r*_b128_tune.json), against
+    tests/golden/configs3_b128_224.npz: the float64 oracle's joint step on the same seeded models and the first 128 frames / crops
+    of the configs[1] case (tests/golden/make_fullsize_golden.py --batch 128).  Same bounds as configs[1].  What the exchange step
+    then does with these gradients -- sum over ranks x 1/world, OutOfImage x world -- is tests/test_gpu_parallel.py and the gloo
+    tests of tests/test_parallel_cpu.py; the pattern is the reference's only data-parallel site, schaaaafrichter/train.py:159-191."""
+    from tests.golden import fullsize_case as K
+    _joint_step_against_fixture(monkeypatch, K.SHARD_FIXTURE, K.SHARD_B, 'b128')
+
+
+def _joint_step_against_fixture(monkeypatch, fixture_name, batch, table_name):
     import os
     from tests.golden import fullsize_case as K
     from tests.test_gpu_model import _updater
-    fixture = os.path.join(os.path.dirname(os.path.abspath(K.__file__)), K.FIXTURE)
+    fixture = os.path.join(os.path.dirname(os.path.abspath(K.__file__)), fixture_name)
     ref = np.load(fixture)
     # the kernels of the bench run: a fresh tile cache, the committed table as proposals, the default (split-K) candidate lists
     monkeypatch.setattr(ops, '_TUNE_CACHE', {})
     monkeypatch.setattr(ops, '_TUNE_LOADED', {})
     monkeypatch.setattr(ops, 'SPLITK', True)
-    table = _newest_b256_table()
+    table = _newest_table(table_name)
     assert table is not None and ops.load_tune_table(table) > 0, 'no committed tile table of the bench workload (or one stamped for another chip)'
     loc, dis = K.build_models()
-    frames, real, labels = K.build_inputs()
+    frames, real, labels = K.build_inputs(batch)
+    assert len(frames) == batch == len(ref['theta'])
     upd = _updater(loc, dis, frames, real, labels)
     seen, calls = {}, {}
 
@@ -224,6 +242,6 @@ def test_configs1_against_oracle_fixture(monkeypatch):
     assert len(rel) == 65 + 11
     order = sorted(rel, key=lambda k: -rel[k] / lim[k])
     report = ', '.join('%s %.2e (bound %.2e)' % (k, rel[k], lim[k]) for k in order[:5])
-    print('configs[1] gradient norms vs the fp64 oracle: median %.2e, worst: %s' % (float(np.median(list(rel.values()))), report))
+    print('%s gradient norms vs the fp64 oracle: median %.2e, worst: %s' % (fixture_name, float(np.median(list(rel.values()))), report))
     assert all(rel[k] <= lim[k] for k in rel), report
     assert float(np.median(list(rel.values()))) <= 2e-4, report

@@ -53,15 +53,47 @@ def test_bench_rccl_at_world_size_one():
     assert out['config']['dist_backend'] == 'nccl' and out['config']['world_size'] == 1 and out['value'] > 0
 
 
-def test_bench_secondary_legs_schema():
+def test_bench_rccl_at_world_size_one_captured_step():
+    """the same with --graph: the data-parallel step captured as hipGraph SEGMENTS with the RCCL exchanges issued between them
+    (sheep_updater.py: localizer chain | all-reduce + Adam | assessor chain | all-reduce + Adam) -- until round 6 only the eager
+    step had met RCCL"""
+    e = dict(os.environ, LOANS_DIST_SELFTEST='1', RANK='0', WORLD_SIZE='1', LOCAL_RANK='0', MASTER_ADDR='127.0.0.1', MASTER_PORT='29733')
+    e.pop('LOANS_SPLITK', None)
+    e.pop('LOANS_DIST_BACKEND', None)
+    args = ['--gpus', '1', '--graph'] + [a if a != '2' else '4' for a in TINY]          # 4 timed steps: capture happens in warm-up
+    r = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py')] + args, cwd=ROOT, env=e, timeout=900,
+                       stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    out = _one_line(r)
+    assert out['config']['dist_backend'] == 'nccl' and out['config']['hip_graph'] is True and out['value'] > 0
+    eager = subprocess.run([sys.executable, os.path.join(ROOT, 'bench.py'), '--gpus', '1'] + TINY, cwd=ROOT, env=e, timeout=900,
+                           stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)
+    assert _one_line(eager)['config']['hip_graph'] is False
+
+
+def test_bench_secondary_legs_schema(tmp_path):
     """The driver's one bench line carries the other single-GPU configurations as `secondary` legs (configs[2]: bf16 joint
-    step; configs[4] per GPU: ResNet-50 localizer, bf16), each with its own roofline -- here on tiny shapes (2 x 3 x 320 x 320:
-    res6 and res7 active) behind a tiny primary leg; the primary keys stay those of the fp32 leg."""
-    out = _one_line(_run('bench.py', ['--gpus', '1', '--secondary-shape', '2,320', '--secondary-steps', '2',
-                                      '--secondary-warmup', '1'] + TINY))
+    step; configs[4] per GPU: ResNet-50 localizer, bf16; configs[3] per GPU: fp32, 128 frames) -- five numbers each on the
+    stdout line, which stays a few KB (round 5's 26.5 KB line was not parsed by the driver), the full legs with their rooflines
+    and tables in --detail-file; here on tiny shapes (2 x 3 x 320 x 320: res6 and res7 active) behind a tiny primary leg; the
+    primary keys stay those of the fp32 leg."""
+    detail = os.path.join(str(tmp_path), 'detail.json')
+    r = _run('bench.py', ['--gpus', '1', '--secondary-shape', '2,320', '--secondary-steps', '2',
+                          '--secondary-warmup', '1', '--detail-file', detail] + TINY)
+    line = _one_line(r)
+    assert len(r.stdout.strip().splitlines()[-1]) < 4096 and line['detail'] == detail
+    assert line['dtype'] == 'f32' and line['config']['baseline_config'] == 'custom' and 0 < line['roofline']['frac'] < 1
+    assert 'binding' not in line['roofline'] and set(line['roofline']['whole_step']) == {'frac', 'binding_frac', 'machine_frac'}
+    out = json.load(open(detail))
+    assert out['value'] == line['value'] and out['ms_per_step'] == line['ms_per_step']
+    for label, leg in out['secondary'].items():
+        c = line['secondary'][label]
+        assert c['value'] == leg['value'] and c['ms_per_step'] == leg['ms_per_step'] and c['dtype'] == leg['dtype']
+        assert c['roofline_frac'] == (leg['roofline'] or {}).get('frac')
     assert out['dtype'] == 'f32' and out['config']['activation_storage'] == 'f32' and out['config']['frame'] == '3x64x64'
     sec = out['secondary']
     b16 = {k: sec.pop(k) for k in list(sec) if k.startswith('reference default')}
+    b128 = sec.pop('configs[3] per GPU')
+    assert b128['dtype'] == 'f32' and b128['config']['activation_storage'] == 'f32' and b128['roofline']['peak'] == 157.3
     assert sorted(sec) == ['configs[2]', 'configs[4] per GPU']
     # the reference's default batch, eager and as a hipGraph (here shrunk like the others): fp32, the same workload twice
     eager, graph = b16['reference default (-b 16, 224 x 224), eager'], b16['reference default (-b 16, 224 x 224), hipGraph']

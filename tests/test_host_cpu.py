@@ -237,6 +237,37 @@ def test_launcher_state_is_per_device_and_capture_safe():
         assert src.count('hipFuncSetAttribute') == 0, name          # only through loans_raise_lds_limit (per device)
 
 
+def test_wgrad_workspace_a_capture_has_seen_is_never_freed(monkeypatch):
+    """the slab workspace of the bf16 weight gradients is regrown by replacing the slot's tensor.  A hipGraph captured
+    earlier has the OLD tensor's address baked in, so a workspace handed out during capture must outlive its replacement (the
+    replayed graph would otherwise store slabs into memory the allocator re-uses).  Host logic, on CPU tensors."""
+    import types
+    import torch
+    from loans_amd import ops
+    need = {'n': 1 << 22}
+    lib = types.SimpleNamespace(loans_wgrad_bf16s_ws_floats=lambda desc, splits: need['n'])
+    capturing = {'on': False}
+    monkeypatch.setattr(torch.cuda, 'is_current_stream_capturing', lambda: capturing['on'])
+    monkeypatch.setattr(ops, '_stream', lambda: 7)
+    monkeypatch.setattr(ops, '_wgrad_ws', {})
+    monkeypatch.setattr(ops, '_wgrad_ws_captured', [])
+    monkeypatch.setattr(ops.C, 'byref', lambda d: d)
+    dev = torch.device('cpu')
+    geo = lambda: types.SimpleNamespace()                 # a fresh geometry per call: no cached need
+    ws0, n0 = ops._wgrad_workspace(lib, geo(), None, 1, 4, dev, 7)            # eager: allocated
+    assert n0 == 1 << 22 and not ops._wgrad_ws_captured
+    capturing['on'] = True
+    ws1, _ = ops._wgrad_workspace(lib, geo(), None, 1, 4, dev, 7)             # captured: the same tensor, now pinned
+    assert ws1 is ws0 and ops._wgrad_ws_captured == [ws0]
+    need['n'] = 1 << 23
+    assert ops._wgrad_workspace(lib, geo(), None, 1, 8, dev, 7) is None       # never grows inside a capture
+    capturing['on'] = False
+    ws2, n2 = ops._wgrad_workspace(lib, geo(), None, 1, 8, dev, 7)            # a later eager step with a larger need
+    assert ws2 is not ws0 and ws2.numel() >= n2 == 1 << 23
+    assert any(b is ws0 for b in ops._wgrad_ws_captured)                      # the graph's workspace is still alive
+    assert ws0.data_ptr() != ws2.data_ptr()
+
+
 def test_tune_table_round_trip(tmp_path, monkeypatch):
     """A normal run writes its tile table, the profiled runs of the same command read it: same kernels in both
     (ops.save_tune_table / load_tune_table, bench.py --tune-file).  What a file holds is a PROPOSAL: it is launched only if

@@ -17,10 +17,15 @@ geo = ops.ConvGeometry(B, H, W, Cin, Cout, 3, 1, 1)
 x = torch.randn(B, H, W, Cin, device='cuda').to(torch.bfloat16)
 w = (torch.randn(Cout, 3, 3, Cin, device='cuda') * 0.05)
 w16 = ops.cast_bf16(w)
+first = None
 for t in tiles:
     stats = ops.stats_buffer(Cout, 'cuda')
     fn = lambda: ops.conv_fprop(x, w16, geo, stats=stats, tile=t)
-    fn(); torch.cuda.synchronize()
+    y = fn(); torch.cuda.synchronize()
+    if first is None:
+        first = y.clone()
+    else:
+        print('tile %3d vs tile %3d: max |diff| %.3g, identical %s' % (t, tiles[0], float((y.float() - first.float()).abs().max()), torch.equal(y, first)))
     ts = []
     for _ in range(20):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -1,8 +1,8 @@
 #!/bin/bash
-# Development happens in /root/repo/_wip (ignored by git and by gpurun): a gpurun call snapshots /root/repo some minutes AFTER it
+# Development happens in /tmp/loans_wip (outside the tree: no tool double-counts it): a gpurun call snapshots /root/repo some minutes AFTER it
 # was started (when a box is free), so the main tree must not be edited while a call is outstanding.
-#   tools/wip.sh pull     main -> _wip   (start of a piece of work)
-#   tools/wip.sh push     _wip -> main   (right before a gpurun call / a commit; never while a call is in flight)
+#   tools/wip.sh pull     main -> /tmp/loans_wip   (start of a piece of work)
+#   tools/wip.sh push     /tmp/loans_wip -> main   (right before a gpurun call / a commit; never while a call is in flight)
 set -e
 cd /root/repo
 PATHS="loans_amd tests tools include oracle bench.py train_sheep_localizer.py evaluate.py __graft_entry__.py"
@@ -14,8 +14,8 @@ copy() {  # copy <from> <to>: mirror the code paths (no rsync in this image)
   find "$2" -name __pycache__ -prune -exec rm -rf {} + 2>/dev/null || true
 }
 case "$1" in
-  pull) mkdir -p _wip; copy . _wip ;;
+  pull) mkdir -p /tmp/loans_wip; copy . /tmp/loans_wip ;;
   push) if gpurun --status | grep -q '"in_flight": 1'; then echo "a gpurun call is in flight: not pushing"; exit 1; fi
-        copy _wip . ;;
+        copy /tmp/loans_wip . ;;
   *) echo "usage: $0 pull|push"; exit 2 ;;
 esac
