@@ -106,8 +106,6 @@ typedef struct loans_igemm_desc {
 #define LOANS_TILE_256x128 7   /* loans_igemm_bf16s only: one 512-thread block per CU, three LDS stages (chunk c + 2 in flight) */
 #define LOANS_TILE_DEEP    32  /* loans_igemm_bf16s, OR-ed onto 128x128 / 128x64 / 64x64: a 4 / 5 / 8-stage LDS ring (3 / 4 / 7 chunks of K in
                                   flight per block) for grids of about one block per CU with a long K (res6 / res7 at 512 px) */
-#define LOANS_TILE_256x256W4 41 /* loans_igemm_bf16s only: the same block tile on FOUR waves -- 256 threads, one wave per SIMD, 128 x 128 wave tiles
-                                   (256 accumulator registers of the 512-entry file): 512 B of operand fragments per MFMA instead of 768 */
 #define LOANS_TILE_256x256 9   /* loans_igemm_bf16s only: 512 threads, eight 128 x 64 wave tiles, two LDS stages; 128 FLOP per staged byte */
 #define LOANS_TILE_FINETAIL 8  /* loans_igemm_f32, forward geometry (out row = grid pixel), flags BIAS / STATS / RELU_IN / DENSE only:
                                   64x64 tiles; the tiles that share out evenly over the CUs at full K, the remaining ones (fewer than
@@ -140,6 +138,10 @@ typedef struct loans_igemm_desc {
                                       nine taps' weights stationary in LDS, halo images double-buffered across 16 x 16 pixel tiles */
 #define LOANS_TILE_HALO_256x128 36 /* 16 x 16 pixels x 128 output channels in one 512-thread block per CU (eight 64 x 64 wave tiles): twice the
                                       MFMA work per staged byte of LOANS_TILE_HALO_128 -- the N = 128 layers, too narrow for a 256-column tile */
+#define LOANS_TILE_HALO_256x256 42 /* 16 x 16 pixels x 256 output channels in one 512-thread block per CU (eight 128 x 64 wave tiles, the wave layout
+                                      of LOANS_TILE_256x256): the 256- and 512-channel 3 x 3 layers (res4 / res5) with their input staged once per
+                                      64-channel chunk instead of once per tap -- 329 KB through the L2 -> LDS path per chunk where the implicit GEMM
+                                      moves 576 KB; the fp32 staging tile of the epilogue takes two passes */
 #define LOANS_TILE_WSW64      37  /* the same layers with the weights stationary and every WAVE on its own unit (2 rows x 16 pixels x 64 channels:
                                       own halo image, own vmcnt, own staging slab): no block barrier after the weights have landed */
 #define LOANS_TILE_WGHALO_64   38  /* loans_wgrad_bf16s, stride-1 3 x 3 forward geometries with Cin % 64 == 0, Cout % 64 == 0: a block owns 64 output x 64

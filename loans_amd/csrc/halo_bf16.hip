@@ -66,9 +66,12 @@ constexpr size_t halo_stage_bytes() {
     constexpr int apieces = ((TH + 2) * (TW + 2) + 7) / 8;
     return (size_t)(ADB ? 2 : 1) * apieces * 1024 + (size_t)2 * BN * BKH * 2;
 }
+// the fp32 staging tile of the epilogue goes through the LDS in EP passes of BM / EP rows (two for the 16 x 16 x 256 tile)
+template <int TH, int TW, int BN>
+constexpr int halo_epilogue_passes() { return (size_t)TH * TW * (BN + 4) * 4 > 140 * 1024 ? 2 : 1; }
 template <int TH, int TW, int BN, bool ADB>
 constexpr size_t halo_aux_bytes() {
-    constexpr size_t cs = (size_t)TH * TW * (BN + 4) * 4;
+    constexpr size_t cs = (size_t)TH * TW / halo_epilogue_passes<TH, TW, BN>() * (BN + 4) * 4;
     return halo_stage_bytes<TH, TW, BN, ADB>() > cs ? halo_stage_bytes<TH, TW, BN, ADB>() : cs;
 }
 template <int TH, int TW, int BN, bool ADB>
@@ -379,67 +382,91 @@ __global__ __launch_bounds__(64 * WM * WN) void halo16_kernel(const Halo16Args a
     }
     // The epilogue's operands (ReLU reference, addend, the BN input of LOANS_F_BNSUMS) are requested BEFORE the tile goes through the
     // staging area: inside the store loop every load waited behind the previous row's store (vector memory operations retire in
-    // order) and paid its own latency, once per row.
-    constexpr int NIT = BM / RSTEP;
-    unsigned eoff[NIT];
-    bf16x8_t e_ref[NIT], e_add[NIT];
+    // order) and paid its own latency, once per row.  (The two-pass tile, 16 x 16 x 256, holds 128 accumulators per wave up to its
+    // pass: there the operands are requested row by row behind the staging, as in igemm16_kernel's 128 x 64 wave tiles.)
+    constexpr int EP = halo_epilogue_passes<TH, TW, BN>();
+    constexpr int PR = BM / EP;                 // rows per pass
+    static_assert(PR % (TM * 32) == 0 || (TM * 32) % PR == 0, "a wave's rows fall into whole passes");
+    constexpr int NIT = PR / RSTEP;
+    constexpr bool EARLY = EP == 1;
+    constexpr int NA = EARLY ? NIT : 1;
+    unsigned eoff[NA];
+    bf16x8_t e_ref[NA], e_add[NA];
+#pragma unroll 1
+    for (int ep = 0; ep < EP; ++ep) {
+        if (EARLY) {
 #pragma unroll
-    for (int p = 0; p < NIT; ++p) {
-        const unsigned po = opix[r0 + p * RSTEP];
-        eoff[p] = (po + coff) | (po == 0xFFFFFFFFu ? 0xFFFFFFFFu : 0u) | cbad;
-    }
-    if (f_mask || f_addmask || f_bnsums) {
+            for (int p = 0; p < NIT; ++p) {
+                const unsigned po = opix[r0 + p * RSTEP];
+                eoff[p] = (po + coff) | (po == 0xFFFFFFFFu ? 0xFFFFFFFFu : 0u) | cbad;
+            }
+            if (f_mask || f_addmask || f_bnsums) {
 #pragma unroll
-        for (int p = 0; p < NIT; ++p)
-            e_ref[p] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_ref, (int)eoff[p], 0, 0));
-    }
-    if (f_add) {
-#pragma unroll
-        for (int p = 0; p < NIT; ++p)
-            e_add[p] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_add, (int)eoff[p], 0, 0));
-    }
-#pragma unroll
-    for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j)
-#pragma unroll
-            for (int e = 0; e < 16; ++e)
-                Cs[(wm * TM * 32 + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h) * LDC + wn * TN * 32 + j * 32 + r] = acc[i][j][e];
-    __syncthreads();
-#pragma unroll
-    for (int p = 0; p < NIT; ++p) {
-        const int row = r0 + p * RSTEP;
-        const unsigned off = eoff[p];
-        f32x4 lo = *reinterpret_cast<const f32x4*>(Cs + row * LDC + oc8 * 8) + b_lo;
-        f32x4 hi = *reinterpret_cast<const f32x4*>(Cs + row * LDC + oc8 * 8 + 4) + b_hi;
-        if (f_mask || f_addmask) {
-            const f32x4 rl = lo4(e_ref[p]), rh = hi4(e_ref[p]);
-            if (f_mask) { lo = keep_pos(lo, rl); hi = keep_pos(hi, rh); }
+                for (int p = 0; p < NIT; ++p)
+                    e_ref[p] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_ref, (int)eoff[p], 0, 0));
+            }
             if (f_add) {
-                f32x4 al = lo4(e_add[p]), ah = hi4(e_add[p]);
-                if (f_addmask) { al = keep_pos(al, rl); ah = keep_pos(ah, rh); }
-                lo += al; hi += ah;
-            }
-        } else if (f_add) {
-            lo += lo4(e_add[p]); hi += hi4(e_add[p]);
-        }
-        bf16x8_t o;
-        const bf16x4_t ol = __builtin_convertvector(lo, bf16x4_t), oh = __builtin_convertvector(hi, bf16x4_t);
-        o[0] = ol[0]; o[1] = ol[1]; o[2] = ol[2]; o[3] = ol[3];
-        o[4] = oh[0]; o[5] = oh[1]; o[6] = oh[2]; o[7] = oh[3];
-        if (f_bnsums) {          // block-uniform; a row that does not exist loaded zeros and its gradient is zeroed below
-            const f32x4 y2[2] = {lo4(e_ref[p]), hi4(e_ref[p])};
-            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
-            const bool live = off != 0xFFFFFFFFu;
-            const f32x4 g2[2] = {live ? __builtin_convertvector(ol, f32x4) : zero4, live ? __builtin_convertvector(oh, f32x4) : zero4};
 #pragma unroll
-            for (int q = 0; q < 2; ++q) {
-                const f32x4 gm = keep_pos(g2[q], y2[q] * bn_scale[q] + bn_shift[q]);
-                bn_s1[q] += gm;
-                bn_s2[q] += gm * (y2[q] - bn_mean[q]);
+                for (int p = 0; p < NIT; ++p)
+                    e_add[p] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_add, (int)eoff[p], 0, 0));
             }
         }
-        LOANS_STORE_B128(__builtin_bit_cast(u32x4, o), rs_out, (int)off, a.nt_out);
+        if (ep) __syncthreads();            // the previous pass has been read
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+            const int trow = wm * TM * 32 + i * 32;         // first row of this 32-row MFMA tile
+            if (trow / PR == ep) {
+#pragma unroll
+                for (int j = 0; j < TN; ++j)
+#pragma unroll
+                    for (int e = 0; e < 16; ++e)
+                        Cs[(trow % PR + (e & 3) + 8 * (e >> 2) + 4 * h) * LDC + wn * TN * 32 + j * 32 + r] = acc[i][j][e];
+            }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int p = 0; p < NIT; ++p) {
+            const int row = r0 + p * RSTEP;
+            if (!EARLY) {
+                const unsigned po = opix[ep * PR + row];
+                eoff[0] = (po + coff) | (po == 0xFFFFFFFFu ? 0xFFFFFFFFu : 0u) | cbad;
+                if (f_mask || f_addmask || f_bnsums)
+                    e_ref[0] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_ref, (int)eoff[0], 0, 0));
+                if (f_add)
+                    e_add[0] = __builtin_bit_cast(bf16x8_t, __builtin_amdgcn_raw_buffer_load_b128(rs_add, (int)eoff[0], 0, 0));
+            }
+            const unsigned off = eoff[p % NA];
+            f32x4 lo = *reinterpret_cast<const f32x4*>(Cs + row * LDC + oc8 * 8) + b_lo;
+            f32x4 hi = *reinterpret_cast<const f32x4*>(Cs + row * LDC + oc8 * 8 + 4) + b_hi;
+            if (f_mask || f_addmask) {
+                const f32x4 rl = lo4(e_ref[p % NA]), rh = hi4(e_ref[p % NA]);
+                if (f_mask) { lo = keep_pos(lo, rl); hi = keep_pos(hi, rh); }
+                if (f_add) {
+                    f32x4 al = lo4(e_add[p % NA]), ah = hi4(e_add[p % NA]);
+                    if (f_addmask) { al = keep_pos(al, rl); ah = keep_pos(ah, rh); }
+                    lo += al; hi += ah;
+                }
+            } else if (f_add) {
+                lo += lo4(e_add[p % NA]); hi += hi4(e_add[p % NA]);
+            }
+            bf16x8_t o;
+            const bf16x4_t ol = __builtin_convertvector(lo, bf16x4_t), oh = __builtin_convertvector(hi, bf16x4_t);
+            o[0] = ol[0]; o[1] = ol[1]; o[2] = ol[2]; o[3] = ol[3];
+            o[4] = oh[0]; o[5] = oh[1]; o[6] = oh[2]; o[7] = oh[3];
+            if (f_bnsums) {          // block-uniform; a row that does not exist loaded zeros and its gradient is zeroed below
+                const f32x4 y2[2] = {lo4(e_ref[p % NA]), hi4(e_ref[p % NA])};
+                const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+                const bool live = off != 0xFFFFFFFFu;
+                const f32x4 g2[2] = {live ? __builtin_convertvector(ol, f32x4) : zero4, live ? __builtin_convertvector(oh, f32x4) : zero4};
+#pragma unroll
+                for (int q = 0; q < 2; ++q) {
+                    const f32x4 gm = keep_pos(g2[q], y2[q] * bn_scale[q] + bn_shift[q]);
+                    bn_s1[q] += gm;
+                    bn_s2[q] += gm * (y2[q] - bn_mean[q]);
+                }
+            }
+            LOANS_STORE_B128(__builtin_bit_cast(u32x4, o), rs_out, (int)off, a.nt_out);
+        }
     }
     if (f_bnsums) {
         __syncthreads();
@@ -1115,6 +1142,7 @@ int loans_halo16_launch(const void* in, const void* w, void* out, const float* b
         case LOANS_TILE_HALO_256x64: return launch_halo<16, 16, 64, 4, 1, false>(a, st);
         case LOANS_TILE_HALO_128x64S: return launch_halo<8, 16, 64, 4, 1, false>(a, st);
         case LOANS_TILE_HALO_256x128: return launch_halo<16, 16, 128, 4, 2, true>(a, st);      // 512 threads, one block per CU
+        case LOANS_TILE_HALO_256x256: return launch_halo<16, 16, 256, 2, 4, true>(a, st);      // 512 threads: eight 128 x 64 wave tiles
         case LOANS_TILE_WS64: return a.nx == 3 && a.ny == 3 ? launch_ws8(a, st) : LOANS_EINVAL;
         case LOANS_TILE_WSW64: return a.nx == 3 && a.ny == 3 ? launch_wsw(a, st) : LOANS_EINVAL;
         default: return LOANS_EINVAL;

@@ -1083,7 +1083,7 @@ static int igemm_bf16s_impl(const void* in, const void* w, void* out, const floa
         const int64_t big = (int64_t)((a.M + 127) / 128) * ((d->Cout + 127) / 128);
         tile = d->Cout <= 64 ? LOANS_TILE_128x64 : (big >= 512 ? LOANS_TILE_128x128 : LOANS_TILE_64x64);
     }
-    const bool halo_tile = (tile >= LOANS_TILE_HALO_128 && tile <= LOANS_TILE_WS64) || tile == LOANS_TILE_HALO_256x128 || tile == LOANS_TILE_WSW64;
+    const bool halo_tile = (tile >= LOANS_TILE_HALO_128 && tile <= LOANS_TILE_WS64) || tile == LOANS_TILE_HALO_256x128 || tile == LOANS_TILE_HALO_256x256 || tile == LOANS_TILE_WSW64;
     if (partial && halo_tile) return LOANS_EINVAL;          // the halo tiles have no split-K form
     if (pair && (tile == LOANS_TILE_STEM || halo_tile)) return LOANS_EINVAL;
     if (tile == LOANS_TILE_STEM) {          // the dense RGB stem as a direct convolution (stem.hip)
@@ -1104,12 +1104,12 @@ static int igemm_bf16s_impl(const void* in, const void* w, void* out, const floa
         case LOANS_TILE_64x64 | LOANS_TILE_DEEP: return launch_igemm16<64, 64, 2, 2, true>(a, st);
         case LOANS_TILE_256x128: return launch_igemm16<256, 128, 4, 2>(a, st);      // 512 threads: eight 64 x 64 wave tiles
         case LOANS_TILE_256x256: return launch_igemm16<256, 256, 2, 4>(a, st);      // 512 threads: eight 128 x 64 wave tiles
-        case LOANS_TILE_256x256W4: return launch_igemm16<256, 256, 2, 2>(a, st);    // 256 threads: four 128 x 128 wave tiles, one wave per SIMD
         case LOANS_TILE_HALO_128:
         case LOANS_TILE_HALO_128x64:
         case LOANS_TILE_HALO_256x64:
         case LOANS_TILE_HALO_128x64S:
         case LOANS_TILE_HALO_256x128:
+        case LOANS_TILE_HALO_256x256:
         case LOANS_TILE_WSW64:
         case LOANS_TILE_WS64:
             return loans_halo16_launch(in, w, out, bias, stats, ref, addend, d, tile, a.in_bytes, a.w_bytes, a.out_bytes, st);

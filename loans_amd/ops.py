@@ -443,6 +443,7 @@ _IGEMM16_TILES = (1, 2, 3, 4, 7)
 # LOANS_TILE_HALO_* (csrc/halo_bf16.hip): stride-1 convolutions with the input tile staged once per 64-channel chunk
 TILE_HALO_128, TILE_HALO_256x64, TILE_HALO_128x64, TILE_HALO_128x64S, TILE_WS64 = 11, 12, 13, 14, 15
 TILE_HALO_256x128 = 36       # one 512-thread block per CU: 16 x 16 pixels x 128 output channels
+TILE_HALO_256x256 = 42       # the same with 256 output channels (eight 128 x 64 wave tiles, two-pass epilogue): the res4 / res5 layers
 TILE_WSW64 = 37              # weights stationary, every wave on its own 2 x 16 pixel unit (no block barriers)
 HALO = True
 
@@ -599,6 +600,8 @@ def _halo_tiles(geo, gathered_channels, out_channels, out_hw, relu_in=False):
     tiles = (TILE_HALO_128, TILE_HALO_128x64) if out_channels > 64 else (TILE_HALO_128x64,)
     if out_channels > 64 and min(out_hw) >= 12:
         tiles += (TILE_HALO_256x128,)
+    if out_channels >= 256 and min(out_hw) >= 12:
+        tiles += (TILE_HALO_256x256,)
     if gathered_channels == 64 and out_channels <= 64:
         tiles += (TILE_HALO_128x64S,) + ((TILE_HALO_256x64,) if min(out_hw) >= 12 else ())
         if geo.k == 3 and geo.pad == 1 and not relu_in and min(out_hw) >= 12:

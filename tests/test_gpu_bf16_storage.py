@@ -411,11 +411,12 @@ HALO_CASES = [
     (2, 64, 12, 17, 128, 1, 0),      # 1x1: no halo
     (1, 64, 40, 48, 64, 3, 1),       # 16 x 16 tiles, three per row
     (3, 64, 21, 35, 32, 3, 1),       # fewer output channels than a block holds
+    (1, 256, 20, 33, 512, 3, 1),     # res4 / res5-like widths: two 256-column blocks, ragged 16 x 16 tiles, four chunks
 ]
 
 
 @pytest.mark.parametrize("case", HALO_CASES)
-@pytest.mark.parametrize("tile", [11, 12, 13, 14, 15, 36, 37])
+@pytest.mark.parametrize("tile", [11, 12, 13, 14, 15, 36, 37, 42])
 def test_conv_halo_tiles_bf16_storage(case, tile):
     """LOANS_TILE_HALO_* (csrc/halo_bf16.hip): stride-1 convolutions and their data gradients with the input tile staged once
     per 64-channel chunk -- against the oracle on the bf16-rounded operands and against the implicit-GEMM tile (bit for bit
@@ -729,7 +730,7 @@ def test_conv_pair_bf16_storage(case, tile):
 
 
 @pytest.mark.parametrize("storage,tiles", [('f32', [0, 1, 2, 3, 4, 6, 17, 18, 19, 20]),
-                                           ('bf16', [0, 1, 2, 3, 4, 7, 9, 33, 34, 35, 11, 12, 13, 14, 36, 37])])
+                                           ('bf16', [0, 1, 2, 3, 4, 7, 9, 33, 34, 35, 11, 12, 13, 14, 36, 37, 42])])
 @pytest.mark.parametrize("case", [(3, 64, 14, 14, 64, 3), (2, 128, 20, 33, 128, 3), (2, 256, 9, 12, 64, 3), (5, 64, 17, 12, 256, 1),
                                   (2, 512, 6, 7, 128, 1)])
 def test_data_gradient_takes_the_bn_backward_sums(storage, tiles, case):
@@ -764,7 +765,7 @@ def test_data_gradient_takes_the_bn_backward_sums(storage, tiles, case):
     try:
         ran = 0
         for tile in tiles:
-            if s16 and tile in (11, 12, 13, 14, 36, 37) and tile not in ops._halo_tiles(geo, geo.Cout, geo.Cin, (geo.H, geo.W)):
+            if s16 and tile in (11, 12, 13, 14, 36, 37, 42) and tile not in ops._halo_tiles(geo, geo.Cout, geo.Cin, (geo.H, geo.W)):
                 continue
             if s16 and tile == 9 and C_ % 256:
                 continue
