@@ -106,6 +106,10 @@ typedef struct loans_igemm_desc {
 #define LOANS_TILE_256x128 7   /* loans_igemm_bf16s only: one 512-thread block per CU, three LDS stages (chunk c + 2 in flight) */
 #define LOANS_TILE_DEEP    32  /* loans_igemm_bf16s, OR-ed onto 128x128 / 128x64 / 64x64: a 4 / 5 / 8-stage LDS ring (3 / 4 / 7 chunks of K in
                                   flight per block) for grids of about one block per CU with a long K (res6 / res7 at 512 px) */
+#define LOANS_TILE_256x256PP 43 /* loans_igemm_bf16s only (not LOANS_F_DENSE, no split-K): LOANS_TILE_256x256 with a ping-pong K loop -- waves 0-3 and
+                                   4-7 (the two waves of every SIMD) run half a phase apart, one group on the matrix pipe while the other reads
+                                   fragments and issues LDS-DMA; operand HALF-tiles re-staged the phase after their last read, counted vmcnt,
+                                   raw barriers (csrc/igemm16_pp.h).  Results bit-identical to LOANS_TILE_256x256. */
 #define LOANS_TILE_256x256 9   /* loans_igemm_bf16s only: 512 threads, eight 128 x 64 wave tiles, two LDS stages; 128 FLOP per staged byte */
 #define LOANS_TILE_FINETAIL 8  /* loans_igemm_f32, forward geometry (out row = grid pixel), flags BIAS / STATS / RELU_IN / DENSE only:
                                   64x64 tiles; the tiles that share out evenly over the CUs at full K, the remaining ones (fewer than

@@ -683,6 +683,8 @@ int launch_igemm16(Igemm16Args& a, hipStream_t st) {
     return (a.d.flags & LOANS_F_RELU_IN) ? launch_igemm16_r<BM, BN, WM, WN, ST, true>(a, st) : launch_igemm16_r<BM, BN, WM, WN, ST, false>(a, st);
 }
 
+#include "igemm16_pp.h"      // LOANS_TILE_256x256PP: the same block tile with a ping-pong K loop
+
 void detect_tap_grid16(const loans_igemm_desc* d, Igemm16Args& a) {
     a.ap.nx = 0; a.ap.ny = 0; a.ap.dy0 = a.ap.dx0 = 0; a.ap.sdy = a.ap.sdx = 1; a.ap.rowpat = 0;
     int nx = 1;
@@ -1104,6 +1106,7 @@ static int igemm_bf16s_impl(const void* in, const void* w, void* out, const floa
         case LOANS_TILE_64x64 | LOANS_TILE_DEEP: return launch_igemm16<64, 64, 2, 2, true>(a, st);
         case LOANS_TILE_256x128: return launch_igemm16<256, 128, 4, 2>(a, st);      // 512 threads: eight 64 x 64 wave tiles
         case LOANS_TILE_256x256: return launch_igemm16<256, 256, 2, 4>(a, st);      // 512 threads: eight 128 x 64 wave tiles
+        case LOANS_TILE_256x256PP: return launch_igemm16pp(a, st);                  // the same tile, wave rows half a phase apart
         case LOANS_TILE_HALO_128:
         case LOANS_TILE_HALO_128x64:
         case LOANS_TILE_HALO_256x64:

@@ -544,6 +544,7 @@ def _pw_packed(lib, w, w16, geo, st):
 
 
 TILE_256x256 = 9        # LOANS_TILE_256x256 (loans_igemm_bf16s): eight 128 x 64 wave tiles, for GEMMs with >= 256 columns
+TILE_256x256PP = 43     # LOANS_TILE_256x256PP: the same tile with a ping-pong K loop (csrc/igemm16_pp.h); not for the dense stem
 
 
 TILE_DEEP = 32          # LOANS_TILE_DEEP: a longer LDS ring for grids of about one block per CU
@@ -553,7 +554,7 @@ TILE_DEEP = 32          # LOANS_TILE_DEEP: a longer LDS ring for grids of about 
 def _wide16_tiles(columns, rows=None):
     """further tile forms of loans_igemm_bf16s by GEMM shape: 256 x 256 where the columns fill it, the deep-ring forms of the
     small tiles where the grid is small (at most four 64 x 64 blocks per CU of an MI355X)"""
-    t = (TILE_256x256,) if columns % 256 == 0 else ()
+    t = (TILE_256x256, TILE_256x256PP) if columns % 256 == 0 else ()
     if rows is not None and ((rows + 63) // 64) * ((columns + 63) // 64) <= 1024:
         t += (1 | TILE_DEEP, 2 | TILE_DEEP, 3 | TILE_DEEP)
     return t

@@ -132,23 +132,62 @@ def test_res6_res7_gradients_and_update_parity(deterministic_forward):
     # A ReLU input within fp32 rounding of zero may take the other branch on the device than in the fp64 oracle.  Every one of these
     # crops has a handful of units that close (non-zero |z| < 2e-5 max|z|: 12 / 7 / 19 of ~170 000, the closest at 3e-7), and which
     # way they fall depends on the summation order, i.e. on the tile: under LOANS_TUNE_SALT=9 one unit flips and the 17 x 13 crop
-    # pixels of its receptive field move by 1.5 % (that image: 9e-3; the other ten assignments of profiles/r5_gputest_runs.txt:
-    # 4e-7 on every image).  So: per image; an image without such a unit has to agree to 1e-4, one with them either does or stays
-    # within what a flipped unit can move, and all images but one agree outright.
-    relu_inputs = [oracle_dis.r0_h1, oracle_dis.h1, oracle_dis.r1_h1, oracle_dis.h2, oracle_dis.r2_h1, oracle_dis.h3, oracle_dis.r3_h1,
-                   oracle_dis.h4]
-    near_ties = [sum(int(((np.abs(z[b]) < 2e-5 * np.abs(z[b]).max()) & (z[b] != 0)).sum()) for z in relu_inputs) for b in range(B)]
+    # pixels of its receptive field move by 1.5 % (the other assignments of profiles/r5_gputest_runs.txt: 4e-7 on every image).
+    # What that allows is stated EXACTLY (round 6): an image either agrees with the oracle to 1e-4, or it agrees to 1e-4 with the
+    # oracle's gradient under ONE of its near-tie units taking the other branch (the oracle's backward re-run with that unit's stored
+    # pre-activation negated) -- so a second flipped unit, or any element outside the flipped unit's receptive field that is off
+    # by more than 1e-4, fails -- and all images but one agree outright.
+    tie_layers = ('r0_h1', 'h1', 'r1_h1', 'h2', 'r2_h1', 'h3', 'r3_h1', 'h4')
+
+    def near_tie_units(b):
+        units = []
+        for name in tie_layers:
+            z = getattr(oracle_dis, name)[b]
+            units += [(name, (b,) + tuple(int(v) for v in i)) for i in np.argwhere((np.abs(z) < 2e-5 * np.abs(z).max()) & (z != 0))]
+        return units
+
+    def crop_gradient(assessor, y, flips=()):
+        saved = [(getattr(assessor, name), idx, getattr(assessor, name)[idx]) for name, idx in flips]
+        for z, idx, v in saved:
+            z[idx] = -v
+        try:
+            return assessor.backward(C.mse_bwd(y, np.ones_like(y)), None, need_gx=True)
+        finally:
+            for z, idx, v in saved:
+                z[idx] = v
+    near_ties = [len(near_tie_units(b)) for b in range(B)]
     e_img = [rel_err(g_rois[b], g_rois_ref[b]) for b in range(B)]
     print('   per image:', ['%.1e' % e for e in e_img], 'ReLU inputs within 2e-5 of zero:', near_ties)
+    flips = []
     for b in range(B):
-        assert e_img[b] < (5e-2 if near_ties[b] else 1e-4), (b, e_img[b], near_ties[b])
-    assert sum(e < 1e-4 for e in e_img) >= B - 1, e_img
-    flipped = max([e for e in e_img if e >= 1e-4], default=0.0)      # (what a flipped unit moves the crop gradient by, 0 as a rule)
+        if e_img[b] < 1e-4:
+            continue
+        explained = [u for u in near_tie_units(b) if rel_err(g_rois[b], crop_gradient(oracle_dis, y_o, [u])[b]) < 1e-4]
+        assert len(explained) == 1, (b, e_img[b], near_ties[b], explained)
+        print('   image %d: the device took the other branch of %s%s (z = %.1e in the oracle); with it flipped the crop gradient agrees '
+              'to %.1e' % (b, explained[0][0], explained[0][1][1:], getattr(oracle_dis, explained[0][0])[explained[0][1]],
+                           rel_err(g_rois[b], crop_gradient(oracle_dis, y_o, explained)[b])))
+        flips += explained
+    assert len(flips) <= 1 and sum(e < 1e-4 for e in e_img) >= B - 1, (e_img, flips)
+    loc_ref = res['loc_grads']
+    if flips:
+        # the backbone's reference gradients under the same branch: the oracle's chain A once more (sheep_updater.py:39-52) with
+        # that unit flipped in the assessor pass over ITS crops, where the unit has to be a near tie as well
+        lp_f, dp_f = {k: v.copy() for k, v in lp0.items()}, {k: v.copy() for k, v in dp0.items()}
+        loc_o = M.Localizer(lp_f, crop, train=True, rng=np.random.RandomState(0))
+        x_o, pts_o = loc_o.forward(f64[0])
+        dis_o = M.Assessor(dp_f)
+        y_fo = dis_o.forward(x_o)
+        for name, idx in flips:
+            z = getattr(dis_o, name)
+            assert abs(z[idx]) < 1e-4 * np.abs(z[idx[0]]).max(), (name, idx, z[idx])
+        loc_ref = {}
+        loc_o.backward(crop_gradient(dis_o, y_fo, flips), C.direction_loss(pts_o, (H, W))[1] + C.out_of_image_loss(pts_o)[1], loc_ref)
 
     # ---- 2. the backbone, res6 / res7 included: every unit in situ (its own test function below shares the helper) ----
     worst, worst32, errs = {}, {}, {}
     for key, p in loc.namedparams():
-        ref = res['loc_grads'].get(key[1:])
+        ref = loc_ref.get(key[1:])
         assert ref is not None, key                              # at this height every parameter has a gradient
         if key == '/feature_extractor/conv1/b':
             continue                                             # analytically zero (BN follows): rounding noise
@@ -169,7 +208,7 @@ def test_res6_res7_gradients_and_update_parity(deterministic_forward):
             '%.1e' % rel_err(r32['loc_grads'][k[1:]], res['loc_grads'][k[1:]])) for k in top])
     drift = max(worst32.values())
     for key, e in errs.items():
-        assert e < max(1e-3, 10 * drift, 3 * flipped), (key, e, drift, flipped)
+        assert e < max(1e-3, 10 * drift), (key, e, drift, flips)
 
     # ---- 4. one whole update_core from the same initial state ----
     for _, link, n in loc.namedpersistents():                    # undo the running-statistics update of the pass above
