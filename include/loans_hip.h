@@ -110,6 +110,8 @@ typedef struct loans_igemm_desc {
                                    4-7 (the two waves of every SIMD) run half a phase apart, one group on the matrix pipe while the other reads
                                    fragments and issues LDS-DMA; operand HALF-tiles re-staged the phase after their last read, counted vmcnt,
                                    raw barriers (csrc/igemm16_pp.h).  Results bit-identical to LOANS_TILE_256x256. */
+#define LOANS_TILE_256x256PP16 44 /* LOANS_TILE_256x256PP on v_mfma_f32_16x16x32_bf16 (the shape the chip holds a higher clock on); 32 k values per
+                                     MFMA: results agree with the other tiles to the position of rare bf16 roundings, not bit for bit */
 #define LOANS_TILE_256x256 9   /* loans_igemm_bf16s only: 512 threads, eight 128 x 64 wave tiles, two LDS stages; 128 FLOP per staged byte */
 #define LOANS_TILE_FINETAIL 8  /* loans_igemm_f32, forward geometry (out row = grid pixel), flags BIAS / STATS / RELU_IN / DENSE only:
                                   64x64 tiles; the tiles that share out evenly over the CUs at full K, the remaining ones (fewer than

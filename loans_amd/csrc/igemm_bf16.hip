@@ -13,6 +13,7 @@
 // data gradient are the same kernel (dgrad: one launch per stride-parity class on re-packed weights).
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 #ifdef LOANS_STAMPS
 // Diagnostic build only (tools/stamp_run16.py): per-wave cycle sums of the K-loop phases of the first 64 blocks.
@@ -1106,7 +1107,8 @@ static int igemm_bf16s_impl(const void* in, const void* w, void* out, const floa
         case LOANS_TILE_64x64 | LOANS_TILE_DEEP: return launch_igemm16<64, 64, 2, 2, true>(a, st);
         case LOANS_TILE_256x128: return launch_igemm16<256, 128, 4, 2>(a, st);      // 512 threads: eight 64 x 64 wave tiles
         case LOANS_TILE_256x256: return launch_igemm16<256, 256, 2, 4>(a, st);      // 512 threads: eight 128 x 64 wave tiles
-        case LOANS_TILE_256x256PP: return launch_igemm16pp(a, st);                  // the same tile, wave rows half a phase apart
+        case LOANS_TILE_256x256PP: return launch_igemm16pp<false>(a, st);           // the same tile, wave rows half a phase apart
+        case LOANS_TILE_256x256PP16: return launch_igemm16pp<true>(a, st);          // ... on v_mfma_f32_16x16x32_bf16
         case LOANS_TILE_HALO_128:
         case LOANS_TILE_HALO_128x64:
         case LOANS_TILE_HALO_256x64:

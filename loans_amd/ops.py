@@ -545,6 +545,7 @@ def _pw_packed(lib, w, w16, geo, st):
 
 TILE_256x256 = 9        # LOANS_TILE_256x256 (loans_igemm_bf16s): eight 128 x 64 wave tiles, for GEMMs with >= 256 columns
 TILE_256x256PP = 43     # LOANS_TILE_256x256PP: the same tile with a ping-pong K loop (csrc/igemm16_pp.h); not for the dense stem
+TILE_256x256PP16 = 44   # ... on v_mfma_f32_16x16x32_bf16 (not bit-identical to the 32 x 32 x 16 tiles: 32 k values per MFMA)
 
 
 TILE_DEEP = 32          # LOANS_TILE_DEEP: a longer LDS ring for grids of about one block per CU
@@ -554,7 +555,7 @@ TILE_DEEP = 32          # LOANS_TILE_DEEP: a longer LDS ring for grids of about 
 def _wide16_tiles(columns, rows=None):
     """further tile forms of loans_igemm_bf16s by GEMM shape: 256 x 256 where the columns fill it, the deep-ring forms of the
     small tiles where the grid is small (at most four 64 x 64 blocks per CU of an MI355X)"""
-    t = (TILE_256x256, TILE_256x256PP) if columns % 256 == 0 else ()
+    t = (TILE_256x256, TILE_256x256PP, TILE_256x256PP16) if columns % 256 == 0 else ()
     if rows is not None and ((rows + 63) // 64) * ((columns + 63) // 64) <= 1024:
         t += (1 | TILE_DEEP, 2 | TILE_DEEP, 3 | TILE_DEEP)
     return t
@@ -1313,9 +1314,9 @@ def crop_dgrad(gy_a, w_a, geo_a, gy_b=None, w_b=None, geo_b=None, addend=None):
     for gy, g in ((gy_a, geo_a), (gy_b, geo_b)):
         if gy is not None:
             _count_flops('dgrad', g)
-            _acct('crop', _conv_flop(g), _nbytes(gy))
+            if CLASS_COUNT is not None: _acct('crop', _conv_flop(g), _nbytes(gy))
     out = _empty((geo_a.B, geo_a.H, geo_a.W, 4), device=gy_a.device, dtype=torch.float32)
-    _acct('crop', 0, _nbytes(addend), _nbytes(out))
+    if CLASS_COUNT is not None: _acct('crop', 0, _nbytes(addend), _nbytes(out))
     mk = lambda g: _lib.SmallConv(g.k, g.stride, g.pad, g.Ho, g.Wo)      # noqa: E731
     ca, cb = mk(geo_a), (mk(geo_b) if geo_b is not None else None)
     fn = lib.loans_crop_dgrad_bf16_f32 if _is16(gy_a) else lib.loans_crop_dgrad_f32
@@ -1549,7 +1550,7 @@ def _wgrad_workspace(lib, geo, desc, tile, splits, device, st):
 def _conv_wgrad(x, gy, dw, geo, relu_in, splits, tile, stream=None, in_affine=None):
     lib = _lib.load()
     _count_flops('wgrad', geo)
-    _acct('wgrad', _conv_flop(geo), _nbytes(x, gy), _nbytes(dw))
+    if CLASS_COUNT is not None: _acct('wgrad', _conv_flop(geo), _nbytes(x, gy), _nbytes(dw))
     assert dw.numel() == geo.w_numel and x.numel() == geo.in_numel
     fl = (F_RELU_IN if relu_in else 0) | geo.base_flags
     s16 = _is16(x)
@@ -1624,7 +1625,7 @@ def prep_images(images_nchw, geo=None):
     B, c, H, W = images_nchw.shape
     assert c == 3
     _chk(images_nchw, 'images')
-    _acct('heads', 0, _nbytes(images_nchw), B * H * W * 3 * (2 if (STORAGE == 'bf16' and DENSE_BF16) else 4))
+    if CLASS_COUNT is not None: _acct('heads', 0, _nbytes(images_nchw), B * H * W * 3 * (2 if (STORAGE == 'bf16' and DENSE_BF16) else 4))
     if geo is not None and geo.dense:
         assert (geo.B, geo.H, geo.W) == (B, H, W)
         # bf16 storage arm: the frames leave this kernel as bf16 (the same rounding the bf16 arm applies to fp32 frames
@@ -1882,7 +1883,7 @@ class _WeightPrep:
                 if getattr(arena, 'data16', None) is None:
                     arena.data16 = torch.empty(arena.numel, device=arena.device, dtype=BF16)
                 check(lib.loans_cast_bf16(_ptr(arena.data), _ptr(arena.data16), arena.numel, st), 'loans_cast_bf16')
-                _acct('optimizer', 0, arena.numel * 4, arena.numel * 2)
+                if CLASS_COUNT is not None: _acct('optimizer', 0, arena.numel * 4, arena.numel * 2)
                 self.shadow_ok[id(arena)] = arena.numel
         self._begin_pw(device, lib, st, capturing)
         if not self.order:
@@ -2070,7 +2071,7 @@ def bn_apply(x, st, relu=True, residual=None, x2=None, st2=None, want_bits=False
         mode, second = 2, x2
     lib = _lib.load()
     assert second is None or second.dtype == x.dtype
-    _acct('bn_fwd', 0, _nbytes(x, second), _nbytes(y) + (rows * (C_ // 4) if (want_bits and relu) else 0))
+    if CLASS_COUNT is not None: _acct('bn_fwd', 0, _nbytes(x, second), _nbytes(y) + (rows * (C_ // 4) if (want_bits and relu) else 0))
     if want_bits and relu:
         bits = _empty(rows * (C_ // 4), device=x.device, dtype=torch.uint8)
         fn = lib.loans_bn_apply_bits_bf16 if _is16(x) else lib.loans_bn_apply_bits_f32
@@ -2102,12 +2103,12 @@ def bn_relu_maxpool(x, st, want_sel=False):
     lib = _lib.load()
     if want_sel and POOL_ARGMAX_VALUES and bn_units_ok(C_, s16) and reduce_channels_ok(C_) and C_ <= 1024:
         xsel = _empty((B, OH, OW, C_), device=x.device, dtype=x.dtype)
-        _acct('stem', 0, _nbytes(x), _nbytes(y, idx, xsel))
+        if CLASS_COUNT is not None: _acct('stem', 0, _nbytes(x), _nbytes(y, idx, xsel))
         fn = lib.loans_bn_relu_maxpool_sel_bf16 if s16 else lib.loans_bn_relu_maxpool_sel_f32
         check(fn(_ptr(x), _ptr(st.scale), _ptr(st.shift), _ptr(y), _ptr(idx), _ptr(xsel), B, H, W, C_, OH, OW, _stream()),
               'loans_bn_relu_maxpool_sel')
         return y, idx, xsel
-    _acct('stem', 0, _nbytes(x), _nbytes(y, idx))
+    if CLASS_COUNT is not None: _acct('stem', 0, _nbytes(x), _nbytes(y, idx))
     fn = lib.loans_bn_relu_maxpool_bf16 if s16 else lib.loans_bn_relu_maxpool_f32
     check(fn(_ptr(x), _ptr(st.scale), _ptr(st.shift), _ptr(y), _ptr(idx), B, H, W, C_, OH, OW, _stream()),
           'loans_bn_relu_maxpool')
@@ -2257,7 +2258,7 @@ def bn_backward_from_sums(gy, x, st, sums, gamma, ggamma, gbeta):
     rows = x.numel() // C_
     s = _stream()
     s16 = _is16(x)
-    _acct('bn_bwd', 0, _nbytes(gy, x), _nbytes(x))              # the sums rode in the data gradient's epilogue: one pass
+    if CLASS_COUNT is not None: _acct('bn_bwd', 0, _nbytes(gy, x), _nbytes(x))              # the sums rode in the data gradient's epilogue: one pass
     assert _is16(gy) == s16 and sums.numel() == STATS_REPLICAS * 2 * C_
     k = _empty((3, C_), device=x.device, dtype=torch.float32)
     check(lib.loans_bn_bwd_coeffs_rep_f32(_ptr(sums), STATS_REPLICAS, 2 * C_, 1, C_, rows, _ptr(gamma), _ptr(st.mean), _ptr(st.rstd),
@@ -2280,9 +2281,9 @@ def pool_bn_backward(gy, idx, x, st, gamma, ggamma, gbeta, gbias=None, xsel=None
     B, H, W, C_ = x.shape
     OH, OW = gy.shape[1], gy.shape[2]
     if xsel is not None:
-        _acct('stem', 0, _nbytes(gy, xsel) + _nbytes(gy, idx) + _nbytes(x), _nbytes(x))  # sums over (gy, xsel), then gx
+        if CLASS_COUNT is not None: _acct('stem', 0, _nbytes(gy, xsel) + _nbytes(gy, idx) + _nbytes(x), _nbytes(x))  # sums over (gy, xsel), then gx
     else:
-        _acct('stem', 0, 2 * _nbytes(gy, idx) + 2 * _nbytes(x), _nbytes(x))    # sums over the pooled gradient (gathers x), then gx
+        if CLASS_COUNT is not None: _acct('stem', 0, 2 * _nbytes(gy, idx) + 2 * _nbytes(x), _nbytes(x))    # sums over the pooled gradient (gathers x), then gx
     if not (reduce_channels_ok(C_) and C_ <= 1024):        # (the three-pass form: channel counts the fused pair does not tile)
         gx = bn_backward(maxpool_relu_bwd(gy, idx, x, st), None, x, st, gamma, ggamma, gbeta)
         if gbias is not None:
@@ -2336,7 +2337,7 @@ def colsum_acc(x, out):
 def gap_fwd(x):
     B, H, W, C_ = x.shape
     y = _empty((B, C_), device=x.device, dtype=torch.float32)
-    _acct('heads', 0, _nbytes(x), _nbytes(y))
+    if CLASS_COUNT is not None: _acct('heads', 0, _nbytes(x), _nbytes(y))
     lib = _lib.load()
     fn = lib.loans_gap_fwd_bf16_f32 if _is16(x) else lib.loans_gap_fwd_f32
     check(fn(_ptr(x), _ptr(y), B, H * W, C_, _stream()), 'loans_gap_fwd')
@@ -2346,7 +2347,7 @@ def gap_fwd(x):
 def gap_bwd(gy, shape, dtype=torch.float32):
     B, H, W, C_ = shape
     gx = _empty(shape, device=gy.device, dtype=dtype)
-    _acct('heads', 0, _nbytes(gy), _nbytes(gx))
+    if CLASS_COUNT is not None: _acct('heads', 0, _nbytes(gy), _nbytes(gx))
     lib = _lib.load()
     fn = lib.loans_gap_bwd_f32_bf16 if dtype == BF16 else lib.loans_gap_bwd_f32
     check(fn(_ptr(gy), _ptr(gx), B, H * W, C_, _stream()), 'loans_gap_bwd')
@@ -2358,7 +2359,7 @@ def linear_fwd(x, W, b, act_in=False, act_out=False):
     K = x.numel() // B
     N = W.numel() // K
     y = _empty((B, N), device=x.device, dtype=torch.float32)
-    _acct('heads', 2 * B * K * N, _nbytes(x, W), _nbytes(y))
+    if CLASS_COUNT is not None: _acct('heads', 2 * B * K * N, _nbytes(x, W), _nbytes(y))
     lib = _lib.load()
     fn = lib.loans_linear_fwd_bf16 if _is16(x) else lib.loans_linear_fwd_f32
     check(fn(_ptr(x), _ptr(W), _ptr(b), _ptr(y), B, K, N, int(act_in), int(act_out), _stream()), 'loans_linear_fwd')
@@ -2370,7 +2371,7 @@ def linear_bwd(x, W, y, gy, gW=None, gb=None, need_gx=True, act_in=False, act_ou
     K = x.numel() // B
     N = W.numel() // K
     gx = _empty_like(x) if need_gx else None
-    _acct('heads', (4 if need_gx else 2) * B * K * N, _nbytes(x, W, gy), _nbytes(gx, gW))
+    if CLASS_COUNT is not None: _acct('heads', (4 if need_gx else 2) * B * K * N, _nbytes(x, W, gy), _nbytes(gx, gW))
     lib = _lib.load()
     fn = lib.loans_linear_bwd_bf16 if _is16(x) else lib.loans_linear_bwd_f32
     check(fn(_ptr(x), _ptr(W), _ptr(y), _ptr(gy), _ptr(gx), _ptr(gW), _ptr(gb),
@@ -2474,7 +2475,7 @@ def st_sampler_fwd(images_nchw, grid):
     B, _, H, W = images_nchw.shape
     th, tw = grid.shape[2:]
     rois = _empty((B, th, tw, 4), device=grid.device, dtype=torch.float32)
-    _acct('crop', 0, _nbytes(grid) + 4 * 3 * 4 * B * th * tw, _nbytes(rois))        # four taps of three channels per crop pixel
+    if CLASS_COUNT is not None: _acct('crop', 0, _nbytes(grid) + 4 * 3 * 4 * B * th * tw, _nbytes(rois))        # four taps of three channels per crop pixel
     check(_lib.load().loans_st_sampler_fwd_f32(_ptr(images_nchw), _ptr(grid), _ptr(rois), B, H, W, th, tw, _stream()),
           'loans_st_sampler_fwd_f32')
     return rois
@@ -2484,7 +2485,7 @@ def st_sampler_bwd_grid(images_nchw, grid, grois):
     B, _, H, W = images_nchw.shape
     th, tw = grid.shape[2:]
     ggrid = _empty_like(grid)
-    _acct('crop', 0, _nbytes(grid, grois) + 4 * 3 * 4 * B * th * tw, _nbytes(ggrid))
+    if CLASS_COUNT is not None: _acct('crop', 0, _nbytes(grid, grois) + 4 * 3 * 4 * B * th * tw, _nbytes(ggrid))
     check(_lib.load().loans_st_sampler_bwd_grid_f32(_ptr(images_nchw), _ptr(grid), _ptr(grois), _ptr(ggrid), 0,
                                                     B, H, W, th, tw, _stream()), 'loans_st_sampler_bwd_grid_f32')
     return ggrid
@@ -2525,7 +2526,7 @@ def grid_loss_bwd(grid, gloss, kind, img_h=0.0, img_w=0.0, oob_scale=1.0):
 def adam_amsgrad(p, g, m, v, vhat, lr_t, beta1, beta2, eps, eta, weight_decay_rate, grad_scale=1.0):
     """lr_t: a Python float, or a 1-element device tensor read by the kernel when it runs (graph-capturable).
     vhat=None: plain Adam (amsgrad=False)."""
-    _acct('optimizer', 0, _nbytes(p, g, m, v, vhat), _nbytes(p, m, v, vhat))
+    if CLASS_COUNT is not None: _acct('optimizer', 0, _nbytes(p, g, m, v, vhat), _nbytes(p, m, v, vhat))
     if vhat is None:
         dev_lr = torch.is_tensor(lr_t)
         if dev_lr:

@@ -45,7 +45,7 @@ CASES = [
 
 
 @pytest.mark.parametrize("case", CASES)
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 7, 9, 43, 33, 34, 35, 5])     # 5: a weight-gradient tile; 7, 9: 512 threads; 43: 9 with a ping-pong K loop; +32: deep ring
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 4, 7, 9, 43, 44, 33, 34, 35, 5])     # 5: a weight-gradient tile; 7, 9: 512 threads; 43 / 44: 9 with a ping-pong K loop (44: 16 x 16 x 32 MFMAs); +32: deep ring
 def test_conv_bf16_storage(case, tile):
     from loans_amd import ops
     B, Cin, H, W, Cout, k, s, p = case
@@ -693,7 +693,7 @@ def test_stem_direct_bf16(case):
 
 
 @pytest.mark.parametrize("case", [(2, 64, 15, 13, 128, 3, 2, 1), (3, 128, 12, 12, 256, 3, 2, 1), (2, 64, 9, 9, 64, 1, 2, 0), (5, 32, 8, 8, 96, 3, 2, 1)])
-@pytest.mark.parametrize("tile", [0, 1, 2, 3, 7, 9, 43, 33, 35])
+@pytest.mark.parametrize("tile", [0, 1, 2, 3, 7, 9, 43, 44, 33, 35])
 def test_conv_pair_bf16_storage(case, tile):
     """loans_igemm_pair_bf16s: a unit's first convolution and its conv shortcut as ONE GEMM with the weights stacked along N.
     Every output element is contracted in the order of the single launch with the same tile, so the two tensors are
@@ -730,7 +730,7 @@ def test_conv_pair_bf16_storage(case, tile):
 
 
 @pytest.mark.parametrize("storage,tiles", [('f32', [0, 1, 2, 3, 4, 6, 17, 18, 19, 20]),
-                                           ('bf16', [0, 1, 2, 3, 4, 7, 9, 43, 33, 34, 35, 11, 12, 13, 14, 36, 37, 42])])
+                                           ('bf16', [0, 1, 2, 3, 4, 7, 9, 43, 44, 33, 34, 35, 11, 12, 13, 14, 36, 37, 42])])
 @pytest.mark.parametrize("case", [(3, 64, 14, 14, 64, 3), (2, 128, 20, 33, 128, 3), (2, 256, 9, 12, 64, 3), (5, 64, 17, 12, 256, 1),
                                   (2, 512, 6, 7, 128, 1)])
 def test_data_gradient_takes_the_bn_backward_sums(storage, tiles, case):
@@ -767,7 +767,7 @@ def test_data_gradient_takes_the_bn_backward_sums(storage, tiles, case):
         for tile in tiles:
             if s16 and tile in (11, 12, 13, 14, 36, 37, 42) and tile not in ops._halo_tiles(geo, geo.Cout, geo.Cin, (geo.H, geo.W)):
                 continue
-            if s16 and tile in (9, 43) and C_ % 256:
+            if s16 and tile in (9, 43, 44) and C_ % 256:
                 continue
             plain = ops.conv_dgrad(gyd, wd, geo, tile=tile)
             z = lambda: torch.zeros(C_, device='cuda')      # noqa: E731

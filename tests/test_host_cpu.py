@@ -189,10 +189,15 @@ def test_round2_tile_offers_host_logic():
         assert ops._class_candidates(g32) == ()                   # fp32 arm only
     finally:
         ops.set_compute_dtype('f32')
-    assert ops._wide16_tiles(512) == (ops.TILE_256x256,) and ops._wide16_tiles(128) == ()
+    # 256 columns: the 256 x 256 tile, its ping-pong form (round 6) and that on 16 x 16 x 32 MFMAs
+    wide = (ops.TILE_256x256, ops.TILE_256x256PP, ops.TILE_256x256PP16)
+    assert ops._wide16_tiles(512) == wide and ops._wide16_tiles(128) == ()
     deep = ops._wide16_tiles(512, rows=2048)                      # res7 at 512 px: 32 x 8 tiles of 64 x 64
-    assert set(deep) == {ops.TILE_256x256, 1 | ops.TILE_DEEP, 2 | ops.TILE_DEEP, 3 | ops.TILE_DEEP}
-    assert ops._wide16_tiles(512, rows=128 * 32 * 32) == (ops.TILE_256x256,)      # res4: a grid that fills the machine
+    assert set(deep) == set(wide) | {1 | ops.TILE_DEEP, 2 | ops.TILE_DEEP, 3 | ops.TILE_DEEP}
+    assert ops._wide16_tiles(512, rows=128 * 32 * 32) == wide                     # res4: a grid that fills the machine
+    res4 = ops.ConvGeometry(2, 32, 32, 256, 256, 3, 1, 1)
+    assert ops.TILE_HALO_256x256 in ops._halo_tiles(res4, 256, 256, (32, 32))     # 16 x 16 pixels x 256 channels (round 6)
+    assert ops.TILE_HALO_256x256 not in ops._halo_tiles(res4, 256, 128, (32, 32))
     res2 = ops.ConvGeometry(2, 128, 128, 64, 64, 3, 1, 1)
     t = ops._halo_tiles(res2, 64, 64, (128, 128))
     assert ops.TILE_WS64 in t and ops.TILE_WSW64 in t and ops.TILE_HALO_256x128 not in t
