@@ -6,8 +6,9 @@ reference's ``ImageDataset`` (common/datasets/image_dataset.py:47-98) do not cha
 of the augmentation do -- so a frame is decoded the first time an epoch asks for it and kept as the uint8 HWC array the
 resize would see:
 
-* ``where='device'`` (default): in HBM, one growing ``[N][H][W][3]`` uint8 tensor per source size (288 GB hold ~300 k frames
-  of 480 x 640).  A batch whose frames are resident is a device-side gather in front of the augmentation / LANCZOS kernels:
+* ``where='device'`` (default): in HBM, fixed-size ``[chunk][H][W][3]`` uint8 pools per source size (288 GB hold ~300 k frames
+  of 480 x 640); what is ALLOCATED counts against the budget -- a pool is added only if it fits what is left -- so the resident
+  bytes never exceed ``budget_bytes`` and nothing is ever copied to grow (the doubling tensor held up to 2-3 x it).  A batch whose frames are resident is a device-side gather in front of the augmentation / LANCZOS kernels:
   no decode, no pinned staging copy, no PCIe transfer.
 * ``where='host'``: the decoded arrays in host memory; the batch is staged and uploaded as before, only the decode is skipped.
   (The naive crop / flip branch -- ``use_imgaug=False`` -- hands strided VIEWS of a frame to the resize and always uses this form.)
@@ -34,7 +35,8 @@ class FrameCache:
         self.where, self.budget, self.bytes = where, int(budget_bytes), 0
         self.host = {}              # index -> uint8 HWC array                         (where == 'host')
         self.slots = {}             # index -> ((H, W), slot)                            (where == 'device')
-        self.pools = {}             # (H, W) -> {'t': uint8 tensor [cap][H][W][3], 'n': frames in it}
+        self.pools = {}             # (H, W) -> {'chunks': [uint8 tensor [cap][H][W][3], ...], 'cap': frames per chunk, 'n': frames stored}
+        self.allocated = 0          # bytes of all pools (device mode): what the budget bounds
         self.lock = threading.Lock()        # the decode thread asks, the finish thread stores
         self.hits = self.misses = 0
 
@@ -66,27 +68,48 @@ class FrameCache:
                 self.bytes += image.nbytes
 
     # ---- finish thread (device mode) ------------------------------------------------------------------------------------------
+    POOL_BYTES = 64 << 20         # a pool chunk: about 64 MiB of frames (at least 8 frames)
+
     def _store(self, size, indices, frames_dev):
-        """append freshly uploaded frames [m][H][W][3] of one size to that size's pool (as many as the budget admits)"""
+        """append freshly uploaded frames [m][H][W][3] of one size to that size's pools (as many as the budget admits)"""
         H, W = size
         per = H * W * 3
         pool = self.pools.get(size)
-        m = min(len(indices), max(0, (self.budget - self.bytes) // per))
-        if m <= 0:
-            return
         if pool is None:
-            pool = self.pools[size] = {'t': torch.empty((max(256, 2 * m), H, W, 3), device=frames_dev.device, dtype=torch.uint8), 'n': 0}
-        if pool['n'] + m > pool['t'].shape[0]:
-            grown = torch.empty((max(2 * pool['t'].shape[0], pool['n'] + m), H, W, 3), device=frames_dev.device, dtype=torch.uint8)
-            grown[:pool['n']].copy_(pool['t'][:pool['n']])
-            pool['t'] = grown
-        n = pool['n']
-        pool['t'][n:n + m].copy_(frames_dev[:m])
-        pool['n'] = n + m
-        with self.lock:
-            for k, i in enumerate(indices[:m]):
-                self.slots[i] = (size, n + k)
-            self.bytes += m * per
+            pool = self.pools[size] = {'chunks': [], 'cap': max(8, self.POOL_BYTES // per), 'n': 0}
+        cap, stored = pool['cap'], 0
+        while stored < len(indices):
+            room = len(pool['chunks']) * cap - pool['n']
+            if room == 0:
+                if self.allocated + cap * per > self.budget:
+                    break                                   # the next chunk does not fit the budget: the rest stays uncached
+                pool['chunks'].append(torch.empty((cap, H, W, 3), device=frames_dev.device, dtype=torch.uint8))
+                self.allocated += cap * per
+                room = cap
+            m = min(room, len(indices) - stored)
+            off = pool['n'] % cap
+            pool['chunks'][-1][off:off + m].copy_(frames_dev[stored:stored + m])
+            with self.lock:
+                for k in range(m):
+                    self.slots[indices[stored + k]] = (size, pool['n'] + k)
+                self.bytes += m * per
+            pool['n'] += m
+            stored += m
+
+    def _gather(self, size, slots, device):
+        """the frames at `slots` (global slot numbers of one size) as one [len][H][W][3] tensor, in that order"""
+        pool = self.pools[size]
+        cap = pool['cap']
+        if len(pool['chunks']) == 1:
+            return pool['chunks'][0].index_select(0, torch.tensor(slots, dtype=torch.int64).to(device, non_blocking=True))
+        out = torch.empty((len(slots),) + tuple(pool['chunks'][0].shape[1:]), device=device, dtype=torch.uint8)
+        by_chunk = {}
+        for pos, sl in enumerate(slots):
+            by_chunk.setdefault(sl // cap, []).append(pos)
+        for c, positions in by_chunk.items():
+            inside = torch.tensor([slots[p] % cap for p in positions], dtype=torch.int64).to(device, non_blocking=True)
+            out[torch.tensor(positions, dtype=torch.int64).to(device, non_blocking=True)] = pool['chunks'][c].index_select(0, inside)
+        return out
 
     def assemble(self, frames, rows, indices, out_hw, device, map_fn=map):
         """``frames_to_device`` for a batch whose entries are decoded arrays (misses: uploaded and stored) or CachedFrame
@@ -115,7 +138,7 @@ class FrameCache:
             else:
                 with self.lock:
                     sl = [self.slots[frames[p].index][1] for p in hit]
-                cached = self.pools[size]['t'].index_select(0, torch.tensor(sl, dtype=torch.int64).to(device, non_blocking=True))
+                cached = self._gather(size, sl, device)
                 g, order = (cached, hit) if up is None else (torch.cat([cached, up], dim=0), hit + miss)
             if rows is not None:            # the imgaug branch (augment.py), per image, before the resize (reference :80-93)
                 g = apply_device(g, [rows[p] for p in order])

@@ -32,11 +32,12 @@ class RotationDropout(Function):
         if not config.train:
             # scale affected weights if we are testing (rotation_droput.py:30-36)
             self.mask = self._mask(x[0], float(self.dropout_ratio))
-            return ops.mul(x[0].contiguous(), self.mask)
+            return ops.mul(x[0].contiguous(), self.mask, keep=True)
         if not hasattr(self, 'mask'):
             flag_data = bool(numpy.random.rand(1)[0] < self.dropout_ratio)      # :41
             self.mask = self._mask(x[0], float(flag_data))
-        return ops.mul(x[0].contiguous(), self.mask)
+        # keep: theta is what SheepLocalizer.last_transform_params holds across steps (ops._StepArena's contract)
+        return ops.mul(x[0].contiguous(), self.mask, keep=True)
 
     def backward(self, x, gy):
         return ops.mul(gy[0].contiguous(), self.mask)

@@ -50,6 +50,12 @@ def set_storage_dtype(name):
     STORAGE = name
 
 
+for _gone in ('LOANS_COMPUTE', 'LOANS_STORAGE'):         # removed in round 5 (the arithmetic is a property of the model): say so
+    if os.environ.get(_gone):
+        import warnings
+        warnings.warn('%s is no longer read: use Link.set_precision / ops.precision' % _gone, stacklevel=1)
+
+
 def check_precision(compute, storage):
     if compute not in ('f32', 'bf16') or storage not in ('f32', 'bf16'):
         raise ValueError("compute / storage dtype must be 'f32' or 'bf16'")
@@ -65,11 +71,22 @@ class precision:
     live in one process (tests/test_gpu_bf16_storage.py::test_fp32_and_bf16_models_step_in_one_process).  COMPUTE / STORAGE
     above are the scope's current value: the process default outside any scope."""
 
+    # The scope is PROCESS-wide (module globals, read by every launcher): one thread at a time may hold one.  A second thread
+    # that asks for ANOTHER arithmetic while a scope is open would silently run -- or make the owner run -- in the wrong one
+    # (ADVICE r5), so that is an error here; the same arithmetic, or no scope at all, is fine from any thread.
+    _owner, _depth = None, 0
+
     def __init__(self, compute, storage=None):
         self.want = check_precision(compute, storage if storage is not None else ('f32' if compute == 'f32' else 'bf16'))
 
     def __enter__(self):
         global COMPUTE, STORAGE
+        me = threading.get_ident()
+        if precision._depth and precision._owner != me and self.want != (COMPUTE, STORAGE):
+            raise RuntimeError('ops.precision%r entered on a second thread while another thread holds %r: the scope is '
+                               'process-wide' % (self.want, (COMPUTE, STORAGE)))
+        self.prev_owner = precision._owner
+        precision._owner, precision._depth = me, precision._depth + 1
         self.old = (COMPUTE, STORAGE)
         COMPUTE, STORAGE = self.want
         return self
@@ -77,6 +94,8 @@ class precision:
     def __exit__(self, *exc):
         global COMPUTE, STORAGE
         COMPUTE, STORAGE = self.old
+        precision._depth -= 1
+        precision._owner = self.prev_owner if precision._depth else None
         return False
 
 
@@ -1667,7 +1686,12 @@ class _StepArena:
     launch is behind that update.  Sized from the step before (the first step of a shape runs on torch's allocator and is
     measured); a request that does not fit, a request from another thread (the feed) and everything outside begin_step ..
     end_step falls back to ``torch.empty``.  Tensors of under 4 KiB (the reported losses, coefficient vectors) stay with torch:
-    observers read them after the step."""
+    observers read them after the step.
+    THE CONTRACT: a tensor of 4 KiB or more made by an op between begin_step and end_step -- a link's outputs, the
+    gradient of a non-parameter input -- is overwritten by the NEXT step; whoever keeps one across ``update()`` calls must copy
+    it.  What the package itself exposes across steps is allocated outside the arena: the reported losses (small), the parameters
+    and their gradients (the links' own arenas), ``SheepLocalizer.last_transform_params`` (``mul(..., keep=True)``).
+    ``tools/arena_poison.py`` fills the arena with NaN bit patterns at every begin_step to catch a violation in development."""
     SMALL = 4096
     ALIGN = 256
     MAX_FRACTION = 0.5
@@ -2379,8 +2403,9 @@ def linear_bwd(x, W, y, gy, gW=None, gb=None, need_gx=True, act_in=False, act_ou
     return gx
 
 
-def mul(x, m):
-    y = _empty_like(x)
+def mul(x, m, keep=False):
+    """keep: the result outlives the step (a tensor callers hold across update() calls): never a slice of the step arena"""
+    y = torch.empty_like(x) if keep else _empty_like(x)
     check(_lib.load().loans_mul_f32(_ptr(x), _ptr(m), _ptr(y), x.numel(), _stream()), 'loans_mul_f32')
     return y
 

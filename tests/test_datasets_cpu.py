@@ -104,3 +104,26 @@ def test_imgaug_branch_restated(tmp_path):
     assert not np.array_equal(a, np.stack([plain.get_example(i) for i in range(4)]))
     ds.reseed(3)
     np.testing.assert_array_equal(np.stack([ds.get_example(i) for i in range(4)]), a)          # same stream, same frames
+
+
+def test_frame_cache_pools_stay_inside_the_budget():
+    """the device frame cache counted stored frames against its budget while its doubling pool held up to 2-3 x that.
+    Now fixed-size pool chunks are allocated only while they fit what is left of the budget, nothing is copied to grow, and a
+    gather across chunks returns the stored bytes in the order asked (host logic on CPU tensors)."""
+    import torch
+    from loans_amd.common.datasets.frame_cache import FrameCache
+    H, W = 6, 10
+    per = H * W * 3
+    cache = FrameCache(budget_bytes=20 * per, where='device')
+    cache.POOL_BYTES = 8 * per                      # 8 frames per chunk: at most two chunks fit 20 frames of budget
+    rng = np.random.RandomState(0)
+    frames = torch.from_numpy(rng.randint(0, 256, (30, H, W, 3)).astype(np.uint8))
+    cache._store((H, W), list(range(100, 113)), frames[:13])            # 13 frames: two chunks
+    assert cache.allocated == 16 * per <= cache.budget and len(cache.pools[(H, W)]['chunks']) == 2
+    cache._store((H, W), list(range(113, 130)), frames[13:30])          # only 3 more fit the two chunks; a third chunk would not
+    assert cache.allocated == 16 * per and cache.bytes == 16 * per and len(cache) == 16
+    assert set(cache.slots) == set(range(100, 116))
+    order = [115, 100, 108, 107, 101]
+    got = cache._gather((H, W), [cache.slots[i][1] for i in order], torch.device('cpu'))
+    assert torch.equal(got, frames[[i - 100 for i in order]])
+    assert cache.lookup(120) is None and cache.lookup(104) is not None

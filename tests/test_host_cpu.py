@@ -273,6 +273,34 @@ def test_wgrad_workspace_a_capture_has_seen_is_never_freed(monkeypatch):
     assert ws0.data_ptr() != ws2.data_ptr()
 
 
+def test_precision_scope_is_loud_about_a_second_thread():
+    """ops.precision sets process-wide globals.  A second thread asking for ANOTHER arithmetic while a scope is open used
+    to run (or make the owner run) in the wrong one silently; now it raises.  The same arithmetic from another thread, nesting on
+    the owner's thread and the restore on exit keep working."""
+    import threading
+    from loans_amd import ops
+    seen = {}
+
+    def other():
+        try:
+            with ops.precision('f32'):
+                seen['f32'] = 'entered'
+        except RuntimeError as e:
+            seen['f32'] = str(e)
+        with ops.precision('bf16'):
+            seen['bf16'] = ops.current_precision()
+    base = ops.current_precision()
+    with ops.precision('bf16'):
+        t = threading.Thread(target=other)
+        t.start()
+        t.join()
+        assert 'second thread' in seen['f32'] and seen['bf16'] == ('bf16', 'bf16')
+        with ops.precision('f32'):
+            assert ops.current_precision() == ('f32', 'f32')
+        assert ops.current_precision() == ('bf16', 'bf16')
+    assert ops.current_precision() == base and ops.precision._depth == 0 and ops.precision._owner is None
+
+
 def test_tune_table_round_trip(tmp_path, monkeypatch):
     """A normal run writes its tile table, the profiled runs of the same command read it: same kernels in both
     (ops.save_tune_table / load_tune_table, bench.py --tune-file).  What a file holds is a PROPOSAL: it is launched only if
