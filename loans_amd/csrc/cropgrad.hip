@@ -13,12 +13,20 @@
 //   B operand: the forward OHWI weights, re-laid into MFMA fragment order by a 64-thread pre-pass of the same call
 //     (crop_pack_w_kernel, 48 blocks, caller-owned 64 KB workspace), then 16 coalesced loads per (wave, column block);
 //   v_mfma_f32_32x32x2_f32, fp32 accumulate; out-of-image gradient pixels are zero rows of T.
+//   bf16 gradient tensors (the bf16 storage arm, round 6): the contraction runs on v_mfma_f32_32x32x16_bf16 -- lane (r, h) reads
+//     channels 16 s + 8 h .. + 7 of its pixel as ONE 16-byte load per step (8 loads per row block instead of 16, 8 MFMAs instead
+//     of 64), the weights are rounded to bf16 (RNE) by the packing pre-pass, fp32 accumulation and fp32 gx as before.  On fp32
+//     MFMAs the kernel was bound by the matrix pipe, not by HBM (56 GFLOP at B = 256 = 0.36 ms at the 157 TFLOP/s peak).
 // Bound: HBM (each gradient tensor once: 0.94 GB at B = 256 of 75 x 75 crops); replaces five launches of the VALU
 // kernel in smalln.hip (2.8 ms per step) on this path -- that kernel stays for geometries this one does not cover.
 #include "common.h"
 #include <stdlib.h>
+#include <type_traits>
 
 namespace {
+
+typedef __bf16 crop_bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned crop_u32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int TILE = 16;             // output tile edge
 constexpr int MAX_JOBS = 4;
@@ -84,6 +92,24 @@ __global__ __launch_bounds__(64) void crop_pack_w_kernel(const CropArgs a, f32x4
     wpack[(jb * KG + g) * 64 + lane] = v;
 }
 
+// the same for the bf16 contraction: wpack16[job][s][lane] = the eight bf16 {w[16 s + 8 h + j][tap(n)][ci(n)], j = 0..7}
+__global__ __launch_bounds__(64) void crop_pack_w16_kernel(const CropArgs a, crop_bf16x8* wpack) {
+    constexpr int KS = KG / 2;
+    const int jb = blockIdx.x / KS, s = blockIdx.x - jb * KS, lane = threadIdx.x;
+    const CropConv& c = a.c[a.job_conv[jb]];
+    const int n = a.job_cb[jb] * 32 + (lane & 31), h = lane >> 5;
+    crop_bf16x8 v;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) v[j] = (__bf16)0.f;
+    if (n < c.ncols && 16 * s < a.C) {
+        const int tap = n / 3, ci = n - tap * 3, kk4 = c.k * c.k * 4;
+        const float* wg = c.w + (int64_t)(16 * s + 8 * h) * kk4 + tap * 4 + ci;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) v[j] = (__bf16)wg[j * kk4];
+    }
+    wpack[(jb * KS + s) * 64 + lane] = v;
+}
+
 template <typename TG> struct lda;           // four consecutive channels of a gradient pixel through a bounds-checked descriptor
 template <> struct lda<float> {
     static constexpr int GB = 32;            // bytes per 8-deep k group
@@ -109,6 +135,9 @@ __global__ __launch_bounds__(256, 2) void crop_dgrad_kernel(const CropArgs a, co
     const int b = blk / a.tiles_y;
     const int oy0 = ty * TILE, ox0 = tx * TILE;
     constexpr int ES = (int)sizeof(TG);
+    constexpr bool M16 = std::is_same<TG, __bf16>::value;       // bf16 gradients: bf16 MFMAs, 16 channels per step
+    constexpr int NS = M16 ? KG / 2 : KG;                        // contraction steps (registers of an operand set: 32 / 64)
+    typedef typename std::conditional<M16, crop_bf16x8, f32x4>::type frag_t;
 
     // A job = one (convolution, 32-column block): its B fragments are loaded once per wave (16 coalesced loads), its row
     // blocks are shared by the four waves round-robin in two alternating register sets, so that the 16 A loads of the wave's
@@ -123,29 +152,39 @@ __global__ __launch_bounds__(256, 2) void crop_dgrad_kernel(const CropArgs a, co
         const int rx0 = floordiv(ox0 + c.pad - (c.k - 1), c.stride);
         const int n = a.job_cb[jb] * 32 + r;
         const bool ncol = n < c.ncols;
-        f32x4 bv[KG];
+        frag_t bv[NS];
 #pragma unroll
-        for (int g = 0; g < KG; ++g) bv[g] = CDBG(2) ? f32x4{0.f, 0.f, 0.f, 0.f} : wpack[(jb * KG + g) * 64 + lane];
+        for (int g = 0; g < NS; ++g) {
+            if constexpr (M16) bv[g] = reinterpret_cast<const crop_bf16x8*>(wpack)[(jb * NS + g) * 64 + lane];
+            else bv[g] = CDBG(2) ? f32x4{0.f, 0.f, 0.f, 0.f} : wpack[(jb * KG + g) * 64 + lane];
+        }
         // rows beyond the image / the region get an offset beyond the descriptor's range: the loads return zeros
         const __amdgpu_buffer_rsrc_t rs = __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(c.gy), 0, (int)c.gy_bytes, 0x00020000);
-        auto load_a = [&](int rb, f32x4 (&av)[KG]) {
+        auto load_a = [&](int rb, frag_t (&av)[NS]) {
             const int q = rb * 32 + r;
             const int qy = (int)(((unsigned)q * c.rw_recip) >> 16), qx = q - qy * c.RW;       // q / RW, exact for q < 2^10
             const int y = ry0 + qy, x = rx0 + qx;
             const bool live = rb < nrb && qy < c.RH && (unsigned)y < (unsigned)c.gH && (unsigned)x < (unsigned)c.gW && !CDBG(1);
-            const int off = live ? (((b * c.gH + y) * c.gW + x) * a.C + 4 * h) * ES : (int)0x80000000;
+            const int off = live ? (((b * c.gH + y) * c.gW + x) * a.C + (M16 ? 8 : 4) * h) * ES : (int)0x80000000;
 #pragma unroll
-            for (int g = 0; g < KG; ++g) av[g] = lda<TG>::ld(rs, off + g * lda<TG>::GB);
+            for (int g = 0; g < NS; ++g) {
+                if constexpr (M16) av[g] = __builtin_bit_cast(crop_bf16x8, __builtin_amdgcn_raw_buffer_load_b128(rs, off + g * 32, 0, 0));
+                else av[g] = lda<TG>::ld(rs, off + g * lda<TG>::GB);
+            }
         };
-        auto contract = [&](int rb, f32x4 (&av)[KG]) {
+        auto contract = [&](int rb, frag_t (&av)[NS]) {
             f32x16 acc = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
             if (!CDBG(4))
 #pragma unroll
-            for (int g = 0; g < KG; ++g) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g].x, bv[g].x, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g].y, bv[g].y, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g].z, bv[g].z, acc, 0, 0, 0);
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g].w, bv[g].w, acc, 0, 0, 0);
+            for (int g = 0; g < NS; ++g) {
+                if constexpr (M16) {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x16_bf16(av[g], bv[g], acc, 0, 0, 0);
+                } else {
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g].x, bv[g].x, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g].y, bv[g].y, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g].z, bv[g].z, acc, 0, 0, 0);
+                    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(av[g].w, bv[g].w, acc, 0, 0, 0);
+                }
             }
             // D layout of the 32x32 MFMA: acc[v] = D[(v / 4) * 8 + h * 4 + v % 4][lane % 32]
             if (ncol && !CDBG(16)) {
@@ -157,7 +196,7 @@ __global__ __launch_bounds__(256, 2) void crop_dgrad_kernel(const CropArgs a, co
         // The prefetch is UNCONDITIONAL (a row block beyond the last one is all out-of-range offsets: zeros, no traffic):
         // with a conditional one the number of loads in flight behind a register set depends on the path taken, and the
         // compiler then has to wait for vmcnt(0) -- prefetch included -- before the first MFMA.
-        f32x4 a0[KG], a1[KG];
+        frag_t a0[NS], a1[NS];
         load_a(wave, a0);
         for (int rb = wave; rb < nrb; rb += 8) {
             load_a(rb + 4, a1);
@@ -256,7 +295,10 @@ int crop_dgrad_impl(const void* gy_a, const float* w_a, const loans_small_conv* 
     static loans_device_once lds_limit_set;
     auto kern = crop_dgrad_kernel<TG>;
     if (int rc_ = loans_raise_lds_limit(lds_limit_set, reinterpret_cast<const void*>(kern), 80 * 1024)) return rc_;
-    hipLaunchKernelGGL(crop_pack_w_kernel, dim3(a.njobs * KG), dim3(64), 0, as_stream(stream), a, reinterpret_cast<f32x4*>(wpack));
+    if (std::is_same<TG, __bf16>::value)
+        hipLaunchKernelGGL(crop_pack_w16_kernel, dim3(a.njobs * (KG / 2)), dim3(64), 0, as_stream(stream), a, reinterpret_cast<crop_bf16x8*>(wpack));
+    else
+        hipLaunchKernelGGL(crop_pack_w_kernel, dim3(a.njobs * KG), dim3(64), 0, as_stream(stream), a, reinterpret_cast<f32x4*>(wpack));
     LOANS_LAUNCH_CHECK();
     hipLaunchKernelGGL(kern, dim3(B * a.tiles_y * a.tiles_x), dim3(256), lds, as_stream(stream), a,
                        reinterpret_cast<const f32x4*>(wpack));

@@ -439,8 +439,9 @@ class Assessor:
             self._conv_bwd('r0/cs', g, grads, need_gx=False)
             self._conv_bwd('r0/c0', g1, grads, need_gx=False)
             return None
-        # the gradient w.r.t. the 4-channel crops: fp32 out, fp32 master weights (loans_dgrad_c4_bf16_f32)
-        return self._conv_bwd('r0/cs', g, grads, round_w=False) + self._conv_bwd('r0/c0', g1, grads, round_w=False)
+        # the gradient w.r.t. the 4-channel crops: fp32 out; in the bf16 emulation the weights are the bf16-rounded ones like
+        # everywhere else (round 6: loans_crop_dgrad_bf16_f32 contracts on bf16 MFMAs; until then it read the fp32 masters)
+        return self._conv_bwd('r0/cs', g, grads) + self._conv_bwd('r0/c0', g1, grads)
 
 
 # --------------------------------------------------------------------------- #

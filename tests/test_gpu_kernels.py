@@ -874,14 +874,16 @@ def test_crop_dgrad_one_launch(shape, g16):
     wb = (rng.standard_normal((Cc, 3, 4, 4)) * 0.05).astype(np.float32)
     gya = rng.standard_normal((B, Cc, ga.Ho, ga.Wo)).astype(np.float32)
     gyb = rng.standard_normal((B, Cc, gb.Ho, gb.Wo)).astype(np.float32)
-    if g16:
+    war, wbr = wa, wb
+    if g16:         # bf16 gradients are contracted on bf16 MFMAs: the pre-pass rounds the weights (RNE), fp32 accumulation
         gya, gyb = _bf16_round(gya), _bf16_round(gyb)
+        war, wbr = _bf16_round(wa), _bf16_round(wb)
     cast = (lambda t: t.to(torch.bfloat16)) if g16 else (lambda t: t)
     x_shape = (B, 3, H, W)
-    _, col_a = C.conv2d_fwd(np.zeros(x_shape), wa.astype(np.float64), None, 1, 1)
-    _, col_b = C.conv2d_fwd(np.zeros(x_shape), wb.astype(np.float64), None, 2, 1)
-    ra = C.conv2d_bwd(x_shape, col_a, wa.astype(np.float64), gya.astype(np.float64), 1, 1, False)[0]
-    rb = C.conv2d_bwd(x_shape, col_b, wb.astype(np.float64), gyb.astype(np.float64), 2, 1, False)[0]
+    _, col_a = C.conv2d_fwd(np.zeros(x_shape), war.astype(np.float64), None, 1, 1)
+    _, col_b = C.conv2d_fwd(np.zeros(x_shape), wbr.astype(np.float64), None, 2, 1)
+    ra = C.conv2d_bwd(x_shape, col_a, war.astype(np.float64), gya.astype(np.float64), 1, 1, False)[0]
+    rb = C.conv2d_bwd(x_shape, col_b, wbr.astype(np.float64), gyb.astype(np.float64), 2, 1, False)[0]
     wad, wbd = dev(_ohwi(wa, 4)), dev(_ohwi(wb, 4))
     gad, gbd = cast(dev(_nhwc(gya))), cast(dev(_nhwc(gyb)))
     assert ops.crop_dgrad_ok(ga, gb)
@@ -902,4 +904,5 @@ def test_crop_dgrad_one_launch(shape, g16):
         ops.conv_dgrad(gad, wad, ga, out=ref, addend=ref)
     finally:
         ops.CROP_DGRAD = old
-    assert rel_err(out.cpu().numpy(), ref.cpu().numpy()) < 5e-6
+    # (on bf16 gradients the VALU kernel reads the fp32 master weights, this one their bf16 roundings: 2^-9 per weight)
+    assert rel_err(out.cpu().numpy(), ref.cpu().numpy()) < (4e-3 if g16 else 5e-6)
