@@ -330,7 +330,9 @@ typedef struct loans_small_conv {
 int loans_crop_dgrad_f32(const float* gy_a, const float* w_a, const loans_small_conv* ca, const float* gy_b, const float* w_b,
                          const loans_small_conv* cb, float* out, const float* addend, float* wpack, int32_t B, int32_t H,
                          int32_t W, int32_t C, void* stream);
-/* same with bf16 gradient tensors (bf16-storage arm); weights, addend and gx fp32 */
+/* same with bf16 gradient tensors (bf16-storage arm); weights, addend and gx fp32.  The contraction runs on bf16 MFMAs with fp32
+ * accumulation: the call's packing pre-pass rounds the weights to bf16 (RNE) into `wpack` (round 6; on fp32 MFMAs the kernel was
+ * bound by the matrix pipe: 56 GFLOP at B = 256). */
 int loans_crop_dgrad_bf16_f32(const void* gy_a, const float* w_a, const loans_small_conv* ca, const void* gy_b, const float* w_b,
                               const loans_small_conv* cb, float* out, const float* addend, float* wpack, int32_t B, int32_t H,
                               int32_t W, int32_t C, void* stream);
