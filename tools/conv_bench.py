@@ -60,6 +60,7 @@ def main():
     names = {0: 'auto', 1: '128x128', 2: '128x64', 3: '64x64', 4: '256x64', 5: '64x128', 6: 'split'}
     names.update({t + 16: n + 'D' for t, n in list(names.items()) if t in (1, 2, 3, 4, 6)})
     names[7] = '256x128'
+    names[8] = 'finetail'
     s16 = args.storage == 'bf16'
     if s16:
         ops.set_compute_dtype('bf16')
@@ -87,7 +88,7 @@ def main():
             for t, dbg in [(t, g) for t in tiles for g in args.dbg.split(',')]:
                 if mode == 'wgrad' and t not in (0, 1, 3, 5):
                     continue
-                if mode != 'wgrad' and t == 5 or (mode == 'dgrad' and (t & 15) in (4, 6) and not s16):
+                if mode != 'wgrad' and t == 5 or (mode == 'dgrad' and ((t & 15) in (4, 6) or t == 8) and not s16):
                     continue
                 if mode == 'fprop':
                     fn = lambda t=t: ops.conv_fprop(x, w, geo, out=y, stats=stats, tile=t)   # noqa: E731
@@ -112,7 +113,7 @@ def main():
                     ts.append(a.elapsed_time(b) / args.inner)
         for mode, t, dbg, fn, ts in cases:
             ms = float(np.median(ts))
-            line += ' %s/%s%s %6.1f TF' % (mode[0], names[t], ('#' + dbg) if args.exp else '', flops / ms / 1e9)
+            line += ' %s/%s%s %6.1f TF' % (mode[0], names.get(t, str(t)), ('#' + dbg) if args.exp else '', flops / ms / 1e9)
         line += ' |'
         print(line, flush=True)
 
