@@ -1,6 +1,6 @@
 """-m gpu: the kernels bench.py TIMES are the kernels this suite checks.
 
-bench.py runs its three committed workloads on committed tile tables (profiles/<round>_{b256,cfg3,r50}_tune.json: what the timing
+bench.py runs its four committed workloads on committed tile tables (profiles/<round>_{b256,b128,cfg3,r50}_tune.json: what the timing
 autotuner picked in the profiled session -- one tile id per layer shape and operation), while the parity tests run on the fixed
 assignment of tests/conftest.py.  This file closes the gap the round-3 verdict named: EVERY entry of the newest committed tables
 is launched at its own full shape (B = 256 / 128 / 64) and compared with the plain 128 x 128 implicit-GEMM tile on the same
@@ -112,7 +112,7 @@ def _check_entry(key, mode, tile, gen):
     return None
 
 
-@pytest.mark.parametrize("name", ['b256', 'cfg3', 'r50'])
+@pytest.mark.parametrize("name", ['b256', 'b128', 'cfg3', 'r50'])        # b128: one rank's shard of configs[3] (round 6)
 def test_every_entry_of_the_committed_tile_table_against_the_plain_tile(name):
     path = _newest_table(name)
     assert path and os.path.exists(path), 'no committed tile table for %s' % name
